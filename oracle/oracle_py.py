@@ -1,0 +1,166 @@
+"""TEST INFRASTRUCTURE -- ctypes wrapper around oracle/_build/libwbc_oracle.so (the CPU oracle).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+Batch arrays here are row-per-state numpy arrays: q[N,19], v[N,18], ...
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libwbc_oracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in ("wbc_oracle.hpp", "wbc_oracle_capi.cpp")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.wbco_model_create.restype = C.c_void_p
+        _lib.wbco_maxv.restype = C.c_int
+    return _lib
+
+
+def _maxv():
+    return lib().wbco_maxv()
+
+
+def make_params_struct(P):
+    MAXV = _maxv()
+
+    class Params(C.Structure):
+        _fields_ = [("S", C.c_double * 6), ("alpha", C.c_double), ("fn_min", C.c_double), ("fn_max", C.c_double),
+                    ("mu_scale", C.c_double), ("dt", C.c_double), ("observer_order", C.c_int), ("max_iter", C.c_int),
+                    ("qp_tol", C.c_double), ("K1", C.c_double * MAXV), ("K2", C.c_double * MAXV)]
+
+    s = Params()
+    for i in range(6):
+        s.S[i] = float(P["S"][i])
+    s.alpha, s.fn_min, s.fn_max = float(P["alpha"]), float(P["fn_min"]), float(P["fn_max"])
+    s.mu_scale, s.dt = float(P["mu_scale"]), float(P["dt"])
+    s.observer_order, s.max_iter, s.qp_tol = int(P["observer_order"]), int(P["max_iter"]), float(P["qp_tol"])
+    for i in range(len(P["K1"])):
+        s.K1[i] = float(P["K1"][i])
+        s.K2[i] = float(P["K2"][i])
+    return s
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, flat):
+        self.flat = flat
+        self.nb = int(flat["nb"])
+        self.nv = 6 + self.nb - 1
+        self.nq = self.nv + 1
+        self.nj = self.nb - 1
+        self.nf = len(flat["foot_body"])
+        self.nm = self.nv * (self.nv + 1) // 2
+        f = lambda k: np.ascontiguousarray(flat[k], dtype=np.float64)
+        self._keep = [np.ascontiguousarray(flat["parent"], dtype=np.int32), f("Rt"), f("rt"), f("axis"), f("mass"),
+                      f("com"), f("Ic"), np.ascontiguousarray(flat["foot_body"], dtype=np.int32), f("foot_off"),
+                      f("gravity")]
+        k = self._keep
+        self.h = lib().wbco_model_create(self.nb, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), _p(k[6]),
+                                         self.nf, _p(k[7]), _p(k[8]), _p(k[9]))
+        assert self.h, "oracle model_create failed"
+        self.h = C.c_void_p(self.h)
+
+    def __del__(self):
+        try:
+            lib().wbco_model_destroy(self.h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _suf(dtype):
+        return "f64" if np.dtype(dtype) == np.float64 else "f32"
+
+    def dynamics(self, q, v, nthreads=1):
+        dt = q.dtype
+        N = q.shape[0]
+        q = np.ascontiguousarray(q)
+        v = np.ascontiguousarray(v, dtype=dt)
+        o = dict(M=np.empty((N, self.nm), dt), h=np.empty((N, self.nv), dt), Jc=np.empty((N, 3 * self.nf * self.nv), dt),
+                 pf=np.empty((N, 3 * self.nf), dt), p=np.empty((N, self.nv), dt), beta=np.empty((N, self.nv), dt))
+        getattr(lib(), "wbco_dynamics_" + self._suf(dt))(self.h, N, _p(q), _p(v), _p(o["M"]), _p(o["h"]), _p(o["Jc"]),
+                                                         _p(o["pf"]), _p(o["p"]), _p(o["beta"]), int(nthreads))
+        return o
+
+    def rnea(self, q, v, vdot=None, gravity=True):
+        dt = q.dtype
+        N = q.shape[0]
+        out = np.empty((N, self.nv), dt)
+        q = np.ascontiguousarray(q)
+        v = np.ascontiguousarray(v, dtype=dt)
+        vd = None if vdot is None else np.ascontiguousarray(vdot, dtype=dt)
+        getattr(lib(), "wbco_rnea_" + self._suf(dt))(self.h, N, _p(q), _p(v), _p(vd), int(gravity), _p(out))
+        return out
+
+    def step(self, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, integ=None, r=None,
+             nthreads=1):
+        """integ, r are updated IN PLACE when the observer is on."""
+        dt = q.dtype
+        N = q.shape[0]
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+        q, v, w_des, vdot_des, normals, mu = map(c, (q, v, w_des, vdot_des, normals, mu))
+        tau_prev, f_prev = c(tau_prev), c(f_prev)
+        mask = np.ascontiguousarray(mask, dtype=np.int32)
+        if P["observer_order"] > 0:
+            assert integ is not None and r is not None and integ.dtype == dt and r.dtype == dt
+            assert integ.flags.c_contiguous and r.flags.c_contiguous
+        tau = np.empty((N, self.nj), dt)
+        f = np.empty((N, 3 * self.nf), dt)
+        status = np.empty(N, np.int32)
+        iters = np.empty(N, np.int32)
+        ps = make_params_struct(P)
+        getattr(lib(), "wbco_step_" + self._suf(dt))(self.h, C.byref(ps), N, _p(q), _p(v), _p(w_des), _p(vdot_des),
+                                                     _p(normals), _p(mu), _p(mask), _p(tau_prev), _p(f_prev), _p(integ),
+                                                     _p(r), _p(tau), _p(f), _p(status), _p(iters), int(nthreads))
+        return dict(tau=tau, f=f, status=status, iters=iters)
+
+
+def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9):
+    dt = H.dtype
+    n, m = len(g), len(d)
+    H, g, Cm, d = (np.ascontiguousarray(a, dtype=dt) for a in (H, g, Cm, d))
+    x = np.zeros(n, dt)
+    lam = np.zeros(max(m, 1), dt)
+    st = C.c_int(0)
+    fn = getattr(lib(), "wbco_qp_solve_" + Oracle._suf(dt))
+    fn.restype = C.c_int
+    ct = C.c_double if dt == np.float64 else C.c_float
+    it = fn(n, m, _p(H), _p(g), _p(Cm), _p(d), int(max_iter), ct(tol), _p(x), _p(lam), C.byref(st))
+    return x, lam[:m], st.value, it
+
+
+def qp_assemble(P, nf, mask, pb, pf, normals, mu, b):
+    dt = np.float64
+    ns = bin(mask).count("1")
+    n, m = 3 * ns, 6 * ns
+    H = np.zeros((max(n, 1), max(n, 1)), dt)
+    g = np.zeros(max(n, 1), dt)
+    Cm = np.zeros((max(m, 1), max(n, 1)), dt)
+    d = np.zeros(max(m, 1), dt)
+    mo = C.c_int(0)
+    ps = make_params_struct(P)
+    c = lambda a: np.ascontiguousarray(a, dtype=dt)
+    fn = lib().wbco_qp_assemble_f64
+    fn.restype = C.c_int
+    nn = fn(C.byref(ps), nf, int(mask), _p(c(pb)), _p(c(pf)), _p(c(normals)), _p(c(mu)), _p(c(b)), _p(H), _p(g),
+            _p(Cm), _p(d), C.byref(mo))
+    assert nn == n and mo.value == m
+    return H[:n, :n].copy() if n else np.zeros((0, 0)), g[:n], Cm[:m, :n].copy() if n else np.zeros((0, 0)), d[:m]

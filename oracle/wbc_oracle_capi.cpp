@@ -1,0 +1,123 @@
+// TEST INFRASTRUCTURE -- C-ABI (ctypes) face of the CPU oracle in wbc_oracle.hpp.
+// PARITY UNPINNED (see wbc_oracle.hpp header).  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg load this library; the product never does.
+// Batch layout here is row-per-state (AoS, numpy-natural): x[N][ncomp].
+#include "wbc_oracle.hpp"
+#include <new>
+
+using namespace wbco;
+
+struct OracleHandle {
+  Model<double> md;
+  Model<float> mf;
+};
+
+extern "C" {
+
+struct wbco_params {  // mirrors wbco::Params
+  double S[6];
+  double alpha, fn_min, fn_max, mu_scale, dt;
+  int observer_order, max_iter;
+  double qp_tol;
+  double K1[MAXV], K2[MAXV];
+};
+
+static Params to_params(const wbco_params* p) {
+  Params P;
+  for (int i = 0; i < 6; ++i) P.S[i] = p->S[i];
+  P.alpha = p->alpha; P.fn_min = p->fn_min; P.fn_max = p->fn_max; P.mu_scale = p->mu_scale; P.dt = p->dt;
+  P.observer_order = p->observer_order; P.max_iter = p->max_iter; P.qp_tol = p->qp_tol;
+  for (int i = 0; i < MAXV; ++i) { P.K1[i] = p->K1[i]; P.K2[i] = p->K2[i]; }
+  return P;
+}
+
+int wbco_maxv() { return MAXV; }
+
+void* wbco_model_create(int nb, const int* parent, const double* Rt, const double* rt, const double* axis,
+                        const double* mass, const double* com, const double* Ic, int nf, const int* foot_body,
+                        const double* foot_off, const double* gravity) {
+  if (nb < 1 || nb > MAXB || nf < 0 || nf > MAXF) return nullptr;
+  OracleHandle* h = new (std::nothrow) OracleHandle;
+  if (!h) return nullptr;
+  model_from_flat(h->md, nb, parent, Rt, rt, axis, mass, com, Ic, nf, foot_body, foot_off, gravity);
+  model_from_flat(h->mf, nb, parent, Rt, rt, axis, mass, com, Ic, nf, foot_body, foot_off, gravity);
+  return h;
+}
+void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
+
+#define DEF_API(SUF, T, MODEL)                                                                                  \
+  void wbco_dynamics_##SUF(void* hh, int N, const T* q, const T* v, T* M, T* h, T* Jc, T* pf, T* p, T* beta,    \
+                           int nthreads) {                                                                      \
+    const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
+    const int nv = m.nv(), nq = nv + 1, nm = nv * (nv + 1) / 2, nf = m.nf;                                      \
+    _Pragma("omp parallel for num_threads(nthreads) schedule(static)") for (int s = 0; s < N; ++s) {           \
+      DynOut<T> o;                                                                                              \
+      dynamics(m, q + (size_t)s * nq, v + (size_t)s * nv, o);                                                   \
+      if (M) for (int e = 0; e < nm; ++e) M[(size_t)s * nm + e] = o.M[e];                                       \
+      if (h) for (int e = 0; e < nv; ++e) h[(size_t)s * nv + e] = o.h[e];                                       \
+      if (Jc) for (int e = 0; e < 3 * nf * nv; ++e) Jc[(size_t)s * 3 * nf * nv + e] = o.Jc[e];                  \
+      if (pf) for (int e = 0; e < 3 * nf; ++e) pf[(size_t)s * 3 * nf + e] = o.pf[e];                            \
+      if (p) for (int e = 0; e < nv; ++e) p[(size_t)s * nv + e] = o.p[e];                                       \
+      if (beta) for (int e = 0; e < nv; ++e) beta[(size_t)s * nv + e] = o.beta[e];                              \
+    }                                                                                                           \
+  }                                                                                                             \
+  void wbco_rnea_##SUF(void* hh, int N, const T* q, const T* v, const T* vdot, int with_gravity, T* out) {      \
+    const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
+    const int nv = m.nv(), nq = nv + 1;                                                                         \
+    for (int s = 0; s < N; ++s) {                                                                               \
+      Kin<T> k;                                                                                                 \
+      fk(m, q + (size_t)s * nq, k);                                                                             \
+      rnea(m, k, v + (size_t)s * nv, vdot ? vdot + (size_t)s * nv : (const T*)nullptr, with_gravity != 0,       \
+           out + (size_t)s * nv);                                                                               \
+    }                                                                                                           \
+  }                                                                                                             \
+  void wbco_step_##SUF(void* hh, const wbco_params* pp, int N, const T* q, const T* v, const T* w_des,          \
+                       const T* vdot_des, const T* normals, const T* mu, const int* mask, const T* tau_prev,    \
+                       const T* f_prev, T* obs_integ, T* obs_r, T* tau, T* f, int* status, int* iters,          \
+                       int nthreads) {                                                                          \
+    const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
+    const Params P = to_params(pp);                                                                             \
+    const int nv = m.nv(), nq = nv + 1, nj = m.nj(), nf = m.nf;                                                 \
+    _Pragma("omp parallel for num_threads(nthreads) schedule(static)") for (int s = 0; s < N; ++s) {           \
+      StepOut<T> o;                                                                                             \
+      T zt[MAXV];                                                                                               \
+      for (int i = 0; i < MAXV; ++i) zt[i] = 0;                                                                 \
+      step(m, P, q + (size_t)s * nq, v + (size_t)s * nv, w_des + (size_t)s * 6, vdot_des + (size_t)s * nv,      \
+           normals + (size_t)s * 3 * nf, mu + (size_t)s * nf, (unsigned)mask[s],                                \
+           tau_prev ? tau_prev + (size_t)s * nj : zt, f_prev ? f_prev + (size_t)s * 3 * nf : zt,                \
+           obs_integ ? obs_integ + (size_t)s * nv : (T*)nullptr, obs_r ? obs_r + (size_t)s * nv : (T*)nullptr,  \
+           o);                                                                                                  \
+      for (int e = 0; e < nj; ++e) tau[(size_t)s * nj + e] = o.tau[e];                                          \
+      for (int e = 0; e < 3 * nf; ++e) f[(size_t)s * 3 * nf + e] = o.f[e];                                      \
+      if (status) status[s] = o.status;                                                                         \
+      if (iters) iters[s] = o.iters;                                                                            \
+    }                                                                                                           \
+  }                                                                                                             \
+  /* dense QP, row-major H[n*n], C[m*n]: min 1/2 x'Hx + g'x  s.t. Cx >= d */                                    \
+  int wbco_qp_solve_##SUF(int n, int mm, const T* H, const T* g, const T* C, const T* d, int max_iter, T tol,   \
+                          T* x, T* lambda, int* status) {                                                       \
+    if (n > QPN || mm > QPM) { *status = -1; return 0; }                                                        \
+    QP<T> qp;                                                                                                   \
+    qp.n = n; qp.m = mm;                                                                                        \
+    for (int i = 0; i < n; ++i) { qp.g[i] = g[i]; for (int j = 0; j < n; ++j) qp.H[i * QPN + j] = H[i * n + j]; } \
+    for (int i = 0; i < mm; ++i) { qp.d[i] = d[i]; for (int j = 0; j < n; ++j) qp.C[i * QPN + j] = C[i * n + j]; } \
+    return qp_solve_gi(qp, max_iter, tol, x, lambda, status);                                                   \
+  }                                                                                                             \
+  /* QP assembly for one state: returns n, writes m; H[QPN*QPN] etc. with leading dimension QPN */              \
+  int wbco_qp_assemble_##SUF(const wbco_params* pp, int nf, int mask, const T* pb, const T* pf,                  \
+                             const T* normals, const T* mu, const T* b, T* H, T* g, T* C, T* d, int* mout) {    \
+    const Params P = to_params(pp);                                                                             \
+    V3<T> pfv[MAXF];                                                                                            \
+    for (int k = 0; k < nf; ++k) pfv[k] = V3<T>(pf[3 * k], pf[3 * k + 1], pf[3 * k + 2]);                       \
+    QP<T> qp;                                                                                                   \
+    qp_assemble(P, nf, (unsigned)mask, V3<T>(pb[0], pb[1], pb[2]), pfv, normals, mu, b, qp);                    \
+    for (int i = 0; i < qp.n; ++i) { g[i] = qp.g[i]; for (int j = 0; j < qp.n; ++j) H[i * qp.n + j] = qp.H[i * QPN + j]; } \
+    for (int i = 0; i < qp.m; ++i) { d[i] = qp.d[i]; for (int j = 0; j < qp.n; ++j) C[i * qp.n + j] = qp.C[i * QPN + j]; } \
+    *mout = qp.m;                                                                                               \
+    return qp.n;                                                                                                \
+  }
+
+DEF_API(f64, double, md)
+DEF_API(f32, float, mf)
+
+}  // extern "C"
