@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the WBC per-tick hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config {2,3,4}] [--no-cpu]
+
+One "step" = one control tick (dynamics sweep -> observer -> GRF QP -> torque map) over one batch of
+synthetic states already resident in HBM.  Default workload = BASELINE.json configs[1]:
+batch 4096 DogBot-like states per GPU, 4-contact stance, observer off, fp64 (the real DogBot URDF is
+absent; a synthetic quadruped of the same topology stands in -- see DESIGN.md).
+For N > 1 the driver launches this under torch.distributed.run, one rank per GPU; the batch shards
+with no data-path collective (weak scaling: per-GPU batch fixed).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DYN_WORDS = 443         # dynamics-sweep stage, in q19+v18(+mask) -> out M171+h18+Jc216
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="states per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4])
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
+    ap.add_argument("--no-mats", action="store_true", help="do not write M,h,Jc to HBM (fused-only variant)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import wbc_quadruped_dob_amd as W
+    from wbc_quadruped_dob_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+
+    dtype = args.dtype or ("f32" if args.config == 4 else "f64")
+    obs = 0 if args.config == 2 else 1
+    td = torch.float64 if dtype == "f64" else torch.float32
+    n = args.batch
+    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    P = synth.default_params(observer_order=obs, dtype=dtype)
+    solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=local_rank, max_batch=n)
+    B = synth.make_batch(args.config, n, model.total_mass, rank=rank)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
+    inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+    mask = torch.from_numpy(B["mask"]).cuda()
+    integ = rr = None
+    if obs:
+        integ = solver.dynamics(inp["q"], inp["v"], want=("p",))["p"].clone()
+        rr = torch.zeros_like(integ)
+    out = {}
+    want_mats = not args.no_mats
+
+    def step():
+        return solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
+                           inp["tau_prev"], inp["f_prev"], integ, rr, out=out, want_mats=want_mats)
+
+    out.update(step())
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    solver.enable_timing(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    tm = solver.collect_timing()
+    solver.enable_timing(False)
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    status = out["status"].cpu().numpy()
+    iters = out["iters"].cpu().numpy()
+
+    # a second, un-instrumented timing of the same K steps (no events between kernels), reported alongside
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    plain = time.perf_counter() - t2
+
+    if rank == 0:
+        ts = 8 if dtype == "f64" else 4
+        dyn_s = tm["dyn_ms"] * 1e-3 / max(1, tm["dyn_launches"])
+        qp_s = tm["qp_ms"] * 1e-3 / max(1, tm["qp_launches"])
+        dyn_bytes = DYN_WORDS * ts * n
+        achieved = dyn_bytes / dyn_s / 1e9 if want_mats else None
+        res = {
+            "metric": "WBC control-steps/sec (batched DogBot)",
+            "value": args.steps * n * world / elapsed,
+            "unit": "control-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": "configs[%d]: batch=%d states/GPU, %s, observer %s, %s; synthetic quadruped URDF "
+                                   "(DogBot URDF absent)" % (args.config - 1, n,
+                                                             "4-contact stance" if args.config == 2 else "mixed 2/3/4-foot trot masks",
+                                                             "on" if obs else "off", dtype),
+                       "batch_per_gpu": n, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "writes_M_h_Jc": want_mats},
+            "roofline": {"kernel": "dyn_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": dyn_bytes, "avg_launch_us": dyn_s * 1e6,
+                         "launches_timed": tm["dyn_launches"]},
+            "kernels": {"dyn_sweep_us": dyn_s * 1e6, "qp_wave_us": qp_s * 1e6,
+                        "qp_us_per_state_amortized": qp_s * 1e6 / n},
+            "ms_per_step_uninstrumented": plain / args.steps * 1e3,
+            "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
+                   "iters_max": int(iters.max())},
+        }
+        if not args.no_cpu and world == 1:
+            res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(B, P, dtype, n):
+    """The build's CPU restatement (oracle, kind "port") timed on this box's host cores: bounded sample."""
+    import numpy as np
+    import wbc_quadruped_dob_amd as W
+    from oracle import oracle_py, urdf_model
+    orc = oracle_py.Oracle(urdf_model.load_urdf(W.SYNTHETIC_URDF))
+    nd = np.float64 if dtype == "f64" else np.float32
+    c = lambda a: np.ascontiguousarray(a, dtype=nd)
+    args = [c(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")] + [B["mask"], c(B["tau_prev"]), c(B["f_prev"])]
+    ncores = os.cpu_count() or 1
+
+    def run(threads, budget):
+        integ = np.zeros((n, 18), nd)
+        r = np.zeros((n, 18), nd)
+        orc.step(P, *args, integ, r, nthreads=threads)  # warm
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < budget:
+            orc.step(P, *args, integ, r, nthreads=threads)
+            reps += 1
+        return reps * n / (time.perf_counter() - t0), reps
+
+    one, r1 = run(1, 6.0)
+    allc, ra = run(ncores, 8.0)
+    return {"value": allc, "unit": "control-steps/s", "cores": ncores, "kind": "port",
+            "sample": "the same %d-state batch repeated %d times on %d OpenMP threads (~8 s); single-thread: %.0f "
+                      "steps/s over %d repeats (~6 s); g++ -O2 -march=native build of oracle/" % (n, ra, ncores, one, r1),
+            "single_thread_value": one}
+
+
+if __name__ == "__main__":
+    main()

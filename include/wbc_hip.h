@@ -1,0 +1,160 @@
+/* wbc_hip.h -- C-ABI of the MI355X (gfx950) batched whole-body-control hot path.
+ *
+ * Drop-in boundary for the per-tick computation of `dogbot_controller`
+ * (reference: /root/reference/.gitmodules:4-6; the controller is started as
+ * `rosrun dogbot_controller dogbot <path>/dogbot.urdf`, /root/reference/README.md:60, and
+ * contains "a momentum-based observer estimator, and an optimization problem based on the
+ * modulation of ground reaction forces", /root/reference/README.md:11).
+ *
+ * PROVISIONAL: the controller's source is an un-vendored submodule that is absent from
+ * /root/reference, so the names and signatures of its compute-torques entry point and its ROS
+ * message types cannot be cited.  Each entry point below states which reference
+ * interface it stands for; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Rules of the ABI: extern "C"; plain pointers and sizes; no exceptions cross it; every function
+ * returns an int status (WBC_OK = 0); the caller owns every batch buffer; a solver is bound to one
+ * HIP device, is not thread-safe, distinct solvers are; no allocation or synchronisation happens
+ * inside wbc_step_batch / wbc_dynamics_batch (they are hipGraph-capturable).
+ *
+ * Batch layout in HBM: structure-of-arrays, component-major: x[c * N + s] is component c of state s
+ * (N = batch size of the call).  Scalars are double (WBC_F64) or float (WBC_F32) per the solver.
+ *   q        [nq = 7+nj][N]  base position (world), base quaternion (x,y,z,w), joint angles
+ *   v        [nv = 6+nj][N]  base linear velocity (world), base angular velocity (world), joint rates
+ *   w_des    [6][N]          desired contact wrench on the base rows (force; moment about base origin)
+ *   vdot_des [nv][N]         desired generalized acceleration
+ *   normals  [3*nf][N]       terrain normal under each foot (world)
+ *   mu       [nf][N]         friction coefficient under each foot
+ *   mask     [N] int32       bit k set = foot k in stance
+ *   tau_prev [nj][N], f_prev [3*nf][N]   previous tick's outputs (observer only)
+ *   obs_integ, obs_r [nv][N] observer state, in/out (observer only)
+ *   tau [nj][N], f [3*nf][N], status [N] int32 (0 ok, 1 QP iteration limit, 2 QP infeasible), iters [N] int32
+ *   M [nv(nv+1)/2][N]  packed upper triangle, idx(i,j) = i*nv - i(i-1)/2 + (j-i), i <= j
+ *   h [nv][N], Jc [3*nf*nv][N] (row (3k+m)*nv + c), pf [3*nf][N]
+ */
+#ifndef WBC_HIP_H
+#define WBC_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WBC_MAXV 32 /* capacity of the per-dof gain arrays */
+
+enum wbc_status {
+  WBC_OK = 0,
+  WBC_E_INVALID = 1,  /* null pointer / bad argument */
+  WBC_E_IO = 2,       /* URDF file cannot be read */
+  WBC_E_PARSE = 3,    /* URDF malformed or uses an unsupported element */
+  WBC_E_TOPOLOGY = 4, /* not a floating base with 4 legs x 3 revolute joints + 4 feet */
+  WBC_E_NODEVICE = 5, /* no HIP device / kernels for gfx950 cannot run here */
+  WBC_E_HIP = 6,      /* a HIP runtime call failed (see wbc_last_error) */
+  WBC_E_CAPACITY = 7  /* N exceeds the solver's max_batch */
+};
+
+enum wbc_dtype { WBC_F64 = 0, WBC_F32 = 1 };
+
+typedef struct wbc_model wbc_model;   /* host-side flattened robot model */
+typedef struct wbc_solver wbc_solver; /* device-side context */
+
+/* Controller parameters.  In the reference these are presumably compile-time constants of the
+ * controller ([UNVERIFIED]); here all are run-time. */
+typedef struct wbc_params {
+  double S[6];        /* wrench-tracking weights: force xyz, moment xyz */
+  double alpha;       /* GRF regularisation (> 0) */
+  double fn_min;      /* normal-force bounds per stance foot */
+  double fn_max;
+  double mu_scale;    /* 1 = pyramid with mu, 1/sqrt(2) = inscribed pyramid */
+  double dt;          /* control period, s */
+  int observer_order; /* 0 = off, 1, 2 */
+  int max_iter;       /* QP active-set iteration cap */
+  double qp_tol;      /* constraint-violation tolerance, N */
+  double K1[WBC_MAXV];
+  double K2[WBC_MAXV];
+} wbc_params;
+
+/* ---- model: stands for the controller's URDF ingestion (argv[1], README.md:60) ---- */
+/* foot_links may be NULL: then the last link hanging off each leg's distal body is the foot. */
+int wbc_model_load_urdf(const char* path, const char* const* foot_links, int n_foot_links, wbc_model** out);
+int wbc_model_from_flat(int nb, const int* parent, const double* Rt, const double* rt, const double* axis,
+                        const double* mass, const double* com, const double* Ic, int nf, const int* foot_body,
+                        const double* foot_off, const double* gravity, wbc_model** out);
+void wbc_model_free(wbc_model* m);
+int wbc_model_dims(const wbc_model* m, int* nb, int* nq, int* nv, int* nj, int* nf);
+/* copies the flat arrays out (sizes per wbc_model_dims; any pointer may be NULL) */
+int wbc_model_get_flat(const wbc_model* m, int* parent, double* Rt, double* rt, double* axis, double* mass,
+                       double* com, double* Ic, int* foot_body, double* foot_off, double* gravity);
+const char* wbc_model_joint_name(const wbc_model* m, int j); /* NULL if out of range / unnamed */
+const char* wbc_model_foot_link(const wbc_model* m, int k);
+double wbc_model_total_mass(const wbc_model* m);
+
+void wbc_params_default(wbc_params* p, int dtype);
+
+/* ---- solver ---- */
+int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
+                      wbc_solver** out);
+void wbc_solver_destroy(wbc_solver* s);
+int wbc_solver_set_params(wbc_solver* s, const wbc_params* p);
+
+typedef struct wbc_batch_in {
+  const void* q;
+  const void* v;
+  const void* w_des;
+  const void* vdot_des;
+  const void* normals;
+  const void* mu;
+  const int* mask;
+  const void* tau_prev; /* observer only, else may be NULL */
+  const void* f_prev;   /* observer only, else may be NULL */
+} wbc_batch_in;
+
+typedef struct wbc_batch_out {
+  void* tau;
+  void* f;
+  int* status;
+  int* iters; /* may be NULL */
+  void* M;    /* optional dynamics outputs: all NULL or M, h, Jc all non-NULL */
+  void* h;
+  void* Jc;
+  void* pf;   /* may be NULL */
+} wbc_batch_out;
+
+typedef struct wbc_observer_state {
+  void* integ;
+  void* r;
+} wbc_observer_state;
+
+/* Dynamics sweep only: M(q), h(q,v), Jc(q) (+ optional pf, p = M v, beta = C^T v - g).
+ * Stands for the rigid-body-dynamics calls the controller makes each tick (north_star:
+ * "CRBA mass matrix, RNEA bias forces, contact Jacobians from the DogBot URDF").
+ * All pointers are device pointers on the solver's device; `stream` is a hipStream_t (NULL = default). */
+int wbc_dynamics_batch(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc,
+                       void* pf, void* p, void* beta, void* stream);
+
+/* One control tick for N independent states: dynamics -> observer -> GRF QP -> torque map.
+ * Stands for the controller's per-tick compute-torques entry point (name [UNVERIFIED]). */
+int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
+                   const wbc_observer_state* obs, void* stream);
+
+/* Single-robot, host-pointer, double-precision convenience call: the shape of the reference's
+ * one-robot tick (BASELINE.json configs[0]).  Runs wbc_step_batch with N = 1 on the GPU and
+ * synchronises.  obs_integ/obs_r (host, nv each) are in/out and may be NULL when the observer is off. */
+int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const double* w_des,
+                        const double* vdot_des, const double* normals, const double* mu, int mask,
+                        const double* tau_prev, const double* f_prev, double* obs_integ, double* obs_r,
+                        double* tau, double* f, int* status);
+
+/* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on ---- */
+int wbc_solver_enable_timing(wbc_solver* s, int on); /* on: record events around every kernel */
+/* synchronises the recorded events; returns summed milliseconds and launch counts since the last
+ * reset for the dynamics-sweep kernel and the QP kernel; resets the accumulators. */
+int wbc_solver_collect_timing(wbc_solver* s, double* dyn_ms, int* dyn_launches, double* qp_ms, int* qp_launches);
+
+const char* wbc_strerror(int status);
+const char* wbc_last_error(void); /* thread-local detail string of the last failure */
+int wbc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WBC_HIP_H */

@@ -1,0 +1,274 @@
+"""MI355X-native batched whole-body-control hot path (host-side Python binding).
+
+Thin ctypes layer over lib/libwbc_hip.so (the C-ABI in include/wbc_hip.h).  PyTorch is used only
+for device memory and streams.  There is NO CPU fallback: if the HIP library is missing or no
+gfx950 device is present, construction fails loudly.
+
+Mirrors the reference controller's shape (/root/reference/README.md:60: the controller is
+started with the URDF path; README.md:11: observer + GRF optimisation per tick):
+    model  = Model.from_urdf(path)
+    solver = Solver(model, params, dtype="f64", device=0, max_batch=N)
+    out    = solver.step(q=..., v=..., w_des=..., ...)      # one control tick for N states
+Batch tensors are component-major: shape [ncomp, N] (see include/wbc_hip.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwbc_hip.so")
+SYNTHETIC_URDF = os.path.join(_HERE, "assets", "synthetic_quadruped.urdf")
+WBC_MAXV = 32
+F64, F32 = 0, 1
+
+_lib = None
+
+
+class WbcError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        detail = lib().wbc_last_error().decode() if _lib is not None else ""
+        super().__init__("%s failed: status %d (%s) %s" % (where, code, lib().wbc_strerror(code).decode(), detail))
+
+
+def build_library(force=False):
+    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-s"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class Params(C.Structure):
+    _fields_ = [("S", C.c_double * 6), ("alpha", C.c_double), ("fn_min", C.c_double), ("fn_max", C.c_double),
+                ("mu_scale", C.c_double), ("dt", C.c_double), ("observer_order", C.c_int), ("max_iter", C.c_int),
+                ("qp_tol", C.c_double), ("K1", C.c_double * WBC_MAXV), ("K2", C.c_double * WBC_MAXV)]
+
+    @staticmethod
+    def default(dtype="f64"):
+        p = Params()
+        lib().wbc_params_default(C.byref(p), F64 if dtype == "f64" else F32)
+        return p
+
+    @staticmethod
+    def from_dict(d, dtype="f64"):
+        p = Params.default(dtype)
+        for i in range(6):
+            p.S[i] = float(d["S"][i])
+        for k in ("alpha", "fn_min", "fn_max", "mu_scale", "dt", "qp_tol"):
+            setattr(p, k, float(d[k]))
+        p.observer_order, p.max_iter = int(d["observer_order"]), int(d["max_iter"])
+        for i in range(min(len(d["K1"]), WBC_MAXV)):
+            p.K1[i] = float(d["K1"][i])
+            p.K2[i] = float(d["K2"][i])
+        return p
+
+
+class _BatchIn(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "mask", "tau_prev", "f_prev")]
+
+
+class _BatchOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("tau", "f", "status", "iters", "M", "h", "Jc", "pf")]
+
+
+class _ObsState(C.Structure):
+    _fields_ = [("integ", C.c_void_p), ("r", C.c_void_p)]
+
+
+def lib():
+    """Load libwbc_hip.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the WBC hot path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.wbc_strerror.restype = C.c_char_p
+        L.wbc_last_error.restype = C.c_char_p
+        L.wbc_model_joint_name.restype = C.c_char_p
+        L.wbc_model_foot_link.restype = C.c_char_p
+        L.wbc_model_total_mass.restype = C.c_double
+        L.wbc_model_total_mass.argtypes = [C.c_void_p]
+        L.wbc_model_joint_name.argtypes = [C.c_void_p, C.c_int]
+        L.wbc_model_foot_link.argtypes = [C.c_void_p, C.c_int]
+        L.wbc_model_free.argtypes = [C.c_void_p]
+        L.wbc_solver_destroy.argtypes = [C.c_void_p]
+        L.wbc_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        L.wbc_dynamics_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
+        L.wbc_step_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
+        _lib = L
+    return _lib
+
+
+def _check(code, where):
+    if code != 0:
+        raise WbcError(code, where)
+
+
+class Model:
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        nb, nq, nv, nj, nf = (C.c_int() for _ in range(5))
+        _check(lib().wbc_model_dims(self._h, C.byref(nb), C.byref(nq), C.byref(nv), C.byref(nj), C.byref(nf)), "wbc_model_dims")
+        self.nb, self.nq, self.nv, self.nj, self.nf = nb.value, nq.value, nv.value, nj.value, nf.value
+
+    @staticmethod
+    def from_urdf(path, foot_links=None):
+        h = C.c_void_p()
+        if foot_links:
+            arr = (C.c_char_p * len(foot_links))(*[s.encode() for s in foot_links])
+            rc = lib().wbc_model_load_urdf(path.encode(), arr, len(foot_links), C.byref(h))
+        else:
+            rc = lib().wbc_model_load_urdf(path.encode(), None, 0, C.byref(h))
+        _check(rc, "wbc_model_load_urdf")
+        return Model(h.value)
+
+    @staticmethod
+    def from_flat(flat):
+        h = C.c_void_p()
+        c = lambda k, t: np.ascontiguousarray(flat[k], dtype=t)
+        a = [c("parent", np.int32), c("Rt", np.float64), c("rt", np.float64), c("axis", np.float64),
+             c("mass", np.float64), c("com", np.float64), c("Ic", np.float64), c("foot_body", np.int32),
+             c("foot_off", np.float64), c("gravity", np.float64)]
+        p = [x.ctypes.data_as(C.c_void_p) for x in a]
+        rc = lib().wbc_model_from_flat(int(flat["nb"]), p[0], p[1], p[2], p[3], p[4], p[5], p[6], len(a[7]), p[7], p[8],
+                                       p[9], C.byref(h))
+        _check(rc, "wbc_model_from_flat")
+        return Model(h.value)
+
+    def flat(self):
+        nb, nf = self.nb, self.nf
+        o = dict(nb=nb, parent=np.zeros(nb, np.int32), Rt=np.zeros((nb, 9)), rt=np.zeros((nb, 3)), axis=np.zeros((nb, 3)),
+                 mass=np.zeros(nb), com=np.zeros((nb, 3)), Ic=np.zeros((nb, 6)), foot_body=np.zeros(nf, np.int32),
+                 foot_off=np.zeros((nf, 3)), gravity=np.zeros(3))
+        p = lambda k: o[k].ctypes.data_as(C.c_void_p)
+        _check(lib().wbc_model_get_flat(self._h, p("parent"), p("Rt"), p("rt"), p("axis"), p("mass"), p("com"), p("Ic"),
+                                        p("foot_body"), p("foot_off"), p("gravity")), "wbc_model_get_flat")
+        o["joint_names"] = [(lib().wbc_model_joint_name(self._h, j) or b"").decode() for j in range(self.nj)]
+        o["foot_links"] = [(lib().wbc_model_foot_link(self._h, k) or b"").decode() for k in range(self.nf)]
+        return o
+
+    @property
+    def total_mass(self):
+        return lib().wbc_model_total_mass(self._h)
+
+    def __del__(self):
+        try:
+            lib().wbc_model_free(self._h)
+        except Exception:
+            pass
+
+
+class Solver:
+    """Device-side context: one per GPU (and per stream)."""
+
+    def __init__(self, model, params=None, dtype="f64", device=0, max_batch=4096):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to torch: the WBC hot path has no CPU fallback")
+        self.torch = torch
+        self.model = model
+        self.dtype = dtype
+        self.tdtype = torch.float64 if dtype == "f64" else torch.float32
+        self.device = torch.device("cuda", device)
+        self.max_batch = int(max_batch)
+        self.params = params if params is not None else Params.default(dtype)
+        h = C.c_void_p()
+        _check(lib().wbc_solver_create(model._h, C.byref(self.params), F64 if dtype == "f64" else F32, device,
+                                       self.max_batch, C.byref(h)), "wbc_solver_create")
+        self._h = h
+
+    def set_params(self, params):
+        _check(lib().wbc_solver_set_params(self._h, C.byref(params)), "wbc_solver_set_params")
+        self.params = params
+
+    def __del__(self):
+        try:
+            lib().wbc_solver_destroy(self._h)
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ptr(self, t, rows, N, dtype=None):
+        if t is None:
+            return None
+        assert t.is_cuda and t.is_contiguous(), "batch tensors must be contiguous CUDA tensors"
+        assert t.dtype == (dtype or self.tdtype), (t.dtype, dtype or self.tdtype)
+        assert t.numel() == rows * N, (tuple(t.shape), rows, N)
+        return C.c_void_p(t.data_ptr())
+
+    def empty(self, rows, N, dtype=None):
+        return self.torch.empty((rows, N), dtype=dtype or self.tdtype, device=self.device)
+
+    def dynamics(self, q, v, want=("M", "h", "Jc", "pf"), out=None):
+        """Dynamics sweep: returns dict of [ncomp, N] tensors for the names in `want`."""
+        m = self.model
+        N = q.shape[1]
+        rows = dict(M=m.nv * (m.nv + 1) // 2, h=m.nv, Jc=3 * m.nf * m.nv, pf=3 * m.nf, p=m.nv, beta=m.nv)
+        out = dict(out or {})
+        for k in want:
+            if k not in out:
+                out[k] = self.empty(rows[k], N)
+        g = lambda k: self._ptr(out.get(k), rows[k], N)
+        _check(lib().wbc_dynamics_batch(self._h, N, self._ptr(q, m.nq, N), self._ptr(v, m.nv, N), g("M"), g("h"), g("Jc"),
+                                        g("pf"), g("p"), g("beta"), self._stream()), "wbc_dynamics_batch")
+        return out
+
+    def step(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None, obs_r=None,
+             out=None, want_mats=False):
+        """One control tick.  Observer state tensors are updated in place.  Returns dict(tau, f, status, iters[, M, h, Jc, pf])."""
+        torch = self.torch
+        m = self.model
+        N = q.shape[1]
+        out = dict(out or {})
+        rows = dict(tau=m.nj, f=3 * m.nf, M=m.nv * (m.nv + 1) // 2, h=m.nv, Jc=3 * m.nf * m.nv, pf=3 * m.nf)
+        for k in ("tau", "f"):
+            if k not in out:
+                out[k] = self.empty(rows[k], N)
+        for k in ("status", "iters"):
+            if k not in out:
+                out[k] = torch.empty(N, dtype=torch.int32, device=self.device)
+        if want_mats:
+            for k in ("M", "h", "Jc", "pf"):
+                if k not in out:
+                    out[k] = self.empty(rows[k], N)
+        bi = _BatchIn(self._ptr(q, m.nq, N), self._ptr(v, m.nv, N), self._ptr(w_des, 6, N), self._ptr(vdot_des, m.nv, N),
+                      self._ptr(normals, 3 * m.nf, N), self._ptr(mu, m.nf, N), self._ptr(mask, 1, N, torch.int32),
+                      self._ptr(tau_prev, m.nj, N), self._ptr(f_prev, 3 * m.nf, N))
+        g = lambda k: self._ptr(out.get(k), rows[k], N)
+        bo = _BatchOut(g("tau"), g("f"), self._ptr(out["status"], 1, N, torch.int32),
+                       self._ptr(out["iters"], 1, N, torch.int32), g("M"), g("h"), g("Jc"), g("pf"))
+        ob = _ObsState(self._ptr(obs_integ, m.nv, N), self._ptr(obs_r, m.nv, N))
+        _check(lib().wbc_step_batch(self._h, N, C.byref(bi), C.byref(bo), C.byref(ob), self._stream()), "wbc_step_batch")
+        return out
+
+    def compute_torques(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None,
+                        obs_r=None):
+        """Single-robot host-array call (numpy float64 in/out): the reference's one-robot tick shape."""
+        d = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        q, v, w_des, vdot_des, normals, mu, tau_prev, f_prev = map(d, (q, v, w_des, vdot_des, normals, mu, tau_prev, f_prev))
+        if obs_integ is not None:
+            assert obs_integ.dtype == np.float64 and obs_integ.flags.c_contiguous
+            assert obs_r.dtype == np.float64 and obs_r.flags.c_contiguous
+        tau = np.zeros(self.model.nj)
+        f = np.zeros(3 * self.model.nf)
+        st = C.c_int(0)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        _check(lib().wbc_compute_torques(self._h, p(q), p(v), p(w_des), p(vdot_des), p(normals), p(mu), int(mask),
+                                         p(tau_prev), p(f_prev), p(obs_integ), p(obs_r), p(tau), p(f), C.byref(st)),
+               "wbc_compute_torques")
+        return tau, f, st.value
+
+    def enable_timing(self, on=True):
+        _check(lib().wbc_solver_enable_timing(self._h, int(on)), "wbc_solver_enable_timing")
+
+    def collect_timing(self):
+        a, b = C.c_double(), C.c_double()
+        na, nb = C.c_int(), C.c_int()
+        _check(lib().wbc_solver_collect_timing(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)),
+               "wbc_solver_collect_timing")
+        return dict(dyn_ms=a.value, dyn_launches=na.value, qp_ms=b.value, qp_launches=nb.value)

@@ -1,0 +1,494 @@
+// C-ABI implementation (include/wbc_hip.h): host side of the HIP path.  No CPU compute fallback
+// exists: without a usable gfx950 device every solver entry point fails with WBC_E_NODEVICE/WBC_E_HIP.
+#include "../../include/wbc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+#include "dyn_sweep.hip.hpp"
+#include "model.hpp"
+#include "qp_wave.hip.hpp"
+
+using namespace wbc;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                     \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) return fail(WBC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+struct wbc_model { FlatModel fm; };
+
+struct wbc_solver {
+  int dtype = WBC_F64;
+  int device = 0;
+  size_t max_batch = 0;
+  wbc_params params;
+  int leg_body[4][3];
+  void* d_model = nullptr;  // DevModel<T>
+  void* d_ws = nullptr;     // WS_WORDS * max_batch * sizeof(T)
+  QpJidx jmap;
+  // N=1 convenience buffers
+  void* d_one = nullptr;
+  size_t one_bytes = 0;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct Span { int kind; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  size_t ev_next = 0;
+};
+
+// ------------------------------------------------------------------------------------------ model
+extern "C" int wbc_model_load_urdf(const char* path, const char* const* foot_links, int n_foot_links, wbc_model** out) {
+  if (!path || !out || n_foot_links < 0 || (n_foot_links > 0 && !foot_links)) return fail(WBC_E_INVALID, "null argument");
+  *out = nullptr;
+  std::vector<std::string> feet;
+  for (int i = 0; i < n_foot_links; ++i) {
+    if (!foot_links[i]) return fail(WBC_E_INVALID, "null foot link name");
+    feet.emplace_back(foot_links[i]);
+  }
+  wbc_model* m = new (std::nothrow) wbc_model;
+  if (!m) return fail(WBC_E_INVALID, "out of memory");
+  std::string err;
+  int rc;
+  try {
+    rc = load_urdf(path, feet, m->fm, err);
+  } catch (const std::exception& e) {
+    rc = WBC_E_PARSE; err = e.what();
+  }
+  if (rc != WBC_OK) { delete m; return fail(rc, err); }
+  *out = m;
+  return WBC_OK;
+}
+
+extern "C" int wbc_model_from_flat(int nb, const int* parent, const double* Rt, const double* rt, const double* axis,
+                                   const double* mass, const double* com, const double* Ic, int nf,
+                                   const int* foot_body, const double* foot_off, const double* gravity,
+                                   wbc_model** out) {
+  if (!out || nb < 1 || nb > 64 || nf < 0 || nf > 16 || !parent || !Rt || !rt || !axis || !mass || !com || !Ic ||
+      (nf > 0 && (!foot_body || !foot_off)))
+    return fail(WBC_E_INVALID, "bad argument");
+  *out = nullptr;
+  for (int i = 0; i < nb; ++i)
+    if ((i == 0 && parent[i] != -1) || (i > 0 && (parent[i] < 0 || parent[i] >= i)))
+      return fail(WBC_E_INVALID, "parent[] must satisfy parent[0] = -1, 0 <= parent[i] < i");
+  for (int k = 0; k < nf; ++k)
+    if (foot_body[k] < 0 || foot_body[k] >= nb) return fail(WBC_E_INVALID, "foot_body out of range");
+  wbc_model* m = new (std::nothrow) wbc_model;
+  if (!m) return fail(WBC_E_INVALID, "out of memory");
+  FlatModel& f = m->fm;
+  f.nb = nb;
+  f.parent.assign(parent, parent + nb);
+  f.Rt.assign(Rt, Rt + 9 * nb);
+  f.rt.assign(rt, rt + 3 * nb);
+  f.axis.assign(axis, axis + 3 * nb);
+  f.mass.assign(mass, mass + nb);
+  f.com.assign(com, com + 3 * nb);
+  f.Ic.assign(Ic, Ic + 6 * nb);
+  f.foot_body.assign(foot_body, foot_body + nf);
+  f.foot_off.assign(foot_off, foot_off + 3 * nf);
+  if (gravity) for (int k = 0; k < 3; ++k) f.gravity[k] = gravity[k];
+  f.joint_names.assign(nb - 1, "");
+  f.foot_links.assign(nf, "");
+  f.body_names.assign(nb, "");
+  *out = m;
+  return WBC_OK;
+}
+
+extern "C" void wbc_model_free(wbc_model* m) { delete m; }
+
+extern "C" int wbc_model_dims(const wbc_model* m, int* nb, int* nq, int* nv, int* nj, int* nf) {
+  if (!m) return fail(WBC_E_INVALID, "null model");
+  if (nb) *nb = m->fm.nb;
+  if (nq) *nq = m->fm.nq();
+  if (nv) *nv = m->fm.nv();
+  if (nj) *nj = m->fm.nj();
+  if (nf) *nf = m->fm.nf();
+  return WBC_OK;
+}
+
+extern "C" int wbc_model_get_flat(const wbc_model* m, int* parent, double* Rt, double* rt, double* axis, double* mass,
+                                  double* com, double* Ic, int* foot_body, double* foot_off, double* gravity) {
+  if (!m) return fail(WBC_E_INVALID, "null model");
+  const FlatModel& f = m->fm;
+  auto cp = [](auto* dst, const auto& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+  cp(parent, f.parent); cp(Rt, f.Rt); cp(rt, f.rt); cp(axis, f.axis); cp(mass, f.mass); cp(com, f.com); cp(Ic, f.Ic);
+  cp(foot_body, f.foot_body); cp(foot_off, f.foot_off);
+  if (gravity) for (int k = 0; k < 3; ++k) gravity[k] = f.gravity[k];
+  return WBC_OK;
+}
+
+extern "C" const char* wbc_model_joint_name(const wbc_model* m, int j) {
+  if (!m || j < 0 || j >= (int)m->fm.joint_names.size()) return nullptr;
+  return m->fm.joint_names[j].c_str();
+}
+extern "C" const char* wbc_model_foot_link(const wbc_model* m, int k) {
+  if (!m || k < 0 || k >= (int)m->fm.foot_links.size()) return nullptr;
+  return m->fm.foot_links[k].c_str();
+}
+extern "C" double wbc_model_total_mass(const wbc_model* m) {
+  if (!m) return 0.0;
+  double s = 0;
+  for (double x : m->fm.mass) s += x;
+  return s;
+}
+
+extern "C" void wbc_params_default(wbc_params* p, int dtype) {
+  if (!p) return;
+  for (int i = 0; i < 6; ++i) p->S[i] = 1.0;
+  p->alpha = 1e-3; p->fn_min = 0.0; p->fn_max = 400.0; p->mu_scale = 1.0; p->dt = 1e-3;
+  p->observer_order = 0; p->max_iter = 100;
+  p->qp_tol = (dtype == WBC_F32) ? 1e-3 : 1e-9;
+  for (int i = 0; i < WBC_MAXV; ++i) { p->K1[i] = 50.0; p->K2[i] = 200.0; }
+}
+
+// ------------------------------------------------------------------------------------------ solver
+template <class T> static void build_dev_model(const FlatModel& f, const int leg_body[4][3], DevModel<T>& d) {
+  std::memset(&d, 0, sizeof(d));
+  auto put = [&](int leg, int idx, double v) { d.cst[idx * 4 + leg] = (T)v; };
+  for (int l = 0; l < 4; ++l) {
+    for (int k = 0; k < 3; ++k) {
+      const int b = leg_body[l][k], o = JOINT_WORDS * k;
+      const double* Rt = &f.Rt[9 * b];
+      const double* ax = &f.axis[3 * b];
+      double A0[9], A2[9];
+      // A0 = Rt a a^T ; A2 = Rt [a]x
+      double Ra[3];
+      for (int i = 0; i < 3; ++i) Ra[i] = Rt[3 * i] * ax[0] + Rt[3 * i + 1] * ax[1] + Rt[3 * i + 2] * ax[2];
+      const double K[9] = {0, -ax[2], ax[1], ax[2], 0, -ax[0], -ax[1], ax[0], 0};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          A0[3 * i + j] = Ra[i] * ax[j];
+          double s = 0;
+          for (int q = 0; q < 3; ++q) s += Rt[3 * i + q] * K[3 * q + j];
+          A2[3 * i + j] = s;
+        }
+      for (int e = 0; e < 9; ++e) { put(l, o + e, A0[e]); put(l, o + 9 + e, Rt[e] - A0[e]); put(l, o + 18 + e, A2[e]); }
+      for (int e = 0; e < 3; ++e) { put(l, o + 27 + e, f.rt[3 * b + e]); put(l, o + 30 + e, ax[e]); }
+      const double m = f.mass[b], *c = &f.com[3 * b], *I = &f.Ic[6 * b];
+      put(l, o + 33, m);
+      for (int e = 0; e < 3; ++e) put(l, o + 34 + e, m * c[e]);
+      const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+      const double Io[6] = {I[0] + m * (cc - c[0] * c[0]), I[1] - m * c[0] * c[1], I[2] - m * c[0] * c[2],
+                            I[3] + m * (cc - c[1] * c[1]), I[4] - m * c[1] * c[2], I[5] + m * (cc - c[2] * c[2])};
+      for (int e = 0; e < 6; ++e) put(l, o + 37 + e, Io[e]);
+      d.jidx[l][k] = b - 1;
+    }
+    for (int e = 0; e < 3; ++e) put(l, 129 + e, f.foot_off[3 * l + e]);
+  }
+  const double m = f.mass[0], *c = &f.com[0], *I = &f.Ic[0];
+  const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+  d.base_m = (T)m;
+  for (int e = 0; e < 3; ++e) d.base_h[e] = (T)(m * c[e]);
+  const double Io[6] = {I[0] + m * (cc - c[0] * c[0]), I[1] - m * c[0] * c[1], I[2] - m * c[0] * c[2],
+                        I[3] + m * (cc - c[1] * c[1]), I[4] - m * c[1] * c[2], I[5] + m * (cc - c[2] * c[2])};
+  for (int e = 0; e < 6; ++e) d.base_Io[e] = (T)Io[e];
+  for (int e = 0; e < 3; ++e) d.grav[e] = (T)f.gravity[e];
+}
+
+template <class T> static DevParams<T> to_dev_params(const wbc_params& p) {
+  DevParams<T> d;
+  for (int i = 0; i < 6; ++i) d.S[i] = (T)p.S[i];
+  d.alpha = (T)p.alpha; d.fn_min = (T)p.fn_min; d.fn_max = (T)p.fn_max; d.mu_scale = (T)p.mu_scale;
+  d.dt = (T)p.dt; d.qp_tol = (T)p.qp_tol;
+  d.observer_order = p.observer_order; d.max_iter = p.max_iter;
+  for (int i = 0; i < 18; ++i) { d.K1[i] = (T)p.K1[i]; d.K2[i] = (T)p.K2[i]; }
+  return d;
+}
+
+static int check_params(const wbc_params* p) {
+  if (!p) return fail(WBC_E_INVALID, "null params");
+  if (!(p->alpha > 0)) return fail(WBC_E_INVALID, "alpha must be > 0 (strict convexity of the GRF QP)");
+  if (!(p->fn_max >= p->fn_min)) return fail(WBC_E_INVALID, "fn_max < fn_min");
+  if (p->observer_order < 0 || p->observer_order > 2) return fail(WBC_E_INVALID, "observer_order must be 0, 1 or 2");
+  if (p->max_iter < 1) return fail(WBC_E_INVALID, "max_iter must be >= 1");
+  for (int i = 0; i < 6; ++i) if (!(p->S[i] >= 0)) return fail(WBC_E_INVALID, "S must be >= 0");
+  return WBC_OK;
+}
+
+extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
+                                 wbc_solver** out) {
+  if (!m || !out || max_batch == 0 || (dtype != WBC_F64 && dtype != WBC_F32)) return fail(WBC_E_INVALID, "bad argument");
+  *out = nullptr;
+  int rc = check_params(p);
+  if (rc) return rc;
+  int leg_body[4][3];
+  std::string err;
+  rc = quadruped_topology(m->fm, leg_body, err);
+  if (rc) return fail(rc, err);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(WBC_E_NODEVICE, "no HIP device: the WBC hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(WBC_E_INVALID, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(WBC_E_NODEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  wbc_solver* s = new (std::nothrow) wbc_solver;
+  if (!s) return fail(WBC_E_INVALID, "out of memory");
+  s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p;
+  std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
+  for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
+  const size_t ts = dtype == WBC_F64 ? 8 : 4;
+  hipError_t e;
+  if (dtype == WBC_F64) {
+    DevModel<double> dm; build_dev_model(m->fm, leg_body, dm);
+    e = hipMalloc(&s->d_model, sizeof(dm));
+    if (e == hipSuccess) e = hipMemcpy(s->d_model, &dm, sizeof(dm), hipMemcpyHostToDevice);
+  } else {
+    DevModel<float> dm; build_dev_model(m->fm, leg_body, dm);
+    e = hipMalloc(&s->d_model, sizeof(dm));
+    if (e == hipSuccess) e = hipMemcpy(s->d_model, &dm, sizeof(dm), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess) e = hipMalloc(&s->d_ws, (size_t)WS_WORDS * max_batch * ts);
+  // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
+  s->one_bytes = 200 * sizeof(double) + 4 * sizeof(int);
+  if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
+  if (e != hipSuccess) {
+    std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
+    wbc_solver_destroy(s);
+    return fail(WBC_E_HIP, msg);
+  }
+  *out = s;
+  return WBC_OK;
+}
+
+extern "C" void wbc_solver_destroy(wbc_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->d_model) (void)hipFree(s->d_model);
+  if (s->d_ws) (void)hipFree(s->d_ws);
+  if (s->d_one) (void)hipFree(s->d_one);
+  for (hipEvent_t ev : s->ev_pool) (void)hipEventDestroy(ev);
+  delete s;
+}
+
+extern "C" int wbc_solver_set_params(wbc_solver* s, const wbc_params* p) {
+  if (!s) return fail(WBC_E_INVALID, "null solver");
+  int rc = check_params(p);
+  if (rc) return rc;
+  s->params = *p;
+  return WBC_OK;
+}
+
+// ---- timing helpers
+static int span_begin(wbc_solver* s, int kind, hipStream_t st) {
+  if (!s->timing) return WBC_OK;
+  if (s->ev_next + 2 > s->ev_pool.size()) {
+    for (int i = 0; i < 64; ++i) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      s->ev_pool.push_back(ev);
+    }
+  }
+  wbc_solver::Span sp{kind, s->ev_pool[s->ev_next], s->ev_pool[s->ev_next + 1]};
+  s->ev_next += 2;
+  HIP_TRY(hipEventRecord(sp.a, st));
+  s->spans.push_back(sp);
+  return WBC_OK;
+}
+static int span_end(wbc_solver* s, hipStream_t st) {
+  if (!s->timing) return WBC_OK;
+  HIP_TRY(hipEventRecord(s->spans.back().b, st));
+  return WBC_OK;
+}
+
+extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
+  if (!s) return fail(WBC_E_INVALID, "null solver");
+  s->timing = on != 0;
+  s->spans.clear();
+  s->ev_next = 0;
+  return WBC_OK;
+}
+
+extern "C" int wbc_solver_collect_timing(wbc_solver* s, double* dyn_ms, int* dyn_launches, double* qp_ms, int* qp_launches) {
+  if (!s) return fail(WBC_E_INVALID, "null solver");
+  double ms[2] = {0, 0};
+  int cnt[2] = {0, 0};
+  for (auto& sp : s->spans) {
+    HIP_TRY(hipEventSynchronize(sp.b));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
+    ms[sp.kind] += t;
+    cnt[sp.kind]++;
+  }
+  s->spans.clear();
+  s->ev_next = 0;
+  if (dyn_ms) *dyn_ms = ms[0];
+  if (dyn_launches) *dyn_launches = cnt[0];
+  if (qp_ms) *qp_ms = ms[1];
+  if (qp_launches) *qp_launches = cnt[1];
+  return WBC_OK;
+}
+
+// ---- launches
+template <class T, int MODE>
+static hipError_t launch_sweep(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
+  const size_t threads = a.N * 4;
+  const unsigned blocks = (unsigned)((threads + 63) / 64);
+  hipLaunchKernelGGL((dyn_sweep_kernel<T, MODE>), dim3(blocks), dim3(64), 0, st, (const DevModel<T>*)s->d_model,
+                     to_dev_params<T>(s->params), a);
+  return hipGetLastError();
+}
+
+template <class T>
+static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc, void* pf,
+                         void* p, void* beta, hipStream_t st) {
+  SweepArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.N = N; a.q = (const T*)q; a.v = (const T*)v;
+  a.M = (T*)M; a.h = (T*)h; a.Jc = (T*)Jc; a.pf = (T*)pf; a.p = (T*)p; a.beta = (T*)beta;
+  const bool mats = M != nullptr, obs = p || beta;
+  int rc = span_begin(s, 0, st);
+  if (rc) return rc;
+  hipError_t e;
+  if (mats && obs) e = launch_sweep<T, SW_MATS | SW_OBS>(s, a, st);
+  else if (mats) e = launch_sweep<T, SW_MATS>(s, a, st);
+  else if (obs) e = launch_sweep<T, SW_OBS>(s, a, st);
+  else e = launch_sweep<T, 0>(s, a, st);
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
+  return span_end(s, st);
+}
+
+extern "C" int wbc_dynamics_batch(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc,
+                                  void* pf, void* p, void* beta, void* stream) {
+  if (!s || !q || !v) return fail(WBC_E_INVALID, "null argument");
+  if (N == 0) return WBC_OK;
+  if ((M || h || Jc) && !(M && h && Jc)) return fail(WBC_E_INVALID, "M, h, Jc must be given together");
+  if (!M && !pf && !p && !beta) return fail(WBC_E_INVALID, "no output requested");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  return s->dtype == WBC_F64 ? dynamics_impl<double>(s, N, q, v, M, h, Jc, pf, p, beta, st)
+                             : dynamics_impl<float>(s, N, q, v, M, h, Jc, pf, p, beta, st);
+}
+
+template <class T>
+static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
+                     const wbc_observer_state* obs, hipStream_t st) {
+  SweepArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.N = N; a.q = (const T*)in->q; a.v = (const T*)in->v;
+  a.M = (T*)out->M; a.h = (T*)out->h; a.Jc = (T*)out->Jc; a.pf = (T*)out->pf;
+  a.w_des = (const T*)in->w_des; a.vdot_des = (const T*)in->vdot_des;
+  a.tau_prev = (const T*)in->tau_prev; a.f_prev = (const T*)in->f_prev;
+  a.obs_integ = obs ? (T*)obs->integ : nullptr; a.obs_r = obs ? (T*)obs->r : nullptr;
+  a.ws = (T*)s->d_ws;
+  const bool mats = out->M != nullptr, ob = s->params.observer_order > 0;
+  int rc = span_begin(s, 0, st);
+  if (rc) return rc;
+  hipError_t e;
+  if (mats && ob) e = launch_sweep<T, SW_MATS | SW_STEP | SW_OBS>(s, a, st);
+  else if (mats) e = launch_sweep<T, SW_MATS | SW_STEP>(s, a, st);
+  else if (ob) e = launch_sweep<T, SW_STEP | SW_OBS>(s, a, st);
+  else e = launch_sweep<T, SW_STEP>(s, a, st);
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
+  rc = span_end(s, st);
+  if (rc) return rc;
+
+  QpArgs<T> qa;
+  qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
+  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
+  rc = span_begin(s, 1, st);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)((N + 3) / 4);
+  hipLaunchKernelGGL((qp_wave_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("qp_wave launch: ") + hipGetErrorString(e));
+  return span_end(s, st);
+}
+
+extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
+                              const wbc_observer_state* obs, void* stream) {
+  if (!s || !in || !out) return fail(WBC_E_INVALID, "null argument");
+  if (N == 0) return WBC_OK;
+  if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
+  if (!in->q || !in->v || !in->w_des || !in->vdot_des || !in->normals || !in->mu || !in->mask)
+    return fail(WBC_E_INVALID, "null input buffer");
+  if (!out->tau || !out->f || !out->status) return fail(WBC_E_INVALID, "null output buffer");
+  if ((out->M || out->h || out->Jc) && !(out->M && out->h && out->Jc))
+    return fail(WBC_E_INVALID, "M, h, Jc must be given together");
+  if (s->params.observer_order > 0) {
+    if (!obs || !obs->integ || !obs->r) return fail(WBC_E_INVALID, "observer on: observer state buffers required");
+    if (!in->tau_prev || !in->f_prev) return fail(WBC_E_INVALID, "observer on: tau_prev and f_prev required");
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  return s->dtype == WBC_F64 ? step_impl<double>(s, N, in, out, obs, st) : step_impl<float>(s, N, in, out, obs, st);
+}
+
+extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const double* w_des,
+                                   const double* vdot_des, const double* normals, const double* mu, int mask,
+                                   const double* tau_prev, const double* f_prev, double* obs_integ, double* obs_r,
+                                   double* tau, double* f, int* status) {
+  if (!s || !q || !v || !w_des || !vdot_des || !normals || !mu || !tau || !f || !status)
+    return fail(WBC_E_INVALID, "null argument");
+  const bool ob = s->params.observer_order > 0;
+  if (ob && (!tau_prev || !f_prev || !obs_integ || !obs_r)) return fail(WBC_E_INVALID, "observer on: state required");
+  HIP_TRY(hipSetDevice(s->device));
+  // host staging in the solver's dtype
+  const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
+  const int off[] = {0, 19, 37, 43, 61, 73, 77, 89, 101, 119, 137, 149, 161};  // q v w a n mu tp fp ig r tau f end
+  std::vector<unsigned char> hbuf(161 * ts);
+  auto put = [&](int o, const double* src, int n) {
+    for (int i = 0; i < n; ++i) {
+      if (s->dtype == WBC_F64) ((double*)hbuf.data())[o + i] = src ? src[i] : 0.0;
+      else ((float*)hbuf.data())[o + i] = src ? (float)src[i] : 0.0f;
+    }
+  };
+  put(off[0], q, 19); put(off[1], v, 18); put(off[2], w_des, 6); put(off[3], vdot_des, 18); put(off[4], normals, 12);
+  put(off[5], mu, 4); put(off[6], tau_prev, 12); put(off[7], f_prev, 12); put(off[8], obs_integ, 18); put(off[9], obs_r, 18);
+  put(off[10], nullptr, 12); put(off[11], nullptr, 12);
+  unsigned char* d = (unsigned char*)s->d_one;
+  int* dints = (int*)(d + 200 * sizeof(double));
+  HIP_TRY(hipMemcpy(d, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dints, &mask, sizeof(int), hipMemcpyHostToDevice));
+  wbc_batch_in in;
+  in.q = d + off[0] * ts; in.v = d + off[1] * ts; in.w_des = d + off[2] * ts; in.vdot_des = d + off[3] * ts;
+  in.normals = d + off[4] * ts; in.mu = d + off[5] * ts; in.mask = dints;
+  in.tau_prev = d + off[6] * ts; in.f_prev = d + off[7] * ts;
+  wbc_batch_out out;
+  std::memset(&out, 0, sizeof(out));
+  out.tau = d + off[10] * ts; out.f = d + off[11] * ts; out.status = dints + 1; out.iters = dints + 2;
+  wbc_observer_state os{d + off[8] * ts, d + off[9] * ts};
+  int rc = wbc_step_batch(s, 1, &in, &out, &os, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(hbuf.data(), d, hbuf.size(), hipMemcpyDeviceToHost));
+  auto get = [&](int o, double* dst, int n) {
+    if (!dst) return;
+    for (int i = 0; i < n; ++i)
+      dst[i] = s->dtype == WBC_F64 ? ((double*)hbuf.data())[o + i] : (double)((float*)hbuf.data())[o + i];
+  };
+  get(off[10], tau, 12); get(off[11], f, 12);
+  if (ob) { get(off[8], obs_integ, 18); get(off[9], obs_r, 18); }
+  HIP_TRY(hipMemcpy(status, dints + 1, sizeof(int), hipMemcpyDeviceToHost));
+  return WBC_OK;
+}
+
+extern "C" const char* wbc_strerror(int st) {
+  switch (st) {
+    case WBC_OK: return "ok";
+    case WBC_E_INVALID: return "invalid argument";
+    case WBC_E_IO: return "cannot read URDF";
+    case WBC_E_PARSE: return "URDF parse error";
+    case WBC_E_TOPOLOGY: return "unsupported robot topology";
+    case WBC_E_NODEVICE: return "no usable gfx950 device";
+    case WBC_E_HIP: return "HIP runtime error";
+    case WBC_E_CAPACITY: return "batch exceeds solver capacity";
+    default: return "unknown status";
+  }
+}
+extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
+extern "C" int wbc_abi_version(void) { return 1; }
