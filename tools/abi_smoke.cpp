@@ -1,0 +1,72 @@
+// Stand-alone C++ consumer of the C-ABI (no Python, no torch): what a C++ host such as the reference's
+// ROS node would do.  Loads the URDF, runs one single-robot tick through wbc_compute_torques and a
+// 1024-state batch through wbc_step_batch with raw hipMalloc'ed buffers.  Build:
+//   hipcc -O2 -I include tools/abi_smoke.cpp -L wbc_quadruped_dob_amd/lib -lwbc_hip -Wl,-rpath,$PWD/wbc_quadruped_dob_amd/lib -o /tmp/abi_smoke
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "wbc_hip.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_) { std::printf("%s -> %d (%s) %s\n", #x, rc_, wbc_strerror(rc_), wbc_last_error()); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  const char* urdf = argc > 1 ? argv[1] : "wbc_quadruped_dob_amd/assets/synthetic_quadruped.urdf";
+  wbc_model* m = nullptr;
+  CK(wbc_model_load_urdf(urdf, nullptr, 0, &m));
+  int nb, nq, nv, nj, nf;
+  CK(wbc_model_dims(m, &nb, &nq, &nv, &nj, &nf));
+  std::printf("model: nb=%d nq=%d nv=%d nj=%d nf=%d mass=%.3f\n", nb, nq, nv, nj, nf, wbc_model_total_mass(m));
+  wbc_params p;
+  wbc_params_default(&p, WBC_F64);
+  wbc_solver* s = nullptr;
+  const size_t N = 1024;
+  CK(wbc_solver_create(m, &p, WBC_F64, 0, N, &s));
+  // single robot, standing still: sum of GRFs must carry the weight
+  double q[19] = {0, 0, 0.4, 0, 0, 0, 1}, v[18] = {0}, w[6] = {0, 0, wbc_model_total_mass(m) * 9.81, 0, 0, 0}, a[18] = {0};
+  for (int l = 0; l < 4; ++l) { q[7 + 3 * l] = 0.05; q[8 + 3 * l] = 0.75; q[9 + 3 * l] = -1.5; }
+  double nrm[12], mu[4] = {0.6, 0.6, 0.6, 0.6}, tau[12], f[12];
+  for (int k = 0; k < 4; ++k) { nrm[3 * k] = 0; nrm[3 * k + 1] = 0; nrm[3 * k + 2] = 1; }
+  int st = -1;
+  CK(wbc_compute_torques(s, q, v, w, a, nrm, mu, 0xF, nullptr, nullptr, nullptr, nullptr, tau, f, &st));
+  double fz = f[2] + f[5] + f[8] + f[11];
+  std::printf("single robot: status=%d sum fz=%.6f (weight %.6f) tau0=%.6f\n", st, fz, w[2], tau[0]);
+  if (st != 0 || std::fabs(fz - w[2]) > 1e-2 * w[2]) return 2;
+  // batch with raw HIP buffers
+  std::vector<double> hq(19 * N), hv(18 * N, 0.0), hw(6 * N, 0.0), ha(18 * N, 0.0), hn(12 * N), hmu(4 * N, 0.6);
+  std::vector<int> hmask(N, 0xF);
+  for (size_t i = 0; i < N; ++i) {
+    for (int c = 0; c < 19; ++c) hq[c * N + i] = q[c];
+    hq[2 * N + i] = 0.3 + 0.0001 * i;
+    hw[2 * N + i] = w[2];
+    for (int c = 0; c < 12; ++c) hn[c * N + i] = nrm[c];
+  }
+  double *dq, *dv, *dw, *da, *dn, *dmu, *dtau, *df;
+  int *dmask, *dst;
+  hipMalloc(&dq, hq.size() * 8); hipMalloc(&dv, hv.size() * 8); hipMalloc(&dw, hw.size() * 8); hipMalloc(&da, ha.size() * 8);
+  hipMalloc(&dn, hn.size() * 8); hipMalloc(&dmu, hmu.size() * 8); hipMalloc(&dtau, 12 * N * 8); hipMalloc(&df, 12 * N * 8);
+  hipMalloc(&dmask, N * 4); hipMalloc(&dst, N * 4);
+  hipMemcpy(dq, hq.data(), hq.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dv, hv.data(), hv.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dw, hw.data(), hw.size() * 8, hipMemcpyHostToDevice); hipMemcpy(da, ha.data(), ha.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dn, hn.data(), hn.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dmu, hmu.data(), hmu.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dmask, hmask.data(), N * 4, hipMemcpyHostToDevice);
+  wbc_batch_in in = {dq, dv, dw, da, dn, dmu, dmask, nullptr, nullptr};
+  wbc_batch_out out = {dtau, df, dst, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream;
+  hipStreamCreate(&stream);
+  CK(wbc_step_batch(s, N, &in, &out, nullptr, stream));
+  hipStreamSynchronize(stream);
+  std::vector<double> hf(12 * N);
+  std::vector<int> hst(N);
+  hipMemcpy(hf.data(), df, hf.size() * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(hst.data(), dst, N * 4, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (size_t i = 0; i < N; ++i) {
+    double z = hf[2 * N + i] + hf[5 * N + i] + hf[8 * N + i] + hf[11 * N + i];
+    if (hst[i] != 0 || std::fabs(z - w[2]) > 1e-2 * w[2]) ++bad;
+  }
+  std::printf("batch %zu: %d bad\n", N, bad);
+  wbc_solver_destroy(s);
+  wbc_model_free(m);
+  return bad ? 3 : 0;
+}

@@ -81,6 +81,9 @@ def lib():
     """Load libwbc_hip.so; fail loudly when it has not been built."""
     global _lib
     if _lib is None:
+        # torch first: its bundled libamdhip64.so.7 must be THE HIP runtime of the process, so that device
+        # pointers and streams handed over from torch are valid inside the library (same SONAME => shared).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the WBC hot path)" % LIB_PATH)
