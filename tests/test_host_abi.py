@@ -1,0 +1,129 @@
+"""CPU: host-side logic of the product library -- URDF reader parity with the independent Python parser,
+C-ABI symbol coverage against include/wbc_hip.h, and error behaviour.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import wbc_quadruped_dob_amd as W
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_every_declared_symbol_is_exported(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "wbc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(wbc_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 18, declared
+    nm = subprocess.run(["nm", "-D", "--defined-only", W.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (wbc_[a-z_0-9]+)\b", nm))
+    assert declared <= exported, declared - exported
+    for name in declared:
+        assert getattr(hip_lib, name) is not None
+
+
+def test_urdf_reader_matches_python_parser(hip_lib, flat_model):
+    m = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    assert (m.nb, m.nq, m.nv, m.nj, m.nf) == (13, 19, 18, 12, 4)
+    f = m.flat()
+    for k in ("parent", "foot_body"):
+        np.testing.assert_array_equal(f[k], flat_model[k])
+    for k in ("Rt", "rt", "axis", "mass", "com", "Ic", "foot_off", "gravity"):
+        np.testing.assert_allclose(np.asarray(f[k]).reshape(-1), np.asarray(flat_model[k]).reshape(-1), rtol=0, atol=1e-14, err_msg=k)
+    assert f["joint_names"] == flat_model["joint_names"]
+    assert f["foot_links"] == flat_model["foot_links"]
+    assert abs(m.total_mass - float(flat_model["mass"].sum())) < 1e-12
+
+
+def test_explicit_foot_links_and_flat_roundtrip(hip_lib, flat_model):
+    feet = ["back_right_foot", "front_left_foot", "back_left_foot", "front_right_foot"]
+    m = W.Model.from_urdf(W.SYNTHETIC_URDF, foot_links=feet)
+    f = m.flat()
+    assert list(f["foot_body"]) == [12, 3, 9, 6] and f["foot_links"] == feet
+    m2 = W.Model.from_flat(f)
+    f2 = m2.flat()
+    for k in ("Rt", "rt", "axis", "mass", "com", "Ic", "foot_off"):
+        np.testing.assert_array_equal(f2[k], f[k])
+
+
+def _load(path_or_text, tmp_path, as_text=False):
+    if as_text:
+        p = tmp_path / "m.urdf"
+        p.write_text(path_or_text)
+        path_or_text = str(p)
+    h = C.c_void_p()
+    rc = W.lib().wbc_model_load_urdf(path_or_text.encode(), None, 0, C.byref(h))
+    if rc == 0:
+        W.lib().wbc_model_free(h)
+    return rc, W.lib().wbc_last_error().decode()
+
+
+def test_urdf_error_codes(hip_lib, tmp_path):
+    rc, msg = _load("/nonexistent/dogbot.urdf", tmp_path)
+    assert rc == 2 and "cannot open" in msg                       # WBC_E_IO
+    rc, msg = _load("<robot name='x'><link name='a'></robot>", tmp_path, True)
+    assert rc == 3                                                  # mismatched tag
+    rc, msg = _load("<notrobot/>", tmp_path, True)
+    assert rc == 3 and "robot" in msg
+    rc, msg = _load("<robot><link name='a'/><link name='b'/><joint name='j' type='prismatic'>"
+                    "<parent link='a'/><child link='b'/></joint></robot>", tmp_path, True)
+    assert rc == 3 and "prismatic" in msg
+    rc, msg = _load("<robot><link name='a'/><joint name='j' type='fixed'><parent link='a'/><child link='zz'/></joint></robot>",
+                    tmp_path, True)
+    assert rc == 3 and "unknown link" in msg
+    assert W.lib().wbc_model_load_urdf(None, None, 0, None) == 1    # WBC_E_INVALID
+
+
+def test_solver_rejects_non_quadruped_and_bad_params(hip_lib, tmp_path):
+    two_link = ("<robot><link name='a'><inertial><mass value='1'/><inertia ixx='1' iyy='1' izz='1'/></inertial></link>"
+                "<link name='b'><inertial><mass value='1'/><inertia ixx='1' iyy='1' izz='1'/></inertial></link>"
+                "<joint name='j' type='revolute'><parent link='a'/><child link='b'/><axis xyz='0 0 1'/></joint></robot>")
+    p = tmp_path / "two.urdf"
+    p.write_text(two_link)
+    m = W.Model.from_urdf(str(p))
+    assert (m.nb, m.nf) == (2, 1)
+    prm = W.Params.default()
+    h = C.c_void_p()
+    rc = W.lib().wbc_solver_create(m._h, C.byref(prm), 0, 0, 16, C.byref(h))
+    assert rc == 4, W.lib().wbc_last_error()                       # WBC_E_TOPOLOGY before any device is touched
+    good = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    prm.alpha = 0.0
+    assert W.lib().wbc_solver_create(good._h, C.byref(prm), 0, 0, 16, C.byref(h)) == 1
+    prm = W.Params.default()
+    prm.observer_order = 3
+    assert W.lib().wbc_solver_create(good._h, C.byref(prm), 0, 0, 16, C.byref(h)) == 1
+    assert W.lib().wbc_solver_create(good._h, C.byref(W.Params.default()), 7, 0, 16, C.byref(h)) == 1  # bad dtype
+
+
+def test_no_cpu_fallback_without_a_gpu(hip_lib):
+    """On a box without a GPU the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    good = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    h = C.c_void_p()
+    rc = W.lib().wbc_solver_create(good._h, C.byref(W.Params.default()), 0, 0, 16, C.byref(h))
+    assert rc == 5 and "no CPU fallback" in W.lib().wbc_last_error().decode()
+    with pytest.raises(RuntimeError):
+        W.Solver(good)
+
+
+def test_product_does_not_reference_the_oracle():
+    """No product source may include, import or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "wbc_quadruped_dob_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or fn == "Makefile":
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "wbc_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+    ldd = subprocess.run(["ldd", W.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd
+
+
+def test_params_default_values(hip_lib):
+    p64, p32 = W.Params.default("f64"), W.Params.default("f32")
+    assert p64.alpha == 1e-3 and p64.qp_tol == 1e-9 and p32.qp_tol == 1e-3 and p64.observer_order == 0
+    assert list(p64.S) == [1.0] * 6 and p64.K1[17] == 50.0 and p64.K2[0] == 200.0

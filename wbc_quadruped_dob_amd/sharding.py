@@ -1,0 +1,70 @@
+"""Batch sharding of the hot path across the GPUs of one node.
+
+The path is embarrassingly parallel over robot states: each rank owns a contiguous slice of the batch and
+runs the same kernels on it; there is NO data-path collective.  Two optional collectives exist for
+consumers that need them: an all-gather of the torques (one consumer wants every tau) and an all-reduce
+of a few status counters.  On the GPU box the backend is RCCL ("nccl") over xGMI; the CPU tests run the
+same code over gloo with an injected compute function.
+
+The reference has no distributed path (single robot, single process; /root/reference/README.md:58-60).
+"""
+import numpy as np
+
+
+def shard_range(n_total, world, rank):
+    """Contiguous, balanced slices: the first (n_total % world) ranks get one extra state."""
+    if world < 1 or not (0 <= rank < world) or n_total < 0:
+        raise ValueError("bad shard arguments")
+    base, extra = divmod(n_total, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+class ShardedBatch:
+    """Owns this rank's slice of a component-major batch [ncomp, n_total] and the optional collectives.
+
+    step_fn(local_inputs: dict) -> dict(tau=[nj, n_local], f=..., status=[n_local], ...) is the per-rank
+    compute: Solver.step on the GPU box.  (Tests inject a CPU stand-in; the product never does.)
+    """
+
+    def __init__(self, step_fn, n_total, dist=None):
+        self.step_fn = step_fn
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.n_total = n_total
+        self.start, self.count = shard_range(n_total, self.world, self.rank)
+
+    def local_slice(self, x):
+        """slice a full [ncomp, n_total] (or [n_total]) array/tensor down to this rank's columns"""
+        return x[..., self.start:self.start + self.count]
+
+    def step(self, local_inputs):
+        return self.step_fn(local_inputs)
+
+    def gather(self, x_local):
+        """all-gather of a [ncomp, n_local] tensor into [ncomp, n_total] on every rank (ragged-safe)."""
+        import torch
+        if self.dist is None:
+            return x_local
+        ncomp = x_local.shape[0]
+        counts = [shard_range(self.n_total, self.world, r)[1] for r in range(self.world)]
+        mx = max(counts)
+        pad = torch.zeros((ncomp, mx), dtype=x_local.dtype, device=x_local.device)
+        pad[:, :self.count] = x_local
+        bufs = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad)
+        return torch.cat([b[:, :c] for b, c in zip(bufs, counts)], dim=1)
+
+    def status_counts(self, status_local, iters_local=None):
+        """all-reduce of [n_ok, n_iter_limit, n_infeasible, sum_iters, max_iters] over ranks."""
+        import torch
+        st = status_local.to(torch.int64)
+        it = iters_local.to(torch.int64) if iters_local is not None else torch.zeros_like(st)
+        sums = torch.stack([(st == 0).sum(), (st == 1).sum(), (st == 2).sum(), it.sum()])
+        mx = it.max().reshape(1) if it.numel() else torch.zeros(1, dtype=torch.int64, device=st.device)
+        if self.dist is not None:
+            self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM)
+            self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
+        return dict(ok=int(sums[0]), iter_limit=int(sums[1]), infeasible=int(sums[2]), iters_sum=int(sums[3]),
+                    iters_max=int(mx[0]))
