@@ -1,0 +1,74 @@
+// Bandwidth probes for the access patterns of the WBC kernels (known-good references on the same device,
+// cdna_hip_programming.md rule 10): linear copy/write at 8 and 16 B/lane, and the component-major
+// "443 rows x 128-byte segments per wave" store pattern of the dynamics sweep with no arithmetic at all.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+__global__ void k_copy8(const double* __restrict__ in, double* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void k_write8(double* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)i;
+}
+__global__ void k_write16(double2* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_double2((double)i, 1.0);
+}
+__global__ void k_read8(const double* __restrict__ in, double* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0;
+  if (i < n) acc = in[i];
+  if (acc == 123.456) out[0] = acc;
+}
+// sweep-like: lane = (state, leg); each lane writes ROWS/4 rows (leg-strided) of 8 B: 128-byte segments per row
+template <int ROWS, int XCD>
+__global__ __launch_bounds__(64) void k_soa_write(double* __restrict__ out, unsigned N) {
+  unsigned bid = blockIdx.x;
+  if (XCD) { const unsigned nb = gridDim.x; bid = (bid % 8) * (nb / 8) + bid / 8; }
+  const unsigned gid = bid * 64 + threadIdx.x;
+  const unsigned leg = gid & 3, s = gid >> 2;
+  if (s >= N) return;
+  const double v = (double)gid;
+#pragma unroll 8
+  for (int r = 0; r < ROWS / 4; ++r) {
+    const unsigned comp = 4 * r + leg;
+    *(double*)((char*)out + (size_t)((comp * N + s) * 8u)) = v + r;
+  }
+}
+template <class F> float timeit(F f, int reps) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  f(); hipDeviceSynchronize();
+  hipEventRecord(a);
+  for (int i = 0; i < reps; ++i) f();
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  return ms / reps;
+}
+int main() {
+  const size_t bytes = (size_t)1 << 30;
+  double *a, *b;
+  hipMalloc(&a, bytes); hipMalloc(&b, bytes);
+  hipMemset(a, 1, bytes); hipMemset(b, 0, bytes);
+  size_t n8 = bytes / 8, n16 = bytes / 16;
+  float t;
+  t = timeit([&] { hipLaunchKernelGGL(k_copy8, dim3((n8 + 255) / 256), dim3(256), 0, 0, a, b, n8); }, 10);
+  printf("copy  8B/lane 1GiB->1GiB : %.1f us  %.0f GB/s (r+w)\n", t * 1e3, 2 * bytes / t / 1e6);
+  t = timeit([&] { hipLaunchKernelGGL(k_read8, dim3((n8 + 255) / 256), dim3(256), 0, 0, a, b, n8); }, 10);
+  printf("read  8B/lane 1GiB       : %.1f us  %.0f GB/s\n", t * 1e3, bytes / t / 1e6);
+  t = timeit([&] { hipLaunchKernelGGL(k_write8, dim3((n8 + 255) / 256), dim3(256), 0, 0, b, n8); }, 10);
+  printf("write 8B/lane 1GiB       : %.1f us  %.0f GB/s\n", t * 1e3, bytes / t / 1e6);
+  t = timeit([&] { hipLaunchKernelGGL(k_write16, dim3((n16 + 255) / 256), dim3(256), 0, 0, (double2*)b, n16); }, 10);
+  printf("write 16B/lane 1GiB      : %.1f us  %.0f GB/s\n", t * 1e3, bytes / t / 1e6);
+  for (unsigned N : {4096u, 32768u, 262144u}) {
+    const size_t wb = (size_t)444 * N * 8;
+    unsigned blocks = (N * 4 + 63) / 64;
+    t = timeit([&] { hipLaunchKernelGGL((k_soa_write<444, 0>), dim3(blocks), dim3(64), 0, 0, b, N); }, 20);
+    printf("SoA 444 rows N=%6u      : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
+    t = timeit([&] { hipLaunchKernelGGL((k_soa_write<444, 1>), dim3(blocks), dim3(64), 0, 0, b, N); }, 20);
+    printf("SoA 444 rows N=%6u xcd  : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
+  }
+  return 0;
+}

@@ -18,7 +18,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwbc_hip.so")
+LIB_PATH = os.environ.get("WBC_LIB") or os.path.join(_HERE, "lib", "libwbc_hip.so")
 SYNTHETIC_URDF = os.path.join(_HERE, "assets", "synthetic_quadruped.urdf")
 WBC_MAXV = 32
 F64, F32 = 0, 1

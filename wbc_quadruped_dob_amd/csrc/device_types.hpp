@@ -26,6 +26,7 @@ template <class T> struct DevModel {
   T base_m, base_h[3], base_Io[6];
   T grav[3];
   int jidx[4][3];  // joint index (0..nj-1) of leg l joint k in the caller's q/v ordering
+  int zidx[64];    // packed-M indices that are structurally zero (cross-leg blocks, base block), -1 padded
 };
 
 template <class T> struct DevParams {

@@ -114,108 +114,200 @@ constexpr int SW_MATS = 1;  // write M, h, Jc
 constexpr int SW_STEP = 2;  // write the step workspace (d, b, taup, JcL)
 constexpr int SW_OBS = 4;   // momentum observer update (needs SW_STEP) / p, beta outputs
 
-template <class T, int MODE>
-__global__ __launch_bounds__(64) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+#ifndef WBC_SWEEP_WAVES
+#define WBC_SWEEP_WAVES 2
+#endif
+// BLOCK = 64 for small batches (N/16 workgroups: one per CU at N = 4096) or 256 for large ones (four waves
+// share one constant table, which lets two workgroups = 8 waves fit the CU's 160 KB of LDS).
+template <class T, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                         SweepArgs<T> a) {
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0;
   __shared__ T cst[CST_WORDS];
+  __shared__ int zidx_s[64];
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
+  if (MATS && threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
   __syncthreads();
 
   const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int leg = (int)(gid & 3);
   const size_t s_raw = gid >> 2;
   const bool live = s_raw < N;
-  const size_t s = live ? s_raw : N - 1;  // dead lanes recompute the last state, stores are masked
+  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);  // dead lanes recompute the last state, stores are masked
+  const unsigned legN = (unsigned)leg * N32;
 #define CS(i) cst[(i) * 4 + leg]
+  // Addressing: every array is < 4 GiB (max_batch is capped at create), so a component row is reached as
+  // (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): no 64-bit vector address arithmetic.
+  //   LDU/STU: component index is wave-uniform;  LDV/STV: component index differs per lane.
+#define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
+#define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define STU(ptr, comp, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))) = (val); } while (0)
+#define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+  // leg-strided component: comp = c0 + stride*leg (+ per-lane extra element offset xN = x*N)
+#define STL(ptr, c0, stride, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STLX(ptr, c0, stride, xN, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+  // four base-replicated values, one per lane of the quad
+#define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 
   // ------------------------------------------------------------------ loads
   T qb[7], vb[6];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) qb[c] = a.q[(size_t)c * N + s];
+  for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) vb[c] = a.v[(size_t)c * N + s];
+  for (int c = 0; c < 6; ++c) vb[c] = LDU(a.v, c);
   int jx[3];
+  unsigned jxN[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) jx[k] = model->jidx[leg][k];
+  for (int k = 0; k < 3; ++k) { jx[k] = model->jidx[leg][k]; jxN[k] = (unsigned)jx[k] * N32; }
   T ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    ql[k] = a.q[(size_t)(7 + jx[k]) * N + s];
-    vl[k] = a.v[(size_t)(6 + jx[k]) * N + s];
+    ql[k] = *(const T*)((const char*)(a.q + (size_t)7 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+    vl[k] = *(const T*)((const char*)(a.v + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+  }
+
+  // observer off: the QP target wrench is just w_des -- forward it now, while the loads are in flight anyway
+  if (STEP && !OBS) {
+    T b[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c);
+    ST4(a.ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+    if (leg < 2) STV(a.ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+  }
+
+  // ------------------------------------------------------------------ data-independent stores first:
+  // structural zeros and ones of M and Jc go out while the sweeps compute (they overlap the VALU work).
+  if (MATS) {
+    const T Z = (T)0;
+    for (int e = leg; e < 64; e += 4) {
+      const int zi = zidx_s[e];
+      if (zi >= 0) STV(a.M, zi, Z);
+    }
+#pragma unroll
+    for (int mrow = 0; mrow < 3; ++mrow) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) STL(a.Jc, 18 * mrow + c, 54, (c == mrow) ? (T)1 : Z);
+      STL(a.Jc, 18 * mrow + 3 + mrow, 54, Z);
+#pragma unroll
+      for (int c = 0; c < 12; ++c) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);
+    }
   }
 
   // ------------------------------------------------------------------ base
-  M3<T> R;
+  // unit quaternion kept (4 words); R is rebuilt after the sweeps instead of living through them (9 words)
+  T qx, qy, qz, qw;
   {
-    T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
-    T x = qb[3] * n, y = qb[4] * n, z = qb[5] * n, w = qb[6] * n;
-    R.a[0] = 1 - 2 * (y * y + z * z); R.a[1] = 2 * (x * y - z * w);     R.a[2] = 2 * (x * z + y * w);
-    R.a[3] = 2 * (x * y + z * w);     R.a[4] = 1 - 2 * (x * x + z * z); R.a[5] = 2 * (y * z - x * w);
-    R.a[6] = 2 * (x * z - y * w);     R.a[7] = 2 * (y * z + x * w);     R.a[8] = 1 - 2 * (x * x + y * y);
+    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    qx = qb[3] * n; qy = qb[4] * n; qz = qb[5] * n; qw = qb[6] * n;
   }
-  const V3<T> vlin_w = mk<T>(vb[0], vb[1], vb[2]);
-  const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
-  const V3<T> v0 = tmul(R, vlin_w);
-  const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));  // R^T (-g)
-  const V3<T> aL0 = gneg - cross(om0, v0);  // bias pass: vdot = 0, gravity folded in
+#define MAKE_R(R_) do { const T x = qx, y = qy, z = qz, w = qw; \
+    R_.a[0] = 1 - 2 * (y * y + z * z); R_.a[1] = 2 * (x * y - z * w);     R_.a[2] = 2 * (x * z + y * w); \
+    R_.a[3] = 2 * (x * y + z * w);     R_.a[4] = 1 - 2 * (x * x + z * z); R_.a[5] = 2 * (y * z - x * w); \
+    R_.a[6] = 2 * (x * z - y * w);     R_.a[7] = 2 * (y * z + x * w);     R_.a[8] = 1 - 2 * (x * x + y * y); } while (0)
   const T bm = model->base_m;
   const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
   S3<T> bI;
   bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
   bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
-
-  // ------------------------------------------------------------------ forward sweep down the leg
-  M3<T> E[3];
-  V3<T> om[3], vv[3];
-  SF<T> frc[3];   // RNEA body force  I a + v x* I v
-  SF<T> mom[3];   // body momentum    I v                 (OBS)
-  SF<T> grv[3];   // gravity-only body force              (OBS)
+  // the base body's own wrench / momentum / weight are formed now, so that om0, v0, aL0 die after joint 0
+  constexpr int PW = OBS ? 33 : 15;        // parked words per joint
+  constexpr int PB = OBS ? 18 : 6;         // parked words of the base body (wrench, momentum, weight)
+  __shared__ T park[2 * PW + PB][BLOCK];
+  const int ln = threadIdx.x;
+  V3<T> omp, vp, aAp, aLp, gLp;
   {
-    V3<T> omp = om0, vp = v0, aAp = mk<T>(0, 0, 0), aLp = aL0, gLp = gneg;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int o = JOINT_WORDS * k;
-      T sn, cs;
-      sincos_t(ql[k], &sn, &cs);
-#pragma unroll
-      for (int e = 0; e < 9; ++e) E[k].a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
-      const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
-      const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
-      const T m = CS(o + 33);
-      const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
-      S3<T> Io;
-      Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
-      const T qd = vl[k];
-      om[k] = tmul(E[k], omp) + ax * qd;
-      vv[k] = tmul(E[k], vp + cross(omp, r));
-      const V3<T> aA = tmul(E[k], aAp) + cross(om[k], ax) * qd;
-      const V3<T> aL = tmul(E[k], aLp + cross(aAp, r)) + cross(vv[k], ax) * qd;
-      const SF<T> Iv = inertia_mul(m, h, Io, om[k], vv[k]);
-      const SF<T> Ia = inertia_mul(m, h, Io, aA, aL);
-      frc[k].n = Ia.n + cross(om[k], Iv.n) + cross(vv[k], Iv.f);
-      frc[k].f = Ia.f + cross(om[k], Iv.f);
-      if (OBS) {
-        mom[k] = Iv;
-        const V3<T> gL = tmul(E[k], gLp);  // angular part stays zero
-        grv[k].n = cross(h, gL);
-        grv[k].f = gL * m;
-        gLp = gL;
-      }
-      omp = om[k]; vp = vv[k]; aAp = aA; aLp = aL;
+    M3<T> R;
+    MAKE_R(R);
+    SF<T> bw, bmom, bgrv;
+    const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
+    const V3<T> v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
+    const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));  // R^T (-g)
+    const V3<T> aL0 = gneg - cross(om0, v0);  // bias pass: vdot = 0, gravity folded in
+    const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+    const SF<T> Ia0 = inertia_mul(bm, bh, bI, mk<T>(0, 0, 0), aL0);
+    bw.n = Ia0.n + cross(om0, Iv0.n) + cross(v0, Iv0.f);
+    bw.f = Ia0.f + cross(om0, Iv0.f);
+    T* pb = &park[2 * PW][ln];
+    pb[0] = bw.n.x; pb[BLOCK] = bw.n.y; pb[BLOCK * 2] = bw.n.z; pb[BLOCK * 3] = bw.f.x; pb[BLOCK * 4] = bw.f.y; pb[BLOCK * 5] = bw.f.z;
+    if (OBS) {
+      bmom = Iv0; bgrv.n = cross(bh, gneg); bgrv.f = gneg * bm;
+      pb[BLOCK * 6] = bmom.n.x; pb[BLOCK * 7] = bmom.n.y; pb[BLOCK * 8] = bmom.n.z; pb[BLOCK * 9] = bmom.f.x; pb[BLOCK * 10] = bmom.f.y; pb[BLOCK * 11] = bmom.f.z;
+      pb[BLOCK * 12] = bgrv.n.x; pb[BLOCK * 13] = bgrv.n.y; pb[BLOCK * 14] = bgrv.n.z; pb[BLOCK * 15] = bgrv.f.x; pb[BLOCK * 16] = bgrv.f.y; pb[BLOCK * 17] = bgrv.f.z;
     }
+    omp = om0; vp = v0; aAp = mk<T>(0, 0, 0); aLp = aL0; gLp = gneg;
   }
 
-  // ------------------------------------------------------------------ backward sweep up the leg
-  T h_leg[3], p_leg[3], ct_leg[3], g_leg[3];
-  T Mll[3][3];          // leg block (upper part used)
-  V3<T> Mbl_f[3], Mbl_n[3];  // base-leg columns in BASE coordinates (force, moment)
-  // composite inertia of the subtree rooted at joint k, in frame k
-  T cm; V3<T> ch; S3<T> cI;
-  // foot Jacobian columns, progressively rotated towards the base frame
-  V3<T> dft = mk<T>(CS(129), CS(130), CS(131));
-  V3<T> jc[3];
+  // ------------------------------------------------------------------ forward sweep down the leg
+  // Per-joint results that the return sweep needs (E, body force, and for the observer the body
+  // momentum, weight and velocity) are PARKED IN LDS for joints 0 and 1 ([word][lane]: conflict-free),
+  // which keeps the kernel at two waves per SIMD without scratch; joint 2's stay in registers.
+  M3<T> E2;
+  SF<T> f2, m2, g2;
+  V3<T> om2, vv2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int o = JOINT_WORDS * k;
+    T sn, cs;
+    sincos_t(ql[k], &sn, &cs);
+    M3<T> E;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+    const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
+    const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
+    const T m = CS(o + 33);
+    const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
+    S3<T> Io;
+    Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
+    const T qd = vl[k];
+    const V3<T> om = tmul(E, omp) + ax * qd;
+    const V3<T> vv = tmul(E, vp + cross(omp, r));
+    const V3<T> aA = tmul(E, aAp) + cross(om, ax) * qd;
+    const V3<T> aL = tmul(E, aLp + cross(aAp, r)) + cross(vv, ax) * qd;
+    const SF<T> Iv = inertia_mul(m, h, Io, om, vv);
+    const SF<T> Ia = inertia_mul(m, h, Io, aA, aL);
+    SF<T> fk, gk;
+    fk.n = Ia.n + cross(om, Iv.n) + cross(vv, Iv.f);
+    fk.f = Ia.f + cross(om, Iv.f);
+    if (OBS) {
+      const V3<T> gL = tmul(E, gLp);  // angular part of the gravity-only acceleration stays zero
+      gk.n = cross(h, gL);
+      gk.f = gL * m;
+      gLp = gL;
+    }
+    if (k < 2) {
+      T* pk = &park[PW * k][ln];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) pk[BLOCK * e] = E.a[e];
+      pk[BLOCK * 9] = fk.n.x; pk[BLOCK * 10] = fk.n.y; pk[BLOCK * 11] = fk.n.z;
+      pk[BLOCK * 12] = fk.f.x; pk[BLOCK * 13] = fk.f.y; pk[BLOCK * 14] = fk.f.z;
+      if (OBS) {
+        pk[BLOCK * 15] = Iv.n.x; pk[BLOCK * 16] = Iv.n.y; pk[BLOCK * 17] = Iv.n.z; pk[BLOCK * 18] = Iv.f.x; pk[BLOCK * 19] = Iv.f.y; pk[BLOCK * 20] = Iv.f.z;
+        pk[BLOCK * 21] = gk.n.x; pk[BLOCK * 22] = gk.n.y; pk[BLOCK * 23] = gk.n.z; pk[BLOCK * 24] = gk.f.x; pk[BLOCK * 25] = gk.f.y; pk[BLOCK * 26] = gk.f.z;
+        pk[BLOCK * 27] = om.x; pk[BLOCK * 28] = om.y; pk[BLOCK * 29] = om.z; pk[BLOCK * 30] = vv.x; pk[BLOCK * 31] = vv.y; pk[BLOCK * 32] = vv.z;
+      }
+    } else {
+      E2 = E; f2 = fk;
+      if (OBS) { m2 = Iv; g2 = gk; om2 = om; vv2 = vv; }
+    }
+    omp = om; vp = vv; aAp = aA; aLp = aL;
+  }
+
+  // ------------------------------------------------------------------ return sweep up the leg
+  T al[3] = {0, 0, 0};
+  if (STEP) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      al[k] = *(const T*)((const char*)(a.vdot_des + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+  }
+  T p_leg[3], ct_leg[3], g_leg[3];
+  T taup[3] = {0, 0, 0};  // (M vdot_des) joint rows of this leg, accumulated as M entries appear
+  T cm; V3<T> ch; S3<T> cI;  // composite inertia of the subtree rooted at joint k, in frame k
+  V3<T> dft = mk<T>(CS(129), CS(130), CS(131));  // foot relative to the current frame origin
+  V3<T> jc[3];                                   // foot Jacobian columns, rotated progressively towards the base
+  SF<T> Fp[3];                                   // CRBA force columns of joints >= k, carried frame by frame
+  SF<T> facc, macc, gacc;                        // children's wrench / momentum / weight in the current frame
 #pragma unroll
   for (int k = 2; k >= 0; --k) {
     const int o = JOINT_WORDS * k;
@@ -225,12 +317,34 @@ __global__ __launch_bounds__(64) void dyn_sweep_kernel(const DevModel<T>* __rest
     const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
     S3<T> Io;
     Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
-    // RNEA
-    h_leg[k] = dot(ax, frc[k].n);
+    M3<T> E;
+    SF<T> fk, mk_, gk;
+    V3<T> om, vv;
+    if (k == 2) {
+      E = E2; fk = f2;
+      if (OBS) { mk_ = m2; gk = g2; om = om2; vv = vv2; }
+    } else {
+      const T* pk = &park[PW * k][ln];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) E.a[e] = pk[BLOCK * e];
+      fk.n = mk<T>(pk[BLOCK * 9], pk[BLOCK * 10], pk[BLOCK * 11]) + facc.n;
+      fk.f = mk<T>(pk[BLOCK * 12], pk[BLOCK * 13], pk[BLOCK * 14]) + facc.f;
+      if (OBS) {
+        mk_.n = mk<T>(pk[BLOCK * 15], pk[BLOCK * 16], pk[BLOCK * 17]) + macc.n; mk_.f = mk<T>(pk[BLOCK * 18], pk[BLOCK * 19], pk[BLOCK * 20]) + macc.f;
+        gk.n = mk<T>(pk[BLOCK * 21], pk[BLOCK * 22], pk[BLOCK * 23]) + gacc.n; gk.f = mk<T>(pk[BLOCK * 24], pk[BLOCK * 25], pk[BLOCK * 26]) + gacc.f;
+        om = mk<T>(pk[BLOCK * 27], pk[BLOCK * 28], pk[BLOCK * 29]); vv = mk<T>(pk[BLOCK * 30], pk[BLOCK * 31], pk[BLOCK * 32]);
+      }
+    }
+    // RNEA / momentum / gravity projections on the joint axis
+    {
+      const T hk = dot(ax, fk.n);
+      if (MATS) STLX(a.h, 6, 0, jxN[k], hk);
+      if (STEP) taup[k] += hk;
+    }
     if (OBS) {
-      p_leg[k] = dot(ax, mom[k].n);
-      ct_leg[k] = -dot(ax, cross(om[k], mom[k].n) + cross(vv[k], mom[k].f));
-      g_leg[k] = dot(ax, grv[k].n);
+      p_leg[k] = dot(ax, mk_.n);
+      ct_leg[k] = -dot(ax, cross(om, mk_.n) + cross(vv, mk_.f));
+      g_leg[k] = dot(ax, gk.n);
     }
     // CRBA: close the composite of joint k
     if (k == 2) { cm = m; ch = h; cI = Io; }
@@ -238,38 +352,29 @@ __global__ __launch_bounds__(64) void dyn_sweep_kernel(const DevModel<T>* __rest
       cm += m; ch = ch + h;
       cI.xx += Io.xx; cI.xy += Io.xy; cI.xz += Io.xz; cI.yy += Io.yy; cI.yz += Io.yz; cI.zz += Io.zz;
     }
-    SF<T> F;
-    F.n = mul(cI, ax);
-    F.f = cross(ax, ch);
-    Mll[k][k] = dot(ax, F.n);
+    Fp[k].n = mul(cI, ax);
+    Fp[k].f = cross(ax, ch);
 #pragma unroll
-    for (int j = k; j >= 1; --j) {  // up the chain: frame j -> frame j-1
-      const int oj = JOINT_WORDS * j;
-      F = to_parent(E[j], mk<T>(CS(oj + 27), CS(oj + 28), CS(oj + 29)), F);
-      Mll[j - 1][k] = dot(mk<T>(CS(oj - JOINT_WORDS + 30), CS(oj - JOINT_WORDS + 31), CS(oj - JOINT_WORDS + 32)), F.n);
-    }
-    F = to_parent(E[0], mk<T>(CS(27), CS(28), CS(29)), F);
-    Mbl_f[k] = F.f; Mbl_n[k] = F.n;
-    // Jacobian column of joint k in frame k, then move everything below into frame k-1 (or base)
-    jc[k] = cross(ax, dft);
-    dft = r + mul(E[k], dft);
-#pragma unroll
-    for (int j = k; j < 3; ++j) jc[j] = mul(E[k], jc[j]);
-    // hand the accumulators to the parent frame
-    {
-      const SF<T> fp = to_parent(E[k], r, frc[k]);
-      if (k > 0) { frc[k - 1].n = frc[k - 1].n + fp.n; frc[k - 1].f = frc[k - 1].f + fp.f; } else frc[0] = fp;
-      if (OBS) {
-        const SF<T> mp = to_parent(E[k], r, mom[k]);
-        const SF<T> gp = to_parent(E[k], r, grv[k]);
-        if (k > 0) {
-          mom[k - 1].n = mom[k - 1].n + mp.n; mom[k - 1].f = mom[k - 1].f + mp.f;
-          grv[k - 1].n = grv[k - 1].n + gp.n; grv[k - 1].f = grv[k - 1].f + gp.f;
-        } else { mom[0] = mp; grv[0] = gp; }
+    for (int j = k; j < 3; ++j) {  // M[k][j] for this leg: columns j >= k are all in frame k now
+      const T mkj = dot(ax, Fp[j].n);
+      if (MATS) {
+        int i = 6 + jx[k], jj = 6 + jx[j];
+        if (i > jj) { const int t = i; i = jj; jj = t; }
+        STV(a.M, i * 18 - i * (i - 1) / 2 + (jj - i), mkj);
       }
-      // composite inertia into the parent frame
-      const V3<T> hr = mul(E[k], ch);
-      const S3<T> Ir = congr(E[k], cI);
+      if (STEP) { taup[k] += mkj * al[j]; if (j != k) taup[j] += mkj * al[k]; }
+    }
+    // Jacobian column of joint k in frame k
+    jc[k] = cross(ax, dft);
+    // move everything to the parent frame (frame k-1, or the base for k = 0)
+    dft = r + mul(E, dft);
+#pragma unroll
+    for (int j = k; j < 3; ++j) { jc[j] = mul(E, jc[j]); Fp[j] = to_parent(E, r, Fp[j]); }
+    facc = to_parent(E, r, fk);
+    if (OBS) { macc = to_parent(E, r, mk_); gacc = to_parent(E, r, gk); }
+    {
+      const V3<T> hr = mul(E, ch);
+      const S3<T> Ir = congr(E, cI);
       const V3<T> w = hr + r * (cm * (T)0.5);
       const T sc = 2 * dot(w, r);
       cI.xx = Ir.xx + sc - 2 * w.x * r.x;
@@ -281,122 +386,101 @@ __global__ __launch_bounds__(64) void dyn_sweep_kernel(const DevModel<T>* __rest
       ch = hr + r * cm;
     }
   }
-  // now: frc[0] (and mom[0], grv[0]) = leg wrench at the base, base coords; (cm,ch,cI) = leg composite
-  // in base coords; dft = foot relative to base origin in base coords; jc[] in base coords.
-
-  // ------------------------------------------------------------------ quad reductions into the base
-  SF<T> bf;  // total bias wrench on the base, base coords
+  // now: facc (macc, gacc) = leg wrench at the base, base coords; (cm,ch,cI) = leg composite in base
+  // coords; dft = foot relative to base origin in base coords; jc[], Fp[] in base coords.
+  M3<T> R;
+  MAKE_R(R);
+  const V3<T> dw = mul(R, dft);
+  V3<T> jw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) jw[k] = mul(R, jc[k]);
   {
-    const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
-    const SF<T> Ia0 = inertia_mul(bm, bh, bI, mk<T>(0, 0, 0), aL0);
-    bf.n = quad_sum(frc[0].n) + Ia0.n + cross(om0, Iv0.n) + cross(v0, Iv0.f);
-    bf.f = quad_sum(frc[0].f) + Ia0.f + cross(om0, Iv0.f);
-    if (OBS) {
-      mom[0].n = quad_sum(mom[0].n) + Iv0.n;
-      mom[0].f = quad_sum(mom[0].f) + Iv0.f;
-      grv[0].n = quad_sum(grv[0].n) + cross(bh, gneg);
-      grv[0].f = quad_sum(grv[0].f) + gneg * bm;
+    T ad[6] = {0, 0, 0, 0, 0, 0};
+    if (STEP) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const V3<T> Mf = mul(R, Fp[k].f), Mn = mul(R, Fp[k].n);  // base-leg column, world axes
+      if (MATS) {
+        const unsigned x = jxN[k];
+        STLX(a.M, 6, 0, x, Mf.x);                       // midx18(0, 6+j) = 6 + j
+        STLX(a.M, midx18(1, 1) + 5, 0, x, Mf.y);        // midx18(r, 6+j) = midx18(r,r) + 6 - r + j
+        STLX(a.M, midx18(2, 2) + 4, 0, x, Mf.z);
+        STLX(a.M, midx18(3, 3) + 3, 0, x, Mn.x);
+        STLX(a.M, midx18(4, 4) + 2, 0, x, Mn.y);
+        STLX(a.M, midx18(5, 5) + 1, 0, x, Mn.z);
+      }
+      if (STEP) taup[k] += Mf.x * ad[0] + Mf.y * ad[1] + Mf.z * ad[2] + Mn.x * ad[3] + Mn.y * ad[4] + Mn.z * ad[5];
     }
   }
-  const V3<T> hb_f = mul(R, bf.f), hb_n = mul(R, bf.n);  // h base rows (force, moment), world
-  const T tm = quad_sum(cm) + bm;
-  const V3<T> th = quad_sum(ch) + bh;
-  S3<T> tI;
-  tI.xx = quad_sum(cI.xx) + bI.xx; tI.xy = quad_sum(cI.xy) + bI.xy; tI.xz = quad_sum(cI.xz) + bI.xz;
-  tI.yy = quad_sum(cI.yy) + bI.yy; tI.yz = quad_sum(cI.yz) + bI.yz; tI.zz = quad_sum(cI.zz) + bI.zz;
-  const V3<T> hw = mul(R, th);
-  const S3<T> Iw = congr(R, tI);
-  // world-frame leg quantities
-  const V3<T> dw = mul(R, dft);
-  V3<T> jw[3], Mf[3], Mn[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { jw[k] = mul(R, jc[k]); Mf[k] = mul(R, Mbl_f[k]); Mn[k] = mul(R, Mbl_n[k]); }
-  Mll[1][0] = Mll[0][1]; Mll[2][0] = Mll[0][2]; Mll[2][1] = Mll[1][2];
-
-#define ST(ptr, comp, val) do { if (live) (ptr)[(size_t)(comp) * N + s] = (val); } while (0)
-  // store four base-replicated values, one per lane of the quad
-#define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) \
-  ST(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
-
-  // ------------------------------------------------------------------ M, h, Jc, pf
   if (MATS) {
-    T* M = a.M;
-    // base 6x6 block, 21 unique entries (rows/cols 0..5)
-    const T Z = (T)0;
-    ST4(M, midx18(0, 0), tm, midx18(0, 1), Z, midx18(0, 2), Z, midx18(0, 3), Z);
-    ST4(M, midx18(0, 4), hw.z, midx18(0, 5), -hw.y, midx18(1, 1), tm, midx18(1, 2), Z);
-    ST4(M, midx18(1, 3), -hw.z, midx18(1, 4), Z, midx18(1, 5), hw.x, midx18(2, 2), tm);
-    ST4(M, midx18(2, 3), hw.y, midx18(2, 4), -hw.x, midx18(2, 5), Z, midx18(3, 3), Iw.xx);
-    ST4(M, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz, midx18(4, 4), Iw.yy, midx18(4, 5), Iw.yz);
-    if (leg == 0) ST(M, midx18(5, 5), Iw.zz);
-    // base-leg block: rows 0..5, cols 6+jx[k]
+    // Jc rows of this lane's foot, (3*leg+m)*18 + c: base rotational block and own-leg columns
+    STL(a.Jc, 0 * 18 + 4, 54, dw.z);  STL(a.Jc, 0 * 18 + 5, 54, -dw.y);
+    STL(a.Jc, 1 * 18 + 3, 54, -dw.z); STL(a.Jc, 1 * 18 + 5, 54, dw.x);
+    STL(a.Jc, 2 * 18 + 3, 54, dw.y);  STL(a.Jc, 2 * 18 + 4, 54, -dw.x);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int c = 6 + jx[k];
-      ST(M, 0 * 18 - 0 + c, Mf[k].x);          // midx18(0,c) = c
-      ST(M, midx18(1, 1) + (c - 1), Mf[k].y);
-      ST(M, midx18(2, 2) + (c - 2), Mf[k].z);
-      ST(M, midx18(3, 3) + (c - 3), Mn[k].x);
-      ST(M, midx18(4, 4) + (c - 4), Mn[k].y);
-      ST(M, midx18(5, 5) + (c - 5), Mn[k].z);
-    }
-    // leg block (upper triangle in the caller's joint order)
-#pragma unroll
-    for (int k1 = 0; k1 < 3; ++k1)
-#pragma unroll
-      for (int k2 = k1; k2 < 3; ++k2) {
-        int i = 6 + jx[k1], j = 6 + jx[k2];
-        if (i > j) { int t = i; i = j; j = t; }
-        ST(M, i * 18 - i * (i - 1) / 2 + (j - i), Mll[k1][k2]);
-      }
-    // structural zeros between different legs: 6 leg pairs x 9 = 54 entries, 14 per lane
-    for (int e = leg; e < 54; e += 4) {
-      const int pr = e / 9, rem = e - 9 * pr, ka = rem / 3, kb = rem - 3 * ka;
-      // pair table {01,02,03,12,13,23}
-      const int l1 = pr < 3 ? 0 : (pr < 5 ? 1 : 2);
-      const int l2 = pr < 3 ? pr + 1 : (pr < 5 ? pr - 1 : 3);
-      int i = 6 + model->jidx[l1][ka], j = 6 + model->jidx[l2][kb];
-      if (i > j) { int t = i; i = j; j = t; }
-      ST(M, i * 18 - i * (i - 1) / 2 + (j - i), Z);
-    }
-    // h
-    T* H = a.h;
-    ST4(H, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
-    if (leg < 2) ST(H, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ST(H, 6 + jx[k], h_leg[k]);
-    // Jc rows of this lane's foot: (3*leg+m)*18 + c
-    T* J = a.Jc;
-    const T ONE = (T)1;
-    const T jb[3][6] = {{ONE, Z, Z, Z, dw.z, -dw.y}, {Z, ONE, Z, -dw.z, Z, dw.x}, {Z, Z, ONE, dw.y, -dw.x, Z}};
-#pragma unroll
-    for (int mrow = 0; mrow < 3; ++mrow) {
-      const int rb = (3 * leg + mrow) * 18;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) ST(J, rb + c, jb[mrow][c]);
-#pragma unroll
-      for (int c = 0; c < 12; ++c) ST(J, rb + 6 + c, Z);
-    }
-    // own-leg columns overwrite the zeros (same lane, program order)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      ST(J, (3 * leg + 0) * 18 + 6 + jx[k], jw[k].x);
-      ST(J, (3 * leg + 1) * 18 + 6 + jx[k], jw[k].y);
-      ST(J, (3 * leg + 2) * 18 + 6 + jx[k], jw[k].z);
+    for (int k = 0; k < 3; ++k) {  // overwrite the zeros written above (same lane, same address: program order)
+      STLX(a.Jc, 0 * 18 + 6, 54, jxN[k], jw[k].x);
+      STLX(a.Jc, 1 * 18 + 6, 54, jxN[k], jw[k].y);
+      STLX(a.Jc, 2 * 18 + 6, 54, jxN[k], jw[k].z);
     }
   }
   if (a.pf) {
-    ST(a.pf, 3 * leg + 0, qb[0] + dw.x);
-    ST(a.pf, 3 * leg + 1, qb[1] + dw.y);
-    ST(a.pf, 3 * leg + 2, qb[2] + dw.z);
+    STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
+    STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
+    STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
+  }
+  if (STEP) {
+    STL(a.ws, WS_D + 0, 3, dw.x);
+    STL(a.ws, WS_D + 1, 3, dw.y);
+    STL(a.ws, WS_D + 2, 3, dw.z);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      STL(a.ws, WS_JCL + 0 + k, 9, jw[k].x);
+      STL(a.ws, WS_JCL + 3 + k, 9, jw[k].y);
+      STL(a.ws, WS_JCL + 6 + k, 9, jw[k].z);
+    }
+  }
+
+  // ------------------------------------------------------------------ quad reductions into the base
+  if (MATS) {
+    const T* pb = &park[2 * PW][ln];
+    const V3<T> bfn = quad_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);   // total bias wrench, base coords
+    const V3<T> bff = quad_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
+    const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);  // h base rows (force, moment), world
+    ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
+    if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
+    const T tm = quad_sum(cm) + bm;
+    const V3<T> th = quad_sum(ch) + bh;
+    S3<T> tI;
+    tI.xx = quad_sum(cI.xx) + bI.xx; tI.xy = quad_sum(cI.xy) + bI.xy; tI.xz = quad_sum(cI.xz) + bI.xz;
+    tI.yy = quad_sum(cI.yy) + bI.yy; tI.yz = quad_sum(cI.yz) + bI.yz; tI.zz = quad_sum(cI.zz) + bI.zz;
+    const V3<T> hw = mul(R, th);
+    const S3<T> Iw = congr(R, tI);
+    // base 6x6 block: 15 data-dependent entries (the 6 structural zeros went out with the early stores)
+    T* M = a.M;
+    ST4(M, midx18(0, 0), tm, midx18(1, 1), tm, midx18(2, 2), tm, midx18(0, 4), hw.z);
+    ST4(M, midx18(0, 5), -hw.y, midx18(1, 3), -hw.z, midx18(1, 5), hw.x, midx18(2, 3), hw.y);
+    ST4(M, midx18(2, 4), -hw.x, midx18(3, 3), Iw.xx, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz);
+    if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
+  }
+  SF<T> mom0, grv0;
+  if (OBS) {
+    const T* pb = &park[2 * PW][ln];
+    mom0.n = quad_sum(macc.n) + mk<T>(pb[BLOCK * 6], pb[BLOCK * 7], pb[BLOCK * 8]);
+    mom0.f = quad_sum(macc.f) + mk<T>(pb[BLOCK * 9], pb[BLOCK * 10], pb[BLOCK * 11]);
+    grv0.n = quad_sum(gacc.n) + mk<T>(pb[BLOCK * 12], pb[BLOCK * 13], pb[BLOCK * 14]);
+    grv0.f = quad_sum(gacc.f) + mk<T>(pb[BLOCK * 15], pb[BLOCK * 16], pb[BLOCK * 17]);
   }
 
   // ------------------------------------------------------------------ momentum, beta = C^T v - g
   T p_b[6], beta_b[6], beta_l[3];
   if (OBS) {
-    const V3<T> Pl = mul(R, mom[0].f), Pa = mul(R, mom[0].n);
-    const V3<T> gl = mul(R, grv[0].f), ga = mul(R, grv[0].n);
-    const V3<T> cx = cross(vlin_w, Pl);
+    const V3<T> Pl = mul(R, mom0.f), Pa = mul(R, mom0.n);
+    const V3<T> gl = mul(R, grv0.f), ga = mul(R, grv0.n);
+    const V3<T> cx = cross(mk<T>(LDU(a.v, 0), LDU(a.v, 1), LDU(a.v, 2)), Pl);
     p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
     beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
     beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
@@ -404,15 +488,15 @@ __global__ __launch_bounds__(64) void dyn_sweep_kernel(const DevModel<T>* __rest
     for (int k = 0; k < 3; ++k) beta_l[k] = ct_leg[k] - g_leg[k];
     if (a.p) {
       ST4(a.p, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
-      if (leg < 2) ST(a.p, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      if (leg < 2) STV(a.p, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) ST(a.p, 6 + jx[k], p_leg[k]);
+      for (int k = 0; k < 3; ++k) STLX(a.p, 6, 0, jxN[k], p_leg[k]);
     }
     if (a.beta) {
       ST4(a.beta, 0, beta_b[0], 1, beta_b[1], 2, beta_b[2], 3, beta_b[3]);
-      if (leg < 2) ST(a.beta, 4 + leg, leg == 0 ? beta_b[4] : beta_b[5]);
+      if (leg < 2) STV(a.beta, 4 + leg, leg == 0 ? beta_b[4] : beta_b[5]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) ST(a.beta, 6 + jx[k], beta_l[k]);
+      for (int k = 0; k < 3; ++k) STLX(a.beta, 6, 0, jxN[k], beta_l[k]);
     }
   }
 
@@ -421,8 +505,7 @@ __global__ __launch_bounds__(64) void dyn_sweep_kernel(const DevModel<T>* __rest
     T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
     if (OBS && prm.observer_order > 0) {
       // generalized force of the previous commands at the current configuration
-      const V3<T> fp = mk<T>(a.f_prev[(size_t)(3 * leg + 0) * N + s], a.f_prev[(size_t)(3 * leg + 1) * N + s],
-                             a.f_prev[(size_t)(3 * leg + 2) * N + s]);
+      const V3<T> fp = mk<T>(LDV(a.f_prev, 3 * leg + 0), LDV(a.f_prev, 3 * leg + 1), LDV(a.f_prev, 3 * leg + 2));
       const V3<T> ub_f = quad_sum(fp);
       const V3<T> ub_n = quad_sum(cross(dw, fp));
       const T ub[6] = {ub_f.x, ub_f.y, ub_f.z, ub_n.x, ub_n.y, ub_n.z};
@@ -430,63 +513,49 @@ __global__ __launch_bounds__(64) void dyn_sweep_kernel(const DevModel<T>* __rest
       const bool o1 = prm.observer_order == 1;
 #pragma unroll
       for (int c = 0; c < 6; ++c) {  // replicated over the quad (same values in all four lanes)
-        const T r0 = a.obs_r[(size_t)c * N + s];
-        const T ig = a.obs_integ[(size_t)c * N + s] + dt * (ub[c] + beta_b[c] + r0);
+        const T r0 = LDU(a.obs_r, c);
+        const T ig = LDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
         const T e = p_b[c] - ig;
         rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
         p_b[c] = ig;  // reuse as the new integ for the store below
       }
-      // all loads of the replicated rows are done in every lane before any lane stores them
+      // every lane's loads of the replicated rows feed its own store values, so all loads of a row have
+      // returned in every lane of the wave before any lane can store to it
       ST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
-      if (leg < 2) ST(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      if (leg < 2) STV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
       ST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
-      if (leg < 2) ST(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+      if (leg < 2) STV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = 6 + jx[k];
-        const T r0 = a.obs_r[(size_t)c * N + s];
-        const T u = a.tau_prev[(size_t)jx[k] * N + s] + dot(jw[k], fp);
-        const T ig = a.obs_integ[(size_t)c * N + s] + dt * (u + beta_l[k] + r0);
+        const T r0 = LDV(a.obs_r, c);
+        const T u = LDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
+        const T ig = LDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
         const T e = p_leg[k] - ig;
         rl[k] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
-        ST(a.obs_integ, c, ig);
-        ST(a.obs_r, c, rl[k]);
+        STV(a.obs_integ, c, ig);
+        STV(a.obs_r, c, rl[k]);
       }
     }
     T* ws = a.ws;
-    ST(ws, WS_D + 3 * leg + 0, dw.x);
-    ST(ws, WS_D + 3 * leg + 1, dw.y);
-    ST(ws, WS_D + 3 * leg + 2, dw.z);
-    {
+    if (OBS) {
       T b[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) b[c] = a.w_des[(size_t)c * N + s] - rb[c];
+      for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
       ST4(ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
-      if (leg < 2) ST(ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
-    }
-    {
-      T ad[6], al[3];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) ad[c] = a.vdot_des[(size_t)c * N + s];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) al[k] = a.vdot_des[(size_t)(6 + jx[k]) * N + s];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        T t = h_leg[k] - rl[k];
-        t += Mf[k].x * ad[0] + Mf[k].y * ad[1] + Mf[k].z * ad[2] + Mn[k].x * ad[3] + Mn[k].y * ad[4] + Mn[k].z * ad[5];
-        t += Mll[k][0] * al[0] + Mll[k][1] * al[1] + Mll[k][2] * al[2];
-        ST(ws, WS_TAUP + 3 * leg + k, t);
-      }
+      if (leg < 2) STV(ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      ST(ws, WS_JCL + 9 * leg + 0 + k, jw[k].x);
-      ST(ws, WS_JCL + 9 * leg + 3 + k, jw[k].y);
-      ST(ws, WS_JCL + 9 * leg + 6 + k, jw[k].z);
-    }
+    for (int k = 0; k < 3; ++k) STL(ws, WS_TAUP + k, 3, taup[k] - rl[k]);
   }
+#undef MAKE_R
 #undef ST4
-#undef ST
+#undef STLX
+#undef STL
+#undef STV
+#undef STU
+#undef LDV
+#undef LDU
 #undef CS
 }
 

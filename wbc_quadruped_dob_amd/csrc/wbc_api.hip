@@ -195,6 +195,16 @@ template <class T> static void build_dev_model(const FlatModel& f, const int leg
                         I[3] + m * (cc - c[1] * c[1]), I[4] - m * c[1] * c[2], I[5] + m * (cc - c[2] * c[2])};
   for (int e = 0; e < 6; ++e) d.base_Io[e] = (T)Io[e];
   for (int e = 0; e < 3; ++e) d.grav[e] = (T)f.gravity[e];
+  // structural zeros of the packed mass matrix
+  int nz = 0;
+  auto mi = [](int i, int j) { if (i > j) { int t = i; i = j; j = t; } return i * 18 - i * (i - 1) / 2 + (j - i); };
+  for (int l1 = 0; l1 < 4; ++l1)
+    for (int l2 = l1 + 1; l2 < 4; ++l2)
+      for (int ka = 0; ka < 3; ++ka)
+        for (int kb = 0; kb < 3; ++kb) d.zidx[nz++] = mi(6 + d.jidx[l1][ka], 6 + d.jidx[l2][kb]);
+  const int bz[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 4}, {2, 5}};
+  for (auto& e : bz) d.zidx[nz++] = mi(e[0], e[1]);
+  for (; nz < 64; ++nz) d.zidx[nz] = -1;
 }
 
 template <class T> static DevParams<T> to_dev_params(const wbc_params& p) {
@@ -221,6 +231,8 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
                                  wbc_solver** out) {
   if (!m || !out || max_batch == 0 || (dtype != WBC_F64 && dtype != WBC_F32)) return fail(WBC_E_INVALID, "bad argument");
   *out = nullptr;
+  if (max_batch > ((size_t)1 << 21))  // keeps every component-major array below 4 GiB (32-bit lane offsets)
+    return fail(WBC_E_CAPACITY, "max_batch above 2^21 states per solver: shard the batch over more solvers");
   int rc = check_params(p);
   if (rc) return rc;
   int leg_body[4][3];
@@ -337,9 +349,19 @@ extern "C" int wbc_solver_collect_timing(wbc_solver* s, double* dyn_ms, int* dyn
 template <class T, int MODE>
 static hipError_t launch_sweep(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
   const size_t threads = a.N * 4;
-  const unsigned blocks = (unsigned)((threads + 63) / 64);
-  hipLaunchKernelGGL((dyn_sweep_kernel<T, MODE>), dim3(blocks), dim3(64), 0, st, (const DevModel<T>*)s->d_model,
-                     to_dev_params<T>(s->params), a);
+  if constexpr ((MODE & SW_OBS) == 0) {  // the observer variants park too much per wave for 256-thread workgroups
+    if (threads >= (size_t)256 * 8 * 64 * 2) {  // enough work for two full rounds of 8 waves per CU: share the tables
+      const unsigned blocks = (unsigned)((threads + 255) / 256);
+      hipLaunchKernelGGL((dyn_sweep_kernel<T, MODE, 256>), dim3(blocks), dim3(256), 0, st,
+                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
+      return hipGetLastError();
+    }
+  }
+  {
+    const unsigned blocks = (unsigned)((threads + 63) / 64);
+    hipLaunchKernelGGL((dyn_sweep_kernel<T, MODE, 64>), dim3(blocks), dim3(64), 0, st, (const DevModel<T>*)s->d_model,
+                       to_dev_params<T>(s->params), a);
+  }
   return hipGetLastError();
 }
 
