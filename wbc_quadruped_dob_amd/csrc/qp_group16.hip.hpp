@@ -1,0 +1,416 @@
+// GRF QP + torque map kernel for gfx950, register/DPP-resident: SURVEY.md 8(a) units a7, a8, a9.
+//
+// Mapping: ONE QP PER 16-LANE DPP ROW, four QPs per wavefront.  A CDNA DPP "row" is 16 lanes, and
+// row_newbcast / row_mirror / row_half_mirror / quad_perm move data inside a row at VALU speed without
+// touching LDS -- so the 12x12 factors of the Goldfarb-Idnani method live entirely in VGPRs:
+//   lane 4f+a (a<3) of a row owns variable (foot f, axis a); lane 4f+3 is a spare that carries constraints
+//   Jc[12] = column `me` of J,  Jr[12] = row `me` of J,  Rr[12] = row `me` of R   (static register indices)
+// Products with J^T use the column copy, products with J use the row copy, the rank-one Householder update
+// of an added constraint touches both; every cross-lane operand is a row broadcast (2 DPP movs per double).
+// All four feet are always variables (swing feet decouple: H_ii = alpha, g_i = 0 => f = 0), so there is no
+// per-QP dimension and no dynamic register index; per-QP control flow is predication, wave-level control
+// flow is a ballot.  Dropping a constraint (rare) restores J from a copy of J0 = L^-T kept in LDS and
+// re-adds the remaining active constraints -- no Givens chain.  LDS is used only for that copy and for the
+// one transposition that derives the row copy of J0 from the column copy.
+//
+// Same algorithm and tolerances as the CPU oracle (dual active set; "no primal step" and "new diagonal"
+// share |d2|); iterates differ from the oracle's only by orthogonal transformations of the free columns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "device_types.hpp"
+#include "qp_wave.hip.hpp"  // Lim<>, QpJidx, sqrt_t/fabs_t
+
+namespace wbc {
+
+template <int I, int N, class F> WBC_DEV void sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+template <int I, int N, class F> WBC_DEV void sfor_down(F&& f) {  // I = N-1 ... 0
+  if constexpr (N > 0) { f(std::integral_constant<int, N - 1>{}); sfor_down<I, N - 1>(f); }
+}
+
+template <int CTRL> WBC_DEV float dppx(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> WBC_DEV double dppx(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> WBC_DEV int dppx(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false); }
+
+constexpr int LJ(int j) { return j + j / 3; }  // lane (within the row) of variable j
+// broadcast the value held by variable j's lane to the whole row
+template <int J, class T> WBC_DEV T gbc(T x) { return dppx<0x150 + LJ(J)>(x); }
+// all-reduce over the 16 lanes of a row: xor-1, xor-2 inside quads, then half-row and row mirrors
+template <class T> WBC_DEV T gsum(T x) {
+  x += dppx<0xB1>(x); x += dppx<0x4E>(x); x += dppx<0x141>(x); x += dppx<0x140>(x);
+  return x;
+}
+template <class T> WBC_DEV void gargmin_step(T& v, int& id, T ov, int oi) {
+  const bool take = (ov < v) || (ov == v && oi < id);
+  v = take ? ov : v;
+  id = take ? oi : id;
+}
+template <class T> WBC_DEV void gargmin(T& v, int& id) {
+  gargmin_step(v, id, dppx<0xB1>(v), dppx<0xB1>(id));
+  gargmin_step(v, id, dppx<0x4E>(v), dppx<0x4E>(id));
+  gargmin_step(v, id, dppx<0x141>(v), dppx<0x141>(id));
+  gargmin_step(v, id, dppx<0x140>(v), dppx<0x140>(id));
+}
+// read from a run-time lane of my own row
+template <class T> WBC_DEV T gread(T x, int lane16) { return __shfl(x, (int)((threadIdx.x & 48) | lane16)); }
+
+WBC_DEV double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0); y = fma(0.5 * y, e, y);
+  e = fma(-x * y, y, 1.0); y = fma(0.5 * y, e, y);
+  return y;
+}
+WBC_DEV float rsqrt_nr(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  float e = fmaf(-x * y, y, 1.0f); y = fmaf(0.5f * y, e, y);
+  return y;
+}
+WBC_DEV double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0); y = fma(y, e, y);
+  e = fma(-x, y, 1.0); y = fma(y, e, y);
+  return y;
+}
+WBC_DEV float rcp_nr(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  float e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);
+  return y;
+}
+
+template <class T> struct G16Lds { T J0[4][144]; };  // per wave: four 12x12 images of J0, [i*12 + c]
+
+template <class T>
+__global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+  __shared__ G16Lds<T> lds_all[4];
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15;
+  const int grp = lane >> 4;
+  const int f = l16 >> 2, c3 = l16 & 3;
+  const bool isvar = c3 < 3;
+  const int v = 3 * f + (isvar ? c3 : 0);  // variable index of this lane (spare lanes: unused)
+  T* J0 = lds_all[threadIdx.x >> 6].J0[grp];
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  const size_t qp_raw = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool live = qp_raw < N;
+  const unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
+  const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
+#define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define GST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
+
+  // ------------------------------------------------------------------ inputs
+  const int mask = a.mask[s32] & 0xF;
+  const bool on = (mask >> f) & 1;
+  const T d_me = isvar ? GLD(a.ws, WS_D + v) : (T)0;
+  const T b_ld = (l16 < 6) ? GLD(a.ws, WS_B + l16) : (T)0;
+  const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
+  const T mu_f = GLD(a.mu, f);
+  const T taup = isvar ? GLD(a.ws, WS_TAUP + v) : (T)0;
+  T jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
+  if (isvar) { jl0 = GLD(a.ws, WS_JCL + 9 * f + 0 + c3); jl1 = GLD(a.ws, WS_JCL + 9 * f + 3 + c3); jl2 = GLD(a.ws, WS_JCL + 9 * f + 6 + c3); }
+  T b[6];
+  b[0] = dppx<0x150 + 0>(b_ld); b[1] = dppx<0x150 + 1>(b_ld); b[2] = dppx<0x150 + 2>(b_ld);
+  b[3] = dppx<0x150 + 3>(b_ld); b[4] = dppx<0x150 + 4>(b_ld); b[5] = dppx<0x150 + 5>(b_ld);
+
+  // ------------------------------------------------------------------ H row (a7) : H = A^T S A + alpha I
+  // A = [I ; [d_f]x] per stance foot.  u = column c3 of [d_f]x for my own foot; w_j likewise for column j.
+  const T dqx = dppx<0x00>(d_me), dqy = dppx<0x55>(d_me), dqz = dppx<0xAA>(d_me);  // quad_perm [0000],[1111],[2222]
+  const T onf = on ? (T)1 : (T)0;
+  T u0, u1, u2;  // [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]] column c3
+  u0 = (c3 == 0) ? (T)0 : (c3 == 1 ? -dqz : dqy);
+  u1 = (c3 == 0) ? dqz : (c3 == 1 ? (T)0 : -dqx);
+  u2 = (c3 == 0) ? -dqy : (c3 == 1 ? dqx : (T)0);
+  u0 *= onf * prm.S[3]; u1 *= onf * prm.S[4]; u2 *= onf * prm.S[5];  // fold S(3..5) and the stance flag in
+  const T Sme = (c3 == 0 ? prm.S[0] : (c3 == 1 ? prm.S[1] : prm.S[2])) * onf;
+  T Hr[12];
+  T dall[12];
+  sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; dall[j] = gbc<j>(d_me); });
+  sfor<0, 12>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    constexpr int fj = j / 3, aj = j % 3;
+    const T onj = ((mask >> fj) & 1) ? (T)1 : (T)0;
+    const T dx = dall[3 * fj], dy = dall[3 * fj + 1], dz = dall[3 * fj + 2];
+    T w0, w1, w2;
+    if (aj == 0) { w0 = 0; w1 = dz; w2 = -dy; } else if (aj == 1) { w0 = -dz; w1 = 0; w2 = dx; } else { w0 = dy; w1 = -dx; w2 = 0; }
+    T h = (u0 * w0 + u1 * w1 + u2 * w2) + ((c3 == aj) ? Sme : (T)0);
+    h *= onj;
+    if (isvar && v == j) h += prm.alpha;
+    Hr[j] = isvar ? h : (T)0;  // spare lanes: zeros
+  });
+  T g_me;
+  {
+    const T bs = (c3 == 0 ? b[0] : (c3 == 1 ? b[1] : b[2]));
+    g_me = isvar ? -(Sme * bs + u0 * b[3] + u1 * b[4] + u2 * b[5]) : (T)0;
+  }
+
+  // ------------------------------------------------------------------ Cholesky H = L L^T, rows in lanes
+  T linv[12];
+  sfor<0, 12>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const T piv = gbc<j>(Hr[j]);
+    const T inv = rsqrt_nr(piv);
+    linv[j] = inv;
+    Hr[j] *= inv;
+    sfor<j + 1, 12>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const T lkj = gbc<k>(Hr[j]);
+      Hr[k] -= Hr[j] * lkj;
+    });
+  });
+  // ------------------------------------------------------------------ J0 = L^-T : my column by back-substitution
+  T Jc[12], Jr[12], Rr[12];
+  sfor_down<0, 12>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    T acc = (isvar && v == i) ? (T)1 : (T)0;
+    sfor<i + 1, 12>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      acc -= gbc<k>(Hr[i]) * Jc[k];
+    });
+    Jc[i] = acc * linv[i];
+  });
+  if (!isvar) sfor<0, 12>([&](auto ic) { Jc[decltype(ic)::value] = 0; });
+  // keep J0 in LDS (for rebuilds) and read my row back: one transposition through LDS per QP
+  if (isvar) sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; J0[i * 12 + v] = Jc[i]; });
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; Jr[c] = isvar ? J0[v * 12 + c] : (T)0; Rr[c] = 0; });
+
+  // ------------------------------------------------------------------ unconstrained minimum x = -J J^T g
+  T x_me;
+  {
+    T t_me = 0;
+    sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; t_me += Jc[i] * gbc<i>(g_me); });
+    T acc = 0;
+    sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; acc += Jr[c] * gbc<c>(t_me); });
+    x_me = -acc;
+  }
+
+  // ------------------------------------------------------------------ my constraints (friction pyramid, force box)
+  T cAx, cAy, cAz, rA, cBx = 0, cBy = 0, cBz = 0;
+  const bool hasB = c3 < 2;
+  {
+    T nx = dppx<0x00>(n_ld), ny = dppx<0x55>(n_ld), nz = dppx<0xAA>(n_ld);
+    const T il = rsqrt_nr(nx * nx + ny * ny + nz * nz);
+    nx *= il; ny *= il; nz *= il;
+    const bool usex = fabs_t(nx) < (T)0.9;
+    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
+    const T rd = rx * nx + ry * ny;
+    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
+    const T it = rsqrt_nr(t1x * t1x + t1y * t1y + t1z * t1z);
+    t1x *= it; t1y *= it; t1z *= it;
+    const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    const T mt = mu_f * prm.mu_scale;
+    const T tx = (c3 == 0) ? t1x : t2x, ty = (c3 == 0) ? t1y : t2y, tz = (c3 == 0) ? t1z : t2z;
+    if (hasB) {
+      cAx = mt * nx - tx; cAy = mt * ny - ty; cAz = mt * nz - tz; rA = 0;
+      cBx = mt * nx + tx; cBy = mt * ny + ty; cBz = mt * nz + tz;
+    } else if (c3 == 2) { cAx = nx; cAy = ny; cAz = nz; rA = prm.fn_min; }
+    else { cAx = -nx; cAy = -ny; cAz = -nz; rA = -prm.fn_max; }
+  }
+
+  // ------------------------------------------------------------------ dual active-set iterations (a8)
+  int iq = 0, ip = -1, status = 0, iter = 0;
+  bool done = !live;
+  bool actA = false, actB = false;
+  T sip = 0, Rnorm = 1, u_me = 0, rdinv = 0;
+  T u_c = 0;  // multiplier of the candidate constraint (row-uniform; it has no position until it is added)
+  int Aid = -1;
+
+  // slack of my constraints at the current x
+  auto slacks = [&](T& sA, T& sB) {
+    const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
+    sA = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA;
+    sB = cBx * xq0 + cBy * xq1 + cBz * xq2;
+  };
+  // step 1 for rows that need a new candidate: most violated inactive constraint
+  auto pick = [&]() {
+    T sA, sB;
+    slacks(sA, sB);
+    T val = INF;
+    int id = 1 << 20;
+    if (on && !actA && sA < -prm.qp_tol) { val = sA; id = 2 * l16; }
+    if (on && hasB && !actB && sB < -prm.qp_tol && sB < val) { val = sB; id = 2 * l16 + 1; }
+    gargmin(val, id);
+    const bool need = !done && ip < 0;
+    if (need) {
+      if (val < INF) {
+        ip = id; sip = val; u_c = 0;
+      } else done = true;
+    }
+  };
+  // add constraint with normal (np0,np1,np2) on foot fp at position `pos` for rows where `doit`;
+  // dd = J^T np of my column (valid when isvar), dn2 = |dd[pos..)|^2.  Householder on J[:, pos..12).
+  auto add_column = [&](bool doit, int pos, T dd, T dn2, T& nr_out) {
+    const int lpos = pos + pos / 3;
+    const T a0 = gread(dd, lpos & 15);
+    const T nr = sqrt_t(dn2);
+    const T sg = (a0 >= 0) ? (T)1 : (T)-1;
+    const T beta = rcp_nr(nr * (nr + fabs_t(a0)));
+    T w_me = 0;
+    if (doit && isvar) w_me = (v == pos) ? a0 + sg * nr : (v > pos ? dd : (T)0);
+    T wrep[12];
+    sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; wrep[j] = gbc<j>(w_me); });
+    T y_me = 0;
+    sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; y_me += Jr[j] * wrep[j]; });
+    y_me = doit ? y_me * beta : (T)0;
+    sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; Jr[j] -= y_me * wrep[j]; });
+    sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; Jc[i] -= gbc<i>(y_me) * w_me; });
+    const T newr = (v < pos) ? dd : -sg * nr;
+    const bool wr = doit && isvar && v <= pos;
+    sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; Rr[c] = (wr && c == pos) ? newr : Rr[c]; });
+    if (doit && isvar && v == pos) rdinv = -sg * rcp_nr(nr);
+    nr_out = nr;
+  };
+  // d = J^T np for my column, np = (n0,n1,n2) on the variables of foot fp
+  auto jt_np = [&](int fp, T n0, T n1, T n2) -> T {
+    const T j0 = fp == 0 ? Jc[0] : (fp == 1 ? Jc[3] : (fp == 2 ? Jc[6] : Jc[9]));
+    const T j1 = fp == 0 ? Jc[1] : (fp == 1 ? Jc[4] : (fp == 2 ? Jc[7] : Jc[10]));
+    const T j2 = fp == 0 ? Jc[2] : (fp == 1 ? Jc[5] : (fp == 2 ? Jc[8] : Jc[11]));
+    return isvar ? j0 * n0 + j1 * n1 + j2 * n2 : (T)0;
+  };
+  // normal of constraint id: its three coefficients live in lane (id >> 1)
+  auto normal_of = [&](int id, T& n0, T& n1, T& n2) {
+    const int lp = (id >> 1) & 15;
+    const bool sb = id & 1;
+    // every lane offers the slot the REQUESTING row asks for; the owner lane's value is fetched
+    n0 = gread(sb ? cBx : cAx, lp); n1 = gread(sb ? cBy : cAy, lp); n2 = gread(sb ? cBz : cAz, lp);
+  };
+
+  pick();
+  int guard = 0;
+  while (__ballot(!done && ip >= 0) != 0ull) {
+    if (++guard > 4 * prm.max_iter + 8) break;  // hard stop; per-row limits are enforced below
+    bool go = !done && ip >= 0;
+    if (go && ++iter > prm.max_iter) { status = 1; done = true; go = false; }
+    const int ipc = ip < 0 ? 0 : ip;
+    const int lp = (ipc >> 1) & 15, fp = lp >> 2;
+    T np0, np1, np2;
+    normal_of(ipc, np0, np1, np2);
+    const T dd = jt_np(fp, np0, np1, np2);
+    const T dn2 = gsum((isvar && v >= iq) ? dd * dd : (T)0);
+    // z = J2 d2 (row copy, d broadcast and masked below iq)
+    T z_me = 0;
+    sfor<0, 12>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const T dj = gbc<j>(dd);
+      z_me += Jr[j] * ((j >= iq) ? dj : (T)0);
+    });
+    // r = R^-1 d1 : column-oriented back-substitution, row k of R lives in variable lane k
+    T r_me = 0;
+    {
+      T acc = (isvar && v < iq) ? dd : (T)0;
+      sfor_down<0, 12>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (__ballot(k < iq && go) != 0ull) {
+          const T rk = gbc<k>(acc * rdinv);
+          const bool use = k < iq;
+          acc = (use && isvar && v < k) ? acc - Rr[k] * rk : acc;
+          r_me = (use && isvar && v == k) ? rk : r_me;
+        }
+      });
+    }
+    // step lengths
+    T t1 = INF;
+    int kmin = 1 << 20;
+    if (isvar && v < iq && r_me > 0) { t1 = u_me / r_me; kmin = v; }
+    gargmin(t1, kmin);
+    T t2 = INF;
+    if (dn2 > (EPS * Rnorm) * (EPS * Rnorm)) t2 = -sip / dn2;  // z.np = |d2|^2
+    if (go && !(t1 < INF) && !(t2 < INF)) { status = 2; done = true; go = false; }
+    const bool dual_only = !(t2 < INF);
+    const bool full = !dual_only && !(t1 < t2);
+    const T t = full ? t2 : t1;
+    if (go) {
+      if (!dual_only) x_me += t * z_me;
+      if (isvar && v < iq) u_me -= t * r_me;
+      u_c += t;
+    }
+    // ---- full step: the candidate joins the active set
+    const bool addg = go && full;
+    if (__ballot(addg) != 0ull) {
+      T nr;
+      add_column(addg, iq, dd, dn2, nr);
+      if (addg) {
+        Rnorm = (nr > Rnorm) ? nr : Rnorm;
+        if (l16 == lp) { if (ipc & 1) actB = true; else actA = true; }
+        if (isvar && v == iq) { u_me = u_c; Aid = ipc; }
+        ++iq;
+        ip = -1;
+      }
+    }
+    // ---- partial / dual-only step: the blocking constraint leaves, factors are rebuilt
+    const bool dropg = go && !full;
+    if (__ballot(dropg) != 0ull) {
+      const int kq = dropg ? kmin : 0;
+      const int cid = gread(Aid, (kq + kq / 3) & 15);
+      if (dropg && l16 == ((cid >> 1) & 15)) { if (cid & 1) actB = false; else actA = false; }
+      // shift multipliers and ids down over the hole (positions kq+1..iq-1 move to kq..iq-2)
+      {
+        const int nxt = v + 1;
+        const T un = gread(u_me, (nxt + nxt / 3) & 15);
+        const int An = gread(Aid, (nxt + nxt / 3) & 15);
+        if (dropg && isvar && v >= kq && v < iq - 1) { u_me = un; Aid = An; }
+        if (dropg && isvar && v == iq - 1) { u_me = 0; Aid = -1; }
+      }
+      if (dropg) --iq;
+      // restore J0 and re-add the remaining active constraints in order
+      if (dropg) {
+        if (isvar) {
+          sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; Jc[i] = J0[i * 12 + v]; });
+          sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; Jr[c] = J0[v * 12 + c]; });
+        }
+        Rnorm = 1;
+      }
+      for (int p = 0; p < 11; ++p) {
+        const bool rg = dropg && p < iq;
+        if (__ballot(rg) == 0ull) break;
+        const int idp = gread(Aid, (p + p / 3) & 15);
+        const int idc = rg ? idp : 0;
+        T m0, m1, m2;
+        normal_of(idc, m0, m1, m2);
+        const T dp = jt_np(((idc >> 1) & 15) >> 2, m0, m1, m2);
+        const T dp2 = gsum((isvar && v >= p) ? dp * dp : (T)0);
+        T nr;
+        add_column(rg, p, dp, dp2, nr);
+        if (rg) Rnorm = (nr > Rnorm) ? nr : Rnorm;
+      }
+      {  // a partial step moved x: refresh the candidate's slack (cross-lane ops stay unconditional)
+        T sA, sB;
+        slacks(sA, sB);
+        const T sv = gread((ipc & 1) ? sB : sA, lp);
+        if (dropg && !dual_only) sip = sv;
+      }
+    }
+    pick();
+  }
+#undef GLD
+
+  // ------------------------------------------------------------------ outputs: f, tau (a9), status
+  if (live) {
+    const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
+    if (isvar) {
+      GST(a.f, v, on ? x_me : (T)0);
+      const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
+      int jm = 0;
+      sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
+      GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+    }
+    if (l16 == 0) {
+      a.status[s32] = status;
+      if (a.iters) a.iters[s32] = iter;
+    }
+  }
+#undef GST
+}
+
+}  // namespace wbc

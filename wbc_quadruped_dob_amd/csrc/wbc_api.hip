@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -15,6 +16,7 @@
 #include "dyn_sweep.hip.hpp"
 #include "model.hpp"
 #include "qp_wave.hip.hpp"
+#include "qp_group16.hip.hpp"
 
 using namespace wbc;
 
@@ -38,6 +40,7 @@ struct wbc_solver {
   void* d_model = nullptr;  // DevModel<T>
   void* d_ws = nullptr;     // WS_WORDS * max_batch * sizeof(T)
   QpJidx jmap;
+  int qp_kernel = 0;  // 0 = qp_group16 (default), 1 = qp_wave; env WBC_QP_KERNEL=wave selects 1
   // N=1 convenience buffers
   void* d_one = nullptr;
   size_t one_bytes = 0;
@@ -251,6 +254,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   wbc_solver* s = new (std::nothrow) wbc_solver;
   if (!s) return fail(WBC_E_INVALID, "out of memory");
   s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p;
+  if (const char* e = std::getenv("WBC_QP_KERNEL")) s->qp_kernel = (std::strcmp(e, "wave") == 0) ? 1 : 0;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
@@ -424,8 +428,13 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
   rc = span_begin(s, 1, st);
   if (rc) return rc;
-  const unsigned blocks = (unsigned)((N + 3) / 4);
-  hipLaunchKernelGGL((qp_wave_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+  if (s->qp_kernel == 1) {  // one QP per wavefront, factors in LDS (north-star sketch; kept for A/B)
+    const unsigned blocks = (unsigned)((N + 3) / 4);
+    hipLaunchKernelGGL((qp_wave_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+  } else {                  // one QP per 16-lane DPP row, factors in registers
+    const unsigned blocks = (unsigned)((N + 15) / 16);
+    hipLaunchKernelGGL((qp_group16_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("qp_wave launch: ") + hipGetErrorString(e));
   return span_end(s, st);
