@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-mats", action="store_true", help="do not write M,h,Jc to HBM (fused-only variant)")
+    ap.add_argument("--sample-every", type=int, default=10, help="HIP-event instrumentation period inside the timed region")
+    ap.add_argument("--large-batch", type=int, default=262144, help="extra roofline characterisation batch (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,7 +81,10 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    solver.enable_timing(True)
+    # HIP events bracket both kernels of every SAMPLE-th tick of the timed region (on the launch stream): recording
+    # events around every launch costs ~15 us per tick at this batch size, which would be a quarter of the step.
+    sample = max(1, args.sample_every)
+    solver.enable_timing(sample)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -91,7 +96,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     tm = solver.collect_timing()
-    solver.enable_timing(False)
+    solver.enable_timing(0)
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -100,13 +105,15 @@ def main():
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
 
-    # a second, un-instrumented timing of the same K steps (no events between kernels), reported alongside
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    for _ in range(args.steps):
+    # cost of an event pair with nothing between them, on the same stream: the part of every measured span that is
+    # not kernel time (reported; the roofline uses the raw span, i.e. it errs on the slow side)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+    for e0, e1 in ev:
         step()
+        e0.record()
+        e1.record()
     torch.cuda.synchronize()
-    plain = time.perf_counter() - t2
+    ev_overhead_us = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3
 
     if rank == 0:
         ts = 8 if dtype == "f64" else 4
@@ -134,20 +141,78 @@ def main():
                        "batch_per_gpu": n, "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "writes_M_h_Jc": want_mats},
             "roofline": {"kernel": "dyn_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": pmc_traffic("dyn_sweep_kernel", n, dtype),
                          "algorithmic_bytes_per_launch": dyn_bytes, "avg_launch_us": dyn_s * 1e6,
-                         "launches_timed": tm["dyn_launches"]},
-            "kernels": {"dyn_sweep_us": dyn_s * 1e6, "qp_wave_us": qp_s * 1e6,
-                        "qp_us_per_state_amortized": qp_s * 1e6 / n},
-            "ms_per_step_uninstrumented": plain / args.steps * 1e3,
+                         "launches_timed": tm["dyn_launches"], "event_pair_overhead_us": ev_overhead_us,
+                         "note": "HIP events on the launch stream around every %d-th tick of the timed region; raw span "
+                                 "(includes the event-pair overhead reported beside it)" % sample},
+            "kernels": {"dyn_sweep_us": dyn_s * 1e6, "qp_us": qp_s * 1e6, "qp_us_per_state_amortized": qp_s * 1e6 / n,
+                        "qp_kernel": os.environ.get("WBC_QP_KERNEL", "group16")},
             "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                    "iters_max": int(iters.max())},
         }
+        if args.large_batch and world == 1:
+            res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs)
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, n, dtype):
+    """HBM bytes per launch from the committed PMC summary of this round (separate rocprofv3 --pmc passes with the
+    FETCH_SIZE x2 correction calibrated in tools/pmc_profile.sh); None when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(path))
+        key = "n%d" % n
+        for k, v in d.get(key, {}).items():
+            if kernel in k and ("double" in k) == (dtype == "f64"):
+                return v.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs):
+    """The same two kernels at 262144 states (the largest BASELINE.json batch): where the sweep is bandwidth-bound
+    rather than launch/latency-bound.  Not part of `value`."""
+    n = args.large_batch
+    P = synth.default_params(observer_order=obs, dtype=dtype)
+    solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=n)
+    B = synth.make_batch(args.config, n, model.total_mass, rank=0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
+    inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+    mask = torch.from_numpy(B["mask"]).cuda()
+    integ = rr = None
+    if obs:
+        integ = solver.dynamics(inp["q"], inp["v"], want=("p",))["p"].clone()
+        rr = torch.zeros_like(integ)
+    out = solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                      inp["f_prev"], integ, rr, want_mats=True)
+    for _ in range(3):
+        solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                    inp["f_prev"], integ, rr, out=out, want_mats=True)
+    torch.cuda.synchronize()
+    solver.enable_timing(1)
+    K = 20
+    t0 = time.perf_counter()
+    for _ in range(K):
+        solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                    inp["f_prev"], integ, rr, out=out, want_mats=True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tm = solver.collect_timing()
+    solver.enable_timing(0)
+    ts = 8 if dtype == "f64" else 4
+    dyn_s = tm["dyn_ms"] * 1e-3 / tm["dyn_launches"]
+    qp_s = tm["qp_ms"] * 1e-3 / tm["qp_launches"]
+    ach = DYN_WORDS * ts * n / dyn_s / 1e9
+    return {"batch": n, "kernel": "dyn_sweep_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("dyn_sweep_kernel", n, dtype), "avg_launch_us": dyn_s * 1e6,
+            "qp_us": qp_s * 1e6, "steps_per_s": K * n / el, "ms_per_step": el / K * 1e3}
 
 
 def cpu_baseline(B, P, dtype, n):

@@ -145,7 +145,7 @@ int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const d
                         double* tau, double* f, int* status);
 
 /* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on ---- */
-int wbc_solver_enable_timing(wbc_solver* s, int on); /* on: record events around every kernel */
+int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 events around every kernel; k > 1: every k-th tick */
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last
  * reset for the dynamics-sweep kernel and the QP kernel; resets the accumulators. */
 int wbc_solver_collect_timing(wbc_solver* s, double* dyn_ms, int* dyn_launches, double* qp_ms, int* qp_launches);

@@ -266,7 +266,8 @@ class Solver:
                "wbc_compute_torques")
         return tau, f, st.value
 
-    def enable_timing(self, on=True):
+    def enable_timing(self, on=1):
+        """0 = off, 1 = HIP events around every kernel, k > 1 = around the kernels of every k-th tick."""
         _check(lib().wbc_solver_enable_timing(self._h, int(on)), "wbc_solver_enable_timing")
 
     def collect_timing(self):

@@ -85,12 +85,12 @@ template <class T> WBC_DEV SF<T> to_parent(const M3<T>& E, V3<T> r, const SF<T>&
 
 // ---- DPP quad reductions: the four lanes of a state sum a value without touching LDS ----------
 template <int CTRL> WBC_DEV float dpp_mov(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL> WBC_DEV double dpp_mov(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 template <class T> WBC_DEV T quad_sum(T x) {

@@ -31,15 +31,15 @@ template <int I, int N, class F> WBC_DEV void sfor_down(F&& f) {  // I = N-1 ...
 }
 
 template <int CTRL> WBC_DEV float dppx(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL> WBC_DEV double dppx(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
+  // 64-bit form: row_newbcast becomes ONE v_mov_b64_dpp (the only DPP64 control on gfx90a+); the other
+  // controls are split by the compiler into two 32-bit DPP movs
+  const long long xi = __double_as_longlong(x);
+  return __longlong_as_double(__builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xF, 0xF, true));
 }
-template <int CTRL> WBC_DEV int dppx(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false); }
+template <int CTRL> WBC_DEV int dppx(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
 
 constexpr int LJ(int j) { return j + j / 3; }  // lane (within the row) of variable j
 // broadcast the value held by variable j's lane to the whole row
@@ -86,10 +86,15 @@ WBC_DEV float rcp_nr(float x) {
   return y;
 }
 
-template <class T> struct G16Lds { T J0[4][144]; };  // per wave: four 12x12 images of J0, [i*12 + c]
+// per wave: four 12x12 images of J0 ([i*12 + c]) and four images of R ([position*16 + lane]: row `me` of R is
+// addressed by a run-time position, which LDS allows and a register array does not)
+template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; };
 
+#ifndef WBC_QP_WAVES
+#define WBC_QP_WAVES 2
+#endif
 template <class T>
-__global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+__global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
   __shared__ G16Lds<T> lds_all[4];
   const int lane = threadIdx.x & 63;
   const int l16 = lane & 15;
@@ -98,6 +103,7 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
   const bool isvar = c3 < 3;
   const int v = 3 * f + (isvar ? c3 : 0);  // variable index of this lane (spare lanes: unused)
   T* J0 = lds_all[threadIdx.x >> 6].J0[grp];
+  T* Rl = lds_all[threadIdx.x >> 6].R[grp] + l16;  // my row of R: Rl[16 * position]
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   const size_t qp_raw = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -114,9 +120,6 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
   const T b_ld = (l16 < 6) ? GLD(a.ws, WS_B + l16) : (T)0;
   const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
   const T mu_f = GLD(a.mu, f);
-  const T taup = isvar ? GLD(a.ws, WS_TAUP + v) : (T)0;
-  T jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
-  if (isvar) { jl0 = GLD(a.ws, WS_JCL + 9 * f + 0 + c3); jl1 = GLD(a.ws, WS_JCL + 9 * f + 3 + c3); jl2 = GLD(a.ws, WS_JCL + 9 * f + 6 + c3); }
   T b[6];
   b[0] = dppx<0x150 + 0>(b_ld); b[1] = dppx<0x150 + 1>(b_ld); b[2] = dppx<0x150 + 2>(b_ld);
   b[3] = dppx<0x150 + 3>(b_ld); b[4] = dppx<0x150 + 4>(b_ld); b[5] = dppx<0x150 + 5>(b_ld);
@@ -132,13 +135,11 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
   u0 *= onf * prm.S[3]; u1 *= onf * prm.S[4]; u2 *= onf * prm.S[5];  // fold S(3..5) and the stance flag in
   const T Sme = (c3 == 0 ? prm.S[0] : (c3 == 1 ? prm.S[1] : prm.S[2])) * onf;
   T Hr[12];
-  T dall[12];
-  sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; dall[j] = gbc<j>(d_me); });
-  sfor<0, 12>([&](auto jc) {
+  sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
     constexpr int fj = j / 3, aj = j % 3;
     const T onj = ((mask >> fj) & 1) ? (T)1 : (T)0;
-    const T dx = dall[3 * fj], dy = dall[3 * fj + 1], dz = dall[3 * fj + 2];
+    const T dx = gbc<3 * fj>(d_me), dy = gbc<3 * fj + 1>(d_me), dz = gbc<3 * fj + 2>(d_me);  // CSE'd per foot
     T w0, w1, w2;
     if (aj == 0) { w0 = 0; w1 = dz; w2 = -dy; } else if (aj == 1) { w0 = -dz; w1 = 0; w2 = dx; } else { w0 = dy; w1 = -dx; w2 = 0; }
     T h = (u0 * w0 + u1 * w1 + u2 * w2) + ((c3 == aj) ? Sme : (T)0);
@@ -153,45 +154,45 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
   }
 
   // ------------------------------------------------------------------ Cholesky H = L L^T, rows in lanes
-  T linv[12];
-  sfor<0, 12>([&](auto jc) {
+  T linv_me = 0;  // 1 / L[me][me]
+  sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
     constexpr int j = decltype(jc)::value;
     const T piv = gbc<j>(Hr[j]);
     const T inv = rsqrt_nr(piv);
-    linv[j] = inv;
+    linv_me = (isvar && v == j) ? inv : linv_me;
     Hr[j] *= inv;
-    sfor<j + 1, 12>([&](auto kc) {
+    sfor<j + 1, 12>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       const T lkj = gbc<k>(Hr[j]);
       Hr[k] -= Hr[j] * lkj;
     });
   });
   // ------------------------------------------------------------------ J0 = L^-T : my column by back-substitution
-  T Jc[12], Jr[12], Rr[12];
-  sfor_down<0, 12>([&](auto ic) {
+  T Jc[12], Jr[12];
+  sfor_down<0, 12>([&](auto ic) __attribute__((always_inline)) {
     constexpr int i = decltype(ic)::value;
     T acc = (isvar && v == i) ? (T)1 : (T)0;
-    sfor<i + 1, 12>([&](auto kc) {
+    sfor<i + 1, 12>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       acc -= gbc<k>(Hr[i]) * Jc[k];
     });
-    Jc[i] = acc * linv[i];
+    Jc[i] = acc * gbc<i>(linv_me);
   });
-  if (!isvar) sfor<0, 12>([&](auto ic) { Jc[decltype(ic)::value] = 0; });
+  if (!isvar) sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { Jc[decltype(ic)::value] = 0; });
   // keep J0 in LDS (for rebuilds) and read my row back: one transposition through LDS per QP
-  if (isvar) sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; J0[i * 12 + v] = Jc[i]; });
+  if (isvar) sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; J0[i * 12 + v] = Jc[i]; });
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; Jr[c] = isvar ? J0[v * 12 + c] : (T)0; Rr[c] = 0; });
+  sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; Jr[c] = isvar ? J0[v * 12 + c] : (T)0; });
 
   // ------------------------------------------------------------------ unconstrained minimum x = -J J^T g
   T x_me;
   {
     T t_me = 0;
-    sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; t_me += Jc[i] * gbc<i>(g_me); });
+    sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; t_me += Jc[i] * gbc<i>(g_me); });
     T acc = 0;
-    sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; acc += Jr[c] * gbc<c>(t_me); });
+    sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; acc += Jr[c] * gbc<c>(t_me); });
     x_me = -acc;
   }
 
@@ -227,13 +228,13 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
   int Aid = -1;
 
   // slack of my constraints at the current x
-  auto slacks = [&](T& sA, T& sB) {
+  auto slacks = [&](T& sA, T& sB) __attribute__((always_inline)) {
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     sA = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA;
     sB = cBx * xq0 + cBy * xq1 + cBz * xq2;
   };
   // step 1 for rows that need a new candidate: most violated inactive constraint
-  auto pick = [&]() {
+  auto pick = [&]() __attribute__((always_inline)) {
     T sA, sB;
     slacks(sA, sB);
     T val = INF;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
   };
   // add constraint with normal (np0,np1,np2) on foot fp at position `pos` for rows where `doit`;
   // dd = J^T np of my column (valid when isvar), dn2 = |dd[pos..)|^2.  Householder on J[:, pos..12).
-  auto add_column = [&](bool doit, int pos, T dd, T dn2, T& nr_out) {
+  auto add_column = [&](bool doit, int pos, T dd, T dn2, T& nr_out) __attribute__((always_inline)) {
     const int lpos = pos + pos / 3;
     const T a0 = gread(dd, lpos & 15);
     const T nr = sqrt_t(dn2);
@@ -258,28 +259,28 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
     const T beta = rcp_nr(nr * (nr + fabs_t(a0)));
     T w_me = 0;
     if (doit && isvar) w_me = (v == pos) ? a0 + sg * nr : (v > pos ? dd : (T)0);
-    T wrep[12];
-    sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; wrep[j] = gbc<j>(w_me); });
     T y_me = 0;
-    sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; y_me += Jr[j] * wrep[j]; });
+    sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; y_me += Jr[j] * gbc<j>(w_me); });
     y_me = doit ? y_me * beta : (T)0;
-    sfor<0, 12>([&](auto jc) { constexpr int j = decltype(jc)::value; Jr[j] -= y_me * wrep[j]; });
-    sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; Jc[i] -= gbc<i>(y_me) * w_me; });
+    sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Jr[j] -= y_me * gbc<j>(w_me); });
+    sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; Jc[i] -= gbc<i>(y_me) * w_me; });
     const T newr = (v < pos) ? dd : -sg * nr;
-    const bool wr = doit && isvar && v <= pos;
-    sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; Rr[c] = (wr && c == pos) ? newr : Rr[c]; });
+    if (doit && isvar && v <= pos) Rl[16 * pos] = newr;
     if (doit && isvar && v == pos) rdinv = -sg * rcp_nr(nr);
     nr_out = nr;
   };
   // d = J^T np for my column, np = (n0,n1,n2) on the variables of foot fp
-  auto jt_np = [&](int fp, T n0, T n1, T n2) -> T {
-    const T j0 = fp == 0 ? Jc[0] : (fp == 1 ? Jc[3] : (fp == 2 ? Jc[6] : Jc[9]));
-    const T j1 = fp == 0 ? Jc[1] : (fp == 1 ? Jc[4] : (fp == 2 ? Jc[7] : Jc[10]));
-    const T j2 = fp == 0 ? Jc[2] : (fp == 1 ? Jc[5] : (fp == 2 ? Jc[8] : Jc[11]));
+  auto jt_np = [&](int fp, T n0, T n1, T n2) __attribute__((always_inline)) -> T {
+    // foot selection by 0/1 weights, not by a select chain: clang turns `fp==0 ? Jc[0] : fp==1 ? Jc[3] ...` into a
+    // run-time index, which forces the whole register array into scratch memory
+    const T m0 = fp == 0 ? (T)1 : (T)0, m1 = fp == 1 ? (T)1 : (T)0, m2 = fp == 2 ? (T)1 : (T)0, m3 = fp == 3 ? (T)1 : (T)0;
+    const T j0 = m0 * Jc[0] + m1 * Jc[3] + m2 * Jc[6] + m3 * Jc[9];
+    const T j1 = m0 * Jc[1] + m1 * Jc[4] + m2 * Jc[7] + m3 * Jc[10];
+    const T j2 = m0 * Jc[2] + m1 * Jc[5] + m2 * Jc[8] + m3 * Jc[11];
     return isvar ? j0 * n0 + j1 * n1 + j2 * n2 : (T)0;
   };
   // normal of constraint id: its three coefficients live in lane (id >> 1)
-  auto normal_of = [&](int id, T& n0, T& n1, T& n2) {
+  auto normal_of = [&](int id, T& n0, T& n1, T& n2) __attribute__((always_inline)) {
     const int lp = (id >> 1) & 15;
     const bool sb = id & 1;
     // every lane offers the slot the REQUESTING row asks for; the owner lane's value is fetched
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
     const T dn2 = gsum((isvar && v >= iq) ? dd * dd : (T)0);
     // z = J2 d2 (row copy, d broadcast and masked below iq)
     T z_me = 0;
-    sfor<0, 12>([&](auto jc) {
+    sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
       const T dj = gbc<j>(dd);
       z_me += Jr[j] * ((j >= iq) ? dj : (T)0);
@@ -309,12 +310,12 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
     T r_me = 0;
     {
       T acc = (isvar && v < iq) ? dd : (T)0;
-      sfor_down<0, 12>([&](auto kc) {
+      sfor_down<0, 12>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if (__ballot(k < iq && go) != 0ull) {
           const T rk = gbc<k>(acc * rdinv);
           const bool use = k < iq;
-          acc = (use && isvar && v < k) ? acc - Rr[k] * rk : acc;
+          acc = (use && isvar && v < k) ? acc - Rl[16 * k] * rk : acc;
           r_me = (use && isvar && v == k) ? rk : r_me;
         }
       });
@@ -366,8 +367,8 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
       // restore J0 and re-add the remaining active constraints in order
       if (dropg) {
         if (isvar) {
-          sfor<0, 12>([&](auto ic) { constexpr int i = decltype(ic)::value; Jc[i] = J0[i * 12 + v]; });
-          sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; Jr[c] = J0[v * 12 + c]; });
+          sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; Jc[i] = J0[i * 12 + v]; });
+          sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; Jr[c] = J0[v * 12 + c]; });
         }
         Rnorm = 1;
       }
@@ -393,16 +394,20 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
     }
     pick();
   }
-#undef GLD
 
   // ------------------------------------------------------------------ outputs: f, tau (a9), status
   if (live) {
+    T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
+    if (isvar) {
+      taup = GLD(a.ws, WS_TAUP + v);
+      jl0 = GLD(a.ws, WS_JCL + 9 * f + 0 + c3); jl1 = GLD(a.ws, WS_JCL + 9 * f + 3 + c3); jl2 = GLD(a.ws, WS_JCL + 9 * f + 6 + c3);
+    }
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     if (isvar) {
       GST(a.f, v, on ? x_me : (T)0);
       const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
       int jm = 0;
-      sfor<0, 12>([&](auto cc) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
+      sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
       GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
     }
     if (l16 == 0) {
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(256) void qp_group16_kernel(DevParams<T> prm, QpArg
     }
   }
 #undef GST
+#undef GLD
 }
 
 }  // namespace wbc

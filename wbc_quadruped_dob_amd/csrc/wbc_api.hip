@@ -46,6 +46,9 @@ struct wbc_solver {
   size_t one_bytes = 0;
   // timing
   bool timing = false;
+  int timing_period = 1;   // instrument every timing_period-th launch pair
+  unsigned long long calls = 0;
+  bool sample_now = false;
   std::vector<hipEvent_t> ev_pool;
   struct Span { int kind; hipEvent_t a, b; };
   std::vector<Span> spans;
@@ -302,6 +305,8 @@ extern "C" int wbc_solver_set_params(wbc_solver* s, const wbc_params* p) {
 // ---- timing helpers
 static int span_begin(wbc_solver* s, int kind, hipStream_t st) {
   if (!s->timing) return WBC_OK;
+  if (kind == 0) s->sample_now = (s->calls++ % (unsigned long long)s->timing_period) == 0;
+  if (!s->sample_now) return WBC_OK;
   if (s->ev_next + 2 > s->ev_pool.size()) {
     for (int i = 0; i < 64; ++i) {
       hipEvent_t ev;
@@ -316,7 +321,7 @@ static int span_begin(wbc_solver* s, int kind, hipStream_t st) {
   return WBC_OK;
 }
 static int span_end(wbc_solver* s, hipStream_t st) {
-  if (!s->timing) return WBC_OK;
+  if (!s->timing || !s->sample_now) return WBC_OK;
   HIP_TRY(hipEventRecord(s->spans.back().b, st));
   return WBC_OK;
 }
@@ -324,6 +329,9 @@ static int span_end(wbc_solver* s, hipStream_t st) {
 extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
   if (!s) return fail(WBC_E_INVALID, "null solver");
   s->timing = on != 0;
+  s->timing_period = on > 1 ? on : 1;  // on = k > 1: sample every k-th tick (keeps the event cost out of the rest)
+  s->calls = 0;
+  s->sample_now = false;
   s->spans.clear();
   s->ev_next = 0;
   return WBC_OK;
