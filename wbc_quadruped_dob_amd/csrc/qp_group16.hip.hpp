@@ -49,16 +49,30 @@ template <class T> WBC_DEV T gsum(T x) {
   x += dppx<0xB1>(x); x += dppx<0x4E>(x); x += dppx<0x141>(x); x += dppx<0x140>(x);
   return x;
 }
-template <class T> WBC_DEV void gargmin_step(T& v, int& id, T ov, int oi) {
-  const bool take = (ov < v) || (ov == v && oi < id);
-  v = take ? ov : v;
-  id = take ? oi : id;
-}
-template <class T> WBC_DEV void gargmin(T& v, int& id) {
-  gargmin_step(v, id, dppx<0xB1>(v), dppx<0xB1>(id));
-  gargmin_step(v, id, dppx<0x4E>(v), dppx<0x4E>(id));
-  gargmin_step(v, id, dppx<0x141>(v), dppx<0x141>(id));
-  gargmin_step(v, id, dppx<0x140>(v), dppx<0x140>(id));
+// Row-wide argmin without a compare/select chain: the 5-bit id is written into the low mantissa bits of the
+// value, which makes all keys distinct, so four DPP steps of v_min are an all-reduce that every lane agrees on.
+// The value moves by < 2^-47 relative (f64) / 2^-18 (f32) -- selection only; callers that need the exact value
+// of the winner fetch it from the winning lane.  BIG (finite) stands for "no candidate": inf | id would be a NaN.
+template <class T> struct KeyT;
+template <> struct KeyT<double> {
+  static constexpr double BIG = 1e300;
+  static WBC_DEV double pack(double v, int id) { return __longlong_as_double((__double_as_longlong(v) & ~63ll) | (long long)id); }
+  static WBC_DEV int id(double k) { return (int)(__double_as_longlong(k) & 63ll); }
+  static WBC_DEV double mn(double a, double b) { return fmin(a, b); }
+};
+template <> struct KeyT<float> {
+  static constexpr float BIG = 1e30f;
+  static WBC_DEV float pack(float v, int id) { return __int_as_float((__float_as_int(v) & ~63) | id); }
+  static WBC_DEV int id(float k) { return __float_as_int(k) & 63; }
+  static WBC_DEV float mn(float a, float b) { return fminf(a, b); }
+};
+// in: v (BIG = none), id in [0,64).  out: row-uniform winner id (or -1) in `id`, found flag returned
+template <class T> WBC_DEV bool gargmin(T v, int& id) {
+  using K = KeyT<T>;
+  T k = K::pack(v, id);
+  k = K::mn(k, dppx<0xB1>(k)); k = K::mn(k, dppx<0x4E>(k)); k = K::mn(k, dppx<0x141>(k)); k = K::mn(k, dppx<0x140>(k));
+  id = K::id(k);
+  return k < (T)(K::BIG * (T)0.5);
 }
 // read from a run-time lane of my own row
 template <class T> WBC_DEV T gread(T x, int lane16) { return __shfl(x, (int)((threadIdx.x & 48) | lane16)); }
@@ -113,6 +127,9 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
 #define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define GST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
 
+#ifdef WBC_QP_STAMP
+  const long long st_t0 = __builtin_readcyclecounter();
+#endif
   // ------------------------------------------------------------------ inputs
   const int mask = a.mask[s32] & 0xF;
   const bool on = (mask >> f) & 1;
@@ -237,15 +254,17 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
   auto pick = [&]() __attribute__((always_inline)) {
     T sA, sB;
     slacks(sA, sB);
-    T val = INF;
-    int id = 1 << 20;
-    if (on && !actA && sA < -prm.qp_tol) { val = sA; id = 2 * l16; }
+    T val = KeyT<T>::BIG;
+    int id = 2 * l16;
+    if (on && !actA && sA < -prm.qp_tol) { val = sA; }
     if (on && hasB && !actB && sB < -prm.qp_tol && sB < val) { val = sB; id = 2 * l16 + 1; }
-    gargmin(val, id);
+    const bool found = gargmin(val, id);
+    // exact slack of the winner (the key carries the id in its low bits)
+    const T sw = gread((id & 1) ? sB : sA, (id >> 1) & 15);
     const bool need = !done && ip < 0;
     if (need) {
-      if (val < INF) {
-        ip = id; sip = val; u_c = 0;
+      if (found) {
+        ip = id; sip = sw; u_c = 0;
       } else done = true;
     }
   };
@@ -254,19 +273,21 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
   auto add_column = [&](bool doit, int pos, T dd, T dn2, T& nr_out) __attribute__((always_inline)) {
     const int lpos = pos + pos / 3;
     const T a0 = gread(dd, lpos & 15);
-    const T nr = sqrt_t(dn2);
+    const T inr = rsqrt_nr(dn2 > 0 ? dn2 : (T)1);
+    const T nr = dn2 * inr;  // |d2| = dn2 / sqrt(dn2)
     const T sg = (a0 >= 0) ? (T)1 : (T)-1;
     const T beta = rcp_nr(nr * (nr + fabs_t(a0)));
     T w_me = 0;
     if (doit && isvar) w_me = (v == pos) ? a0 + sg * nr : (v > pos ? dd : (T)0);
-    T y_me = 0;
-    sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; y_me += Jr[j] * gbc<j>(w_me); });
+    T ya[3] = {0, 0, 0};
+    sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; ya[j % 3] += Jr[j] * gbc<j>(w_me); });
+    T y_me = (ya[0] + ya[1]) + ya[2];
     y_me = doit ? y_me * beta : (T)0;
     sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Jr[j] -= y_me * gbc<j>(w_me); });
     sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; Jc[i] -= gbc<i>(y_me) * w_me; });
     const T newr = (v < pos) ? dd : -sg * nr;
     if (doit && isvar && v <= pos) Rl[16 * pos] = newr;
-    if (doit && isvar && v == pos) rdinv = -sg * rcp_nr(nr);
+    if (doit && isvar && v == pos) rdinv = -sg * inr;
     nr_out = nr;
   };
   // d = J^T np for my column, np = (n0,n1,n2) on the variables of foot fp
@@ -287,8 +308,18 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     n0 = gread(sb ? cBx : cAx, lp); n1 = gread(sb ? cBy : cAy, lp); n2 = gread(sb ? cBz : cAz, lp);
   };
 
+#ifdef WBC_QP_STAMP
+  const long long st_t1 = __builtin_readcyclecounter();
+#endif
   pick();
   int guard = 0;
+#ifdef WBC_QP_STAMP
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_last = __builtin_readcyclecounter();
+#define SEG(i) do { const long long now_ = __builtin_readcyclecounter(); seg[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define SEG(i) do {} while (0)
+#endif
   while (__ballot(!done && ip >= 0) != 0ull) {
     if (++guard > 4 * prm.max_iter + 8) break;  // hard stop; per-row limits are enforced below
     bool go = !done && ip >= 0;
@@ -299,34 +330,54 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     normal_of(ipc, np0, np1, np2);
     const T dd = jt_np(fp, np0, np1, np2);
     const T dn2 = gsum((isvar && v >= iq) ? dd * dd : (T)0);
+    SEG(0);
     // z = J2 d2 (row copy, d broadcast and masked below iq)
-    T z_me = 0;
-    sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
-      constexpr int j = decltype(jc)::value;
-      const T dj = gbc<j>(dd);
-      z_me += Jr[j] * ((j >= iq) ? dj : (T)0);
-    });
+    T z_me;
+    {
+      T za[3] = {0, 0, 0};  // three independent chains instead of one 12-deep FMA chain
+      sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const T dj = gbc<j>(dd);
+        za[j % 3] += Jr[j] * ((j >= iq) ? dj : (T)0);
+      });
+      z_me = (za[0] + za[1]) + za[2];
+    }
+    SEG(1);
     // r = R^-1 d1 : column-oriented back-substitution, row k of R lives in variable lane k
     T r_me = 0;
     {
       T acc = (isvar && v < iq) ? dd : (T)0;
+      T Rrow[12];  // my row of R, fetched up front so that no LDS latency sits inside the dependent chain
+      sfor<0, 12>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rrow[k] = Rl[16 * k]; });
+      // wave-uniform bound: the largest active-set size among the four rows (one readlane per row, scalar max)
+      const int iqg = go ? iq : 0;
+      int iqmax = __builtin_amdgcn_readlane(iqg, 0);
+      { const int b1 = __builtin_amdgcn_readlane(iqg, 16), b2 = __builtin_amdgcn_readlane(iqg, 32), b3 = __builtin_amdgcn_readlane(iqg, 48);
+        iqmax = iqmax > b1 ? iqmax : b1; iqmax = iqmax > b2 ? iqmax : b2; iqmax = iqmax > b3 ? iqmax : b3; }
       sfor_down<0, 12>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        if (__ballot(k < iq && go) != 0ull) {
+        if (k < iqmax) {
           const T rk = gbc<k>(acc * rdinv);
           const bool use = k < iq;
-          acc = (use && isvar && v < k) ? acc - Rl[16 * k] * rk : acc;
+          acc = (use && isvar && v < k) ? acc - Rrow[k] * rk : acc;
           r_me = (use && isvar && v == k) ? rk : r_me;
         }
       });
     }
+    SEG(2);
     // step lengths
     T t1 = INF;
-    int kmin = 1 << 20;
-    if (isvar && v < iq && r_me > 0) { t1 = u_me / r_me; kmin = v; }
-    gargmin(t1, kmin);
+    int kmin = isvar ? v : 15;
+    {
+      T t1k = KeyT<T>::BIG;
+      if (isvar && v < iq && r_me > 0) t1k = u_me * rcp_nr(r_me);
+      const T mine = t1k;
+      const bool found = gargmin(t1k, kmin);
+      const T tw = gread(mine, (kmin + kmin / 3) & 15);  // exact ratio of the winner
+      if (found) t1 = tw;
+    }
     T t2 = INF;
-    if (dn2 > (EPS * Rnorm) * (EPS * Rnorm)) t2 = -sip / dn2;  // z.np = |d2|^2
+    if (dn2 > (EPS * Rnorm) * (EPS * Rnorm)) t2 = -sip * rcp_nr(dn2);  // z.np = |d2|^2
     if (go && !(t1 < INF) && !(t2 < INF)) { status = 2; done = true; go = false; }
     const bool dual_only = !(t2 < INF);
     const bool full = !dual_only && !(t1 < t2);
@@ -336,6 +387,7 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
       if (isvar && v < iq) u_me -= t * r_me;
       u_c += t;
     }
+    SEG(3);
     // ---- full step: the candidate joins the active set
     const bool addg = go && full;
     if (__ballot(addg) != 0ull) {
@@ -349,6 +401,7 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
         ip = -1;
       }
     }
+    SEG(4);
     // ---- partial / dual-only step: the blocking constraint leaves, factors are rebuilt
     const bool dropg = go && !full;
     if (__ballot(dropg) != 0ull) {
@@ -392,7 +445,9 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
         if (dropg && !dual_only) sip = sv;
       }
     }
+    SEG(5);
     pick();
+    SEG(6);
   }
 
   // ------------------------------------------------------------------ outputs: f, tau (a9), status
@@ -412,7 +467,19 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     }
     if (l16 == 0) {
       a.status[s32] = status;
+#ifdef WBC_QP_STAMP  // diagnostic build only: per-wave cycle stamps (two 16-bit fields of cycles/16 per group) instead of iteration counts
+      {
+        const long long vals[8] = {st_t1 - st_t0, seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[6]};
+        long long lo = vals[0], hi = vals[1];
+        if (grp == 1) { lo = vals[2]; hi = vals[3]; } else if (grp == 2) { lo = vals[4]; hi = vals[5]; } else if (grp == 3) { lo = vals[6]; hi = vals[7]; }
+        lo >>= 4; hi >>= 4;
+        if (lo > 0xFFFF) lo = 0xFFFF;
+        if (hi > 0x7FFF) hi = 0x7FFF;
+        if (a.iters) a.iters[s32] = (int)(lo | (hi << 16));
+      }
+#else
       if (a.iters) a.iters[s32] = iter;
+#endif
     }
   }
 #undef GST
