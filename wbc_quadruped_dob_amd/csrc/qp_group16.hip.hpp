@@ -58,20 +58,24 @@ template <> struct KeyT<double> {
   static constexpr double BIG = 1e300;
   static WBC_DEV double pack(double v, int id) { return __longlong_as_double((__double_as_longlong(v) & ~63ll) | (long long)id); }
   static WBC_DEV int id(double k) { return (int)(__double_as_longlong(k) & 63ll); }
+  static WBC_DEV double val(double k) { return __longlong_as_double(__double_as_longlong(k) & ~63ll); }
   static WBC_DEV double mn(double a, double b) { return fmin(a, b); }
 };
 template <> struct KeyT<float> {
   static constexpr float BIG = 1e30f;
   static WBC_DEV float pack(float v, int id) { return __int_as_float((__float_as_int(v) & ~63) | id); }
   static WBC_DEV int id(float k) { return __float_as_int(k) & 63; }
+  static WBC_DEV float val(float k) { return __int_as_float(__float_as_int(k) & ~63); }
   static WBC_DEV float mn(float a, float b) { return fminf(a, b); }
 };
-// in: v (BIG = none), id in [0,64).  out: row-uniform winner id (or -1) in `id`, found flag returned
-template <class T> WBC_DEV bool gargmin(T v, int& id) {
+// in: v (BIG = none), id in [0,64).  out: row-uniform winner id in `id`, its value (low 6 mantissa bits cleared:
+// relative error < 2^-46 in f64, 2^-17 in f32) in `v`; returns whether any lane had a candidate
+template <class T> WBC_DEV bool gargmin(T& v, int& id) {
   using K = KeyT<T>;
   T k = K::pack(v, id);
   k = K::mn(k, dppx<0xB1>(k)); k = K::mn(k, dppx<0x4E>(k)); k = K::mn(k, dppx<0x141>(k)); k = K::mn(k, dppx<0x140>(k));
   id = K::id(k);
+  v = K::val(k);
   return k < (T)(K::BIG * (T)0.5);
 }
 // read from a run-time lane of my own row
@@ -102,7 +106,8 @@ WBC_DEV float rcp_nr(float x) {
 
 // per wave: four 12x12 images of J0 ([i*12 + c]) and four images of R ([position*16 + lane]: row `me` of R is
 // addressed by a run-time position, which LDS allows and a register array does not)
-template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; };
+// ... and the 32 constraint rows (3 coefficients each) so that a candidate's normal is three broadcast reads
+template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]; };
 
 #ifndef WBC_QP_WAVES
 #define WBC_QP_WAVES 2
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
   const int v = 3 * f + (isvar ? c3 : 0);  // variable index of this lane (spare lanes: unused)
   T* J0 = lds_all[threadIdx.x >> 6].J0[grp];
   T* Rl = lds_all[threadIdx.x >> 6].R[grp] + l16;  // my row of R: Rl[16 * position]
+  T* Cl = lds_all[threadIdx.x >> 6].C[grp];        // constraint rows by id
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   const size_t qp_raw = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -236,6 +242,14 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     else { cAx = -nx; cAy = -ny; cAz = -nz; rA = -prm.fn_max; }
   }
 
+  {
+    T* c = Cl + 3 * (2 * l16);
+    c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
   // ------------------------------------------------------------------ dual active-set iterations (a8)
   int iq = 0, ip = -1, status = 0, iter = 0;
   bool done = !live;
@@ -259,8 +273,7 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     if (on && !actA && sA < -prm.qp_tol) { val = sA; }
     if (on && hasB && !actB && sB < -prm.qp_tol && sB < val) { val = sB; id = 2 * l16 + 1; }
     const bool found = gargmin(val, id);
-    // exact slack of the winner (the key carries the id in its low bits)
-    const T sw = gread((id & 1) ? sB : sA, (id >> 1) & 15);
+    const T sw = val;  // winner's slack, exact to 2^-46
     const bool need = !done && ip < 0;
     if (need) {
       if (found) {
@@ -271,8 +284,7 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
   // add constraint with normal (np0,np1,np2) on foot fp at position `pos` for rows where `doit`;
   // dd = J^T np of my column (valid when isvar), dn2 = |dd[pos..)|^2.  Householder on J[:, pos..12).
   auto add_column = [&](bool doit, int pos, T dd, T dn2, T& nr_out) __attribute__((always_inline)) {
-    const int lpos = pos + pos / 3;
-    const T a0 = gread(dd, lpos & 15);
+    const T a0 = gsum((isvar && v == pos) ? dd : (T)0);  // d[pos]: row sum of a one-hot, no LDS round trip
     const T inr = rsqrt_nr(dn2 > 0 ? dn2 : (T)1);
     const T nr = dn2 * inr;  // |d2| = dn2 / sqrt(dn2)
     const T sg = (a0 >= 0) ? (T)1 : (T)-1;
@@ -302,10 +314,8 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
   };
   // normal of constraint id: its three coefficients live in lane (id >> 1)
   auto normal_of = [&](int id, T& n0, T& n1, T& n2) __attribute__((always_inline)) {
-    const int lp = (id >> 1) & 15;
-    const bool sb = id & 1;
-    // every lane offers the slot the REQUESTING row asks for; the owner lane's value is fetched
-    n0 = gread(sb ? cBx : cAx, lp); n1 = gread(sb ? cBy : cAy, lp); n2 = gread(sb ? cBz : cAz, lp);
+    const T* c = Cl + 3 * (id & 31);
+    n0 = c[0]; n1 = c[1]; n2 = c[2];
   };
 
 #ifdef WBC_QP_STAMP
@@ -371,10 +381,8 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     {
       T t1k = KeyT<T>::BIG;
       if (isvar && v < iq && r_me > 0) t1k = u_me * rcp_nr(r_me);
-      const T mine = t1k;
       const bool found = gargmin(t1k, kmin);
-      const T tw = gread(mine, (kmin + kmin / 3) & 15);  // exact ratio of the winner
-      if (found) t1 = tw;
+      if (found) t1 = t1k;
     }
     T t2 = INF;
     if (dn2 > (EPS * Rnorm) * (EPS * Rnorm)) t2 = -sip * rcp_nr(dn2);  // z.np = |d2|^2
