@@ -228,3 +228,72 @@ def test_capacity_and_argument_errors(torch_cuda, gpu_model):
     with pytest.raises(W.WbcError) as e:
         _run_step(torch, solver_obs, B, "f64")  # observer on but no state buffers
     assert e.value.code == 1
+
+
+def _permuted_urdf(tmp_path):
+    """Same robot, different document order: legs interleaved and listed back-to-front, so that neither the joint
+    order (q/v components) nor the foot order is leg-major any more."""
+    import re
+    import wbc_quadruped_dob_amd as W
+    txt = open(W.SYNTHETIC_URDF).read()
+    head, rest = txt.split('<link name="front_left_hip">', 1)
+    rest = '<link name="front_left_hip">' + rest.replace("</robot>", "")
+    # split the four leg sections
+    legs = {}
+    for name in ("front_left", "front_right", "back_left", "back_right"):
+        m = re.search(r'(<link name="%s_hip">.*?<joint name="%s_foot_joint" type="fixed">.*?</joint>\n)' % (name, name), rest, re.S)
+        legs[name] = m.group(1)
+    out = head + legs["back_right"] + legs["front_left"] + legs["back_left"] + legs["front_right"] + "</robot>\n"
+    p = tmp_path / "permuted.urdf"
+    p.write_text(out)
+    return str(p)
+
+
+def test_permuted_joint_and_foot_order(torch_cuda, tmp_path):
+    """Joint order != leg-major and user-chosen foot order: exercises every index map (jidx, packed M, Jc rows)."""
+    import wbc_quadruped_dob_amd as W
+    from oracle import oracle_py, urdf_model
+    torch = torch_cuda
+    path = _permuted_urdf(tmp_path)
+    feet = ["front_right_foot", "back_right_foot", "front_left_foot", "back_left_foot"]
+    flat = urdf_model.load_urdf(path, foot_links=feet)
+    assert flat["joint_names"][0].startswith("back_right") and list(flat["foot_body"]) != sorted(flat["foot_body"])
+    orc = oracle_py.Oracle(flat)
+    model = W.Model.from_urdf(path, foot_links=feet)
+    n = 777
+    for obs in (0, 2):
+        P = synth.default_params(observer_order=obs)
+        solver = W.Solver(model, W.Params.from_dict(P), dtype="f64", device=0, max_batch=n)
+        B = synth.make_batch(4, n, model.total_mass, rank=5)
+        integ = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] + 0.02 if obs else None
+        r = 0.1 * np.cos(np.arange(n * 18).reshape(n, 18)) if obs else None
+        ig_ref = None if integ is None else integ.copy()
+        r_ref = None if r is None else r.copy()
+        ref = orc.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"],
+                       B["f_prev"], ig_ref, r_ref, nthreads=8)
+        got = _run_step(torch, solver, B, "f64", integ, r, want_mats=True)
+        d = orc.dynamics(B["q"], B["v"], nthreads=8)
+        for k in ("M", "h", "Jc", "pf"):
+            assert relerr(got[k], d[k]) < TIGHT64, (obs, k)
+        assert np.array_equal(got["status"], ref["status"])
+        assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
+        if obs:
+            assert relerr(got["integ"], ig_ref) < TIGHT64 and relerr(got["r"], r_ref) < TIGHT64
+
+
+def test_qp_wave_kernel_variant_matches(torch_cuda, gpu_model, oracle, monkeypatch):
+    """The LDS wave-per-QP kernel (WBC_QP_KERNEL=wave) stays parity-green too."""
+    torch = torch_cuda
+    monkeypatch.setenv("WBC_QP_KERNEL", "wave")
+    n = 1500
+    solver, P = _solver(gpu_model, obs=1, max_batch=n)
+    monkeypatch.delenv("WBC_QP_KERNEL")
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=9)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    r = np.zeros((n, 18))
+    ig_ref, r_ref = integ.copy(), r.copy()
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"],
+                      B["f_prev"], ig_ref, r_ref, nthreads=8)
+    got = _run_step(torch, solver, B, "f64", integ, r)
+    assert np.array_equal(got["status"], ref["status"])
+    assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
