@@ -21,7 +21,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-DYN_WORDS = 443         # dynamics-sweep stage, in q19+v18(+mask) -> out M171+h18+Jc216
+# Algorithmic words per state of the kernel the roofline is quoted on:
+#   fused dyn_sweep (WBC_SWEEP=fused): SURVEY.md 8(d) dynamics-sweep stage, in q19+v18(+mask) -> out M171+h18+Jc216 = 443
+#   split default: mass_jac_kernel, in q19 -> out M171+Jc216 = 406 (h and the step workspace belong to rnea_step_kernel)
+DYN_WORDS_FUSED = 443
+DYN_WORDS_MASS_JAC = 406
+
+
+def dyn_words(split):
+    return DYN_WORDS_MASS_JAC if split else DYN_WORDS_FUSED
+
+
+def dyn_kernel_name(split):
+    return "mass_jac_kernel" if split else "dyn_sweep_kernel"
 
 
 def main():
@@ -72,6 +84,7 @@ def main():
         rr = torch.zeros_like(integ)
     out = {}
     want_mats = not args.no_mats
+    split = os.environ.get("WBC_SWEEP", "fused") == "split"
 
     def step():
         return solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
@@ -119,7 +132,9 @@ def main():
         ts = 8 if dtype == "f64" else 4
         dyn_s = tm["dyn_ms"] * 1e-3 / max(1, tm["dyn_launches"])
         qp_s = tm["qp_ms"] * 1e-3 / max(1, tm["qp_launches"])
-        dyn_bytes = DYN_WORDS * ts * n
+        rnea_s = tm["rnea_ms"] * 1e-3 / max(1, tm["rnea_launches"])
+        words = dyn_words(split)
+        dyn_bytes = words * ts * n
         achieved = dyn_bytes / dyn_s / 1e9 if want_mats else None
         res = {
             "metric": "WBC control-steps/sec (batched DogBot)",
@@ -140,20 +155,23 @@ def main():
                                                              "on" if obs else "off", dtype),
                        "batch_per_gpu": n, "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "writes_M_h_Jc": want_mats},
-            "roofline": {"kernel": "dyn_sweep_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": dyn_kernel_name(split), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": pmc_traffic("dyn_sweep_kernel", n, dtype),
+                         "traffic": pmc_traffic(dyn_kernel_name(split), n, dtype),
+                         "algorithmic_words_per_state": words,
                          "algorithmic_bytes_per_launch": dyn_bytes, "avg_launch_us": dyn_s * 1e6,
                          "launches_timed": tm["dyn_launches"], "event_pair_overhead_us": ev_overhead_us,
                          "note": "HIP events on the launch stream around every %d-th tick of the timed region; raw span "
                                  "(includes the event-pair overhead reported beside it)" % sample},
-            "kernels": {"dyn_sweep_us": dyn_s * 1e6, "qp_us": qp_s * 1e6, "qp_us_per_state_amortized": qp_s * 1e6 / n,
-                        "qp_kernel": os.environ.get("WBC_QP_KERNEL", "group16")},
+            "kernels": {"dyn_sweep_us": dyn_s * 1e6, "rnea_step_us": rnea_s * 1e6 if split else None, "qp_us": qp_s * 1e6,
+                        "qp_us_per_state_amortized": qp_s * 1e6 / n,
+                        "qp_kernel": os.environ.get("WBC_QP_KERNEL", "group16"),
+                        "sweep": "split: mass_jac on a 2nd stream || rnea_step -> qp" if split else "fused dyn_sweep -> qp"},
             "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                    "iters_max": int(iters.max())},
         }
         if args.large_batch and world == 1:
-            res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs)
+            res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split)
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
         print(json.dumps(res))
@@ -176,7 +194,7 @@ def pmc_traffic(kernel, n, dtype):
     return None
 
 
-def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs):
+def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split):
     """The same two kernels at 262144 states (the largest BASELINE.json batch): where the sweep is bandwidth-bound
     rather than launch/latency-bound.  Not part of `value`."""
     n = args.large_batch
@@ -209,10 +227,12 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs):
     ts = 8 if dtype == "f64" else 4
     dyn_s = tm["dyn_ms"] * 1e-3 / tm["dyn_launches"]
     qp_s = tm["qp_ms"] * 1e-3 / tm["qp_launches"]
-    ach = DYN_WORDS * ts * n / dyn_s / 1e9
-    return {"batch": n, "kernel": "dyn_sweep_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("dyn_sweep_kernel", n, dtype), "avg_launch_us": dyn_s * 1e6,
-            "qp_us": qp_s * 1e6, "steps_per_s": K * n / el, "ms_per_step": el / K * 1e3}
+    ach = dyn_words(split) * ts * n / dyn_s / 1e9
+    return {"batch": n, "kernel": dyn_kernel_name(split), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dyn_kernel_name(split), n, dtype),
+            "algorithmic_words_per_state": dyn_words(split), "avg_launch_us": dyn_s * 1e6,
+            "rnea_step_us": tm["rnea_ms"] * 1e3 / max(1, tm["rnea_launches"]), "qp_us": qp_s * 1e6,
+            "steps_per_s": K * n / el, "ms_per_step": el / K * 1e3}
 
 
 def cpu_baseline(B, P, dtype, n):

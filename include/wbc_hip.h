@@ -146,9 +146,10 @@ int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const d
 
 /* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on ---- */
 int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 events around every kernel; k > 1: every k-th tick */
-/* synchronises the recorded events; returns summed milliseconds and launch counts since the last
- * reset for the dynamics-sweep kernel and the QP kernel; resets the accumulators. */
-int wbc_solver_collect_timing(wbc_solver* s, double* dyn_ms, int* dyn_launches, double* qp_ms, int* qp_launches);
+/* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed
+ * 0 = fused dyn_sweep kernel (or mass_jac with WBC_SWEEP=split), 1 = QP kernel, 2 = rnea_step kernel (split only);
+ * resets the accumulators. */
+int wbc_solver_collect_timing(wbc_solver* s, double ms[3], int launches[3]);
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */

@@ -38,6 +38,36 @@ __global__ __launch_bounds__(64) void k_soa_write(double* __restrict__ out, unsi
     *(double*)((char*)out + (size_t)((comp * N + s) * 8u)) = v + r;
   }
 }
+// same rows, but lane order inside the wave is leg-major: lanes 16*leg .. 16*leg+15 hold 16 consecutive states of
+// ONE component row -> every 16-lane group writes one contiguous 128-byte line
+template <int ROWS>
+__global__ __launch_bounds__(64) void k_soa_write_legmajor(double* __restrict__ out, unsigned N) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned leg = lane >> 4;
+  const unsigned s = blockIdx.x * 16 + (lane & 15);
+  if (s >= N) return;
+  const double v = (double)lane;
+#pragma unroll 8
+  for (int r = 0; r < ROWS / 4; ++r) {
+    const unsigned comp = 4 * r + leg;
+    *(double*)((char*)out + (size_t)((comp * N + s) * 8u)) = v + r;
+  }
+}
+// 16 bytes per lane: lane pairs (state s, s+1) merged: 32 lanes x 16 B cover the same 4 x 128 B per instruction pair
+template <int ROWS>
+__global__ __launch_bounds__(64) void k_soa_write_x4(double* __restrict__ out, unsigned N) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned leg = lane & 3, sl = lane >> 2;       // interleaved order as the sweep kernel
+  const unsigned s = blockIdx.x * 16 + (sl & ~1u);     // even state of the pair
+  const unsigned odd = sl & 1;
+  if (s >= N) return;
+  const double v = (double)lane;
+#pragma unroll 8
+  for (int r = 0; r < ROWS / 8; ++r) {                 // each lane writes half the rows, two states at a time
+    const unsigned comp = 8 * r + 2 * leg + odd;
+    *(double2*)((char*)out + (size_t)((comp * N + s) * 8u)) = make_double2(v + r, v - r);
+  }
+}
 template <class F> float timeit(F f, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -69,6 +99,10 @@ int main() {
     printf("SoA 444 rows N=%6u      : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
     t = timeit([&] { hipLaunchKernelGGL((k_soa_write<444, 1>), dim3(blocks), dim3(64), 0, 0, b, N); }, 20);
     printf("SoA 444 rows N=%6u xcd  : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
+    t = timeit([&] { hipLaunchKernelGGL((k_soa_write_legmajor<444>), dim3((N + 15) / 16), dim3(64), 0, 0, b, N); }, 20);
+    printf("SoA 444 rows N=%6u legmajor lanes : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
+    t = timeit([&] { hipLaunchKernelGGL((k_soa_write_x4<440>), dim3((N + 15) / 16), dim3(64), 0, 0, b, N); }, 20);
+    printf("SoA 440 rows N=%6u 16B/lane pairs : %.1f us  %.0f GB/s\n", N, t * 1e3, (size_t)440 * N * 8 / t / 1e6);
   }
   return 0;
 }

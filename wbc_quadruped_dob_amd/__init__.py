@@ -271,8 +271,12 @@ class Solver:
         _check(lib().wbc_solver_enable_timing(self._h, int(on)), "wbc_solver_enable_timing")
 
     def collect_timing(self):
-        a, b = C.c_double(), C.c_double()
-        na, nb = C.c_int(), C.c_int()
-        _check(lib().wbc_solver_collect_timing(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)),
-               "wbc_solver_collect_timing")
-        return dict(dyn_ms=a.value, dyn_launches=na.value, qp_ms=b.value, qp_launches=nb.value)
+        ms = (C.c_double * 3)()
+        cnt = (C.c_int * 3)()
+        _check(lib().wbc_solver_collect_timing(self._h, ms, cnt), "wbc_solver_collect_timing")
+        names = ("dyn", "qp", "rnea")  # dyn = mass_jac kernel (or the fused sweep with WBC_SWEEP=fused)
+        out = {}
+        for i, n in enumerate(names):
+            out[n + "_ms"] = ms[i]
+            out[n + "_launches"] = cnt[i]
+        return out

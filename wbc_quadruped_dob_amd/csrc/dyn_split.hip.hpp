@@ -1,0 +1,542 @@
+// EXPERIMENT (WBC_SWEEP=split; NOT the default): the dynamics sweep as TWO kernels that run concurrently on two
+// HIP streams.  Measured on MI355X it is 20 % slower per tick at N = 4 096 and 5 % slower at N = 262 144 than the
+// fused dyn_sweep kernel: at small batch each half pays the same fixed latencies (table staging, state loads,
+// sincos chains, store drain) as the fused kernel, and at large batch the duplicated kinematics and the second
+// force recursion cost more than the overlap with the QP kernel returns.  Kept because it is parity-green and
+// documents the negative result.
+//
+//   mass_jac_kernel   (a1, a3, a4)  q        -> M, Jc, pf      store-bound: 387 of the 443 words of the stage
+//   rnea_step_kernel  (a1, a2, a5, a6, a7/a9 prologue)  q, v, vdot_des, w_des -> h, step workspace, observer state
+//
+// Why split: the GRF QP only needs the small workspace (foot positions, own-leg Jacobian blocks, target wrench,
+// tau_partial), none of M / Jc.  With one fused sweep the QP waited for 3.5 kB/state of stores it never reads;
+// now the QP kernel is queued behind rnea_step only, and the store-heavy mass_jac kernel overlaps with it on a
+// second stream (the QP is latency-bound and leaves HBM idle).  Each half also needs far fewer registers than the
+// fused sweep (no scratch, more waves per SIMD), and tau_partial = (M vdot_des + h) comes from a second force
+// recursion in rnea_step instead of from the M entries, so vdot_des is consumed in the first sweep, not loaded late.
+//
+// Same lane-per-leg mapping, DPP quad reductions, LDS constant table and component-major addressing as
+// dyn_sweep.hip.hpp (the fused form, kept selectable with WBC_SWEEP=fused).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+#include "dyn_sweep.hip.hpp"  // V3/M3/S3 helpers, quad_sum, sel4, midx18, sincos_t
+
+namespace wbc {
+
+// MODE bits of rnea_step_kernel
+constexpr int RS_H = 1;     // write h (bias forces)
+constexpr int RS_STEP = 2;  // write the step workspace (d, b, taup, JcL)
+constexpr int RS_OBS = 4;   // momentum / gravity recursions: p, beta outputs and the observer update
+constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
+
+#define WBC_ADDR_MACROS                                                                                                   \
+  const size_t N = a.N;                                                                                                    \
+  const unsigned N32 = (unsigned)N;                                                                                        \
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;                                                        \
+  const int leg = (int)(gid & 3);                                                                                          \
+  const size_t s_raw = gid >> 2;                                                                                           \
+  const bool live = s_raw < N;                                                                                             \
+  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);                                                                   \
+  const unsigned legN = (unsigned)leg * N32;
+#define CS(i) cst[(i) * 4 + leg]
+#define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
+#define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define LDX(ptr, c0, xN) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((xN) + s32) * (unsigned)sizeof(T))))
+#define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STL(ptr, c0, stride, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STLX(ptr, c0, stride, xN, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define MAKE_R(R_, qx, qy, qz, qw) do { const T x = qx, y = qy, z = qz, w = qw; \
+    R_.a[0] = 1 - 2 * (y * y + z * z); R_.a[1] = 2 * (x * y - z * w);     R_.a[2] = 2 * (x * z + y * w); \
+    R_.a[3] = 2 * (x * y + z * w);     R_.a[4] = 1 - 2 * (x * x + z * z); R_.a[5] = 2 * (y * z - x * w); \
+    R_.a[6] = 2 * (x * z - y * w);     R_.a[7] = 2 * (y * z + x * w);     R_.a[8] = 1 - 2 * (x * x + y * y); } while (0)
+
+#ifndef WBC_MJ_WAVES
+#define WBC_MJ_WAVES 2
+#endif
+#ifndef WBC_RS_WAVES
+#define WBC_RS_WAVES 2
+#endif
+
+// ======================================================================================================================
+// mass_jac_kernel: M(q) by CRBA, Jc(q), pf(q).  No velocities anywhere.
+// ======================================================================================================================
+template <class T, int BLOCK>
+__global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const DevModel<T>* __restrict__ model, SweepArgs<T> a) {
+  __shared__ T cst[CST_WORDS];
+  __shared__ int zidx_s[64];
+  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
+  if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
+  __syncthreads();
+  WBC_ADDR_MACROS
+
+  T qq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qq[c] = LDU(a.q, 3 + c);
+  int jx[3];
+  unsigned jxN[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { jx[k] = model->jidx[leg][k]; jxN[k] = (unsigned)jx[k] * N32; }
+  T ql[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ql[k] = LDX(a.q, 7, jxN[k]);
+
+  // structural zeros / ones first: they drain while the sweeps compute
+  {
+    const T Z = (T)0;
+    for (int e = leg; e < 64; e += 4) {
+      const int zi = zidx_s[e];
+      if (zi >= 0) STV(a.M, zi, Z);
+    }
+#pragma unroll
+    for (int mrow = 0; mrow < 3; ++mrow) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) STL(a.Jc, 18 * mrow + c, 54, (c == mrow) ? (T)1 : Z);
+      STL(a.Jc, 18 * mrow + 3 + mrow, 54, Z);
+#pragma unroll
+      for (int c = 0; c < 12; ++c) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);
+    }
+  }
+  T qx, qy, qz, qw;
+  {
+    const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
+  }
+  // joint transforms: E of joints 0 and 1 wait in LDS ([word][lane]) until the return sweep reaches them
+  __shared__ T park[18][BLOCK];
+  const int ln = threadIdx.x;
+  M3<T> E2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int o = JOINT_WORDS * k;
+    T sn, cs;
+    sincos_t(ql[k], &sn, &cs);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      const T v = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+      if (k < 2) park[9 * k + e][ln] = v; else E2.a[e] = v;
+    }
+  }
+  // return sweep: composite inertias, CRBA force columns, Jacobian columns
+  T cm; V3<T> ch; S3<T> cI;
+  V3<T> dft = mk<T>(CS(129), CS(130), CS(131));
+  V3<T> jc[3];
+  SF<T> Fp[3];
+#pragma unroll
+  for (int k = 2; k >= 0; --k) {
+    const int o = JOINT_WORDS * k;
+    const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
+    const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
+    const T m = CS(o + 33);
+    const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
+    S3<T> Io;
+    Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
+    M3<T> E;
+    if (k == 2) E = E2;
+    else {
+#pragma unroll
+      for (int e = 0; e < 9; ++e) E.a[e] = park[9 * k + e][ln];
+    }
+    if (k == 2) { cm = m; ch = h; cI = Io; }
+    else {
+      cm += m; ch = ch + h;
+      cI.xx += Io.xx; cI.xy += Io.xy; cI.xz += Io.xz; cI.yy += Io.yy; cI.yz += Io.yz; cI.zz += Io.zz;
+    }
+    Fp[k].n = mul(cI, ax);
+    Fp[k].f = cross(ax, ch);
+#pragma unroll
+    for (int j = k; j < 3; ++j) {
+      const T mkj = dot(ax, Fp[j].n);
+      int i = 6 + jx[k], jj = 6 + jx[j];
+      if (i > jj) { const int t = i; i = jj; jj = t; }
+      STV(a.M, i * 18 - i * (i - 1) / 2 + (jj - i), mkj);
+    }
+    jc[k] = cross(ax, dft);
+    dft = r + mul(E, dft);
+#pragma unroll
+    for (int j = k; j < 3; ++j) { jc[j] = mul(E, jc[j]); Fp[j] = to_parent(E, r, Fp[j]); }
+    {
+      const V3<T> hr = mul(E, ch);
+      const S3<T> Ir = congr(E, cI);
+      const V3<T> w = hr + r * (cm * (T)0.5);
+      const T sc = 2 * dot(w, r);
+      cI.xx = Ir.xx + sc - 2 * w.x * r.x;
+      cI.yy = Ir.yy + sc - 2 * w.y * r.y;
+      cI.zz = Ir.zz + sc - 2 * w.z * r.z;
+      cI.xy = Ir.xy - (w.x * r.y + r.x * w.y);
+      cI.xz = Ir.xz - (w.x * r.z + r.x * w.z);
+      cI.yz = Ir.yz - (w.y * r.z + r.y * w.z);
+      ch = hr + r * cm;
+    }
+  }
+  M3<T> R;
+  MAKE_R(R, qx, qy, qz, qw);
+  const V3<T> dw = mul(R, dft);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const V3<T> Mf = mul(R, Fp[k].f), Mn = mul(R, Fp[k].n);
+    const unsigned x = jxN[k];
+    STLX(a.M, 6, 0, x, Mf.x);
+    STLX(a.M, midx18(1, 1) + 5, 0, x, Mf.y);
+    STLX(a.M, midx18(2, 2) + 4, 0, x, Mf.z);
+    STLX(a.M, midx18(3, 3) + 3, 0, x, Mn.x);
+    STLX(a.M, midx18(4, 4) + 2, 0, x, Mn.y);
+    STLX(a.M, midx18(5, 5) + 1, 0, x, Mn.z);
+    const V3<T> jw = mul(R, jc[k]);
+    STLX(a.Jc, 0 * 18 + 6, 54, x, jw.x);  // overwrites a zero written above (same lane, program order)
+    STLX(a.Jc, 1 * 18 + 6, 54, x, jw.y);
+    STLX(a.Jc, 2 * 18 + 6, 54, x, jw.z);
+  }
+  STL(a.Jc, 0 * 18 + 4, 54, dw.z);  STL(a.Jc, 0 * 18 + 5, 54, -dw.y);
+  STL(a.Jc, 1 * 18 + 3, 54, -dw.z); STL(a.Jc, 1 * 18 + 5, 54, dw.x);
+  STL(a.Jc, 2 * 18 + 3, 54, dw.y);  STL(a.Jc, 2 * 18 + 4, 54, -dw.x);
+  if (a.pf) {
+    STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
+    STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
+    STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
+  }
+  {
+    const T bm = model->base_m;
+    const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
+    const T tm = quad_sum(cm) + bm;
+    const V3<T> th = quad_sum(ch) + bh;
+    S3<T> tI;
+    tI.xx = quad_sum(cI.xx) + model->base_Io[0]; tI.xy = quad_sum(cI.xy) + model->base_Io[1]; tI.xz = quad_sum(cI.xz) + model->base_Io[2];
+    tI.yy = quad_sum(cI.yy) + model->base_Io[3]; tI.yz = quad_sum(cI.yz) + model->base_Io[4]; tI.zz = quad_sum(cI.zz) + model->base_Io[5];
+    const V3<T> hw = mul(R, th);
+    const S3<T> Iw = congr(R, tI);
+    T* M = a.M;
+    ST4(M, midx18(0, 0), tm, midx18(1, 1), tm, midx18(2, 2), tm, midx18(0, 4), hw.z);
+    ST4(M, midx18(0, 5), -hw.y, midx18(1, 3), -hw.z, midx18(1, 5), hw.x, midx18(2, 3), hw.y);
+    ST4(M, midx18(2, 4), -hw.x, midx18(3, 3), Iw.xx, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz);
+    if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
+  }
+}
+
+// ======================================================================================================================
+// rnea_step_kernel: bias forces h, tau_partial = (M vdot_des + h - rhat) by a second (acceleration-only) force
+// recursion, foot geometry for the QP, momentum observer.
+// ======================================================================================================================
+template <class T, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+                                                                         SweepArgs<T> a) {
+  constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
+  constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
+  constexpr bool TWO = STEP && WH;              // h and tau_partial both wanted: two force chains; else one (merged)
+  constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
+  __shared__ T cst[CST_WORDS];
+  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
+  __syncthreads();
+  WBC_ADDR_MACROS
+
+  T qq[4], vb[6];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qq[c] = LDU(a.q, 3 + c);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) vb[c] = LDU(a.v, c);
+  int jx[3];
+  unsigned jxN[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { jx[k] = model->jidx[leg][k]; jxN[k] = (unsigned)jx[k] * N32; }
+  T ql[3], vl[3], al[3] = {0, 0, 0}, ad[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { ql[k] = LDX(a.q, 7, jxN[k]); vl[k] = LDX(a.v, 6, jxN[k]); }
+  if (STEP) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) al[k] = LDX(a.vdot_des, 6, jxN[k]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
+  }
+  if (STEP && !OBS) {  // observer off: the QP target wrench is just w_des
+    T b[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c);
+    ST4(a.ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+    if (leg < 2) STV(a.ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+  }
+  T qx, qy, qz, qw;
+  {
+    const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
+  }
+  const T bm = model->base_m;
+  const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
+  S3<T> bI;
+  bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
+  bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
+
+  // parked per joint (k = 0, 1): E 9, chain-b force 6, [chain-a force 6], [OBS: momentum 6, weight 6, velocity 6]
+  constexpr int PW = 15 + (TWO ? 6 : 0) + (OBS ? 18 : 0);
+  constexpr int PB = BASEROWS ? (OBS ? 18 : 6) : 1;
+  __shared__ T park[2 * PW + PB][BLOCK];
+  const int ln = threadIdx.x;
+  constexpr int OFF_A = 15, OFF_O = 15 + (TWO ? 6 : 0);
+
+  V3<T> omp, vp, aAp, aLp, gLp, a2Ap, a2Lp;
+  {
+    M3<T> R;
+    MAKE_R(R, qx, qy, qz, qw);
+    const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
+    const V3<T> v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
+    const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));
+    const V3<T> aL0 = gneg - cross(om0, v0);
+    if (BASEROWS) {
+      const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+      const SF<T> Ia0 = inertia_mul(bm, bh, bI, mk<T>(0, 0, 0), aL0);
+      T* pb = &park[2 * PW][ln];
+      const V3<T> bwn = Ia0.n + cross(om0, Iv0.n) + cross(v0, Iv0.f), bwf = Ia0.f + cross(om0, Iv0.f);
+      pb[0] = bwn.x; pb[BLOCK] = bwn.y; pb[BLOCK * 2] = bwn.z; pb[BLOCK * 3] = bwf.x; pb[BLOCK * 4] = bwf.y; pb[BLOCK * 5] = bwf.z;
+      if (OBS) {
+        const V3<T> gn = cross(bh, gneg), gf = gneg * bm;
+        pb[BLOCK * 6] = Iv0.n.x; pb[BLOCK * 7] = Iv0.n.y; pb[BLOCK * 8] = Iv0.n.z; pb[BLOCK * 9] = Iv0.f.x; pb[BLOCK * 10] = Iv0.f.y; pb[BLOCK * 11] = Iv0.f.z;
+        pb[BLOCK * 12] = gn.x; pb[BLOCK * 13] = gn.y; pb[BLOCK * 14] = gn.z; pb[BLOCK * 15] = gf.x; pb[BLOCK * 16] = gf.y; pb[BLOCK * 17] = gf.z;
+      }
+    }
+    omp = om0; vp = v0; aAp = mk<T>(0, 0, 0); aLp = aL0; gLp = gneg;
+    a2Ap = tmul(R, mk<T>(ad[3], ad[4], ad[5]));   // acceleration-only chain: base [R^T wdot ; R^T pddot]
+    a2Lp = tmul(R, mk<T>(ad[0], ad[1], ad[2]));
+    if (STEP && !TWO) { aAp = aAp + a2Ap; aLp = aLp + a2Lp; }  // one merged chain: RNEA(q, v, vdot_des)
+  }
+
+  // ------------------------------------------------------------------ forward sweep
+  M3<T> E2;
+  SF<T> f2, fa2, m2, g2;
+  V3<T> om2, vv2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int o = JOINT_WORDS * k;
+    T sn, cs;
+    sincos_t(ql[k], &sn, &cs);
+    M3<T> E;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+    const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
+    const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
+    const T m = CS(o + 33);
+    const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
+    S3<T> Io;
+    Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
+    const T qd = vl[k];
+    const V3<T> om = tmul(E, omp) + ax * qd;
+    const V3<T> vv = tmul(E, vp + cross(omp, r));
+    V3<T> aA = tmul(E, aAp) + cross(om, ax) * qd;
+    const V3<T> aL = tmul(E, aLp + cross(aAp, r)) + cross(vv, ax) * qd;
+    if (STEP && !TWO) aA = aA + ax * al[k];
+    const SF<T> Iv = inertia_mul(m, h, Io, om, vv);
+    const SF<T> Ia = inertia_mul(m, h, Io, aA, aL);
+    SF<T> fk, fak, gk;
+    fk.n = Ia.n + cross(om, Iv.n) + cross(vv, Iv.f);
+    fk.f = Ia.f + cross(om, Iv.f);
+    if (TWO) {
+      const V3<T> a2A = tmul(E, a2Ap) + ax * al[k];
+      const V3<T> a2L = tmul(E, a2Lp + cross(a2Ap, r));
+      fak = inertia_mul(m, h, Io, a2A, a2L);
+      a2Ap = a2A; a2Lp = a2L;
+    }
+    if (OBS) {
+      const V3<T> gL = tmul(E, gLp);
+      gk.n = cross(h, gL);
+      gk.f = gL * m;
+      gLp = gL;
+    }
+    if (k < 2) {
+      T* pk = &park[PW * k][ln];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) pk[BLOCK * e] = E.a[e];
+      pk[BLOCK * 9] = fk.n.x; pk[BLOCK * 10] = fk.n.y; pk[BLOCK * 11] = fk.n.z;
+      pk[BLOCK * 12] = fk.f.x; pk[BLOCK * 13] = fk.f.y; pk[BLOCK * 14] = fk.f.z;
+      if (TWO) {
+        pk[BLOCK * (OFF_A + 0)] = fak.n.x; pk[BLOCK * (OFF_A + 1)] = fak.n.y; pk[BLOCK * (OFF_A + 2)] = fak.n.z;
+        pk[BLOCK * (OFF_A + 3)] = fak.f.x; pk[BLOCK * (OFF_A + 4)] = fak.f.y; pk[BLOCK * (OFF_A + 5)] = fak.f.z;
+      }
+      if (OBS) {
+        pk[BLOCK * (OFF_O + 0)] = Iv.n.x; pk[BLOCK * (OFF_O + 1)] = Iv.n.y; pk[BLOCK * (OFF_O + 2)] = Iv.n.z;
+        pk[BLOCK * (OFF_O + 3)] = Iv.f.x; pk[BLOCK * (OFF_O + 4)] = Iv.f.y; pk[BLOCK * (OFF_O + 5)] = Iv.f.z;
+        pk[BLOCK * (OFF_O + 6)] = gk.n.x; pk[BLOCK * (OFF_O + 7)] = gk.n.y; pk[BLOCK * (OFF_O + 8)] = gk.n.z;
+        pk[BLOCK * (OFF_O + 9)] = gk.f.x; pk[BLOCK * (OFF_O + 10)] = gk.f.y; pk[BLOCK * (OFF_O + 11)] = gk.f.z;
+        pk[BLOCK * (OFF_O + 12)] = om.x; pk[BLOCK * (OFF_O + 13)] = om.y; pk[BLOCK * (OFF_O + 14)] = om.z;
+        pk[BLOCK * (OFF_O + 15)] = vv.x; pk[BLOCK * (OFF_O + 16)] = vv.y; pk[BLOCK * (OFF_O + 17)] = vv.z;
+      }
+    } else {
+      E2 = E; f2 = fk;
+      if (TWO) fa2 = fak;
+      if (OBS) { m2 = Iv; g2 = gk; om2 = om; vv2 = vv; }
+    }
+    omp = om; vp = vv; aAp = aA; aLp = aL;
+  }
+
+  // ------------------------------------------------------------------ return sweep
+  T p_leg[3], ct_leg[3], g_leg[3], taup[3] = {0, 0, 0};
+  V3<T> dft = mk<T>(CS(129), CS(130), CS(131));
+  V3<T> jc[3];
+  SF<T> facc, aacc, macc, gacc;
+#pragma unroll
+  for (int k = 2; k >= 0; --k) {
+    const int o = JOINT_WORDS * k;
+    const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
+    const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
+    M3<T> E;
+    SF<T> fk, fak, mk_, gk;
+    V3<T> om, vv;
+    if (k == 2) {
+      E = E2; fk = f2;
+      if (TWO) fak = fa2;
+      if (OBS) { mk_ = m2; gk = g2; om = om2; vv = vv2; }
+    } else {
+      const T* pk = &park[PW * k][ln];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) E.a[e] = pk[BLOCK * e];
+      fk.n = mk<T>(pk[BLOCK * 9], pk[BLOCK * 10], pk[BLOCK * 11]) + facc.n;
+      fk.f = mk<T>(pk[BLOCK * 12], pk[BLOCK * 13], pk[BLOCK * 14]) + facc.f;
+      if (TWO) {
+        fak.n = mk<T>(pk[BLOCK * (OFF_A + 0)], pk[BLOCK * (OFF_A + 1)], pk[BLOCK * (OFF_A + 2)]) + aacc.n;
+        fak.f = mk<T>(pk[BLOCK * (OFF_A + 3)], pk[BLOCK * (OFF_A + 4)], pk[BLOCK * (OFF_A + 5)]) + aacc.f;
+      }
+      if (OBS) {
+        mk_.n = mk<T>(pk[BLOCK * (OFF_O + 0)], pk[BLOCK * (OFF_O + 1)], pk[BLOCK * (OFF_O + 2)]) + macc.n;
+        mk_.f = mk<T>(pk[BLOCK * (OFF_O + 3)], pk[BLOCK * (OFF_O + 4)], pk[BLOCK * (OFF_O + 5)]) + macc.f;
+        gk.n = mk<T>(pk[BLOCK * (OFF_O + 6)], pk[BLOCK * (OFF_O + 7)], pk[BLOCK * (OFF_O + 8)]) + gacc.n;
+        gk.f = mk<T>(pk[BLOCK * (OFF_O + 9)], pk[BLOCK * (OFF_O + 10)], pk[BLOCK * (OFF_O + 11)]) + gacc.f;
+        om = mk<T>(pk[BLOCK * (OFF_O + 12)], pk[BLOCK * (OFF_O + 13)], pk[BLOCK * (OFF_O + 14)]);
+        vv = mk<T>(pk[BLOCK * (OFF_O + 15)], pk[BLOCK * (OFF_O + 16)], pk[BLOCK * (OFF_O + 17)]);
+      }
+    }
+    {
+      const T hk = dot(ax, fk.n);  // bias torque (TWO) or merged M vdot_des + h (one chain)
+      if (WH) STLX(a.h, 6, 0, jxN[k], hk);
+      if (STEP) taup[k] = hk + (TWO ? dot(ax, fak.n) : (T)0);
+    }
+    if (OBS) {
+      p_leg[k] = dot(ax, mk_.n);
+      ct_leg[k] = -dot(ax, cross(om, mk_.n) + cross(vv, mk_.f));
+      g_leg[k] = dot(ax, gk.n);
+    }
+    if (GEOM) {
+      jc[k] = cross(ax, dft);
+      dft = r + mul(E, dft);
+#pragma unroll
+      for (int j = k; j < 3; ++j) jc[j] = mul(E, jc[j]);
+    }
+    if (k > 0 || BASEROWS) facc = to_parent(E, r, fk);
+    if (TWO && k > 0) aacc = to_parent(E, r, fak);
+    if (OBS) { macc = to_parent(E, r, mk_); gacc = to_parent(E, r, gk); }
+  }
+
+  M3<T> R;
+  MAKE_R(R, qx, qy, qz, qw);
+  V3<T> dw = mk<T>(0, 0, 0), jw[3];
+  if (GEOM) {
+    dw = mul(R, dft);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) jw[k] = mul(R, jc[k]);
+  }
+  if (WPF && a.pf) {
+    STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
+    STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
+    STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
+  }
+  if (STEP) {
+    STL(a.ws, WS_D + 0, 3, dw.x);
+    STL(a.ws, WS_D + 1, 3, dw.y);
+    STL(a.ws, WS_D + 2, 3, dw.z);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      STL(a.ws, WS_JCL + 0 + k, 9, jw[k].x);
+      STL(a.ws, WS_JCL + 3 + k, 9, jw[k].y);
+      STL(a.ws, WS_JCL + 6 + k, 9, jw[k].z);
+    }
+  }
+  if (WH) {
+    const T* pb = &park[2 * PW][ln];
+    const V3<T> bfn = quad_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);
+    const V3<T> bff = quad_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
+    const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);
+    ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
+    if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
+  }
+  T p_b[6], beta_b[6], beta_l[3];
+  if (OBS) {
+    const T* pb = &park[2 * PW][ln];
+    SF<T> mom0, grv0;
+    mom0.n = quad_sum(macc.n) + mk<T>(pb[BLOCK * 6], pb[BLOCK * 7], pb[BLOCK * 8]);
+    mom0.f = quad_sum(macc.f) + mk<T>(pb[BLOCK * 9], pb[BLOCK * 10], pb[BLOCK * 11]);
+    grv0.n = quad_sum(gacc.n) + mk<T>(pb[BLOCK * 12], pb[BLOCK * 13], pb[BLOCK * 14]);
+    grv0.f = quad_sum(gacc.f) + mk<T>(pb[BLOCK * 15], pb[BLOCK * 16], pb[BLOCK * 17]);
+    const V3<T> Pl = mul(R, mom0.f), Pa = mul(R, mom0.n);
+    const V3<T> gl = mul(R, grv0.f), ga = mul(R, grv0.n);
+    const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
+    p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
+    beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
+    beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) beta_l[k] = ct_leg[k] - g_leg[k];
+    if (a.p) {
+      ST4(a.p, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) STV(a.p, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) STLX(a.p, 6, 0, jxN[k], p_leg[k]);
+    }
+    if (a.beta) {
+      ST4(a.beta, 0, beta_b[0], 1, beta_b[1], 2, beta_b[2], 3, beta_b[3]);
+      if (leg < 2) STV(a.beta, 4 + leg, leg == 0 ? beta_b[4] : beta_b[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) STLX(a.beta, 6, 0, jxN[k], beta_l[k]);
+    }
+  }
+  if (STEP) {
+    T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
+    if (OBS && prm.observer_order > 0) {
+      const V3<T> fp = mk<T>(LDV(a.f_prev, 3 * leg + 0), LDV(a.f_prev, 3 * leg + 1), LDV(a.f_prev, 3 * leg + 2));
+      const V3<T> ub_f = quad_sum(fp);
+      const V3<T> ub_n = quad_sum(cross(dw, fp));
+      const T ub[6] = {ub_f.x, ub_f.y, ub_f.z, ub_n.x, ub_n.y, ub_n.z};
+      const T dt = prm.dt;
+      const bool o1 = prm.observer_order == 1;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const T r0 = LDU(a.obs_r, c);
+        const T ig = LDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
+        const T e = p_b[c] - ig;
+        rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        p_b[c] = ig;
+      }
+      ST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) STV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      ST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+      if (leg < 2) STV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int c = 6 + jx[k];
+        const T r0 = LDV(a.obs_r, c);
+        const T u = LDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
+        const T ig = LDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
+        const T e = p_leg[k] - ig;
+        rl[k] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        STV(a.obs_integ, c, ig);
+        STV(a.obs_r, c, rl[k]);
+      }
+    }
+    if (OBS) {
+      T b[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
+      ST4(a.ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+      if (leg < 2) STV(a.ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) STL(a.ws, WS_TAUP + k, 3, taup[k] - rl[k]);
+  }
+}
+
+#undef MAKE_R
+#undef ST4
+#undef STLX
+#undef STL
+#undef STV
+#undef LDX
+#undef LDV
+#undef LDU
+#undef CS
+
+}  // namespace wbc

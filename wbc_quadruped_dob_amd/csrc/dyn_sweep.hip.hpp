@@ -1,11 +1,11 @@
 // Dynamics-sweep kernel for gfx950 (CDNA4): SURVEY.md 8(a) units a1-a7/a9-prologue for one batch.
 //
 // Mapping: ONE LANE PER LEG.  A quadruped's four legs are independent subtrees of the floating
-// base, so lanes 4s..4s+3 of a wave own the four legs of state s (16 states per 64-wide wave).
+// base; lane 16*leg + s of a wave owns leg `leg` of the wave's state s (16 states per 64-wide wave).
 // Everything leg-local (joint transforms, RNEA/CRBA/momentum sweeps up and down the 3-joint
 // chain, the leg's Jacobian block) runs without communication; the only cross-lane traffic is
 // the leaf->root accumulation into the base (leg wrench, leg momentum, leg composite inertia),
-// done with DPP quad_perm adds -- no LDS, no barriers.  Per-leg model constants are staged once
+// done with v_permlane16/32_swap row exchanges (gfx950) -- no LDS, no barriers.  Per-leg model constants are staged once
 // per block in LDS as cst[word][leg] (four consecutive words per row: conflict-free).
 // HBM layout is component-major x[c*N+s]: every load/store instruction of a wave touches four
 // fully used 128-byte lines (16 consecutive states x 8 B per leg-specific component), base
@@ -100,9 +100,73 @@ template <class T> WBC_DEV T quad_sum(T x) {
 }
 template <class T> WBC_DEV V3<T> quad_sum(V3<T> v) { return mk<T>(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z)); }
 
+// ---- cross-ROW reductions: the four legs of a state sit in the four 16-lane rows of the wave (lane = 16*leg + s),
+// so that every 16-lane group reads and writes 16 consecutive states of ONE component row = one whole 128-byte
+// line (tools/bw_probe.hip: 5.5-6.3 TB/s for this lane order against 4.1-4.7 TB/s when the legs of a state are
+// adjacent lanes).  gfx950's v_permlane16_swap / v_permlane32_swap exchange rows inside the VALU: with both
+// operands equal they return (even rows replicated, odd rows replicated), whose sum is the xor-16 / xor-32 sum.
+WBC_DEV int xsum16_parts(int x, int& other) {
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  other = r[1];
+  return r[0];
+}
+WBC_DEV int xsum32_parts(int x, int& other) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  other = r[1];
+  return r[0];
+}
+WBC_DEV double xrow_sum(double x) {
+  {
+    int lo = __double2loint(x), hi = __double2hiint(x), lo2, hi2;
+    lo = xsum16_parts(lo, lo2); hi = xsum16_parts(hi, hi2);
+    x = __hiloint2double(hi, lo) + __hiloint2double(hi2, lo2);
+  }
+  {
+    int lo = __double2loint(x), hi = __double2hiint(x), lo2, hi2;
+    lo = xsum32_parts(lo, lo2); hi = xsum32_parts(hi, hi2);
+    x = __hiloint2double(hi, lo) + __hiloint2double(hi2, lo2);
+  }
+  return x;
+}
+WBC_DEV float xrow_sum(float x) {
+  int o;
+  int a = xsum16_parts(__float_as_int(x), o);
+  x = __int_as_float(a) + __int_as_float(o);
+  a = xsum32_parts(__float_as_int(x), o);
+  return __int_as_float(a) + __int_as_float(o);
+}
+template <class T> WBC_DEV V3<T> xrow_sum(V3<T> v) { return mk<T>(xrow_sum(v.x), xrow_sum(v.y), xrow_sum(v.z)); }
+
 template <class T> WBC_DEV T sel4(int leg, T a, T b, T c, T d) { return leg == 0 ? a : (leg == 1 ? b : (leg == 2 ? c : d)); }
 
-WBC_DEV void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
+// fp64 sin/cos, straight-line (no branches, so the three joints of a leg interleave in the pipeline): two-term
+// Cody-Waite reduction by pi/2 with FMA, then the classic degree-13 / degree-14 minimax kernels on |r| <= pi/4
+// (coefficients of the well-known fdlibm kernels; < 1 ulp there).  Valid for |x| up to ~1e5 rad -- joint angles.
+// ocml's sincos() handles 1e300 through a Payne-Hanek branch and costs ~4x the latency of this form.
+WBC_DEV void sincos_t(double x, double* sp, double* cp) {
+  const double n = rint(x * 0.6366197723675814);             // 2/pi
+  double r = fma(-n, 1.5707963267948966, x);                 // pi/2 high part
+  r = fma(-n, 6.123233995736766e-17, r);                     // pi/2 low part
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = fma(ps, z, -2.50507602534068634195e-08);
+  ps = fma(ps, z, 2.75573137070700676789e-06);
+  ps = fma(ps, z, -1.98412698298579493134e-04);
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = fma(pc, z, 2.08757232129817482790e-09);
+  pc = fma(pc, z, -2.75573143513906633035e-07);
+  pc = fma(pc, z, 2.48015872894767294178e-05);
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)n & 3;
+  const double s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+  *sp = (q & 2) ? -s1 : s1;
+  *cp = ((q + 1) & 2) ? -c1 : c1;
+}
 WBC_DEV void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
 WBC_DEV double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 WBC_DEV float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
@@ -125,15 +189,20 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0;
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
-  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
-  if (MATS && threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  __syncthreads();
+#ifdef WBC_SWEEP_STAMP  // diagnostic build only: cycle stamps per phase, written over the pf output
+  long long stp[13];
+  int stn = 0;
+#define SSTAMP() do { stp[stn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SSTAMP() do {} while (0)
+#endif
+  SSTAMP();  // 0: kernel entry
 
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int leg = (int)(gid & 3);
-  const size_t s_raw = gid >> 2;
+  // lane = 16*leg + (state within the wave): each 16-lane row owns one leg of 16 consecutive states
+  const int leg = (int)((threadIdx.x & 63) >> 4);
+  const size_t s_raw = ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);
   const bool live = s_raw < N;
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);  // dead lanes recompute the last state, stores are masked
   const unsigned legN = (unsigned)leg * N32;
@@ -168,6 +237,13 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     vl[k] = *(const T*)((const char*)(a.v + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
   }
 
+  SSTAMP();  // 1: state loads issued
+  // the per-leg constant table is staged AFTER the state loads have been issued: one memory round trip, not two
+  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
+  if (MATS && threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
+  __syncthreads();
+  SSTAMP();  // 2: table staged (barrier passed)
+
   // observer off: the QP target wrench is just w_des -- forward it now, while the loads are in flight anyway
   if (STEP && !OBS) {
     T b[6];
@@ -196,6 +272,7 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
   }
 
   // ------------------------------------------------------------------ base
+  SSTAMP();  // 3: early stores issued
   // unit quaternion kept (4 words); R is rebuilt after the sweeps instead of living through them (9 words)
   T qx, qy, qz, qw;
   {
@@ -239,6 +316,7 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     omp = om0; vp = v0; aAp = mk<T>(0, 0, 0); aLp = aL0; gLp = gneg;
   }
 
+  SSTAMP();  // 4: base quantities done (state loads have arrived)
   // ------------------------------------------------------------------ forward sweep down the leg
   // Per-joint results that the return sweep needs (E, body force, and for the observer the body
   // momentum, weight and velocity) are PARKED IN LDS for joints 0 and 1 ([word][lane]: conflict-free),
@@ -294,6 +372,7 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     omp = om; vp = vv; aAp = aA; aLp = aL;
   }
 
+  SSTAMP();  // 5: forward sweep done
   // ------------------------------------------------------------------ return sweep up the leg
   T al[3] = {0, 0, 0};
   if (STEP) {
@@ -386,6 +465,7 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
       ch = hr + r * cm;
     }
   }
+  SSTAMP();  // 6: return sweep done
   // now: facc (macc, gacc) = leg wrench at the base, base coords; (cm,ch,cI) = leg composite in base
   // coords; dft = foot relative to base origin in base coords; jc[], Fp[] in base coords.
   M3<T> R;
@@ -444,19 +524,20 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     }
   }
 
+  SSTAMP();  // 7: leg outputs stored
   // ------------------------------------------------------------------ quad reductions into the base
   if (MATS) {
     const T* pb = &park[2 * PW][ln];
-    const V3<T> bfn = quad_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);   // total bias wrench, base coords
-    const V3<T> bff = quad_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
+    const V3<T> bfn = xrow_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);   // total bias wrench, base coords
+    const V3<T> bff = xrow_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
     const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);  // h base rows (force, moment), world
     ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
     if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
-    const T tm = quad_sum(cm) + bm;
-    const V3<T> th = quad_sum(ch) + bh;
+    const T tm = xrow_sum(cm) + bm;
+    const V3<T> th = xrow_sum(ch) + bh;
     S3<T> tI;
-    tI.xx = quad_sum(cI.xx) + bI.xx; tI.xy = quad_sum(cI.xy) + bI.xy; tI.xz = quad_sum(cI.xz) + bI.xz;
-    tI.yy = quad_sum(cI.yy) + bI.yy; tI.yz = quad_sum(cI.yz) + bI.yz; tI.zz = quad_sum(cI.zz) + bI.zz;
+    tI.xx = xrow_sum(cI.xx) + bI.xx; tI.xy = xrow_sum(cI.xy) + bI.xy; tI.xz = xrow_sum(cI.xz) + bI.xz;
+    tI.yy = xrow_sum(cI.yy) + bI.yy; tI.yz = xrow_sum(cI.yz) + bI.yz; tI.zz = xrow_sum(cI.zz) + bI.zz;
     const V3<T> hw = mul(R, th);
     const S3<T> Iw = congr(R, tI);
     // base 6x6 block: 15 data-dependent entries (the 6 structural zeros went out with the early stores)
@@ -469,12 +550,13 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
   SF<T> mom0, grv0;
   if (OBS) {
     const T* pb = &park[2 * PW][ln];
-    mom0.n = quad_sum(macc.n) + mk<T>(pb[BLOCK * 6], pb[BLOCK * 7], pb[BLOCK * 8]);
-    mom0.f = quad_sum(macc.f) + mk<T>(pb[BLOCK * 9], pb[BLOCK * 10], pb[BLOCK * 11]);
-    grv0.n = quad_sum(gacc.n) + mk<T>(pb[BLOCK * 12], pb[BLOCK * 13], pb[BLOCK * 14]);
-    grv0.f = quad_sum(gacc.f) + mk<T>(pb[BLOCK * 15], pb[BLOCK * 16], pb[BLOCK * 17]);
+    mom0.n = xrow_sum(macc.n) + mk<T>(pb[BLOCK * 6], pb[BLOCK * 7], pb[BLOCK * 8]);
+    mom0.f = xrow_sum(macc.f) + mk<T>(pb[BLOCK * 9], pb[BLOCK * 10], pb[BLOCK * 11]);
+    grv0.n = xrow_sum(gacc.n) + mk<T>(pb[BLOCK * 12], pb[BLOCK * 13], pb[BLOCK * 14]);
+    grv0.f = xrow_sum(gacc.f) + mk<T>(pb[BLOCK * 15], pb[BLOCK * 16], pb[BLOCK * 17]);
   }
 
+  SSTAMP();  // 8: base block stored
   // ------------------------------------------------------------------ momentum, beta = C^T v - g
   T p_b[6], beta_b[6], beta_l[3];
   if (OBS) {
@@ -506,8 +588,8 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     if (OBS && prm.observer_order > 0) {
       // generalized force of the previous commands at the current configuration
       const V3<T> fp = mk<T>(LDV(a.f_prev, 3 * leg + 0), LDV(a.f_prev, 3 * leg + 1), LDV(a.f_prev, 3 * leg + 2));
-      const V3<T> ub_f = quad_sum(fp);
-      const V3<T> ub_n = quad_sum(cross(dw, fp));
+      const V3<T> ub_f = xrow_sum(fp);
+      const V3<T> ub_n = xrow_sum(cross(dw, fp));
       const T ub[6] = {ub_f.x, ub_f.y, ub_f.z, ub_n.x, ub_n.y, ub_n.z};
       const T dt = prm.dt;
       const bool o1 = prm.observer_order == 1;
@@ -548,6 +630,15 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
 #pragma unroll
     for (int k = 0; k < 3; ++k) STL(ws, WS_TAUP + k, 3, taup[k] - rl[k]);
   }
+#ifdef WBC_SWEEP_STAMP
+  SSTAMP();  // 9: everything issued
+  __builtin_amdgcn_s_waitcnt(0);  // drain: all stores acknowledged
+  SSTAMP();  // 10
+  if (a.pf && leg < 3)
+    for (int m = 0; m < 3; ++m) STL(a.pf, m, 3, (T)(stp[3 * leg + m + 1] - stp[3 * leg + m]));
+  if (a.pf && leg == 3) STL(a.pf, 0, 3, (T)(stp[10] - stp[9]));
+#endif
+#undef SSTAMP
 #undef MAKE_R
 #undef ST4
 #undef STLX

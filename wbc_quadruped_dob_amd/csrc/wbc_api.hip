@@ -14,6 +14,7 @@
 
 #include "device_types.hpp"
 #include "dyn_sweep.hip.hpp"
+#include "dyn_split.hip.hpp"
 #include "model.hpp"
 #include "qp_wave.hip.hpp"
 #include "qp_group16.hip.hpp"
@@ -41,6 +42,10 @@ struct wbc_solver {
   void* d_ws = nullptr;     // WS_WORDS * max_batch * sizeof(T)
   QpJidx jmap;
   int qp_kernel = 0;  // 0 = qp_group16 (default), 1 = qp_wave; env WBC_QP_KERNEL=wave selects 1
+  int sweep_mode = 1; // 1 = fused dyn_sweep (default), 0 = split (mass_jac on a second stream || rnea_step -> QP); env WBC_SWEEP=split
+                      // measured on MI355X: split is 5-20 % slower (two kernels pay the fixed latencies twice), kept for A/B
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // N=1 convenience buffers
   void* d_one = nullptr;
   size_t one_bytes = 0;
@@ -258,6 +263,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (!s) return fail(WBC_E_INVALID, "out of memory");
   s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p;
   if (const char* e = std::getenv("WBC_QP_KERNEL")) s->qp_kernel = (std::strcmp(e, "wave") == 0) ? 1 : 0;
+  if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
@@ -275,6 +281,9 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
   s->one_bytes = 200 * sizeof(double) + 4 * sizeof(int);
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
   if (e != hipSuccess) {
     std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
     wbc_solver_destroy(s);
@@ -290,6 +299,9 @@ extern "C" void wbc_solver_destroy(wbc_solver* s) {
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_ws) (void)hipFree(s->d_ws);
   if (s->d_one) (void)hipFree(s->d_one);
+  if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+  if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+  if (s->aux) (void)hipStreamDestroy(s->aux);
   for (hipEvent_t ev : s->ev_pool) (void)hipEventDestroy(ev);
   delete s;
 }
@@ -304,9 +316,7 @@ extern "C" int wbc_solver_set_params(wbc_solver* s, const wbc_params* p) {
 
 // ---- timing helpers
 static int span_begin(wbc_solver* s, int kind, hipStream_t st) {
-  if (!s->timing) return WBC_OK;
-  if (kind == 0) s->sample_now = (s->calls++ % (unsigned long long)s->timing_period) == 0;
-  if (!s->sample_now) return WBC_OK;
+  if (!s->timing || !s->sample_now) return WBC_OK;
   if (s->ev_next + 2 > s->ev_pool.size()) {
     for (int i = 0; i < 64; ++i) {
       hipEvent_t ev;
@@ -319,6 +329,9 @@ static int span_begin(wbc_solver* s, int kind, hipStream_t st) {
   HIP_TRY(hipEventRecord(sp.a, st));
   s->spans.push_back(sp);
   return WBC_OK;
+}
+static void timing_tick(wbc_solver* s) {  // once per API call: is this tick instrumented?
+  s->sample_now = s->timing && (s->calls++ % (unsigned long long)s->timing_period) == 0;
 }
 static int span_end(wbc_solver* s, hipStream_t st) {
   if (!s->timing || !s->sample_now) return WBC_OK;
@@ -337,23 +350,18 @@ extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
   return WBC_OK;
 }
 
-extern "C" int wbc_solver_collect_timing(wbc_solver* s, double* dyn_ms, int* dyn_launches, double* qp_ms, int* qp_launches) {
-  if (!s) return fail(WBC_E_INVALID, "null solver");
-  double ms[2] = {0, 0};
-  int cnt[2] = {0, 0};
+extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[3], int launches[3]) {
+  if (!s || !ms || !launches) return fail(WBC_E_INVALID, "null argument");
+  for (int k = 0; k < 3; ++k) { ms[k] = 0; launches[k] = 0; }
   for (auto& sp : s->spans) {
     HIP_TRY(hipEventSynchronize(sp.b));
     float t = 0;
     HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
     ms[sp.kind] += t;
-    cnt[sp.kind]++;
+    launches[sp.kind]++;
   }
   s->spans.clear();
   s->ev_next = 0;
-  if (dyn_ms) *dyn_ms = ms[0];
-  if (dyn_launches) *dyn_launches = cnt[0];
-  if (qp_ms) *qp_ms = ms[1];
-  if (qp_launches) *qp_launches = cnt[1];
   return WBC_OK;
 }
 
@@ -378,6 +386,61 @@ static hipError_t launch_sweep(wbc_solver* s, const SweepArgs<T>& a, hipStream_t
 }
 
 template <class T>
+static hipError_t launch_mass_jac(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
+  const size_t threads = a.N * 4;
+  if (threads >= (size_t)256 * 8 * 64 * 2) {
+    hipLaunchKernelGGL((mass_jac_kernel<T, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                       (const DevModel<T>*)s->d_model, a);
+  } else {
+    hipLaunchKernelGGL((mass_jac_kernel<T, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
+                       (const DevModel<T>*)s->d_model, a);
+  }
+  return hipGetLastError();
+}
+
+template <class T, int MODE>
+static hipError_t launch_rnea_step_mode(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
+  const size_t threads = a.N * 4;
+  // 256-thread workgroups only where four waves' parked state fits the CU twice (one force chain, no observer)
+  if constexpr ((MODE & RS_OBS) == 0 && !((MODE & RS_STEP) && (MODE & RS_H))) {
+    if (threads >= (size_t)256 * 8 * 64 * 2) {
+      hipLaunchKernelGGL((rnea_step_kernel<T, MODE, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((rnea_step_kernel<T, MODE, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
+                     (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
+  return hipGetLastError();
+}
+
+template <class T>
+static hipError_t launch_rnea_step(wbc_solver* s, int mode, const SweepArgs<T>& a, hipStream_t st) {
+  switch (mode) {
+#define RS_CASE(M) case M: return launch_rnea_step_mode<T, M>(s, a, st);
+    RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
+    RS_CASE(8) RS_CASE(9) RS_CASE(10) RS_CASE(11) RS_CASE(12) RS_CASE(13) RS_CASE(14) RS_CASE(15)
+#undef RS_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// fork the store-heavy mass_jac kernel onto the solver's second stream; the caller's stream waits for it at the end
+template <class T>
+static int fork_mass_jac(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
+  HIP_TRY(hipEventRecord(s->ev_fork, st));
+  HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
+  int rc = span_begin(s, 0, s->aux);
+  if (rc) return rc;
+  hipError_t e = launch_mass_jac<T>(s, a, s->aux);
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("mass_jac launch: ") + hipGetErrorString(e));
+  rc = span_end(s, s->aux);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(s->ev_join, s->aux));
+  return WBC_OK;
+}
+
+template <class T>
 static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc, void* pf,
                          void* p, void* beta, hipStream_t st) {
   SweepArgs<T> a;
@@ -385,6 +448,22 @@ static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, 
   a.N = N; a.q = (const T*)q; a.v = (const T*)v;
   a.M = (T*)M; a.h = (T*)h; a.Jc = (T*)Jc; a.pf = (T*)pf; a.p = (T*)p; a.beta = (T*)beta;
   const bool mats = M != nullptr, obs = p || beta;
+  timing_tick(s);
+  if (s->sweep_mode == 0) {
+    int rc = WBC_OK;
+    if (mats) { rc = fork_mass_jac<T>(s, a, st); if (rc) return rc; }
+    const int mode = (mats ? RS_H : 0) | (obs ? RS_OBS : 0) | ((!mats && pf) ? RS_PF : 0);
+    if (mode) {
+      rc = span_begin(s, 2, st);
+      if (rc) return rc;
+      hipError_t e2 = launch_rnea_step<T>(s, mode, a, st);
+      if (e2 != hipSuccess) return fail(WBC_E_HIP, std::string("rnea_step launch: ") + hipGetErrorString(e2));
+      rc = span_end(s, st);
+      if (rc) return rc;
+    }
+    if (mats) HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
+    return WBC_OK;
+  }
   int rc = span_begin(s, 0, st);
   if (rc) return rc;
   hipError_t e;
@@ -420,16 +499,29 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   a.obs_integ = obs ? (T*)obs->integ : nullptr; a.obs_r = obs ? (T*)obs->r : nullptr;
   a.ws = (T*)s->d_ws;
   const bool mats = out->M != nullptr, ob = s->params.observer_order > 0;
-  int rc = span_begin(s, 0, st);
-  if (rc) return rc;
+  timing_tick(s);
+  int rc;
   hipError_t e;
-  if (mats && ob) e = launch_sweep<T, SW_MATS | SW_STEP | SW_OBS>(s, a, st);
-  else if (mats) e = launch_sweep<T, SW_MATS | SW_STEP>(s, a, st);
-  else if (ob) e = launch_sweep<T, SW_STEP | SW_OBS>(s, a, st);
-  else e = launch_sweep<T, SW_STEP>(s, a, st);
-  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
-  rc = span_end(s, st);
-  if (rc) return rc;
+  if (s->sweep_mode == 0) {
+    if (mats) { rc = fork_mass_jac<T>(s, a, st); if (rc) return rc; }
+    const int mode = RS_STEP | (mats ? RS_H : 0) | (ob ? RS_OBS : 0) | ((!mats && out->pf) ? RS_PF : 0);
+    rc = span_begin(s, 2, st);
+    if (rc) return rc;
+    e = launch_rnea_step<T>(s, mode, a, st);
+    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rnea_step launch: ") + hipGetErrorString(e));
+    rc = span_end(s, st);
+    if (rc) return rc;
+  } else {
+    rc = span_begin(s, 0, st);
+    if (rc) return rc;
+    if (mats && ob) e = launch_sweep<T, SW_MATS | SW_STEP | SW_OBS>(s, a, st);
+    else if (mats) e = launch_sweep<T, SW_MATS | SW_STEP>(s, a, st);
+    else if (ob) e = launch_sweep<T, SW_STEP | SW_OBS>(s, a, st);
+    else e = launch_sweep<T, SW_STEP>(s, a, st);
+    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
+    rc = span_end(s, st);
+    if (rc) return rc;
+  }
 
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
@@ -444,8 +536,11 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     hipLaunchKernelGGL((qp_group16_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
   }
   e = hipGetLastError();
-  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("qp_wave launch: ") + hipGetErrorString(e));
-  return span_end(s, st);
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("qp launch: ") + hipGetErrorString(e));
+  rc = span_end(s, st);
+  if (rc) return rc;
+  if (s->sweep_mode == 0 && mats) HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));  // join: M, Jc, pf are complete
+  return WBC_OK;
 }
 
 extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
