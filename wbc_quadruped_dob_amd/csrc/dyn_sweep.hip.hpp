@@ -257,21 +257,44 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
   // structural zeros and ones of M and Jc go out while the sweeps compute (they overlap the VALU work).
   if (MATS) {
     const T Z = (T)0;
-    for (int e = leg; e < 64; e += 4) {
-      const int zi = zidx_s[e];
-      if (zi >= 0) STV(a.M, zi, Z);
-    }
+    if ((N & 1) == 0) {
+      // 16 bytes per lane: lanes (s, s+1) of a row are neighbours, the even one takes the even-numbered constants and
+      // the odd one the odd-numbered ones, each for BOTH states -- half the store instructions for the same bytes
+      // (a wave store instruction costs ~90 cycles to issue whatever its width)
+      struct alignas(16) T2 { T a, b; };
+      const unsigned odd = s32 & 1u, s2 = s32 & ~1u;
+      const bool live2 = live;  // N even: both states of a pair are in range together
+#define ST2C(ptr, comp, val) do { if (live2) *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
+      for (int e = 2 * leg + (int)odd; e < 64; e += 8) {
+        const int zi = zidx_s[e];
+        if (zi >= 0) ST2C(a.M, zi, Z);
+      }
+      // Jc rows of my foot: 16 constant entries per row (identity block, skew diagonal, 12 joint columns), 48 in all
 #pragma unroll
-    for (int mrow = 0; mrow < 3; ++mrow) {
+      for (int mrow = 0; mrow < 3; ++mrow) {
+        const int rb = 54 * leg + 18 * mrow;
+        // pairs (even entry, odd entry): (0,1) (2, 3+mrow) (6,7) (8,9) (10,11) (12,13) (14,15) (16,17)
+        ST2C(a.Jc, rb + (odd ? 1 : 0), ((odd ? 1 : 0) == mrow) ? (T)1 : Z);
+        ST2C(a.Jc, rb + (odd ? 3 + mrow : 2), (!odd && mrow == 2) ? (T)1 : Z);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) STL(a.Jc, 18 * mrow + c, 54, (c == mrow) ? (T)1 : Z);
-      STL(a.Jc, 18 * mrow + 3 + mrow, 54, Z);
+        for (int c = 6; c < 18; c += 2) ST2C(a.Jc, rb + c + (int)odd, Z);
+      }
+#undef ST2C
+    } else {
+      for (int e = leg; e < 64; e += 4) {
+        const int zi = zidx_s[e];
+        if (zi >= 0) STV(a.M, zi, Z);
+      }
 #pragma unroll
-      for (int c = 0; c < 12; ++c) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);
+      for (int mrow = 0; mrow < 3; ++mrow) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) STL(a.Jc, 18 * mrow + c, 54, (c == mrow) ? (T)1 : Z);
+        STL(a.Jc, 18 * mrow + 3 + mrow, 54, Z);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);
+      }
     }
   }
-
-  // ------------------------------------------------------------------ base
   SSTAMP();  // 3: early stores issued
   // unit quaternion kept (4 words); R is rebuilt after the sweeps instead of living through them (9 words)
   T qx, qy, qz, qw;
