@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-mats", action="store_true", help="do not write M,h,Jc to HBM (fused-only variant)")
     ap.add_argument("--sample-every", type=int, default=10, help="HIP-event instrumentation period inside the timed region")
     ap.add_argument("--large-batch", type=int, default=262144, help="extra roofline characterisation batch (0 = skip)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-state latency leg (p50 over 1000 ticks)")
     args = ap.parse_args()
 
     import numpy as np
@@ -170,6 +171,8 @@ def main():
             "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                    "iters_max": int(iters.max())},
         }
+        if not args.no_latency and world == 1:
+            res["qp_latency"] = qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs)
         if args.large_batch and world == 1:
             res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split)
         if not args.no_cpu and world == 1:
@@ -177,6 +180,44 @@ def main():
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):
+    """BASELINE.json metric, second half ("p50 QP us"): one state per launch, 1000 synchronous ticks.
+    tick_p50 = host-observed wall time of one wbc_step_batch(N=1) + stream sync (what a 1-robot control loop sees);
+    qp_kernel_p50 = HIP-event span around the QP kernel alone in those ticks (raw, includes the event-pair cost)."""
+    solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=1)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a[:1].T)).to(td).cuda()
+    inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+    mask = torch.from_numpy(B["mask"][:1].copy()).cuda()
+    integ = rr = None
+    if obs:
+        integ = solver.dynamics(inp["q"], inp["v"], want=("p",))["p"].clone()
+        rr = torch.zeros_like(integ)
+    out = {}
+
+    def tick():
+        return solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                           inp["f_prev"], integ, rr, out=out, want_mats=False)
+
+    out.update(tick())
+    for _ in range(20):
+        tick()
+    torch.cuda.synchronize()
+    wall, qpk, dynk = [], [], []
+    solver.enable_timing(1)
+    for _ in range(1000):
+        t0 = time.perf_counter()
+        tick()
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)
+        tm = solver.collect_timing()
+        qpk.append(tm["qp_ms"])
+        dynk.append(tm["dyn_ms"])
+    solver.enable_timing(0)
+    return {"ticks": 1000, "tick_p50_us": float(np.median(wall)) * 1e6, "tick_p99_us": float(np.percentile(wall, 99)) * 1e6,
+            "qp_kernel_p50_us": float(np.median(qpk)) * 1e3, "dyn_kernel_p50_us": float(np.median(dynk)) * 1e3,
+            "note": "N=1 per launch, synchronous; kernel spans are raw HIP-event spans"}
 
 
 def pmc_traffic(kernel, n, dtype):

@@ -8,7 +8,7 @@ for rep in 1 2; do
 for L in "$@"; do
   for B in 4096 262144; do
     echo "== $L batch $B rep $rep" >> gpurun_out/ab.log
-    WBC_LIB=$PWD/wbc_quadruped_dob_amd/lib/$L python bench.py --steps 100 --warmup 10 --no-cpu --large-batch 0 --batch $B 2>/dev/null | python3 -c "
+    WBC_LIB=$PWD/wbc_quadruped_dob_amd/lib/$L python bench.py --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch $B 2>/dev/null | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.read()); print('ms/step %.4f  steps/s %.3e  dyn %.1f us (%.0f GB/s, frac %.3f)  qp %.1f us'%(r['ms_per_step'],r['value'],r['kernels']['dyn_sweep_us'],r['roofline']['achieved'],r['roofline']['frac'],r['kernels']['qp_us']))" >> gpurun_out/ab.log
   done

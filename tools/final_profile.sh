@@ -8,12 +8,12 @@ python -m pytest tests -q -m gpu 2>&1 | tail -4 > "$O/pytest_gpu.log"
 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 ./tools/abi_smoke.bin > "$O/abi_smoke.log" 2>&1
 python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/bench.err"
-python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
-python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
-python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --large-batch 0 > "$O/bench_cfg2_n262144.json" 2>> "$O/bench.err"
+python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
+python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
+python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144.json" 2>> "$O/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
 find "$O" -name "*kernel_trace.csv" -delete
 cd "$R"
 bash tools/pmc_profile.sh > "$O/pmc.log" 2>&1

@@ -11,10 +11,10 @@ echo "smoke exit: $?" >> gpurun_out/smoke.log
 echo "abi_smoke exit: $?" >> gpurun_out/abi_smoke.log
 python bench.py --steps 200 --warmup 20 > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench exit: $?" >> gpurun_out/bench.err
-python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --large-batch 0 > gpurun_out/bench_262144.json 2>> gpurun_out/bench.err
+python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > gpurun_out/bench_262144.json 2>> gpurun_out/bench.err
 if [ "${PROFILE:-1}" = "1" ]; then
   rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r01 -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 200 --warmup 20 --no-cpu --large-batch 0 > "$GRAFT_REPO_ROOT/gpurun_out/prof/bench_under_rocprof.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof/rocprof.err" )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o r01 -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 200 --warmup 20 --no-cpu --no-latency --large-batch 0 > "$GRAFT_REPO_ROOT/gpurun_out/prof/bench_under_rocprof.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/prof/rocprof.err" )
   find gpurun_out/prof -name "*kernel_trace.csv" -size +2M -delete
 fi
 cat gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/abi_smoke.log gpurun_out/bench.json gpurun_out/bench_262144.json

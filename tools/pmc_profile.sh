@@ -8,8 +8,8 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o calib_$C -- "$R/tools/calib_copy.bin" > "$OUT/calib_$C.log" 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o n4096_$C -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu --large-batch 0 > "$OUT/n4096_$C.log" 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o n262144_$C -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu --large-batch 0 --batch 262144 > "$OUT/n262144_$C.log" 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o n4096_$C -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-cpu --no-latency --large-batch 0 > "$OUT/n4096_$C.log" 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT" -o n262144_$C -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$OUT/n262144_$C.log" 2>&1
 done
 ls -la "$OUT"
 python3 "$R/tools/pmc_summarize.py" "$OUT" > "$OUT/summary.json"

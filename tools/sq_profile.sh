@@ -11,7 +11,7 @@ P4="SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INS
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT" -o p$i -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu --large-batch 0 --batch $B > "$OUT/p$i.log" 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT" -o p$i -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu --no-latency --large-batch 0 --batch $B > "$OUT/p$i.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv,glob,sys,collections,json,os
