@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="states per GPU")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--horizon", type=int, default=20, help="config 5: ticks per rollout")
     ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-mats", action="store_true", help="do not write M,h,Jc to HBM (fused-only variant)")
@@ -68,6 +69,8 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
 
+    if args.config == 5:
+        return rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank)
     dtype = args.dtype or ("f32" if args.config == 4 else "f64")
     obs = 0 if args.config == 2 else 1
     td = torch.float64 if dtype == "f64" else torch.float32
@@ -178,6 +181,69 @@ def main():
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
         print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
+    """BASELINE.json configs[4]: MPC-style WBC-in-the-loop rollouts, horizon 20 x 1024 states per GPU (the config does
+    not say whether 1024 is per GPU or total; per GPU here, --batch overrides).  One "step" = one rollout = `horizon`
+    dependent ticks of {dyn_sweep, QP, forward dynamics + integrator}; value is still control-steps/s."""
+    dtype = args.dtype or "f64"
+    td = torch.float64 if dtype == "f64" else torch.float32
+    n = args.batch if args.batch != 4096 else 1024
+    H = args.horizon
+    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    P = synth.default_params(observer_order=1, dtype=dtype)
+    solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=local_rank, max_batch=n)
+    B = synth.make_batch(3, n, model.total_mass, rank=rank)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
+    inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")}
+    q0, v0 = inp["q"].clone(), inp["v"].clone()
+    mask = torch.from_numpy(B["mask"]).cuda()
+    text = np.zeros((n, 18))
+    text[:, 0:3] = B["push"]
+    tau_ext = dev(text)
+    integ0 = solver.dynamics(q0, v0, want=("p",))["p"].clone()
+    integ, rr = integ0.clone(), torch.zeros_like(integ0)
+    out = dict(tau=torch.zeros((12, n), dtype=td, device="cuda"), f=torch.zeros((12, n), dtype=td, device="cuda"),
+               status=torch.zeros(n, dtype=torch.int32, device="cuda"), iters=torch.zeros(n, dtype=torch.int32, device="cuda"),
+               M=solver.empty(171, n), h=solver.empty(18, n), Jc=solver.empty(216, n), pf=solver.empty(12, n))
+
+    def one_rollout():
+        inp["q"].copy_(q0); inp["v"].copy_(v0); integ.copy_(integ0); rr.zero_(); out["tau"].zero_(); out["f"].zero_()
+        solver.rollout(H, inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, out, integ, rr,
+                       tau_ext)
+
+    for _ in range(max(1, args.warmup)):
+        one_rollout()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_rollout()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ok = float((out["status"].cpu().numpy() == 0).mean())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "WBC control-steps/sec (batched DogBot)", "value": args.steps * H * n * world / elapsed,
+            "unit": "control-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "configs[4]: horizon=%d x batch=%d rollouts per GPU, trot masks, observer on, pushes, %s; "
+                                   "one step = one rollout (%d dependent ticks incl. forward dynamics + integrator)" % (H, n, dtype, H),
+                       "batch_per_gpu": n, "horizon": H, "parallelism": "batch-sharded x%d, rank-local for all ticks" % world},
+            "us_per_tick": elapsed / args.steps / H * 1e6, "qp": {"status_ok_frac_last_tick": ok},
+            "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()
 

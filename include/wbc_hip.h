@@ -136,6 +136,21 @@ int wbc_dynamics_batch(wbc_solver* s, size_t N, const void* q, const void* v, vo
 int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
                    const wbc_observer_state* obs, void* stream);
 
+/* SURVEY.md 8(f)-1 -- the step Gazebo performs in the reference loop (/root/reference/README.md:58), as the simplest
+ * model that closes the loop for rollouts: forward dynamics with the planned GRFs applied,
+ *   vdot = M^-1 (S^T tau + Jc^T f + tau_ext - h),  then semi-implicit Euler on (q, v) IN PLACE with the solver's dt.
+ * Must follow a wbc_step_batch of the same solver and N that wrote M and h (it also reads that tick's workspace).
+ * tau_ext [nv][N] may be NULL. */
+int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h, const void* tau,
+                        const void* f, const void* tau_ext, void* stream);
+
+/* `horizon` dependent ticks of {wbc_step_batch, wbc_integrate_batch} with constant references (BASELINE.json
+ * configs[4]: MPC-style WBC-in-the-loop rollouts).  in->q / in->v are ADVANCED IN PLACE (const is cast away);
+ * out->tau / out->f must hold the previous tick's outputs (or zeros) on entry and serve as tau_prev / f_prev;
+ * out->M, out->h, out->Jc are required.  tau_traj (optional) receives tau of every tick: [horizon][nj][N]. */
+int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
+                      const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, void* stream);
+
 /* Single-robot, host-pointer, double-precision convenience call: the shape of the reference's
  * one-robot tick (BASELINE.json configs[0]).  Runs wbc_step_batch with N = 1 on the GPU and
  * synchronises.  obs_integ/obs_r (host, nv each) are in/out and may be NULL when the observer is off. */

@@ -340,3 +340,28 @@ def step(model, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev, f_prev, i
     tau = (M @ vdot_des + h - Jd.T @ f - rhat)[6:]
     out.update(f=f, tau=tau)
     return out
+
+
+# ------------------------------------------------------------------ rollout (a10): independent restatement
+def rollout(model, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext=None, integ=None, r=None):
+    """horizon ticks of {step by the independent algorithms, vdot = solve(M, S^T tau + Jc^T f + tau_ext - h) with
+    numpy's LU, semi-implicit Euler with integrate_q}.  Returns final (q, v, tau list, integ, r)."""
+    nv = model.nv
+    q, v = q.copy(), v.copy()
+    tau_prev = np.zeros(nv - 6)
+    f_prev = np.zeros(3 * model.nf)
+    integ = np.zeros(nv) if integ is None else integ.copy()
+    r = np.zeros(nv) if r is None else r.copy()
+    taus = []
+    for _ in range(horizon):
+        o = step(model, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev, f_prev, integ, r)
+        integ, r = o["integ"], o["r"]
+        rhs = np.concatenate([np.zeros(6), o["tau"]]) + o["Jc"].reshape(-1, nv).T @ o["f"] - o["h"]
+        if tau_ext is not None:
+            rhs = rhs + tau_ext
+        vdot = np.linalg.solve(o["M"], rhs)
+        v = v + P["dt"] * vdot
+        q = integrate_q(q, v, P["dt"])
+        tau_prev, f_prev = o["tau"], o["f"]
+        taus.append(o["tau"])
+    return q, v, np.array(taus), integ, r

@@ -133,6 +133,36 @@ class Oracle:
         return dict(tau=tau, f=f, status=status, iters=iters)
 
 
+def _rollout(self, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext=None, tau_prev=None, f_prev=None,
+             integ=None, r=None, want_traj=False, nthreads=1):
+    """q, v (and tau_prev, f_prev, integ, r when given) are updated IN PLACE.  Returns dict(status[, tau_traj])."""
+    dt = q.dtype
+    N = q.shape[0]
+    assert q.flags.c_contiguous and v.flags.c_contiguous and v.dtype == dt
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+    w_des, vdot_des, normals, mu, tau_ext = map(c, (w_des, vdot_des, normals, mu, tau_ext))
+    mask = np.ascontiguousarray(mask, dtype=np.int32)
+    if tau_prev is None:
+        tau_prev = np.zeros((N, self.nj), dt)
+    if f_prev is None:
+        f_prev = np.zeros((N, 3 * self.nf), dt)
+    for a in (tau_prev, f_prev, integ, r):
+        assert a is None or (a.dtype == dt and a.flags.c_contiguous)
+    traj = np.zeros((N, horizon, self.nj), dt) if want_traj else None
+    status = np.zeros(N, np.int32)
+    ps = make_params_struct(P)
+    getattr(lib(), "wbco_rollout_" + self._suf(dt))(self.h, C.byref(ps), N, int(horizon), _p(q), _p(v), _p(w_des),
+                                                    _p(vdot_des), _p(normals), _p(mu), _p(mask), _p(tau_ext), _p(tau_prev),
+                                                    _p(f_prev), _p(integ), _p(r), _p(traj), _p(status), int(nthreads))
+    out = dict(status=status, tau_prev=tau_prev, f_prev=f_prev)
+    if want_traj:
+        out["tau_traj"] = traj
+    return out
+
+
+Oracle.rollout = _rollout
+
+
 def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9):
     dt = H.dtype
     n, m = len(g), len(d)

@@ -93,6 +93,28 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
       if (iters) iters[s] = o.iters;                                                                            \
     }                                                                                                           \
   }                                                                                                             \
+  /* horizon ticks of {step, forward dynamics with the planned GRFs, integration}; q, v, tau_prev, f_prev, obs in/out */ \
+  void wbco_rollout_##SUF(void* hh, const wbco_params* pp, int N, int horizon, T* q, T* v, const T* w_des,              \
+                          const T* vdot_des, const T* normals, const T* mu, const int* mask, const T* tau_ext,         \
+                          T* tau_prev, T* f_prev, T* obs_integ, T* obs_r, T* tau_traj, int* status, int nthreads) {     \
+    const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
+    const Params P = to_params(pp);                                                                             \
+    const int nv = m.nv(), nq = nv + 1, nj = m.nj(), nf = m.nf;                                                 \
+    _Pragma("omp parallel for num_threads(nthreads) schedule(static)") for (int s = 0; s < N; ++s) {           \
+      T zi[MAXV], zr[MAXV];                                                                                     \
+      for (int i = 0; i < MAXV; ++i) zi[i] = zr[i] = 0;                                                         \
+      rollout(m, P, horizon, q + (size_t)s * nq, v + (size_t)s * nv, w_des + (size_t)s * 6,                     \
+              vdot_des + (size_t)s * nv, normals + (size_t)s * 3 * nf, mu + (size_t)s * nf, (unsigned)mask[s],   \
+              tau_ext ? tau_ext + (size_t)s * nv : (const T*)nullptr, tau_prev + (size_t)s * nj,                 \
+              f_prev + (size_t)s * 3 * nf, obs_integ ? obs_integ + (size_t)s * nv : zi,                          \
+              obs_r ? obs_r + (size_t)s * nv : zr, tau_traj ? tau_traj + (size_t)s * horizon * nj : (T*)nullptr, \
+              status ? status + s : (int*)nullptr);                                                             \
+    }                                                                                                           \
+  }                                                                                                             \
+  void wbco_forward_dynamics_##SUF(int nv, int nj, int nf, const T* Mp, const T* h, const T* Jc, const T* tau,  \
+                                   const T* f, const T* tau_ext, T* vdot) {                                     \
+    forward_dynamics(nv, nj, nf, Mp, h, Jc, tau, f, tau_ext, vdot);                                             \
+  }                                                                                                             \
   /* dense QP, row-major H[n*n], C[m*n]: min 1/2 x'Hx + g'x  s.t. Cx >= d */                                    \
   int wbco_qp_solve_##SUF(int n, int mm, const T* H, const T* g, const T* C, const T* d, int max_iter, T tol,   \
                           T* x, T* lambda, int* status) {                                                       \

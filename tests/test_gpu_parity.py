@@ -297,3 +297,94 @@ def test_qp_wave_kernel_variant_matches(torch_cuda, gpu_model, oracle, monkeypat
     got = _run_step(torch, solver, B, "f64", integ, r)
     assert np.array_equal(got["status"], ref["status"])
     assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
+
+
+def _gpu_rollout(torch, solver, P, H, B, tau_ext, integ, r, want_traj=True):
+    td = torch.float64
+    n = B["q"].shape[0]
+    dv = lambda a: to_dev(a, torch, td)
+    q, v = dv(B["q"]), dv(B["v"])
+    mask = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
+    out = dict(tau=torch.zeros((12, n), dtype=td, device="cuda"), f=torch.zeros((12, n), dtype=td, device="cuda"),
+               status=torch.zeros(n, dtype=torch.int32, device="cuda"), iters=torch.zeros(n, dtype=torch.int32, device="cuda"),
+               M=solver.empty(171, n), h=solver.empty(18, n), Jc=solver.empty(216, n), pf=solver.empty(12, n))
+    ig = None if integ is None else dv(integ)
+    rr = None if r is None else dv(r)
+    traj = torch.zeros((H, 12, n), dtype=td, device="cuda") if want_traj else None
+    solver.rollout(H, q, v, dv(B["w_des"]), dv(B["vdot_des"]), dv(B["normals"]), dv(B["mu"]), mask, out, ig, rr,
+                   None if tau_ext is None else dv(tau_ext), traj)
+    torch.cuda.synchronize()
+    res = dict(q=to_host(q), v=to_host(v), status=out["status"].cpu().numpy())
+    if traj is not None:
+        res["tau_traj"] = traj.cpu().numpy().transpose(2, 0, 1).copy()  # [n, H, 12]
+    if ig is not None:
+        res["integ"], res["r"] = to_host(ig), to_host(rr)
+    return res
+
+
+@pytest.mark.parametrize("cfg,obs,n,H", [(2, 0, 1024, 20), (3, 1, 1000, 20), (4, 2, 333, 7)])
+def test_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H):
+    """BASELINE.json configs[4] shape: horizon-20 WBC-in-the-loop rollouts of 1024 states."""
+    torch = torch_cuda
+    solver, P = _solver(gpu_model, obs=obs, max_batch=n)
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=17)
+    tau_ext = np.zeros((n, 18))
+    tau_ext[:, 0:3] = B["push"] if cfg > 2 else 10.0
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    r = np.zeros((n, 18)) if obs else None
+    q, v = B["q"].copy(), B["v"].copy()
+    ig_ref = None if integ is None else integ.copy()
+    r_ref = None if r is None else r.copy()
+    ref = oracle.rollout(P, H, q, v, B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], tau_ext=tau_ext,
+                         integ=ig_ref, r=r_ref, want_traj=True, nthreads=8)
+    got = _gpu_rollout(torch, solver, P, H, B, tau_ext, integ, r)
+    assert np.all(ref["status"] == 0) and np.all(got["status"] == 0)
+    # 20 dependent ticks: differences compound through the dynamics; 1e-8 relative is what fp64 holds here
+    assert relerr(got["q"], q) < 1e-8 and relerr(got["v"], v) < 1e-8
+    assert relerr(got["tau_traj"], ref["tau_traj"]) < 1e-7
+    assert relerr(got["tau_traj"][:, 0], ref["tau_traj"][:, 0]) < TIGHT64  # first tick: no compounding yet
+    if obs:
+        assert relerr(got["integ"], ig_ref) < 1e-8 and relerr(got["r"], r_ref) < 1e-6
+    assert np.allclose(np.linalg.norm(got["q"][:, 3:7], axis=1), 1.0, atol=1e-13)
+
+
+def test_rollout_vs_golden(torch_cuda, gpu_model):
+    import os
+    torch = torch_cuda
+    gr = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_rollout_v1.npz")))
+    H = int(gr["horizon"])
+    for name in ("r_obs0", "r_obs1"):
+        obs = int(gr[name + "_observer_order"])
+        g = lambda k: gr[f"{name}_in_{k}"]
+        n = g("q").shape[0]
+        solver, P = _solver(gpu_model, obs=obs, max_batch=n)
+        B = {k: g(k) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "mask")}
+        got = _gpu_rollout(torch, solver, P, H, B, g("tau_ext"), g("integ0").copy() if obs else None,
+                           np.zeros((n, 18)) if obs else None)
+        assert relerr(got["q"], gr[name + "_out_q"]) < 1e-10
+        assert relerr(got["v"], gr[name + "_out_v"]) < 1e-9
+        assert relerr(got["tau_traj"], gr[name + "_out_tau_traj"]) < 1e-8
+
+
+def test_integrate_single_call_matches_forward_dynamics(torch_cuda, gpu_model, oracle):
+    """wbc_integrate_batch after a step: M vdot + h = S^T tau + Jc^T f + tau_ext for the velocity change it made."""
+    torch = torch_cuda
+    n = 2000
+    solver, P = _solver(gpu_model, max_batch=n)
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=23)
+    td = torch.float64
+    dv = lambda a: to_dev(a, torch, td)
+    q, v = dv(B["q"]), dv(B["v"])
+    mask = torch.from_numpy(B["mask"]).cuda()
+    out = solver.step(q, v, dv(B["w_des"]), dv(B["vdot_des"]), dv(B["normals"]), dv(B["mu"]), mask, want_mats=True)
+    text = np.zeros((n, 18))
+    text[:, 1] = -30.0
+    solver.integrate(q, v, out["M"], out["h"], out["tau"], out["f"], dv(text))
+    torch.cuda.synchronize()
+    M = unpack_M(to_host(out["M"]))
+    vdot = (to_host(v) - B["v"]) / P["dt"]
+    lhs = np.einsum("nij,nj->ni", M, vdot) + to_host(out["h"])
+    rhs = text.copy()
+    rhs[:, 6:] += to_host(out["tau"])
+    rhs += np.einsum("nei,ne->ni", to_host(out["Jc"]).reshape(n, 12, 18), to_host(out["f"]))
+    assert np.abs(lhs - rhs).max() < 1e-8 * np.abs(rhs).max()

@@ -101,6 +101,8 @@ def lib():
         L.wbc_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.wbc_dynamics_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
         L.wbc_step_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
+        L.wbc_integrate_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
+        L.wbc_rollout_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 6
         _lib = L
     return _lib
 
@@ -247,6 +249,37 @@ class Solver:
                        self._ptr(out["iters"], 1, N, torch.int32), g("M"), g("h"), g("Jc"), g("pf"))
         ob = _ObsState(self._ptr(obs_integ, m.nv, N), self._ptr(obs_r, m.nv, N))
         _check(lib().wbc_step_batch(self._h, N, C.byref(bi), C.byref(bo), C.byref(ob), self._stream()), "wbc_step_batch")
+        return out
+
+    def integrate(self, q, v, M, h, tau, f, tau_ext=None):
+        """Forward dynamics with the planned GRFs + semi-implicit Euler; q, v advance IN PLACE (one dt)."""
+        m = self.model
+        N = q.shape[1]
+        _check(lib().wbc_integrate_batch(self._h, N, self._ptr(q, m.nq, N), self._ptr(v, m.nv, N),
+                                         self._ptr(M, m.nv * (m.nv + 1) // 2, N), self._ptr(h, m.nv, N),
+                                         self._ptr(tau, m.nj, N), self._ptr(f, 3 * m.nf, N), self._ptr(tau_ext, m.nv, N),
+                                         self._stream()), "wbc_integrate_batch")
+
+    def rollout(self, horizon, q, v, w_des, vdot_des, normals, mu, mask, out, obs_integ=None, obs_r=None, tau_ext=None,
+                tau_traj=None):
+        """`horizon` dependent ticks; q, v advance IN PLACE; `out` must hold tau, f (previous outputs or zeros), status,
+        iters, M, h, Jc (e.g. the dict a previous step(..., want_mats=True) returned)."""
+        torch = self.torch
+        m = self.model
+        N = q.shape[1]
+        rows = dict(tau=m.nj, f=3 * m.nf, M=m.nv * (m.nv + 1) // 2, h=m.nv, Jc=3 * m.nf * m.nv, pf=3 * m.nf)
+        bi = _BatchIn(self._ptr(q, m.nq, N), self._ptr(v, m.nv, N), self._ptr(w_des, 6, N), self._ptr(vdot_des, m.nv, N),
+                      self._ptr(normals, 3 * m.nf, N), self._ptr(mu, m.nf, N), self._ptr(mask, 1, N, torch.int32), None, None)
+        g = lambda k: self._ptr(out.get(k), rows[k], N)
+        bo = _BatchOut(g("tau"), g("f"), self._ptr(out["status"], 1, N, torch.int32),
+                       self._ptr(out.get("iters"), 1, N, torch.int32), g("M"), g("h"), g("Jc"), g("pf"))
+        ob = _ObsState(self._ptr(obs_integ, m.nv, N), self._ptr(obs_r, m.nv, N))
+        tt = None
+        if tau_traj is not None:
+            assert tau_traj.is_cuda and tau_traj.is_contiguous() and tau_traj.numel() == horizon * m.nj * N
+            tt = C.c_void_p(tau_traj.data_ptr())
+        _check(lib().wbc_rollout_batch(self._h, N, int(horizon), C.byref(bi), C.byref(bo), C.byref(ob),
+                                       self._ptr(tau_ext, m.nv, N), tt, self._stream()), "wbc_rollout_batch")
         return out
 
     def compute_torques(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None,

@@ -1,0 +1,196 @@
+// Forward dynamics with the planned GRFs + semi-implicit Euler: SURVEY.md 8(f)-1, the step Gazebo performs in the
+// reference loop (/root/reference/README.md:58), restated as the simplest model that closes the loop for rollouts:
+//     vdot = M^-1 (S^T tau + Jc^T f + tau_ext - h),   v += dt vdot,   q <- q (+) dt v   (world-frame omega)
+//
+// Same lane mapping as the dynamics sweep (lane = 16*leg + state; one leg per 16-lane row).  The quadruped's mass
+// matrix is an arrow: a 6x6 base block, four 6x3 base-leg blocks and four independent 3x3 leg blocks.  Each lane
+// inverts ITS leg block in closed form, forms its part of the base Schur complement (21 + 6 words summed across
+// the four rows with v_permlane16/32_swap), every lane solves the 6x6 base system redundantly in registers, and
+// back-substitutes its own leg.  M, h come from the buffers the sweep wrote, foot geometry from the step workspace.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+#include "dyn_sweep.hip.hpp"
+
+namespace wbc {
+
+template <class T> struct IntegrateArgs {
+  size_t N;
+  T* q; T* v;                       // in/out
+  const T* M; const T* h;           // from the sweep (packed M, bias)
+  const T* ws;                      // step workspace of the same tick: d (foot rel. base), JcL
+  const T* tau; const T* f;         // this tick's outputs
+  const T* tau_ext;                 // [nv][N] or null
+  T* tau_traj;                      // [nj][N] slice for this tick, or null
+  T dt;
+};
+
+template <class T>
+__global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __restrict__ model, IntegrateArgs<T> a) {
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  const int leg = (int)((threadIdx.x & 63) >> 4);
+  const size_t s_raw = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const bool live = s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
+  const unsigned legN = (unsigned)leg * N32;
+#define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
+#define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define LDL(ptr, c0, stride) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))))
+#define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+  int jx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) jx[k] = model->jidx[leg][k];
+
+  // ---- my leg: rhs_l = tau_l + JcL^T f_l + tau_ext_l - h_l
+  const V3<T> fl = mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
+  const V3<T> dl = mk<T>(LDL(a.ws, WS_D + 0, 3), LDL(a.ws, WS_D + 1, 3), LDL(a.ws, WS_D + 2, 3));
+  T rl[3], ql[3], vl[3], taul[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const T jc0 = LDL(a.ws, WS_JCL + 0 + k, 9), jc1 = LDL(a.ws, WS_JCL + 3 + k, 9), jc2 = LDL(a.ws, WS_JCL + 6 + k, 9);
+    taul[k] = LDV(a.tau, jx[k]);
+    rl[k] = taul[k] + jc0 * fl.x + jc1 * fl.y + jc2 * fl.z - LDV(a.h, 6 + jx[k]) + (a.tau_ext ? LDV(a.tau_ext, 6 + jx[k]) : (T)0);
+    ql[k] = LDV(a.q, 7 + jx[k]);
+    vl[k] = LDV(a.v, 6 + jx[k]);
+  }
+  // leg block (symmetric 3x3) and base-leg block (6x3) of M
+  auto mi = [](int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return i * 18 - i * (i - 1) / 2 + (j - i); };
+  T Ml[3][3], Mb[6][3];
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+    for (int k2 = k1; k2 < 3; ++k2) { Ml[k1][k2] = LDV(a.M, mi(6 + jx[k1], 6 + jx[k2])); Ml[k2][k1] = Ml[k1][k2]; }
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Mb[r][k] = LDV(a.M, midx18(r, r) + (6 + jx[k] - r));
+  // A = Ml^-1 by cofactors (SPD 3x3)
+  T A[3][3];
+  {
+    const T c00 = Ml[1][1] * Ml[2][2] - Ml[1][2] * Ml[1][2];
+    const T c01 = Ml[0][2] * Ml[1][2] - Ml[0][1] * Ml[2][2];
+    const T c02 = Ml[0][1] * Ml[1][2] - Ml[0][2] * Ml[1][1];
+    const T c11 = Ml[0][0] * Ml[2][2] - Ml[0][2] * Ml[0][2];
+    const T c12 = Ml[0][1] * Ml[0][2] - Ml[0][0] * Ml[1][2];
+    const T c22 = Ml[0][0] * Ml[1][1] - Ml[0][1] * Ml[0][1];
+    const T idet = (T)1 / (Ml[0][0] * c00 + Ml[0][1] * c01 + Ml[0][2] * c02);
+    A[0][0] = c00 * idet; A[0][1] = A[1][0] = c01 * idet; A[0][2] = A[2][0] = c02 * idet;
+    A[1][1] = c11 * idet; A[1][2] = A[2][1] = c12 * idet; A[2][2] = c22 * idet;
+  }
+  // W = Mb A (6x3); Schur contribution W Mb^T (sym 6x6) and W rl (6)
+  T W[6][3];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W[r][k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
+  // ---- base system S vb' = rb,  S = Mbb - sum W Mb^T,  rb = rhs_b - sum W rl
+  T S[6][6], rb[6];
+  {
+    const V3<T> mo = cross(dl, fl);
+    const T own[6] = {fl.x, fl.y, fl.z, mo.x, mo.y, mo.z};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const T part = own[r] - (W[r][0] * rl[0] + W[r][1] * rl[1] + W[r][2] * rl[2]);
+      rb[r] = xrow_sum(part) - LDU(a.h, r) + (a.tau_ext ? LDU(a.tau_ext, r) : (T)0);
+#pragma unroll
+      for (int c = r; c < 6; ++c) {
+        const T sc = W[r][0] * Mb[c][0] + W[r][1] * Mb[c][1] + W[r][2] * Mb[c][2];
+        S[r][c] = LDU(a.M, midx18(r, c)) - xrow_sum(sc);
+      }
+    }
+  }
+  // Cholesky of S (upper storage: S[r][c], r <= c holds L[c][r]) and the two triangular solves, in registers
+  T vb[6];
+  {
+    T L[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      T d = S[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+      const T inv = rsqrt_t(d);
+      L[j][j] = inv;  // store 1/L_jj
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        T sij = S[j][i];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sij -= L[i][k] * L[j][k];
+        L[i][j] = sij * inv;
+      }
+    }
+    T y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      T sy = rb[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) sy -= L[i][k] * y[k];
+      y[i] = sy * L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      T sx = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) sx -= L[k][i] * vb[k];
+      vb[i] = sx * L[i][i];
+    }
+  }
+  // ---- leg accelerations: vdl = A (rl - Mb^T vb)
+  T tl[3], vdl[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    T t = rl[k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) t -= Mb[r][k] * vb[r];
+    tl[k] = t;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) vdl[k] = A[k][0] * tl[0] + A[k][1] * tl[1] + A[k][2] * tl[2];
+
+  // ---- semi-implicit Euler
+  const T dt = a.dt;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const T vn = vl[k] + dt * vdl[k];
+    STV(a.v, 6 + jx[k], vn);
+    STV(a.q, 7 + jx[k], ql[k] + dt * vn);
+    if (a.tau_traj) STV(a.tau_traj, jx[k], taul[k]);
+  }
+  T vbn[6], qb[7];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) vbn[c] = LDU(a.v, c) + dt * vb[c];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
+  T qn[7];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) qn[c] = qb[c] + dt * vbn[c];
+  {
+    const T wx = vbn[3] * dt, wy = vbn[4] * dt, wz = vbn[5] * dt;
+    const T th2 = wx * wx + wy * wy + wz * wz;
+    const T th = th2 > (T)0 ? th2 * rsqrt_t(th2) : (T)0;
+    T sn, cs;
+    sincos_t(th * (T)0.5, &sn, &cs);
+    const bool small = th <= (T)1e-8;
+    const T sc = small ? (T)0.5 - th2 * (T)(1.0 / 48.0) : sn / (small ? (T)1 : th);
+    const T dw = small ? (T)1 - th2 * (T)0.125 : cs;
+    const T dx = sc * wx, dy = sc * wy, dz = sc * wz;
+    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    const T x = qb[3] * n, y = qb[4] * n, z = qb[5] * n, w = qb[6] * n;
+    qn[3] = dw * x + dx * w + dy * z - dz * y;
+    qn[4] = dw * y - dx * z + dy * w + dz * x;
+    qn[5] = dw * z + dx * y - dy * x + dz * w;
+    qn[6] = dw * w - dx * x - dy * y - dz * z;
+  }
+  // the 13 base words are replicated over the four leg rows: every row stores its share.  All rows have read
+  // q/v base rows above (their values feed these stores), so no lane can store before every lane has loaded.
+  STV(a.v, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, vbn[0], vbn[1], vbn[2], vbn[3]));
+  if (leg < 2) STV(a.v, 4 + leg, leg == 0 ? vbn[4] : vbn[5]);
+  STV(a.q, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, qn[0], qn[1], qn[2], qn[3]));
+  if (leg < 3) STV(a.q, 4 + leg, sel4<T>(leg, qn[4], qn[5], qn[6], qn[6]));
+#undef STV
+#undef LDL
+#undef LDV
+#undef LDU
+}
+
+}  // namespace wbc

@@ -18,6 +18,7 @@
 #include "model.hpp"
 #include "qp_wave.hip.hpp"
 #include "qp_group16.hip.hpp"
+#include "integrate.hip.hpp"
 
 using namespace wbc;
 
@@ -560,6 +561,55 @@ extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, c
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
   return s->dtype == WBC_F64 ? step_impl<double>(s, N, in, out, obs, st) : step_impl<float>(s, N, in, out, obs, st);
+}
+
+template <class T>
+static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h, const void* tau,
+                          const void* f, const void* tau_ext, void* tau_traj, hipStream_t st) {
+  IntegrateArgs<T> a;
+  a.N = N; a.q = (T*)q; a.v = (T*)v; a.M = (const T*)M; a.h = (const T*)h; a.ws = (const T*)s->d_ws;
+  a.tau = (const T*)tau; a.f = (const T*)f; a.tau_ext = (const T*)tau_ext; a.tau_traj = (T*)tau_traj;
+  a.dt = (T)s->params.dt;
+  hipLaunchKernelGGL((integrate_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
+                     (const DevModel<T>*)s->d_model, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("integrate launch: ") + hipGetErrorString(e));
+  return WBC_OK;
+}
+
+extern "C" int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h,
+                                   const void* tau, const void* f, const void* tau_ext, void* stream) {
+  if (!s || !q || !v || !M || !h || !tau || !f) return fail(WBC_E_INVALID, "null argument");
+  if (N == 0) return WBC_OK;
+  if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  return s->dtype == WBC_F64 ? integrate_impl<double>(s, N, q, v, M, h, tau, f, tau_ext, nullptr, st)
+                             : integrate_impl<float>(s, N, q, v, M, h, tau, f, tau_ext, nullptr, st);
+}
+
+extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
+                                 const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, void* stream) {
+  if (!s || !in || !out) return fail(WBC_E_INVALID, "null argument");
+  if (horizon < 1) return fail(WBC_E_INVALID, "horizon must be >= 1");
+  if (!out->M || !out->h || !out->Jc) return fail(WBC_E_INVALID, "rollouts need the M, h, Jc buffers (forward dynamics reads them)");
+  if (s->sweep_mode == 0) return fail(WBC_E_INVALID, "rollouts need the fused sweep (unset WBC_SWEEP=split)");
+  wbc_batch_in tick = *in;
+  tick.tau_prev = out->tau;  // the previous tick's outputs are this tick's tau_prev / f_prev: the sweep reads them
+  tick.f_prev = out->f;      // before the QP kernel of the same tick overwrites them
+  const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
+  const size_t nj = 12;
+  for (int t = 0; t < horizon; ++t) {
+    int rc = wbc_step_batch(s, N, &tick, out, obs, stream);
+    if (rc) return rc;
+    void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    rc = s->dtype == WBC_F64
+             ? integrate_impl<double>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st)
+             : integrate_impl<float>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st);
+    if (rc) return rc;
+  }
+  return WBC_OK;
 }
 
 extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const double* w_des,
