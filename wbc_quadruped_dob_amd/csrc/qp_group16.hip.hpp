@@ -397,8 +397,10 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     }
     SEG(3);
     // ---- full step: the candidate joins the active set
+    // Executed unconditionally (predicated per row) and followed directly by the search for the next candidate, so
+    // that the factor update and the independent slack/argmin chain share one basic block and interleave.
     const bool addg = go && full;
-    if (__ballot(addg) != 0ull) {
+    {
       T nr;
       add_column(addg, iq, dd, dn2, nr);
       if (addg) {
@@ -409,6 +411,8 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
         ip = -1;
       }
     }
+    // rows that just added look for their next candidate now (rows that drop keep theirs: ip >= 0 there)
+    pick();
     SEG(4);
     // ---- partial / dual-only step: the blocking constraint leaves, factors are rebuilt
     const bool dropg = go && !full;
@@ -454,8 +458,6 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
       }
     }
     SEG(5);
-    pick();
-    SEG(6);
   }
 
   // ------------------------------------------------------------------ outputs: f, tau (a9), status
