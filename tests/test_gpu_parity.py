@@ -388,3 +388,31 @@ def test_integrate_single_call_matches_forward_dynamics(torch_cuda, gpu_model, o
     rhs[:, 6:] += to_host(out["tau"])
     rhs += np.einsum("nei,ne->ni", to_host(out["Jc"]).reshape(n, 12, 18), to_host(out["f"]))
     assert np.abs(lhs - rhs).max() < 1e-8 * np.abs(rhs).max()
+
+
+def test_hard_qps_many_active_constraints_and_drops(torch_cuda, gpu_model, oracle):
+    """Stress the active-set paths: low friction, strong lateral demand, tight normal-force box, tilted normals --
+    many active constraints, partial steps and constraint drops (the kernel's rebuild path)."""
+    torch = torch_cuda
+    n = 20000
+    rng = np.random.default_rng(99)
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=31)
+    B["mu"] = rng.choice([0.15, 0.25, 0.4], size=(n, 4))
+    B["w_des"][:, 0:2] += rng.uniform(-180, 180, (n, 2))
+    B["w_des"][:, 3:6] += rng.uniform(-40, 40, (n, 3))
+    B["mask"][: n // 2] = 0b1111
+    solver, P = _solver(gpu_model, max_batch=n, fn_max=90.0, fn_min=5.0)
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
+    got = _run_step(torch, solver, B, "f64")
+    assert ref["iters"].max() >= 10 and (ref["iters"] > 6).mean() > 0.05  # the batch really is hard
+    np.testing.assert_array_equal(got["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert ok.mean() > 0.99
+    assert relerr(got["f"][ok], ref["f"][ok]) < TIGHT64 and relerr(got["tau"][ok], ref["tau"][ok]) < TIGHT64
+    # the box and the pyramid hold at the solution
+    f = got["f"][ok].reshape(-1, 4, 3)
+    nrm = B["normals"][ok].reshape(-1, 4, 3)
+    nrm = nrm / np.linalg.norm(nrm, axis=2, keepdims=True)
+    fn = np.einsum("nka,nka->nk", f, nrm)
+    on = (((B["mask"][ok][:, None] >> np.arange(4)[None, :]) & 1) == 1)
+    assert fn[on].min() > 5.0 - 1e-7 and fn[on].max() < 90.0 + 1e-7
