@@ -124,9 +124,10 @@ def test_step_vs_golden(torch_cuda, gpu_model, golden):
 
 
 def test_step_fp32_vs_fp32_oracle(torch_cuda, gpu_model, oracle):
-    """BASELINE.json configs[3] arithmetic (fp32).  fp32 cannot meet 1e-6: stated tolerance 5e-3 of the largest
-    torque/force against the fp32 oracle (both sides carry fp32 rounding through an ill-conditioned 12x12 QP),
-    and 1e-2 against the fp64 oracle."""
+    """BASELINE.json configs[3] arithmetic (fp32).  fp32 cannot meet 1e-6: stated tolerance 1e-3 of the largest
+    torque/force against the fp32 oracle AND against the fp64 oracle (measured on 32 768 states,
+    tools/f32_error_survey.py: p50 1e-5..4e-5, max 2.7e-4 for all three pairs gpu32/oracle32/oracle64 -- the HIP
+    path is as accurate as the fp32 oracle; the error is fp32 rounding through a QP of condition ~1e4)."""
     torch = torch_cuda
     n = 4096
     solver, P = _solver(gpu_model, dtype="f32", obs=1, max_batch=n)
@@ -144,9 +145,9 @@ def test_step_fp32_vs_fp32_oracle(torch_cuda, gpu_model, oracle):
     got = _run_step(torch, solver, B, "f32", integ, r)
     ok = (got["status"] == 0) & (ref32["status"] == 0)
     assert ok.mean() > 0.99
-    assert relerr(got["tau"][ok], ref32["tau"][ok]) < 5e-3
-    assert relerr(got["tau"][ok], ref64["tau"][ok]) < 1e-2
-    assert relerr(got["f"][ok], ref64["f"][ok]) < 1e-2
+    assert relerr(got["tau"][ok], ref32["tau"][ok]) < 1e-3
+    assert relerr(got["tau"][ok], ref64["tau"][ok]) < 1e-3
+    assert relerr(got["f"][ok], ref64["f"][ok]) < 1e-3
 
 
 def test_status_iteration_limit_and_mask_edges(torch_cuda, gpu_model, oracle):
