@@ -167,10 +167,11 @@ def main():
                          "launches_timed": tm["dyn_launches"], "event_pair_overhead_us": ev_overhead_us,
                          "note": "HIP events on the launch stream around every %d-th tick of the timed region; raw span "
                                  "(includes the event-pair overhead reported beside it)" % sample},
-            "kernels": {"dyn_sweep_us": dyn_s * 1e6, "rnea_step_us": rnea_s * 1e6 if split else None, "qp_us": qp_s * 1e6,
+            "kernels": {"dyn_sweep_us": dyn_s * 1e6, "rnea_step_us": rnea_s * 1e6 if tm["rnea_launches"] else None, "qp_us": qp_s * 1e6,
                         "qp_us_per_state_amortized": qp_s * 1e6 / n,
                         "qp_kernel": os.environ.get("WBC_QP_KERNEL", "group16"),
-                        "sweep": "split: mass_jac on a 2nd stream || rnea_step -> qp" if split else "fused dyn_sweep -> qp"},
+                        "sweep": ("split: mass_jac on a 2nd stream || rnea_step -> qp" if split else "fused dyn_sweep -> qp") if want_mats
+                                 else "rnea_step (no CRBA, no M/h/Jc) -> qp"},
             "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                    "iters_max": int(iters.max())},
         }

@@ -417,3 +417,44 @@ def test_hard_qps_many_active_constraints_and_drops(torch_cuda, gpu_model, oracl
     fn = np.einsum("nka,nka->nk", f, nrm)
     on = (((B["mask"][ok][:, None] >> np.arange(4)[None, :]) & 1) == 1)
     assert fn[on].min() > 5.0 - 1e-7 and fn[on].max() < 90.0 + 1e-7
+
+
+@pytest.mark.parametrize("obs", [0, 1])
+def test_step_without_matrix_outputs(torch_cuda, gpu_model, oracle, obs):
+    """Callers that only want tau, f (no M, h, Jc buffers) go through the CRBA-free front half: same answers."""
+    torch = torch_cuda
+    n = 3000
+    solver, P = _solver(gpu_model, obs=obs, max_batch=n)
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=41)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    r = 0.2 * np.sin(np.arange(n * 18).reshape(n, 18)) if obs else None
+    ig_ref = None if integ is None else integ.copy()
+    r_ref = None if r is None else r.copy()
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"],
+                      B["f_prev"], ig_ref, r_ref, nthreads=8)
+    got = _run_step(torch, solver, B, "f64", integ, r, want_mats=False)
+    assert np.array_equal(got["status"], ref["status"])
+    assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
+    if obs:
+        assert relerr(got["integ"], ig_ref) < TIGHT64 and relerr(got["r"], r_ref) < TIGHT64
+
+
+def test_split_sweep_variant_matches(torch_cuda, gpu_model, oracle, monkeypatch):
+    """WBC_SWEEP=split (mass_jac on a second stream || rnea_step -> QP) stays parity-green."""
+    torch = torch_cuda
+    monkeypatch.setenv("WBC_SWEEP", "split")
+    n = 2000
+    solver, P = _solver(gpu_model, obs=2, max_batch=n)
+    monkeypatch.delenv("WBC_SWEEP")
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=43)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    r = np.zeros((n, 18))
+    ig_ref, r_ref = integ.copy(), r.copy()
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"],
+                      B["f_prev"], ig_ref, r_ref, nthreads=8)
+    got = _run_step(torch, solver, B, "f64", integ, r, want_mats=True)
+    d = oracle.dynamics(B["q"], B["v"], nthreads=8)
+    for k in ("M", "h", "Jc", "pf"):
+        assert relerr(got[k], d[k]) < TIGHT64, k
+    assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
+    assert relerr(got["integ"], ig_ref) < TIGHT64

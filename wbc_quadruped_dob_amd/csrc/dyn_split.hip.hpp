@@ -1,3 +1,6 @@
+// rnea_step_kernel<RS_STEP...> is also the DEFAULT front half of a tick whose caller does not ask for M, h, Jc
+// (no CRBA at all: tau_partial comes from the merged force recursion).  The two-kernel split for ticks that DO
+// want M, h, Jc is an
 // EXPERIMENT (WBC_SWEEP=split; NOT the default): the dynamics sweep as TWO kernels that run concurrently on two
 // HIP streams.  Measured on MI355X it is 20 % slower per tick at N = 4 096 and 5 % slower at N = 262 144 than the
 // fused dyn_sweep kernel: at small batch each half pays the same fixed latencies (table staging, state loads,
@@ -15,7 +18,7 @@
 // fused sweep (no scratch, more waves per SIMD), and tau_partial = (M vdot_des + h) comes from a second force
 // recursion in rnea_step instead of from the M entries, so vdot_des is consumed in the first sweep, not loaded late.
 //
-// Same lane-per-leg mapping, DPP quad reductions, LDS constant table and component-major addressing as
+// Same lane-per-leg mapping (leg-major rows), permlane row reductions, LDS constant table and addressing as
 // dyn_sweep.hip.hpp (the fused form, kept selectable with WBC_SWEEP=fused).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -33,9 +36,9 @@ constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
 #define WBC_ADDR_MACROS                                                                                                   \
   const size_t N = a.N;                                                                                                    \
   const unsigned N32 = (unsigned)N;                                                                                        \
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;                                                        \
-  const int leg = (int)(gid & 3);                                                                                          \
-  const size_t s_raw = gid >> 2;                                                                                           \
+  /* lane = 16*leg + (state within the wave), as in dyn_sweep_kernel */                                                    \
+  const int leg = (int)((threadIdx.x & 63) >> 4);                                                                          \
+  const size_t s_raw = ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);                \
   const bool live = s_raw < N;                                                                                             \
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);                                                                   \
   const unsigned legN = (unsigned)leg * N32;
@@ -199,11 +202,11 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
   {
     const T bm = model->base_m;
     const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
-    const T tm = quad_sum(cm) + bm;
-    const V3<T> th = quad_sum(ch) + bh;
+    const T tm = xrow_sum(cm) + bm;
+    const V3<T> th = xrow_sum(ch) + bh;
     S3<T> tI;
-    tI.xx = quad_sum(cI.xx) + model->base_Io[0]; tI.xy = quad_sum(cI.xy) + model->base_Io[1]; tI.xz = quad_sum(cI.xz) + model->base_Io[2];
-    tI.yy = quad_sum(cI.yy) + model->base_Io[3]; tI.yz = quad_sum(cI.yz) + model->base_Io[4]; tI.zz = quad_sum(cI.zz) + model->base_Io[5];
+    tI.xx = xrow_sum(cI.xx) + model->base_Io[0]; tI.xy = xrow_sum(cI.xy) + model->base_Io[1]; tI.xz = xrow_sum(cI.xz) + model->base_Io[2];
+    tI.yy = xrow_sum(cI.yy) + model->base_Io[3]; tI.yz = xrow_sum(cI.yz) + model->base_Io[4]; tI.zz = xrow_sum(cI.zz) + model->base_Io[5];
     const V3<T> hw = mul(R, th);
     const S3<T> Iw = congr(R, tI);
     T* M = a.M;
@@ -449,8 +452,8 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
   }
   if (WH) {
     const T* pb = &park[2 * PW][ln];
-    const V3<T> bfn = quad_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);
-    const V3<T> bff = quad_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
+    const V3<T> bfn = xrow_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);
+    const V3<T> bff = xrow_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
     const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);
     ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
     if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
@@ -459,10 +462,10 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
   if (OBS) {
     const T* pb = &park[2 * PW][ln];
     SF<T> mom0, grv0;
-    mom0.n = quad_sum(macc.n) + mk<T>(pb[BLOCK * 6], pb[BLOCK * 7], pb[BLOCK * 8]);
-    mom0.f = quad_sum(macc.f) + mk<T>(pb[BLOCK * 9], pb[BLOCK * 10], pb[BLOCK * 11]);
-    grv0.n = quad_sum(gacc.n) + mk<T>(pb[BLOCK * 12], pb[BLOCK * 13], pb[BLOCK * 14]);
-    grv0.f = quad_sum(gacc.f) + mk<T>(pb[BLOCK * 15], pb[BLOCK * 16], pb[BLOCK * 17]);
+    mom0.n = xrow_sum(macc.n) + mk<T>(pb[BLOCK * 6], pb[BLOCK * 7], pb[BLOCK * 8]);
+    mom0.f = xrow_sum(macc.f) + mk<T>(pb[BLOCK * 9], pb[BLOCK * 10], pb[BLOCK * 11]);
+    grv0.n = xrow_sum(gacc.n) + mk<T>(pb[BLOCK * 12], pb[BLOCK * 13], pb[BLOCK * 14]);
+    grv0.f = xrow_sum(gacc.f) + mk<T>(pb[BLOCK * 15], pb[BLOCK * 16], pb[BLOCK * 17]);
     const V3<T> Pl = mul(R, mom0.f), Pa = mul(R, mom0.n);
     const V3<T> gl = mul(R, grv0.f), ga = mul(R, grv0.n);
     const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
@@ -488,8 +491,8 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
     T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
     if (OBS && prm.observer_order > 0) {
       const V3<T> fp = mk<T>(LDV(a.f_prev, 3 * leg + 0), LDV(a.f_prev, 3 * leg + 1), LDV(a.f_prev, 3 * leg + 2));
-      const V3<T> ub_f = quad_sum(fp);
-      const V3<T> ub_n = quad_sum(cross(dw, fp));
+      const V3<T> ub_f = xrow_sum(fp);
+      const V3<T> ub_n = xrow_sum(cross(dw, fp));
       const T ub[6] = {ub_f.x, ub_f.y, ub_f.z, ub_n.x, ub_n.y, ub_n.z};
       const T dt = prm.dt;
       const bool o1 = prm.observer_order == 1;

@@ -503,7 +503,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   timing_tick(s);
   int rc;
   hipError_t e;
-  if (s->sweep_mode == 0) {
+  if (s->sweep_mode == 0 || !mats) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
     if (mats) { rc = fork_mass_jac<T>(s, a, st); if (rc) return rc; }
     const int mode = RS_STEP | (mats ? RS_H : 0) | (ob ? RS_OBS : 0) | ((!mats && out->pf) ? RS_PF : 0);
     rc = span_begin(s, 2, st);
