@@ -345,10 +345,10 @@ __global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_group16_kernel(DevParams
     T z_me;
     {
       T za[3] = {0, 0, 0};  // three independent chains instead of one 12-deep FMA chain
+      const T ddz = (isvar && v >= iq) ? dd : (T)0;  // mask at the source lane: one select instead of twelve
       sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        const T dj = gbc<j>(dd);
-        za[j % 3] += Jr[j] * ((j >= iq) ? dj : (T)0);
+        za[j % 3] += Jr[j] * gbc<j>(ddz);
       });
       z_me = (za[0] + za[1]) + za[2];
     }
