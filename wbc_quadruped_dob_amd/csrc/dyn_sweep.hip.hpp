@@ -183,8 +183,10 @@ constexpr int SW_OBS = 4;   // momentum observer update (needs SW_STEP) / p, bet
 #endif
 // BLOCK = 64 for small batches (N/16 workgroups: one per CU at N = 4096) or 256 for large ones (four waves
 // share one constant table, which lets two workgroups = 8 waves fit the CU's 160 KB of LDS).
+// The observer variants may use more than 256 VGPRs (their occupancy is LDS-bound anyway); forcing two waves per
+// SIMD there makes the compiler spill to scratch.
 template <class T, int MODE, int BLOCK>
-__global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+__global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                         SweepArgs<T> a) {
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0;
   __shared__ T cst[CST_WORDS];
@@ -312,15 +314,16 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
   bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
   bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
   // the base body's own wrench / momentum / weight are formed now, so that om0, v0, aL0 die after joint 0
-  constexpr int PW = OBS ? 33 : 15;        // parked words per joint
-  constexpr int PB = OBS ? 18 : 6;         // parked words of the base body (wrench, momentum, weight)
-  __shared__ T park[2 * PW + PB][BLOCK];
+  constexpr int PW = 15;                   // parked words per joint: E 9 + body wrench 6
+  constexpr int PB = 6;                    // parked words of the base body's own wrench
+  constexpr int PE2 = OBS ? 9 : 0;         // observer: E of joint 2 too (the momentum pass walks the leg again)
+  __shared__ T park[2 * PW + PB + PE2][BLOCK];
   const int ln = threadIdx.x;
-  V3<T> omp, vp, aAp, aLp, gLp;
+  V3<T> omp, vp, aAp, aLp;
   {
     M3<T> R;
     MAKE_R(R);
-    SF<T> bw, bmom, bgrv;
+    SF<T> bw;
     const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
     const V3<T> v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
     const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));  // R^T (-g)
@@ -331,22 +334,17 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     bw.f = Ia0.f + cross(om0, Iv0.f);
     T* pb = &park[2 * PW][ln];
     pb[0] = bw.n.x; pb[BLOCK] = bw.n.y; pb[BLOCK * 2] = bw.n.z; pb[BLOCK * 3] = bw.f.x; pb[BLOCK * 4] = bw.f.y; pb[BLOCK * 5] = bw.f.z;
-    if (OBS) {
-      bmom = Iv0; bgrv.n = cross(bh, gneg); bgrv.f = gneg * bm;
-      pb[BLOCK * 6] = bmom.n.x; pb[BLOCK * 7] = bmom.n.y; pb[BLOCK * 8] = bmom.n.z; pb[BLOCK * 9] = bmom.f.x; pb[BLOCK * 10] = bmom.f.y; pb[BLOCK * 11] = bmom.f.z;
-      pb[BLOCK * 12] = bgrv.n.x; pb[BLOCK * 13] = bgrv.n.y; pb[BLOCK * 14] = bgrv.n.z; pb[BLOCK * 15] = bgrv.f.x; pb[BLOCK * 16] = bgrv.f.y; pb[BLOCK * 17] = bgrv.f.z;
-    }
-    omp = om0; vp = v0; aAp = mk<T>(0, 0, 0); aLp = aL0; gLp = gneg;
+    omp = om0; vp = v0; aAp = mk<T>(0, 0, 0); aLp = aL0;
   }
 
   SSTAMP();  // 4: base quantities done (state loads have arrived)
   // ------------------------------------------------------------------ forward sweep down the leg
-  // Per-joint results that the return sweep needs (E, body force, and for the observer the body
-  // momentum, weight and velocity) are PARKED IN LDS for joints 0 and 1 ([word][lane]: conflict-free),
-  // which keeps the kernel at two waves per SIMD without scratch; joint 2's stay in registers.
+  // Per-joint results that the return sweep needs (E, body wrench) are PARKED IN LDS for joints 0 and 1
+  // ([word][lane]: conflict-free), which keeps the kernel at two waves per SIMD without scratch; joint 2's stay in
+  // registers.  The observer's momentum / gravity recursions run as a SECOND pass over the leg after the main
+  // outputs are stored (their registers are free by then), re-using the parked E matrices.
   M3<T> E2;
-  SF<T> f2, m2, g2;
-  V3<T> om2, vv2;
+  SF<T> f2;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int o = JOINT_WORDS * k;
@@ -368,29 +366,22 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     const V3<T> aL = tmul(E, aLp + cross(aAp, r)) + cross(vv, ax) * qd;
     const SF<T> Iv = inertia_mul(m, h, Io, om, vv);
     const SF<T> Ia = inertia_mul(m, h, Io, aA, aL);
-    SF<T> fk, gk;
+    SF<T> fk;
     fk.n = Ia.n + cross(om, Iv.n) + cross(vv, Iv.f);
     fk.f = Ia.f + cross(om, Iv.f);
-    if (OBS) {
-      const V3<T> gL = tmul(E, gLp);  // angular part of the gravity-only acceleration stays zero
-      gk.n = cross(h, gL);
-      gk.f = gL * m;
-      gLp = gL;
-    }
     if (k < 2) {
       T* pk = &park[PW * k][ln];
 #pragma unroll
       for (int e = 0; e < 9; ++e) pk[BLOCK * e] = E.a[e];
       pk[BLOCK * 9] = fk.n.x; pk[BLOCK * 10] = fk.n.y; pk[BLOCK * 11] = fk.n.z;
       pk[BLOCK * 12] = fk.f.x; pk[BLOCK * 13] = fk.f.y; pk[BLOCK * 14] = fk.f.z;
-      if (OBS) {
-        pk[BLOCK * 15] = Iv.n.x; pk[BLOCK * 16] = Iv.n.y; pk[BLOCK * 17] = Iv.n.z; pk[BLOCK * 18] = Iv.f.x; pk[BLOCK * 19] = Iv.f.y; pk[BLOCK * 20] = Iv.f.z;
-        pk[BLOCK * 21] = gk.n.x; pk[BLOCK * 22] = gk.n.y; pk[BLOCK * 23] = gk.n.z; pk[BLOCK * 24] = gk.f.x; pk[BLOCK * 25] = gk.f.y; pk[BLOCK * 26] = gk.f.z;
-        pk[BLOCK * 27] = om.x; pk[BLOCK * 28] = om.y; pk[BLOCK * 29] = om.z; pk[BLOCK * 30] = vv.x; pk[BLOCK * 31] = vv.y; pk[BLOCK * 32] = vv.z;
-      }
     } else {
       E2 = E; f2 = fk;
-      if (OBS) { m2 = Iv; g2 = gk; om2 = om; vv2 = vv; }
+      if (OBS) {
+        T* pe = &park[2 * PW + PB][ln];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) pe[BLOCK * e] = E.a[e];
+      }
     }
     omp = om; vp = vv; aAp = aA; aLp = aL;
   }
@@ -403,13 +394,12 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     for (int k = 0; k < 3; ++k)
       al[k] = *(const T*)((const char*)(a.vdot_des + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
   }
-  T p_leg[3], ct_leg[3], g_leg[3];
   T taup[3] = {0, 0, 0};  // (M vdot_des) joint rows of this leg, accumulated as M entries appear
   T cm; V3<T> ch; S3<T> cI;  // composite inertia of the subtree rooted at joint k, in frame k
   V3<T> dft = mk<T>(CS(129), CS(130), CS(131));  // foot relative to the current frame origin
   V3<T> jc[3];                                   // foot Jacobian columns, rotated progressively towards the base
   SF<T> Fp[3];                                   // CRBA force columns of joints >= k, carried frame by frame
-  SF<T> facc, macc, gacc;                        // children's wrench / momentum / weight in the current frame
+  SF<T> facc;                                    // children's wrench in the current frame
 #pragma unroll
   for (int k = 2; k >= 0; --k) {
     const int o = JOINT_WORDS * k;
@@ -420,33 +410,21 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     S3<T> Io;
     Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
     M3<T> E;
-    SF<T> fk, mk_, gk;
-    V3<T> om, vv;
+    SF<T> fk;
     if (k == 2) {
       E = E2; fk = f2;
-      if (OBS) { mk_ = m2; gk = g2; om = om2; vv = vv2; }
     } else {
       const T* pk = &park[PW * k][ln];
 #pragma unroll
       for (int e = 0; e < 9; ++e) E.a[e] = pk[BLOCK * e];
       fk.n = mk<T>(pk[BLOCK * 9], pk[BLOCK * 10], pk[BLOCK * 11]) + facc.n;
       fk.f = mk<T>(pk[BLOCK * 12], pk[BLOCK * 13], pk[BLOCK * 14]) + facc.f;
-      if (OBS) {
-        mk_.n = mk<T>(pk[BLOCK * 15], pk[BLOCK * 16], pk[BLOCK * 17]) + macc.n; mk_.f = mk<T>(pk[BLOCK * 18], pk[BLOCK * 19], pk[BLOCK * 20]) + macc.f;
-        gk.n = mk<T>(pk[BLOCK * 21], pk[BLOCK * 22], pk[BLOCK * 23]) + gacc.n; gk.f = mk<T>(pk[BLOCK * 24], pk[BLOCK * 25], pk[BLOCK * 26]) + gacc.f;
-        om = mk<T>(pk[BLOCK * 27], pk[BLOCK * 28], pk[BLOCK * 29]); vv = mk<T>(pk[BLOCK * 30], pk[BLOCK * 31], pk[BLOCK * 32]);
-      }
     }
-    // RNEA / momentum / gravity projections on the joint axis
+    // RNEA projection on the joint axis
     {
       const T hk = dot(ax, fk.n);
       if (MATS) STLX(a.h, 6, 0, jxN[k], hk);
       if (STEP) taup[k] += hk;
-    }
-    if (OBS) {
-      p_leg[k] = dot(ax, mk_.n);
-      ct_leg[k] = -dot(ax, cross(om, mk_.n) + cross(vv, mk_.f));
-      g_leg[k] = dot(ax, gk.n);
     }
     // CRBA: close the composite of joint k
     if (k == 2) { cm = m; ch = h; cI = Io; }
@@ -473,7 +451,6 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
 #pragma unroll
     for (int j = k; j < 3; ++j) { jc[j] = mul(E, jc[j]); Fp[j] = to_parent(E, r, Fp[j]); }
     facc = to_parent(E, r, fk);
-    if (OBS) { macc = to_parent(E, r, mk_); gacc = to_parent(E, r, gk); }
     {
       const V3<T> hr = mul(E, ch);
       const S3<T> Ir = congr(E, cI);
@@ -570,13 +547,72 @@ __global__ __launch_bounds__(BLOCK, WBC_SWEEP_WAVES) void dyn_sweep_kernel(const
     ST4(M, midx18(2, 4), -hw.x, midx18(3, 3), Iw.xx, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz);
     if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
   }
+  // ------------------------------------------------------------------ observer: second pass over the leg
+  // body momenta I v, gravity-only forces and their leaf->root accumulation (a5): velocities are re-propagated
+  // with the parked E matrices (cheap), so nothing of this lived in registers during the first pass.
   SF<T> mom0, grv0;
+  T p_leg[3], ct_leg[3], g_leg[3];
   if (OBS) {
-    const T* pb = &park[2 * PW][ln];
-    mom0.n = xrow_sum(macc.n) + mk<T>(pb[BLOCK * 6], pb[BLOCK * 7], pb[BLOCK * 8]);
-    mom0.f = xrow_sum(macc.f) + mk<T>(pb[BLOCK * 9], pb[BLOCK * 10], pb[BLOCK * 11]);
-    grv0.n = xrow_sum(gacc.n) + mk<T>(pb[BLOCK * 12], pb[BLOCK * 13], pb[BLOCK * 14]);
-    grv0.f = xrow_sum(gacc.f) + mk<T>(pb[BLOCK * 15], pb[BLOCK * 16], pb[BLOCK * 17]);
+    // keep the compiler from hoisting this pass's loads into the first pass (that is what made the one-pass form spill)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    V3<T> omk[3], vvk[3], glk[3];
+    SF<T> ivk[3];
+    V3<T> om0, v0, gneg;
+    {
+      om0 = tmul(R, mk<T>(LDU(a.v, 3), LDU(a.v, 4), LDU(a.v, 5)));
+      v0 = tmul(R, mk<T>(LDU(a.v, 0), LDU(a.v, 1), LDU(a.v, 2)));
+      gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));
+      V3<T> omp2 = om0, vp2 = v0, gp2 = gneg;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int o = JOINT_WORDS * k;
+        const T* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];
+        M3<T> Ek;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Ek.a[e] = pe[BLOCK * e];
+        const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
+        const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
+        S3<T> Io;
+        Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
+        const T qd = *(const T*)((const char*)(a.v + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+        omk[k] = tmul(Ek, omp2) + ax * qd;
+        vvk[k] = tmul(Ek, vp2 + cross(omp2, r));
+        glk[k] = tmul(Ek, gp2);
+        ivk[k] = inertia_mul(CS(o + 33), mk<T>(CS(o + 34), CS(o + 35), CS(o + 36)), Io, omk[k], vvk[k]);
+        omp2 = omk[k]; vp2 = vvk[k]; gp2 = glk[k];
+      }
+    }
+    SF<T> macc, gacc;
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+      const int o = JOINT_WORDS * k;
+      const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
+      const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
+      const T m = CS(o + 33);
+      const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
+      SF<T> mk_, gk;
+      mk_ = ivk[k];
+      gk.n = cross(h, glk[k]);
+      gk.f = glk[k] * m;
+      if (k < 2) { mk_.n = mk_.n + macc.n; mk_.f = mk_.f + macc.f; gk.n = gk.n + gacc.n; gk.f = gk.f + gacc.f; }
+      p_leg[k] = dot(ax, mk_.n);
+      ct_leg[k] = -dot(ax, cross(omk[k], mk_.n) + cross(vvk[k], mk_.f));
+      g_leg[k] = dot(ax, gk.n);
+      {
+        const T* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];  // E again, from LDS rather than from 27 registers
+        M3<T> Ek;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Ek.a[e] = pe[BLOCK * e];
+        macc = to_parent(Ek, r, mk_);
+        gacc = to_parent(Ek, r, gk);
+      }
+    }
+    const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+    mom0.n = xrow_sum(macc.n) + Iv0.n;
+    mom0.f = xrow_sum(macc.f) + Iv0.f;
+    grv0.n = xrow_sum(gacc.n) + cross(bh, gneg);
+    grv0.f = xrow_sum(gacc.f) + gneg * bm;
   }
 
   SSTAMP();  // 8: base block stored
