@@ -458,3 +458,29 @@ def test_split_sweep_variant_matches(torch_cuda, gpu_model, oracle, monkeypatch)
         assert relerr(got[k], d[k]) < TIGHT64, k
     assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
     assert relerr(got["integ"], ig_ref) < TIGHT64
+
+
+def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle):
+    """Quaternions and terrain normals are normalised inside (as in the oracle); a NaN in one state's inputs must not
+    hang the kernels nor disturb any other state."""
+    torch = torch_cuda
+    n = 512
+    solver, P = _solver(gpu_model, max_batch=n)
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=51)
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
+    B2 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}
+    B2["q"][:, 3:7] *= 0.37
+    B2["normals"] *= 2.5
+    got = _run_step(torch, solver, B2, "f64")
+    assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
+    B3 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}
+    bad = [5, 130, 131, 400]
+    B3["w_des"][bad[0], 2] = np.nan
+    B3["q"][bad[1], 9] = np.nan
+    B3["normals"][bad[2], 4] = np.inf
+    B3["mu"][bad[3], 1] = np.nan
+    got3 = _run_step(torch, solver, B3, "f64")   # must return (the QP loop is bounded)
+    good = np.ones(n, bool)
+    good[bad] = False
+    assert relerr(got3["tau"][good], ref["tau"][good]) < TIGHT64
+    np.testing.assert_array_equal(got3["status"][good], ref["status"][good])
