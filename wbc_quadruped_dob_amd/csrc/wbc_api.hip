@@ -43,6 +43,8 @@ struct wbc_solver {
   void* d_ws = nullptr;     // WS_WORDS * max_batch * sizeof(T)
   QpJidx jmap;
   int qp_kernel = 0;  // 0 = qp_group16 (default), 1 = qp_wave; env WBC_QP_KERNEL=wave selects 1
+  int qp_wpb = 1;           // wavefronts per QP workgroup: 1 (default) or 4 (env WBC_QP_WPB=4)
+  bool qp_regroup = false;  // env WBC_QP_REGROUP=1 with WBC_QP_WPB=4: re-deal the 16 QPs of a workgroup by predicted work (A/B; measured: no gain)
   int sweep_mode = 1; // 1 = fused dyn_sweep (default), 0 = split (mass_jac on a second stream || rnea_step -> QP); env WBC_SWEEP=split
                       // measured on MI355X: split is 5-20 % slower (two kernels pay the fixed latencies twice), kept for A/B
   hipStream_t aux = nullptr;
@@ -264,6 +266,8 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (!s) return fail(WBC_E_INVALID, "out of memory");
   s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p;
   if (const char* e = std::getenv("WBC_QP_KERNEL")) s->qp_kernel = (std::strcmp(e, "wave") == 0) ? 1 : 0;
+  if (const char* e = std::getenv("WBC_QP_WPB")) s->qp_wpb = (std::strcmp(e, "4") == 0) ? 4 : 1;
+  if (const char* e = std::getenv("WBC_QP_REGROUP")) s->qp_regroup = (std::strcmp(e, "1") == 0);
   if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
@@ -533,8 +537,16 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     const unsigned blocks = (unsigned)((N + 3) / 4);
     hipLaunchKernelGGL((qp_wave_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
   } else {                  // one QP per 16-lane DPP row, factors in registers
-    const unsigned blocks = (unsigned)((N + 15) / 16);
-    hipLaunchKernelGGL((qp_group16_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+    if (s->qp_wpb == 4) {
+      const unsigned blocks = (unsigned)((N + 15) / 16);
+      if (s->qp_regroup)
+        hipLaunchKernelGGL((qp_group16_kernel<T, true, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+      else
+        hipLaunchKernelGGL((qp_group16_kernel<T, false, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+    } else {
+      const unsigned blocks = (unsigned)((N + 3) / 4);
+      hipLaunchKernelGGL((qp_group16_kernel<T, false, 1>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+    }
   }
   e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("qp launch: ") + hipGetErrorString(e));
