@@ -11,7 +11,11 @@ python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/benc
 python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
 python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
 python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144.json" 2>> "$O/bench.err"
+python bench.py --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --no-mats > "$O/bench_cfg2_n4096_nomats.json" 2>> "$O/bench.err"
+python bench.py --config 5 --steps 100 --warmup 10 > "$O/bench_cfg5_h20_n1024.json" 2>> "$O/bench.err"
+python bench.py --config 5 --steps 20 --warmup 3 --batch 32768 > "$O/bench_cfg5_h20_n32768.json" 2>> "$O/bench.err"
 cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- python3 "$R/bench.py" --config 5 --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
 find "$O" -name "*kernel_trace.csv" -delete
@@ -19,7 +23,7 @@ cd "$R"
 bash tools/pmc_profile.sh > "$O/pmc.log" 2>&1
 cp gpurun_out/pmc/summary.json "$O/pmc_summary.json"
 cat "$O/pytest_gpu.log" "$O/smoke.log" "$O/abi_smoke.log"
-for f in "$O"/bench_cfg*.json; do echo "== $f"; python3 -c "
+for f in "$O"/bench_cfg[234]_n*[0-9].json; do echo "== $f"; python3 -c "
 import json,sys
 r=json.load(open('$f')); print(r['config']['workload']); print('  ms/step %.4f  steps/s %.4e  dyn %.1f us frac %.3f  qp %.1f us'%(r['ms_per_step'],r['value'],r['kernels']['dyn_sweep_us'],r['roofline']['frac'],r['kernels']['qp_us']))"; done
 cat "$O"/stats_n4096_kernel_stats.csv "$O"/stats_n262144_kernel_stats.csv

@@ -307,7 +307,7 @@ class Solver:
         ms = (C.c_double * 3)()
         cnt = (C.c_int * 3)()
         _check(lib().wbc_solver_collect_timing(self._h, ms, cnt), "wbc_solver_collect_timing")
-        names = ("dyn", "qp", "rnea")  # dyn = mass_jac kernel (or the fused sweep with WBC_SWEEP=fused)
+        names = ("dyn", "qp", "rnea")  # dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
         out = {}
         for i, n in enumerate(names):
             out[n + "_ms"] = ms[i]
