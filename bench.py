@@ -20,6 +20,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+VALU_F64_PEAK_TFLOPS = 78.6  # fp64 vector FMA; tools/fma_probe.hip measures it on the box
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Algorithmic words per state of the kernel the roofline is quoted on:
 #   fused dyn_sweep (WBC_SWEEP=fused): SURVEY.md 8(d) dynamics-sweep stage, in q19+v18(+mask) -> out M171+h18+Jc216 = 443
@@ -181,6 +182,19 @@ def main():
             res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split)
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
+            fl = res["cpu_baseline"].get("flops_per_step")
+            if fl:
+                # whole path (sweep + QP) against the fp64 vector-FMA peak (the fused path sits above the
+                # fp64 ridge, so this -- not HBM -- is its ceiling); 78.6 TFLOP/s = 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
+                tf = fl * res["value"] / 1e12
+                res["roofline_whole_path"] = {"bound": "valu_f64", "achieved": tf, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                              "frac": tf / VALU_F64_PEAK_TFLOPS, "flops_per_step": fl,
+                                              "note": "flops = instrumented oracle op count x control-steps/s at the bench batch"}
+                lb = res.get("roofline_large_batch")
+                if lb:
+                    tfl = fl * lb["steps_per_s"] / 1e12
+                    lb["whole_path_tflops"] = tfl
+                    lb["whole_path_frac_of_valu_f64_peak"] = tfl / VALU_F64_PEAK_TFLOPS
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
@@ -382,7 +396,23 @@ def cpu_baseline(B, P, dtype, n):
         tried[t] = val
         if val > best:
             best, bt, br = val, t, reps
-    return {"value": best, "unit": "control-steps/s", "cores": bt, "kind": "port",
+    # SURVEY.md 8d extras from the same oracle: per-QP wall time on one thread, instrumented operation count per step
+    extras = {}
+    if dtype == "f64":
+        ns, _ = orc.qp_time(P, *[args[i] for i in (0, 1, 2, 4, 5)], B["mask"])
+        extras["qp_p50_us"] = float(np.median(ns)) * 1e-3
+        extras["qp_p99_us"] = float(np.percentile(ns, 99)) * 1e-3
+        ns_ = min(n, 256)
+        integ0 = orc.dynamics(args[0][:ns_], args[1][:ns_])["p"]
+        fl = []
+        for i in range(ns_):
+            oc = orc.op_count(P, *[a[i] for a in args[:6]], int(B["mask"][i]), args[7][i], args[8][i],
+                              integ0[i] if P["observer_order"] else None, np.zeros(18) if P["observer_order"] else None)
+            fl.append(oc["flops"])
+        extras["flops_per_step"] = float(np.mean(fl))
+        extras["flops_note"] = ("instrumented count (add+mul+div+sqrt+trig, FMA = 2) of the oracle's scalar type over the first "
+                                "%d states; dense restatement, upper bound for a structure-exploiting kernel" % ns_)
+    return {"value": best, "unit": "control-steps/s", "cores": bt, "kind": "port", **extras,
             "sample": "the same %d-state batch repeated %d times on %d OpenMP thread(s); ~5 s single-thread + ~4 s per "
                       "thread count tried %s (host reports %d usable cores); g++ -O2 -march=native build of oracle/"
                       % (n, br, bt, sorted(tried), navail),

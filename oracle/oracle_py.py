@@ -15,7 +15,7 @@ _LIB = os.path.join(_HERE, "_build", "libwbc_oracle.so")
 def build(force=False):
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
-            for f in ("wbc_oracle.hpp", "wbc_oracle_capi.cpp")):
+            for f in ("wbc_oracle.hpp", "wbc_oracle_capi.cpp", "op_count.cpp")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB
 
@@ -161,6 +161,48 @@ def _rollout(self, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext
 
 
 Oracle.rollout = _rollout
+
+def _qp_time(self, P, q, v, w_des, normals, mu, mask):
+    """Per-QP wall time (ns) of {assembly + solve} on one thread, float64; returns (ns[N], iters[N])."""
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    N = q.shape[0]
+    ns = np.zeros(N)
+    it = np.zeros(N, np.int32)
+    ps = make_params_struct(P)
+    lib().wbco_qp_time_f64(self.h, C.byref(ps), N, _p(c(q)), _p(c(v)), _p(c(w_des)), _p(c(normals)), _p(c(mu)),
+                           _p(np.ascontiguousarray(mask, dtype=np.int32)), _p(ns), _p(it))
+    return ns, it
+
+
+Oracle.qp_time = _qp_time
+
+OP_STAGES = ("dynamics", "observer", "qp_assemble", "qp_solve", "torque_map")
+OP_KINDS = ("add", "mul", "div", "sqrt", "trig", "cmp")
+
+
+def _op_count(self, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, integ=None, r=None):
+    """Instrumented operation count of ONE oracle step for ONE state (1-D float64 inputs; oracle/op_count.cpp).
+    Returns dict(counts={stage: {kind: n}}, flops=adds+muls+divs+sqrts+trig, iters, tau, f)."""
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    k = self._keep
+    counts = np.zeros((len(OP_STAGES), len(OP_KINDS)), np.int64)
+    tau = np.zeros(self.nj)
+    f = np.zeros(3 * self.nf)
+    ps = make_params_struct(P)
+    if integ is not None:
+        integ, r = integ.copy(), r.copy()
+    fn = lib().wbco_op_count
+    fn.restype = C.c_int
+    it = fn(self.nb, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), _p(k[6]), self.nf, _p(k[7]), _p(k[8]),
+            _p(k[9]), C.byref(ps), _p(c(q)), _p(c(v)), _p(c(w_des)), _p(c(vdot_des)), _p(c(normals)), _p(c(mu)), int(mask),
+            _p(c(tau_prev)), _p(c(f_prev)), _p(integ), _p(r), _p(counts), _p(tau), _p(f))
+    assert it >= 0
+    d = {s: {kd: int(counts[i, j]) for j, kd in enumerate(OP_KINDS)} for i, s in enumerate(OP_STAGES)}
+    return dict(counts=d, flops=int(counts[:, :5].sum()), flops_by_stage={s: int(counts[i, :5].sum()) for i, s in enumerate(OP_STAGES)},
+                iters=it, tau=tau, f=f)
+
+
+Oracle.op_count = _op_count
 
 
 def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9):

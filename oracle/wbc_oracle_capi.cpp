@@ -3,6 +3,7 @@
 // bench.py's cpu_baseline leg load this library; the product never does.
 // Batch layout here is row-per-state (AoS, numpy-natural): x[N][ncomp].
 #include "wbc_oracle.hpp"
+#include <chrono>
 #include <new>
 
 using namespace wbco;
@@ -141,5 +142,31 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
 
 DEF_API(f64, double, md)
 DEF_API(f32, float, mf)
+
+// Per-QP wall time on one thread (SURVEY.md 8d "CPU: p50 of per-QP wall time over the batch"): for every state the
+// dynamics run untimed, then {a7 assembly + a8 solve} is timed with steady_clock; ns_out[N], iters_out[N] (may be null).
+void wbco_qp_time_f64(void* hh, const wbco_params* pp, int N, const double* q, const double* v, const double* w_des,
+                      const double* normals, const double* mu, const int* mask, double* ns_out, int* iters_out) {
+  const Model<double>& m = ((OracleHandle*)hh)->md;
+  const Params P = to_params(pp);
+  const int nv = m.nv(), nq = nv + 1, nf = m.nf;
+  for (int s = 0; s < N; ++s) {
+    DynOut<double> d;
+    dynamics(m, q + (size_t)s * nq, v + (size_t)s * nv, d);
+    V3<double> pf[MAXF];
+    for (int f = 0; f < nf; ++f) pf[f] = V3<double>(d.pf[3 * f], d.pf[3 * f + 1], d.pf[3 * f + 2]);
+    const double* qs = q + (size_t)s * nq;
+    double x[QPN], lam[QPM];
+    int status = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    QP<double> qp;
+    qp_assemble(P, nf, (unsigned)mask[s], V3<double>(qs[0], qs[1], qs[2]), pf, normals + (size_t)s * 3 * nf,
+                mu + (size_t)s * nf, w_des + (size_t)s * 6, qp);
+    const int it = qp_solve_gi(qp, P.max_iter, P.qp_tol, x, lam, &status);
+    const auto t1 = std::chrono::steady_clock::now();
+    ns_out[s] = std::chrono::duration<double, std::nano>(t1 - t0).count() + 0.0 * x[0];
+    if (iters_out) iters_out[s] = it;
+  }
+}
 
 }  // extern "C"

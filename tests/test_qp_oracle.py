@@ -108,3 +108,35 @@ def test_property_kkt_random(seed, mask):
     stat, feas, dual, comp = X.kkt_residuals(H, g, C, d, x, lam)
     scale = max(1.0, np.abs(g).max())
     assert stat < 1e-8 * scale and feas < 1e-8 and dual < 1e-12 and comp < 1e-6 * scale
+
+
+def test_instrumented_op_count_reproduces_the_step_and_is_in_the_surveyed_range(oracle, flat_model):
+    """oracle/op_count.cpp: the counting scalar runs the same step (results agree up to FMA contraction) and the
+    per-step count is the 25-35 kflop SURVEY.md 8d estimates for a 4-foot stance."""
+    B = synth.make_batch(2, 32, float(flat_model["mass"].sum()))
+    P = synth.default_params(observer_order=0)
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"])
+    flops = []
+    for s in range(32):
+        oc = oracle.op_count(P, B["q"][s], B["v"][s], B["w_des"][s], B["vdot_des"][s], B["normals"][s], B["mu"][s],
+                             int(B["mask"][s]))
+        assert oc["iters"] == ref["iters"][s]
+        np.testing.assert_allclose(oc["tau"], ref["tau"][s], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(oc["f"], ref["f"][s], rtol=1e-8, atol=1e-8)
+        assert oc["counts"]["dynamics"]["trig"] == 24          # one sin + one cos per joint
+        assert oc["flops_by_stage"]["observer"] == 0
+        flops.append(oc["flops"])
+    assert 20e3 < np.mean(flops) < 40e3
+    # more active-set iterations cost more QP operations
+    order = np.argsort(ref["iters"])
+    lo = oracle.op_count(P, *[B[k][order[0]] for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")], int(B["mask"][order[0]]))
+    hi = oracle.op_count(P, *[B[k][order[-1]] for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")], int(B["mask"][order[-1]]))
+    assert hi["flops_by_stage"]["qp_solve"] > lo["flops_by_stage"]["qp_solve"]
+
+
+def test_per_qp_timing_api(oracle, flat_model):
+    B = synth.make_batch(3, 64, float(flat_model["mass"].sum()))
+    P = synth.default_params(observer_order=0)
+    ns, it = oracle.qp_time(P, B["q"], B["v"], B["w_des"], B["normals"], B["mu"], B["mask"])
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"])
+    assert np.array_equal(it, ref["iters"]) and np.all(ns > 0)

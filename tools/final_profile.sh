@@ -7,12 +7,15 @@ cd "$R"
 python -m pytest tests -q -m gpu 2>&1 | tail -4 > "$O/pytest_gpu.log"
 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 ./tools/abi_smoke.bin > "$O/abi_smoke.log" 2>&1
+./tools/fma_probe.bin > "$O/fma_probe.log" 2>&1
+./tools/bw_probe.bin > "$O/bw_probe.log" 2>&1
 python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/bench.err"
 python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
 python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
 python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144.json" 2>> "$O/bench.err"
 python bench.py --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --no-mats > "$O/bench_cfg2_n4096_nomats.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 100 --warmup 10 > "$O/bench_cfg5_h20_n1024.json" 2>> "$O/bench.err"
+python bench.py --config 5 --steps 100 --warmup 10 --batch 128 > "$O/bench_cfg5_h20_n128.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 20 --warmup 3 --batch 32768 > "$O/bench_cfg5_h20_n32768.json" 2>> "$O/bench.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- python3 "$R/bench.py" --config 5 --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
@@ -22,7 +25,7 @@ find "$O" -name "*kernel_trace.csv" -delete
 cd "$R"
 bash tools/pmc_profile.sh > "$O/pmc.log" 2>&1
 cp gpurun_out/pmc/summary.json "$O/pmc_summary.json"
-cat "$O/pytest_gpu.log" "$O/smoke.log" "$O/abi_smoke.log"
+cat "$O/pytest_gpu.log" "$O/smoke.log" "$O/abi_smoke.log" "$O/fma_probe.log"
 for f in "$O"/bench_cfg[234]_n*[0-9].json; do echo "== $f"; python3 -c "
 import json,sys
 r=json.load(open('$f')); print(r['config']['workload']); print('  ms/step %.4f  steps/s %.4e  dyn %.1f us frac %.3f  qp %.1f us'%(r['ms_per_step'],r['value'],r['kernels']['dyn_sweep_us'],r['roofline']['frac'],r['kernels']['qp_us']))"; done
