@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--horizon", type=int, default=20, help="config 5: ticks per rollout")
     ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
+    ap.add_argument("--tracking", action="store_true", help="config 5: CoM planner in the loop (reference kernel every tick)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-mats", action="store_true", help="do not write M,h,Jc to HBM (fused-only variant)")
     ap.add_argument("--sample-every", type=int, default=10, help="HIP-event instrumentation period inside the timed region")
@@ -225,10 +226,19 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
                status=torch.zeros(n, dtype=torch.int32, device="cuda"), iters=torch.zeros(n, dtype=torch.int32, device="cuda"),
                M=solver.empty(171, n), h=solver.empty(18, n), Jc=solver.empty(216, n), pf=solver.empty(12, n))
 
+    plan = None
+    if args.tracking:
+        solver.set_ref_params(synth.default_ref_params())
+        plan = dev(synth.make_plan(B, rank=rank))
+
     def one_rollout():
         inp["q"].copy_(q0); inp["v"].copy_(v0); integ.copy_(integ0); rr.zero_(); out["tau"].zero_(); out["f"].zero_()
-        solver.rollout(H, inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, out, integ, rr,
-                       tau_ext)
+        if plan is not None:
+            solver.rollout_tracking(H, inp["q"], inp["v"], plan, inp["normals"], inp["mu"], mask, out, inp["w_des"],
+                                    inp["vdot_des"], integ, rr, tau_ext)
+        else:
+            solver.rollout(H, inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, out, integ,
+                           rr, tau_ext)
 
     for _ in range(max(1, args.warmup)):
         one_rollout()
@@ -255,7 +265,8 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": "configs[4]: horizon=%d x batch=%d rollouts per GPU, trot masks, observer on, pushes, %s; "
-                                   "one step = one rollout (%d dependent ticks incl. forward dynamics + integrator)" % (H, n, dtype, H),
+                                   "one step = one rollout (%d dependent ticks incl. %sforward dynamics + integrator)"
+                                   % (H, n, dtype, H, "CoM planner/reference generator + " if args.tracking else ""),
                        "batch_per_gpu": n, "horizon": H, "parallelism": "batch-sharded x%d, rank-local for all ticks" % world},
             "us_per_tick": elapsed / args.steps / H * 1e6, "qp": {"status_ok_frac_last_tick": ok},
             "roofline": None, "cpu_baseline": None}))

@@ -151,6 +151,37 @@ int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, const void* M
 int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                       const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, void* stream);
 
+/* SURVEY.md 8(f)-3 -- the caller on the input side of the tick: "a motion planner for the trajectory of the robot's
+ * center of mass" (/root/reference/README.md:11) produces the references the whole-body controller tracks.  The
+ * planner's source is absent from the reference ([UNVERIFIED] interface); this entry point is the build's definition:
+ *   plan [12][N]: c0 (3) start CoM, c1 (3) goal CoM (world), T duration [s], t0 time already elapsed [s],
+ *                 quat_des (x,y,z,w) desired trunk attitude
+ *   rest-to-rest quintic c_ref(u), u = clamp((t0 + t) / T, 0, 1)   (T <= 0: the goal itself)
+ *   a_cmd = cdd_ref + kp_com (c_ref - c) + kd_com (cd_ref - cd)      c, cd = CoM position / velocity of (q, v)
+ *   alpha_cmd = kp_rot e_R - kd_rot omega,  e_R = 2 vec(quat_des (x) quat^-1) with non-negative scalar part
+ *   vdot_des = [a_cmd; alpha_cmd; kp_joint (q_nom - q_j) - kd_joint qd_j]
+ *   w_des = [F; (c - p_b) x F + R diag(inertia_nom) R^T alpha_cmd],  F = m_total (a_cmd - gravity)
+ * Writes w_des [6][N] and vdot_des [nv][N] (the wbc_batch_in fields of the same names); com (optional) [6][N] = c, cd. */
+typedef struct wbc_ref_params {
+  double kp_com[3], kd_com[3];
+  double kp_rot[3], kd_rot[3];
+  double kp_joint, kd_joint;
+  double inertia_nom[3];    /* nominal trunk inertia, body axes */
+  double q_nom[WBC_MAXV];   /* nominal joint posture, caller's joint order */
+} wbc_ref_params;
+#define WBC_PLAN_WORDS 12
+void wbc_ref_params_default(wbc_ref_params* g);
+int wbc_solver_set_ref_params(wbc_solver* s, const wbc_ref_params* g);
+int wbc_reference_batch(wbc_solver* s, size_t N, const void* q, const void* v, const void* plan, double t,
+                        void* w_des, void* vdot_des, void* com, void* stream);
+
+/* wbc_rollout_batch with the planner in the loop: every tick k first regenerates in->w_des / in->vdot_des from `plan`
+ * at t = k * dt (those two buffers are OVERWRITTEN; const is cast away), then steps and integrates.
+ * com_traj (optional) receives the CoM state the planner saw at every tick: [horizon][6][N]. */
+int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
+                               const wbc_observer_state* obs, const void* tau_ext, const void* plan, void* tau_traj,
+                               void* com_traj, void* stream);
+
 /* Single-robot, host-pointer, double-precision convenience call: the shape of the reference's
  * one-robot tick (BASELINE.json configs[0]).  Runs wbc_step_batch with N = 1 on the GPU and
  * synchronises.  obs_integ/obs_r (host, nv each) are in/out and may be NULL when the observer is off. */

@@ -365,3 +365,77 @@ def rollout(model, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext
         tau_prev, f_prev = o["tau"], o["f"]
         taus.append(o["tau"])
     return q, v, np.array(taus), integ, r
+
+
+# ------------------------------------------------------------------ CoM reference generator (a11): independent restatement
+def com_state(model, q, v):
+    """CoM position and velocity by the mass-weighted point Jacobians (oracle: first moments + linear momentum)."""
+    T = model.fk(q)
+    mtot = model.mass.sum()
+    c = np.zeros(3)
+    Jc = np.zeros((3, model.nv))
+    for i in range(model.nb):
+        ci = (T[i] @ np.append(model.com[i], 1.0))[:3]
+        c += model.mass[i] * ci
+        Jc += model.mass[i] * model.point_jacobian(T, i, ci)
+    return c / mtot, Jc @ v / mtot, mtot, T
+
+
+def default_ref_params(nj=12):
+    return dict(kp_com=np.array([100.0, 100.0, 150.0]), kd_com=np.array([20.0, 20.0, 25.0]),
+                kp_rot=np.array([200.0, 200.0, 100.0]), kd_rot=np.array([25.0, 25.0, 15.0]), kp_joint=200.0, kd_joint=28.0,
+                inertia_nom=np.array([0.8, 1.85, 2.05]), q_nom=np.zeros(nj))
+
+
+def reference(model, G, q, v, plan, t):
+    """Returns (w_des[6], vdot_des[nv], com[6]); plan = [c0 3, c1 3, T, t0, quat_des 4]."""
+    c, cd, mtot, T = com_state(model, q, v)
+    Tp = plan[6]
+    u = min(max((plan[7] + t) / Tp, 0.0), 1.0) if Tp > 0 else 1.0
+    iT = 1.0 / Tp if Tp > 0 else 0.0
+    s = np.polyval([6, -15, 10, 0, 0, 0], u)
+    sd = np.polyval(np.polyder([6, -15, 10, 0, 0, 0]), u) * iT
+    sdd = np.polyval(np.polyder([6, -15, 10, 0, 0, 0], 2), u) * iT * iT
+    d = plan[3:6] - plan[0:3]
+    a_cmd = sdd * d + G["kp_com"] * (plan[0:3] + s * d - c) + G["kd_com"] * (sd * d - cd)
+    # attitude error from rotation matrices: R_e = R_des R^T, e_R = 2 * vector part of its quaternion (w >= 0)
+    R = quat_to_R(q[3:7])
+    Re = quat_to_R(plan[8:12]) @ R.T
+    w4 = max(1.0 + np.trace(Re), 0.0)
+    ew = 0.5 * np.sqrt(w4)
+    if ew > 1e-6:
+        evec = np.array([Re[2, 1] - Re[1, 2], Re[0, 2] - Re[2, 0], Re[1, 0] - Re[0, 1]]) / (4 * ew)
+    else:  # rotation by pi: fall back to the quaternion product
+        qc = q[3:7] / np.linalg.norm(q[3:7]) * np.array([-1, -1, -1, 1.0])
+        qe = quat_mul(plan[8:12] / np.linalg.norm(plan[8:12]), qc)
+        evec = qe[:3] * (1 if qe[3] >= 0 else -1)
+    al_cmd = G["kp_rot"] * 2 * evec - G["kd_rot"] * v[3:6]
+    nj = model.nv - 6
+    vdot_des = np.concatenate([a_cmd, al_cmd, G["kp_joint"] * (G["q_nom"][:nj] - q[7:]) - G["kd_joint"] * v[6:]])
+    F = mtot * (a_cmd - model.grav)
+    Mo = np.cross(c - q[0:3], F) + R @ (G["inertia_nom"] * (R.T @ al_cmd))
+    return np.concatenate([F, Mo]), vdot_des, np.concatenate([c, cd])
+
+
+def rollout_tracking(model, P, G, horizon, q, v, plan, normals, mu, mask, tau_ext=None, integ=None, r=None):
+    nv = model.nv
+    q, v = q.copy(), v.copy()
+    tau_prev = np.zeros(nv - 6)
+    f_prev = np.zeros(3 * model.nf)
+    integ = np.zeros(nv) if integ is None else integ.copy()
+    r = np.zeros(nv) if r is None else r.copy()
+    taus, coms = [], []
+    for k in range(horizon):
+        w_des, vdot_des, com = reference(model, G, q, v, plan, k * P["dt"])
+        o = step(model, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev, f_prev, integ, r)
+        integ, r = o["integ"], o["r"]
+        rhs = np.concatenate([np.zeros(6), o["tau"]]) + o["Jc"].reshape(-1, nv).T @ o["f"] - o["h"]
+        if tau_ext is not None:
+            rhs = rhs + tau_ext
+        vdot = np.linalg.solve(o["M"], rhs)
+        v = v + P["dt"] * vdot
+        q = integrate_q(q, v, P["dt"])
+        tau_prev, f_prev = o["tau"], o["f"]
+        taus.append(o["tau"])
+        coms.append(com)
+    return q, v, np.array(taus), np.array(coms), integ, r

@@ -56,6 +56,25 @@ def make_params_struct(P):
     return s
 
 
+def make_ref_params_struct(G):
+    MAXV = _maxv()
+
+    class RefParams(C.Structure):
+        _fields_ = [("kp_com", C.c_double * 3), ("kd_com", C.c_double * 3), ("kp_rot", C.c_double * 3),
+                    ("kd_rot", C.c_double * 3), ("kp_joint", C.c_double), ("kd_joint", C.c_double),
+                    ("inertia_nom", C.c_double * 3), ("q_nom", C.c_double * MAXV)]
+
+    s = RefParams()
+    for i in range(3):
+        s.kp_com[i], s.kd_com[i] = float(G["kp_com"][i]), float(G["kd_com"][i])
+        s.kp_rot[i], s.kd_rot[i] = float(G["kp_rot"][i]), float(G["kd_rot"][i])
+        s.inertia_nom[i] = float(G["inertia_nom"][i])
+    s.kp_joint, s.kd_joint = float(G["kp_joint"]), float(G["kd_joint"])
+    for i, x in enumerate(G["q_nom"]):
+        s.q_nom[i] = float(x)
+    return s
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -161,6 +180,55 @@ def _rollout(self, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext
 
 
 Oracle.rollout = _rollout
+
+def _reference(self, G, q, v, plan, t=0.0):
+    """CoM reference generator (a11): plan [N,12] -> dict(w_des [N,6], vdot_des [N,nv], com [N,6])."""
+    dt = q.dtype
+    N = q.shape[0]
+    c = lambda a: np.ascontiguousarray(a, dtype=dt)
+    w = np.empty((N, 6), dt)
+    vd = np.empty((N, self.nv), dt)
+    com = np.empty((N, 6), dt)
+    gs = make_ref_params_struct(G)
+    ct = C.c_double if dt == np.float64 else C.c_float
+    getattr(lib(), "wbco_reference_" + self._suf(dt))(self.h, C.byref(gs), N, _p(c(q)), _p(c(v)), _p(c(plan)), ct(t), _p(w),
+                                                      _p(vd), _p(com))
+    return dict(w_des=w, vdot_des=vd, com=com)
+
+
+def _rollout_tracking(self, P, G, horizon, q, v, plan, normals, mu, mask, tau_ext=None, tau_prev=None, f_prev=None,
+                      integ=None, r=None, want_traj=False, want_com=False, nthreads=1):
+    """Planner-in-the-loop rollout; q, v (and tau_prev, f_prev, integ, r when given) are updated IN PLACE."""
+    dt = q.dtype
+    N = q.shape[0]
+    assert q.flags.c_contiguous and v.flags.c_contiguous and v.dtype == dt
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+    plan, normals, mu, tau_ext = map(c, (plan, normals, mu, tau_ext))
+    mask = np.ascontiguousarray(mask, dtype=np.int32)
+    if tau_prev is None:
+        tau_prev = np.zeros((N, self.nj), dt)
+    if f_prev is None:
+        f_prev = np.zeros((N, 3 * self.nf), dt)
+    for a in (tau_prev, f_prev, integ, r):
+        assert a is None or (a.dtype == dt and a.flags.c_contiguous)
+    traj = np.zeros((N, horizon, self.nj), dt) if want_traj else None
+    com = np.zeros((N, horizon, 6), dt) if want_com else None
+    status = np.zeros(N, np.int32)
+    getattr(lib(), "wbco_rollout_tracking_" + self._suf(dt))(
+        self.h, C.byref(make_params_struct(P)), C.byref(make_ref_params_struct(G)), N, int(horizon), _p(q), _p(v), _p(plan),
+        _p(normals), _p(mu), _p(mask), _p(tau_ext), _p(tau_prev), _p(f_prev), _p(integ), _p(r), _p(traj), _p(com), _p(status),
+        int(nthreads))
+    out = dict(status=status, tau_prev=tau_prev, f_prev=f_prev)
+    if want_traj:
+        out["tau_traj"] = traj
+    if want_com:
+        out["com_traj"] = com
+    return out
+
+
+Oracle.reference = _reference
+Oracle.rollout_tracking = _rollout_tracking
+
 
 def _qp_time(self, P, q, v, w_des, normals, mu, mask):
     """Per-QP wall time (ns) of {assembly + solve} on one thread, float64; returns (ns[N], iters[N])."""

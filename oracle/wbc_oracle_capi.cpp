@@ -32,6 +32,24 @@ static Params to_params(const wbco_params* p) {
   return P;
 }
 
+struct wbco_ref_params {  // mirrors wbco::RefParams
+  double kp_com[3], kd_com[3], kp_rot[3], kd_rot[3];
+  double kp_joint, kd_joint;
+  double inertia_nom[3];
+  double q_nom[MAXV];
+};
+
+static RefParams to_ref(const wbco_ref_params* g) {
+  RefParams G;
+  for (int i = 0; i < 3; ++i) {
+    G.kp_com[i] = g->kp_com[i]; G.kd_com[i] = g->kd_com[i]; G.kp_rot[i] = g->kp_rot[i]; G.kd_rot[i] = g->kd_rot[i];
+    G.inertia_nom[i] = g->inertia_nom[i];
+  }
+  G.kp_joint = g->kp_joint; G.kd_joint = g->kd_joint;
+  for (int i = 0; i < MAXV; ++i) G.q_nom[i] = g->q_nom[i];
+  return G;
+}
+
 int wbco_maxv() { return MAXV; }
 
 void* wbco_model_create(int nb, const int* parent, const double* Rt, const double* rt, const double* axis,
@@ -110,6 +128,37 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
               f_prev + (size_t)s * 3 * nf, obs_integ ? obs_integ + (size_t)s * nv : zi,                          \
               obs_r ? obs_r + (size_t)s * nv : zr, tau_traj ? tau_traj + (size_t)s * horizon * nj : (T*)nullptr, \
               status ? status + s : (int*)nullptr);                                                             \
+    }                                                                                                           \
+  }                                                                                                             \
+  /* CoM reference generator (a11): plan [N][12] -> w_des [N][6], vdot_des [N][nv], optional com [N][6] */       \
+  void wbco_reference_##SUF(void* hh, const wbco_ref_params* gg, int N, const T* q, const T* v, const T* plan,   \
+                            T t, T* w_des, T* vdot_des, T* com) {                                               \
+    const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
+    const RefParams G = to_ref(gg);                                                                             \
+    const int nv = m.nv(), nq = nv + 1;                                                                         \
+    for (int s = 0; s < N; ++s)                                                                                 \
+      reference(m, G, q + (size_t)s * nq, v + (size_t)s * nv, plan + (size_t)s * PLAN_WORDS, t,                 \
+                w_des + (size_t)s * 6, vdot_des + (size_t)s * nv, com ? com + (size_t)s * 6 : (T*)nullptr);     \
+  }                                                                                                             \
+  void wbco_rollout_tracking_##SUF(void* hh, const wbco_params* pp, const wbco_ref_params* gg, int N,           \
+                                   int horizon, T* q, T* v, const T* plan, const T* normals, const T* mu,       \
+                                   const int* mask, const T* tau_ext, T* tau_prev, T* f_prev, T* obs_integ,     \
+                                   T* obs_r, T* tau_traj, T* com_traj, int* status, int nthreads) {             \
+    const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
+    const Params P = to_params(pp);                                                                             \
+    const RefParams G = to_ref(gg);                                                                             \
+    const int nv = m.nv(), nq = nv + 1, nj = m.nj(), nf = m.nf;                                                 \
+    _Pragma("omp parallel for num_threads(nthreads) schedule(static)") for (int s = 0; s < N; ++s) {           \
+      T zi[MAXV], zr[MAXV];                                                                                     \
+      for (int i = 0; i < MAXV; ++i) zi[i] = zr[i] = 0;                                                         \
+      rollout_tracking(m, P, G, horizon, q + (size_t)s * nq, v + (size_t)s * nv, plan + (size_t)s * PLAN_WORDS, \
+                       normals + (size_t)s * 3 * nf, mu + (size_t)s * nf, (unsigned)mask[s],                    \
+                       tau_ext ? tau_ext + (size_t)s * nv : (const T*)nullptr, tau_prev + (size_t)s * nj,        \
+                       f_prev + (size_t)s * 3 * nf, obs_integ ? obs_integ + (size_t)s * nv : zi,                 \
+                       obs_r ? obs_r + (size_t)s * nv : zr,                                                     \
+                       tau_traj ? tau_traj + (size_t)s * horizon * nj : (T*)nullptr,                            \
+                       com_traj ? com_traj + (size_t)s * horizon * 6 : (T*)nullptr,                             \
+                       status ? status + s : (int*)nullptr);                                                    \
     }                                                                                                           \
   }                                                                                                             \
   void wbco_forward_dynamics_##SUF(int nv, int nj, int nf, const T* Mp, const T* h, const T* Jc, const T* tau,  \

@@ -65,6 +65,33 @@ class Params(C.Structure):
         return p
 
 
+class RefParams(C.Structure):
+    """wbc_ref_params: gains of the CoM reference generator (include/wbc_hip.h)."""
+    _fields_ = [("kp_com", C.c_double * 3), ("kd_com", C.c_double * 3), ("kp_rot", C.c_double * 3), ("kd_rot", C.c_double * 3),
+                ("kp_joint", C.c_double), ("kd_joint", C.c_double), ("inertia_nom", C.c_double * 3),
+                ("q_nom", C.c_double * WBC_MAXV)]
+
+    @staticmethod
+    def default():
+        g = RefParams()
+        lib().wbc_ref_params_default(C.byref(g))
+        return g
+
+    @staticmethod
+    def from_dict(d):
+        g = RefParams.default()
+        for k in ("kp_com", "kd_com", "kp_rot", "kd_rot", "inertia_nom"):
+            for i in range(3):
+                getattr(g, k)[i] = float(d[k][i])
+        g.kp_joint, g.kd_joint = float(d["kp_joint"]), float(d["kd_joint"])
+        for i, x in enumerate(d["q_nom"]):
+            g.q_nom[i] = float(x)
+        return g
+
+
+PLAN_WORDS = 12
+
+
 class _BatchIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "mask", "tau_prev", "f_prev")]
 
@@ -103,6 +130,11 @@ def lib():
         L.wbc_step_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
         L.wbc_integrate_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
         L.wbc_rollout_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 6
+        L.wbc_ref_params_default.argtypes = [C.c_void_p]
+        L.wbc_ref_params_default.restype = None
+        L.wbc_solver_set_ref_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.wbc_reference_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4
+        L.wbc_rollout_tracking_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 8
         _lib = L
     return _lib
 
@@ -280,6 +312,53 @@ class Solver:
             tt = C.c_void_p(tau_traj.data_ptr())
         _check(lib().wbc_rollout_batch(self._h, N, int(horizon), C.byref(bi), C.byref(bo), C.byref(ob),
                                        self._ptr(tau_ext, m.nv, N), tt, self._stream()), "wbc_rollout_batch")
+        return out
+
+    def set_ref_params(self, g):
+        """g: RefParams or dict (see RefParams.from_dict)."""
+        if isinstance(g, dict):
+            g = RefParams.from_dict(g)
+        _check(lib().wbc_solver_set_ref_params(self._h, C.byref(g)), "wbc_solver_set_ref_params")
+
+    def reference(self, q, v, plan, t=0.0, out=None, want_com=False):
+        """CoM reference generator: plan [12, N] -> dict(w_des [6, N], vdot_des [nv, N][, com [6, N]])."""
+        torch = self.torch
+        m = self.model
+        N = q.shape[1]
+        out = {} if out is None else out
+        for k, rows in (("w_des", 6), ("vdot_des", m.nv)) + ((("com", 6),) if want_com else ()):
+            if k not in out:
+                out[k] = torch.empty((rows, N), dtype=self.tdtype, device=q.device)
+        _check(lib().wbc_reference_batch(self._h, N, self._ptr(q, m.nq, N), self._ptr(v, m.nv, N),
+                                         self._ptr(plan, PLAN_WORDS, N), C.c_double(t), self._ptr(out["w_des"], 6, N),
+                                         self._ptr(out["vdot_des"], m.nv, N),
+                                         self._ptr(out["com"], 6, N) if want_com else None, self._stream()),
+               "wbc_reference_batch")
+        return out
+
+    def rollout_tracking(self, horizon, q, v, plan, normals, mu, mask, out, w_des, vdot_des, obs_integ=None, obs_r=None,
+                         tau_ext=None, tau_traj=None, com_traj=None):
+        """rollout() with the planner in the loop: w_des / vdot_des are scratch buffers regenerated every tick."""
+        torch = self.torch
+        m = self.model
+        N = q.shape[1]
+        rows = dict(tau=m.nj, f=3 * m.nf, M=m.nv * (m.nv + 1) // 2, h=m.nv, Jc=3 * m.nf * m.nv, pf=3 * m.nf)
+        bi = _BatchIn(self._ptr(q, m.nq, N), self._ptr(v, m.nv, N), self._ptr(w_des, 6, N), self._ptr(vdot_des, m.nv, N),
+                      self._ptr(normals, 3 * m.nf, N), self._ptr(mu, m.nf, N), self._ptr(mask, 1, N, torch.int32), None, None)
+        g = lambda k: self._ptr(out.get(k), rows[k], N)
+        bo = _BatchOut(g("tau"), g("f"), self._ptr(out["status"], 1, N, torch.int32),
+                       self._ptr(out.get("iters"), 1, N, torch.int32), g("M"), g("h"), g("Jc"), g("pf"))
+        ob = _ObsState(self._ptr(obs_integ, m.nv, N), self._ptr(obs_r, m.nv, N))
+        tt = ct = None
+        if tau_traj is not None:
+            assert tau_traj.is_cuda and tau_traj.is_contiguous() and tau_traj.numel() == horizon * m.nj * N
+            tt = C.c_void_p(tau_traj.data_ptr())
+        if com_traj is not None:
+            assert com_traj.is_cuda and com_traj.is_contiguous() and com_traj.numel() == horizon * 6 * N
+            ct = C.c_void_p(com_traj.data_ptr())
+        _check(lib().wbc_rollout_tracking_batch(self._h, N, int(horizon), C.byref(bi), C.byref(bo), C.byref(ob),
+                                                self._ptr(tau_ext, m.nv, N), self._ptr(plan, PLAN_WORDS, N), tt, ct,
+                                                self._stream()), "wbc_rollout_tracking_batch")
         return out
 
     def compute_torques(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None,

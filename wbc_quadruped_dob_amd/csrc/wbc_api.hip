@@ -19,6 +19,7 @@
 #include "qp_wave.hip.hpp"
 #include "qp_group16.hip.hpp"
 #include "integrate.hip.hpp"
+#include "com_ref.hip.hpp"
 
 using namespace wbc;
 
@@ -49,6 +50,7 @@ struct wbc_solver {
                       // measured on MI355X: split is 5-20 % slower (two kernels pay the fixed latencies twice), kept for A/B
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
   // N=1 convenience buffers
   void* d_one = nullptr;
   size_t one_bytes = 0;
@@ -304,6 +306,7 @@ extern "C" void wbc_solver_destroy(wbc_solver* s) {
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_ws) (void)hipFree(s->d_ws);
   if (s->d_one) (void)hipFree(s->d_one);
+  if (s->d_ref) (void)hipFree(s->d_ref);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
   if (s->aux) (void)hipStreamDestroy(s->aux);
@@ -613,6 +616,92 @@ extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc
   const size_t nj = 12;
   for (int t = 0; t < horizon; ++t) {
     int rc = wbc_step_batch(s, N, &tick, out, obs, stream);
+    if (rc) return rc;
+    void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    rc = s->dtype == WBC_F64
+             ? integrate_impl<double>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st)
+             : integrate_impl<float>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st);
+    if (rc) return rc;
+  }
+  return WBC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ CoM reference generator
+extern "C" void wbc_ref_params_default(wbc_ref_params* g) {
+  if (!g) return;
+  std::memset(g, 0, sizeof(*g));
+  const double kp[3] = {100, 100, 150}, kd[3] = {20, 20, 25}, kr[3] = {200, 200, 100}, dr[3] = {25, 25, 15};
+  const double in[3] = {0.8, 1.85, 2.05};  // composite inertia of the synthetic quadruped in its nominal stance
+  for (int i = 0; i < 3; ++i) { g->kp_com[i] = kp[i]; g->kd_com[i] = kd[i]; g->kp_rot[i] = kr[i]; g->kd_rot[i] = dr[i]; g->inertia_nom[i] = in[i]; }
+  g->kp_joint = 200; g->kd_joint = 28;
+}
+
+template <class T> static int upload_ref(wbc_solver* s, const wbc_ref_params* g) {
+  DevRefParams<T> d;
+  for (int i = 0; i < 3; ++i) {
+    d.kp_com[i] = (T)g->kp_com[i]; d.kd_com[i] = (T)g->kd_com[i]; d.kp_rot[i] = (T)g->kp_rot[i]; d.kd_rot[i] = (T)g->kd_rot[i];
+    d.inertia_nom[i] = (T)g->inertia_nom[i];
+  }
+  d.kp_joint = (T)g->kp_joint; d.kd_joint = (T)g->kd_joint;
+  for (int i = 0; i < 12; ++i) d.q_nom[i] = (T)g->q_nom[i];
+  if (!s->d_ref) HIP_TRY(hipMalloc(&s->d_ref, sizeof(DevRefParams<double>)));
+  HIP_TRY(hipMemcpy(s->d_ref, &d, sizeof(d), hipMemcpyHostToDevice));
+  return WBC_OK;
+}
+
+extern "C" int wbc_solver_set_ref_params(wbc_solver* s, const wbc_ref_params* g) {
+  if (!s || !g) return fail(WBC_E_INVALID, "null argument");
+  for (int i = 0; i < 3; ++i)
+    if (!(g->inertia_nom[i] >= 0)) return fail(WBC_E_INVALID, "inertia_nom must be non-negative");
+  HIP_TRY(hipSetDevice(s->device));
+  return s->dtype == WBC_F64 ? upload_ref<double>(s, g) : upload_ref<float>(s, g);
+}
+
+template <class T>
+static int reference_impl(wbc_solver* s, size_t N, const void* q, const void* v, const void* plan, double t, void* w_des,
+                          void* vdot_des, void* com, hipStream_t st) {
+  RefArgs<T> a;
+  a.N = N; a.q = (const T*)q; a.v = (const T*)v; a.plan = (const T*)plan; a.t = (T)t;
+  a.w_des = (T*)w_des; a.vdot_des = (T*)vdot_des; a.com = (T*)com;
+  hipLaunchKernelGGL((com_reference_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
+                     (const DevModel<T>*)s->d_model, (const DevRefParams<T>*)s->d_ref, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("reference launch: ") + hipGetErrorString(e));
+  return WBC_OK;
+}
+
+extern "C" int wbc_reference_batch(wbc_solver* s, size_t N, const void* q, const void* v, const void* plan, double t,
+                                   void* w_des, void* vdot_des, void* com, void* stream) {
+  if (!s || !q || !v || !plan || !w_des || !vdot_des) return fail(WBC_E_INVALID, "null argument");
+  if (!s->d_ref) return fail(WBC_E_INVALID, "call wbc_solver_set_ref_params first");
+  if (N == 0) return WBC_OK;
+  if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  return s->dtype == WBC_F64 ? reference_impl<double>(s, N, q, v, plan, t, w_des, vdot_des, com, st)
+                             : reference_impl<float>(s, N, q, v, plan, t, w_des, vdot_des, com, st);
+}
+
+extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in,
+                                          const wbc_batch_out* out, const wbc_observer_state* obs, const void* tau_ext,
+                                          const void* plan, void* tau_traj, void* com_traj, void* stream) {
+  if (!s || !in || !out || !plan) return fail(WBC_E_INVALID, "null argument");
+  if (horizon < 1) return fail(WBC_E_INVALID, "horizon must be >= 1");
+  if (!out->M || !out->h || !out->Jc) return fail(WBC_E_INVALID, "rollouts need the M, h, Jc buffers (forward dynamics reads them)");
+  if (s->sweep_mode == 0) return fail(WBC_E_INVALID, "rollouts need the fused sweep (unset WBC_SWEEP=split)");
+  if (!in->q || !in->v || !in->w_des || !in->vdot_des) return fail(WBC_E_INVALID, "null input buffer");
+  wbc_batch_in tick = *in;
+  tick.tau_prev = out->tau;
+  tick.f_prev = out->f;
+  const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
+  const size_t nj = 12;
+  for (int t = 0; t < horizon; ++t) {
+    void* com = com_traj ? (void*)((char*)com_traj + (size_t)t * 6 * N * ts) : nullptr;
+    int rc = wbc_reference_batch(s, N, in->q, in->v, plan, (double)t * s->params.dt, (void*)in->w_des, (void*)in->vdot_des, com,
+                                 stream);
+    if (rc) return rc;
+    rc = wbc_step_batch(s, N, &tick, out, obs, stream);
     if (rc) return rc;
     void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
     hipStream_t st = (hipStream_t)stream;

@@ -62,3 +62,29 @@ def default_params(nv=18, observer_order=0, dtype="f64"):
     return dict(S=np.ones(6), alpha=1e-3, fn_min=0.0, fn_max=400.0, mu_scale=1.0, dt=1e-3,
                 observer_order=observer_order, max_iter=100, qp_tol=1e-9 if dtype == "f64" else 1e-3,
                 K1=np.full(nv, 50.0), K2=np.full(nv, 200.0))
+
+
+def default_ref_params(nj=12):
+    """Gains of the CoM reference generator (wbc_ref_params); nominal posture = the synthetic quadruped's stance."""
+    return dict(kp_com=np.array([100.0, 100.0, 150.0]), kd_com=np.array([20.0, 20.0, 25.0]),
+                kp_rot=np.array([200.0, 200.0, 100.0]), kd_rot=np.array([25.0, 25.0, 15.0]), kp_joint=200.0, kd_joint=28.0,
+                inertia_nom=np.array([0.8, 1.85, 2.05]), q_nom=np.tile(np.array(NOMINAL_LEG), nj // 3))
+
+
+def make_plan(B, rank=0, duration=0.5, reach=0.08):
+    """Synthetic CoM plans for a batch from make_batch(): start near the base position, goal within `reach` metres,
+    random elapsed time, desired attitude within 0.1 rad of upright.  Row-per-state [n, 12] float64.
+    Edge rows: state 3 (if present) has T = 0 (goal reached: pure regulation), state 4 is past its end time."""
+    n = B["q"].shape[0]
+    rng = np.random.default_rng(SEED + 77 + rank)
+    plan = np.zeros((n, 12))
+    plan[:, 0:3] = B["q"][:, 0:3] + rng.uniform(-0.02, 0.02, (n, 3))
+    plan[:, 3:6] = plan[:, 0:3] + rng.uniform(-reach, reach, (n, 3))
+    plan[:, 6] = duration
+    plan[:, 7] = rng.uniform(0.0, 0.6 * duration, n)
+    plan[:, 8:12] = _rand_unit_quat_near_upright(rng, n, 0.1)
+    if n > 3:
+        plan[3, 6] = 0.0
+    if n > 4:
+        plan[4, 7] = 1.5 * duration
+    return plan
