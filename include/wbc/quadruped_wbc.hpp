@@ -41,6 +41,11 @@ struct ContactState {         // per-foot stance flag, terrain normal and fricti
   double normal[4][3];
   double mu[4];
 };
+struct ComPlan {              // input of the CoM planner (wbc_reference_batch's plan row)
+  double start[3], goal[3];   // CoM start / goal, world
+  double duration;            // s; <= 0 = hold the goal
+  double quat_des_xyzw[4];    // desired trunk attitude
+};
 struct Command {              // what the planner hands to the tick
   double w_des[6];            // desired contact wrench on the base rows
   std::array<double, 18> vdot_des;
@@ -75,16 +80,8 @@ class QuadrupedWBC {
   // Throws on ABI errors; returns the QP status (0 optimal, 1 iteration limit, 2 infeasible).
   int computeTorques(const BaseState& base, const JointState& js, const ContactState& contacts, const Command& cmd,
                      std::vector<double>& tau_out, double* grf_out = nullptr) {
-    std::vector<double> q(nq_), v(nv_);
-    for (int k = 0; k < 3; ++k) { q[k] = base.position[k]; v[k] = base.linear[k]; v[3 + k] = base.angular[k]; }
-    for (int k = 0; k < 4; ++k) q[3 + k] = base.orientation_xyzw[k];
-    // JointState carries names: map by name, as ROS controllers do
-    for (int j = 0; j < nj_; ++j) {
-      bool found = false;
-      for (size_t i = 0; i < js.name.size(); ++i)
-        if (js.name[i] == joint_names_[j]) { q[7 + j] = js.position[i]; v[6 + j] = js.velocity[i]; found = true; break; }
-      if (!found) throw std::invalid_argument("JointState lacks joint " + joint_names_[j]);
-    }
+    std::vector<double> q, v;
+    packState(base, js, q, v);
     double normals[12], mu[4];
     int mask = 0;
     for (int f = 0; f < nf_; ++f) {
@@ -109,11 +106,41 @@ class QuadrupedWBC {
     return status;
   }
 
+  // The planner side of the tick (/root/reference/README.md:11 "a motion planner for the trajectory of the robot's
+  // center of mass"): turns a CoM plan evaluated `t` seconds after its start into the Command computeTorques tracks.
+  // com_out (6, optional) receives the CoM position and velocity of the given state.
+  void setReferenceGains(const wbc_ref_params& g) { check(wbc_solver_set_ref_params(solver_, &g), "wbc_solver_set_ref_params"); ref_set_ = true; }
+  Command plan(const BaseState& base, const JointState& js, const ComPlan& cp, double t, double* com_out = nullptr) {
+    if (!ref_set_) { wbc_ref_params g; wbc_ref_params_default(&g); setReferenceGains(g); }
+    std::vector<double> q, v;
+    packState(base, js, q, v);
+    double row[WBC_PLAN_WORDS];
+    for (int k = 0; k < 3; ++k) { row[k] = cp.start[k]; row[3 + k] = cp.goal[k]; }
+    row[6] = cp.duration; row[7] = 0.0;
+    for (int k = 0; k < 4; ++k) row[8 + k] = cp.quat_des_xyzw[k];
+    Command c;
+    check(wbc_compute_reference(solver_, q.data(), v.data(), row, t, c.w_des, c.vdot_des.data(), com_out), "wbc_compute_reference");
+    return c;
+  }
+
   // Observer state (the only per-robot state carried across ticks): snapshot / restore / initialise.
   void setObserverState(const std::vector<double>& integ, const std::vector<double>& r) { obs_integ_ = integ; obs_r_ = r; }
   const std::vector<double>& disturbanceEstimate() const { return obs_r_; }
 
  private:
+  void packState(const BaseState& base, const JointState& js, std::vector<double>& q, std::vector<double>& v) const {
+    q.assign(nq_, 0.0); v.assign(nv_, 0.0);
+    for (int k = 0; k < 3; ++k) { q[k] = base.position[k]; v[k] = base.linear[k]; v[3 + k] = base.angular[k]; }
+    for (int k = 0; k < 4; ++k) q[3 + k] = base.orientation_xyzw[k];
+    // JointState carries names: map by name, as ROS controllers do
+    for (int j = 0; j < nj_; ++j) {
+      bool found = false;
+      for (size_t i = 0; i < js.name.size(); ++i)
+        if (js.name[i] == joint_names_[j]) { q[7 + j] = js.position[i]; v[6 + j] = js.velocity[i]; found = true; break; }
+      if (!found) throw std::invalid_argument("JointState lacks joint " + joint_names_[j]);
+    }
+  }
+  bool ref_set_ = false;
   wbc_model* model_ = nullptr;
   wbc_solver* solver_ = nullptr;
   wbc_params params_;

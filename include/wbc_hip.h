@@ -190,6 +190,11 @@ int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const d
                         const double* tau_prev, const double* f_prev, double* obs_integ, double* obs_r,
                         double* tau, double* f, int* status);
 
+/* Single-robot, host-pointer form of wbc_reference_batch (q[19], v[18], plan[12] in; w_des[6], vdot_des[18] and the
+ * optional com[6] out): the planner call of a one-robot control loop.  Synchronises. */
+int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const double* plan, double t,
+                          double* w_des, double* vdot_des, double* com);
+
 /* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on ---- */
 int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 events around every kernel; k > 1: every k-th tick */
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed

@@ -164,6 +164,16 @@ def test_case_study_push_rejection_on_gpu(torch_cuda, gpu_model, oracle):
     assert final[0].min() > 8e-3 and final[1].max() < 1.5e-3
 
 
+def test_compute_reference_single_robot(torch_cuda, gpu_model, oracle):
+    solver, P, G = _solver(gpu_model, max_batch=1)
+    B = synth.make_batch(4, 3, gpu_model.total_mass, rank=44)
+    plan = synth.make_plan(B, rank=44)
+    ref = oracle.reference(G, B["q"], B["v"], plan, 0.05)
+    for s in range(3):
+        w, vd, com = solver.compute_reference(B["q"][s], B["v"][s], plan[s], 0.05)
+        assert relerr(w, ref["w_des"][s]) < 1e-12 and relerr(vd, ref["vdot_des"][s]) < 1e-12 and relerr(com, ref["com"][s]) < 1e-13
+
+
 def test_reference_errors(torch_cuda, gpu_model):
     import wbc_quadruped_dob_amd as W
     torch = torch_cuda

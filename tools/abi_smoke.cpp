@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <vector>
 #include "wbc_hip.h"
+#include "wbc/quadruped_wbc.hpp"   // header-only C++ host class over the same ABI
 
 #define CK(x) do { int rc_ = (x); if (rc_) { std::printf("%s -> %d (%s) %s\n", #x, rc_, wbc_strerror(rc_), wbc_last_error()); return 1; } } while (0)
 
@@ -68,5 +69,33 @@ int main(int argc, char** argv) {
   std::printf("batch %zu: %d bad\n", N, bad);
   wbc_solver_destroy(s);
   wbc_model_free(m);
-  return bad ? 3 : 0;
+  if (bad) return 3;
+  // the C++ host class: planner call + tick for one robot standing on its goal -> weight-carrying GRFs again
+  try {
+    wbc::QuadrupedWBC ctl(urdf);
+    wbc::BaseState base = {{0, 0, 0.4}, {0, 0, 0, 1}, {0, 0, 0}, {0, 0, 0}};
+    wbc::JointState js;
+    js.name = ctl.jointNames();
+    for (int l = 0; l < 4; ++l) { js.position.insert(js.position.end(), {0.05, 0.75, -1.5}); js.velocity.insert(js.velocity.end(), {0, 0, 0}); }
+    // jointNames() order may interleave legs; the nominal posture is the same for every leg only if names map leg-wise
+    for (size_t j = 0; j < js.name.size(); ++j) js.position[j] = q[7 + j];
+    wbc::ContactState cs;
+    for (int k = 0; k < 4; ++k) { cs.stance[k] = true; cs.normal[k][0] = 0; cs.normal[k][1] = 0; cs.normal[k][2] = 1; cs.mu[k] = 0.6; }
+    wbc::ComPlan cp = {{0, 0, 0.36}, {0, 0, 0.36}, 0.0, {0, 0, 0, 1}};
+    double com[6];
+    wbc::Command c0 = ctl.plan(base, js, cp, 0.0, com);      // learn the CoM, then plan to hold it
+    for (int k = 0; k < 3; ++k) cp.start[k] = cp.goal[k] = com[k];
+    wbc::Command cmd = ctl.plan(base, js, cp, 0.0);
+    (void)c0;
+    std::vector<double> tq;
+    double grf[12];
+    int stq = ctl.computeTorques(base, js, cs, cmd, tq, grf);
+    double gz = grf[2] + grf[5] + grf[8] + grf[11];
+    std::printf("QuadrupedWBC plan+tick: status=%d w_des z=%.4f sum fz=%.4f com=(%.4f %.4f %.4f)\n", stq, cmd.w_des[2], gz, com[0], com[1], com[2]);
+    if (stq != 0 || std::fabs(gz - w[2]) > 1e-2 * w[2] || std::fabs(cmd.w_des[2] - w[2]) > 1e-6) return 4;
+  } catch (const std::exception& e) {
+    std::printf("QuadrupedWBC: %s\n", e.what());
+    return 5;
+  }
+  return 0;
 }

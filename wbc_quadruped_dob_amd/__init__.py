@@ -134,6 +134,7 @@ def lib():
         L.wbc_ref_params_default.restype = None
         L.wbc_solver_set_ref_params.argtypes = [C.c_void_p, C.c_void_p]
         L.wbc_reference_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4
+        L.wbc_compute_reference.argtypes = [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 3
         L.wbc_rollout_tracking_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 8
         _lib = L
     return _lib
@@ -377,6 +378,16 @@ class Solver:
                                          p(tau_prev), p(f_prev), p(obs_integ), p(obs_r), p(tau), p(f), C.byref(st)),
                "wbc_compute_torques")
         return tau, f, st.value
+
+    def compute_reference(self, q, v, plan, t=0.0):
+        """Single-robot host-array planner call (numpy float64): returns (w_des[6], vdot_des[nv], com[6])."""
+        d = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        q, v, plan = d(q), d(v), d(plan)
+        w, vd, com = np.zeros(6), np.zeros(self.model.nv), np.zeros(6)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _check(lib().wbc_compute_reference(self._h, p(q), p(v), p(plan), C.c_double(t), p(w), p(vd), p(com)),
+               "wbc_compute_reference")
+        return w, vd, com
 
     def enable_timing(self, on=1):
         """0 = off, 1 = HIP events around every kernel, k > 1 = around the kernels of every k-th tick."""

@@ -762,6 +762,37 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   return WBC_OK;
 }
 
+extern "C" int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const double* plan, double t,
+                                     double* w_des, double* vdot_des, double* com) {
+  if (!s || !q || !v || !plan || !w_des || !vdot_des) return fail(WBC_E_INVALID, "null argument");
+  if (!s->d_ref) return fail(WBC_E_INVALID, "call wbc_solver_set_ref_params first");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
+  const int off[] = {0, 19, 37, 49, 55, 73, 79};  // q v plan | w_des vdot_des com end
+  std::vector<unsigned char> hbuf(79 * ts);
+  auto put = [&](int o, const double* src, int n) {
+    for (int i = 0; i < n; ++i) {
+      if (s->dtype == WBC_F64) ((double*)hbuf.data())[o + i] = src[i];
+      else ((float*)hbuf.data())[o + i] = (float)src[i];
+    }
+  };
+  put(off[0], q, 19); put(off[1], v, 18); put(off[2], plan, PLAN_WORDS);
+  unsigned char* d = (unsigned char*)s->d_one;
+  HIP_TRY(hipMemcpy(d, hbuf.data(), 49 * ts, hipMemcpyHostToDevice));
+  int rc = wbc_reference_batch(s, 1, d + off[0] * ts, d + off[1] * ts, d + off[2] * ts, t, d + off[3] * ts, d + off[4] * ts,
+                               d + off[5] * ts, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(hbuf.data() + 49 * ts, d + 49 * ts, 30 * ts, hipMemcpyDeviceToHost));
+  auto get = [&](int o, double* dst, int n) {
+    if (!dst) return;
+    for (int i = 0; i < n; ++i)
+      dst[i] = s->dtype == WBC_F64 ? ((double*)hbuf.data())[o + i] : (double)((float*)hbuf.data())[o + i];
+  };
+  get(off[3], w_des, 6); get(off[4], vdot_des, 18); get(off[5], com, 6);
+  return WBC_OK;
+}
+
 extern "C" const char* wbc_strerror(int st) {
   switch (st) {
     case WBC_OK: return "ok";
