@@ -123,6 +123,17 @@ def main():
         elapsed = float(t.item())
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
+    # the optional consumer-side collective (every rank receives all torques), reported BESIDE `value`
+    gather_res = None
+    if dist is not None and not os.environ.get("WBC_BENCH_NO_GATHER"):
+        try:
+            from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather
+            el_g, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, args.steps, torch.cuda.synchronize)
+            gather_res = {"value": args.steps * n * world / el_g, "ms_per_step": el_g / args.steps * 1e3,
+                          "collective": "all_gather_into_tensor(tau) after every step, RCCL, %d B per rank per step"
+                                        % (12 * n * (8 if dtype == "f64" else 4))}
+        except Exception as e:  # never lose the main line to the optional leg
+            gather_res = {"error": repr(e)[:200]}
 
     # cost of an event pair with nothing between them, on the same stream: the part of every measured span that is
     # not kernel time (reported; the roofline uses the raw span, i.e. it errs on the slow side)
@@ -176,6 +187,7 @@ def main():
                                  else "rnea_step (no CRBA, no M/h/Jc) -> qp"},
             "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                    "iters_max": int(iters.max())},
+            "with_tau_allgather": gather_res,
         }
         if not args.no_latency and world == 1:
             res["qp_latency"] = qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs)

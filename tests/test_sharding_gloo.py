@@ -59,6 +59,12 @@ def _worker(rank, world, port, n_total, q):
         out = sb.step(loc)
         tau_all = sb.gather(out["tau"])
         stats = sb.status_counts(out["status"], out["iters"])
+        # the bench's "with all-gather" leg needs equal slices: run it on the first 500 states of each rank
+        from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather
+        eq = {k: v[..., :500].contiguous() for k, v in loc.items()}
+        secs, gathered = timed_steps_with_gather(lambda: sb.step(eq), lambda o: o["tau"], dist, 2)
+        assert secs > 0 and tuple(gathered.shape) == (world, 12, 500)
+        assert torch.equal(gathered[rank], sb.step(eq)["tau"])
         if rank == 0:
             ref = orc.step(P, *[B[k] for k in keys], B["mask"])
             q.put((float(np.abs(tau_all.numpy().T - ref["tau"]).max()), stats, int((ref["status"] == 0).sum()),

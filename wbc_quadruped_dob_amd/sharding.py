@@ -68,3 +68,30 @@ class ShardedBatch:
             self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
         return dict(ok=int(sums[0]), iter_limit=int(sums[1]), infeasible=int(sums[2]), iters_sum=int(sums[3]),
                     iters_max=int(mx[0]))
+
+
+def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None):
+    """SURVEY.md 8e "report steps/s with and without the all-gather": runs `steps` ticks where every tick is followed by
+    an all-gather of this rank's tau ([nj, n_local], equal n_local on every rank) into a preallocated
+    [world, nj, n_local] buffer.  Returns (max-over-ranks seconds, gathered buffer).  bench.py calls it on the GPU box
+    (RCCL); tests/test_sharding_gloo.py runs the same function over gloo."""
+    import time
+    import torch
+    world = dist.get_world_size()
+    tau = get_tau(step_fn())
+    # output = the ranks' blocks concatenated along dim 0 (the one layout both RCCL and gloo accept)
+    flat = torch.empty((world * tau.shape[0],) + tuple(tau.shape[1:]), dtype=tau.dtype, device=tau.device)
+    gathered = flat.view((world,) + tuple(tau.shape))
+    dist.all_gather_into_tensor(flat, tau.contiguous())   # warm the communicator
+    sync()
+    dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tau = get_tau(step_fn())
+        dist.all_gather_into_tensor(flat, tau.contiguous())
+    sync()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=tau.device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item()), gathered
