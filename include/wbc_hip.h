@@ -139,10 +139,10 @@ int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_ba
 /* SURVEY.md 8(f)-1 -- the step Gazebo performs in the reference loop (/root/reference/README.md:58), as the simplest
  * model that closes the loop for rollouts: forward dynamics with the planned GRFs applied,
  *   vdot = M^-1 (S^T tau + Jc^T f + tau_ext - h),  then semi-implicit Euler on (q, v) IN PLACE with the solver's dt.
- * Must follow a wbc_step_batch of the same solver and N that wrote M and h (it also reads that tick's workspace).
- * tau_ext [nv][N] may be NULL. */
-int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h, const void* tau,
-                        const void* f, const void* tau_ext, void* stream);
+ * M, h, Jc, tau, f are the outputs of the wbc_step_batch of the same tick (foot lever arms and the own-leg Jacobian
+ * blocks are read from Jc).  tau_ext [nv][N] may be NULL. */
+int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h, const void* Jc,
+                        const void* tau, const void* f, const void* tau_ext, void* stream);
 
 /* `horizon` dependent ticks of {wbc_step_batch, wbc_integrate_batch} with constant references (BASELINE.json
  * configs[4]: MPC-style WBC-in-the-loop rollouts).  in->q / in->v are ADVANCED IN PLACE (const is cast away);
@@ -198,9 +198,9 @@ int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const
 /* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on ---- */
 int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 events around every kernel; k > 1: every k-th tick */
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed
- * 0 = fused dyn_sweep kernel (or mass_jac with WBC_SWEEP=split), 1 = QP kernel, 2 = rnea_step kernel (split only);
- * resets the accumulators. */
-int wbc_solver_collect_timing(wbc_solver* s, double ms[3], int launches[3]);
+ * 0 = dyn_sweep kernel (or mass_jac with WBC_SWEEP=split), 1 = QP kernel, 2 = rnea_step kernel (no-M/h/Jc ticks and
+ * split mode), 3 = fused tick kernel (sweep + QP of small batches in one launch); resets the accumulators. */
+int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launches[4]);
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */

@@ -380,7 +380,7 @@ def test_integrate_single_call_matches_forward_dynamics(torch_cuda, gpu_model, o
     out = solver.step(q, v, dv(B["w_des"]), dv(B["vdot_des"]), dv(B["normals"]), dv(B["mu"]), mask, want_mats=True)
     text = np.zeros((n, 18))
     text[:, 1] = -30.0
-    solver.integrate(q, v, out["M"], out["h"], out["tau"], out["f"], dv(text))
+    solver.integrate(q, v, out["M"], out["h"], out["Jc"], out["tau"], out["f"], dv(text))
     torch.cuda.synchronize()
     M = unpack_M(to_host(out["M"]))
     vdot = (to_host(v) - B["v"]) / P["dt"]
@@ -458,6 +458,46 @@ def test_split_sweep_variant_matches(torch_cuda, gpu_model, oracle, monkeypatch)
         assert relerr(got[k], d[k]) < TIGHT64, k
     assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
     assert relerr(got["integ"], ig_ref) < TIGHT64
+
+
+@pytest.mark.parametrize("obs,dtype,n", [(0, "f64", 4096), (0, "f64", 1003), (1, "f64", 2049), (2, "f64", 17), (0, "f32", 3000),
+                                         (1, "f32", 555)])
+def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkeypatch, obs, dtype, n):
+    """Observer-off batches that fit one workgroup per CU (N <= 4096) run the tick as ONE kernel (fused_tick.hip.hpp);
+    WBC_FUSED_MAX=0 forces the two-kernel tick.  The fused kernel's front half is rnea_step + mass_jac (another recursion
+    order than dyn_sweep) -> equal to rounding, both within the oracle tolerance.  Observer-on ticks are never fused."""
+    torch = torch_cuda
+    B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=51)
+    nd = _np_dtype(dtype)
+    integ0 = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"].astype(nd) if obs else None
+    res = {}
+    for tag, env in (("fused", None), ("two", "0")):
+        if env is not None:
+            monkeypatch.setenv("WBC_FUSED_MAX", env)
+        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
+        monkeypatch.delenv("WBC_FUSED_MAX", raising=False)
+        res[tag] = _run_step(torch, solver, B, dtype, None if integ0 is None else integ0.copy(),
+                             None if integ0 is None else np.zeros((n, 18), nd), want_mats=True)
+        solver.enable_timing(1)
+        _run_step(torch, solver, B, dtype, None if integ0 is None else integ0.copy(),
+                  None if integ0 is None else np.zeros((n, 18), nd), want_mats=True)
+        tm = solver.collect_timing()
+        assert (tm["fused_launches"] == 1) == (tag == "fused" and obs == 0) and (tm["qp_launches"] == 1) == (tag == "two" or obs > 0)
+    a, b = res["fused"], res["two"]
+    assert np.array_equal(a["status"], b["status"])
+    exact = obs > 0                   # observer on: both solvers run the same two kernels
+    assert np.mean(a["iters"] != b["iters"]) <= (0.0 if exact else 2e-3 if dtype == "f64" else 2e-2)   # a rounding-level
+    # difference may flip a degenerate pivot choice (fp32 works with qp_tol = 1e-3)
+    keys = ("tau", "f", "M", "h", "Jc", "pf") + (("integ", "r") if obs else ())
+    for k in keys:
+        if exact:
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert relerr(a[k], b[k]) < (1e-12 if dtype == "f64" else 1e-3), k
+    if dtype == "f64":
+        ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"],
+                          None if integ0 is None else integ0.copy(), None if integ0 is None else np.zeros((n, 18)), nthreads=8)
+        assert relerr(a["tau"], ref["tau"]) < TIGHT64 and relerr(a["f"], ref["f"]) < TIGHT64
 
 
 def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle):

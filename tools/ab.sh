@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of library variants on one device in one gpurun call: tools/ab.sh lib1.so lib2.so ...
 set -u
+export WBC_FUSED_MAX=${WBC_FUSED_MAX:-0}   # kernel-level A/B of the two-kernel tick: keep small batches off the fused launch
 mkdir -p gpurun_out
 : > gpurun_out/ab.log
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3 >> gpurun_out/ab.log

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of an environment switch on one device: tools/ab_env.sh VAR val1 val2 [batches...]
 set -u
+export WBC_FUSED_MAX=${WBC_FUSED_MAX:-0}   # kernel-level A/B of the two-kernel tick: keep small batches off the fused launch
 VAR=$1; V1=$2; V2=$3; shift 3
 BATCHES=${@:-"4096 262144"}
 mkdir -p gpurun_out; : > gpurun_out/abenv.log

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the two QP kernels (env WBC_QP_KERNEL) on one device
 set -u
+export WBC_FUSED_MAX=${WBC_FUSED_MAX:-0}   # kernel-level A/B of the two-kernel tick: keep small batches off the fused launch
 mkdir -p gpurun_out
 : > gpurun_out/abqp.log
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -15 >> gpurun_out/abqp.log

@@ -29,5 +29,7 @@ cp gpurun_out/pmc/summary.json "$O/pmc_summary.json"
 cat "$O/pytest_gpu.log" "$O/smoke.log" "$O/abi_smoke.log" "$O/fma_probe.log"
 for f in "$O"/bench_cfg[234]_n*[0-9].json; do echo "== $f"; python3 -c "
 import json,sys
-r=json.load(open('$f')); print(r['config']['workload']); print('  ms/step %.4f  steps/s %.4e  dyn %.1f us frac %.3f  qp %.1f us'%(r['ms_per_step'],r['value'],r['kernels']['dyn_sweep_us'],r['roofline']['frac'],r['kernels']['qp_us']))"; done
+r=json.load(open('$f')); k=r['kernels']; print(r['config']['workload'])
+us=lambda x: 'n/a' if x is None else '%.1f us'%x
+print('  ms/step %.4f  steps/s %.4e  fused %s  dyn %s  qp %s  roofline.frac %s'%(r['ms_per_step'],r['value'],us(k.get('fused_tick_us')),us(k['dyn_sweep_us']),us(k['qp_us']),r['roofline']['frac']))"; done
 cat "$O"/stats_n4096_kernel_stats.csv "$O"/stats_n262144_kernel_stats.csv

@@ -128,7 +128,7 @@ def lib():
         L.wbc_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.wbc_dynamics_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
         L.wbc_step_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
-        L.wbc_integrate_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 8
+        L.wbc_integrate_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
         L.wbc_rollout_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 6
         L.wbc_ref_params_default.argtypes = [C.c_void_p]
         L.wbc_ref_params_default.restype = None
@@ -284,13 +284,13 @@ class Solver:
         _check(lib().wbc_step_batch(self._h, N, C.byref(bi), C.byref(bo), C.byref(ob), self._stream()), "wbc_step_batch")
         return out
 
-    def integrate(self, q, v, M, h, tau, f, tau_ext=None):
+    def integrate(self, q, v, M, h, Jc, tau, f, tau_ext=None):
         """Forward dynamics with the planned GRFs + semi-implicit Euler; q, v advance IN PLACE (one dt)."""
         m = self.model
         N = q.shape[1]
         _check(lib().wbc_integrate_batch(self._h, N, self._ptr(q, m.nq, N), self._ptr(v, m.nv, N),
                                          self._ptr(M, m.nv * (m.nv + 1) // 2, N), self._ptr(h, m.nv, N),
-                                         self._ptr(tau, m.nj, N), self._ptr(f, 3 * m.nf, N), self._ptr(tau_ext, m.nv, N),
+                                         self._ptr(Jc, 3 * m.nf * m.nv, N), self._ptr(tau, m.nj, N), self._ptr(f, 3 * m.nf, N), self._ptr(tau_ext, m.nv, N),
                                          self._stream()), "wbc_integrate_batch")
 
     def rollout(self, horizon, q, v, w_des, vdot_des, normals, mu, mask, out, obs_integ=None, obs_r=None, tau_ext=None,
@@ -394,10 +394,10 @@ class Solver:
         _check(lib().wbc_solver_enable_timing(self._h, int(on)), "wbc_solver_enable_timing")
 
     def collect_timing(self):
-        ms = (C.c_double * 3)()
-        cnt = (C.c_int * 3)()
+        ms = (C.c_double * 4)()
+        cnt = (C.c_int * 4)()
         _check(lib().wbc_solver_collect_timing(self._h, ms, cnt), "wbc_solver_collect_timing")
-        names = ("dyn", "qp", "rnea")  # dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
+        names = ("dyn", "qp", "rnea", "fused")  # fused = one-kernel tick of small batches; dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
         out = {}
         for i, n in enumerate(names):
             out[n + "_ms"] = ms[i]

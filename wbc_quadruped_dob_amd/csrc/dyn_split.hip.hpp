@@ -38,7 +38,8 @@ constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
   const unsigned N32 = (unsigned)N;                                                                                        \
   /* lane = 16*leg + (state within the wave), as in dyn_sweep_kernel */                                                    \
   const int leg = (int)((threadIdx.x & 63) >> 4);                                                                          \
-  const size_t s_raw = ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);                \
+  const size_t s_raw = EXT ? (size_t)blockIdx.x * 16 + (threadIdx.x & 15)                                                  \
+                           : ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);           \
   const bool live = s_raw < N;                                                                                             \
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);                                                                   \
   const unsigned legN = (unsigned)leg * N32;
@@ -65,13 +66,20 @@ constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
 // ======================================================================================================================
 // mass_jac_kernel: M(q) by CRBA, Jc(q), pf(q).  No velocities anywhere.
 // ======================================================================================================================
-template <class T, int BLOCK>
-__global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const DevModel<T>* __restrict__ model, SweepArgs<T> a) {
-  __shared__ T cst[CST_WORDS];
-  __shared__ int zidx_s[64];
-  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
-  if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  __syncthreads();
+// EXT (fused_tick.hip.hpp): the body is ONE wavefront of a larger workgroup that owns 16 states; the constant tables
+// were staged by the whole workgroup (cst_ext, zidx_ext) and the body contains no barrier.
+template <class T, int BLOCK, bool EXT>
+WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext) {
+  static_assert(!EXT || BLOCK == 64, "one wavefront");
+  __shared__ T cst_own[EXT ? 1 : CST_WORDS];
+  __shared__ int zidx_own[EXT ? 1 : 64];
+  if constexpr (!EXT) {
+    for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
+    if (threadIdx.x < 64) zidx_own[threadIdx.x] = model->zidx[threadIdx.x];
+    __syncthreads();
+  }
+  const T* cst = EXT ? cst_ext : cst_own;
+  const int* zidx_s = EXT ? zidx_ext : zidx_own;
   WBC_ADDR_MACROS
 
   T qq[4];
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
   }
   // joint transforms: E of joints 0 and 1 wait in LDS ([word][lane]) until the return sweep reaches them
   __shared__ T park[18][BLOCK];
-  const int ln = threadIdx.x;
+  const int ln = EXT ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   M3<T> E2;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -217,21 +225,34 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
   }
 }
 
+template <class T, int BLOCK>
+__global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const DevModel<T>* __restrict__ model, SweepArgs<T> a) {
+  mass_jac_body<T, BLOCK, false>(model, a, nullptr, nullptr);
+}
+
 // ======================================================================================================================
 // rnea_step_kernel: bias forces h, tau_partial = (M vdot_des + h - rhat) by a second (acceleration-only) force
 // recursion, foot geometry for the QP, momentum observer.
 // ======================================================================================================================
-template <class T, int MODE, int BLOCK>
-__global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
-                                                                         SweepArgs<T> a) {
+// EXT: as for mass_jac_body; additionally the step workspace goes to the workgroup's LDS image wsl[word][16].
+template <class T, int MODE, int BLOCK, bool EXT>
+WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
+                            T* wsl) {
+  static_assert(!EXT || BLOCK == 64, "one wavefront");
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
   constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
   constexpr bool TWO = STEP && WH;              // h and tau_partial both wanted: two force chains; else one (merged)
   constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
-  __shared__ T cst[CST_WORDS];
-  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
-  __syncthreads();
+  __shared__ T cst_own[EXT ? 1 : CST_WORDS];
+  if constexpr (!EXT) {
+    for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
+    __syncthreads();
+  }
+  const T* cst = EXT ? cst_ext : cst_own;
   WBC_ADDR_MACROS
+#define WSTV(comp, val) do { if constexpr (EXT) wsl[(comp) * 16 + (int)(threadIdx.x & 15)] = (val); else STV(a.ws, comp, val); } while (0)
+#define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
 
   T qq[4], vb[6];
 #pragma unroll
@@ -255,8 +276,8 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
     T b[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c);
-    ST4(a.ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
-    if (leg < 2) STV(a.ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+    WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+    if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
   }
   T qx, qy, qz, qw;
   {
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
   constexpr int PW = 15 + (TWO ? 6 : 0) + (OBS ? 18 : 0);
   constexpr int PB = BASEROWS ? (OBS ? 18 : 6) : 1;
   __shared__ T park[2 * PW + PB][BLOCK];
-  const int ln = threadIdx.x;
+  const int ln = EXT ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   constexpr int OFF_A = 15, OFF_O = 15 + (TWO ? 6 : 0);
 
   V3<T> omp, vp, aAp, aLp, gLp, a2Ap, a2Lp;
@@ -440,14 +461,14 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
     STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
   }
   if (STEP) {
-    STL(a.ws, WS_D + 0, 3, dw.x);
-    STL(a.ws, WS_D + 1, 3, dw.y);
-    STL(a.ws, WS_D + 2, 3, dw.z);
+    WSTL(WS_D + 0, 3, dw.x);
+    WSTL(WS_D + 1, 3, dw.y);
+    WSTL(WS_D + 2, 3, dw.z);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      STL(a.ws, WS_JCL + 0 + k, 9, jw[k].x);
-      STL(a.ws, WS_JCL + 3 + k, 9, jw[k].y);
-      STL(a.ws, WS_JCL + 6 + k, 9, jw[k].z);
+      WSTL(WS_JCL + 0 + k, 9, jw[k].x);
+      WSTL(WS_JCL + 3 + k, 9, jw[k].y);
+      WSTL(WS_JCL + 6 + k, 9, jw[k].z);
     }
   }
   if (WH) {
@@ -524,12 +545,21 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
       T b[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
-      ST4(a.ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
-      if (leg < 2) STV(a.ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+      WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+      if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) STL(a.ws, WS_TAUP + k, 3, taup[k] - rl[k]);
+    for (int k = 0; k < 3; ++k) WSTL(WS_TAUP + k, 3, taup[k] - rl[k]);
   }
+#undef WSTL
+#undef WST4
+#undef WSTV
+}
+
+template <class T, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+                                                                         SweepArgs<T> a) {
+  rnea_step_body<T, MODE, BLOCK, false>(model, prm, a, nullptr, nullptr);
 }
 
 #undef MAKE_R

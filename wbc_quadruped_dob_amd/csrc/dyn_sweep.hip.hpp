@@ -137,6 +137,12 @@ WBC_DEV float xrow_sum(float x) {
 }
 template <class T> WBC_DEV V3<T> xrow_sum(V3<T> v) { return mk<T>(xrow_sum(v.x), xrow_sum(v.y), xrow_sum(v.z)); }
 
+// K cross-leg sums at once (v_permlane16/32_swap)
+template <class T, int K> WBC_DEV void xrow_sum_k(T (&x)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) x[k] = xrow_sum(x[k]);
+}
+
 template <class T> WBC_DEV T sel4(int leg, T a, T b, T c, T d) { return leg == 0 ? a : (leg == 1 ? b : (leg == 2 ? c : d)); }
 
 // fp64 sin/cos, straight-line (no branches, so the three joints of a leg interleave in the pipeline): two-term
@@ -185,9 +191,13 @@ constexpr int SW_OBS = 4;   // momentum observer update (needs SW_STEP) / p, bet
 // share one constant table, which lets two workgroups = 8 waves fit the CU's 160 KB of LDS).
 // The observer variants may use more than 256 VGPRs (their occupancy is LDS-bound anyway); forcing two waves per
 // SIMD there makes the compiler spill to scratch.
+// (Measured and removed: (1) a "leg per wavefront" mapping for small batches -- wave w runs leg w in 16 lanes, cross-leg sums
+// through LDS -- to spread the 117 store instructions of a state group over four SIMDs: bitwise-equal results, 8-10 %
+// SLOWER at N = 1 024 ... 4 096, the sweep wave is bound by its dependent fp64 chain, not by store issue; (2) this body as
+// wave 0 of a fused sweep+QP workgroup with the workspace in LDS: -7 % per tick with the observer off, nothing with it
+// on; superseded by the role-split fused tick in fused_tick.hip.hpp, which does not use this body.)
 template <class T, int MODE, int BLOCK>
-__global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
-                                                        SweepArgs<T> a) {
+WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0;
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
@@ -221,6 +231,9 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
 #define STLX(ptr, c0, stride, xN, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   // four base-replicated values, one per lane of the quad
 #define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define WSTV(comp, val) STV(a.ws, comp, val)   /* step workspace */
+#define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
 
   // ------------------------------------------------------------------ loads
   T qb[7], vb[6];
@@ -243,6 +256,13 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
   // the per-leg constant table is staged AFTER the state loads have been issued: one memory round trip, not two
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (MATS && threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
+  // observer gains of the joint rows are indexed by a run-time joint number: from LDS (a dynamic index into the
+  // kernel-argument struct can end up as a private copy of the whole struct)
+  __shared__ T kgain[OBS ? 36 : 1];
+  if (OBS && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { kgain[i] = prm.K1[i]; kgain[18 + i] = prm.K2[i]; }  // static indices only
+  }
   __syncthreads();
   SSTAMP();  // 2: table staged (barrier passed)
 
@@ -251,8 +271,8 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
     T b[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c);
-    ST4(a.ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
-    if (leg < 2) STV(a.ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+    WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+    if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
   }
 
   // ------------------------------------------------------------------ data-independent stores first:
@@ -319,6 +339,7 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
   constexpr int PE2 = OBS ? 9 : 0;         // observer: E of joint 2 too (the momentum pass walks the leg again)
   __shared__ T park[2 * PW + PB + PE2][BLOCK];
   const int ln = threadIdx.x;
+#define XSUM(arr, K) xrow_sum_k<T, K>(arr)
   V3<T> omp, vp, aAp, aLp;
   {
     M3<T> R;
@@ -513,14 +534,14 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
     STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
   }
   if (STEP) {
-    STL(a.ws, WS_D + 0, 3, dw.x);
-    STL(a.ws, WS_D + 1, 3, dw.y);
-    STL(a.ws, WS_D + 2, 3, dw.z);
+    WSTL(WS_D + 0, 3, dw.x);
+    WSTL(WS_D + 1, 3, dw.y);
+    WSTL(WS_D + 2, 3, dw.z);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      STL(a.ws, WS_JCL + 0 + k, 9, jw[k].x);
-      STL(a.ws, WS_JCL + 3 + k, 9, jw[k].y);
-      STL(a.ws, WS_JCL + 6 + k, 9, jw[k].z);
+      WSTL(WS_JCL + 0 + k, 9, jw[k].x);
+      WSTL(WS_JCL + 3 + k, 9, jw[k].y);
+      WSTL(WS_JCL + 6 + k, 9, jw[k].z);
     }
   }
 
@@ -528,16 +549,19 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
   // ------------------------------------------------------------------ quad reductions into the base
   if (MATS) {
     const T* pb = &park[2 * PW][ln];
-    const V3<T> bfn = xrow_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);   // total bias wrench, base coords
-    const V3<T> bff = xrow_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
+    T xa[16] = {facc.n.x, facc.n.y, facc.n.z, facc.f.x, facc.f.y, facc.f.z, cm, ch.x, ch.y, ch.z,
+                cI.xx, cI.xy, cI.xz, cI.yy, cI.yz, cI.zz};
+    XSUM(xa, 16);   // the four legs' contributions to the base: bias wrench 6, composite mass 1, first moment 3, inertia 6
+    const V3<T> bfn = mk<T>(xa[0], xa[1], xa[2]) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);   // total bias wrench, base coords
+    const V3<T> bff = mk<T>(xa[3], xa[4], xa[5]) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
     const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);  // h base rows (force, moment), world
     ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
     if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
-    const T tm = xrow_sum(cm) + bm;
-    const V3<T> th = xrow_sum(ch) + bh;
+    const T tm = xa[6] + bm;
+    const V3<T> th = mk<T>(xa[7], xa[8], xa[9]) + bh;
     S3<T> tI;
-    tI.xx = xrow_sum(cI.xx) + bI.xx; tI.xy = xrow_sum(cI.xy) + bI.xy; tI.xz = xrow_sum(cI.xz) + bI.xz;
-    tI.yy = xrow_sum(cI.yy) + bI.yy; tI.yz = xrow_sum(cI.yz) + bI.yz; tI.zz = xrow_sum(cI.zz) + bI.zz;
+    tI.xx = xa[10] + bI.xx; tI.xy = xa[11] + bI.xy; tI.xz = xa[12] + bI.xz;
+    tI.yy = xa[13] + bI.yy; tI.yz = xa[14] + bI.yz; tI.zz = xa[15] + bI.zz;
     const V3<T> hw = mul(R, th);
     const S3<T> Iw = congr(R, tI);
     // base 6x6 block: 15 data-dependent entries (the 6 structural zeros went out with the early stores)
@@ -609,10 +633,12 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
       }
     }
     const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
-    mom0.n = xrow_sum(macc.n) + Iv0.n;
-    mom0.f = xrow_sum(macc.f) + Iv0.f;
-    grv0.n = xrow_sum(gacc.n) + cross(bh, gneg);
-    grv0.f = xrow_sum(gacc.f) + gneg * bm;
+    T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
+    XSUM(xb, 12);
+    mom0.n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n;
+    mom0.f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
+    grv0.n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg);
+    grv0.f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
   }
 
   SSTAMP();  // 8: base block stored
@@ -647,9 +673,9 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
     if (OBS && prm.observer_order > 0) {
       // generalized force of the previous commands at the current configuration
       const V3<T> fp = mk<T>(LDV(a.f_prev, 3 * leg + 0), LDV(a.f_prev, 3 * leg + 1), LDV(a.f_prev, 3 * leg + 2));
-      const V3<T> ub_f = xrow_sum(fp);
-      const V3<T> ub_n = xrow_sum(cross(dw, fp));
-      const T ub[6] = {ub_f.x, ub_f.y, ub_f.z, ub_n.x, ub_n.y, ub_n.z};
+      const V3<T> dxf = cross(dw, fp);
+      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+      XSUM(ub, 6);
       const T dt = prm.dt;
       const bool o1 = prm.observer_order == 1;
 #pragma unroll
@@ -673,21 +699,20 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
         const T u = LDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
         const T ig = LDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
         const T e = p_leg[k] - ig;
-        rl[k] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        rl[k] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
         STV(a.obs_integ, c, ig);
         STV(a.obs_r, c, rl[k]);
       }
     }
-    T* ws = a.ws;
     if (OBS) {
       T b[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
-      ST4(ws, WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
-      if (leg < 2) STV(ws, WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+      WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+      if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) STL(ws, WS_TAUP + k, 3, taup[k] - rl[k]);
+    for (int k = 0; k < 3; ++k) WSTL(WS_TAUP + k, 3, taup[k] - rl[k]);
   }
 #ifdef WBC_SWEEP_STAMP
   SSTAMP();  // 9: everything issued
@@ -698,7 +723,11 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
   if (a.pf && leg == 3) STL(a.pf, 0, 3, (T)(stp[10] - stp[9]));
 #endif
 #undef SSTAMP
+#undef XSUM
 #undef MAKE_R
+#undef WSTL
+#undef WST4
+#undef WSTV
 #undef ST4
 #undef STLX
 #undef STL
@@ -707,6 +736,12 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
 #undef LDV
 #undef LDU
 #undef CS
+}
+
+template <class T, int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+                                                        SweepArgs<T> a) {
+  dyn_sweep_body<T, MODE, BLOCK>(model, prm, a);
 }
 
 }  // namespace wbc

@@ -6,7 +6,8 @@
 // matrix is an arrow: a 6x6 base block, four 6x3 base-leg blocks and four independent 3x3 leg blocks.  Each lane
 // inverts ITS leg block in closed form, forms its part of the base Schur complement (21 + 6 words summed across
 // the four rows with v_permlane16/32_swap), every lane solves the 6x6 base system redundantly in registers, and
-// back-substitutes its own leg.  M, h come from the buffers the sweep wrote, foot geometry from the step workspace.
+// back-substitutes its own leg.  M, h, Jc come from the buffers the sweep wrote (foot lever arms = the base-angular
+// columns of Jc, own-leg Jacobian blocks = its joint columns).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
@@ -17,8 +18,7 @@ namespace wbc {
 template <class T> struct IntegrateArgs {
   size_t N;
   T* q; T* v;                       // in/out
-  const T* M; const T* h;           // from the sweep (packed M, bias)
-  const T* ws;                      // step workspace of the same tick: d (foot rel. base), JcL
+  const T* M; const T* h; const T* Jc;   // from the sweep of the same tick
   const T* tau; const T* f;         // this tick's outputs
   const T* tau_ext;                 // [nv][N] or null
   T* tau_traj;                      // [nj][N] slice for this tick, or null
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __rest
 #define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define LDL(ptr, c0, stride) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))))
+#define LDLX(ptr, c0, stride, xN) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))))
 #define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   int jx[3];
 #pragma unroll
@@ -44,11 +45,13 @@ __global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __rest
 
   // ---- my leg: rhs_l = tau_l + JcL^T f_l + tau_ext_l - h_l
   const V3<T> fl = mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
-  const V3<T> dl = mk<T>(LDL(a.ws, WS_D + 0, 3), LDL(a.ws, WS_D + 1, 3), LDL(a.ws, WS_D + 2, 3));
+  // foot position relative to the base origin from the base-angular block of my foot's Jacobian rows, -[d]x
+  const V3<T> dl = mk<T>(LDL(a.Jc, 18 * 1 + 5, 54), LDL(a.Jc, 18 * 2 + 3, 54), LDL(a.Jc, 18 * 0 + 4, 54));
   T rl[3], ql[3], vl[3], taul[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const T jc0 = LDL(a.ws, WS_JCL + 0 + k, 9), jc1 = LDL(a.ws, WS_JCL + 3 + k, 9), jc2 = LDL(a.ws, WS_JCL + 6 + k, 9);
+    const unsigned jo = (unsigned)(6 + jx[k]) * N32;   // column of joint (leg, k) in rows 3*leg + m of Jc
+    const T jc0 = LDLX(a.Jc, 0, 54, jo), jc1 = LDLX(a.Jc, 18, 54, jo), jc2 = LDLX(a.Jc, 36, 54, jo);
     taul[k] = LDV(a.tau, jx[k]);
     rl[k] = taul[k] + jc0 * fl.x + jc1 * fl.y + jc2 * fl.z - LDV(a.h, 6 + jx[k]) + (a.tau_ext ? LDV(a.tau_ext, 6 + jx[k]) : (T)0);
     ql[k] = LDV(a.q, 7 + jx[k]);
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __rest
   STV(a.q, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, qn[0], qn[1], qn[2], qn[3]));
   if (leg < 3) STV(a.q, 4 + leg, sel4<T>(leg, qn[4], qn[5], qn[6], qn[6]));
 #undef STV
+#undef LDLX
 #undef LDL
 #undef LDV
 #undef LDU

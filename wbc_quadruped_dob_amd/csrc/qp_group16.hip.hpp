@@ -119,9 +119,12 @@ template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]
 // WPB = wavefronts per workgroup.  1 (default): every wavefront is its own workgroup, so its LDS and wave slot are
 // released the moment ITS four QPs are done and the CU backfills -- with 4-wave workgroups the slot lived as long as
 // the slowest of 16 QPs.  Workgroups that share a 128-byte line of the inputs are mapped to the same XCD (L2).
-template <class T, bool REGROUP, int WPB>
-__global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+// WSLDS (fused_tick.hip.hpp): the step workspace of the workgroup's 16 states is read from LDS (wsl[word][16], written
+// by the sweep phase of the same workgroup) instead of from HBM.
+template <class T, bool REGROUP, int WPB, bool WSLDS>
+WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl) {
   static_assert(!REGROUP || WPB == 4, "re-dealing needs the 16 rows of a 4-wave workgroup");
+  static_assert(!WSLDS || (WPB == 4 && !REGROUP), "the fused tick pairs one sweep wavefront with four QP wavefronts");
   __shared__ G16Lds<T> lds_all[WPB];
   const int lane = threadIdx.x & 63;
   const int l16 = lane & 15;
@@ -138,11 +141,13 @@ __global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevP
   // and take four CONSECUTIVE 4-state groups = one whole 128-byte line per component row.  Speed only.
   size_t wg = blockIdx.x;
   if (WPB == 1 && (gridDim.x & 31) == 0) wg = (wg & ~(size_t)31) + ((wg & 7) << 2) + ((wg >> 3) & 3);
-  const size_t qp_raw = (wg * blockDim.x + threadIdx.x) >> 4;
+  const size_t qp_raw = WSLDS ? (size_t)blockIdx.x * 16 + (threadIdx.x >> 4)   // fused tick: QP wavefronts are threads 0..255 of a larger workgroup
+                              : (wg * blockDim.x + threadIdx.x) >> 4;
   bool live = qp_raw < N;
   unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
   const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
 #define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define WSLD(comp) (WSLDS ? wsl[(comp) * 16 + (int)(threadIdx.x >> 4)] : GLD(a.ws, comp))
 #define GST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
 
 #ifdef WBC_QP_STAMP
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevP
   // ------------------------------------------------------------------ inputs
   int mask = a.mask[s32] & 0xF;
   bool on = (mask >> f) & 1;
-  const T d_me = isvar ? GLD(a.ws, WS_D + v) : (T)0;
-  const T b_ld = (l16 < 6) ? GLD(a.ws, WS_B + l16) : (T)0;
+  const T d_me = isvar ? WSLD(WS_D + v) : (T)0;
+  const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) : (T)0;
   const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
   const T mu_f = GLD(a.mu, f);
   T b[6];
@@ -515,8 +520,8 @@ __global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevP
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     if (isvar) {
-      taup = GLD(a.ws, WS_TAUP + v);
-      jl0 = GLD(a.ws, WS_JCL + 9 * f + 0 + c3); jl1 = GLD(a.ws, WS_JCL + 9 * f + 3 + c3); jl2 = GLD(a.ws, WS_JCL + 9 * f + 6 + c3);
+      taup = WSLD(WS_TAUP + v);
+      jl0 = WSLD(WS_JCL + 9 * f + 0 + c3); jl1 = WSLD(WS_JCL + 9 * f + 3 + c3); jl2 = WSLD(WS_JCL + 9 * f + 6 + c3);
     }
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     if (isvar) {
@@ -544,7 +549,13 @@ __global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevP
     }
   }
 #undef GST
+#undef WSLD
 #undef GLD
+}
+
+template <class T, bool REGROUP, int WPB>
+__global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+  qp_group16_body<T, REGROUP, WPB, false>(prm, a, jmap, nullptr);
 }
 
 }  // namespace wbc

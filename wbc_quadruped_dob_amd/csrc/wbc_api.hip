@@ -20,6 +20,7 @@
 #include "qp_group16.hip.hpp"
 #include "integrate.hip.hpp"
 #include "com_ref.hip.hpp"
+#include "fused_tick.hip.hpp"
 
 using namespace wbc;
 
@@ -48,6 +49,7 @@ struct wbc_solver {
   bool qp_regroup = false;  // env WBC_QP_REGROUP=1 with WBC_QP_WPB=4: re-deal the 16 QPs of a workgroup by predicted work (A/B; measured: no gain)
   int sweep_mode = 1; // 1 = fused dyn_sweep (default), 0 = split (mass_jac on a second stream || rnea_step -> QP); env WBC_SWEEP=split
                       // measured on MI355X: split is 5-20 % slower (two kernels pay the fixed latencies twice), kept for A/B
+  size_t fused_max = 4096;  // observer-off ticks of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
@@ -270,6 +272,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (const char* e = std::getenv("WBC_QP_KERNEL")) s->qp_kernel = (std::strcmp(e, "wave") == 0) ? 1 : 0;
   if (const char* e = std::getenv("WBC_QP_WPB")) s->qp_wpb = (std::strcmp(e, "4") == 0) ? 4 : 1;
   if (const char* e = std::getenv("WBC_QP_REGROUP")) s->qp_regroup = (std::strcmp(e, "1") == 0);
+  if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
@@ -358,9 +361,9 @@ extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
   return WBC_OK;
 }
 
-extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[3], int launches[3]) {
+extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launches[4]) {
   if (!s || !ms || !launches) return fail(WBC_E_INVALID, "null argument");
-  for (int k = 0; k < 3; ++k) { ms[k] = 0; launches[k] = 0; }
+  for (int k = 0; k < 4; ++k) { ms[k] = 0; launches[k] = 0; }
   for (auto& sp : s->spans) {
     HIP_TRY(hipEventSynchronize(sp.b));
     float t = 0;
@@ -510,6 +513,20 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   timing_tick(s);
   int rc;
   hipError_t e;
+  QpArgs<T> qa;
+  qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
+  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
+  if (mats && !ob && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 && N <= s->fused_max) {
+    // small batch, observer off: one launch, 16 states per workgroup, rnea_step | mass_jac | QP as wavefront roles and
+    // the workspace through LDS (fused_tick.hip.hpp)
+    rc = span_begin(s, 3, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fused_tick_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(384), 0, st,
+                       (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a, qa, s->jmap);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("fused tick launch: ") + hipGetErrorString(e));
+    return span_end(s, st);
+  }
   if (s->sweep_mode == 0 || !mats) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
     if (mats) { rc = fork_mass_jac<T>(s, a, st); if (rc) return rc; }
     const int mode = RS_STEP | (mats ? RS_H : 0) | (ob ? RS_OBS : 0) | ((!mats && out->pf) ? RS_PF : 0);
@@ -531,9 +548,6 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     if (rc) return rc;
   }
 
-  QpArgs<T> qa;
-  qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
-  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
   rc = span_begin(s, 1, st);
   if (rc) return rc;
   if (s->qp_kernel == 1) {  // one QP per wavefront, factors in LDS (north-star sketch; kept for A/B)
@@ -579,10 +593,10 @@ extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, c
 }
 
 template <class T>
-static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h, const void* tau,
-                          const void* f, const void* tau_ext, void* tau_traj, hipStream_t st) {
+static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h, const void* Jc,
+                          const void* tau, const void* f, const void* tau_ext, void* tau_traj, hipStream_t st) {
   IntegrateArgs<T> a;
-  a.N = N; a.q = (T*)q; a.v = (T*)v; a.M = (const T*)M; a.h = (const T*)h; a.ws = (const T*)s->d_ws;
+  a.N = N; a.q = (T*)q; a.v = (T*)v; a.M = (const T*)M; a.h = (const T*)h; a.Jc = (const T*)Jc;
   a.tau = (const T*)tau; a.f = (const T*)f; a.tau_ext = (const T*)tau_ext; a.tau_traj = (T*)tau_traj;
   a.dt = (T)s->params.dt;
   hipLaunchKernelGGL((integrate_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
@@ -593,14 +607,14 @@ static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void*
 }
 
 extern "C" int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h,
-                                   const void* tau, const void* f, const void* tau_ext, void* stream) {
-  if (!s || !q || !v || !M || !h || !tau || !f) return fail(WBC_E_INVALID, "null argument");
+                                   const void* Jc, const void* tau, const void* f, const void* tau_ext, void* stream) {
+  if (!s || !q || !v || !M || !h || !Jc || !tau || !f) return fail(WBC_E_INVALID, "null argument");
   if (N == 0) return WBC_OK;
   if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  return s->dtype == WBC_F64 ? integrate_impl<double>(s, N, q, v, M, h, tau, f, tau_ext, nullptr, st)
-                             : integrate_impl<float>(s, N, q, v, M, h, tau, f, tau_ext, nullptr, st);
+  return s->dtype == WBC_F64 ? integrate_impl<double>(s, N, q, v, M, h, Jc, tau, f, tau_ext, nullptr, st)
+                             : integrate_impl<float>(s, N, q, v, M, h, Jc, tau, f, tau_ext, nullptr, st);
 }
 
 extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
@@ -620,8 +634,8 @@ extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc
     void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     rc = s->dtype == WBC_F64
-             ? integrate_impl<double>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st)
-             : integrate_impl<float>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st);
+             ? integrate_impl<double>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->Jc, out->tau, out->f, tau_ext, traj, st)
+             : integrate_impl<float>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->Jc, out->tau, out->f, tau_ext, traj, st);
     if (rc) return rc;
   }
   return WBC_OK;
@@ -706,8 +720,8 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
     void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     rc = s->dtype == WBC_F64
-             ? integrate_impl<double>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st)
-             : integrate_impl<float>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->tau, out->f, tau_ext, traj, st);
+             ? integrate_impl<double>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->Jc, out->tau, out->f, tau_ext, traj, st)
+             : integrate_impl<float>(s, N, (void*)in->q, (void*)in->v, out->M, out->h, out->Jc, out->tau, out->f, tau_ext, traj, st);
     if (rc) return rc;
   }
   return WBC_OK;
