@@ -42,6 +42,8 @@ template <class T> struct DevParams {
 //   18..29 taup   (M vdot_des + h - rhat) joint rows, leg-major (leg l joint k at 18+3l+k)
 //   30..65 JcL    own-leg Jacobian block of foot l: 30 + 9 l + 3 m + k = d pf_m / d q_{l,k}
 constexpr int WS_D = 0, WS_B = 12, WS_TAUP = 18, WS_JCL = 30, WS_WORDS = 66;
+// LDS image of the fused tick only: 66..83 rhat (observer estimate: base rows 6, joint rows leg-major 12)
+constexpr int WS_RHAT = 66, WS_LDS_WORDS = 84;
 
 template <class T> struct SweepArgs {
   size_t N;

@@ -32,6 +32,8 @@ constexpr int RS_H = 1;     // write h (bias forces)
 constexpr int RS_STEP = 2;  // write the step workspace (d, b, taup, JcL)
 constexpr int RS_OBS = 4;   // momentum / gravity recursions: p, beta outputs and the observer update
 constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
+constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, without RS_STEP / RS_H): no force recursion, the
+                            // momentum observer is updated and rhat (18 words) goes to the LDS image at WS_RHAT
 
 #define WBC_ADDR_MACROS                                                                                                   \
   const size_t N = a.N;                                                                                                    \
@@ -240,6 +242,8 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
                             T* wsl) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
+  constexpr bool OBSW = (MODE & RS_OBSW) != 0;
+  static_assert(!OBSW || (EXT && OBS && !STEP && !WH), "the observer role exists only inside the fused tick");
   constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
   constexpr bool TWO = STEP && WH;              // h and tau_partial both wanted: two force chains; else one (merged)
   constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
@@ -508,7 +512,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
       for (int k = 0; k < 3; ++k) STLX(a.beta, 6, 0, jxN[k], beta_l[k]);
     }
   }
-  if (STEP) {
+  if (STEP || OBSW) {
     T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
     if (OBS && prm.observer_order > 0) {
       const V3<T> fp = mk<T>(LDV(a.f_prev, 3 * leg + 0), LDV(a.f_prev, 3 * leg + 1), LDV(a.f_prev, 3 * leg + 2));
@@ -536,20 +540,32 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
         const T u = LDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
         const T ig = LDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
         const T e = p_leg[k] - ig;
-        rl[k] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        // gains of joint row c = 6 + jx[k] by a select over the 12 joint rows: a run-time index into the kernel-argument
+        // struct may become a private (scratch) copy of the whole struct
+        T k1 = prm.K1[6], k2 = prm.K2[6];
+#pragma unroll
+        for (int j = 1; j < 12; ++j) { k1 = (jx[k] == j) ? prm.K1[6 + j] : k1; k2 = (jx[k] == j) ? prm.K2[6 + j] : k2; }
+        rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
         STV(a.obs_integ, c, ig);
         STV(a.obs_r, c, rl[k]);
       }
     }
-    if (OBS) {
-      T b[6];
+    if constexpr (OBSW) {   // hand rhat to the QP waves, which subtract it from b and tau_partial themselves
+      WST4(WS_RHAT + 0, rb[0], WS_RHAT + 1, rb[1], WS_RHAT + 2, rb[2], WS_RHAT + 3, rb[3]);
+      if (leg < 2) WSTV(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
-      WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
-      if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+      for (int k = 0; k < 3; ++k) WSTL(WS_RHAT + 6 + k, 3, rl[k]);
+    } else {
+      if (OBS) {
+        T b[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
+        WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
+        if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) WSTL(WS_TAUP + k, 3, taup[k] - rl[k]);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) WSTL(WS_TAUP + k, 3, taup[k] - rl[k]);
   }
 #undef WSTL
 #undef WST4

@@ -5,10 +5,10 @@
 // -- before the QP may start, and a round trip of the 66-word step workspace through HBM.  Here a workgroup owns 16
 // consecutive states and hands the workspace over in LDS; M/h/Jc stores drain behind the QP.
 //
-// Observer OFF only: the front half is split by consumer into wavefront roles (below); N = 4 096: 25.7 us per tick
-// against 32.5 us for the two-kernel tick (154 M vs 126 M control-steps/s).  Observer-on ticks keep the two-kernel tick
-// (their rnea_step needs > 256 VGPRs, which six wavefronts per CU do not have; a whole-sweep-then-QP fusion was
-// measured: no gain).  Larger batches keep the two-kernel tick too: the sweep is HBM-bound there and wants all lanes of 8 waves per CU, which
+// The front half is split by consumer into wavefront roles (below).  N = 4 096, observer off: 25.6 us per tick against
+// 32.5 us for the two-kernel tick (155 M vs 126 M control-steps/s); observer on (a seventh wavefront): 29.3 us against
+// 34.3 us (140 M vs 120 M).  (A whole-sweep-then-QP fusion was measured before this one: -7 % / no gain.)
+// Larger batches keep the two-kernel tick: the sweep is HBM-bound there and wants all lanes of 8 waves per CU, which
 // the fused kernels' LDS (100 kB per workgroup in fp64) does not allow; measured slower from N = 8 192 on.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -24,12 +24,15 @@ namespace wbc {
 // and run the GRF QP.  The QP therefore starts after the ~1/3 of the dynamics it depends on, and the CRBA and its
 // stores overlap with it on otherwise idle issue slots.  No barrier after the table staging: the hand-over is an
 // LDS flag (the four QP waves poll it; all waves of a workgroup are resident, so the producer always runs).
-template <class T>
-__global__ __launch_bounds__(384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
-                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
+// OBSERVER on: a seventh wavefront takes the observer role (rnea_step_body<RS_OBS | RS_OBSW>: velocities, momenta,
+// gravity terms, beta = C^T v - g, the update of {integ, r}) and leaves rhat in LDS; the QP waves wait for both producers
+// and subtract rhat from b and tau_partial themselves.
+template <class T, bool OBSERVER>
+__global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+                                                                            SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
-  __shared__ T wsl[WS_WORDS * 16];
+  __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
@@ -39,13 +42,19 @@ __global__ __launch_bounds__(384, 1) void fused_tick_kernel(const DevModel<T>* _
   if (wave == 4) {
     rnea_step_body<T, RS_STEP | RS_H, 64, true>(model, prm, a, cst, wsl);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
   } else if (wave == 5) {
     mass_jac_body<T, 64, true>(model, a, cst, zidx_s);
+  } else if (OBSERVER && wave == 6) {
+    if constexpr (OBSERVER) {
+      rnea_step_body<T, RS_OBS | RS_OBSW, 64, true>(model, prm, a, cst, wsl);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   } else {
-    while (__hip_atomic_load(&ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(&ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (OBSERVER ? 2 : 1)) __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    qp_group16_body<T, false, 4, true>(prm, qa, jmap, wsl);
+    qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl);
   }
 }
 

@@ -121,7 +121,9 @@ template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]
 // the slowest of 16 QPs.  Workgroups that share a 128-byte line of the inputs are mapped to the same XCD (L2).
 // WSLDS (fused_tick.hip.hpp): the step workspace of the workgroup's 16 states is read from LDS (wsl[word][16], written
 // by the sweep phase of the same workgroup) instead of from HBM.
-template <class T, bool REGROUP, int WPB, bool WSLDS>
+// RHAT (with WSLDS, observer-on fused tick): the observer role left rhat in the LDS image; b and tau_partial are
+// completed here (b -= rhat_base, tau_partial -= rhat_joint).
+template <class T, bool REGROUP, int WPB, bool WSLDS, bool RHAT = false>
 WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl) {
   static_assert(!REGROUP || WPB == 4, "re-dealing needs the 16 rows of a 4-wave workgroup");
   static_assert(!WSLDS || (WPB == 4 && !REGROUP), "the fused tick pairs one sweep wavefront with four QP wavefronts");
@@ -157,7 +159,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   int mask = a.mask[s32] & 0xF;
   bool on = (mask >> f) & 1;
   const T d_me = isvar ? WSLD(WS_D + v) : (T)0;
-  const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) : (T)0;
+  const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
   const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
   const T mu_f = GLD(a.mu, f);
   T b[6];
@@ -520,7 +522,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     if (isvar) {
-      taup = WSLD(WS_TAUP + v);
+      taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
       jl0 = WSLD(WS_JCL + 9 * f + 0 + c3); jl1 = WSLD(WS_JCL + 9 * f + 3 + c3); jl2 = WSLD(WS_JCL + 9 * f + 6 + c3);
     }
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
