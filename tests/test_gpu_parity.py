@@ -349,6 +349,29 @@ def test_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H):
     assert np.allclose(np.linalg.norm(got["q"][:, 3:7], axis=1), 1.0, atol=1e-13)
 
 
+@pytest.mark.parametrize("cfg,obs,n,H", [(3, 1, 1000, 20), (2, 0, 129, 7)])
+def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, oracle, monkeypatch, cfg, obs, n, H):
+    """wbc_rollout_batch of small batches is ONE launch for the whole horizon (rollout_kernel); WBC_ROLLOUT_PERSISTENT=0
+    forces {fused tick, integrate} launches per tick.  Same device functions -> equal to rounding."""
+    torch = torch_cuda
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=61)
+    tau_ext = np.zeros((n, 18))
+    tau_ext[:, 0:3] = B["push"] if cfg > 2 else 10.0
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    res = {}
+    for tag, env in (("persistent", None), ("per_tick", "0")):
+        if env is not None:
+            monkeypatch.setenv("WBC_ROLLOUT_PERSISTENT", env)
+        solver, P = _solver(gpu_model, obs=obs, max_batch=n)
+        monkeypatch.delenv("WBC_ROLLOUT_PERSISTENT", raising=False)
+        res[tag] = _gpu_rollout(torch, solver, P, H, B, tau_ext, None if integ is None else integ.copy(),
+                                np.zeros((n, 18)) if obs else None)
+    a, b = res["persistent"], res["per_tick"]
+    assert np.array_equal(a["status"], b["status"])
+    for k in ("q", "v", "tau_traj") + (("integ", "r") if obs else ()):
+        assert relerr(a[k], b[k]) < 1e-10, k
+
+
 def test_rollout_vs_golden(torch_cuda, gpu_model):
     import os
     torch = torch_cuda

@@ -35,13 +35,17 @@ constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
 constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, without RS_STEP / RS_H): no force recursion, the
                             // momentum observer is updated and rhat (18 words) goes to the LDS image at WS_RHAT
 
+// The work-item id passes through an empty asm at the top of every body: inside the persistent rollout kernel the bodies
+// sit in the horizon loop, and without this every lane-derived predicate, LDS address and table index (hundreds of
+// registers' worth) is hoisted out of that loop as "invariant" and spilled.  One no-op per call elsewhere.
+#define WBC_LAUNDERED_TID(name) unsigned name = threadIdx.x; asm volatile("" : "+v"(name))
 #define WBC_ADDR_MACROS                                                                                                   \
   const size_t N = a.N;                                                                                                    \
   const unsigned N32 = (unsigned)N;                                                                                        \
   /* lane = 16*leg + (state within the wave), as in dyn_sweep_kernel */                                                    \
-  const int leg = (int)((threadIdx.x & 63) >> 4);                                                                          \
-  const size_t s_raw = EXT ? (size_t)blockIdx.x * 16 + (threadIdx.x & 15)                                                  \
-                           : ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);           \
+  const int leg = (int)((tx & 63) >> 4);                                                                          \
+  const size_t s_raw = EXT ? (size_t)blockIdx.x * 16 + (tx & 15)                                                  \
+                           : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);           \
   const bool live = s_raw < N;                                                                                             \
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);                                                                   \
   const unsigned legN = (unsigned)leg * N32;
@@ -73,11 +77,12 @@ constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, wit
 template <class T, int BLOCK, bool EXT>
 WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
+  WBC_LAUNDERED_TID(tx);
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
   __shared__ int zidx_own[EXT ? 1 : 64];
   if constexpr (!EXT) {
-    for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
-    if (threadIdx.x < 64) zidx_own[threadIdx.x] = model->zidx[threadIdx.x];
+    for (int i = tx; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
+    if (tx < 64) zidx_own[tx] = model->zidx[tx];
     __syncthreads();
   }
   const T* cst = EXT ? cst_ext : cst_own;
@@ -118,7 +123,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   }
   // joint transforms: E of joints 0 and 1 wait in LDS ([word][lane]) until the return sweep reaches them
   __shared__ T park[18][BLOCK];
-  const int ln = EXT ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int ln = EXT ? (int)(tx & 63) : (int)tx;
   M3<T> E2;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -241,6 +246,7 @@ template <class T, int MODE, int BLOCK, bool EXT>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
                             T* wsl) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
+  WBC_LAUNDERED_TID(tx);
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
   constexpr bool OBSW = (MODE & RS_OBSW) != 0;
   static_assert(!OBSW || (EXT && OBS && !STEP && !WH), "the observer role exists only inside the fused tick");
@@ -249,12 +255,12 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
   if constexpr (!EXT) {
-    for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
+    for (int i = tx; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
     __syncthreads();
   }
   const T* cst = EXT ? cst_ext : cst_own;
   WBC_ADDR_MACROS
-#define WSTV(comp, val) do { if constexpr (EXT) wsl[(comp) * 16 + (int)(threadIdx.x & 15)] = (val); else STV(a.ws, comp, val); } while (0)
+#define WSTV(comp, val) do { if constexpr (EXT) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else STV(a.ws, comp, val); } while (0)
 #define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 #define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
 
@@ -298,7 +304,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr int PW = 15 + (TWO ? 6 : 0) + (OBS ? 18 : 0);
   constexpr int PB = BASEROWS ? (OBS ? 18 : 6) : 1;
   __shared__ T park[2 * PW + PB][BLOCK];
-  const int ln = EXT ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int ln = EXT ? (int)(tx & 63) : (int)tx;
   constexpr int OFF_A = 15, OFF_O = 15 + (TWO ? 6 : 0);
 
   V3<T> omp, vp, aAp, aLp, gLp, a2Ap, a2Lp;

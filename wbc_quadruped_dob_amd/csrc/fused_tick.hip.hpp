@@ -15,6 +15,7 @@
 #include "device_types.hpp"
 #include "dyn_split.hip.hpp"
 #include "qp_group16.hip.hpp"
+#include "integrate.hip.hpp"
 
 namespace wbc {
 
@@ -59,5 +60,66 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
 }
 
 
+
+// Persistent rollout (BASELINE.json configs[4]): `horizon` dependent ticks of {tick roles as above, forward
+// dynamics + integrator} in ONE launch.  A workgroup owns its 16 states for the whole horizon, so no tick boundary ever
+// leaves the CU: per tick two workgroup barriers (M, h, Jc, tau, f visible to the integrator wave; q, v visible to the
+// next tick's producers), no launch, no HBM round trip of the workspace.  The integrator is wave 0 after its QP.
+// tau_prev / f_prev of the observer are the tau / f buffers themselves: the observer role reads them before it raises
+// its flag, the QP waves overwrite them only after both flags.
+// Measured (MI355X, observer on, horizon 20): 37.1 us per tick against 38.2 us for {fused tick + integrate} launches at
+// 1 024 rollouts, 32.1 against 34.2 at 128 -- a modest gain: with the QP, the integrator or both compiled out the tick
+// costs 17.4 / 28.4 us, i.e. every phase runs ~1.5x slower here than as its own kernel (9 000 instructions = 72 kB of
+// code executed once per tick against a 64 kB instruction cache is the suspect; not yet confirmed with counters).
+template <class T, bool OBSERVER>
+__global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+                                                                         SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,
+                                                                         int horizon) {
+  __shared__ T cst[CST_WORDS];
+  __shared__ int zidx_s[64];
+  __shared__ T wsl[WS_LDS_WORDS * 16];
+  __shared__ int ready;
+  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
+  if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
+  if (threadIdx.x == 0) ready = 0;
+  __syncthreads();
+  const int wave = (int)(threadIdx.x >> 6);
+  constexpr int NPROD = OBSERVER ? 2 : 1;
+  T* const traj0 = ia.tau_traj;
+  for (int t = 0; t < horizon; ++t) {
+    // The batch size is laundered through an empty asm once per tick: every per-lane address in the role bodies derives
+    // from it, so none of that (tick-invariant) address arithmetic is hoisted out of the horizon loop -- hoisted, it
+    // occupied ~250 registers for the whole kernel and spilled 1-2 kB per lane.
+    unsigned long long n_tick = a.N;
+    asm volatile("" : "+s"(n_tick) : : "memory");
+    SweepArgs<T> at = a;
+    QpArgs<T> qat = qa;
+    IntegrateArgs<T> iat = ia;
+    at.N = qat.N = iat.N = (size_t)n_tick;
+    if (wave == 4) {
+      rnea_step_body<T, RS_STEP | RS_H, 64, true>(model, prm, at, cst, wsl);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (wave == 5) {
+      mass_jac_body<T, 64, true>(model, at, cst, zidx_s);
+    } else if (OBSERVER && wave == 6) {
+      if constexpr (OBSERVER) {
+        rnea_step_body<T, RS_OBS | RS_OBSW, 64, true>(model, prm, at, cst, wsl);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {
+      while (__hip_atomic_load(&ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NPROD * (t + 1)) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl);
+    }
+    __syncthreads();   // M, h, Jc (waves 4, 5) and tau, f (waves 0..3) are visible to the whole workgroup
+    if (wave == 0) {
+      iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
+      integrate_body<T>(model, iat);
+    }
+    __syncthreads();   // q, v of the next tick
+  }
+}
 
 }  // namespace wbc

@@ -25,12 +25,15 @@ template <class T> struct IntegrateArgs {
   T dt;
 };
 
+// (also called as one wavefront of the persistent rollout kernel, fused_tick.hip.hpp: same mapping, no LDS, no barrier)
 template <class T>
-__global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __restrict__ model, IntegrateArgs<T> a) {
+WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a) {
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
-  const int leg = (int)((threadIdx.x & 63) >> 4);
-  const size_t s_raw = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  unsigned tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
+  const int leg = (int)((tx & 63) >> 4);
+  const size_t s_raw = (size_t)blockIdx.x * 16 + (tx & 15);
   const bool live = s_raw < N;
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
   const unsigned legN = (unsigned)leg * N32;
@@ -81,12 +84,7 @@ __global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __rest
     A[0][0] = c00 * idet; A[0][1] = A[1][0] = c01 * idet; A[0][2] = A[2][0] = c02 * idet;
     A[1][1] = c11 * idet; A[1][2] = A[2][1] = c12 * idet; A[2][2] = c22 * idet;
   }
-  // W = Mb A (6x3); Schur contribution W Mb^T (sym 6x6) and W rl (6)
-  T W[6][3];
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) W[r][k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
+  // W = Mb A (6x3), one row at a time: Schur contribution W Mb^T (sym 6x6) and W rl (6)
   // ---- base system S vb' = rb,  S = Mbb - sum W Mb^T,  rb = rhs_b - sum W rl
   T S[6][6], rb[6];
   {
@@ -94,11 +92,14 @@ __global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __rest
     const T own[6] = {fl.x, fl.y, fl.z, mo.x, mo.y, mo.z};
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const T part = own[r] - (W[r][0] * rl[0] + W[r][1] * rl[1] + W[r][2] * rl[2]);
+      T Wr[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Wr[k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
+      const T part = own[r] - (Wr[0] * rl[0] + Wr[1] * rl[1] + Wr[2] * rl[2]);
       rb[r] = xrow_sum(part) - LDU(a.h, r) + (a.tau_ext ? LDU(a.tau_ext, r) : (T)0);
 #pragma unroll
       for (int c = r; c < 6; ++c) {
-        const T sc = W[r][0] * Mb[c][0] + W[r][1] * Mb[c][1] + W[r][2] * Mb[c][2];
+        const T sc = Wr[0] * Mb[c][0] + Wr[1] * Mb[c][1] + Wr[2] * Mb[c][2];
         S[r][c] = LDU(a.M, midx18(r, c)) - xrow_sum(sc);
       }
     }
@@ -195,6 +196,11 @@ __global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __rest
 #undef LDL
 #undef LDV
 #undef LDU
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void integrate_kernel(const DevModel<T>* __restrict__ model, IntegrateArgs<T> a) {
+  integrate_body<T>(model, a);
 }
 
 }  // namespace wbc

@@ -79,7 +79,7 @@ template <class T> WBC_DEV bool gargmin(T& v, int& id) {
   return k < (T)(K::BIG * (T)0.5);
 }
 // read from a run-time lane of my own row
-template <class T> WBC_DEV T gread(T x, int lane16) { return __shfl(x, (int)((threadIdx.x & 48) | lane16)); }
+template <class T> WBC_DEV T gread(T x, int lane16, int rowbase) { return __shfl(x, rowbase | lane16); }
 
 WBC_DEV double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -128,28 +128,31 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   static_assert(!REGROUP || WPB == 4, "re-dealing needs the 16 rows of a 4-wave workgroup");
   static_assert(!WSLDS || (WPB == 4 && !REGROUP), "the fused tick pairs one sweep wavefront with four QP wavefronts");
   __shared__ G16Lds<T> lds_all[WPB];
-  const int lane = threadIdx.x & 63;
+  unsigned tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
+  const int lane = tx & 63;
   const int l16 = lane & 15;
+  const int rowbase = lane & 48;   // first lane of my 16-lane row
   const int grp = lane >> 4;
   const int f = l16 >> 2, c3 = l16 & 3;
   const bool isvar = c3 < 3;
   const int v = 3 * f + (isvar ? c3 : 0);  // variable index of this lane (spare lanes: unused)
-  T* J0 = lds_all[threadIdx.x >> 6].J0[grp];
-  T* Rl = lds_all[threadIdx.x >> 6].R[grp] + l16;  // my row of R: Rl[16 * position]
-  T* Cl = lds_all[threadIdx.x >> 6].C[grp];        // constraint rows by id
+  T* J0 = lds_all[tx >> 6].J0[grp];
+  T* Rl = lds_all[tx >> 6].R[grp] + l16;  // my row of R: Rl[16 * position]
+  T* Cl = lds_all[tx >> 6].C[grp];        // constraint rows by id
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   // XCD-aware order for one-wave workgroups: workgroups b, b+8, b+16, b+24 land on the same XCD (round-robin dispatch)
   // and take four CONSECUTIVE 4-state groups = one whole 128-byte line per component row.  Speed only.
   size_t wg = blockIdx.x;
   if (WPB == 1 && (gridDim.x & 31) == 0) wg = (wg & ~(size_t)31) + ((wg & 7) << 2) + ((wg >> 3) & 3);
-  const size_t qp_raw = WSLDS ? (size_t)blockIdx.x * 16 + (threadIdx.x >> 4)   // fused tick: QP wavefronts are threads 0..255 of a larger workgroup
-                              : (wg * blockDim.x + threadIdx.x) >> 4;
+  const size_t qp_raw = WSLDS ? (size_t)blockIdx.x * 16 + (tx >> 4)   // fused tick: QP wavefronts are threads 0..255 of a larger workgroup
+                              : (wg * blockDim.x + tx) >> 4;
   bool live = qp_raw < N;
   unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
   const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
 #define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
-#define WSLD(comp) (WSLDS ? wsl[(comp) * 16 + (int)(threadIdx.x >> 4)] : GLD(a.ws, comp))
+#define WSLD(comp) (WSLDS ? wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
 #define GST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
 
 #ifdef WBC_QP_STAMP
@@ -271,7 +274,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     __shared__ int rg_key[16];
     __shared__ T rg_x[16][16];
     __shared__ int rg_i[16][2];
-    const int slot = (int)(threadIdx.x >> 4);  // my row among the 16 of the workgroup
+    const int slot = (int)(tx >> 4);  // my row among the 16 of the workgroup
     // violated constraints at the unconstrained minimum
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     const T sA0 = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA, sB0 = cBx * xq0 + cBy * xq1 + cBz * xq2;
@@ -476,13 +479,13 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     const bool dropg = go && !full;
     if (__ballot(dropg) != 0ull) {
       const int kq = dropg ? kmin : 0;
-      const int cid = gread(Aid, (kq + kq / 3) & 15);
+      const int cid = gread(Aid, (kq + kq / 3) & 15, rowbase);
       if (dropg && l16 == ((cid >> 1) & 15)) { if (cid & 1) actB = false; else actA = false; }
       // shift multipliers and ids down over the hole (positions kq+1..iq-1 move to kq..iq-2)
       {
         const int nxt = v + 1;
-        const T un = gread(u_me, (nxt + nxt / 3) & 15);
-        const int An = gread(Aid, (nxt + nxt / 3) & 15);
+        const T un = gread(u_me, (nxt + nxt / 3) & 15, rowbase);
+        const int An = gread(Aid, (nxt + nxt / 3) & 15, rowbase);
         if (dropg && isvar && v >= kq && v < iq - 1) { u_me = un; Aid = An; }
         if (dropg && isvar && v == iq - 1) { u_me = 0; Aid = -1; }
       }
@@ -498,7 +501,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
       for (int p = 0; p < 11; ++p) {
         const bool rg = dropg && p < iq;
         if (__ballot(rg) == 0ull) break;
-        const int idp = gread(Aid, (p + p / 3) & 15);
+        const int idp = gread(Aid, (p + p / 3) & 15, rowbase);
         const int idc = rg ? idp : 0;
         T m0, m1, m2;
         normal_of(idc, m0, m1, m2);
@@ -511,7 +514,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
       {  // a partial step moved x: refresh the candidate's slack (cross-lane ops stay unconditional)
         T sA, sB;
         slacks(sA, sB);
-        const T sv = gread((ipc & 1) ? sB : sA, lp);
+        const T sv = gread((ipc & 1) ? sB : sA, lp, rowbase);
         if (dropg && !dual_only) sip = sv;
       }
     }

@@ -49,6 +49,7 @@ struct wbc_solver {
   bool qp_regroup = false;  // env WBC_QP_REGROUP=1 with WBC_QP_WPB=4: re-deal the 16 QPs of a workgroup by predicted work (A/B; measured: no gain)
   int sweep_mode = 1; // 1 = fused dyn_sweep (default), 0 = split (mass_jac on a second stream || rnea_step -> QP); env WBC_SWEEP=split
                       // measured on MI355X: split is 5-20 % slower (two kernels pay the fixed latencies twice), kept for A/B
+  bool rollout_persistent = true;  // wbc_rollout_batch of at most fused_max states: the whole horizon in one launch; env WBC_ROLLOUT_PERSISTENT=0 disables
   size_t fused_max = 4096;  // observer-off ticks of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -272,6 +273,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (const char* e = std::getenv("WBC_QP_KERNEL")) s->qp_kernel = (std::strcmp(e, "wave") == 0) ? 1 : 0;
   if (const char* e = std::getenv("WBC_QP_WPB")) s->qp_wpb = (std::strcmp(e, "4") == 0) ? 4 : 1;
   if (const char* e = std::getenv("WBC_QP_REGROUP")) s->qp_regroup = (std::strcmp(e, "1") == 0);
+  if (const char* e = std::getenv("WBC_ROLLOUT_PERSISTENT")) s->rollout_persistent = std::strcmp(e, "0") != 0;
   if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
@@ -621,12 +623,55 @@ extern "C" int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, co
                              : integrate_impl<float>(s, N, q, v, M, h, Jc, tau, f, tau_ext, nullptr, st);
 }
 
+// small batches: the whole horizon in ONE launch (rollout_kernel, fused_tick.hip.hpp)
+template <class T>
+static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
+                              const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, hipStream_t st) {
+  SweepArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.N = N; a.q = (const T*)in->q; a.v = (const T*)in->v;
+  a.M = (T*)out->M; a.h = (T*)out->h; a.Jc = (T*)out->Jc; a.pf = (T*)out->pf;
+  a.w_des = (const T*)in->w_des; a.vdot_des = (const T*)in->vdot_des;
+  a.tau_prev = (const T*)out->tau; a.f_prev = (const T*)out->f;
+  a.obs_integ = obs ? (T*)obs->integ : nullptr; a.obs_r = obs ? (T*)obs->r : nullptr;
+  a.ws = (T*)s->d_ws;
+  QpArgs<T> qa;
+  qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
+  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
+  IntegrateArgs<T> ia;
+  ia.N = N; ia.q = (T*)in->q; ia.v = (T*)in->v; ia.M = (const T*)out->M; ia.h = (const T*)out->h; ia.Jc = (const T*)out->Jc;
+  ia.tau = (const T*)out->tau; ia.f = (const T*)out->f; ia.tau_ext = (const T*)tau_ext; ia.tau_traj = (T*)tau_traj;
+  ia.dt = (T)s->params.dt;
+  const unsigned blocks = (unsigned)((N + 15) / 16);
+  if (s->params.observer_order > 0)
+    hipLaunchKernelGGL((rollout_kernel<T, true>), dim3(blocks), dim3(448), 0, st, (const DevModel<T>*)s->d_model,
+                       to_dev_params<T>(s->params), a, qa, s->jmap, ia, horizon);
+  else
+    hipLaunchKernelGGL((rollout_kernel<T, false>), dim3(blocks), dim3(384), 0, st, (const DevModel<T>*)s->d_model,
+                       to_dev_params<T>(s->params), a, qa, s->jmap, ia, horizon);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
+  return WBC_OK;
+}
+
 extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                                  const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, void* stream) {
   if (!s || !in || !out) return fail(WBC_E_INVALID, "null argument");
   if (horizon < 1) return fail(WBC_E_INVALID, "horizon must be >= 1");
   if (!out->M || !out->h || !out->Jc) return fail(WBC_E_INVALID, "rollouts need the M, h, Jc buffers (forward dynamics reads them)");
   if (s->sweep_mode == 0) return fail(WBC_E_INVALID, "rollouts need the fused sweep (unset WBC_SWEEP=split)");
+  if (N > 0 && N <= s->fused_max && s->rollout_persistent && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1) {
+    if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
+    if (!in->q || !in->v || !in->w_des || !in->vdot_des || !in->normals || !in->mu || !in->mask)
+      return fail(WBC_E_INVALID, "null input buffer");
+    if (!out->tau || !out->f || !out->status) return fail(WBC_E_INVALID, "null output buffer");
+    if (s->params.observer_order > 0 && (!obs || !obs->integ || !obs->r))
+      return fail(WBC_E_INVALID, "observer on: observer state buffers required");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st0 = (hipStream_t)stream;
+    return s->dtype == WBC_F64 ? rollout_persistent<double>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0)
+                               : rollout_persistent<float>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0);
+  }
   wbc_batch_in tick = *in;
   tick.tau_prev = out->tau;  // the previous tick's outputs are this tick's tau_prev / f_prev: the sweep reads them
   tick.f_prev = out->f;      // before the QP kernel of the same tick overwrites them
