@@ -69,8 +69,11 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
 // its flag, the QP waves overwrite them only after both flags.
 // Measured (MI355X, observer on, horizon 20): 37.1 us per tick against 38.2 us for {fused tick + integrate} launches at
 // 1 024 rollouts, 32.1 against 34.2 at 128 -- a modest gain: with the QP, the integrator or both compiled out the tick
-// costs 17.4 / 28.4 us, i.e. every phase runs ~1.5x slower here than as its own kernel (9 000 instructions = 72 kB of
-// code executed once per tick against a 64 kB instruction cache is the suspect; not yet confirmed with counters).
+// costs 17.4 / 28.4 us: front ~8.7, QP ~19.7, integrator + barrier ~8.7 us -- about what the stand-alone kernels take.
+// Back-to-back launches on one stream cost far less than their nominal 2-3 us each, so removing them buys little; what a
+// tick is made of is ~6 dependent trips through L2 (state loads, table-indexed joint loads, store acks at the two
+// barriers) around the arithmetic.  PMC (tools/icache_profile.sh): instruction-cache hit rate 99.7 %, same misses per
+// tick as the per-tick launches -- code size (72 kB) is not the limiter.
 template <class T, bool OBSERVER>
 __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,

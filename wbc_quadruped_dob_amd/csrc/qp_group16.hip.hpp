@@ -81,10 +81,15 @@ template <class T> WBC_DEV bool gargmin(T& v, int& id) {
 // read from a run-time lane of my own row
 template <class T> WBC_DEV T gread(T x, int lane16, int rowbase) { return __shfl(x, rowbase | lane16); }
 
+#ifndef WBC_NR_STEPS
+#define WBC_NR_STEPS 2   // Newton steps after v_rsq_f64 / v_rcp_f64 (2^-23 relative): 2 -> full double
+#endif
 WBC_DEV double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
   double e = fma(-x * y, y, 1.0); y = fma(0.5 * y, e, y);
+#if WBC_NR_STEPS > 1
   e = fma(-x * y, y, 1.0); y = fma(0.5 * y, e, y);
+#endif
   return y;
 }
 WBC_DEV float rsqrt_nr(float x) {
@@ -95,7 +100,9 @@ WBC_DEV float rsqrt_nr(float x) {
 WBC_DEV double rcp_nr(double x) {
   double y = __builtin_amdgcn_rcp(x);
   double e = fma(-x, y, 1.0); y = fma(y, e, y);
+#if WBC_NR_STEPS > 1
   e = fma(-x, y, 1.0); y = fma(y, e, y);
+#endif
   return y;
 }
 WBC_DEV float rcp_nr(float x) {
