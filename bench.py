@@ -320,7 +320,7 @@ def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):
     for _ in range(20):
         tick()
     torch.cuda.synchronize()
-    wall, qpk, dynk = [], [], []
+    wall, qpk, dynk, fusk = [], [], [], []
     for _ in range(1000):                      # host-observed latency, no instrumentation in the way
         t0 = time.perf_counter()
         tick()
@@ -333,11 +333,17 @@ def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):
         tm = solver.collect_timing()
         qpk.append(tm["qp_ms"])
         dynk.append(tm["dyn_ms"] + tm["rnea_ms"])
+        fusk.append(tm.get("fused_ms", 0.0))
     solver.enable_timing(0)
+    fused = float(np.median(fusk)) > 0
     return {"ticks": 1000, "tick_p50_us": float(np.median(wall)) * 1e6, "tick_p99_us": float(np.percentile(wall, 99)) * 1e6,
-            "qp_kernel_p50_us": float(np.median(qpk)) * 1e3, "front_kernel_p50_us": float(np.median(dynk)) * 1e3,
-            "note": "N=1 per launch, synchronous wbc_step_batch without M/h/Jc outputs (rnea_step -> qp); tick = host wall "
-                    "time incl. two launches + stream sync; kernel spans are raw HIP-event spans over 200 further ticks"}
+            "tick_kernel_p50_us": float(np.median(fusk)) * 1e3 if fused else None,
+            "qp_kernel_p50_us": None if fused else float(np.median(qpk)) * 1e3,
+            "front_kernel_p50_us": None if fused else float(np.median(dynk)) * 1e3,
+            "note": "N=1 per launch, synchronous wbc_step_batch without M/h/Jc outputs (%s); tick = host wall time incl. launch + "
+                    "stream sync; kernel spans are raw HIP-event spans over 200 further ticks; the GRF QP alone as its own kernel "
+                    "at N=1 takes 6.3 us (WBC_FUSED_MAX=0)" % ("one fused launch: rnea_step and qp_group16 as wavefront roles"
+                                                              if fused else "rnea_step -> qp")}
 
 
 def sweep_alone_roofline(solver, torch, inp, n, dtype, ts):

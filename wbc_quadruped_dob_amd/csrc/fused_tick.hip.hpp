@@ -28,7 +28,8 @@ namespace wbc {
 // OBSERVER on: a seventh wavefront takes the observer role (rnea_step_body<RS_OBS | RS_OBSW>: velocities, momenta,
 // gravity terms, beta = C^T v - g, the update of {integ, r}) and leaves rhat in LDS; the QP waves wait for both producers
 // and subtract rhat from b and tau_partial themselves.
-template <class T, bool OBSERVER>
+// MATS = false (the caller wants tau, f only): no mass_jac role, and the rnea role runs the single merged force chain.
+template <class T, bool OBSERVER, bool MATS>
 __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   __shared__ T cst[CST_WORDS];
@@ -41,11 +42,11 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   if (wave == 4) {
-    rnea_step_body<T, RS_STEP | RS_H, 64, true>(model, prm, a, cst, wsl);
+    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, true>(model, prm, a, cst, wsl);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
   } else if (wave == 5) {
-    mass_jac_body<T, 64, true>(model, a, cst, zidx_s);
+    if constexpr (MATS) mass_jac_body<T, 64, true>(model, a, cst, zidx_s);
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
       rnea_step_body<T, RS_OBS | RS_OBSW, 64, true>(model, prm, a, cst, wsl);

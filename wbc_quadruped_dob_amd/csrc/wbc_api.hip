@@ -518,17 +518,18 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
-  if (mats && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 && N <= s->fused_max) {
-    // small batch, observer off: one launch, 16 states per workgroup, rnea_step | mass_jac | QP as wavefront roles and
-    // the workspace through LDS (fused_tick.hip.hpp)
+  if ((mats || !out->pf) && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 && N <= s->fused_max) {
+    // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
+    // workspace through LDS (fused_tick.hip.hpp)
     rc = span_begin(s, 3, st);
     if (rc) return rc;
-    if (ob)
-      hipLaunchKernelGGL((fused_tick_kernel<T, true>), dim3((unsigned)((N + 15) / 16)), dim3(448), 0, st,
-                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a, qa, s->jmap);
-    else
-      hipLaunchKernelGGL((fused_tick_kernel<T, false>), dim3((unsigned)((N + 15) / 16)), dim3(384), 0, st,
-                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a, qa, s->jmap);
+    const dim3 grid((unsigned)((N + 15) / 16));
+    const DevModel<T>* dm = (const DevModel<T>*)s->d_model;
+    const DevParams<T> dp = to_dev_params<T>(s->params);
+    if (ob && mats) hipLaunchKernelGGL((fused_tick_kernel<T, true, true>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
+    else if (ob) hipLaunchKernelGGL((fused_tick_kernel<T, true, false>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
+    else if (mats) hipLaunchKernelGGL((fused_tick_kernel<T, false, true>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
+    else hipLaunchKernelGGL((fused_tick_kernel<T, false, false>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(WBC_E_HIP, std::string("fused tick launch: ") + hipGetErrorString(e));
     return span_end(s, st);
