@@ -72,15 +72,17 @@ constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, wit
 // ======================================================================================================================
 // mass_jac_kernel: M(q) by CRBA, Jc(q), pf(q).  No velocities anywhere.
 // ======================================================================================================================
-// EXT (fused_tick.hip.hpp): the body is ONE wavefront of a larger workgroup that owns 16 states; the constant tables
-// were staged by the whole workgroup (cst_ext, zidx_ext) and the body contains no barrier.
-template <class T, int BLOCK, bool EXT>
+// EXT != 0 (fused_tick.hip.hpp): the body is ONE wavefront of a larger workgroup that owns 16 states and the constant
+// tables are staged by other wavefronts of the workgroup (cst_ext, zidx_ext).  EXT = 1: they are complete on entry, the
+// body contains no barrier.  EXT = 2: the body issues its state loads first and THEN joins the workgroup barrier behind
+// which the tables are complete (one memory round trip instead of two at the head of the tick).
+template <class T, int BLOCK, int EXT>
 WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   WBC_LAUNDERED_TID(tx);
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
   __shared__ int zidx_own[EXT ? 1 : 64];
-  if constexpr (!EXT) {
+  if constexpr (EXT == 0) {
     for (int i = tx; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
     if (tx < 64) zidx_own[tx] = model->zidx[tx];
     __syncthreads();
@@ -99,6 +101,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   T ql[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) ql[k] = LDX(a.q, 7, jxN[k]);
+  if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
 
   // structural zeros / ones first: they drain while the sweeps compute
   {
@@ -234,7 +237,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
 
 template <class T, int BLOCK>
 __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const DevModel<T>* __restrict__ model, SweepArgs<T> a) {
-  mass_jac_body<T, BLOCK, false>(model, a, nullptr, nullptr);
+  mass_jac_body<T, BLOCK, 0>(model, a, nullptr, nullptr);
 }
 
 // ======================================================================================================================
@@ -242,25 +245,25 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
 // recursion, foot geometry for the QP, momentum observer.
 // ======================================================================================================================
 // EXT: as for mass_jac_body; additionally the step workspace goes to the workgroup's LDS image wsl[word][16].
-template <class T, int MODE, int BLOCK, bool EXT>
+template <class T, int MODE, int BLOCK, int EXT>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
                             T* wsl) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   WBC_LAUNDERED_TID(tx);
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
   constexpr bool OBSW = (MODE & RS_OBSW) != 0;
-  static_assert(!OBSW || (EXT && OBS && !STEP && !WH), "the observer role exists only inside the fused tick");
+  static_assert(!OBSW || (EXT != 0 && OBS && !STEP && !WH), "the observer role exists only inside the fused tick");
   constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
   constexpr bool TWO = STEP && WH;              // h and tau_partial both wanted: two force chains; else one (merged)
   constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
-  if constexpr (!EXT) {
+  if constexpr (EXT == 0) {
     for (int i = tx; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
     __syncthreads();
   }
   const T* cst = EXT ? cst_ext : cst_own;
   WBC_ADDR_MACROS
-#define WSTV(comp, val) do { if constexpr (EXT) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else STV(a.ws, comp, val); } while (0)
+#define WSTV(comp, val) do { if constexpr (EXT != 0) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else STV(a.ws, comp, val); } while (0)
 #define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 #define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
 
@@ -282,6 +285,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 #pragma unroll
     for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
   }
+  if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
   if (STEP && !OBS) {  // observer off: the QP target wrench is just w_des
     T b[6];
 #pragma unroll
@@ -581,7 +585,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 template <class T, int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a) {
-  rnea_step_body<T, MODE, BLOCK, false>(model, prm, a, nullptr, nullptr);
+  rnea_step_body<T, MODE, BLOCK, 0>(model, prm, a, nullptr, nullptr);
 }
 
 #undef MAKE_R

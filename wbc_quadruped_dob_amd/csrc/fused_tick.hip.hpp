@@ -36,31 +36,32 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready;
-  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
-  if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) ready = 0;
-  __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
+  // The four QP wavefronts stage the tables; the producers issue their state loads first and join the ONE workgroup
+  // barrier from inside their bodies (EXT = 2), so table staging and state loads share a memory round trip.
   if (wave == 4) {
-    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, true>(model, prm, a, cst, wsl);
+    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
   } else if (wave == 5) {
-    if constexpr (MATS) mass_jac_body<T, 64, true>(model, a, cst, zidx_s);
+    if constexpr (MATS) mass_jac_body<T, 64, 2>(model, a, cst, zidx_s);
+    else __syncthreads();
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
-      rnea_step_body<T, RS_OBS | RS_OBSW, 64, true>(model, prm, a, cst, wsl);
+      rnea_step_body<T, RS_OBS | RS_OBSW, 64, 2>(model, prm, a, cst, wsl);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   } else {
+    for (int i = threadIdx.x; i < CST_WORDS; i += 256) cst[i] = model->cst[i];
+    if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
+    if (threadIdx.x == 0) ready = 0;
+    __syncthreads();
     while (__hip_atomic_load(&ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (OBSERVER ? 2 : 1)) __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl);
   }
 }
-
-
 
 // Persistent rollout (BASELINE.json configs[4]): `horizon` dependent ticks of {tick roles as above, forward
 // dynamics + integrator} in ONE launch.  A workgroup owns its 16 states for the whole horizon, so no tick boundary ever
@@ -101,14 +102,14 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void rollout_kernel(const 
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
     if (wave == 4) {
-      rnea_step_body<T, RS_STEP | RS_H, 64, true>(model, prm, at, cst, wsl);
+      rnea_step_body<T, RS_STEP | RS_H, 64, 1>(model, prm, at, cst, wsl);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wave == 5) {
-      mass_jac_body<T, 64, true>(model, at, cst, zidx_s);
+      mass_jac_body<T, 64, 1>(model, at, cst, zidx_s);
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {
-        rnea_step_body<T, RS_OBS | RS_OBSW, 64, true>(model, prm, at, cst, wsl);
+        rnea_step_body<T, RS_OBS | RS_OBSW, 64, 1>(model, prm, at, cst, wsl);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
