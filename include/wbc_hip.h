@@ -204,7 +204,7 @@ int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launches[4]);
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void);
+int wbc_abi_version(void); /* 2 */
 
 #ifdef __cplusplus
 }

@@ -871,4 +871,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 1; }
+extern "C" int wbc_abi_version(void) { return 2; }  // 2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points
