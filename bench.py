@@ -151,9 +151,12 @@ def main():
         dyn_s = (tm["fused_ms"] * 1e-3 / tm["fused_launches"]) if fused else tm["dyn_ms"] * 1e-3 / max(1, tm["dyn_launches"])
         qp_s = tm["qp_ms"] * 1e-3 / max(1, tm["qp_launches"])
         rnea_s = tm["rnea_ms"] * 1e-3 / max(1, tm["rnea_launches"])
-        words = dyn_words(split)
+        # algorithmic words per state of the timed launch: the dynamics stage alone is 443 (in q 19 + v 18,
+        # out M 171 + h 18 + Jc 216, + 1); the fused tick launch does the WHOLE tick: in 78 (q, v, w_des, vdot_des, normals,
+        # mu, mask) + out 24 (tau, f) + M/h/Jc 405 = 507; observer on adds 60 in (state, tau_prev, f_prev) + 36 out = 603
+        words = (507 + (96 if obs else 0) - (0 if want_mats else 405)) if fused else dyn_words(split)
         dyn_bytes = words * ts * n
-        achieved = dyn_bytes / dyn_s / 1e9 if (want_mats and dyn_s > 0) else None
+        achieved = dyn_bytes / dyn_s / 1e9 if ((want_mats or fused) and dyn_s > 0) else None
         res = {
             "metric": "WBC control-steps/sec (batched DogBot)",
             "value": args.steps * n * world / elapsed,
@@ -184,9 +187,9 @@ def main():
                          "note": ("HIP events on the launch stream around every %d-th tick of the timed region; raw span "
                                   "(includes the event-pair overhead reported beside it)" % sample) +
                                  ("; at this batch the whole tick is ONE launch (dynamics + GRF QP as wavefront roles of a "
-                                  "workgroup, latency-bound: one workgroup per CU), so `achieved` = the dynamics stage's 443 words/"
-                                  "state over a duration that also contains the QP -- see roofline_dyn_sweep_alone for the sweep "
-                                  "kernel by itself at this batch and roofline_large_batch for the HBM-bound regime" if fused else "")},
+                                  "workgroup, latency-bound: one workgroup per CU), so `achieved` = the algorithmic bytes of the whole tick "
+                                  "(inputs + tau, f + M, h, Jc) over that launch -- see roofline_dyn_sweep_alone for the 443-word "
+                                  "sweep kernel by itself at this batch and roofline_large_batch for the HBM-bound regime" if fused else "")},
             "kernels": {"dyn_sweep_us": None if fused else dyn_s * 1e6, "fused_tick_us": dyn_s * 1e6 if fused else None,
                         "rnea_step_us": rnea_s * 1e6 if tm["rnea_launches"] else None,
                         "qp_us": None if fused else qp_s * 1e6,

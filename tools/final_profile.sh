@@ -19,7 +19,8 @@ python bench.py --config 5 --steps 100 --warmup 10 --batch 128 > "$O/bench_cfg5_
 python bench.py --config 5 --tracking --steps 100 --warmup 10 > "$O/bench_cfg5_tracking_h20_n1024.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 20 --warmup 3 --batch 32768 > "$O/bench_cfg5_h20_n32768.json" 2>> "$O/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- python3 "$R/bench.py" --config 5 --tracking --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- python3 "$R/bench.py" --config 5 --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5trk -- python3 "$R/bench.py" --config 5 --tracking --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
 find "$O" -name "*kernel_trace.csv" -delete
