@@ -65,31 +65,35 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
 
 // Persistent rollout (BASELINE.json configs[4]): `horizon` dependent ticks of {tick roles as above, forward
 // dynamics + integrator} in ONE launch.  A workgroup owns its 16 states for the whole horizon, so no tick boundary ever
-// leaves the CU: per tick two workgroup barriers (M, h, Jc, tau, f visible to the integrator wave; q, v visible to the
-// next tick's producers), no launch, no HBM round trip of the workspace.  The integrator is wave 0 after its QP.
+// leaves the CU: per tick two workgroup barriers (tau, f, h visible to the integrator wave; q, v visible to the next
+// tick's producers), no launch, no HBM round trip of the workspace.  The integrator is its own wavefront: it factors the
+// arrow matrix beside the QP (that needs only M, Jc, published by the mass_jac role through a flag) and finishes the
+// right-hand sides, solves and state update between the two barriers.
 // tau_prev / f_prev of the observer are the tau / f buffers themselves: the observer role reads them before it raises
 // its flag, the QP waves overwrite them only after both flags.
-// Measured (MI355X, observer on, horizon 20): 37.1 us per tick against 38.2 us for {fused tick + integrate} launches at
-// 1 024 rollouts, 32.1 against 34.2 at 128 -- a modest gain: with the QP, the integrator or both compiled out the tick
-// costs 17.4 / 28.4 us: front ~8.7, QP ~19.7, integrator + barrier ~8.7 us -- about what the stand-alone kernels take.
+// Measured (MI355X, observer on, horizon 20): 33.7 us per tick against 37.2 us for {fused tick + integrate} launches at
+// 1 024 rollouts, 28.6 against 32.8 at 128.  History: with the integrator as "wave 0 after its QP" the tick cost 37.1 us
+// -- with the QP, the integrator or both compiled out 17.4 / 28.4 us, i.e. front ~8.7, QP ~19.7, integrator + barrier
+// ~8.7 us, about what the stand-alone kernels take; moving the factorisation beside the QP removed ~3.5 us of that.
 // Back-to-back launches on one stream cost far less than their nominal 2-3 us each, so removing them buys little; what a
 // tick is made of is ~6 dependent trips through L2 (state loads, table-indexed joint loads, store acks at the two
 // barriers) around the arithmetic.  PMC (tools/icache_profile.sh): instruction-cache hit rate 99.7 %, same misses per
 // tick as the per-tick launches -- code size (72 kB) is not the limiter.
 template <class T, bool OBSERVER>
-__global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+__global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,
                                                                          int horizon) {
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready;
+  __shared__ int ready, mready;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) ready = 0;
+  if (threadIdx.x == 0) { ready = 0; mready = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   constexpr int NPROD = OBSERVER ? 2 : 1;
+  constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
   T* const traj0 = ia.tau_traj;
   for (int t = 0; t < horizon; ++t) {
     // The batch size is laundered through an empty asm once per tick: every per-lane address in the role bodies derives
@@ -101,12 +105,24 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void rollout_kernel(const 
     QpArgs<T> qat = qa;
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
+    if (wave == WINT) {
+      // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has published them
+      // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
+      while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
+      integrate_body<T>(model, iat, [] __device__() { __syncthreads(); });   // <- barrier A inside
+      __syncthreads();                                                       // barrier B: q, v of the next tick
+      continue;
+    }
     if (wave == 4) {
       rnea_step_body<T, RS_STEP | RS_H, 64, 1>(model, prm, at, cst, wsl);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wave == 5) {
       mass_jac_body<T, 64, 1>(model, at, cst, zidx_s);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // M, Jc are in L2 (waits for my stores) ...
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&mready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {
         rnea_step_body<T, RS_OBS | RS_OBSW, 64, 1>(model, prm, at, cst, wsl);
@@ -118,12 +134,8 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void rollout_kernel(const 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl);
     }
-    __syncthreads();   // M, h, Jc (waves 4, 5) and tau, f (waves 0..3) are visible to the whole workgroup
-    if (wave == 0) {
-      iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
-      integrate_body<T>(model, iat);
-    }
-    __syncthreads();   // q, v of the next tick
+    __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator
+    __syncthreads();   // barrier B: q, v of the next tick
   }
 }
 

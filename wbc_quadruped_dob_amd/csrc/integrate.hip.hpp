@@ -25,9 +25,13 @@ template <class T> struct IntegrateArgs {
   T dt;
 };
 
-// (also called as one wavefront of the persistent rollout kernel, fused_tick.hip.hpp: same mapping, no LDS, no barrier)
-template <class T>
-WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a) {
+// (also called as one wavefront of the persistent rollout kernel, fused_tick.hip.hpp: same mapping, no LDS.)
+// Two phases.  Phase 1 needs only M and Jc: the leg blocks' inverses, the base Schur complement and its Cholesky factor.
+// `between()` runs after it (nothing in the stand-alone kernel; the tick barrier in the rollout kernel, where phase 1
+// overlaps the QP).  Phase 2 needs tau, f, h, q, v: right-hand sides, the two triangular solves, the state update.
+struct IntegrateNoWait { WBC_DEV void operator()() const {} };
+template <class T, class Between = IntegrateNoWait>
+WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between()) {
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   unsigned tx = threadIdx.x;
@@ -46,19 +50,14 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
   for (int k = 0; k < 3; ++k) jx[k] = model->jidx[leg][k];
 
-  // ---- my leg: rhs_l = tau_l + JcL^T f_l + tau_ext_l - h_l
-  const V3<T> fl = mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
+  // ================================================================== phase 1: M, Jc only
   // foot position relative to the base origin from the base-angular block of my foot's Jacobian rows, -[d]x
   const V3<T> dl = mk<T>(LDL(a.Jc, 18 * 1 + 5, 54), LDL(a.Jc, 18 * 2 + 3, 54), LDL(a.Jc, 18 * 0 + 4, 54));
-  T rl[3], ql[3], vl[3], taul[3];
+  T jcl[3][3];   // own-leg Jacobian block: jcl[m][k] = d pf_m / d q_(leg, k)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const unsigned jo = (unsigned)(6 + jx[k]) * N32;   // column of joint (leg, k) in rows 3*leg + m of Jc
-    const T jc0 = LDLX(a.Jc, 0, 54, jo), jc1 = LDLX(a.Jc, 18, 54, jo), jc2 = LDLX(a.Jc, 36, 54, jo);
-    taul[k] = LDV(a.tau, jx[k]);
-    rl[k] = taul[k] + jc0 * fl.x + jc1 * fl.y + jc2 * fl.z - LDV(a.h, 6 + jx[k]) + (a.tau_ext ? LDV(a.tau_ext, 6 + jx[k]) : (T)0);
-    ql[k] = LDV(a.q, 7 + jx[k]);
-    vl[k] = LDV(a.v, 6 + jx[k]);
+    jcl[0][k] = LDLX(a.Jc, 0, 54, jo); jcl[1][k] = LDLX(a.Jc, 18, 54, jo); jcl[2][k] = LDLX(a.Jc, 36, 54, jo);
   }
   // leg block (symmetric 3x3) and base-leg block (6x3) of M
   auto mi = [](int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return i * 18 - i * (i - 1) / 2 + (j - i); };
@@ -84,9 +83,53 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     A[0][0] = c00 * idet; A[0][1] = A[1][0] = c01 * idet; A[0][2] = A[2][0] = c02 * idet;
     A[1][1] = c11 * idet; A[1][2] = A[2][1] = c12 * idet; A[2][2] = c22 * idet;
   }
-  // W = Mb A (6x3), one row at a time: Schur contribution W Mb^T (sym 6x6) and W rl (6)
-  // ---- base system S vb' = rb,  S = Mbb - sum W Mb^T,  rb = rhs_b - sum W rl
-  T S[6][6], rb[6];
+  // base Schur complement S = Mbb - sum_legs W Mb^T with W = Mb A (6x3), one row of W at a time
+  T S[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    T Wr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Wr[k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      const T sc = Wr[0] * Mb[c][0] + Wr[1] * Mb[c][1] + Wr[2] * Mb[c][2];
+      S[r][c] = LDU(a.M, midx18(r, c)) - xrow_sum(sc);
+    }
+  }
+  // Cholesky of S (L[j][j] holds 1 / L_jj), in registers
+  T L[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    T d = S[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    const T inv = rsqrt_t(d);
+    L[j][j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      T sij = S[j][i];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sij -= L[i][k] * L[j][k];
+      L[i][j] = sij * inv;
+    }
+  }
+
+  between();
+
+  // ================================================================== phase 2: tau, f, h, q, v
+  // ---- my leg: rhs_l = tau_l + JcL^T f_l + tau_ext_l - h_l
+  const V3<T> fl = mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
+  T rl[3], ql[3], vl[3], taul[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    taul[k] = LDV(a.tau, jx[k]);
+    rl[k] = taul[k] + jcl[0][k] * fl.x + jcl[1][k] * fl.y + jcl[2][k] * fl.z - LDV(a.h, 6 + jx[k]) +
+            (a.tau_ext ? LDV(a.tau_ext, 6 + jx[k]) : (T)0);
+    ql[k] = LDV(a.q, 7 + jx[k]);
+    vl[k] = LDV(a.v, 6 + jx[k]);
+  }
+  // ---- base right-hand side rb = rhs_b - sum_legs W rl
+  T rb[6];
   {
     const V3<T> mo = cross(dl, fl);
     const T own[6] = {fl.x, fl.y, fl.z, mo.x, mo.y, mo.z};
@@ -97,32 +140,11 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
       for (int k = 0; k < 3; ++k) Wr[k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
       const T part = own[r] - (Wr[0] * rl[0] + Wr[1] * rl[1] + Wr[2] * rl[2]);
       rb[r] = xrow_sum(part) - LDU(a.h, r) + (a.tau_ext ? LDU(a.tau_ext, r) : (T)0);
-#pragma unroll
-      for (int c = r; c < 6; ++c) {
-        const T sc = Wr[0] * Mb[c][0] + Wr[1] * Mb[c][1] + Wr[2] * Mb[c][2];
-        S[r][c] = LDU(a.M, midx18(r, c)) - xrow_sum(sc);
-      }
     }
   }
-  // Cholesky of S (upper storage: S[r][c], r <= c holds L[c][r]) and the two triangular solves, in registers
+  // ---- the two triangular solves
   T vb[6];
   {
-    T L[6][6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      T d = S[j][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-      const T inv = rsqrt_t(d);
-      L[j][j] = inv;  // store 1/L_jj
-#pragma unroll
-      for (int i = j + 1; i < 6; ++i) {
-        T sij = S[j][i];
-#pragma unroll
-        for (int k = 0; k < j; ++k) sij -= L[i][k] * L[j][k];
-        L[i][j] = sij * inv;
-      }
-    }
     T y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {

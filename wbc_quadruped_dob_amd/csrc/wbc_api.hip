@@ -645,10 +645,10 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   ia.dt = (T)s->params.dt;
   const unsigned blocks = (unsigned)((N + 15) / 16);
   if (s->params.observer_order > 0)
-    hipLaunchKernelGGL((rollout_kernel<T, true>), dim3(blocks), dim3(448), 0, st, (const DevModel<T>*)s->d_model,
+    hipLaunchKernelGGL((rollout_kernel<T, true>), dim3(blocks), dim3(512), 0, st, (const DevModel<T>*)s->d_model,
                        to_dev_params<T>(s->params), a, qa, s->jmap, ia, horizon);
   else
-    hipLaunchKernelGGL((rollout_kernel<T, false>), dim3(blocks), dim3(384), 0, st, (const DevModel<T>*)s->d_model,
+    hipLaunchKernelGGL((rollout_kernel<T, false>), dim3(blocks), dim3(448), 0, st, (const DevModel<T>*)s->d_model,
                        to_dev_params<T>(s->params), a, qa, s->jmap, ia, horizon);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
