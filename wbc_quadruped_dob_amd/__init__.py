@@ -257,7 +257,7 @@ class Solver:
         return out
 
     def step(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None, obs_r=None,
-             out=None, want_mats=False):
+             out=None, want_mats=False, _prepared=False):
         """One control tick.  Observer state tensors are updated in place.  Returns dict(tau, f, status, iters[, M, h, Jc, pf])."""
         torch = self.torch
         m = self.model
@@ -281,8 +281,23 @@ class Solver:
         bo = _BatchOut(g("tau"), g("f"), self._ptr(out["status"], 1, N, torch.int32),
                        self._ptr(out["iters"], 1, N, torch.int32), g("M"), g("h"), g("Jc"), g("pf"))
         ob = _ObsState(self._ptr(obs_integ, m.nv, N), self._ptr(obs_r, m.nv, N))
+        if _prepared:   # prepare_step(): hand back the validated argument structs instead of launching
+            return out, (N, bi, bo, ob, (q, v, w_des, vdot_des, normals, mu, mask, tau_prev, f_prev, obs_integ, obs_r))
         _check(lib().wbc_step_batch(self._h, N, C.byref(bi), C.byref(bo), C.byref(ob), self._stream()), "wbc_step_batch")
         return out
+
+    def prepare_step(self, *args, **kw):
+        """Same arguments as step(); validates them and builds the C argument structs ONCE.  Returns (tick, out):
+        tick() launches one control tick on the current stream with nothing but the C call in it (a control loop or a
+        benchmark that reuses its buffers: ~3 us of host time per tick instead of ~15), out is step()'s dict."""
+        out, (N, bi, bo, ob, keep) = self.step(*args, _prepared=True, **kw)
+        fn, h, rbi, rbo, rob, stream_of = lib().wbc_step_batch, self._h, C.byref(bi), C.byref(bo), C.byref(ob), self._stream
+
+        def tick(_keep=(keep, bi, bo, ob, out)):   # the tensors and structs stay alive as long as the closure does
+            rc = fn(h, N, rbi, rbo, rob, stream_of())
+            if rc:
+                _check(rc, "wbc_step_batch")
+        return tick, out
 
     def integrate(self, q, v, M, h, Jc, tau, f, tau_ext=None):
         """Forward dynamics with the planned GRFs + semi-implicit Euler; q, v advance IN PLACE (one dt)."""
