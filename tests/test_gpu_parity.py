@@ -523,6 +523,31 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkey
         assert relerr(a["tau"], ref["tau"]) < TIGHT64 and relerr(a["f"], ref["f"]) < TIGHT64
 
 
+def test_prepared_tick_equals_step(torch_cuda, gpu_model):
+    """Solver.prepare_step builds the argument structs once; its tick() must do exactly what step() does."""
+    torch = torch_cuda
+    n = 777
+    solver, P = _solver(gpu_model, obs=1, max_batch=n)
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=71)
+    td = torch.float64
+    dv = lambda k: to_dev(B[k], torch, td)
+    mask = torch.from_numpy(B["mask"]).cuda()
+    args = [dv(k) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")] + [mask, dv("tau_prev"), dv("f_prev")]
+    ig0 = solver.dynamics(args[0], args[1], want=("p",))["p"]
+    ig_a, r_a, ig_b, r_b = ig0.clone(), torch.zeros_like(ig0), ig0.clone(), torch.zeros_like(ig0)
+    a = solver.step(*args, ig_a, r_a, want_mats=True)
+    tick, b = solver.prepare_step(*args, ig_b, r_b, want_mats=True)
+    tick()
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(ig_a, ig_b) and torch.equal(r_a, r_b)
+    tick()   # second tick advances the observer state again, like a second step() would
+    solver.step(*args, ig_a, r_a, out=a, want_mats=True)
+    torch.cuda.synchronize()
+    assert torch.equal(r_a, r_b) and torch.equal(a["tau"], b["tau"])
+
+
 def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle):
     """Quaternions and terrain normals are normalised inside (as in the oracle); a NaN in one state's inputs must not
     hang the kernels nor disturb any other state."""
