@@ -122,6 +122,29 @@ def test_tracking_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, 
         assert relerr(got["r"][ok], r_ref[ok]) < 1e-6
 
 
+def test_persistent_tracking_equals_per_tick_launches(torch_cuda, gpu_model, oracle, monkeypatch):
+    """Planner-in-the-loop rollouts of small batches run as ONE launch (rollout_kernel<., TRACK>: the integrator wavefront
+    runs the reference generator at the head of every tick); WBC_ROLLOUT_PERSISTENT=0 = {reference, fused tick, integrate}
+    launches per tick.  Same device functions -> equal to rounding."""
+    torch = torch_cuda
+    n, H = 777, 12
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=45)
+    plan = synth.make_plan(B, rank=45)
+    tau_ext = np.zeros((n, 18)); tau_ext[:, 0:3] = B["push"]
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    res = {}
+    for tag, env in (("persistent", None), ("per_tick", "0")):
+        if env is not None:
+            monkeypatch.setenv("WBC_ROLLOUT_PERSISTENT", env)
+        solver, P, G = _solver(gpu_model, obs=1, max_batch=n)
+        monkeypatch.delenv("WBC_ROLLOUT_PERSISTENT", raising=False)
+        res[tag] = _gpu_tracking(torch, solver, H, B, plan, tau_ext, integ.copy(), np.zeros((n, 18)))
+    a, b = res["persistent"], res["per_tick"]
+    assert np.array_equal(a["status"], b["status"])
+    for k in ("q", "v", "tau_traj", "com_traj", "integ", "r"):
+        assert relerr(a[k], b[k]) < 1e-10, k
+
+
 def test_tracking_rollout_vs_golden(torch_cuda, gpu_model):
     torch = torch_cuda
     g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_reference_v1.npz")))

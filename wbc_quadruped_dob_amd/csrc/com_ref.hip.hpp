@@ -33,16 +33,22 @@ template <class T> struct RefArgs {
   T* com;   // [6][N] or null
 };
 
-template <class T>
-__global__ __launch_bounds__(64) void com_reference_kernel(const DevModel<T>* __restrict__ model,
-                                                           const DevRefParams<T>* __restrict__ G, RefArgs<T> a) {
-  __shared__ T cst[CST_WORDS];
-  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
-  __syncthreads();
+// EXT (persistent rollout kernel, fused_tick.hip.hpp): one wavefront of a larger workgroup, tables already in LDS.
+template <class T, bool EXT>
+WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const DevRefParams<T>* __restrict__ G, const RefArgs<T>& a,
+                                const T* cst_ext) {
+  __shared__ T cst_own[EXT ? 1 : CST_WORDS];
+  if constexpr (!EXT) {
+    for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
+    __syncthreads();
+  }
+  const T* cst = EXT ? cst_ext : cst_own;
+  unsigned tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
-  const int leg = (int)((threadIdx.x & 63) >> 4);
-  const size_t s_raw = (size_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int leg = (int)((tx & 63) >> 4);
+  const size_t s_raw = (size_t)blockIdx.x * 16 + (tx & 15);
   const bool live = s_raw < N;
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
 #define RCS(i) cst[(i) * 4 + leg]
@@ -176,6 +182,12 @@ __global__ __launch_bounds__(64) void com_reference_kernel(const DevModel<T>* __
 #undef RLDV
 #undef RLDU
 #undef RCS
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void com_reference_kernel(const DevModel<T>* __restrict__ model,
+                                                           const DevRefParams<T>* __restrict__ G, RefArgs<T> a) {
+  com_reference_body<T, false>(model, G, a, nullptr);
 }
 
 }  // namespace wbc

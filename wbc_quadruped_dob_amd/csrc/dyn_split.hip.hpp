@@ -245,9 +245,12 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
 // recursion, foot geometry for the QP, momentum observer.
 // ======================================================================================================================
 // EXT: as for mass_jac_body; additionally the step workspace goes to the workgroup's LDS image wsl[word][16].
-template <class T, int MODE, int BLOCK, int EXT>
+// `before_refs()` runs after the state loads are issued and before w_des / vdot_des are read (the persistent tracking
+// rollout waits there for the planner role that writes them).
+struct NoWait { WBC_DEV void operator()() const {} };
+template <class T, int MODE, int BLOCK, int EXT, class BeforeRefs = NoWait>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
-                            T* wsl) {
+                            T* wsl, BeforeRefs before_refs = BeforeRefs()) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   WBC_LAUNDERED_TID(tx);
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
@@ -279,6 +282,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   T ql[3], vl[3], al[3] = {0, 0, 0}, ad[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 3; ++k) { ql[k] = LDX(a.q, 7, jxN[k]); vl[k] = LDX(a.v, 6, jxN[k]); }
+  before_refs();
   if (STEP) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) al[k] = LDX(a.vdot_des, 6, jxN[k]);

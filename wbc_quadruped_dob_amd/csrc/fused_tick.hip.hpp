@@ -16,6 +16,7 @@
 #include "dyn_split.hip.hpp"
 #include "qp_group16.hip.hpp"
 #include "integrate.hip.hpp"
+#include "com_ref.hip.hpp"
 
 namespace wbc {
 
@@ -79,22 +80,26 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
 // tick is made of is ~6 dependent trips through L2 (state loads, table-indexed joint loads, store acks at the two
 // barriers) around the arithmetic.  PMC (tools/icache_profile.sh): instruction-cache hit rate 99.7 %, same misses per
 // tick as the per-tick launches -- code size (72 kB) is not the limiter.
-template <class T, bool OBSERVER>
+// TRACK: the CoM planner in the loop (wbc_rollout_tracking_batch).  The integrator wavefront, idle at the head of a tick,
+// first runs the reference generator (com_reference_body: w_des, vdot_des of this tick -> HBM, optional CoM record) and
+// raises a third flag; the rnea role issues its state loads, then waits for that flag before it reads the references.
+template <class T, bool OBSERVER, bool TRACK>
 __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,
-                                                                         int horizon) {
+                                                                         int horizon, const DevRefParams<T>* __restrict__ G, RefArgs<T> ra) {
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready, mready;
+  __shared__ int ready, mready, rready;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) { ready = 0; mready = 0; }
+  if (threadIdx.x == 0) { ready = 0; mready = 0; rready = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   constexpr int NPROD = OBSERVER ? 2 : 1;
   constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
   T* const traj0 = ia.tau_traj;
+  T* const com0 = ra.com;
   for (int t = 0; t < horizon; ++t) {
     // The batch size is laundered through an empty asm once per tick: every per-lane address in the role bodies derives
     // from it, so none of that (tick-invariant) address arithmetic is hoisted out of the horizon loop -- hoisted, it
@@ -106,6 +111,15 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
     if (wave == WINT) {
+      if constexpr (TRACK) {   // planner role first: this tick's references
+        RefArgs<T> rt = ra;
+        rt.N = (size_t)n_tick;
+        rt.t = (T)t * prm.dt + ra.t;
+        rt.com = com0 ? com0 + (size_t)t * 6 * (size_t)n_tick : nullptr;
+        com_reference_body<T, true>(model, G, rt, cst);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
+      }
       // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has published them
       // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
       while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(2);
@@ -116,7 +130,14 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       continue;
     }
     if (wave == 4) {
-      rnea_step_body<T, RS_STEP | RS_H, 64, 1>(model, prm, at, cst, wsl);
+      int* const rflag = &rready;
+      const int rneed = t + 1;
+      rnea_step_body<T, RS_STEP | RS_H, 64, 1>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
+        if constexpr (TRACK) {
+          while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+      });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wave == 5) {

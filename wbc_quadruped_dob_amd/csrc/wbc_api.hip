@@ -627,7 +627,8 @@ extern "C" int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, co
 // small batches: the whole horizon in ONE launch (rollout_kernel, fused_tick.hip.hpp)
 template <class T>
 static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
-                              const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, hipStream_t st) {
+                              const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, hipStream_t st,
+                              const void* plan = nullptr, void* com_traj = nullptr) {
   SweepArgs<T> a;
   std::memset(&a, 0, sizeof(a));
   a.N = N; a.q = (const T*)in->q; a.v = (const T*)in->v;
@@ -644,12 +645,21 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   ia.tau = (const T*)out->tau; ia.f = (const T*)out->f; ia.tau_ext = (const T*)tau_ext; ia.tau_traj = (T*)tau_traj;
   ia.dt = (T)s->params.dt;
   const unsigned blocks = (unsigned)((N + 15) / 16);
-  if (s->params.observer_order > 0)
-    hipLaunchKernelGGL((rollout_kernel<T, true>), dim3(blocks), dim3(512), 0, st, (const DevModel<T>*)s->d_model,
-                       to_dev_params<T>(s->params), a, qa, s->jmap, ia, horizon);
-  else
-    hipLaunchKernelGGL((rollout_kernel<T, false>), dim3(blocks), dim3(448), 0, st, (const DevModel<T>*)s->d_model,
-                       to_dev_params<T>(s->params), a, qa, s->jmap, ia, horizon);
+  RefArgs<T> ra;
+  std::memset(&ra, 0, sizeof(ra));
+  ra.N = N; ra.q = (const T*)in->q; ra.v = (const T*)in->v; ra.plan = (const T*)plan; ra.t = (T)0;
+  ra.w_des = (T*)in->w_des; ra.vdot_des = (T*)in->vdot_des; ra.com = (T*)com_traj;
+  const DevModel<T>* dm = (const DevModel<T>*)s->d_model;
+  const DevParams<T> dp = to_dev_params<T>(s->params);
+  const DevRefParams<T>* G = (const DevRefParams<T>*)s->d_ref;
+  const bool ob = s->params.observer_order > 0;
+  if (plan) {
+    if (ob) hipLaunchKernelGGL((rollout_kernel<T, true, true>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+    else hipLaunchKernelGGL((rollout_kernel<T, false, true>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+  } else {
+    if (ob) hipLaunchKernelGGL((rollout_kernel<T, true, false>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+    else hipLaunchKernelGGL((rollout_kernel<T, false, false>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
   return WBC_OK;
@@ -755,6 +765,18 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
   if (!out->M || !out->h || !out->Jc) return fail(WBC_E_INVALID, "rollouts need the M, h, Jc buffers (forward dynamics reads them)");
   if (s->sweep_mode == 0) return fail(WBC_E_INVALID, "rollouts need the fused sweep (unset WBC_SWEEP=split)");
   if (!in->q || !in->v || !in->w_des || !in->vdot_des) return fail(WBC_E_INVALID, "null input buffer");
+  if (!s->d_ref) return fail(WBC_E_INVALID, "call wbc_solver_set_ref_params first");
+  if (N > 0 && N <= s->fused_max && s->rollout_persistent && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1) {
+    if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
+    if (!in->normals || !in->mu || !in->mask) return fail(WBC_E_INVALID, "null input buffer");
+    if (!out->tau || !out->f || !out->status) return fail(WBC_E_INVALID, "null output buffer");
+    if (s->params.observer_order > 0 && (!obs || !obs->integ || !obs->r))
+      return fail(WBC_E_INVALID, "observer on: observer state buffers required");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st0 = (hipStream_t)stream;
+    return s->dtype == WBC_F64 ? rollout_persistent<double>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0, plan, com_traj)
+                               : rollout_persistent<float>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0, plan, com_traj);
+  }
   wbc_batch_in tick = *in;
   tick.tau_prev = out->tau;
   tick.f_prev = out->f;
