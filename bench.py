@@ -299,7 +299,9 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
             "config": {"workload": "configs[4]: horizon=%d x batch=%d rollouts per GPU, trot masks, observer on, pushes, %s; "
                                    "one step = one rollout (%d dependent ticks incl. %sforward dynamics + integrator)"
                                    % (H, n, dtype, H, "CoM planner/reference generator + " if args.tracking else ""),
-                       "batch_per_gpu": n, "horizon": H, "parallelism": "batch-sharded x%d, rank-local for all ticks" % world},
+                       "batch_per_gpu": n, "horizon": H, "parallelism": "batch-sharded x%d, rank-local for all ticks" % world,
+                       "launches": ("one persistent rollout_kernel launch per rollout" if (n <= 4096 and os.environ.get("WBC_ROLLOUT_PERSISTENT", "1") != "0")
+                                    else "per tick: %sdyn_sweep/fused tick, qp, integrate" % ("reference, " if args.tracking else ""))},
             "us_per_tick": elapsed / args.steps / H * 1e6, "qp": {"status_ok_frac_last_tick": ok},
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
