@@ -24,3 +24,22 @@ for cfg, obs in ((2,0),(3,1),(4,2)):
 H=np.eye(2); g=np.zeros(2); C=np.array([[1.0,0],[-1.0,0]]); d=np.array([1.0,0.0])
 print(O.qp_solve(H,g,C,d)[2])
 print('asan run complete')
+# reference generator, tracking rollout, op count, per-QP timing (added after the first ASan pass)
+G = synth.default_ref_params()
+for dt in (np.float64, np.float32):
+    n = 65
+    B = synth.make_batch(3, n, float(flat['mass'].sum()))
+    plan = synth.make_plan(B).astype(dt)
+    c = lambda a: a.astype(dt)
+    orc.reference(G, c(B['q']), c(B['v']), plan, 0.01)
+    P = synth.default_params(observer_order=1, dtype='f64' if dt == np.float64 else 'f32')
+    q, v = c(B['q']).copy(), c(B['v']).copy()
+    integ = orc.dynamics(q, v)['p'].copy(); r = np.zeros((n, 18), dt)
+    orc.rollout_tracking(P, G, 4, q, v, plan, c(B['normals']), c(B['mu']), B['mask'], integ=integ, r=r, want_traj=True, want_com=True, nthreads=3)
+B = synth.make_batch(3, 16, float(flat['mass'].sum()))
+P = synth.default_params(observer_order=2)
+for s in range(16):
+    orc.op_count(P, B['q'][s], B['v'][s], B['w_des'][s], B['vdot_des'][s], B['normals'][s], B['mu'][s], int(B['mask'][s]),
+                 B['tau_prev'][s], B['f_prev'][s], np.zeros(18), np.zeros(18))
+orc.qp_time(P, B['q'], B['v'], B['w_des'], B['normals'], B['mu'], B['mask'])
+print('asan run 2 complete')
