@@ -298,8 +298,13 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         // pairs (even entry, odd entry): (0,1) (2, 3+mrow) (6,7) (8,9) (10,11) (12,13) (14,15) (16,17)
         ST2C(a.Jc, rb + (odd ? 1 : 0), ((odd ? 1 : 0) == mrow) ? (T)1 : Z);
         ST2C(a.Jc, rb + (odd ? 3 + mrow : 2), (!odd && mrow == 2) ? (T)1 : Z);
+        // joint columns: zeros, EXCEPT the three columns of my own leg, which the return sweep writes with data
+        // (zero-filling them first cost 9 words/leg = 7 % of the kernel's store bytes, PMC WRITE_SIZE)
 #pragma unroll
-        for (int c = 6; c < 18; c += 2) ST2C(a.Jc, rb + c + (int)odd, Z);
+        for (int c = 6; c < 18; c += 2) {
+          const int col = c + (int)odd - 6;
+          if (col != jx[0] && col != jx[1] && col != jx[2]) ST2C(a.Jc, rb + c + (int)odd, Z);
+        }
       }
 #undef ST2C
     } else {
@@ -313,7 +318,8 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         for (int c = 0; c < 3; ++c) STL(a.Jc, 18 * mrow + c, 54, (c == mrow) ? (T)1 : Z);
         STL(a.Jc, 18 * mrow + 3 + mrow, 54, Z);
 #pragma unroll
-        for (int c = 0; c < 12; ++c) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);
+        for (int c = 0; c < 12; ++c)
+          if (c != jx[0] && c != jx[1] && c != jx[2]) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);
       }
     }
   }
