@@ -116,7 +116,8 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
       for (int c = 0; c < 3; ++c) STL(a.Jc, 18 * mrow + c, 54, (c == mrow) ? (T)1 : Z);
       STL(a.Jc, 18 * mrow + 3 + mrow, 54, Z);
 #pragma unroll
-      for (int c = 0; c < 12; ++c) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);
+      for (int c = 0; c < 12; ++c)
+        if (c != jx[0] && c != jx[1] && c != jx[2]) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);   // own-leg columns get data below
     }
   }
   T qx, qy, qz, qw;
