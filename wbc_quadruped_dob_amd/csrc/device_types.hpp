@@ -54,11 +54,13 @@ template <class T> struct SweepArgs {
   const T* w_des; const T* vdot_des; const T* tau_prev; const T* f_prev;
   T* obs_integ; T* obs_r;
   T* ws;
+  int ws_geom;   // 1: also write d and the own-leg Jacobian blocks to the workspace; 0: the QP reads them from Jc (M/h/Jc ticks)
 };
 
 template <class T> struct QpArgs {
   size_t N;
   const T* ws; const T* normals; const T* mu; const int* mask;
+  const T* Jc;   // non-null: foot lever arms and own-leg Jacobian blocks come from the Jacobian the sweep wrote, not from ws
   T* tau; T* f; int* status; int* iters;
 };
 

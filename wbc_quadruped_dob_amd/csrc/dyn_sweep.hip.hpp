@@ -539,7 +539,9 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
     STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
   }
-  if (STEP) {
+  // the QP's geometry (foot lever arms, own-leg Jacobian blocks: 48 of the 66 workspace words) is a subset of Jc; when
+  // Jc is being written anyway the QP kernel reads it from there and these stores are skipped (-9 % store bytes)
+  if (STEP && (!MATS || a.ws_geom)) {
     WSTL(WS_D + 0, 3, dw.x);
     WSTL(WS_D + 1, 3, dw.y);
     WSTL(WS_D + 2, 3, dw.z);

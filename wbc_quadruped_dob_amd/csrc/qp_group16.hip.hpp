@@ -168,7 +168,12 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   // ------------------------------------------------------------------ inputs
   int mask = a.mask[s32] & 0xF;
   bool on = (mask >> f) & 1;
-  const T d_me = isvar ? WSLD(WS_D + v) : (T)0;
+  const bool geom_jc = !WSLDS && a.Jc != nullptr;   // uniform: lever arms / own-leg blocks from Jc (see QpArgs)
+  T d_me = 0;
+  if (geom_jc) {   // -[d]x block of my foot's Jacobian rows: d_x = Jc[(3f+1), 5], d_y = Jc[(3f+2), 3], d_z = Jc[(3f), 4]
+    const int comp = c3 == 0 ? (3 * f + 1) * 18 + 5 : (c3 == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4);
+    if (isvar) d_me = GLD(a.Jc, comp);
+  } else if (isvar) d_me = WSLD(WS_D + v);
   const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
   const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
   const T mu_f = GLD(a.mu, f);
@@ -531,16 +536,20 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   // ------------------------------------------------------------------ outputs: f, tau (a9), status
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
+    int jm = 0;   // caller's index of my joint (leg f, joint c3)
+    sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
     if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
-      jl0 = WSLD(WS_JCL + 9 * f + 0 + c3); jl1 = WSLD(WS_JCL + 9 * f + 3 + c3); jl2 = WSLD(WS_JCL + 9 * f + 6 + c3);
+      if (geom_jc) {
+        jl0 = GLD(a.Jc, (3 * f + 0) * 18 + 6 + jm); jl1 = GLD(a.Jc, (3 * f + 1) * 18 + 6 + jm); jl2 = GLD(a.Jc, (3 * f + 2) * 18 + 6 + jm);
+      } else {
+        jl0 = WSLD(WS_JCL + 9 * f + 0 + c3); jl1 = WSLD(WS_JCL + 9 * f + 3 + c3); jl2 = WSLD(WS_JCL + 9 * f + 6 + c3);
+      }
     }
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     if (isvar) {
       GST(a.f, v, on ? x_me : (T)0);
       const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
-      int jm = 0;
-      sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
       GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
     }
     if (l16 == 0) {

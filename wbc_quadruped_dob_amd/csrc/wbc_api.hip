@@ -518,6 +518,10 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
+  // two-kernel tick with M/h/Jc outputs: the QP takes its geometry from Jc and the sweep skips those workspace words
+  const bool geom_from_jc = mats && s->sweep_mode == 1 && s->qp_kernel == 0;
+  qa.Jc = geom_from_jc ? (const T*)out->Jc : nullptr;
+  a.ws_geom = geom_from_jc ? 0 : 1;
   if ((mats || !out->pf) && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 && N <= s->fused_max) {
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
@@ -639,7 +643,8 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   a.ws = (T*)s->d_ws;
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
-  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
+  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters; qa.Jc = nullptr;
+  a.ws_geom = 1;
   IntegrateArgs<T> ia;
   ia.N = N; ia.q = (T*)in->q; ia.v = (T*)in->v; ia.M = (const T*)out->M; ia.h = (const T*)out->h; ia.Jc = (const T*)out->Jc;
   ia.tau = (const T*)out->tau; ia.f = (const T*)out->f; ia.tau_ext = (const T*)tau_ext; ia.tau_traj = (T*)tau_traj;
