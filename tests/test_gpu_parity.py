@@ -523,6 +523,38 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkey
         assert relerr(a["tau"], ref["tau"]) < TIGHT64 and relerr(a["f"], ref["f"]) < TIGHT64
 
 
+@pytest.mark.parametrize("obs,dtype,n", [(1, "f64", 3001), (2, "f64", 130), (1, "f32", 2048), (1, "f64", 70000)])
+def test_separate_observer_kernel_matches(torch_cuda, gpu_model, oracle, monkeypatch, obs, dtype, n):
+    """Large observer-on batches run {observer kernel on the second stream || dyn_sweep without the observer} -> QP that
+    completes b and tau_partial with rhat (observer.hip.hpp); WBC_OBS_SPLIT_MIN=1 forces that path at test-sized batches
+    (70000 also takes its 256-thread variant).  Must equal the all-in-one observer sweep to rounding and stay within the
+    oracle tolerance, also over a second tick (observer state carried)."""
+    torch = torch_cuda
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=81)
+    nd = _np_dtype(dtype)
+    integ0 = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"].astype(nd)
+    res = {}
+    for tag, env in (("split", "1"), ("one_sweep", "1000000000")):
+        monkeypatch.setenv("WBC_FUSED_MAX", "0")
+        monkeypatch.setenv("WBC_OBS_SPLIT_MIN", env)
+        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
+        monkeypatch.delenv("WBC_OBS_SPLIT_MIN", raising=False)
+        monkeypatch.delenv("WBC_FUSED_MAX", raising=False)
+        res[tag] = _run_step(torch, solver, B, dtype, integ0.copy(), np.zeros((n, 18), nd), want_mats=True)
+        res[tag + "_2"] = _run_step(torch, solver, B, dtype, res[tag]["integ"], res[tag]["r"], want_mats=True)
+    a, b = res["split"], res["one_sweep"]
+    tol = 1e-11 if dtype == "f64" else 1e-3
+    assert np.array_equal(a["status"], b["status"])
+    for k in ("tau", "f", "M", "h", "Jc", "pf", "integ", "r"):
+        assert relerr(a[k], b[k]) < tol, k
+        assert relerr(res["split_2"][k], res["one_sweep_2"][k]) < tol * 10, k
+    if dtype == "f64" and n < 10000:
+        ig, r = integ0.copy(), np.zeros((n, 18))
+        ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"],
+                          ig, r, nthreads=8)
+        assert relerr(a["tau"], ref["tau"]) < TIGHT64 and relerr(a["r"], r) < TIGHT64
+
+
 def test_prepared_tick_equals_step(torch_cuda, gpu_model):
     """Solver.prepare_step builds the argument structs once; its tick() must do exactly what step() does."""
     torch = torch_cuda

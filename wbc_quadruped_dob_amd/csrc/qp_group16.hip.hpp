@@ -574,9 +574,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
 #undef GLD
 }
 
-template <class T, bool REGROUP, int WPB>
+// RHAT: rhat comes from the separate observer kernel through the HBM workspace (large observer-on batches)
+template <class T, bool REGROUP, int WPB, bool RHAT = false>
 __global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
-  qp_group16_body<T, REGROUP, WPB, false>(prm, a, jmap, nullptr);
+  qp_group16_body<T, REGROUP, WPB, false, RHAT>(prm, a, jmap, nullptr);
 }
 
 }  // namespace wbc

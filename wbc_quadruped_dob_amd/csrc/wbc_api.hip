@@ -21,6 +21,7 @@
 #include "integrate.hip.hpp"
 #include "com_ref.hip.hpp"
 #include "fused_tick.hip.hpp"
+#include "observer.hip.hpp"
 
 using namespace wbc;
 
@@ -42,7 +43,7 @@ struct wbc_solver {
   wbc_params params;
   int leg_body[4][3];
   void* d_model = nullptr;  // DevModel<T>
-  void* d_ws = nullptr;     // WS_WORDS * max_batch * sizeof(T)
+  void* d_ws = nullptr;     // WS_LDS_WORDS * max_batch * sizeof(T): the 66 step words + 18 words of rhat (separate observer kernel)
   QpJidx jmap;
   int qp_kernel = 0;  // 0 = qp_group16 (default), 1 = qp_wave; env WBC_QP_KERNEL=wave selects 1
   int qp_wpb = 1;           // wavefronts per QP workgroup: 1 (default) or 4 (env WBC_QP_WPB=4)
@@ -50,6 +51,10 @@ struct wbc_solver {
   int sweep_mode = 1; // 1 = fused dyn_sweep (default), 0 = split (mass_jac on a second stream || rnea_step -> QP); env WBC_SWEEP=split
                       // measured on MI355X: split is 5-20 % slower (two kernels pay the fixed latencies twice), kept for A/B
   bool rollout_persistent = true;  // wbc_rollout_batch of at most fused_max states: the whole horizon in one launch; env WBC_ROLLOUT_PERSISTENT=0 disables
+  size_t obs_split_min = (size_t)-1;  // opt-in (env WBC_OBS_SPLIT_MIN): observer-on ticks of at least this many states run the observer
+                                      // as its own kernel on the second stream beside dyn_sweep<no observer> (observer.hip.hpp).
+                                      // Measured at N = 262 144: fp32 0.482 -> 0.441 ms per tick, fp64 0.713 -> 0.810 ms (slower), and
+                                      // slower for both at N = 32 768 -> not the default
   size_t fused_max = 4096;  // observer-off ticks of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -274,6 +279,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (const char* e = std::getenv("WBC_QP_WPB")) s->qp_wpb = (std::strcmp(e, "4") == 0) ? 4 : 1;
   if (const char* e = std::getenv("WBC_QP_REGROUP")) s->qp_regroup = (std::strcmp(e, "1") == 0);
   if (const char* e = std::getenv("WBC_ROLLOUT_PERSISTENT")) s->rollout_persistent = std::strcmp(e, "0") != 0;
+  if (const char* e = std::getenv("WBC_OBS_SPLIT_MIN")) s->obs_split_min = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
@@ -289,7 +295,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
     e = hipMalloc(&s->d_model, sizeof(dm));
     if (e == hipSuccess) e = hipMemcpy(s->d_model, &dm, sizeof(dm), hipMemcpyHostToDevice);
   }
-  if (e == hipSuccess) e = hipMalloc(&s->d_ws, (size_t)WS_WORDS * max_batch * ts);
+  if (e == hipSuccess) e = hipMalloc(&s->d_ws, (size_t)WS_LDS_WORDS * max_batch * ts);
   // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
   s->one_bytes = 200 * sizeof(double) + 4 * sizeof(int);
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
@@ -515,6 +521,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   timing_tick(s);
   int rc;
   hipError_t e;
+  bool obs_split = false;
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
@@ -547,6 +554,33 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rnea_step launch: ") + hipGetErrorString(e));
     rc = span_end(s, st);
     if (rc) return rc;
+  } else if (mats && ob && N >= s->obs_split_min && s->qp_kernel == 0 && s->qp_wpb == 1 && !s->qp_regroup) {
+    // large observer-on batch: the observer update runs as its own light kernel on the second stream while dyn_sweep
+    // WITHOUT the observer passes (252 instead of 370 VGPRs: two waves per SIMD, shared tables) writes M, h, Jc; rhat
+    // travels through 18 extra workspace words and the QP kernel completes b and tau_partial with it
+    obs_split = true;
+    HIP_TRY(hipEventRecord(s->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
+    rc = span_begin(s, 2, s->aux);
+    if (rc) return rc;
+    if (N * 4 >= (size_t)256 * 8 * 64 * 2)
+      hipLaunchKernelGGL((observer_kernel<T, 256>), dim3((unsigned)((N * 4 + 255) / 256)), dim3(256), 0, s->aux,
+                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
+    else
+      hipLaunchKernelGGL((observer_kernel<T, 64>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, s->aux,
+                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("observer launch: ") + hipGetErrorString(e));
+    rc = span_end(s, s->aux);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev_join, s->aux));
+    rc = span_begin(s, 0, st);
+    if (rc) return rc;
+    e = launch_sweep<T, SW_MATS | SW_STEP>(s, a, st);
+    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
+    rc = span_end(s, st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));   // the QP needs rhat
   } else {
     rc = span_begin(s, 0, st);
     if (rc) return rc;
@@ -573,7 +607,10 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
         hipLaunchKernelGGL((qp_group16_kernel<T, false, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
     } else {
       const unsigned blocks = (unsigned)((N + 3) / 4);
-      hipLaunchKernelGGL((qp_group16_kernel<T, false, 1>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+      if (obs_split)
+        hipLaunchKernelGGL((qp_group16_kernel<T, false, 1, true>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+      else
+        hipLaunchKernelGGL((qp_group16_kernel<T, false, 1>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
     }
   }
   e = hipGetLastError();
