@@ -67,6 +67,27 @@ int main(int argc, char** argv) {
     if (hst[i] != 0 || std::fabs(z - w[2]) > 1e-2 * w[2]) ++bad;
   }
   std::printf("batch %zu: %d bad\n", N, bad);
+  {  // a 5-tick rollout of the same batch from C++ (raw buffers): needs M, h, Jc; q, v advance in place
+    double *dM, *dh, *dJ;
+    int* dit;
+    hipMalloc(&dM, 171 * N * 8); hipMalloc(&dh, 18 * N * 8); hipMalloc(&dJ, 216 * N * 8); hipMalloc(&dit, N * 4);
+    hipMemset(dtau, 0, 12 * N * 8); hipMemset(df, 0, 12 * N * 8);
+    wbc_batch_out ro = {dtau, df, dst, dit, dM, dh, dJ, nullptr};
+    CK(wbc_rollout_batch(s, N, 5, &in, &ro, nullptr, nullptr, nullptr, stream));
+    hipStreamSynchronize(stream);
+    std::vector<double> hq2(19 * N);
+    hipMemcpy(hq2.data(), dq, hq2.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(hst.data(), dst, N * 4, hipMemcpyDeviceToHost);
+    int rbad = 0;
+    double dz = 0;
+    for (size_t i = 0; i < N; ++i) {
+      if (hst[i] != 0) ++rbad;
+      const double d = std::fabs(hq2[2 * N + i] - hq[2 * N + i]);   // standing robots asked to hold still: base height barely moves
+      if (d > dz) dz = d;
+    }
+    std::printf("rollout 5 ticks: %d bad, max |dz| = %.2e m\n", rbad, dz);
+    if (rbad || !(dz < 1e-3)) return 6;
+  }
   wbc_solver_destroy(s);
   wbc_model_free(m);
   if (bad) return 3;
