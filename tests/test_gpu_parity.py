@@ -509,7 +509,7 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkey
     a, b = res["fused"], res["two"]
     assert np.array_equal(a["status"], b["status"])
     exact = False
-    assert np.mean(a["iters"] != b["iters"]) <= (0.0 if exact else 2e-3 if dtype == "f64" else 2e-2)   # a rounding-level
+    assert np.mean(a["iters"] != b["iters"]) <= (0.0 if exact else 2e-3 if dtype == "f64" else 5e-2)   # a rounding-level
     # difference may flip a degenerate pivot choice (fp32 works with qp_tol = 1e-3)
     keys = ("tau", "f", "M", "h", "Jc", "pf") + (("integ", "r") if obs else ())
     for k in keys:

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Scan the gfx950 ISA of the product library for VGPR spill stores that execute with EXEC possibly empty.
+
+Why: hipcc 7.2 once placed `scratch_store ... Folded Spill` instructions into the exit block of a divergent loop BEFORE the
+`s_or_b64 exec, exec, <saved>` that re-enables the lanes (observer_kernel<double>, caught by the parity tests as garbage
+rhat).  A spill store in that position writes nothing for the lanes that are masked off and the later reload returns junk.
+VGPR spills themselves are fine; this flags only spill stores (and reloads) that sit between a block label and the block's exec restore.
+`v_writelane` SGPR spills ignore EXEC and are not flagged.
+
+usage: tools/spill_lint.py [file.s]     (without a file: compiles csrc/wbc_api.hip to /tmp/asm/wbc_lint.s first)
+exit status 1 when something is flagged.
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def compile_asm(out="/tmp/asm/wbc_lint.s"):
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    src = os.path.join(ROOT, "wbc_quadruped_dob_amd", "csrc", "wbc_api.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-w", "-o", out, src]
+    subprocess.run(cmd, check=True, cwd=os.path.dirname(src))
+    return out
+
+
+def lint(path):
+    """Returns [(kernel, label, line_no, text)] for every masked spill store."""
+    bad = []
+    kernel, label = None, None
+    pending = []          # spill stores seen in the current block before any exec restore
+    restore = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
+    spill = re.compile(r"^\s*(scratch|buffer)_(store|load)\S*\s.*Folded (Spill|Reload)")
+    lab = re.compile(r"^(\.LBB\d+_\d+):")
+    fn = re.compile(r"^(_Z\w+):")
+    with open(path) as f:
+        for no, line in enumerate(f, 1):
+            m = fn.match(line)
+            if m:
+                kernel, label, pending = m.group(1), None, []
+                continue
+            m = lab.match(line)
+            if m:
+                label, pending = m.group(1), []
+                continue
+            if label is None:
+                continue
+            if spill.match(line):
+                pending.append((no, line.strip()))
+            elif restore.match(line):
+                bad += [(kernel, label, n, t) for n, t in pending]
+                pending = []
+            elif re.match(r"^\s*s_(cbranch|branch|endpgm)", line):
+                pending = []      # block ends without restoring exec: the stores ran under the block's own mask
+    return bad
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else compile_asm()
+    bad = lint(path)
+    for k, l, n, t in bad:
+        print(f"{path}:{n}: {k[:60]} {l}: spill store / reload before the exec restore: {t}")
+    print(f"spill_lint: {len(bad)} masked spill store(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

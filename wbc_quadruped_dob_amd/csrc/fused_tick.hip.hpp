@@ -17,8 +17,16 @@
 #include "qp_group16.hip.hpp"
 #include "integrate.hip.hpp"
 #include "com_ref.hip.hpp"
+#include "observer.hip.hpp"
 
 namespace wbc {
+
+// the observer role: the register-only body of observer.hip.hpp (no LDS parking), or -DWBC_OBS_ROLE_RNEA: rnea_step_body
+#ifdef WBC_OBS_ROLE_RNEA
+#define WBC_OBS_ROLE(EXT_, ARGS_) rnea_step_body<T, RS_OBS | RS_OBSW, 64, EXT_>(model, prm, ARGS_, cst, wsl)
+#else
+#define WBC_OBS_ROLE(EXT_, ARGS_) observer_body<T, 64, EXT_>(model, prm, ARGS_, cst, wsl)
+#endif
 
 // The front half is SPLIT by consumer.  Six wavefronts per workgroup of
 // 16 states: wave 4 runs rnea_step_body (bias forces h, and the 66-word step workspace -- all the QP needs -- into LDS),
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
     else __syncthreads();
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
-      rnea_step_body<T, RS_OBS | RS_OBSW, 64, 2>(model, prm, a, cst, wsl);
+      WBC_OBS_ROLE(2, a);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&mready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {
-        rnea_step_body<T, RS_OBS | RS_OBSW, 64, 1>(model, prm, at, cst, wsl);
+        WBC_OBS_ROLE(1, at);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }

@@ -17,13 +17,20 @@
 
 namespace wbc {
 
-template <class T, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void observer_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a) {
-  __shared__ T cst[CST_WORDS];
+// EXT = 0: the stand-alone kernel below.  EXT = 1 / 2: the observer ROLE of the fused tick / persistent rollout kernels
+// (fused_tick.hip.hpp): one wavefront of a larger workgroup that owns 16 states, constant table staged by other wavefronts
+// (EXT = 2: this body joins the workgroup barrier after issuing its state loads), rhat goes to the LDS image wsl.
+template <class T, int BLOCK, int EXT>
+WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext, T* wsl) {
+  static_assert(EXT == 0 || BLOCK == 64, "one wavefront");
+  __shared__ T cst_own[EXT ? 1 : CST_WORDS];
+  const T* cst = EXT ? cst_ext : cst_own;
+  unsigned tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
-  const int leg = (int)((threadIdx.x & 63) >> 4);
-  const size_t s_raw = ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);
+  const int leg = (int)((tx & 63) >> 4);
+  const size_t s_raw = EXT ? (size_t)blockIdx.x * 16 + (tx & 15) : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);
   const bool live = s_raw < N;
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
 #define OCS(i) cst[(i) * 4 + leg]
@@ -31,6 +38,8 @@ __global__ __launch_bounds__(BLOCK, 2) void observer_kernel(const DevModel<T>* _
 #define OLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define OSTV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define OST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) OSTV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+  // rhat: HBM workspace (stand-alone kernel) or the workgroup's LDS image (role)
+#define ORHAT(comp, val) do { if constexpr (EXT != 0) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else OSTV(a.ws, comp, val); } while (0)
   // state loads first, table staging while they are in flight
   T qq[4], vb[6];
 #pragma unroll
@@ -45,8 +54,18 @@ __global__ __launch_bounds__(BLOCK, 2) void observer_kernel(const DevModel<T>* _
     ql[k] = OLDV(a.q, 7 + jx[k]);
     vl[k] = OLDV(a.v, 6 + jx[k]);
   }
-  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
-  __syncthreads();
+  if constexpr (EXT == 0) {
+    // branch-free (clamped index, the tail lanes rewrite the last word): with a divergent staging loop here hipcc 7.2 put
+    // VGPR spill stores of the fp64 build into the loop's exit block BEFORE exec is restored, i.e. with no lane enabled
+    // (found by parity: rhat garbage in every state; tools/spill_lint.py now scans the ISA for that pattern)
+#pragma unroll
+    for (int i0 = 0; i0 < CST_WORDS; i0 += BLOCK) {
+      const int i = min(i0 + (int)tx, CST_WORDS - 1);
+      cst_own[i] = model->cst[i];
+    }
+    __syncthreads();
+  }
+  if constexpr (EXT == 2) __syncthreads();
 
   T qx, qy, qz, qw;
   {
@@ -174,15 +193,21 @@ __global__ __launch_bounds__(BLOCK, 2) void observer_kernel(const DevModel<T>* _
       OSTV(a.obs_r, c, rl[k]);
     }
   }
-  OST4(a.ws, WS_RHAT + 0, rb[0], WS_RHAT + 1, rb[1], WS_RHAT + 2, rb[2], WS_RHAT + 3, rb[3]);
-  if (leg < 2) OSTV(a.ws, WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
+  ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
+  if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) OSTV(a.ws, WS_RHAT + 6 + 3 * leg + k, rl[k]);
+  for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
+#undef ORHAT
 #undef OST4
 #undef OSTV
 #undef OLDV
 #undef OLDU
 #undef OCS
+}
+
+template <class T, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void observer_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a) {
+  observer_body<T, BLOCK, 0>(model, prm, a, nullptr, nullptr);
 }
 
 }  // namespace wbc
