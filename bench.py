@@ -140,8 +140,8 @@ def main():
         except Exception as e:  # never lose the main line to the optional leg
             gather_res = {"error": repr(e)[:200]}
 
-    # cost of an event pair with nothing between them, on the same stream: the part of every measured span that is
-    # not kernel time (reported; the roofline uses the raw span, i.e. it errs on the slow side)
+    # cost of an event pair with nothing between them, on the same stream (reported for reference: the per-kernel times
+    # are the dispatches' own start/stop events unless WBC_TIMING=pair)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
     for e0, e1 in ev:
         step()
@@ -189,8 +189,8 @@ def main():
                          "algorithmic_bytes_per_launch": dyn_bytes, "avg_launch_us": dyn_s * 1e6,
                          "launches_timed": tm["fused_launches"] if fused else tm["dyn_launches"],
                          "event_pair_overhead_us": ev_overhead_us,
-                         "note": ("HIP events on the launch stream around every %d-th tick of the timed region; raw span "
-                                  "(includes the event-pair overhead reported beside it)" % sample) +
+                         "note": ("HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on the launch stream, every "
+                                  "%d-th tick of the timed region" % sample) +
                                  ("; at this batch the whole tick is ONE launch (dynamics + GRF QP as wavefront roles of a "
                                   "workgroup, latency-bound: one workgroup per CU), so `achieved` = the algorithmic bytes of the whole tick "
                                   "(inputs + tau, f + M, h, Jc) over that launch -- see roofline_dyn_sweep_alone for the 443-word "

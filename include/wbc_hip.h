@@ -195,8 +195,9 @@ int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const d
 int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const double* plan, double t,
                           double* w_des, double* vdot_des, double* com);
 
-/* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on ---- */
-int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 events around every kernel; k > 1: every k-th tick */
+/* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on (the dispatch's own start /
+ * stop events; env WBC_TIMING=pair: an event pair recorded around the launch instead) ---- */
+int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 every kernel launch; k > 1: every k-th tick */
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed
  * 0 = dyn_sweep kernel (or mass_jac with WBC_SWEEP=split), 1 = QP kernel, 2 = rnea_step kernel (no-M/h/Jc ticks and
  * split mode), 3 = fused tick kernel (sweep + QP of small batches in one launch); resets the accumulators. */

@@ -580,6 +580,66 @@ def test_prepared_tick_equals_step(torch_cuda, gpu_model):
     assert torch.equal(r_a, r_b) and torch.equal(a["tau"], b["tau"])
 
 
+@pytest.mark.parametrize("mode", ["fused", "two_kernel", "no_mats", "obs_split", "rollout"])
+def test_tick_is_graph_capturable(torch_cuda, gpu_model, monkeypatch, mode):
+    """Every dispatch variant of the tick (and a persistent rollout) can be captured into a hipGraph: no allocation, no
+    synchronisation, no host read inside the C call.  Replaying the graph must reproduce the eager results bit for bit."""
+    torch = torch_cuda
+    n = 1000
+    if mode in ("two_kernel", "obs_split"):
+        monkeypatch.setenv("WBC_FUSED_MAX", "0")
+    if mode == "obs_split":
+        monkeypatch.setenv("WBC_OBS_SPLIT_MIN", "1")
+    solver, P = _solver(gpu_model, obs=1, max_batch=n)
+    monkeypatch.delenv("WBC_FUSED_MAX", raising=False)
+    monkeypatch.delenv("WBC_OBS_SPLIT_MIN", raising=False)
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=91)
+    td = torch.float64
+    dv = lambda k: to_dev(B[k], torch, td)
+    mask = torch.from_numpy(B["mask"]).cuda()
+    args = [dv(k) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")] + [mask, dv("tau_prev"), dv("f_prev")]
+    q0, v0 = args[0].clone(), args[1].clone()
+    ig0 = solver.dynamics(args[0], args[1], want=("p",))["p"]
+    ig, r = ig0.clone(), torch.zeros_like(ig0)
+    if mode == "rollout":
+        out = solver.step(*args, ig, r, want_mats=True)
+        out0 = {k: t.clone() for k, t in out.items()}
+        run = lambda: solver.rollout(5, args[0], args[1], args[2], args[3], args[4], args[5], mask, out, ig, r)
+    else:
+        run, out = solver.prepare_step(*args, ig, r, want_mats=(mode != "no_mats"))
+        out0 = None
+
+    def reset():
+        args[0].copy_(q0); args[1].copy_(v0); ig.copy_(ig0); r.zero_()
+        for k, t in out.items():
+            if out0 is not None:
+                t.copy_(out0[k])
+            else:
+                t.zero_()
+
+    reset()
+    run()
+    torch.cuda.synchronize()
+    want = {k: t.clone() for k, t in out.items()}
+    want.update(q=args[0].clone(), v=args[1].clone(), ig=ig.clone(), r=r.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()                       # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        run()
+    for _ in range(2):
+        reset()
+        g.replay()
+        torch.cuda.synchronize()
+        got = dict(out, q=args[0], v=args[1], ig=ig, r=r)
+        for k in want:
+            assert torch.equal(want[k], got[k]), (mode, k)
+
+
 def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle):
     """Quaternions and terrain normals are normalised inside (as in the oracle); a NaN in one state's inputs must not
     hang the kernels nor disturb any other state."""

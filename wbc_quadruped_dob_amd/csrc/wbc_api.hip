@@ -3,6 +3,7 @@
 #include "../../include/wbc_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -71,6 +72,10 @@ struct wbc_solver {
   struct Span { int kind; hipEvent_t a, b; };
   std::vector<Span> spans;
   size_t ev_next = 0;
+  // timing source: true = the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL start/stop events, what
+  // rocprofv3 reports); false (env WBC_TIMING=pair) = an event pair recorded around the launch (+2-3 us per span)
+  bool timing_ext = true;
+  hipEvent_t cur_a = nullptr, cur_b = nullptr;   // events the next launch inside the open span attaches to
 };
 
 // ------------------------------------------------------------------------------------------ model
@@ -280,6 +285,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (const char* e = std::getenv("WBC_QP_REGROUP")) s->qp_regroup = (std::strcmp(e, "1") == 0);
   if (const char* e = std::getenv("WBC_ROLLOUT_PERSISTENT")) s->rollout_persistent = std::strcmp(e, "0") != 0;
   if (const char* e = std::getenv("WBC_OBS_SPLIT_MIN")) s->obs_split_min = (size_t)std::strtoull(e, nullptr, 10);
+  if (const char* e = std::getenv("WBC_TIMING")) s->timing_ext = std::strcmp(e, "pair") != 0;
   if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
@@ -345,7 +351,8 @@ static int span_begin(wbc_solver* s, int kind, hipStream_t st) {
   }
   wbc_solver::Span sp{kind, s->ev_pool[s->ev_next], s->ev_pool[s->ev_next + 1]};
   s->ev_next += 2;
-  HIP_TRY(hipEventRecord(sp.a, st));
+  if (s->timing_ext) { s->cur_a = sp.a; s->cur_b = sp.b; }   // WBC_LAUNCH hands them to the one launch of this span
+  else HIP_TRY(hipEventRecord(sp.a, st));
   s->spans.push_back(sp);
   return WBC_OK;
 }
@@ -354,9 +361,24 @@ static void timing_tick(wbc_solver* s) {  // once per API call: is this tick ins
 }
 static int span_end(wbc_solver* s, hipStream_t st) {
   if (!s->timing || !s->sample_now) return WBC_OK;
+  if (s->timing_ext) {
+    if (s->cur_a) { s->cur_a = s->cur_b = nullptr; s->spans.pop_back(); }   // no launch happened inside the span
+    return WBC_OK;
+  }
   HIP_TRY(hipEventRecord(s->spans.back().b, st));
   return WBC_OK;
 }
+
+// every kernel launch of this file: inside an instrumented span the dispatch carries the span's start/stop events
+#define WBC_LAUNCH(kern, grid, block, shmem, st, ...)                                                          \
+  do {                                                                                                         \
+    if (s->cur_a) {                                                                                            \
+      hipExtLaunchKernelGGL(kern, grid, block, shmem, st, s->cur_a, s->cur_b, 0, __VA_ARGS__);                 \
+      s->cur_a = s->cur_b = nullptr;                                                                           \
+    } else {                                                                                                   \
+      hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                           \
+    }                                                                                                          \
+  } while (0)
 
 extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
   if (!s) return fail(WBC_E_INVALID, "null solver");
@@ -391,14 +413,14 @@ static hipError_t launch_sweep(wbc_solver* s, const SweepArgs<T>& a, hipStream_t
   if constexpr ((MODE & SW_OBS) == 0) {  // the observer variants park too much per wave for 256-thread workgroups
     if (threads >= (size_t)256 * 8 * 64 * 2) {  // enough work for two full rounds of 8 waves per CU: share the tables
       const unsigned blocks = (unsigned)((threads + 255) / 256);
-      hipLaunchKernelGGL((dyn_sweep_kernel<T, MODE, 256>), dim3(blocks), dim3(256), 0, st,
+      WBC_LAUNCH((dyn_sweep_kernel<T, MODE, 256>), dim3(blocks), dim3(256), 0, st,
                          (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
       return hipGetLastError();
     }
   }
   {
     const unsigned blocks = (unsigned)((threads + 63) / 64);
-    hipLaunchKernelGGL((dyn_sweep_kernel<T, MODE, 64>), dim3(blocks), dim3(64), 0, st, (const DevModel<T>*)s->d_model,
+    WBC_LAUNCH((dyn_sweep_kernel<T, MODE, 64>), dim3(blocks), dim3(64), 0, st, (const DevModel<T>*)s->d_model,
                        to_dev_params<T>(s->params), a);
   }
   return hipGetLastError();
@@ -408,10 +430,10 @@ template <class T>
 static hipError_t launch_mass_jac(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
   const size_t threads = a.N * 4;
   if (threads >= (size_t)256 * 8 * 64 * 2) {
-    hipLaunchKernelGGL((mass_jac_kernel<T, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+    WBC_LAUNCH((mass_jac_kernel<T, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
                        (const DevModel<T>*)s->d_model, a);
   } else {
-    hipLaunchKernelGGL((mass_jac_kernel<T, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
+    WBC_LAUNCH((mass_jac_kernel<T, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
                        (const DevModel<T>*)s->d_model, a);
   }
   return hipGetLastError();
@@ -423,12 +445,12 @@ static hipError_t launch_rnea_step_mode(wbc_solver* s, const SweepArgs<T>& a, hi
   // 256-thread workgroups only where four waves' parked state fits the CU twice (one force chain, no observer)
   if constexpr ((MODE & RS_OBS) == 0 && !((MODE & RS_STEP) && (MODE & RS_H))) {
     if (threads >= (size_t)256 * 8 * 64 * 2) {
-      hipLaunchKernelGGL((rnea_step_kernel<T, MODE, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
+      WBC_LAUNCH((rnea_step_kernel<T, MODE, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
                          (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((rnea_step_kernel<T, MODE, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
+  WBC_LAUNCH((rnea_step_kernel<T, MODE, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
                      (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
   return hipGetLastError();
 }
@@ -537,10 +559,10 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     const dim3 grid((unsigned)((N + 15) / 16));
     const DevModel<T>* dm = (const DevModel<T>*)s->d_model;
     const DevParams<T> dp = to_dev_params<T>(s->params);
-    if (ob && mats) hipLaunchKernelGGL((fused_tick_kernel<T, true, true>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
-    else if (ob) hipLaunchKernelGGL((fused_tick_kernel<T, true, false>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
-    else if (mats) hipLaunchKernelGGL((fused_tick_kernel<T, false, true>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
-    else hipLaunchKernelGGL((fused_tick_kernel<T, false, false>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
+    if (ob && mats) WBC_LAUNCH((fused_tick_kernel<T, true, true>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
+    else if (ob) WBC_LAUNCH((fused_tick_kernel<T, true, false>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
+    else if (mats) WBC_LAUNCH((fused_tick_kernel<T, false, true>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
+    else WBC_LAUNCH((fused_tick_kernel<T, false, false>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(WBC_E_HIP, std::string("fused tick launch: ") + hipGetErrorString(e));
     return span_end(s, st);
@@ -564,10 +586,10 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     rc = span_begin(s, 2, s->aux);
     if (rc) return rc;
     if (N * 4 >= (size_t)256 * 8 * 64 * 2)
-      hipLaunchKernelGGL((observer_kernel<T, 256>), dim3((unsigned)((N * 4 + 255) / 256)), dim3(256), 0, s->aux,
+      WBC_LAUNCH((observer_kernel<T, 256>), dim3((unsigned)((N * 4 + 255) / 256)), dim3(256), 0, s->aux,
                          (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
     else
-      hipLaunchKernelGGL((observer_kernel<T, 64>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, s->aux,
+      WBC_LAUNCH((observer_kernel<T, 64>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, s->aux,
                          (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(WBC_E_HIP, std::string("observer launch: ") + hipGetErrorString(e));
@@ -597,20 +619,20 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   if (rc) return rc;
   if (s->qp_kernel == 1) {  // one QP per wavefront, factors in LDS (north-star sketch; kept for A/B)
     const unsigned blocks = (unsigned)((N + 3) / 4);
-    hipLaunchKernelGGL((qp_wave_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+    WBC_LAUNCH((qp_wave_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
   } else {                  // one QP per 16-lane DPP row, factors in registers
     if (s->qp_wpb == 4) {
       const unsigned blocks = (unsigned)((N + 15) / 16);
       if (s->qp_regroup)
-        hipLaunchKernelGGL((qp_group16_kernel<T, true, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+        WBC_LAUNCH((qp_group16_kernel<T, true, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
       else
-        hipLaunchKernelGGL((qp_group16_kernel<T, false, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+        WBC_LAUNCH((qp_group16_kernel<T, false, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
     } else {
       const unsigned blocks = (unsigned)((N + 3) / 4);
       if (obs_split)
-        hipLaunchKernelGGL((qp_group16_kernel<T, false, 1, true>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+        WBC_LAUNCH((qp_group16_kernel<T, false, 1, true>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
       else
-        hipLaunchKernelGGL((qp_group16_kernel<T, false, 1>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
+        WBC_LAUNCH((qp_group16_kernel<T, false, 1>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
     }
   }
   e = hipGetLastError();
@@ -647,7 +669,7 @@ static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void*
   a.N = N; a.q = (T*)q; a.v = (T*)v; a.M = (const T*)M; a.h = (const T*)h; a.Jc = (const T*)Jc;
   a.tau = (const T*)tau; a.f = (const T*)f; a.tau_ext = (const T*)tau_ext; a.tau_traj = (T*)tau_traj;
   a.dt = (T)s->params.dt;
-  hipLaunchKernelGGL((integrate_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
+  WBC_LAUNCH((integrate_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
                      (const DevModel<T>*)s->d_model, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("integrate launch: ") + hipGetErrorString(e));
@@ -696,11 +718,11 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   const DevRefParams<T>* G = (const DevRefParams<T>*)s->d_ref;
   const bool ob = s->params.observer_order > 0;
   if (plan) {
-    if (ob) hipLaunchKernelGGL((rollout_kernel<T, true, true>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
-    else hipLaunchKernelGGL((rollout_kernel<T, false, true>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+    if (ob) WBC_LAUNCH((rollout_kernel<T, true, true>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+    else WBC_LAUNCH((rollout_kernel<T, false, true>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
   } else {
-    if (ob) hipLaunchKernelGGL((rollout_kernel<T, true, false>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
-    else hipLaunchKernelGGL((rollout_kernel<T, false, false>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+    if (ob) WBC_LAUNCH((rollout_kernel<T, true, false>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+    else WBC_LAUNCH((rollout_kernel<T, false, false>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
@@ -780,7 +802,7 @@ static int reference_impl(wbc_solver* s, size_t N, const void* q, const void* v,
   RefArgs<T> a;
   a.N = N; a.q = (const T*)q; a.v = (const T*)v; a.plan = (const T*)plan; a.t = (T)t;
   a.w_des = (T*)w_des; a.vdot_des = (T*)vdot_des; a.com = (T*)com;
-  hipLaunchKernelGGL((com_reference_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
+  WBC_LAUNCH((com_reference_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
                      (const DevModel<T>*)s->d_model, (const DevRefParams<T>*)s->d_ref, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("reference launch: ") + hipGetErrorString(e));
