@@ -248,10 +248,12 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
 // EXT: as for mass_jac_body; additionally the step workspace goes to the workgroup's LDS image wsl[word][16].
 // `before_refs()` runs after the state loads are issued and before w_des / vdot_des are read (the persistent tracking
 // rollout waits there for the planner role that writes them).
+// `after_geom()` (wavefront roles, EXT != 0): the lever arms WS_D and, observer off, the target wrench WS_B are in the LDS
+// image -- all the QP needs to assemble and factor H -- long before tau_partial is; the role raises its first flag there.
 struct NoWait { WBC_DEV void operator()() const {} };
-template <class T, int MODE, int BLOCK, int EXT, class BeforeRefs = NoWait>
+template <class T, int MODE, int BLOCK, int EXT, class BeforeRefs = NoWait, class AfterGeom = NoWait>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
-                            T* wsl, BeforeRefs before_refs = BeforeRefs()) {
+                            T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom()) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   WBC_LAUNDERED_TID(tx);
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
@@ -260,6 +262,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
   constexpr bool TWO = STEP && WH;              // h and tau_partial both wanted: two force chains; else one (merged)
   constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
+  constexpr bool EARLY = EXT != 0 && STEP;      // role inside the fused tick: publish the foot lever arms first
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
   if constexpr (EXT == 0) {
     for (int i = tx; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
@@ -302,6 +305,33 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   {
     const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
+  }
+  T sn3[3] = {0, 0, 0}, cs3[3] = {0, 0, 0};
+  if constexpr (EARLY) {
+    // The QP waves can assemble and factor H from the four lever arms alone, so those go out ahead of the force
+    // recursions: d = r_0 + E_0 (r_1 + E_1 (r_2 + E_2 d_foot)), the same expression the return sweep evaluates (which
+    // then does not store WS_D again).  The joint rotations are rebuilt in the forward sweep from the same sin / cos
+    // (laundered here, so that the compiler does not keep 27 matrix entries alive until then).
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sincos_t(ql[k], &sn3[k], &cs3[k]);
+    V3<T> d = mk<T>(CS(129), CS(130), CS(131));
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+      const int o = JOINT_WORDS * k;
+      T s_ = sn3[k], c_ = cs3[k];
+      asm volatile("" : "+v"(s_), "+v"(c_));
+      M3<T> E;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + c_ * CS(o + 9 + e) + s_ * CS(o + 18 + e);
+      d = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29)) + mul(E, d);
+    }
+    M3<T> R0;
+    MAKE_R(R0, qx, qy, qz, qw);
+    const V3<T> dw0 = mul(R0, d);
+    WSTL(WS_D + 0, 3, dw0.x);
+    WSTL(WS_D + 1, 3, dw0.y);
+    WSTL(WS_D + 2, 3, dw0.z);
+    after_geom();
   }
   const T bm = model->base_m;
   const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
@@ -350,7 +380,8 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   for (int k = 0; k < 3; ++k) {
     const int o = JOINT_WORDS * k;
     T sn, cs;
-    sincos_t(ql[k], &sn, &cs);
+    if constexpr (EARLY) { sn = sn3[k]; cs = cs3[k]; }
+    else sincos_t(ql[k], &sn, &cs);
     M3<T> E;
 #pragma unroll
     for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
@@ -480,9 +511,11 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
   }
   if (STEP) {
-    WSTL(WS_D + 0, 3, dw.x);
-    WSTL(WS_D + 1, 3, dw.y);
-    WSTL(WS_D + 2, 3, dw.z);
+    if constexpr (!EARLY) {
+      WSTL(WS_D + 0, 3, dw.x);
+      WSTL(WS_D + 1, 3, dw.y);
+      WSTL(WS_D + 2, 3, dw.z);
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       WSTL(WS_JCL + 0 + k, 9, jw[k].x);

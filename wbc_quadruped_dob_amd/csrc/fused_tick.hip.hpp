@@ -38,18 +38,26 @@ namespace wbc {
 // gravity terms, beta = C^T v - g, the update of {integ, r}) and leaves rhat in LDS; the QP waves wait for both producers
 // and subtract rhat from b and tau_partial themselves.
 // MATS = false (the caller wants tau, f only): no mass_jac role, and the rnea role runs the single merged force chain.
+// Staged hand-over (QpSync, qp_group16.hip.hpp): the rnea role publishes the four lever arms and w_des right after its
+// state loads (flag `gready`) -- H and its factor need nothing else -- rhat follows from the observer role (`oready`,
+// first needed for g = -A^T S b) and tau_partial + the own-leg Jacobian blocks when the force recursions are done
+// (`ready`, first needed in the torque map).  Observer off, N = 4 096: 25.5 -> 22.5 us per tick.
 template <class T, bool OBSERVER, bool MATS>
 __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready;
+  __shared__ int ready, gready, oready;   // rnea role done / its lever arms are out / observer role done
   const int wave = (int)(threadIdx.x >> 6);
   // The four QP wavefronts stage the tables; the producers issue their state loads first and join the ONE workgroup
   // barrier from inside their bodies (EXT = 2), so table staging and state loads share a memory round trip.
   if (wave == 4) {
-    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl);
+    int* const gflag = &gready;
+    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [gflag] __device__() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
   } else if (wave == 5) {
@@ -59,16 +67,15 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
     if constexpr (OBSERVER) {
       WBC_OBS_ROLE(2, a);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   } else {
     for (int i = threadIdx.x; i < CST_WORDS; i += 256) cst[i] = model->cst[i];
     if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-    if (threadIdx.x == 0) ready = 0;
+    if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; }
     __syncthreads();
-    while (__hip_atomic_load(&ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (OBSERVER ? 2 : 1)) __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl);
+    const QpSync sy{&gready, &oready, &ready, 1, 1, 1};   // the QP waits for each piece where it first needs it
+    qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
   }
 }
 
@@ -98,13 +105,12 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready, mready, rready;
+  __shared__ int ready, gready, oready, mready, rready;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) { ready = 0; mready = 0; rready = 0; }
+  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
-  constexpr int NPROD = OBSERVER ? 2 : 1;
   constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
   T* const traj0 = ia.tau_traj;
   T* const com0 = ra.com;
@@ -140,11 +146,15 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     if (wave == 4) {
       int* const rflag = &rready;
       const int rneed = t + 1;
+      int* const gflag = &gready;
       rnea_step_body<T, RS_STEP | RS_H, 64, 1>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
+      }, [gflag] __device__() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -156,12 +166,11 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       if constexpr (OBSERVER) {
         WBC_OBS_ROLE(1, at);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     } else {
-      while (__hip_atomic_load(&ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NPROD * (t + 1)) __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-      qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl);
+      const QpSync sy{&gready, &oready, &ready, t + 1, t + 1, t + 1};
+      qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl, &sy);
     }
     __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator
     __syncthreads();   // barrier B: q, v of the next tick

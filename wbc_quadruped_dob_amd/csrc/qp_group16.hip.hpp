@@ -130,8 +130,21 @@ template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]
 // by the sweep phase of the same workgroup) instead of from HBM.
 // RHAT (with WSLDS, observer-on fused tick): the observer role left rhat in the LDS image; b and tau_partial are
 // completed here (b -= rhat_base, tau_partial -= rhat_joint).
+// QpSync (WSLDS only): the producer roles of the fused tick publish the workspace in three steps, each behind an LDS
+// counter -- lever arms (+ w_des) early, rhat when the observer role is done, tau_partial and the own-leg Jacobian
+// blocks when the force recursions are -- and the QP waits for each only where it first needs it: H and its factor
+// come from the lever arms alone, the target wrench enters with g, tau_partial only in the torque map.
+struct QpSync {
+  int* geom; int* rhat; int* fin;
+  int need_geom, need_rhat, need_fin;
+};
+WBC_DEV void qp_wait(int* flag, int need) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <class T, bool REGROUP, int WPB, bool WSLDS, bool RHAT = false>
-WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl) {
+WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr) {
   static_assert(!REGROUP || WPB == 4, "re-dealing needs the 16 rows of a 4-wave workgroup");
   static_assert(!WSLDS || (WPB == 4 && !REGROUP), "the fused tick pairs one sweep wavefront with four QP wavefronts");
   __shared__ G16Lds<T> lds_all[WPB];
@@ -169,17 +182,14 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   int mask = a.mask[s32] & 0xF;
   bool on = (mask >> f) & 1;
   const bool geom_jc = !WSLDS && a.Jc != nullptr;   // uniform: lever arms / own-leg blocks from Jc (see QpArgs)
+  const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
+  const T mu_f = GLD(a.mu, f);
+  if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
   T d_me = 0;
   if (geom_jc) {   // -[d]x block of my foot's Jacobian rows: d_x = Jc[(3f+1), 5], d_y = Jc[(3f+2), 3], d_z = Jc[(3f), 4]
     const int comp = c3 == 0 ? (3 * f + 1) * 18 + 5 : (c3 == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4);
     if (isvar) d_me = GLD(a.Jc, comp);
   } else if (isvar) d_me = WSLD(WS_D + v);
-  const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
-  const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
-  const T mu_f = GLD(a.mu, f);
-  T b[6];
-  b[0] = dppx<0x150 + 0>(b_ld); b[1] = dppx<0x150 + 1>(b_ld); b[2] = dppx<0x150 + 2>(b_ld);
-  b[3] = dppx<0x150 + 3>(b_ld); b[4] = dppx<0x150 + 4>(b_ld); b[5] = dppx<0x150 + 5>(b_ld);
 
   // ------------------------------------------------------------------ H row (a7) : H = A^T S A + alpha I
   // A = [I ; [d_f]x] per stance foot.  u = column c3 of [d_f]x for my own foot; w_j likewise for column j.
@@ -204,12 +214,6 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     if (isvar && v == j) h += prm.alpha;
     Hr[j] = isvar ? h : (T)0;  // spare lanes: zeros
   });
-  T g_me;
-  {
-    const T bs = (c3 == 0 ? b[0] : (c3 == 1 ? b[1] : b[2]));
-    g_me = isvar ? -(Sme * bs + u0 * b[3] + u1 * b[4] + u2 * b[5]) : (T)0;
-  }
-
   // ------------------------------------------------------------------ Cholesky H = L L^T, rows in lanes
   T linv_me = 0;  // 1 / L[me][me]
   sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
@@ -243,6 +247,17 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; Jr[c] = isvar ? J0[v * 12 + c] : (T)0; });
 
+  // ------------------------------------------------------------------ g = -A^T S b (b = w_des - rhat_base enters here)
+  T g_me;
+  {
+    if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
+    const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
+    T b[6];
+    b[0] = dppx<0x150 + 0>(b_ld); b[1] = dppx<0x150 + 1>(b_ld); b[2] = dppx<0x150 + 2>(b_ld);
+    b[3] = dppx<0x150 + 3>(b_ld); b[4] = dppx<0x150 + 4>(b_ld); b[5] = dppx<0x150 + 5>(b_ld);
+    const T bs = (c3 == 0 ? b[0] : (c3 == 1 ? b[1] : b[2]));
+    g_me = isvar ? -(Sme * bs + u0 * b[3] + u1 * b[4] + u2 * b[5]) : (T)0;
+  }
   // ------------------------------------------------------------------ unconstrained minimum x = -J J^T g
   T x_me;
   {
@@ -534,6 +549,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   }
 
   // ------------------------------------------------------------------ outputs: f, tau (a9), status
+  if constexpr (WSLDS) { if (sync) qp_wait(sync->fin, sync->need_fin); }
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     int jm = 0;   // caller's index of my joint (leg f, joint c3)
