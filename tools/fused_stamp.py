@@ -1,0 +1,31 @@
+"""Diagnostic: timeline of the fused tick's wavefront roles (needs the -DWBC_FUSED_STAMP build:
+   hipcc ... -DWBC_FUSED_STAMP -o lib/libwbc_hip_fstamp.so;  WBC_LIB=.../libwbc_hip_fstamp.so python tools/fused_stamp.py).
+In that build the `pf` output carries 100 MHz timestamps (wall_clock64) per workgroup instead of foot positions."""
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+import wbc_quadruped_dob_amd as W
+from wbc_quadruped_dob_amd import synth
+m = W.Model.from_urdf(W.SYNTHETIC_URDF)
+names = ["QP0 entry", "QP0 tables staged, inputs issued", "QP0 lever arms seen", "QP0 factor done", "QP0 rhat seen", "QP0 iterations done",
+         "QP0 tau_partial seen", "rnea: lever arms out", "rnea: done", "mass_jac: done", "obs done / QP3 iterations done", "QP0 stores issued"]
+for cfg, obs in ((2, 0), (3, 1)):
+    n = 4096
+    P = synth.default_params(observer_order=obs); s = W.Solver(m, W.Params.from_dict(P), max_batch=n)
+    B = synth.make_batch(cfg, n, m.total_mass)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+    inp = [dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")]
+    mask = torch.from_numpy(B["mask"]).cuda()
+    extra = []
+    if obs:
+        ig = s.dynamics(inp[0], inp[1], want=("p",))["p"]
+        extra = [dev(B["tau_prev"]), dev(B["f_prev"]), ig, torch.zeros_like(ig)]
+    for _ in range(5):
+        out = s.step(*inp, mask, *extra, want_mats=True)
+    torch.cuda.synchronize()
+    st = out["pf"].cpu().numpy()[:, ::16]            # [12 slots, workgroups]
+    t0 = st[0]
+    rel = (st - t0[None, :]) * 10.0                   # ns since the workgroup's first stamp
+    print("config", cfg, "observer", obs, " kernel-wide span (first entry -> last stamp): %.2f us" % ((st.max() - st[0].min()) * 1e-2))
+    print("  workgroup entry spread: %.2f us" % ((t0.max() - t0.min()) * 1e-2))
+    for i, nm in enumerate(names):
+        print("  %-36s median %+7.2f us   p90 %+7.2f us" % (nm, np.median(rel[i]) * 1e-3, np.percentile(rel[i], 90) * 1e-3))

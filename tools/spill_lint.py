@@ -4,7 +4,9 @@
 Why: hipcc 7.2 once placed `scratch_store ... Folded Spill` instructions into the exit block of a divergent loop BEFORE the
 `s_or_b64 exec, exec, <saved>` that re-enables the lanes (observer_kernel<double>, caught by the parity tests as garbage
 rhat).  A spill store in that position writes nothing for the lanes that are masked off and the later reload returns junk.
-VGPR spills themselves are fine; this flags only spill stores (and reloads) that sit between a block label and the block's exec restore.
+VGPR spills themselves are fine; this flags only spill stores (and reloads) that sit between the label of a JOIN block and
+its exec restore with nothing but bookkeeping (scalar ops, lane writes) around them -- a block that does real work before the
+restore is the body of a masked region, whose spills serve the lanes that run it.
 `v_writelane` SGPR spills ignore EXEC and are not flagged.
 
 usage: tools/spill_lint.py [file.s]     (without a file: compiles csrc/wbc_api.hip to /tmp/asm/wbc_lint.s first)
@@ -29,31 +31,38 @@ def compile_asm(out="/tmp/asm/wbc_lint.s"):
 def lint(path):
     """Returns [(kernel, label, line_no, text)] for every masked spill store."""
     bad = []
-    kernel, label = None, None
+    kernel, label, work = None, None, False
     pending = []          # spill stores seen in the current block before any exec restore
     restore = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
     spill = re.compile(r"^\s*(scratch|buffer)_(store|load)\S*\s.*Folded (Spill|Reload)")
     lab = re.compile(r"^(\.LBB\d+_\d+):")
     fn = re.compile(r"^(_Z\w+):")
+    # bookkeeping that may legitimately sit in front of the exec restore of a join block
+    book = re.compile(r"^\s*($|;|\.|s_|v_writelane|v_readlane|v_readfirstlane)")
     with open(path) as f:
         for no, line in enumerate(f, 1):
             m = fn.match(line)
             if m:
-                kernel, label, pending = m.group(1), None, []
+                kernel, label, pending, work = m.group(1), None, [], False
                 continue
             m = lab.match(line)
             if m:
-                label, pending = m.group(1), []
+                label, pending, work = m.group(1), [], False
                 continue
             if label is None:
                 continue
             if spill.match(line):
                 pending.append((no, line.strip()))
             elif restore.match(line):
-                bad += [(kernel, label, n, t) for n, t in pending]
+                if not work:
+                    bad += [(kernel, label, n, t) for n, t in pending]
                 pending = []
             elif re.match(r"^\s*s_(cbranch|branch|endpgm)", line):
                 pending = []      # block ends without restoring exec: the stores ran under the block's own mask
+            elif not book.match(line):
+                # real work before the restore: this block is the BODY of a masked region (its spills / reloads serve the
+                # lanes that run it, the restore at its end closes the region) -- not a join block
+                work = True
     return bad
 
 

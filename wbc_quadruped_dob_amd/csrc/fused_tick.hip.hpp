@@ -50,31 +50,48 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
   __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready, gready, oready;   // rnea role done / its lever arms are out / observer role done
   const int wave = (int)(threadIdx.x >> 6);
+#ifdef WBC_FUSED_STAMP   // diagnostic build: the pf output carries the role timestamps (slot, workgroup) instead of foot positions
+  double* const stamp = (double*)a.pf;
+  const unsigned stampN = (unsigned)a.N;
+  a.pf = nullptr;
+#define FSTAMP(slot) do { if (stamp) WBC_FSTAMP(stamp, stampN, slot); } while (0)
+  if (wave == 0) FSTAMP(0);
+#else
+#define FSTAMP(slot) do {} while (0)
+#endif
   // The four QP wavefronts stage the tables; the producers issue their state loads first and join the ONE workgroup
   // barrier from inside their bodies (EXT = 2), so table staging and state loads share a memory round trip.
   if (wave == 4) {
     int* const gflag = &gready;
-    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [gflag] __device__() {
+    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [=] __device__() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      FSTAMP(7);
     });
+    FSTAMP(8);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
   } else if (wave == 5) {
     if constexpr (MATS) mass_jac_body<T, 64, 2>(model, a, cst, zidx_s);
     else __syncthreads();
+    FSTAMP(9);
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
       WBC_OBS_ROLE(2, a);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      FSTAMP(10);      // (observer builds: slot 10 is the observer role's end, otherwise QP wave 3's)
     }
   } else {
     for (int i = threadIdx.x; i < CST_WORDS; i += 256) cst[i] = model->cst[i];
     if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
     if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; }
     __syncthreads();
+#ifdef WBC_FUSED_STAMP
+    const QpSync sy{&gready, &oready, &ready, 1, 1, 1, stamp, stampN};
+#else
     const QpSync sy{&gready, &oready, &ready, 1, 1, 1};   // the QP waits for each piece where it first needs it
+#endif
     qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
   }
 }

@@ -137,7 +137,18 @@ template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]
 struct QpSync {
   int* geom; int* rhat; int* fin;
   int need_geom, need_rhat, need_fin;
+#ifdef WBC_FUSED_STAMP   // diagnostic build (tools/fused_stamp.py): 100 MHz timestamps of the roles, one column per workgroup
+  double* stamp; unsigned stampN;
+#endif
 };
+#ifdef WBC_FUSED_STAMP
+#define WBC_FSTAMP(ptr, N_, slot) do { if ((threadIdx.x & 63) == 0) (ptr)[(size_t)(slot) * (N_) + (size_t)blockIdx.x * 16] = (double)wall_clock64(); } while (0)
+#define WBC_QSTAMP(slot) do { if (sync && sync->stamp && (tx >> 6) == 0) WBC_FSTAMP(sync->stamp, sync->stampN, slot); } while (0)
+#define WBC_QSTAMP3(slot) do { if (!RHAT && sync && sync->stamp && (tx >> 6) == 3) WBC_FSTAMP(sync->stamp, sync->stampN, slot); } while (0)
+#else
+#define WBC_QSTAMP(slot) do {} while (0)
+#define WBC_QSTAMP3(slot) do {} while (0)
+#endif
 WBC_DEV void qp_wait(int* flag, int need) {
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -184,7 +195,9 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   const bool geom_jc = !WSLDS && a.Jc != nullptr;   // uniform: lever arms / own-leg blocks from Jc (see QpArgs)
   const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
   const T mu_f = GLD(a.mu, f);
+  WBC_QSTAMP(1);
   if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
+  WBC_QSTAMP(2);
   T d_me = 0;
   if (geom_jc) {   // -[d]x block of my foot's Jacobian rows: d_x = Jc[(3f+1), 5], d_y = Jc[(3f+2), 3], d_z = Jc[(3f), 4]
     const int comp = c3 == 0 ? (3 * f + 1) * 18 + 5 : (c3 == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4);
@@ -250,7 +263,9 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   // ------------------------------------------------------------------ g = -A^T S b (b = w_des - rhat_base enters here)
   T g_me;
   {
+    WBC_QSTAMP(3);
     if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
+    WBC_QSTAMP(4);
     const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
     T b[6];
     b[0] = dppx<0x150 + 0>(b_ld); b[1] = dppx<0x150 + 1>(b_ld); b[2] = dppx<0x150 + 2>(b_ld);
@@ -549,7 +564,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   }
 
   // ------------------------------------------------------------------ outputs: f, tau (a9), status
+  WBC_QSTAMP(5);
+  WBC_QSTAMP3(10);
   if constexpr (WSLDS) { if (sync) qp_wait(sync->fin, sync->need_fin); }
+  WBC_QSTAMP(6);
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     int jm = 0;   // caller's index of my joint (leg f, joint c3)
@@ -585,6 +603,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
 #endif
     }
   }
+  WBC_QSTAMP(11);
 #undef GST
 #undef WSLD
 #undef GLD
