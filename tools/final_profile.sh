@@ -18,6 +18,11 @@ python bench.py --config 5 --steps 100 --warmup 10 > "$O/bench_cfg5_h20_n1024.js
 python bench.py --config 5 --steps 100 --warmup 10 --batch 128 > "$O/bench_cfg5_h20_n128.json" 2>> "$O/bench.err"
 python bench.py --config 5 --tracking --steps 100 --warmup 10 > "$O/bench_cfg5_tracking_h20_n1024.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 20 --warmup 3 --batch 32768 > "$O/bench_cfg5_h20_n32768.json" 2>> "$O/bench.err"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu --no-latency --large-batch 0 > "$O/bench_torchrun_1rank.json" 2>> "$O/bench.err"
+# role timeline of the fused tick (diagnostic build, made beforehand: hipcc ... -DWBC_FUSED_STAMP -o lib/libwbc_hip_fstamp.so)
+if [ -f wbc_quadruped_dob_amd/lib/libwbc_hip_fstamp.so ]; then
+  WBC_LIB=$R/wbc_quadruped_dob_amd/lib/libwbc_hip_fstamp.so python tools/fused_stamp.py > "$O/fused_timeline.txt" 2>> "$O/bench.err"
+fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- python3 "$R/bench.py" --config 5 --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5trk -- python3 "$R/bench.py" --config 5 --tracking --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"

@@ -56,7 +56,8 @@ struct wbc_solver {
                                       // as its own kernel on the second stream beside dyn_sweep<no observer> (observer.hip.hpp).
                                       // Measured at N = 262 144: fp32 0.482 -> 0.441 ms per tick, fp64 0.713 -> 0.810 ms (slower), and
                                       // slower for both at N = 32 768 -> not the default
-  size_t fused_max = 4096;  // observer-off ticks of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
+  size_t fused_max = 4096;  // ticks / rollouts of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
+  size_t fused_max_noobs = 8192;  // observer-off ticks: the fused kernel still wins with two rounds of workgroups (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on); WBC_FUSED_MAX sets both
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
@@ -286,7 +287,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (const char* e = std::getenv("WBC_ROLLOUT_PERSISTENT")) s->rollout_persistent = std::strcmp(e, "0") != 0;
   if (const char* e = std::getenv("WBC_OBS_SPLIT_MIN")) s->obs_split_min = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_TIMING")) s->timing_ext = std::strcmp(e, "pair") != 0;
-  if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = (size_t)std::strtoull(e, nullptr, 10);
+  if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = s->fused_max_noobs = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
@@ -551,7 +552,8 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   const bool geom_from_jc = mats && s->sweep_mode == 1 && s->qp_kernel == 0;
   qa.Jc = geom_from_jc ? (const T*)out->Jc : nullptr;
   a.ws_geom = geom_from_jc ? 0 : 1;
-  if ((mats || !out->pf) && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 && N <= s->fused_max) {
+  if ((mats || !out->pf) && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 &&
+      N <= (ob ? s->fused_max : s->fused_max_noobs)) {
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
     rc = span_begin(s, 3, st);
