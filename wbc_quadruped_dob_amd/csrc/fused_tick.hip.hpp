@@ -27,6 +27,13 @@ namespace wbc {
 #else
 #define WBC_OBS_ROLE(EXT_, ARGS_) observer_body<T, 64, EXT_>(model, prm, ARGS_, cst, wsl)
 #endif
+// fused tick, observer on: the observer role is TWO wavefronts (base rows -> rhat_base, which the QP's b waits for; joint
+// rows -> rhat_joint, needed only in the torque map); -DWBC_OBS_ONE_WAVE: one wavefront does both
+#ifdef WBC_OBS_ONE_WAVE
+constexpr int FUSED_OBS_WAVES = 1;
+#else
+constexpr int FUSED_OBS_WAVES = 2;
+#endif
 
 // The front half is SPLIT by consumer.  Six wavefronts per workgroup of
 // 16 states: wave 4 runs rnea_step_body (bias forces h, and the 66-word step workspace -- all the QP needs -- into LDS),
@@ -43,7 +50,7 @@ namespace wbc {
 // first needed for g = -A^T S b) and tau_partial + the own-leg Jacobian blocks when the force recursions are done
 // (`ready`, first needed in the torque map).  Observer off, N = 4 096: 25.5 -> 22.5 us per tick.
 template <class T, bool OBSERVER, bool MATS>
-__global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+__global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   __shared__ T cst[CST_WORDS];
   __shared__ int zidx_s[64];
@@ -77,20 +84,28 @@ __global__ __launch_bounds__(OBSERVER ? 448 : 384, 1) void fused_tick_kernel(con
     FSTAMP(9);
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
-      WBC_OBS_ROLE(2, a);
+      if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 2, 1>(model, prm, a, cst, wsl);   // base rows
+      else WBC_OBS_ROLE(2, a);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       FSTAMP(10);      // (observer builds: slot 10 is the observer role's end, otherwise QP wave 3's)
+    }
+  } else if (OBSERVER && FUSED_OBS_WAVES == 2 && wave == 7) {
+    if constexpr (OBSERVER && FUSED_OBS_WAVES == 2) {
+      observer_body<T, 64, 2, 2>(model, prm, a, cst, wsl);                                      // joint rows
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // counts with the rnea role: both feed the torque map
     }
   } else {
     for (int i = threadIdx.x; i < CST_WORDS; i += 256) cst[i] = model->cst[i];
     if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
     if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; }
     __syncthreads();
+    constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint-row wavefront)
 #ifdef WBC_FUSED_STAMP
-    const QpSync sy{&gready, &oready, &ready, 1, 1, 1, stamp, stampN};
+    const QpSync sy{&gready, &oready, &ready, 1, 1, NFIN, stamp, stampN};
 #else
-    const QpSync sy{&gready, &oready, &ready, 1, 1, 1};   // the QP waits for each piece where it first needs it
+    const QpSync sy{&gready, &oready, &ready, 1, 1, NFIN};   // the QP waits for each piece where it first needs it
 #endif
     qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
   }
@@ -151,6 +166,13 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
       }
+      if constexpr (OBSERVER && FUSED_OBS_WAVES == 2) {
+        // idle until M, Jc exist: this wavefront takes the JOINT rows of the observer update (rhat_joint, which the QP
+        // needs only in its torque map); wave 6 is left with the base rows, whose rhat_base the QP's b waits for
+        observer_body<T, 64, 1, 2>(model, prm, at, cst, wsl);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has published them
       // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
       while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(2);
@@ -181,12 +203,14 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&mready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {
-        WBC_OBS_ROLE(1, at);
+        if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1>(model, prm, at, cst, wsl);   // base rows
+        else WBC_OBS_ROLE(1, at);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     } else {
-      const QpSync sy{&gready, &oready, &ready, t + 1, t + 1, t + 1};
+      constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint rows, run by the integrator wavefront)
+      const QpSync sy{&gready, &oready, &ready, t + 1, t + 1, NFIN * (t + 1)};
       qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl, &sy);
     }
     __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator

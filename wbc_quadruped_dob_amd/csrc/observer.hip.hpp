@@ -20,9 +20,14 @@ namespace wbc {
 // EXT = 0: the stand-alone kernel below.  EXT = 1 / 2: the observer ROLE of the fused tick / persistent rollout kernels
 // (fused_tick.hip.hpp): one wavefront of a larger workgroup that owns 16 states, constant table staged by other wavefronts
 // (EXT = 2: this body joins the workgroup barrier after issuing its state loads), rhat goes to the LDS image wsl.
-template <class T, int BLOCK, int EXT>
+// PART (roles only): 0 = the whole update; 1 = base rows only (momentum / gravity sums over the legs, rhat_base: what the QP's
+// target wrench b waits for); 2 = joint rows only (rhat_joint, needed in the torque map).  Two wavefronts running parts 1
+// and 2 side by side share the sweeps' arithmetic but each drops the other's projections and update.
+template <class T, int BLOCK, int EXT, int PART = 0>
 WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext, T* wsl) {
   static_assert(EXT == 0 || BLOCK == 64, "one wavefront");
+  static_assert(PART == 0 || EXT != 0, "split parts exist only as roles");
+  constexpr bool BASE = PART != 2, JOINTS = PART != 1;
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
   const T* cst = EXT ? cst_ext : cst_own;
   unsigned tx = threadIdx.x;
@@ -141,8 +146,8 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   for (int k = 0; k < 3; ++k) jw[k] = mul(R, jc[k]);
 
   // ---- base rows: the four legs + the base body itself
-  T p_b[6], beta_b[6];
-  {
+  T p_b[6] = {0, 0, 0, 0, 0, 0}, beta_b[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (BASE) {
     const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
     T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
     xrow_sum_k<T, 12>(xb);
@@ -159,27 +164,29 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
   if (prm.observer_order > 0) {
     const V3<T> fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
-    const V3<T> dxf = cross(dw, fp);
-    T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
-    xrow_sum_k<T, 6>(ub);
     const T dt = prm.dt;
     const bool o1 = prm.observer_order == 1;
+    if constexpr (BASE) {
+      const V3<T> dxf = cross(dw, fp);
+      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+      xrow_sum_k<T, 6>(ub);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const T r0 = OLDU(a.obs_r, c);
-      const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
-      const T e = p_b[c] - ig;
-      rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
-      p_b[c] = ig;
+      for (int c = 0; c < 6; ++c) {
+        const T r0 = OLDU(a.obs_r, c);
+        const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
+        const T e = p_b[c] - ig;
+        rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        p_b[c] = ig;
+      }
+      // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
+      // of the wave before any lane stores to it
+      OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+      if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
     }
-    // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
-    // of the wave before any lane stores to it
-    OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
-    if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
-    OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
-    if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < (JOINTS ? 3 : 0); ++k) {
       const int c = 6 + jx[k];
       const T r0 = OLDV(a.obs_r, c);
       const T u = OLDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
@@ -193,10 +200,14 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
       OSTV(a.obs_r, c, rl[k]);
     }
   }
-  ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
-  if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
+  if constexpr (BASE) {
+    ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
+    if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
+  }
+  if constexpr (JOINTS) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
+    for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
+  }
 #undef ORHAT
 #undef OST4
 #undef OSTV

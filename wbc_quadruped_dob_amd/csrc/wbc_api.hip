@@ -561,8 +561,9 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     const dim3 grid((unsigned)((N + 15) / 16));
     const DevModel<T>* dm = (const DevModel<T>*)s->d_model;
     const DevParams<T> dp = to_dev_params<T>(s->params);
-    if (ob && mats) WBC_LAUNCH((fused_tick_kernel<T, true, true>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
-    else if (ob) WBC_LAUNCH((fused_tick_kernel<T, true, false>), grid, dim3(448), 0, st, dm, dp, a, qa, s->jmap);
+    constexpr unsigned obs_threads = 384 + 64 * FUSED_OBS_WAVES;
+    if (ob && mats) WBC_LAUNCH((fused_tick_kernel<T, true, true>), grid, dim3(obs_threads), 0, st, dm, dp, a, qa, s->jmap);
+    else if (ob) WBC_LAUNCH((fused_tick_kernel<T, true, false>), grid, dim3(obs_threads), 0, st, dm, dp, a, qa, s->jmap);
     else if (mats) WBC_LAUNCH((fused_tick_kernel<T, false, true>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
     else WBC_LAUNCH((fused_tick_kernel<T, false, false>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
     e = hipGetLastError();
