@@ -5,9 +5,9 @@
 // -- before the QP may start, and a round trip of the 66-word step workspace through HBM.  Here a workgroup owns 16
 // consecutive states and hands the workspace over in LDS; M/h/Jc stores drain behind the QP.
 //
-// The front half is split by consumer into wavefront roles (below).  N = 4 096, observer off: 25.6 us per tick against
-// 32.5 us for the two-kernel tick (155 M vs 126 M control-steps/s); observer on (a seventh wavefront): 29.3 us against
-// 34.3 us (140 M vs 120 M).  (A whole-sweep-then-QP fusion was measured before this one: -7 % / no gain.)
+// The front half is split by consumer into wavefront roles (below).  N = 4 096, observer off: 22.3 us per tick against
+// 32.5 us for the two-kernel tick (184 M vs 126 M control-steps/s); observer on (two more wavefronts): 21.2 us against
+// 34.3 us (193 M vs 120 M).  (A whole-sweep-then-QP fusion was measured before this one: -7 % / no gain.)
 // Larger batches keep the two-kernel tick: the sweep is HBM-bound there and wants all lanes of 8 waves per CU, which
 // the fused kernels' LDS (100 kB per workgroup in fp64) does not allow; measured slower from N = 8 192 on.
 #pragma once
@@ -41,9 +41,10 @@ constexpr int FUSED_OBS_WAVES = 2;
 // and run the GRF QP.  The QP therefore starts after the ~1/3 of the dynamics it depends on, and the CRBA and its
 // stores overlap with it on otherwise idle issue slots.  No barrier after the table staging: the hand-over is an
 // LDS flag (the four QP waves poll it; all waves of a workgroup are resident, so the producer always runs).
-// OBSERVER on: a seventh wavefront takes the observer role (rnea_step_body<RS_OBS | RS_OBSW>: velocities, momenta,
-// gravity terms, beta = C^T v - g, the update of {integ, r}) and leaves rhat in LDS; the QP waves wait for both producers
-// and subtract rhat from b and tau_partial themselves.
+// OBSERVER on: two more wavefronts take the observer role (observer_body: velocities, momenta, gravity terms,
+// beta = C^T v - g, the update of {integ, r}), split by rows: wave 6 the base rows (rhat_base -> LDS, flag `oready`; the
+// QP's b waits for it), wave 7 the joint rows (rhat_joint -> LDS, counted on `ready`; needed in the torque map only).
+// The QP waves subtract rhat from b and tau_partial themselves.
 // MATS = false (the caller wants tau, f only): no mass_jac role, and the rnea role runs the single merged force chain.
 // Staged hand-over (QpSync, qp_group16.hip.hpp): the rnea role publishes the four lever arms and w_des right after its
 // state loads (flag `gready`) -- H and its factor need nothing else -- rhat follows from the observer role (`oready`,
