@@ -29,3 +29,26 @@ for cfg, obs in ((2, 0), (3, 1)):
     print("  workgroup entry spread: %.2f us" % ((t0.max() - t0.min()) * 1e-2))
     for i, nm in enumerate(names):
         print("  %-36s median %+7.2f us   p90 %+7.2f us" % (nm, np.median(rel[i]) * 1e-3, np.percentile(rel[i], 90) * 1e-3))
+
+# ---- persistent rollout: the LAST tick of a horizon-20 rollout of 1 024 robots (observer on)
+rnames = ["tick start (after barrier B)", "QP0 inputs issued", "QP0 lever arms seen", "QP0 factor done", "QP0 rhat seen", "QP0 iterations done",
+          "QP0 tau_partial / rhat_joint seen", "integrator: barrier A passed", "integrator: update done", "integrator: M, Jc seen (obs joint rows done)",
+          "observer base rows done", "QP0 stores issued"]
+n, H = 1024, 20
+P = synth.default_params(observer_order=1); s = W.Solver(m, W.Params.from_dict(P), max_batch=n)
+B = synth.make_batch(5, n, m.total_mass)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
+inp = [dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")]
+mask = torch.from_numpy(B["mask"]).cuda()
+ig = s.dynamics(inp[0], inp[1], want=("p",))["p"]; r = torch.zeros_like(ig)
+out = s.step(*inp, mask, dev(B["tau_prev"]), dev(B["f_prev"]), ig, r, want_mats=True)
+q0, v0 = inp[0].clone(), inp[1].clone()
+for _ in range(3):
+    inp[0].copy_(q0); inp[1].copy_(v0)
+    s.rollout(H, inp[0], inp[1], inp[2], inp[3], inp[4], inp[5], mask, out, ig, r)
+torch.cuda.synchronize()
+st = out["pf"].cpu().numpy()[:, ::16]
+rel = (st - st[0][None, :]) * 10.0
+print("rollout, 1024 robots, horizon 20, observer on: last tick")
+for i, nm in enumerate(rnames):
+    print("  %-46s median %+7.2f us   p90 %+7.2f us" % (nm, np.median(rel[i]) * 1e-3, np.percentile(rel[i], 90) * 1e-3))

@@ -157,6 +157,15 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     QpArgs<T> qat = qa;
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
+#ifdef WBC_FUSED_STAMP   // diagnostic build: the last tick's role timestamps go out through the pf output
+    double* const rstamp = (t == horizon - 1) ? (double*)a.pf : nullptr;
+    const unsigned rstampN = (unsigned)n_tick;
+    at.pf = nullptr;
+#define RSTAMP(slot) do { if (rstamp) WBC_FSTAMP(rstamp, rstampN, slot); } while (0)
+    if (wave == 0) RSTAMP(0);
+#else
+#define RSTAMP(slot) do {} while (0)
+#endif
     if (wave == WINT) {
       if constexpr (TRACK) {   // planner role first: this tick's references
         RefArgs<T> rt = ra;
@@ -179,7 +188,13 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(2);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
+#ifdef WBC_FUSED_STAMP
+      RSTAMP(9);   // factorisation can start (M, Jc published; the observer's joint rows are done)
+      integrate_body<T>(model, iat, [=] __device__() { __syncthreads(); RSTAMP(7); });
+      RSTAMP(8);
+#else
       integrate_body<T>(model, iat, [] __device__() { __syncthreads(); });   // <- barrier A inside
+#endif
       __syncthreads();                                                       // barrier B: q, v of the next tick
       continue;
     }
@@ -208,10 +223,15 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         else WBC_OBS_ROLE(1, at);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        RSTAMP(10);
       }
     } else {
       constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint rows, run by the integrator wavefront)
+#ifdef WBC_FUSED_STAMP
+      const QpSync sy{&gready, &oready, &ready, t + 1, t + 1, NFIN * (t + 1), rstamp, rstampN};
+#else
       const QpSync sy{&gready, &oready, &ready, t + 1, t + 1, NFIN * (t + 1)};
+#endif
       qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl, &sy);
     }
     __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator
