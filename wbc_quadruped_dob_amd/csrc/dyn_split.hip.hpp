@@ -22,6 +22,7 @@
 // dyn_sweep.hip.hpp (the fused form, kept selectable with WBC_SWEEP=fused).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_types.hpp"
 #include "dyn_sweep.hip.hpp"  // V3/M3/S3 helpers, quad_sum, sel4, midx18, sincos_t
 
@@ -248,8 +249,9 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
 // EXT: as for mass_jac_body; additionally the step workspace goes to the workgroup's LDS image wsl[word][16].
 // `before_refs()` runs after the state loads are issued and before w_des / vdot_des are read (the persistent tracking
 // rollout waits there for the planner role that writes them).
-// `after_geom()` (wavefront roles, EXT != 0): the lever arms WS_D and, observer off, the target wrench WS_B are in the LDS
-// image -- all the QP needs to assemble and factor H -- long before tau_partial is; the role raises its first flag there.
+// `after_geom()` (wavefront roles, EXT != 0) is called twice, long before tau_partial is ready: when the lever arms WS_D are
+// in the LDS image -- all the QP needs to assemble and factor H -- and again when the target wrench WS_B (w_des) is; the
+// role counts both on its first flag.
 struct NoWait { WBC_DEV void operator()() const {} };
 template <class T, int MODE, int BLOCK, int EXT, class BeforeRefs = NoWait, class AfterGeom = NoWait>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
@@ -286,20 +288,30 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   T ql[3], vl[3], al[3] = {0, 0, 0}, ad[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 3; ++k) { ql[k] = LDX(a.q, 7, jxN[k]); vl[k] = LDX(a.v, 6, jxN[k]); }
-  before_refs();
-  if (STEP) {
+  // The references: requested with the state -- unless somebody has to be waited for first (before_refs is a real hook:
+  // the planner role of the tracking rollout), in which case the lever arms, which need q only, go out before that wait.
+  constexpr bool LATE_REFS = EARLY && !std::is_same<BeforeRefs, NoWait>::value;
+  T bw[6] = {0, 0, 0, 0, 0, 0};
+  auto load_refs = [&]() __attribute__((always_inline)) {
+    before_refs();
+    if (STEP) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) al[k] = LDX(a.vdot_des, 6, jxN[k]);
+      for (int k = 0; k < 3; ++k) al[k] = LDX(a.vdot_des, 6, jxN[k]);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
-  }
+      for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
+    }
+    if (STEP && !OBS) {  // observer off: the QP target wrench is just w_des
+#pragma unroll
+      for (int c = 0; c < 6; ++c) bw[c] = LDU(a.w_des, c);
+    }
+  };
+  if constexpr (!LATE_REFS) load_refs();
   if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
-  if (STEP && !OBS) {  // observer off: the QP target wrench is just w_des
-    T b[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c);
-    WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
-    if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+  if constexpr (!EARLY) {   // (EARLY: w_des is stored after the lever arms, so that those do not wait for its load)
+    if (STEP && !OBS) {
+      WST4(WS_B + 0, bw[0], WS_B + 1, bw[1], WS_B + 2, bw[2], WS_B + 3, bw[3]);
+      if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? bw[4] : bw[5]);
+    }
   }
   T qx, qy, qz, qw;
   {
@@ -331,7 +343,13 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     WSTL(WS_D + 0, 3, dw0.x);
     WSTL(WS_D + 1, 3, dw0.y);
     WSTL(WS_D + 2, 3, dw0.z);
-    after_geom();
+    after_geom();   // first call: lever arms are out
+    if constexpr (LATE_REFS) load_refs();
+    if (STEP && !OBS) {
+      WST4(WS_B + 0, bw[0], WS_B + 1, bw[1], WS_B + 2, bw[2], WS_B + 3, bw[3]);
+      if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? bw[4] : bw[5]);
+    }
+    after_geom();   // second call: w_des is out
   }
   const T bm = model->base_m;
   const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);

@@ -46,8 +46,9 @@ constexpr int FUSED_OBS_WAVES = 2;
 // QP's b waits for it), wave 7 the joint rows (rhat_joint -> LDS, counted on `ready`; needed in the torque map only).
 // The QP waves subtract rhat from b and tau_partial themselves.
 // MATS = false (the caller wants tau, f only): no mass_jac role, and the rnea role runs the single merged force chain.
-// Staged hand-over (QpSync, qp_group16.hip.hpp): the rnea role publishes the four lever arms and w_des right after its
-// state loads (flag `gready`) -- H and its factor need nothing else -- rhat follows from the observer role (`oready`,
+// Staged hand-over (QpSync, qp_group16.hip.hpp): the rnea role publishes the four lever arms right after its state
+// loads and w_des right behind them (`gready` counts both) -- H and its factor need the former only, b the latter --
+// rhat follows from the observer role (`oready`,
 // first needed for g = -A^T S b) and tau_partial + the own-leg Jacobian blocks when the force recursions are done
 // (`ready`, first needed in the torque map).  Observer off, N = 4 096: 25.5 -> 22.5 us per tick.
 template <class T, bool OBSERVER, bool MATS>
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
     __syncthreads();
     constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint-row wavefront)
 #ifdef WBC_FUSED_STAMP
-    const QpSync sy{&gready, &oready, &ready, 1, 1, NFIN, stamp, stampN};
+    const QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN, stamp, stampN};
 #else
-    const QpSync sy{&gready, &oready, &ready, 1, 1, NFIN};   // the QP waits for each piece where it first needs it
+    const QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN};   // the QP waits for each piece where it first needs it
 #endif
     qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
   }
@@ -228,9 +229,9 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     } else {
       constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint rows, run by the integrator wavefront)
 #ifdef WBC_FUSED_STAMP
-      const QpSync sy{&gready, &oready, &ready, t + 1, t + 1, NFIN * (t + 1), rstamp, rstampN};
+      const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1), rstamp, rstampN};
 #else
-      const QpSync sy{&gready, &oready, &ready, t + 1, t + 1, NFIN * (t + 1)};
+      const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
       qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl, &sy);
     }

@@ -131,12 +131,12 @@ template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]
 // RHAT (with WSLDS, observer-on fused tick): the observer role left rhat in the LDS image; b and tau_partial are
 // completed here (b -= rhat_base, tau_partial -= rhat_joint).
 // QpSync (WSLDS only): the producer roles of the fused tick publish the workspace in three steps, each behind an LDS
-// counter -- lever arms (+ w_des) early, rhat when the observer role is done, tau_partial and the own-leg Jacobian
+// counter -- lever arms, then w_des, early; rhat when the observer role is done, tau_partial and the own-leg Jacobian
 // blocks when the force recursions are -- and the QP waits for each only where it first needs it: H and its factor
 // come from the lever arms alone, the target wrench enters with g, tau_partial only in the torque map.
 struct QpSync {
   int* geom; int* rhat; int* fin;
-  int need_geom, need_rhat, need_fin;
+  int need_geom, need_b, need_rhat, need_fin;   // `geom` counts twice per tick: lever arms out, then w_des out
 #ifdef WBC_FUSED_STAMP   // diagnostic build (tools/fused_stamp.py): 100 MHz timestamps of the roles, one column per workgroup
   double* stamp; unsigned stampN;
 #endif
@@ -264,6 +264,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   T g_me;
   {
     WBC_QSTAMP(3);
+    if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
     if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
     WBC_QSTAMP(4);
     const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
