@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/collect_profiles.sh r01g : copy what tools/final_profile.sh left under gpurun_out/final/ into profiles/<tag>_* (tracked)
+set -eu
+T="$1"; O=gpurun_out/final; P=profiles
+for f in bench_cfg2_n262144 bench_cfg2_n4096 bench_cfg2_n4096_nomats bench_cfg3_n4096 bench_cfg4_f32_n32768 bench_cfg5_h20_n1024 \
+         bench_cfg5_h20_n128 bench_cfg5_h20_n32768 bench_cfg5_tracking_h20_n1024 bench_under_rocprof_n262144 bench_under_rocprof_n4096 bench_torchrun_1rank; do
+  cp "$O/$f.json" "$P/${T}_$f.json"
+done
+for f in abi_smoke bw_probe fma_probe pytest_gpu; do cp "$O/$f.log" "$P/${T}_$f.log"; done
+[ -f "$O/fused_timeline.txt" ] && cp "$O/fused_timeline.txt" "$P/${T}_fused_timeline.txt"
+cp "$O/pmc_summary.json" "$P/${T}_pmc_summary.json"; cp "$O/pmc_summary.json" "$P/pmc_latest.json"
+cp "$O/stats_n4096_kernel_stats.csv" "$P/${T}_kernel_stats_cfg2_n4096.csv"
+cp "$O/stats_n262144_kernel_stats.csv" "$P/${T}_kernel_stats_cfg2_n262144.csv"
+cp "$O/stats_cfg5_kernel_stats.csv" "$P/${T}_kernel_stats_cfg5_h20_n1024.csv"
+cp "$O/stats_cfg5trk_kernel_stats.csv" "$P/${T}_kernel_stats_cfg5_tracking_h20_n1024.csv"
+for f in "$O"/bench_*.json; do python3 -c "
+import json,sys; r=json.load(open('$f')); print('%-46s ms/step %.5f  value %.4e' % ('$(basename $f)', r['ms_per_step'], r['value']))"; done
+grep -h "wbc::" "$P/${T}_kernel_stats_cfg2_n4096.csv" "$P/${T}_kernel_stats_cfg2_n262144.csv" "$P/${T}_kernel_stats_cfg5_h20_n1024.csv" | awk -F'",' '{split($1,a,"("); print a[1], $2}' | cut -c1-140
