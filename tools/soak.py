@@ -1,0 +1,97 @@
+"""Soak run on the GPU box: many random batches through every small-batch dispatch variant, each compared with the two-kernel /
+per-tick-launch path of the same library (same device functions, other synchronisation) and, every few cases, with the CPU
+oracle.  The fused tick and the persistent rollouts hand data between wavefronts through LDS counters; a synchronisation
+mistake there would show up as a rare, timing-dependent mismatch, which the fixed-seed unit tests could miss.
+usage: python tools/soak.py [cases] [seed]     (prints one summary line; exit status 1 on any mismatch)"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import torch
+from tests.util import relerr
+from tests.test_gpu_parity import _solver, _run_step, _gpu_rollout
+import wbc_quadruped_dob_amd as W
+from wbc_quadruped_dob_amd import synth
+from oracle import oracle_py, urdf_model
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+gm = W.Model.from_urdf(W.SYNTHETIC_URDF)
+orc = oracle_py.Oracle(urdf_model.load_urdf(W.SYNTHETIC_URDF))
+
+
+def solver_with(env, **kw):
+    for k, v in env.items():
+        os.environ[k] = v
+    s = _solver(gm, **kw)
+    for k in env:
+        del os.environ[k]
+    return s
+
+
+bad, worst, t0 = [], 0.0, time.time()
+for c in range(cases):
+    obs = int(rng.integers(0, 3))
+    cfg = int(rng.choice([2, 3, 4]))
+    n = int(rng.choice([1, 7, 16, 17, 100, 1000, 2048, 4096, 5000, 8192][: (10 if obs == 0 else 8)]))
+    if rng.random() < 0.3:
+        n = int(rng.integers(1, 4097))
+    B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
+    integ0 = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    z = lambda: (None if integ0 is None else integ0.copy(), None if integ0 is None else np.zeros((n, 18)))
+    if c % 3 != 2:   # ---- one tick: fused vs two-kernel, two consecutive ticks (observer state carried)
+        res = {}
+        for tag, env in (("fused", {}), ("two", {"WBC_FUSED_MAX": "0"})):
+            s, P = solver_with(env, obs=obs, max_batch=n)
+            a1 = _run_step(torch, s, B, "f64", *z(), want_mats=bool(c % 2))
+            a2 = _run_step(torch, s, B, "f64", a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
+            res[tag] = (a1, a2)
+        if c % 5 == 0:   # the same launch again, several times: results must be bit-identical run to run
+            s, P = solver_with({}, obs=obs, max_batch=n)
+            first = _run_step(torch, s, B, "f64", *z(), want_mats=True)
+            for _ in range(6):
+                again = _run_step(torch, s, B, "f64", *z(), want_mats=True)
+                for k in first:
+                    if not np.array_equal(first[k], again[k], equal_nan=True):
+                        bad.append((c, "nondeterministic " + k, n, obs, cfg))
+        for i in (0, 1):
+            a, b = res["fused"][i], res["two"][i]
+            if not np.array_equal(a["status"], b["status"]):
+                bad.append((c, "status", n, obs, cfg))
+            for k in a:
+                if k in ("status", "iters"):
+                    continue
+                e = relerr(a[k], b[k])
+                worst = max(worst, e)
+                if not e < 1e-11:
+                    bad.append((c, k, n, obs, cfg, e))
+        if c % 9 == 0:
+            ig, r = z()
+            ref = orc.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"], ig, r, nthreads=8)
+            e = max(relerr(res["fused"][0]["tau"], ref["tau"]), relerr(res["fused"][0]["f"], ref["f"]))
+            if not e < 1e-9:
+                bad.append((c, "oracle", n, obs, cfg, e))
+    else:            # ---- rollout: persistent vs per-tick launches
+        n = min(n, 2048)
+        B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
+        integ0 = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+        H = int(rng.integers(2, 12))
+        tau_ext = np.zeros((n, 18)); tau_ext[:, 0:3] = B["push"] if cfg > 2 else 5.0
+        res = {}
+        for tag, env in (("persistent", {}), ("per_tick", {"WBC_ROLLOUT_PERSISTENT": "0"})):
+            s, P = solver_with(env, obs=obs, max_batch=n)
+            res[tag] = _gpu_rollout(torch, s, P, H, B, tau_ext, None if integ0 is None else integ0.copy(), np.zeros((n, 18)) if obs else None)
+        a, b = res["persistent"], res["per_tick"]
+        if not np.array_equal(a["status"], b["status"]):
+            bad.append((c, "rollout status", n, obs, cfg))
+        for k in a:
+            if k == "status":
+                continue
+            e = relerr(a[k], b[k])
+            worst = max(worst, e)
+            if not e < 1e-9:
+                bad.append((c, "rollout " + k, n, obs, cfg, H, e))
+print("soak: %d cases, seed %d, %.0f s, worst relative difference between dispatch variants %.2e, mismatches: %d %s"
+      % (cases, seed, time.time() - t0, worst, len(bad), bad[:10]))
+sys.exit(1 if bad else 0)
