@@ -395,6 +395,7 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
     """The same two kernels at 262144 states (the largest BASELINE.json batch): where the sweep is bandwidth-bound
     rather than launch/latency-bound.  Not part of `value`."""
     n = args.large_batch
+    torch.cuda.empty_cache()   # fresh 2 MiB-aligned segments for the big buffers instead of holes of the small run's cache
     P = synth.default_params(observer_order=obs, dtype=dtype)
     solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=n)
     B = synth.make_batch(args.config, n, model.total_mass, rank=0)
@@ -407,12 +408,12 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
         rr = torch.zeros_like(integ)
     out = solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
                       inp["f_prev"], integ, rr, want_mats=True)
-    for _ in range(3):
+    for _ in range(10):   # clocks and TLBs settle: the first few launches at this size read 5-8 % slower
         solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
                     inp["f_prev"], integ, rr, out=out, want_mats=True)
     torch.cuda.synchronize()
     solver.enable_timing(1)
-    K = 20
+    K = 30
     t0 = time.perf_counter()
     for _ in range(K):
         solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
