@@ -57,7 +57,7 @@ struct wbc_solver {
                                       // Measured at N = 262 144: fp32 0.482 -> 0.441 ms per tick, fp64 0.713 -> 0.810 ms (slower), and
                                       // slower for both at N = 32 768 -> not the default
   size_t fused_max = 4096;  // ticks / rollouts of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
-  size_t fused_max_noobs = 8192;  // observer-off ticks: the fused kernel still wins with two rounds of workgroups (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on); WBC_FUSED_MAX sets both
+  size_t fused_max_noobs = 8192;  // observer-off (and all fp32) ticks: the fused kernel still wins with two rounds of workgroups (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on); WBC_FUSED_MAX sets both
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
@@ -553,7 +553,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   qa.Jc = geom_from_jc ? (const T*)out->Jc : nullptr;
   a.ws_geom = geom_from_jc ? 0 : 1;
   if ((mats || !out->pf) && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 &&
-      N <= (ob ? s->fused_max : s->fused_max_noobs)) {
+      N <= ((ob && s->dtype == WBC_F64) ? s->fused_max : s->fused_max_noobs)) {   // fp32: half the LDS, 8 192 also with the observer on (29.7 vs 36.9 us)
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
     rc = span_begin(s, 3, st);
