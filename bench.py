@@ -346,7 +346,21 @@ def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):
         fusk.append(tm.get("fused_ms", 0.0))
     solver.enable_timing(0)
     fused = float(np.median(fusk)) > 0
+    # the host-pointer single-robot call (BASELINE.json configs[0] shape): staging copy in, tick, copy out, one sync
+    h = {k: np.ascontiguousarray(B[k][0], dtype=np.float64) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+    hig = np.zeros(18) if obs else None
+    hr = np.zeros(18) if obs else None
+    ct = lambda: solver.compute_torques(h["q"], h["v"], h["w_des"], h["vdot_des"], h["normals"], h["mu"], int(B["mask"][0]),
+                                        h["tau_prev"] if obs else None, h["f_prev"] if obs else None, hig, hr)
+    for _ in range(20):
+        ct()
+    cwall = []
+    for _ in range(500):
+        t0 = time.perf_counter()
+        ct()
+        cwall.append(time.perf_counter() - t0)
     return {"ticks": 1000, "tick_p50_us": float(np.median(wall)) * 1e6, "tick_p99_us": float(np.percentile(wall, 99)) * 1e6,
+            "compute_torques_p50_us": float(np.median(cwall)) * 1e6, "compute_torques_p99_us": float(np.percentile(cwall, 99)) * 1e6,
             "tick_kernel_p50_us": float(np.median(fusk)) * 1e3 if fused else None,
             "qp_kernel_p50_us": None if fused else float(np.median(qpk)) * 1e3,
             "front_kernel_p50_us": None if fused else float(np.median(dynk)) * 1e3,

@@ -63,6 +63,7 @@ struct wbc_solver {
   void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
   // N=1 convenience buffers
   void* d_one = nullptr;
+  void* h_one = nullptr;   // pinned host image of d_one: the single-robot calls move it with ONE copy each way
   size_t one_bytes = 0;
   // timing
   bool timing = false;
@@ -306,6 +307,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
   s->one_bytes = 200 * sizeof(double) + 4 * sizeof(int);
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
+  if (e == hipSuccess) e = hipHostMalloc(&s->h_one, s->one_bytes, hipHostMallocDefault);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
@@ -324,6 +326,7 @@ extern "C" void wbc_solver_destroy(wbc_solver* s) {
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_ws) (void)hipFree(s->d_ws);
   if (s->d_one) (void)hipFree(s->d_one);
+  if (s->h_one) (void)hipHostFree(s->h_one);
   if (s->d_ref) (void)hipFree(s->d_ref);
   if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
   if (s->ev_join) (void)hipEventDestroy(s->ev_join);
@@ -875,23 +878,25 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   const bool ob = s->params.observer_order > 0;
   if (ob && (!tau_prev || !f_prev || !obs_integ || !obs_r)) return fail(WBC_E_INVALID, "observer on: state required");
   HIP_TRY(hipSetDevice(s->device));
-  // host staging in the solver's dtype
+  // host staging in the solver's dtype: a pinned image of the device scratch (doubles/floats, then mask | status | iters),
+  // one asynchronous copy each way around the launch and one synchronisation (was four blocking copies from pageable memory)
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const int off[] = {0, 19, 37, 43, 61, 73, 77, 89, 101, 119, 137, 149, 161};  // q v w a n mu tp fp ig r tau f end
-  std::vector<unsigned char> hbuf(161 * ts);
+  unsigned char* hb = (unsigned char*)s->h_one;
+  int* hints = (int*)(hb + 200 * sizeof(double));
   auto put = [&](int o, const double* src, int n) {
     for (int i = 0; i < n; ++i) {
-      if (s->dtype == WBC_F64) ((double*)hbuf.data())[o + i] = src ? src[i] : 0.0;
-      else ((float*)hbuf.data())[o + i] = src ? (float)src[i] : 0.0f;
+      if (s->dtype == WBC_F64) ((double*)hb)[o + i] = src ? src[i] : 0.0;
+      else ((float*)hb)[o + i] = src ? (float)src[i] : 0.0f;
     }
   };
   put(off[0], q, 19); put(off[1], v, 18); put(off[2], w_des, 6); put(off[3], vdot_des, 18); put(off[4], normals, 12);
   put(off[5], mu, 4); put(off[6], tau_prev, 12); put(off[7], f_prev, 12); put(off[8], obs_integ, 18); put(off[9], obs_r, 18);
   put(off[10], nullptr, 12); put(off[11], nullptr, 12);
+  hints[0] = mask; hints[1] = 0; hints[2] = 0;
   unsigned char* d = (unsigned char*)s->d_one;
   int* dints = (int*)(d + 200 * sizeof(double));
-  HIP_TRY(hipMemcpy(d, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dints, &mask, sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(d, hb, s->one_bytes, hipMemcpyHostToDevice, nullptr));
   wbc_batch_in in;
   in.q = d + off[0] * ts; in.v = d + off[1] * ts; in.w_des = d + off[2] * ts; in.vdot_des = d + off[3] * ts;
   in.normals = d + off[4] * ts; in.mu = d + off[5] * ts; in.mask = dints;
@@ -902,16 +907,16 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   wbc_observer_state os{d + off[8] * ts, d + off[9] * ts};
   int rc = wbc_step_batch(s, 1, &in, &out, &os, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(hbuf.data(), d, hbuf.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(hb, d, s->one_bytes, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   auto get = [&](int o, double* dst, int n) {
     if (!dst) return;
     for (int i = 0; i < n; ++i)
-      dst[i] = s->dtype == WBC_F64 ? ((double*)hbuf.data())[o + i] : (double)((float*)hbuf.data())[o + i];
+      dst[i] = s->dtype == WBC_F64 ? ((double*)hb)[o + i] : (double)((float*)hb)[o + i];
   };
   get(off[10], tau, 12); get(off[11], f, 12);
   if (ob) { get(off[8], obs_integ, 18); get(off[9], obs_r, 18); }
-  HIP_TRY(hipMemcpy(status, dints + 1, sizeof(int), hipMemcpyDeviceToHost));
+  *status = hints[1];
   return WBC_OK;
 }
 
@@ -922,25 +927,25 @@ extern "C" int wbc_compute_reference(wbc_solver* s, const double* q, const doubl
   HIP_TRY(hipSetDevice(s->device));
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const int off[] = {0, 19, 37, 49, 55, 73, 79};  // q v plan | w_des vdot_des com end
-  std::vector<unsigned char> hbuf(79 * ts);
+  unsigned char* hb = (unsigned char*)s->h_one;   // pinned staging, one copy each way
   auto put = [&](int o, const double* src, int n) {
     for (int i = 0; i < n; ++i) {
-      if (s->dtype == WBC_F64) ((double*)hbuf.data())[o + i] = src[i];
-      else ((float*)hbuf.data())[o + i] = (float)src[i];
+      if (s->dtype == WBC_F64) ((double*)hb)[o + i] = src[i];
+      else ((float*)hb)[o + i] = (float)src[i];
     }
   };
   put(off[0], q, 19); put(off[1], v, 18); put(off[2], plan, PLAN_WORDS);
   unsigned char* d = (unsigned char*)s->d_one;
-  HIP_TRY(hipMemcpy(d, hbuf.data(), 49 * ts, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(d, hb, 49 * ts, hipMemcpyHostToDevice, nullptr));
   int rc = wbc_reference_batch(s, 1, d + off[0] * ts, d + off[1] * ts, d + off[2] * ts, t, d + off[3] * ts, d + off[4] * ts,
                                d + off[5] * ts, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(hbuf.data() + 49 * ts, d + 49 * ts, 30 * ts, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(hb + 49 * ts, d + 49 * ts, 30 * ts, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   auto get = [&](int o, double* dst, int n) {
     if (!dst) return;
     for (int i = 0; i < n; ++i)
-      dst[i] = s->dtype == WBC_F64 ? ((double*)hbuf.data())[o + i] : (double)((float*)hbuf.data())[o + i];
+      dst[i] = s->dtype == WBC_F64 ? ((double*)hb)[o + i] : (double)((float*)hb)[o + i];
   };
   get(off[3], w_des, 6); get(off[4], vdot_des, 18); get(off[5], com, 6);
   return WBC_OK;
