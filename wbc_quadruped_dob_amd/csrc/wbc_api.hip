@@ -64,6 +64,8 @@ struct wbc_solver {
   // N=1 convenience buffers
   void* d_one = nullptr;
   void* h_one = nullptr;   // pinned host image of d_one: the single-robot calls move it with ONE copy each way
+  void* h_one_dev = nullptr;   // device address of h_one (mapped): WBC_ONE_ZEROCOPY=1 lets the N = 1 kernels read / write it directly
+  bool one_zerocopy = false;
   size_t one_bytes = 0;
   // timing
   bool timing = false;
@@ -307,7 +309,9 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
   s->one_bytes = 200 * sizeof(double) + 4 * sizeof(int);
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
-  if (e == hipSuccess) e = hipHostMalloc(&s->h_one, s->one_bytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(&s->h_one, s->one_bytes, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&s->h_one_dev, s->h_one, 0);
+  if (const char* z = std::getenv("WBC_ONE_ZEROCOPY")) s->one_zerocopy = std::atoi(z) != 0;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
@@ -894,9 +898,10 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   put(off[5], mu, 4); put(off[6], tau_prev, 12); put(off[7], f_prev, 12); put(off[8], obs_integ, 18); put(off[9], obs_r, 18);
   put(off[10], nullptr, 12); put(off[11], nullptr, 12);
   hints[0] = mask; hints[1] = 0; hints[2] = 0;
-  unsigned char* d = (unsigned char*)s->d_one;
+  const bool zc = s->one_zerocopy;
+  unsigned char* d = (unsigned char*)(zc ? s->h_one_dev : s->d_one);
   int* dints = (int*)(d + 200 * sizeof(double));
-  HIP_TRY(hipMemcpyAsync(d, hb, s->one_bytes, hipMemcpyHostToDevice, nullptr));
+  if (!zc) HIP_TRY(hipMemcpyAsync(d, hb, s->one_bytes, hipMemcpyHostToDevice, nullptr));
   wbc_batch_in in;
   in.q = d + off[0] * ts; in.v = d + off[1] * ts; in.w_des = d + off[2] * ts; in.vdot_des = d + off[3] * ts;
   in.normals = d + off[4] * ts; in.mu = d + off[5] * ts; in.mask = dints;
@@ -907,7 +912,7 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   wbc_observer_state os{d + off[8] * ts, d + off[9] * ts};
   int rc = wbc_step_batch(s, 1, &in, &out, &os, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(hb, d, s->one_bytes, hipMemcpyDeviceToHost, nullptr));
+  if (!zc) HIP_TRY(hipMemcpyAsync(hb, d, s->one_bytes, hipMemcpyDeviceToHost, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   auto get = [&](int o, double* dst, int n) {
     if (!dst) return;
