@@ -440,7 +440,11 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
     dyn_s = tm["dyn_ms"] * 1e-3 / tm["dyn_launches"]
     qp_s = tm["qp_ms"] * 1e-3 / tm["qp_launches"]
     ach = dyn_words(split) * ts * n / dyn_s / 1e9
+    # the dynamics stage exactly as SURVEY.md 8(d) defines it (q, v -> M, h, Jc as its own kernel, no step prologue)
+    alone = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
+    alone["traffic"] = None   # no PMC pass of this variant at this size is committed
     return {"batch": n, "kernel": dyn_kernel_name(split), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "dynamics_stage_alone": alone,
             "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dyn_kernel_name(split), n, dtype),
             "algorithmic_words_per_state": dyn_words(split), "avg_launch_us": dyn_s * 1e6,
             "rnea_step_us": tm["rnea_ms"] * 1e3 / max(1, tm["rnea_launches"]), "qp_us": qp_s * 1e6,

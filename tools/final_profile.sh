@@ -28,6 +28,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5trk -- python3 "$R/bench.py" --config 5 --tracking --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
+# the default bench command itself (incl. its N = 262 144 characterisation legs: tick sweep and the dynamics stage alone)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_default -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency > "$O/bench_under_rocprof_default.json" 2>> "$O/rocprof.err"
 find "$O" -name "*kernel_trace.csv" -delete
 cd "$R"
 bash tools/pmc_profile.sh > "$O/pmc.log" 2>&1
