@@ -34,7 +34,7 @@ template <class T> struct RefArgs {
 };
 
 // EXT (persistent rollout kernel, fused_tick.hip.hpp): one wavefront of a larger workgroup, tables already in LDS.
-template <class T, bool EXT>
+template <class T, bool EXT, int SPW = 16>
 WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const DevRefParams<T>* __restrict__ G, const RefArgs<T>& a,
                                 const T* cst_ext) {
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
@@ -48,9 +48,10 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   const int leg = (int)((tx & 63) >> 4);
-  const size_t s_raw = (size_t)blockIdx.x * 16 + (tx & 15);
-  const bool live = s_raw < N;
-  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
+  const size_t s_raw = (size_t)blockIdx.x * SPW + (tx & 15);
+  const bool slot_ok = SPW == 16 || (int)(tx & 15) < SPW;   // (SPW <= 16 states per workgroup, see WBC_ADDR_MACROS)
+  const bool live = slot_ok && s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));
 #define RCS(i) cst[(i) * 4 + leg]
 #define RLDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define RLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))

@@ -45,10 +45,12 @@ constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, wit
   const unsigned N32 = (unsigned)N;                                                                                        \
   /* lane = 16*leg + (state within the wave), as in dyn_sweep_kernel */                                                    \
   const int leg = (int)((tx & 63) >> 4);                                                                          \
-  const size_t s_raw = EXT ? (size_t)blockIdx.x * 16 + (tx & 15)                                                  \
+  /* roles (EXT != 0): a workgroup owns SPW <= 16 consecutive states; lanes of the other slots repeat its first state */   \
+  const size_t s_raw = EXT ? (size_t)blockIdx.x * SPW + (tx & 15)                                                 \
                            : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);           \
-  const bool live = s_raw < N;                                                                                             \
-  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);                                                                   \
+  const bool slot_ok = SPW == 16 || (int)(tx & 15) < SPW;                                                                  \
+  const bool live = slot_ok && s_raw < N;                                                                                  \
+  const unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));                            \
   const unsigned legN = (unsigned)leg * N32;
 #define CS(i) cst[(i) * 4 + leg]
 #define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
@@ -77,9 +79,10 @@ constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, wit
 // tables are staged by other wavefronts of the workgroup (cst_ext, zidx_ext).  EXT = 1: they are complete on entry, the
 // body contains no barrier.  EXT = 2: the body issues its state loads first and THEN joins the workgroup barrier behind
 // which the tables are complete (one memory round trip instead of two at the head of the tick).
-template <class T, int BLOCK, int EXT>
+template <class T, int BLOCK, int EXT, int SPW = 16>
 WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
+  static_assert(SPW == 16 || EXT != 0, "fewer states per workgroup only for roles");
   WBC_LAUNDERED_TID(tx);
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
   __shared__ int zidx_own[EXT ? 1 : 64];
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
 // in the LDS image -- all the QP needs to assemble and factor H -- and again when the target wrench WS_B (w_des) is; the
 // role counts both on its first flag.
 struct NoWait { WBC_DEV void operator()() const {} };
-template <class T, int MODE, int BLOCK, int EXT, class BeforeRefs = NoWait, class AfterGeom = NoWait>
+template <class T, int MODE, int BLOCK, int EXT, int SPW = 16, class BeforeRefs = NoWait, class AfterGeom = NoWait>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
                             T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom()) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
 // TRACK: the CoM planner in the loop (wbc_rollout_tracking_batch).  The integrator wavefront, idle at the head of a tick,
 // first runs the reference generator (com_reference_body: w_des, vdot_des of this tick -> HBM, optional CoM record) and
 // raises a third flag; the rnea role issues its state loads, then waits for that flag before it reads the references.
-template <class T, bool OBSERVER, bool TRACK>
+// SPW: states per workgroup (16, or 4 for rollouts of at most 1 024 states: every CU gets a workgroup and a tick waits for
+// the slowest of 4 QPs instead of 16 -- only QP wavefront 0 works then, the producer lanes of the other slots idle along).
+template <class T, bool OBSERVER, bool TRACK, int SPW = 16>
 __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,
                                                                          int horizon, const DevRefParams<T>* __restrict__ G, RefArgs<T> ra) {
@@ -173,14 +175,14 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         rt.N = (size_t)n_tick;
         rt.t = (T)t * prm.dt + ra.t;
         rt.com = com0 ? com0 + (size_t)t * 6 * (size_t)n_tick : nullptr;
-        com_reference_body<T, true>(model, G, rt, cst);
+        com_reference_body<T, true, SPW>(model, G, rt, cst);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
       }
       if constexpr (OBSERVER && FUSED_OBS_WAVES == 2) {
         // idle until M, Jc exist: this wavefront takes the JOINT rows of the observer update (rhat_joint, which the QP
         // needs only in its torque map); wave 6 is left with the base rows, whose rhat_base the QP's b waits for
-        observer_body<T, 64, 1, 2>(model, prm, at, cst, wsl);
+        observer_body<T, 64, 1, 2, SPW>(model, prm, at, cst, wsl);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
 #ifdef WBC_FUSED_STAMP
       RSTAMP(9);   // factorisation can start (M, Jc published; the observer's joint rows are done)
-      integrate_body<T>(model, iat, [=] __device__() { __syncthreads(); RSTAMP(7); });
+      integrate_body<T, SPW>(model, iat, [=] __device__() { __syncthreads(); RSTAMP(7); });
       RSTAMP(8);
 #else
-      integrate_body<T>(model, iat, [] __device__() { __syncthreads(); });   // <- barrier A inside
+      integrate_body<T, SPW>(model, iat, [] __device__() { __syncthreads(); });   // <- barrier A inside
 #endif
       __syncthreads();                                                       // barrier B: q, v of the next tick
       continue;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       int* const rflag = &rready;
       const int rneed = t + 1;
       int* const gflag = &gready;
-      rnea_step_body<T, RS_STEP | RS_H, 64, 1>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
+      rnea_step_body<T, RS_STEP | RS_H, 64, 1, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -215,13 +217,13 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wave == 5) {
-      mass_jac_body<T, 64, 1>(model, at, cst, zidx_s);
+      mass_jac_body<T, 64, 1, SPW>(model, at, cst, zidx_s);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // M, Jc are in L2 (waits for my stores) ...
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&mready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {
-        if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1>(model, prm, at, cst, wsl);   // base rows
-        else WBC_OBS_ROLE(1, at);
+        if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1, SPW>(model, prm, at, cst, wsl);   // base rows
+        else observer_body<T, 64, 1, 0, SPW>(model, prm, at, cst, wsl);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         RSTAMP(10);
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #else
       const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
-      qp_group16_body<T, false, 4, true, OBSERVER>(prm, qat, jmap, wsl, &sy);
+      if (wave * 4 < SPW) qp_group16_body<T, false, 4, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
     }
     __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator
     __syncthreads();   // barrier B: q, v of the next tick

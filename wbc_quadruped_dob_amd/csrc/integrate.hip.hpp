@@ -30,16 +30,17 @@ template <class T> struct IntegrateArgs {
 // `between()` runs after it (nothing in the stand-alone kernel; the tick barrier in the rollout kernel, where phase 1
 // overlaps the QP).  Phase 2 needs tau, f, h, q, v: right-hand sides, the two triangular solves, the state update.
 struct IntegrateNoWait { WBC_DEV void operator()() const {} };
-template <class T, class Between = IntegrateNoWait>
+template <class T, int SPW = 16, class Between = IntegrateNoWait>
 WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between()) {
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
   const int leg = (int)((tx & 63) >> 4);
-  const size_t s_raw = (size_t)blockIdx.x * 16 + (tx & 15);
-  const bool live = s_raw < N;
-  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
+  const size_t s_raw = (size_t)blockIdx.x * SPW + (tx & 15);
+  const bool slot_ok = SPW == 16 || (int)(tx & 15) < SPW;   // (SPW <= 16 states per workgroup, see WBC_ADDR_MACROS)
+  const bool live = slot_ok && s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));
   const unsigned legN = (unsigned)leg * N32;
 #define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))

@@ -23,7 +23,7 @@ namespace wbc {
 // PART (roles only): 0 = the whole update; 1 = base rows only (momentum / gravity sums over the legs, rhat_base: what the QP's
 // target wrench b waits for); 2 = joint rows only (rhat_joint, needed in the torque map).  Two wavefronts running parts 1
 // and 2 side by side share the sweeps' arithmetic but each drops the other's projections and update.
-template <class T, int BLOCK, int EXT, int PART = 0>
+template <class T, int BLOCK, int EXT, int PART = 0, int SPW = 16>
 WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext, T* wsl) {
   static_assert(EXT == 0 || BLOCK == 64, "one wavefront");
   static_assert(PART == 0 || EXT != 0, "split parts exist only as roles");
@@ -35,9 +35,10 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   const int leg = (int)((tx & 63) >> 4);
-  const size_t s_raw = EXT ? (size_t)blockIdx.x * 16 + (tx & 15) : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);
-  const bool live = s_raw < N;
-  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
+  const size_t s_raw = EXT ? (size_t)blockIdx.x * SPW + (tx & 15) : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);
+  const bool slot_ok = SPW == 16 || (int)(tx & 15) < SPW;   // (roles: SPW <= 16 states per workgroup, see WBC_ADDR_MACROS)
+  const bool live = slot_ok && s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));
 #define OCS(i) cst[(i) * 4 + leg]
 #define OLDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define OLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))

@@ -154,7 +154,7 @@ WBC_DEV void qp_wait(int* flag, int need) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <class T, bool REGROUP, int WPB, bool WSLDS, bool RHAT = false>
+template <class T, bool REGROUP, int WPB, bool WSLDS, bool RHAT = false, int SPW = 16>
 WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr) {
   static_assert(!REGROUP || WPB == 4, "re-dealing needs the 16 rows of a 4-wave workgroup");
   static_assert(!WSLDS || (WPB == 4 && !REGROUP), "the fused tick pairs one sweep wavefront with four QP wavefronts");
@@ -177,9 +177,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   // and take four CONSECUTIVE 4-state groups = one whole 128-byte line per component row.  Speed only.
   size_t wg = blockIdx.x;
   if (WPB == 1 && (gridDim.x & 31) == 0) wg = (wg & ~(size_t)31) + ((wg & 7) << 2) + ((wg >> 3) & 3);
-  const size_t qp_raw = WSLDS ? (size_t)blockIdx.x * 16 + (tx >> 4)   // fused tick: QP wavefronts are threads 0..255 of a larger workgroup
+  static_assert(SPW == 16 || WSLDS, "fewer states per workgroup only inside the fused kernels");
+  const size_t qp_raw = WSLDS ? (size_t)blockIdx.x * SPW + (tx >> 4)   // fused tick: QP wavefronts are threads 0..255 of a larger workgroup
                               : (wg * blockDim.x + tx) >> 4;
-  bool live = qp_raw < N;
+  bool live = qp_raw < N && (SPW == 16 || (int)(tx >> 4) < SPW);
   unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
   const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
 #define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))

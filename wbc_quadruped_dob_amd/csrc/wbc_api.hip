@@ -57,6 +57,7 @@ struct wbc_solver {
                                       // Measured at N = 262 144: fp32 0.482 -> 0.441 ms per tick, fp64 0.713 -> 0.810 ms (slower), and
                                       // slower for both at N = 32 768 -> not the default
   size_t fused_max = 4096;  // ticks / rollouts of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
+  int rollout_spw = 0;   // states per workgroup of the persistent rollout kernel: 0 = auto (4 up to 1 024 states, else 16); env WBC_ROLLOUT_SPW = 4 | 16
   size_t fused_max_noobs = 8192;  // observer-off (and all fp32) ticks: the fused kernel still wins with two rounds of workgroups (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on); WBC_FUSED_MAX sets both
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -288,6 +289,7 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (const char* e = std::getenv("WBC_QP_WPB")) s->qp_wpb = (std::strcmp(e, "4") == 0) ? 4 : 1;
   if (const char* e = std::getenv("WBC_QP_REGROUP")) s->qp_regroup = (std::strcmp(e, "1") == 0);
   if (const char* e = std::getenv("WBC_ROLLOUT_PERSISTENT")) s->rollout_persistent = std::strcmp(e, "0") != 0;
+  if (const char* e = std::getenv("WBC_ROLLOUT_SPW")) s->rollout_spw = std::atoi(e);
   if (const char* e = std::getenv("WBC_OBS_SPLIT_MIN")) s->obs_split_min = (size_t)std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("WBC_TIMING")) s->timing_ext = std::strcmp(e, "pair") != 0;
   if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = s->fused_max_noobs = (size_t)std::strtoull(e, nullptr, 10);
@@ -718,7 +720,9 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   ia.N = N; ia.q = (T*)in->q; ia.v = (T*)in->v; ia.M = (const T*)out->M; ia.h = (const T*)out->h; ia.Jc = (const T*)out->Jc;
   ia.tau = (const T*)out->tau; ia.f = (const T*)out->f; ia.tau_ext = (const T*)tau_ext; ia.tau_traj = (T*)tau_traj;
   ia.dt = (T)s->params.dt;
-  const unsigned blocks = (unsigned)((N + 15) / 16);
+  // states per workgroup: 4 while that still fits one workgroup per CU (a tick then waits for the slowest of 4 QPs, not 16)
+  const int spw = (s->rollout_spw == 4 || (s->rollout_spw == 0 && N <= 1024)) ? 4 : 16;
+  const unsigned blocks = (unsigned)((N + spw - 1) / spw);
   RefArgs<T> ra;
   std::memset(&ra, 0, sizeof(ra));
   ra.N = N; ra.q = (const T*)in->q; ra.v = (const T*)in->v; ra.plan = (const T*)plan; ra.t = (T)0;
@@ -727,13 +731,15 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   const DevParams<T> dp = to_dev_params<T>(s->params);
   const DevRefParams<T>* G = (const DevRefParams<T>*)s->d_ref;
   const bool ob = s->params.observer_order > 0;
-  if (plan) {
-    if (ob) WBC_LAUNCH((rollout_kernel<T, true, true>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
-    else WBC_LAUNCH((rollout_kernel<T, false, true>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+#define WBC_ROLLOUT(OB_, TRK_, SPW_) WBC_LAUNCH((rollout_kernel<T, OB_, TRK_, SPW_>), dim3(blocks), dim3(OB_ ? 512 : 448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra)
+  if (spw == 4) {
+    if (plan) { if (ob) WBC_ROLLOUT(true, true, 4); else WBC_ROLLOUT(false, true, 4); }
+    else { if (ob) WBC_ROLLOUT(true, false, 4); else WBC_ROLLOUT(false, false, 4); }
   } else {
-    if (ob) WBC_LAUNCH((rollout_kernel<T, true, false>), dim3(blocks), dim3(512), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
-    else WBC_LAUNCH((rollout_kernel<T, false, false>), dim3(blocks), dim3(448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra);
+    if (plan) { if (ob) WBC_ROLLOUT(true, true, 16); else WBC_ROLLOUT(false, true, 16); }
+    else { if (ob) WBC_ROLLOUT(true, false, 16); else WBC_ROLLOUT(false, false, 16); }
   }
+#undef WBC_ROLLOUT
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
   return WBC_OK;
