@@ -34,6 +34,8 @@ for cfg, obs in ((2, 0), (3, 1)):
 rnames = ["tick start (after barrier B)", "QP0 inputs issued", "QP0 lever arms seen", "QP0 factor done", "QP0 rhat seen", "QP0 iterations done",
           "QP0 tau_partial / rhat_joint seen", "integrator: barrier A passed", "integrator: update done", "integrator: M, Jc seen (obs joint rows done)",
           "observer base rows done", "QP0 stores issued"]
+import os
+os.environ["WBC_ROLLOUT_SPW"] = "16"   # the stamp columns are indexed by 16-state workgroups
 n, H = 1024, 20
 P = synth.default_params(observer_order=1); s = W.Solver(m, W.Params.from_dict(P), max_batch=n)
 B = synth.make_batch(5, n, m.total_mass)
