@@ -372,6 +372,26 @@ def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, orac
         assert relerr(a[k], b[k]) < 1e-10, k
 
 
+@pytest.mark.parametrize("obs,n", [(1, 777), (0, 130), (2, 1500)])
+def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, oracle, monkeypatch, obs, n):
+    """The persistent rollout kernel gives a workgroup 4 states (up to 1024 rollouts) or 16 (WBC_ROLLOUT_SPW): another
+    distribution of the same per-state arithmetic over the device -> bit-identical results."""
+    torch = torch_cuda
+    B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=67)
+    tau_ext = np.zeros((n, 18))
+    tau_ext[:, 0:3] = B["push"]
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    res = {}
+    for spw in ("4", "16"):
+        monkeypatch.setenv("WBC_ROLLOUT_SPW", spw)
+        solver, P = _solver(gpu_model, obs=obs, max_batch=n)
+        monkeypatch.delenv("WBC_ROLLOUT_SPW", raising=False)
+        res[spw] = _gpu_rollout(torch, solver, P, 9, B, tau_ext, None if integ is None else integ.copy(),
+                                np.zeros((n, 18)) if obs else None)
+    for k in res["4"]:
+        assert np.array_equal(res["4"][k], res["16"][k]), k
+
+
 def test_rollout_vs_golden(torch_cuda, gpu_model):
     import os
     torch = torch_cuda
