@@ -504,7 +504,7 @@ def test_split_sweep_variant_matches(torch_cuda, gpu_model, oracle, monkeypatch)
 
 
 @pytest.mark.parametrize("obs,dtype,n", [(0, "f64", 4096), (0, "f64", 1003), (1, "f64", 2049), (2, "f64", 17), (0, "f32", 3000),
-                                         (1, "f32", 555)])
+                                         (1, "f32", 555), (0, "f64", 8192), (1, "f32", 6000)])   # the last two: two rounds of workgroups
 def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkeypatch, obs, dtype, n):
     """Batches that fit one workgroup per CU (N <= 4096) run the tick as ONE kernel (fused_tick.hip.hpp); WBC_FUSED_MAX=0
     forces the two-kernel tick.  The fused kernel's front half is rnea_step + mass_jac (+ an observer role), i.e. another
