@@ -2,7 +2,8 @@
 per-tick-launch path of the same library (same device functions, other synchronisation) and, every few cases, with the CPU
 oracle.  The fused tick and the persistent rollouts hand data between wavefronts through LDS counters; a synchronisation
 mistake there would show up as a rare, timing-dependent mismatch, which the fixed-seed unit tests could miss.
-usage: python tools/soak.py [cases] [seed]     (prints one summary line; exit status 1 on any mismatch)"""
+usage: python tools/soak.py [cases] [seed] [f64|f32]     (prints one summary line; exit status 1 on any mismatch;
+fp32: single ticks only, rounding-level tolerances, a state whose status flips between the variants is counted, not failed)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -16,6 +17,9 @@ from oracle import oracle_py, urdf_model
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+DT = sys.argv[3] if len(sys.argv) > 3 else "f64"
+TOL = 1e-11 if DT == "f64" else 2e-2
+flips = 0
 rng = np.random.default_rng(seed)
 gm = W.Model.from_urdf(W.SYNTHETIC_URDF)
 orc = oracle_py.Oracle(urdf_model.load_urdf(W.SYNTHETIC_URDF))
@@ -40,14 +44,15 @@ for c in range(cases):
     B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
     integ0 = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
     z = lambda: (None if integ0 is None else integ0.copy(), None if integ0 is None else np.zeros((n, 18)))
-    if c % 3 != 2:   # ---- one tick: fused vs two-kernel, two consecutive ticks (observer state carried)
+    if c % 3 != 2 or DT == "f32":   # ---- one tick: fused vs two-kernel, two consecutive ticks (observer state carried)
         res = {}
         for tag, env in (("fused", {}), ("two", {"WBC_FUSED_MAX": "0"})):
-            s, P = solver_with(env, obs=obs, max_batch=n)
-            a1 = _run_step(torch, s, B, "f64", *z(), want_mats=bool(c % 2))
-            a2 = _run_step(torch, s, B, "f64", a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
+            s, P = solver_with(env, obs=obs, max_batch=n, dtype=DT)
+            zz = tuple(None if t is None else t.astype(np.float32 if DT == "f32" else np.float64) for t in z())
+            a1 = _run_step(torch, s, B, DT, *zz, want_mats=bool(c % 2))
+            a2 = _run_step(torch, s, B, DT, a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
             res[tag] = (a1, a2)
-        if c % 5 == 0:   # the same launch again, several times: results must be bit-identical run to run
+        if c % 5 == 0 and DT == "f64":   # the same launch again, several times: results must be bit-identical run to run
             s, P = solver_with({}, obs=obs, max_batch=n)
             first = _run_step(torch, s, B, "f64", *z(), want_mats=True)
             for _ in range(6):
@@ -57,16 +62,20 @@ for c in range(cases):
                         bad.append((c, "nondeterministic " + k, n, obs, cfg))
         for i in (0, 1):
             a, b = res["fused"][i], res["two"][i]
-            if not np.array_equal(a["status"], b["status"]):
-                bad.append((c, "status", n, obs, cfg))
+            same = a["status"] == b["status"]
+            if not same.all():
+                if DT == "f64" or same.mean() < 0.995:
+                    bad.append((c, "status", n, obs, cfg))
+                flips += int((~same).sum())
             for k in a:
                 if k in ("status", "iters"):
                     continue
-                e = relerr(a[k], b[k])
+                x, y = (a[k][same], b[k][same]) if a[k].shape[0] == same.shape[0] else (a[k], b[k])
+                e = relerr(x, y) if x.size else 0.0
                 worst = max(worst, e)
-                if not e < 1e-11:
+                if not e < TOL:
                     bad.append((c, k, n, obs, cfg, e))
-        if c % 9 == 0:
+        if c % 9 == 0 and DT == "f64":
             ig, r = z()
             ref = orc.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"], ig, r, nthreads=8)
             e = max(relerr(res["fused"][0]["tau"], ref["tau"]), relerr(res["fused"][0]["f"], ref["f"]))
@@ -92,6 +101,6 @@ for c in range(cases):
             worst = max(worst, e)
             if not e < 1e-9:
                 bad.append((c, "rollout " + k, n, obs, cfg, H, e))
-print("soak: %d cases, seed %d, %.0f s, worst relative difference between dispatch variants %.2e, mismatches: %d %s"
-      % (cases, seed, time.time() - t0, worst, len(bad), bad[:10]))
+print("soak: %d cases (%s), seed %d, %.0f s, worst relative difference between dispatch variants %.2e, status flips %d, mismatches: %d %s"
+      % (cases, DT, seed, time.time() - t0, worst, flips, len(bad), bad[:10]))
 sys.exit(1 if bad else 0)
