@@ -262,8 +262,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; Jr[c] = isvar ? J0[v * 12 + c] : (T)0; });
 
   // ------------------------------------------------------------------ g = -A^T S b (b = w_des - rhat_base enters here)
-  T g_me;
-  {
+  // and the unconstrained minimum x = -J J^T g.  Inside the fused kernels (WSLDS) this runs AFTER the constraint rows
+  // below are set up: those need the terrain only, and b may still be on its way from the observer role.
+  T g_me = 0, x_me = 0;
+  auto solve_x0 = [&]() __attribute__((always_inline)) {
     WBC_QSTAMP(3);
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
     if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
@@ -274,16 +276,13 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     b[3] = dppx<0x150 + 3>(b_ld); b[4] = dppx<0x150 + 4>(b_ld); b[5] = dppx<0x150 + 5>(b_ld);
     const T bs = (c3 == 0 ? b[0] : (c3 == 1 ? b[1] : b[2]));
     g_me = isvar ? -(Sme * bs + u0 * b[3] + u1 * b[4] + u2 * b[5]) : (T)0;
-  }
-  // ------------------------------------------------------------------ unconstrained minimum x = -J J^T g
-  T x_me;
-  {
     T t_me = 0;
     sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; t_me += Jc[i] * gbc<i>(g_me); });
     T acc = 0;
     sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; acc += Jr[c] * gbc<c>(t_me); });
     x_me = -acc;
-  }
+  };
+  if constexpr (!WSLDS) solve_x0();
 
   // ------------------------------------------------------------------ my constraints (friction pyramid, force box)
   T cAx, cAy, cAz, rA, cBx = 0, cBy = 0, cBz = 0;
@@ -314,6 +313,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (WSLDS) solve_x0();
   } else {
     __shared__ int rg_key[16];
     __shared__ T rg_x[16][16];
