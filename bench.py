@@ -7,8 +7,11 @@ One "step" = one control tick (dynamics sweep -> observer -> GRF QP -> torque ma
 synthetic states already resident in HBM.  Default workload = BASELINE.json configs[1]:
 batch 4096 DogBot-like states per GPU, 4-contact stance, observer off, fp64 (the real DogBot URDF is
 absent; a synthetic quadruped of the same topology stands in -- see DESIGN.md).
-For N > 1 the driver launches this under torch.distributed.run, one rank per GPU; the batch shards
-with no data-path collective (weak scaling: per-GPU batch fixed).
+For N > 1: one rank per GPU over RCCL; the batch shards with no data-path collective (weak scaling: per-GPU batch
+fixed).  Under torch.distributed.run (the driver's form) this process is one rank.  Started bare
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) it launches the N ranks itself as a child
+`python -m torch.distributed.run ...` BEFORE touching the GPU, forwards rank 0's JSON line and exits with the
+children's status (non-zero with a clear message when the box has fewer than N GPUs).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -37,6 +40,53 @@ def dyn_kernel_name(split):
     return "mass_jac_kernel" if split else "dyn_sweep_kernel"
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks as a child process.  Nothing in THIS process
+    initialises the GPU (device_count() does not, on this image) and nothing is exec'ed: the child is a subprocess and
+    its exit status becomes ours."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this box: nothing measured\n" % (args.gpus, have))
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400):
+    """Times blocks of EXACTLY `steps` ticks, each bracketed by barrier + synchronize on both sides, until at least
+    `min_total_s` has been measured; returns the per-block seconds (max over ranks).  A 20-tick block at the bench
+    default lasts 0.5 ms -- one scheduler hiccup moves a single sample by > 5 %, the median of ~100 blocks does not."""
+    times = []
+    total = 0.0
+    while len(times) < max_blocks and (total < min_total_s or not times):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:   # every rank takes the same decision: the slowest rank's clock
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+        total += dt
+    return times
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,7 +102,12 @@ def main():
     ap.add_argument("--sample-every", type=int, default=10, help="HIP-event instrumentation period inside the timed region")
     ap.add_argument("--large-batch", type=int, default=262144, help="extra roofline characterisation batch (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-state latency leg (p50 over 1000 ticks)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 without torchrun: ONE process drives N devices through the C-ABI's wbc_multi_* path")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
+        sys.exit(self_launch(args))
 
     import numpy as np
     import torch
@@ -68,7 +123,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if args.single_process:
+        return multi_capi_bench(args, W, synth, torch, np)
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
 
     if args.config == 5:
@@ -109,23 +168,10 @@ def main():
     # events around every launch costs ~15 us per tick at this batch size, which would be a quarter of the step.
     sample = max(1, args.sample_every)
     solver.enable_timing(sample)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
+    blocks = timed_blocks(step, args.steps, dist, torch)
     tm = solver.collect_timing()
     solver.enable_timing(0)
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(np.median(blocks))   # seconds per block of exactly args.steps ticks
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
     # the optional consumer-side collective (every rank receives all torques), reported BESIDE `value`
@@ -185,6 +231,7 @@ def main():
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": pmc_traffic(("fused_tick" if fused else dyn_kernel_name(split)), n, dtype),
+                         "traffic_source": PMC_SOURCE,
                          "algorithmic_words_per_state": words,
                          "algorithmic_bytes_per_launch": dyn_bytes, "avg_launch_us": dyn_s * 1e6,
                          "launches_timed": tm["fused_launches"] if fused else tm["dyn_launches"],
@@ -205,7 +252,12 @@ def main():
                                   else "rnea_step (no CRBA, no M/h/Jc) -> qp")},
             "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                    "iters_max": int(iters.max())},
+            "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_min": min(blocks) * 1e3,
+                       "block_ms_median": elapsed * 1e3, "block_ms_max": max(blocks) * 1e3,
+                       "note": "value and ms_per_step are the MEDIAN block of exactly `steps` ticks (barrier + synchronize on both "
+                               "sides of every block, max over ranks); blocks repeat until >= 50 ms are measured"},
             "with_tau_allgather": gather_res,
+            "rccl_ranks": world if dist is not None else None,
         }
         if not args.no_latency and world == 1:
             res["qp_latency"] = qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs)
@@ -231,6 +283,72 @@ def main():
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def multi_capi_bench(args, W, synth, torch, np):
+    """--single-process: ONE host process, --gpus shards through the C-ABI's wbc_multi_* (what a C++ host does; shards are
+    dealt round-robin over the visible devices, so on a 1-GPU box this is a functional run on device 0).  Same workload,
+    timing brackets and JSON keys as the torchrun path; `value` excludes the gather, `with_tau_allgather` includes it."""
+    dtype = args.dtype or ("f32" if args.config == 4 else "f64")
+    obs = 0 if args.config == 2 else 1
+    td = torch.float64 if dtype == "f64" else torch.float32
+    k = args.gpus
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(k)]
+    distinct = ndev >= k
+    n_total = args.batch * k
+    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    P = synth.default_params(observer_order=obs, dtype=dtype)
+    ms = W.MultiSolver(model, W.Params.from_dict(P, dtype), dtype=dtype, devices=devices, max_batch_total=n_total,
+                       gather="rccl" if distinct else "peer")
+    shards = [synth.make_batch(args.config, args.batch, model.total_mass, rank=r) for r in range(k)]
+    put = lambda a, d: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).to(torch.device("cuda", d))
+    ins = {name: [put(B[name], d) for B, d in zip(shards, devices)] for name in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+    ins["mask"] = [torch.from_numpy(B["mask"]).to(torch.device("cuda", d)) for B, d in zip(shards, devices)]
+    obs_state = None
+    if obs:
+        integ = []
+        for i, d in enumerate(devices):
+            sv = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=d, max_batch=args.batch)
+            integ.append(sv.dynamics(ins["q"][i], ins["v"][i], want=("p",))["p"].clone())
+        obs_state = (integ, [torch.zeros_like(x) for x in integ])
+    tick, outs = ms.prepare_step(n_total, ins, obs_state, want_mats=not args.no_mats)
+    tau_all = ms.allgather_tau(n_total, outs)
+    ms.synchronize()
+
+    def run(with_gather):
+        times, total = [], 0.0
+        while total < 0.05 or not times:
+            ms.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                tick()
+                if with_gather:
+                    ms.allgather_tau(n_total, outs, tau_all)
+            ms.synchronize()
+            times.append(time.perf_counter() - t0)
+            total += times[-1]
+        return times
+
+    for _ in range(args.warmup):
+        tick()
+    blocks = run(False)
+    gblocks = run(True)
+    el, gel = float(np.median(blocks)), float(np.median(gblocks))
+    ok = float(np.mean([(o["status"] == 0).double().mean().item() for o in outs]))
+    print(json.dumps({
+        "metric": "WBC control-steps/sec (batched DogBot)", "value": args.steps * n_total / el, "unit": "control-steps/s",
+        "n_gpus": k, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": "configs[%d] per shard: batch=%d states, observer %s, %s; ONE process, %d shards through wbc_multi_* "
+                               "on devices %s" % (args.config - 1, args.batch, "on" if obs else "off", dtype, k, devices),
+                   "batch_per_gpu": args.batch, "parallelism": "single process, batch-sharded x%d (C-ABI wbc_multi_step_batch), no data-path collective" % k,
+                   "distinct_devices": distinct},
+        "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_median": el * 1e3, "block_ms_min": min(blocks) * 1e3,
+                   "block_ms_max": max(blocks) * 1e3},
+        "with_tau_allgather": {"value": args.steps * n_total / gel, "ms_per_step": gel / args.steps * 1e3,
+                               "collective": ("RCCL ncclAllGather (ncclCommInitAll, one group call)" if distinct else "peer copies (shards share a device)")},
+        "rccl_ranks": ms.rccl_ranks, "qp": {"status_ok_frac": ok}, "roofline": None, "cpu_baseline": None}))
 
 
 def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
@@ -275,20 +393,8 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
     for _ in range(max(1, args.warmup)):
         one_rollout()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_rollout()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    blocks = timed_blocks(one_rollout, args.steps, dist, torch)
+    elapsed = float(np.median(blocks))
     ok = float((out["status"].cpu().numpy() == 0).mean())
     if rank == 0:
         print(json.dumps({
@@ -303,6 +409,8 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
                        "launches": ("one persistent rollout_kernel launch per rollout" if (n <= 4096 and os.environ.get("WBC_ROLLOUT_PERSISTENT", "1") != "0")
                                     else "per tick: %sdyn_sweep/fused tick, qp, integrate" % ("reference, " if args.tracking else ""))},
             "us_per_tick": elapsed / args.steps / H * 1e6, "qp": {"status_ok_frac_last_tick": ok},
+            "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_min": min(blocks) * 1e3,
+                       "block_ms_median": elapsed * 1e3, "block_ms_max": max(blocks) * 1e3},
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()
@@ -346,6 +454,31 @@ def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):
         fusk.append(tm.get("fused_ms", 0.0))
     solver.enable_timing(0)
     fused = float(np.median(fusk)) > 0
+    # BASELINE.json "p50 QP us": the GRF QP as its own kernel at N = 1, measured here with a second solver whose tick is
+    # the two-kernel form (wbc_solver_options.fused_max = 0): dispatch start/stop events of the QP kernel, 300 ticks
+    s2 = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=1,
+                  options={"fused_max": 0})
+    out2 = {}
+    integ2 = None if integ is None else integ.clone()
+    rr2 = None if rr is None else torch.zeros_like(rr)
+
+    def tick2():
+        return s2.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                       inp["f_prev"], integ2, rr2, out=out2, want_mats=False)
+
+    out2.update(tick2())
+    for _ in range(20):
+        tick2()
+    torch.cuda.synchronize()
+    s2.enable_timing(1)
+    qp2, front2 = [], []
+    for _ in range(300):
+        tick2()
+        torch.cuda.synchronize()
+        tm = s2.collect_timing()
+        qp2.append(tm["qp_ms"])
+        front2.append(tm["dyn_ms"] + tm["rnea_ms"])
+    s2.enable_timing(0)
     # the host-pointer single-robot call (BASELINE.json configs[0] shape): staging copy in, tick, copy out, one sync
     h = {k: np.ascontiguousarray(B[k][0], dtype=np.float64) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
     hig = np.zeros(18) if obs else None
@@ -362,12 +495,13 @@ def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):
     return {"ticks": 1000, "tick_p50_us": float(np.median(wall)) * 1e6, "tick_p99_us": float(np.percentile(wall, 99)) * 1e6,
             "compute_torques_p50_us": float(np.median(cwall)) * 1e6, "compute_torques_p99_us": float(np.percentile(cwall, 99)) * 1e6,
             "tick_kernel_p50_us": float(np.median(fusk)) * 1e3 if fused else None,
-            "qp_kernel_p50_us": None if fused else float(np.median(qpk)) * 1e3,
-            "front_kernel_p50_us": None if fused else float(np.median(dynk)) * 1e3,
-            "note": "N=1 per launch, synchronous wbc_step_batch without M/h/Jc outputs (%s); tick = host wall time incl. launch + "
-                    "stream sync; kernel spans are raw HIP-event spans over 200 further ticks; the GRF QP alone as its own kernel "
-                    "at N=1 takes 6.3 us (WBC_FUSED_MAX=0)" % ("one fused launch: rnea_step and qp_group16 as wavefront roles"
-                                                              if fused else "rnea_step -> qp")}
+            "qp_kernel_p50_us": float(np.median(qp2)) * 1e3, "qp_kernel_p99_us": float(np.percentile(qp2, 99)) * 1e3,
+            "front_kernel_p50_us": float(np.median(front2)) * 1e3,
+            "note": "N=1 per launch, synchronous wbc_step_batch without M/h/Jc outputs; tick = host wall time incl. launch + stream "
+                    "sync of the default dispatch (%s); tick_kernel = its kernel span over 200 further ticks; qp_kernel / "
+                    "front_kernel = the GRF QP (assembly + solve + torque map) and the rnea_step front half as their own kernels, "
+                    "measured in this run on a second solver with fused_max = 0 (dispatch start/stop events, 300 ticks)"
+                    % ("one fused launch: rnea_step and qp_group16 as wavefront roles" if fused else "rnea_step -> qp")}
 
 
 def sweep_alone_roofline(solver, torch, inp, n, dtype, ts):
@@ -388,6 +522,10 @@ def sweep_alone_roofline(solver, torch, inp, n, dtype, ts):
     return {"kernel": "dyn_sweep_kernel (M, h, Jc only)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "avg_launch_us": t * 1e6, "launches_timed": tm["dyn_launches"],
             "traffic": pmc_traffic("dyn_sweep_kernel", n, dtype), "algorithmic_words_per_state": DYN_WORDS_FUSED}
+
+
+PMC_SOURCE = ("profiles/pmc_latest.json: committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs) of this "
+              "workload on MI355X -- NOT collected inside this run")
 
 
 def pmc_traffic(kernel, n, dtype):

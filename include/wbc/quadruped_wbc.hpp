@@ -6,8 +6,9 @@
 // (/root/reference/README.md:11).  The reference's class and method names live in an absent
 // submodule (/root/reference/.gitmodules:4-6) and are [UNVERIFIED]; rename to taste when binding.
 //
-// The ROS message adaptors at the bottom are compiled only with -DWBC_WITH_ROS (ROS is absent from
-// this image, so they are UNTESTED); without it, plain structs of the same field layout are used.
+// The ROS message adaptors at the bottom are compiled only with -DWBC_WITH_ROS.  ROS is absent from this image: the
+// section is compile-checked against field-layout stubs of the three message headers (tests/stubs/, labelled as
+// stubs -- they pin nothing about the real controller's topics or types, which are [UNVERIFIED]).
 #pragma once
 #include <array>
 #include <stdexcept>
@@ -15,6 +16,11 @@
 #include <vector>
 
 #include "../wbc_hip.h"
+#ifdef WBC_WITH_ROS
+#include <gazebo_msgs/ModelStates.h>
+#include <sensor_msgs/JointState.h>
+#include <std_msgs/Float64MultiArray.h>
+#endif
 
 namespace wbc {
 
@@ -93,7 +99,8 @@ class QuadrupedWBC {
     std::vector<double> f(3 * nf_);
     int status = -1;
     const bool obs = params_.observer_order > 0;
-    if (obs && !obs_started_) {  // integ(0) = p(0): one dynamics-only tick would give M v; start from rest instead
+    if (obs && !obs_started_) {  // start-up contract of the observer (wbc_observer_state): integ(0) = p(0) = M(q0) v0, r(0) = 0
+      check(wbc_observer_init(solver_, q.data(), v.data(), obs_integ_.data(), obs_r_.data()), "wbc_observer_init");
       obs_started_ = true;
     }
     check(wbc_compute_torques(solver_, q.data(), v.data(), cmd.w_des, cmd.vdot_des.data(), normals, mu, mask,
@@ -124,7 +131,8 @@ class QuadrupedWBC {
   }
 
   // Observer state (the only per-robot state carried across ticks): snapshot / restore / initialise.
-  void setObserverState(const std::vector<double>& integ, const std::vector<double>& r) { obs_integ_ = integ; obs_r_ = r; }
+  void setObserverState(const std::vector<double>& integ, const std::vector<double>& r) { obs_integ_ = integ; obs_r_ = r; obs_started_ = true; }
+  void resetObserver() { obs_started_ = false; }   // the next computeTorques re-seeds integ = M v, r = 0
   const std::vector<double>& disturbanceEstimate() const { return obs_r_; }
 
  private:
@@ -151,12 +159,16 @@ class QuadrupedWBC {
 };
 
 #ifdef WBC_WITH_ROS
-// UNTESTED (ROS absent from the build image).  Adaptors from the real message types:
+// Compile-checked against stubs only (ROS absent from the build image).  Adaptors from the standard message types of a
+// Gazebo + ros_control loop (/root/reference/README.md:38 names ros-control / ros-controllers as dependencies):
 //   BaseState  <- gazebo_msgs::ModelStates (pose[i], twist[i] of the robot model)
 //   JointState <- sensor_msgs::JointState
-//   torques    -> std_msgs::Float64 per joint effort controller (ros_control, README.md:38)
-#include <gazebo_msgs/ModelStates.h>
-#include <sensor_msgs/JointState.h>
+//   torques    -> std_msgs::Float64MultiArray for a JointGroupEffortController (ros_controllers), jointNames() order
+// index of the robot in a ModelStates message; -1 when absent
+inline int findModel(const gazebo_msgs::ModelStates& ms, const std::string& model_name) {
+  for (size_t i = 0; i < ms.name.size(); ++i) if (ms.name[i] == model_name) return (int)i;
+  return -1;
+}
 inline BaseState fromRos(const gazebo_msgs::ModelStates& ms, size_t i) {
   BaseState b;
   b.position[0] = ms.pose[i].position.x; b.position[1] = ms.pose[i].position.y; b.position[2] = ms.pose[i].position.z;
@@ -167,6 +179,11 @@ inline BaseState fromRos(const gazebo_msgs::ModelStates& ms, size_t i) {
   return b;
 }
 inline JointState fromRos(const sensor_msgs::JointState& m) { return JointState{m.name, m.position, m.velocity}; }
+inline std_msgs::Float64MultiArray toRos(const std::vector<double>& tau) {
+  std_msgs::Float64MultiArray cmd;
+  cmd.data = tau;
+  return cmd;
+}
 #endif
 
 }  // namespace wbc

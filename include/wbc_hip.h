@@ -14,7 +14,9 @@
  * Rules of the ABI: extern "C"; plain pointers and sizes; no exceptions cross it; every function
  * returns an int status (WBC_OK = 0); the caller owns every batch buffer; a solver is bound to one
  * HIP device, is not thread-safe, distinct solvers are; no allocation or synchronisation happens
- * inside wbc_step_batch / wbc_dynamics_batch (they are hipGraph-capturable).
+ * inside wbc_step_batch / wbc_dynamics_batch (they are hipGraph-capturable -- except while per-kernel
+ * timing is enabled: a dispatch that carries timing events cannot be captured).  Every entry point runs
+ * on its solver's device and restores the caller's current HIP device before it returns.
  *
  * Batch layout in HBM: structure-of-arrays, component-major: x[c * N + s] is component c of state s
  * (N = batch size of the call).  Scalars are double (WBC_F64) or float (WBC_F32) per the solver.
@@ -93,6 +95,26 @@ void wbc_params_default(wbc_params* p, int dtype);
 /* ---- solver ---- */
 int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
                       wbc_solver** out);
+
+/* Kernel-selection options.  The defaults are the measured winners; nothing in the library reads the
+ * environment, so a C++ host sees every switch here.  Call wbc_solver_options_default first, then change fields. */
+enum wbc_timing_mode { WBC_TIMING_DISPATCH = 0, /* the dispatch's own start/stop timestamps (what rocprofv3 reports) */
+                       WBC_TIMING_EVENT_PAIR = 1 /* an event pair recorded around the launch (+2-3 us per span) */ };
+typedef struct wbc_solver_options {
+  size_t struct_size;     /* sizeof(wbc_solver_options) of the caller's build (set by wbc_solver_options_default) */
+  long long fused_max;    /* ticks of at most this many states run as ONE launch of wavefront roles; -1 = auto
+                             (4096 for fp64 observer-on ticks, 8192 otherwise), 0 = always the two-kernel tick */
+  int rollout_persistent; /* 1 (default): rollouts of at most fused_max states = one launch per rollout; 0: per-tick launches */
+  int rollout_spw;        /* states per workgroup of the rollout kernel: 0 = auto (4 up to 1024 states, else 16), 4, 16 */
+  long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
+                             kernel on a second stream beside the sweep; -1 = never (default) */
+  int one_zerocopy;       /* 1: the single-robot host-pointer calls let the kernel read/write the pinned staging image directly */
+  int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */
+} wbc_solver_options;
+void wbc_solver_options_default(wbc_solver_options* o);
+int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
+                         const wbc_solver_options* opt /* NULL = defaults */, wbc_solver** out);
+int wbc_solver_device(const wbc_solver* s); /* HIP device index, -1 for NULL */
 void wbc_solver_destroy(wbc_solver* s);
 int wbc_solver_set_params(wbc_solver* s, const wbc_params* p);
 
@@ -119,6 +141,11 @@ typedef struct wbc_batch_out {
   void* pf;   /* may be NULL */
 } wbc_batch_out;
 
+/* Momentum-observer state, in/out across ticks.  START-UP CONTRACT: the residual is r = K1 (M v - integ), so before the
+ * first observer-on tick integ must hold the generalized momentum p(0) = M(q0) v0 of the state the loop starts from and
+ * r must be zero -- zeros in integ are only right for a robot at rest (otherwise the first ticks carry a spurious
+ * estimate of about K1 p(0) that decays with time constant 1/K1).  Batch callers get p from
+ * wbc_dynamics_batch(..., p = integ, ...); the single-robot loop calls wbc_observer_init. */
 typedef struct wbc_observer_state {
   void* integ;
   void* r;
@@ -190,22 +217,68 @@ int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const d
                         const double* tau_prev, const double* f_prev, double* obs_integ, double* obs_r,
                         double* tau, double* f, int* status);
 
+/* Observer start-up for the single-robot host-pointer loop (see wbc_observer_state): writes integ = M(q) v and r = 0
+ * (host arrays of nv doubles).  Synchronises. */
+int wbc_observer_init(wbc_solver* s, const double* q, const double* v, double* obs_integ, double* obs_r);
+
 /* Single-robot, host-pointer form of wbc_reference_batch (q[19], v[18], plan[12] in; w_des[6], vdot_des[18] and the
  * optional com[6] out): the planner call of a one-robot control loop.  Synchronises. */
 int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const double* plan, double t,
                           double* w_des, double* vdot_des, double* com);
 
-/* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on (the dispatch's own start /
- * stop events; env WBC_TIMING=pair: an event pair recorded around the launch instead) ---- */
+/* ---- measurement: per-kernel HIP-event timing on the stream the kernels are launched on (wbc_solver_options.timing_mode:
+ * the dispatch's own start / stop events, or an event pair recorded around the launch).  Enabling allocates a ring of
+ * 4096 event pairs once; samples beyond it are dropped until wbc_solver_collect_timing drains the ring, so a tick never
+ * allocates.  While timing is on, the instrumented dispatches are not hipGraph-capturable. ---- */
 int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 every kernel launch; k > 1: every k-th tick */
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed
- * 0 = dyn_sweep kernel (or mass_jac with WBC_SWEEP=split), 1 = QP kernel, 2 = rnea_step kernel (no-M/h/Jc ticks and
- * split mode), 3 = fused tick kernel (sweep + QP of small batches in one launch); resets the accumulators. */
+ * 0 = dyn_sweep kernel, 1 = QP kernel, 2 = rnea_step kernel (no-M/h/Jc ticks) / stand-alone observer kernel,
+ * 3 = fused tick kernel (sweep + QP of small batches in one launch); resets the accumulators. */
 int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launches[4]);
+
+/* ---- multi-device: ONE host process, one solver per GPU of the node.  The reference is a single C++
+ * process (/root/reference/README.md:58-60); this is how that process shards a batch over the node without Python.
+ * The batch splits into contiguous slices (wbc_shard_range), shard k runs on devices[k] on its own stream; there is NO
+ * data-path collective.  Optional consumer-side collective: every device receives all torques -- RCCL ncclAllGather
+ * over xGMI (communicators from ncclCommInitAll; librccl is loaded on demand) or peer copies. ---- */
+typedef struct wbc_multi wbc_multi;
+enum wbc_gather_backend { WBC_GATHER_NONE = 0, WBC_GATHER_RCCL = 1, WBC_GATHER_PEER_COPY = 2 };
+/* contiguous balanced slices: the first (n_total % n_shards) shards hold one extra state */
+int wbc_shard_range(size_t n_total, int n_shards, int shard, size_t* start, size_t* count);
+/* devices[k] = HIP device of shard k (RCCL: all distinct; NONE / PEER_COPY: a device may host several shards).
+ * max_batch_total bounds n_total of every later call; opt may be NULL. */
+int wbc_multi_create(const wbc_model* m, const wbc_params* p, int dtype, const int* devices, int n_devices,
+                     size_t max_batch_total, int gather_backend, const wbc_solver_options* opt, wbc_multi** out);
+void wbc_multi_destroy(wbc_multi* mm);
+int wbc_multi_size(const wbc_multi* mm);                    /* number of shards */
+int wbc_multi_device(const wbc_multi* mm, int shard);       /* HIP device of a shard */
+wbc_solver* wbc_multi_solver(wbc_multi* mm, int shard);     /* the shard's solver (dynamics, timing, reference ... on its device) */
+void* wbc_multi_stream(wbc_multi* mm, int shard);           /* hipStream_t the shard's work is enqueued on */
+int wbc_multi_rccl_ranks(const wbc_multi* mm);              /* ranks of the RCCL communicator; 0 when RCCL is not in use */
+int wbc_multi_set_params(wbc_multi* mm, const wbc_params* p);
+/* One control tick of n_total states.  in[k] / out[k] / obs[k] (arrays of wbc_multi_size entries; obs may be NULL when
+ * the observer is off) describe shard k's slice: device pointers on devices[k], component-major with N = the shard's
+ * count.  Enqueues every shard on its stream and returns without synchronising. */
+int wbc_multi_step_batch(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out,
+                         const wbc_observer_state* obs);
+/* wbc_rollout_batch per shard (BASELINE.json configs[4]: rank-local for all ticks); tau_ext[k] may be NULL (as may tau_ext) */
+int wbc_multi_rollout_batch(wbc_multi* mm, size_t n_total, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
+                            const wbc_observer_state* obs, const void* const* tau_ext);
+/* All-gather of the torques behind a tick (on the shard streams): tau_local[k] = shard k's [nj][count_k] on devices[k];
+ * tau_all[k] on devices[k] receives wbc_multi_size blocks of nj * count_0 scalars, block j = shard j's tau exactly as
+ * shard j laid it out ([nj][count_j], packed; the tail of a shorter shard's block is padding). */
+int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all);
+int wbc_multi_synchronize(wbc_multi* mm);                   /* waits for every shard stream */
+/* Host-resident batch (a C++ caller that holds host arrays, e.g. the ROS side): in / out / obs hold HOST pointers to
+ * component-major arrays [ncomp][n_total] of the solver's scalar type; slices are scattered to the devices with pitched
+ * copies, stepped, and tau, f, status, iters (and the observer state, when obs is given) gathered back.  out->M, h, Jc,
+ * pf must be NULL.  Synchronises.  PCIe-bound by construction. */
+int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batch_in* host_in, const wbc_batch_out* host_out,
+                        const wbc_observer_state* host_obs);
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void); /* 2 */
+int wbc_abi_version(void); /* 3 */
 
 #ifdef __cplusplus
 }

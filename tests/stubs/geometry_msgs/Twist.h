@@ -1,0 +1,6 @@
+// STUB of geometry_msgs/Twist (field layout only) -- see tests/stubs/README.md
+#pragma once
+namespace geometry_msgs {
+struct Vector3 { double x = 0, y = 0, z = 0; };
+struct Twist { Vector3 linear, angular; };
+}

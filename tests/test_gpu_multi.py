@@ -1,0 +1,195 @@
+"""GPU: the multi-device C-ABI (wbc_multi_*) and the C++ consumers of the boundary.
+
+A stand-alone C++ program (tools/abi_consumer.cpp: no Python, no torch inside) reads a seeded batch the test wrote,
+runs one control tick through the C-ABI with raw hipMalloc'ed buffers and dumps tau, f, status and the observer state;
+the test compares that dump with the CPU oracle and the sharded variants with the single-solver run bit for bit.
+On a 1-GPU box several shards share device 0 (peer-copy gather); the RCCL gather runs with however many devices are
+visible (ncclCommInitAll over all of them)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.util import relerr, to_dev, to_host
+from wbc_quadruped_dob_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROWS = dict(q=19, v=18, w_des=6, vdot_des=18, normals=12, mu=4, tau_prev=12, f_prev=12)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def consumer():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools")])
+    return os.path.join(ROOT, "tools", "abi_consumer.bin")
+
+
+def _write_input(path, B, P, integ, r):
+    n = B["q"].shape[0]
+    with open(path, "wb") as f:
+        np.array([n, P["observer_order"]], np.int64).tofile(f)
+        pv = np.concatenate([P["S"], [P["alpha"], P["fn_min"], P["fn_max"], P["mu_scale"], P["dt"], P["qp_tol"], float(P["max_iter"])],
+                             P["K1"][:18], P["K2"][:18]]).astype(np.float64)
+        assert pv.size == 49
+        pv.tofile(f)
+        for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev"):
+            np.ascontiguousarray(B[k].T, np.float64).tofile(f)      # component-major
+        np.ascontiguousarray(integ.T, np.float64).tofile(f)
+        np.ascontiguousarray(r.T, np.float64).tofile(f)
+        np.ascontiguousarray(B["mask"], np.int32).tofile(f)
+
+
+def _read_output(path, n):
+    raw = open(path, "rb").read()
+    o, res = 0, {}
+    for k, rows in (("tau", 12), ("f", 12), ("integ", 18), ("r", 18)):
+        res[k] = np.frombuffer(raw, np.float64, rows * n, o).reshape(rows, n).T.copy()
+        o += rows * n * 8
+    for k in ("status", "iters"):
+        res[k] = np.frombuffer(raw, np.int32, n, o).copy()
+        o += 4 * n
+    res["rccl_ranks"], res["gather_mismatches"] = (int(x) for x in np.frombuffer(raw, np.int32, 2, o))
+    return res
+
+
+def _consume(consumer, tmp_path, mode, B, P, integ, r):
+    import wbc_quadruped_dob_amd as W
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / ("out_%s.bin" % mode.replace(":", "_")))
+    _write_input(fin, B, P, integ, r)
+    run = subprocess.run([consumer, W.SYNTHETIC_URDF, fin, fout, mode], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    return _read_output(fout, B["q"].shape[0])
+
+
+@pytest.mark.parametrize("obs,n", [(0, 1000), (1, 1001)])
+def test_cpp_consumer_matches_oracle_and_shards_match_single(torch_cuda, gpu_model, oracle, consumer, tmp_path, obs, n):
+    """C++ through the C-ABI vs the oracle (1e-9), then the same tick through wbc_multi_* (3 ragged shards, peer-copy
+    all-gather checked on every device), through the RCCL gather over the visible devices, and through the host-batch
+    convenience call: every sharded variant equals the single-solver result bit for bit."""
+    P = synth.default_params(observer_order=obs)
+    B = synth.make_batch(4 if obs else 2, n, gpu_model.total_mass, rank=23)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else np.zeros((n, 18))
+    r = 0.1 * np.cos(np.arange(n * 18).reshape(n, 18)) if obs else np.zeros((n, 18))
+    one = _consume(consumer, tmp_path, "single", B, P, integ, r)
+    ig_ref, r_ref = integ.copy(), r.copy()
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"],
+                      ig_ref if obs else None, r_ref if obs else None, nthreads=8)
+    assert np.array_equal(one["status"], ref["status"]) and np.array_equal(one["iters"], ref["iters"])
+    assert relerr(one["tau"], ref["tau"]) < 1e-9 and relerr(one["f"], ref["f"]) < 1e-9
+    if obs:
+        assert relerr(one["integ"], ig_ref) < 1e-9 and relerr(one["r"], r_ref) < 1e-9
+    ndev = torch_cuda.cuda.device_count()
+    for mode in ("multi:3", "multi:%d" % max(2, ndev), "rccl", "host:2", "host:5"):
+        got = _consume(consumer, tmp_path, mode, B, P, integ, r)
+        assert got["gather_mismatches"] == 0, mode
+        if mode == "rccl":
+            assert got["rccl_ranks"] == ndev     # the communicator RCCL built spans every visible device
+        for k in ("tau", "f", "status", "iters") + (("integ", "r") if obs else ()):
+            assert np.array_equal(got[k], one[k]), (mode, k)
+
+
+def test_abi_smoke_cpp_program_runs(torch_cuda, consumer):
+    """tools/abi_smoke.cpp: URDF -> single-robot tick, raw-buffer batch, 5-tick rollout and the header-only C++ host
+    class (planner + tick), each with its own physical sanity check; exit status 0 = all held."""
+    import wbc_quadruped_dob_amd as W
+    run = subprocess.run([os.path.join(ROOT, "tools", "abi_smoke.bin"), W.SYNTHETIC_URDF], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "QuadrupedWBC plan+tick: status=0" in run.stdout
+
+
+@pytest.mark.parametrize("obs,gather", [(0, "peer"), (1, "peer"), (1, "rccl")])
+def test_python_multisolver_equals_single_solver(torch_cuda, gpu_model, obs, gather):
+    """The binding over wbc_multi_*: shards on the visible devices (device 0 repeated for the peer-copy variant on a 1-GPU
+    box) against ONE solver over the whole batch -- bit-identical tau, f, status and observer state; the gathered torques
+    on every device equal the single solver's."""
+    import wbc_quadruped_dob_amd as W
+    torch = torch_cuda
+    n = 2051
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev)) if gather == "rccl" else [k % ndev for k in range(max(3, ndev))]
+    P = synth.default_params(observer_order=obs)
+    prm = W.Params.from_dict(P)
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=29)
+    td = torch.float64
+    full = {k: to_dev(B[k], torch, td) for k in ROWS}
+    mask = torch.from_numpy(B["mask"]).cuda()
+    single = W.Solver(gpu_model, prm, device=0, max_batch=n, options={})
+    ig = rr = None
+    if obs:
+        ig = single.dynamics(full["q"], full["v"], want=("p",))["p"].clone()
+        rr = torch.zeros_like(ig)
+    ig0 = None if ig is None else ig.clone()
+    ref = single.step(full["q"], full["v"], full["w_des"], full["vdot_des"], full["normals"], full["mu"], mask, full["tau_prev"],
+                      full["f_prev"], ig, rr)
+    torch.cuda.synchronize()
+    ms = W.MultiSolver(gpu_model, prm, devices=devices, max_batch_total=n, gather=gather, options={})
+    assert ms.rccl_ranks == (len(devices) if gather == "rccl" else 0)
+    ins = {k: ms.scatter(full[k], ROWS[k], n) for k in ROWS}
+    ins["mask"] = ms.scatter(mask, 1, n)
+    obs_state = None
+    if obs:
+        obs_state = (ms.scatter(ig0, 18, n), ms.scatter(torch.zeros_like(ig0), 18, n))
+    tick, outs = ms.prepare_step(n, ins, obs_state)
+    tick()
+    tau_all = ms.allgather_tau(n, outs)
+    ms.synchronize()
+    for k in ("tau", "f", "status", "iters"):
+        got = torch.cat([o[k].to("cuda:0") for o in outs], dim=-1)
+        assert torch.equal(got, ref[k]), k
+    if obs:
+        assert torch.equal(torch.cat([x.to("cuda:0") for x in obs_state[0]], dim=-1), ig)
+        assert torch.equal(torch.cat([x.to("cuda:0") for x in obs_state[1]], dim=-1), rr)
+    c0 = W.shard_range(n, ms.n, 0)[1]
+    for d, ta in enumerate(tau_all):
+        for j in range(ms.n):
+            st, cnt = W.shard_range(n, ms.n, j)
+            blk = ta[j, :12 * cnt].reshape(12, cnt).to("cuda:0")
+            assert torch.equal(blk, ref["tau"][:, st:st + cnt]), (d, j)
+        assert ta.shape == (ms.n, 12 * c0)
+
+
+def test_multi_step_host_numpy_batch(torch_cuda, gpu_model, oracle):
+    """wbc_multi_step_host: host-resident component-major batch in, tau / f / status / observer state back (pitched copies)."""
+    import wbc_quadruped_dob_amd as W
+    n = 777
+    P = synth.default_params(observer_order=2)
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=31)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    r = np.zeros((n, 18))
+    ig_ref, r_ref = integ.copy(), r.copy()
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"],
+                      ig_ref, r_ref, nthreads=8)
+    ndev = torch_cuda.cuda.device_count()
+    ms = W.MultiSolver(gpu_model, W.Params.from_dict(P), devices=[k % ndev for k in range(4)], max_batch_total=n, options={})
+    cm = lambda a: np.ascontiguousarray(a.T)
+    ig, rr = cm(integ), cm(r)
+    out = ms.step_host(cm(B["q"]), cm(B["v"]), cm(B["w_des"]), cm(B["vdot_des"]), cm(B["normals"]), cm(B["mu"]), B["mask"],
+                       cm(B["tau_prev"]), cm(B["f_prev"]), ig, rr)
+    assert np.array_equal(out["status"], ref["status"])
+    assert relerr(out["tau"].T, ref["tau"]) < 1e-9 and relerr(out["f"].T, ref["f"]) < 1e-9
+    assert relerr(ig.T, ig_ref) < 1e-9 and relerr(rr.T, r_ref) < 1e-9
+    with pytest.raises(W.WbcError):   # capacity is checked
+        big = np.zeros((19, n + 1))
+        ms.step_host(big, np.zeros((18, n + 1)), np.zeros((6, n + 1)), np.zeros((18, n + 1)), np.zeros((12, n + 1)),
+                     np.zeros((4, n + 1)), np.zeros(n + 1, np.int32))
+
+
+def test_observer_init_and_restored_device(torch_cuda, gpu_model, oracle):
+    """wbc_observer_init seeds integ = M v (the observer's start-up contract); entry points leave the caller's current
+    HIP device alone."""
+    import wbc_quadruped_dob_amd as W
+    torch = torch_cuda
+    B = synth.make_batch(3, 4, gpu_model.total_mass, rank=37)
+    solver = W.Solver(gpu_model, W.Params.from_dict(synth.default_params(observer_order=1)), device=0, max_batch=4, options={})
+    integ, r = solver.observer_init(B["q"][2], B["v"][2])
+    p = oracle.dynamics(B["q"][2:3], B["v"][2:3])["p"][0]
+    assert relerr(integ, p) < 1e-12 and not r.any()
+    assert torch.cuda.current_device() == 0

@@ -24,11 +24,13 @@ def torch_cuda():
     return torch
 
 
-def _solver(gpu_model, dtype="f64", obs=0, max_batch=4096, **kw):
+def _solver(gpu_model, dtype="f64", obs=0, max_batch=4096, options=None, **kw):
+    """options: dict of wbc_solver_options overrides (kernel-selection switches; {} = the library defaults)"""
     import wbc_quadruped_dob_amd as W
     P = synth.default_params(observer_order=obs, dtype=dtype)
     P.update(kw)
-    return W.Solver(gpu_model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=max_batch), P
+    return W.Solver(gpu_model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=max_batch,
+                    options=options or {}), P
 
 
 def _np_dtype(dtype):
@@ -229,6 +231,32 @@ def test_capacity_and_argument_errors(torch_cuda, gpu_model):
     with pytest.raises(W.WbcError) as e:
         _run_step(torch, solver_obs, B, "f64")  # observer on but no state buffers
     assert e.value.code == 1
+    with pytest.raises(W.WbcError) as e:         # the dynamics-only entry point checks the capacity too (32-bit lane offsets)
+        solver.dynamics(to_dev(B["q"], torch, torch.float64), to_dev(B["v"], torch, torch.float64))
+    assert e.value.code == 7
+
+
+def test_empty_shard_is_a_no_op_everywhere(torch_cuda, gpu_model):
+    """N = 0 (an empty shard of a ragged split) returns WBC_OK from every batch entry point, rollouts included."""
+    import ctypes as C
+    import wbc_quadruped_dob_amd as W
+    solver, _ = _solver(gpu_model, obs=1, max_batch=8)
+    solver.set_ref_params(synth.default_ref_params())
+    L = W.lib()
+    one = torch_cuda.zeros(8, dtype=torch_cuda.float64, device="cuda")
+    p = C.c_void_p(one.data_ptr())
+    bi = W._BatchIn(p, p, p, p, p, p, p, p, p)
+    bo = W._BatchOut(p, p, p, p, p, p, p, p)
+    ob = W._ObsState(p, p)
+    assert L.wbc_step_batch(solver._h, 0, C.byref(bi), C.byref(bo), C.byref(ob), None) == 0
+    assert L.wbc_dynamics_batch(solver._h, 0, p, p, p, p, p, None, None, None, None) == 0
+    assert L.wbc_integrate_batch(solver._h, 0, p, p, p, p, p, p, p, None, None) == 0
+    assert L.wbc_rollout_batch(solver._h, 0, 5, C.byref(bi), C.byref(bo), C.byref(ob), None, None, None) == 0
+    assert L.wbc_reference_batch(solver._h, 0, p, p, p, C.c_double(0.0), p, p, None, None) == 0
+    assert L.wbc_rollout_tracking_batch(solver._h, 0, 5, C.byref(bi), C.byref(bo), C.byref(ob), None, p, None, None, None) == 0
+    for fm in (0, -1):   # ... whichever dispatch the solver would pick
+        s2, _ = _solver(gpu_model, obs=0, max_batch=8, options={"fused_max": fm, "rollout_persistent": 0})
+        assert L.wbc_rollout_batch(s2._h, 0, 3, C.byref(bi), C.byref(bo), None, None, None, None) == 0
 
 
 def _permuted_urdf(tmp_path):
@@ -282,24 +310,6 @@ def test_permuted_joint_and_foot_order(torch_cuda, tmp_path):
             assert relerr(got["integ"], ig_ref) < TIGHT64 and relerr(got["r"], r_ref) < TIGHT64
 
 
-def test_qp_wave_kernel_variant_matches(torch_cuda, gpu_model, oracle, monkeypatch):
-    """The LDS wave-per-QP kernel (WBC_QP_KERNEL=wave) stays parity-green too."""
-    torch = torch_cuda
-    monkeypatch.setenv("WBC_QP_KERNEL", "wave")
-    n = 1500
-    solver, P = _solver(gpu_model, obs=1, max_batch=n)
-    monkeypatch.delenv("WBC_QP_KERNEL")
-    B = synth.make_batch(3, n, gpu_model.total_mass, rank=9)
-    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
-    r = np.zeros((n, 18))
-    ig_ref, r_ref = integ.copy(), r.copy()
-    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"],
-                      B["f_prev"], ig_ref, r_ref, nthreads=8)
-    got = _run_step(torch, solver, B, "f64", integ, r)
-    assert np.array_equal(got["status"], ref["status"])
-    assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
-
-
 def _gpu_rollout(torch, solver, P, H, B, tau_ext, integ, r, want_traj=True):
     td = torch.float64
     n = B["q"].shape[0]
@@ -350,7 +360,7 @@ def test_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H):
 
 
 @pytest.mark.parametrize("cfg,obs,n,H", [(3, 1, 1000, 20), (2, 0, 129, 7)])
-def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, oracle, monkeypatch, cfg, obs, n, H):
+def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, oracle, cfg, obs, n, H):
     """wbc_rollout_batch of small batches is ONE launch for the whole horizon (rollout_kernel); WBC_ROLLOUT_PERSISTENT=0
     forces {fused tick, integrate} launches per tick.  Same device functions -> equal to rounding."""
     torch = torch_cuda
@@ -359,11 +369,8 @@ def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, orac
     tau_ext[:, 0:3] = B["push"] if cfg > 2 else 10.0
     integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
     res = {}
-    for tag, env in (("persistent", None), ("per_tick", "0")):
-        if env is not None:
-            monkeypatch.setenv("WBC_ROLLOUT_PERSISTENT", env)
-        solver, P = _solver(gpu_model, obs=obs, max_batch=n)
-        monkeypatch.delenv("WBC_ROLLOUT_PERSISTENT", raising=False)
+    for tag, opt in (("persistent", {}), ("per_tick", {"rollout_persistent": 0})):
+        solver, P = _solver(gpu_model, obs=obs, max_batch=n, options=opt)
         res[tag] = _gpu_rollout(torch, solver, P, H, B, tau_ext, None if integ is None else integ.copy(),
                                 np.zeros((n, 18)) if obs else None)
     a, b = res["persistent"], res["per_tick"]
@@ -373,8 +380,8 @@ def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, orac
 
 
 @pytest.mark.parametrize("obs,n", [(1, 777), (0, 130), (2, 1500)])
-def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, oracle, monkeypatch, obs, n):
-    """The persistent rollout kernel gives a workgroup 4 states (up to 1024 rollouts) or 16 (WBC_ROLLOUT_SPW): another
+def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, oracle, obs, n):
+    """The persistent rollout kernel gives a workgroup 4 states (up to 1024 rollouts) or 16 (wbc_solver_options.rollout_spw): another
     distribution of the same per-state arithmetic over the device -> bit-identical results."""
     torch = torch_cuda
     B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=67)
@@ -383,9 +390,7 @@ def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, orac
     integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
     res = {}
     for spw in ("4", "16"):
-        monkeypatch.setenv("WBC_ROLLOUT_SPW", spw)
-        solver, P = _solver(gpu_model, obs=obs, max_batch=n)
-        monkeypatch.delenv("WBC_ROLLOUT_SPW", raising=False)
+        solver, P = _solver(gpu_model, obs=obs, max_batch=n, options={"rollout_spw": int(spw)})
         res[spw] = _gpu_rollout(torch, solver, P, 9, B, tau_ext, None if integ is None else integ.copy(),
                                 np.zeros((n, 18)) if obs else None)
     for k in res["4"]:
@@ -482,31 +487,44 @@ def test_step_without_matrix_outputs(torch_cuda, gpu_model, oracle, obs):
         assert relerr(got["integ"], ig_ref) < TIGHT64 and relerr(got["r"], r_ref) < TIGHT64
 
 
-def test_split_sweep_variant_matches(torch_cuda, gpu_model, oracle, monkeypatch):
-    """WBC_SWEEP=split (mass_jac on a second stream || rnea_step -> QP) stays parity-green."""
+@pytest.mark.parametrize("obs,n,pf", [(0, 3000, False), (1, 3000, True), (0, 66000, True), (1, 66000, False), (2, 65536, False)])
+def test_rnea_step_kernel_ticks_without_matrix_outputs(torch_cuda, gpu_model, oracle, obs, n, pf):
+    """The stand-alone CRBA-free front half (rnea_step_kernel -> QP, two launches): forced at a small batch with
+    fused_max = 0, and taken by default at >= 65 536 states, where the observer-off variant runs 256-thread workgroups.
+    With and without the optional pf output, observer orders 0 / 1 / 2, against the oracle."""
     torch = torch_cuda
-    monkeypatch.setenv("WBC_SWEEP", "split")
-    n = 2000
-    solver, P = _solver(gpu_model, obs=2, max_batch=n)
-    monkeypatch.delenv("WBC_SWEEP")
-    B = synth.make_batch(4, n, gpu_model.total_mass, rank=43)
-    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
-    r = np.zeros((n, 18))
-    ig_ref, r_ref = integ.copy(), r.copy()
+    solver, P = _solver(gpu_model, obs=obs, max_batch=n, options={"fused_max": 0})
+    B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=47)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    r = 0.1 * np.sin(np.arange(n * 18).reshape(n, 18)) if obs else None
+    ig_ref = None if integ is None else integ.copy()
+    r_ref = None if r is None else r.copy()
     ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"],
                       B["f_prev"], ig_ref, r_ref, nthreads=8)
-    got = _run_step(torch, solver, B, "f64", integ, r, want_mats=True)
-    d = oracle.dynamics(B["q"], B["v"], nthreads=8)
-    for k in ("M", "h", "Jc", "pf"):
-        assert relerr(got[k], d[k]) < TIGHT64, k
-    assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
-    assert relerr(got["integ"], ig_ref) < TIGHT64
+    td = torch.float64
+    dv = lambda k: to_dev(B[k], torch, td)
+    mask = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
+    ig = None if integ is None else to_dev(integ, torch, td)
+    rr = None if r is None else to_dev(r, torch, td)
+    out = {"pf": solver.empty(12, n)} if pf else {}
+    solver.enable_timing(1)
+    got = solver.step(dv("q"), dv("v"), dv("w_des"), dv("vdot_des"), dv("normals"), dv("mu"), mask, dv("tau_prev"), dv("f_prev"),
+                      ig, rr, out=out, want_mats=False)
+    torch.cuda.synchronize()
+    tm = solver.collect_timing()
+    assert tm["rnea_launches"] == 1 and tm["qp_launches"] == 1 and tm["fused_launches"] == 0 and tm["dyn_launches"] == 0
+    assert np.array_equal(got["status"].cpu().numpy(), ref["status"])
+    assert relerr(to_host(got["tau"]), ref["tau"]) < TIGHT64 and relerr(to_host(got["f"]), ref["f"]) < TIGHT64
+    if pf:
+        assert relerr(to_host(got["pf"]), oracle.dynamics(B["q"], B["v"], nthreads=8)["pf"]) < TIGHT64
+    if obs:
+        assert relerr(to_host(ig), ig_ref) < TIGHT64 and relerr(to_host(rr), r_ref) < TIGHT64
 
 
 @pytest.mark.parametrize("obs,dtype,n", [(0, "f64", 4096), (0, "f64", 1003), (1, "f64", 2049), (2, "f64", 17), (0, "f32", 3000),
                                          (1, "f32", 555), (0, "f64", 8192), (1, "f32", 6000)])   # the last two: two rounds of workgroups
-def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkeypatch, obs, dtype, n):
-    """Batches that fit one workgroup per CU (N <= 4096) run the tick as ONE kernel (fused_tick.hip.hpp); WBC_FUSED_MAX=0
+def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, obs, dtype, n):
+    """Batches that fit one workgroup per CU (N <= 4096) run the tick as ONE kernel (fused_tick.hip.hpp); wbc_solver_options.fused_max = 0
     forces the two-kernel tick.  The fused kernel's front half is rnea_step + mass_jac (+ an observer role), i.e. another
     recursion order than dyn_sweep -> equal to rounding, both within the oracle tolerance."""
     torch = torch_cuda
@@ -514,11 +532,8 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkey
     nd = _np_dtype(dtype)
     integ0 = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"].astype(nd) if obs else None
     res = {}
-    for tag, env in (("fused", None), ("two", "0")):
-        if env is not None:
-            monkeypatch.setenv("WBC_FUSED_MAX", env)
-        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
-        monkeypatch.delenv("WBC_FUSED_MAX", raising=False)
+    for tag, opt in (("fused", {}), ("two", {"fused_max": 0})):
+        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n, options=opt)
         res[tag] = _run_step(torch, solver, B, dtype, None if integ0 is None else integ0.copy(),
                              None if integ0 is None else np.zeros((n, 18), nd), want_mats=True)
         solver.enable_timing(1)
@@ -544,9 +559,9 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, monkey
 
 
 @pytest.mark.parametrize("obs,dtype,n", [(1, "f64", 3001), (2, "f64", 130), (1, "f32", 2048), (1, "f64", 70000)])
-def test_separate_observer_kernel_matches(torch_cuda, gpu_model, oracle, monkeypatch, obs, dtype, n):
+def test_separate_observer_kernel_matches(torch_cuda, gpu_model, oracle, obs, dtype, n):
     """Large observer-on batches run {observer kernel on the second stream || dyn_sweep without the observer} -> QP that
-    completes b and tau_partial with rhat (observer.hip.hpp); WBC_OBS_SPLIT_MIN=1 forces that path at test-sized batches
+    completes b and tau_partial with rhat (observer.hip.hpp); wbc_solver_options.obs_split_min = 1 forces that path at test-sized batches
     (70000 also takes its 256-thread variant).  Must equal the all-in-one observer sweep to rounding and stay within the
     oracle tolerance, also over a second tick (observer state carried)."""
     torch = torch_cuda
@@ -554,12 +569,8 @@ def test_separate_observer_kernel_matches(torch_cuda, gpu_model, oracle, monkeyp
     nd = _np_dtype(dtype)
     integ0 = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"].astype(nd)
     res = {}
-    for tag, env in (("split", "1"), ("one_sweep", "1000000000")):
-        monkeypatch.setenv("WBC_FUSED_MAX", "0")
-        monkeypatch.setenv("WBC_OBS_SPLIT_MIN", env)
-        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
-        monkeypatch.delenv("WBC_OBS_SPLIT_MIN", raising=False)
-        monkeypatch.delenv("WBC_FUSED_MAX", raising=False)
+    for tag, split_min in (("split", 1), ("one_sweep", -1)):
+        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n, options={"fused_max": 0, "obs_split_min": split_min})
         res[tag] = _run_step(torch, solver, B, dtype, integ0.copy(), np.zeros((n, 18), nd), want_mats=True)
         res[tag + "_2"] = _run_step(torch, solver, B, dtype, res[tag]["integ"], res[tag]["r"], want_mats=True)
     a, b = res["split"], res["one_sweep"]
@@ -601,18 +612,17 @@ def test_prepared_tick_equals_step(torch_cuda, gpu_model):
 
 
 @pytest.mark.parametrize("mode", ["fused", "two_kernel", "no_mats", "obs_split", "rollout"])
-def test_tick_is_graph_capturable(torch_cuda, gpu_model, monkeypatch, mode):
+def test_tick_is_graph_capturable(torch_cuda, gpu_model, mode):
     """Every dispatch variant of the tick (and a persistent rollout) can be captured into a hipGraph: no allocation, no
     synchronisation, no host read inside the C call.  Replaying the graph must reproduce the eager results bit for bit."""
     torch = torch_cuda
     n = 1000
+    opt = {}
     if mode in ("two_kernel", "obs_split"):
-        monkeypatch.setenv("WBC_FUSED_MAX", "0")
+        opt["fused_max"] = 0
     if mode == "obs_split":
-        monkeypatch.setenv("WBC_OBS_SPLIT_MIN", "1")
-    solver, P = _solver(gpu_model, obs=1, max_batch=n)
-    monkeypatch.delenv("WBC_FUSED_MAX", raising=False)
-    monkeypatch.delenv("WBC_OBS_SPLIT_MIN", raising=False)
+        opt["obs_split_min"] = 1
+    solver, P = _solver(gpu_model, obs=1, max_batch=n, options=opt)
     B = synth.make_batch(3, n, gpu_model.total_mass, rank=91)
     td = torch.float64
     dv = lambda k: to_dev(B[k], torch, td)

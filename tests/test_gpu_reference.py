@@ -20,10 +20,10 @@ def torch_cuda():
     return torch
 
 
-def _solver(gpu_model, dtype="f64", obs=0, max_batch=4096, ref=True):
+def _solver(gpu_model, dtype="f64", obs=0, max_batch=4096, ref=True, options=None):
     import wbc_quadruped_dob_amd as W
     P = synth.default_params(observer_order=obs, dtype=dtype)
-    s = W.Solver(gpu_model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=max_batch)
+    s = W.Solver(gpu_model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=max_batch, options=options or {})
     G = synth.default_ref_params()
     if ref:
         s.set_ref_params(G)
@@ -122,9 +122,9 @@ def test_tracking_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, 
         assert relerr(got["r"][ok], r_ref[ok]) < 1e-6
 
 
-def test_persistent_tracking_equals_per_tick_launches(torch_cuda, gpu_model, oracle, monkeypatch):
+def test_persistent_tracking_equals_per_tick_launches(torch_cuda, gpu_model, oracle):
     """Planner-in-the-loop rollouts of small batches run as ONE launch (rollout_kernel<., TRACK>: the integrator wavefront
-    runs the reference generator at the head of every tick); WBC_ROLLOUT_PERSISTENT=0 = {reference, fused tick, integrate}
+    runs the reference generator at the head of every tick); wbc_solver_options.rollout_persistent = 0 = {reference, fused tick, integrate}
     launches per tick.  Same device functions -> equal to rounding."""
     torch = torch_cuda
     n, H = 777, 12
@@ -133,11 +133,8 @@ def test_persistent_tracking_equals_per_tick_launches(torch_cuda, gpu_model, ora
     tau_ext = np.zeros((n, 18)); tau_ext[:, 0:3] = B["push"]
     integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
     res = {}
-    for tag, env in (("persistent", None), ("per_tick", "0")):
-        if env is not None:
-            monkeypatch.setenv("WBC_ROLLOUT_PERSISTENT", env)
-        solver, P, G = _solver(gpu_model, obs=1, max_batch=n)
-        monkeypatch.delenv("WBC_ROLLOUT_PERSISTENT", raising=False)
+    for tag, opt in (("persistent", {}), ("per_tick", {"rollout_persistent": 0})):
+        solver, P, G = _solver(gpu_model, obs=1, max_batch=n, options=opt)
         res[tag] = _gpu_tracking(torch, solver, H, B, plan, tau_ext, integ.copy(), np.zeros((n, 18)))
     a, b = res["persistent"], res["per_tick"]
     assert np.array_equal(a["status"], b["status"])

@@ -127,3 +127,74 @@ def test_params_default_values(hip_lib):
     p64, p32 = W.Params.default("f64"), W.Params.default("f32")
     assert p64.alpha == 1e-3 and p64.qp_tol == 1e-9 and p32.qp_tol == 1e-3 and p64.observer_order == 0
     assert list(p64.S) == [1.0] * 6 and p64.K1[17] == 50.0 and p64.K2[0] == 200.0
+
+
+def test_solver_options_struct_and_validation(hip_lib):
+    """wbc_solver_options carries every kernel-selection switch (the library reads no environment variable)."""
+    o = W.SolverOptions.default()
+    assert o.struct_size == C.sizeof(W.SolverOptions)
+    assert (o.fused_max, o.rollout_persistent, o.rollout_spw, o.obs_split_min, o.one_zerocopy, o.timing_mode) == (-1, 1, 0, -1, 0, 0)
+    good = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    h = C.c_void_p()
+    prm = W.Params.default()
+    bad = W.SolverOptions.default()
+    bad.struct_size = 0
+    assert W.lib().wbc_solver_create_ex(good._h, C.byref(prm), 0, 0, 16, C.byref(bad), C.byref(h)) == 1
+    bad = W.SolverOptions.default()
+    bad.rollout_spw = 5
+    assert W.lib().wbc_solver_create_ex(good._h, C.byref(prm), 0, 0, 16, C.byref(bad), C.byref(h)) == 1
+    assert "rollout_spw" in W.lib().wbc_last_error().decode()
+    with pytest.raises(KeyError):
+        W.SolverOptions.make({"no_such_switch": 1})
+    src = open(os.path.join(ROOT, "wbc_quadruped_dob_amd", "csrc", "wbc_api.cpp")).read() + \
+        open(os.path.join(ROOT, "wbc_quadruped_dob_amd", "csrc", "wbc_multi.cpp")).read()
+    assert "getenv" not in src
+
+
+def test_shard_range_c_abi_matches_python_sharding(hip_lib):
+    from wbc_quadruped_dob_amd.sharding import shard_range
+    for n_total in (0, 1, 7, 1001, 262144):
+        for world in (1, 2, 3, 8):
+            spans = [W.shard_range(n_total, world, r) for r in range(world)]
+            assert spans == [shard_range(n_total, world, r) for r in range(world)]
+            assert sum(c for _, c in spans) == n_total and spans[0][1] == max(c for _, c in spans)
+    st, cnt = C.c_size_t(), C.c_size_t()
+    assert W.lib().wbc_shard_range(10, 0, 0, C.byref(st), C.byref(cnt)) == 1
+    assert W.lib().wbc_shard_range(10, 2, 2, C.byref(st), C.byref(cnt)) == 1
+
+
+def test_multi_create_argument_errors(hip_lib):
+    good = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    prm = W.Params.default()
+    h = C.c_void_p()
+    dup = (C.c_int * 2)(0, 0)
+    rc = W.lib().wbc_multi_create(good._h, C.byref(prm), 0, dup, 2, 64, W.GATHER_RCCL, None, C.byref(h))
+    assert rc == 1 and "distinct devices" in W.lib().wbc_last_error().decode()
+    assert W.lib().wbc_multi_create(good._h, C.byref(prm), 0, dup, 0, 64, 0, None, C.byref(h)) == 1
+    assert W.lib().wbc_multi_create(good._h, C.byref(prm), 0, dup, 2, 64, 9, None, C.byref(h)) == 1
+    assert W.lib().wbc_multi_size(None) == 0 and W.lib().wbc_multi_rccl_ranks(None) == 0
+
+
+def test_ros_section_compiles_against_stubs(hip_lib, tmp_path):
+    """The WBC_WITH_ROS adaptors of include/wbc/quadruped_wbc.hpp against field-layout STUBS of the message headers
+    (tests/stubs/: labelled stubs, they pin nothing about the reference's topics).  Catches rot of code that no ROS-less
+    build would otherwise ever compile."""
+    exe = str(tmp_path / "ros_check")
+    libdir = os.path.dirname(W.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "stubs"),
+                    os.path.join(ROOT, "tests", "stubs", "ros_section_check.cpp"), "-o", exe, "-L" + libdir, "-lwbc_hip",
+                    "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0 and "ros adaptors ok" in run.stdout, run.stdout + run.stderr
+
+
+def test_bench_refuses_more_gpus_than_present():
+    """`python bench.py --gpus N` started bare launches its own ranks; with fewer GPUs than asked for it must exit
+    non-zero with a clear message instead of asserting or hanging."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    if n < 2:
+        n = 2
+    run = subprocess.run(["python", os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    assert run.returncode == 3 and "GPU(s) visible" in run.stderr

@@ -9,7 +9,8 @@ its exec restore with nothing but bookkeeping (scalar ops, lane writes) around t
 restore is the body of a masked region, whose spills serve the lanes that run it.
 `v_writelane` SGPR spills ignore EXEC and are not flagged.
 
-usage: tools/spill_lint.py [file.s]     (without a file: compiles csrc/wbc_api.hip to /tmp/asm/wbc_lint.s first)
+usage: tools/spill_lint.py [file.s]     (without a file: compiles the kernel units csrc/k_*.hip for both scalar types to
+                                         device assembly and lints the concatenation, /tmp/asm/wbc_lint.s)
 exit status 1 when something is flagged.
 """
 import os
@@ -20,11 +21,28 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def compile_asm(out="/tmp/asm/wbc_lint.s"):
+KUNITS = [("k_sweep", ()), ("k_rnea", ()), ("k_qp", ()), ("k_misc", ()), ("k_fused", ()), ("k_rollout", ()),
+          ("k_rollout", ("-DWBC_ROLLOUT_TRACK=1",))]
+
+
+def compile_asm(out="/tmp/asm/wbc_lint.s", extra=()):
+    """Device assembly of every kernel unit x scalar type (the flags of csrc/Makefile), compiled side by side and
+    concatenated into `out`."""
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    src = os.path.join(ROOT, "wbc_quadruped_dob_amd", "csrc", "wbc_api.hip")
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-w", "-o", out, src]
-    subprocess.run(cmd, check=True, cwd=os.path.dirname(src))
+    csrc = os.path.join(ROOT, "wbc_quadruped_dob_amd", "csrc")
+    jobs = []
+    for unit, defs in KUNITS:
+        for scalar in ("double", "float"):
+            part = "%s.%s%s.%s.s" % (out, unit, "_track" if defs else "", scalar)
+            cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-DWBC_SCALAR=" + scalar, *defs, *extra, "-S",
+                   "--cuda-device-only", "-w", "-o", part, unit + ".hip"]
+            jobs.append((part, subprocess.Popen(cmd, cwd=csrc)))
+    with open(out, "w") as f:
+        for part, proc in jobs:
+            if proc.wait() != 0:
+                raise RuntimeError("hipcc failed for " + part)
+            f.write(open(part).read())
+            os.remove(part)
     return out
 
 

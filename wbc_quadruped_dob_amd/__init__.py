@@ -92,6 +92,41 @@ class RefParams(C.Structure):
 PLAN_WORDS = 12
 
 
+class SolverOptions(C.Structure):
+    """wbc_solver_options (include/wbc_hip.h): the kernel-selection switches of a solver.  The library itself never reads
+    the environment; Solver(options=None) builds them from the defaults overridden by the WBC_* variables below -- a
+    convenience of THIS binding for the A/B scripts under tools/ and bench.py."""
+    _fields_ = [("struct_size", C.c_size_t), ("fused_max", C.c_longlong), ("rollout_persistent", C.c_int),
+                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int)]
+    ENV = {"WBC_FUSED_MAX": ("fused_max", int), "WBC_ROLLOUT_PERSISTENT": ("rollout_persistent", int),
+           "WBC_ROLLOUT_SPW": ("rollout_spw", int), "WBC_OBS_SPLIT_MIN": ("obs_split_min", int),
+           "WBC_ONE_ZEROCOPY": ("one_zerocopy", int),
+           "WBC_TIMING": ("timing_mode", lambda v: 1 if v == "pair" else 0)}
+
+    @staticmethod
+    def default():
+        o = SolverOptions()
+        lib().wbc_solver_options_default(C.byref(o))
+        return o
+
+    @staticmethod
+    def make(options=None):
+        """options: None (defaults + WBC_* environment), a dict of field overrides, or a SolverOptions."""
+        if isinstance(options, SolverOptions):
+            return options
+        o = SolverOptions.default()
+        if options is None:
+            for var, (field, conv) in SolverOptions.ENV.items():
+                if var in os.environ:
+                    setattr(o, field, conv(os.environ[var]))
+        else:
+            for k, v in options.items():
+                if k not in dict(SolverOptions._fields_) or k == "struct_size":
+                    raise KeyError("unknown solver option %r" % k)
+                setattr(o, k, int(v))
+        return o
+
+
 class _BatchIn(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "mask", "tau_prev", "f_prev")]
 
@@ -126,6 +161,27 @@ def lib():
         L.wbc_model_free.argtypes = [C.c_void_p]
         L.wbc_solver_destroy.argtypes = [C.c_void_p]
         L.wbc_solver_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
+        L.wbc_solver_create_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.wbc_solver_options_default.argtypes = [C.c_void_p]
+        L.wbc_solver_options_default.restype = None
+        L.wbc_observer_init.argtypes = [C.c_void_p] * 5
+        L.wbc_shard_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.wbc_multi_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.wbc_multi_destroy.argtypes = [C.c_void_p]
+        L.wbc_multi_destroy.restype = None
+        L.wbc_multi_size.argtypes = [C.c_void_p]
+        L.wbc_multi_device.argtypes = [C.c_void_p, C.c_int]
+        L.wbc_multi_solver.argtypes = [C.c_void_p, C.c_int]
+        L.wbc_multi_solver.restype = C.c_void_p
+        L.wbc_multi_stream.argtypes = [C.c_void_p, C.c_int]
+        L.wbc_multi_stream.restype = C.c_void_p
+        L.wbc_multi_rccl_ranks.argtypes = [C.c_void_p]
+        L.wbc_multi_set_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.wbc_multi_step_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wbc_multi_rollout_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wbc_multi_allgather_tau.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.wbc_multi_synchronize.argtypes = [C.c_void_p]
+        L.wbc_multi_step_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wbc_dynamics_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
         L.wbc_step_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
         L.wbc_integrate_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
@@ -202,7 +258,7 @@ class Model:
 class Solver:
     """Device-side context: one per GPU (and per stream)."""
 
-    def __init__(self, model, params=None, dtype="f64", device=0, max_batch=4096):
+    def __init__(self, model, params=None, dtype="f64", device=0, max_batch=4096, options=None):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible to torch: the WBC hot path has no CPU fallback")
@@ -214,8 +270,9 @@ class Solver:
         self.max_batch = int(max_batch)
         self.params = params if params is not None else Params.default(dtype)
         h = C.c_void_p()
-        _check(lib().wbc_solver_create(model._h, C.byref(self.params), F64 if dtype == "f64" else F32, device,
-                                       self.max_batch, C.byref(h)), "wbc_solver_create")
+        self.options = SolverOptions.make(options)
+        _check(lib().wbc_solver_create_ex(model._h, C.byref(self.params), F64 if dtype == "f64" else F32, device,
+                                          self.max_batch, C.byref(self.options), C.byref(h)), "wbc_solver_create_ex")
         self._h = h
 
     def set_params(self, params):
@@ -394,6 +451,15 @@ class Solver:
                "wbc_compute_torques")
         return tau, f, st.value
 
+    def observer_init(self, q, v):
+        """Observer start-up of the single-robot loop: returns (integ = M(q) v, r = 0) as numpy float64 arrays."""
+        d = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        q, v = d(q), d(v)
+        integ, r = np.zeros(self.model.nv), np.ones(self.model.nv)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _check(lib().wbc_observer_init(self._h, p(q), p(v), p(integ), p(r)), "wbc_observer_init")
+        return integ, r
+
     def compute_reference(self, q, v, plan, t=0.0):
         """Single-robot host-array planner call (numpy float64): returns (w_des[6], vdot_des[nv], com[6])."""
         d = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -417,4 +483,128 @@ class Solver:
         for i, n in enumerate(names):
             out[n + "_ms"] = ms[i]
             out[n + "_launches"] = cnt[i]
+        return out
+
+
+def shard_range(n_total, n_shards, shard):
+    """wbc_shard_range: (start, count) of a shard's contiguous slice."""
+    st, cnt = C.c_size_t(), C.c_size_t()
+    _check(lib().wbc_shard_range(n_total, n_shards, shard, C.byref(st), C.byref(cnt)), "wbc_shard_range")
+    return st.value, cnt.value
+
+
+GATHER_NONE, GATHER_RCCL, GATHER_PEER_COPY = 0, 1, 2
+
+
+class MultiSolver:
+    """wbc_multi_*: ONE process, one solver per device of the node (the C-ABI path a C++ host uses; the torchrun path of
+    bench.py / sharding.py is one process per GPU instead).  devices may repeat a device for NONE / PEER_COPY gathers."""
+
+    def __init__(self, model, params=None, dtype="f64", devices=(0,), max_batch_total=4096, gather="none", options=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to torch: the WBC hot path has no CPU fallback")
+        self.torch, self.model, self.dtype = torch, model, dtype
+        self.tdtype = torch.float64 if dtype == "f64" else torch.float32
+        self.devices = [int(d) for d in devices]
+        self.params = params if params is not None else Params.default(dtype)
+        self.options = SolverOptions.make(options)
+        self.max_batch_total = int(max_batch_total)
+        backend = dict(none=GATHER_NONE, rccl=GATHER_RCCL, peer=GATHER_PEER_COPY)[gather]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        _check(lib().wbc_multi_create(model._h, C.byref(self.params), F64 if dtype == "f64" else F32, arr, len(self.devices),
+                                      self.max_batch_total, backend, C.byref(self.options), C.byref(h)), "wbc_multi_create")
+        self._h = h
+        self.n = lib().wbc_multi_size(self._h)
+
+    def __del__(self):
+        try:
+            lib().wbc_multi_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def rccl_ranks(self):
+        return lib().wbc_multi_rccl_ranks(self._h)
+
+    def stream(self, k):
+        return lib().wbc_multi_stream(self._h, k)
+
+    def synchronize(self):
+        _check(lib().wbc_multi_synchronize(self._h), "wbc_multi_synchronize")
+
+    def scatter(self, full, rows, n_total, dtype=None):
+        """host/any-device [rows, n_total] tensor -> list of per-shard contiguous [rows, count_k] tensors on devices[k]"""
+        outs = []
+        for k, dev in enumerate(self.devices):
+            st, cnt = shard_range(n_total, self.n, k)
+            x = full[..., st:st + cnt].contiguous().to(self.torch.device("cuda", dev))
+            outs.append(x.to(dtype) if dtype is not None else x)
+        return outs
+
+    def prepare_step(self, n_total, ins, obs=None, want_mats=False):
+        """ins: dict name -> list of per-shard tensors (q, v, w_des, vdot_des, normals, mu, mask[, tau_prev, f_prev]);
+        obs: (list integ, list r) or None.  Returns (tick, outs): tick() enqueues one control tick on every shard
+        (wbc_multi_step_batch), outs is a list of per-shard output dicts."""
+        torch, m = self.torch, self.model
+        BI, BO, OS = (_BatchIn * self.n)(), (_BatchOut * self.n)(), (_ObsState * self.n)()
+        outs, keep = [], []
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        for k, dev in enumerate(self.devices):
+            _, cnt = shard_range(n_total, self.n, k)
+            d = torch.device("cuda", dev)
+            o = dict(tau=torch.zeros((m.nj, cnt), dtype=self.tdtype, device=d), f=torch.zeros((3 * m.nf, cnt), dtype=self.tdtype, device=d),
+                     status=torch.zeros(cnt, dtype=torch.int32, device=d), iters=torch.zeros(cnt, dtype=torch.int32, device=d))
+            if want_mats:
+                o.update(M=torch.empty((m.nv * (m.nv + 1) // 2, cnt), dtype=self.tdtype, device=d), h=torch.empty((m.nv, cnt), dtype=self.tdtype, device=d),
+                         Jc=torch.empty((3 * m.nf * m.nv, cnt), dtype=self.tdtype, device=d), pf=torch.empty((3 * m.nf, cnt), dtype=self.tdtype, device=d))
+            g = lambda name: ins[name][k] if name in ins and ins[name] is not None else None
+            for name in ("q", "v", "w_des", "vdot_des", "normals", "mu", "mask", "tau_prev", "f_prev"):
+                t = g(name)
+                assert t is None or (t.is_cuda and t.is_contiguous() and t.device == d and t.shape[-1] == cnt), (name, k)
+            BI[k] = _BatchIn(p(g("q")), p(g("v")), p(g("w_des")), p(g("vdot_des")), p(g("normals")), p(g("mu")), p(g("mask")),
+                             p(g("tau_prev")), p(g("f_prev")))
+            BO[k] = _BatchOut(p(o["tau"]), p(o["f"]), p(o["status"]), p(o["iters"]), p(o.get("M")), p(o.get("h")), p(o.get("Jc")), p(o.get("pf")))
+            if obs is not None:
+                OS[k] = _ObsState(p(obs[0][k]), p(obs[1][k]))
+            outs.append(o)
+        keep = (ins, obs, outs, BI, BO, OS)
+        fn, h, has_obs = lib().wbc_multi_step_batch, self._h, obs is not None
+
+        def tick(_keep=keep):
+            rc = fn(h, n_total, BI, BO, OS if has_obs else None)
+            if rc:
+                _check(rc, "wbc_multi_step_batch")
+        return tick, outs
+
+    def allgather_tau(self, n_total, outs, tau_all=None):
+        """every device receives all torques: returns list (per device) of [n_shards, nj * count_0] tensors"""
+        torch, m = self.torch, self.model
+        _, c0 = shard_range(n_total, self.n, 0)
+        if tau_all is None:
+            tau_all = [torch.zeros((self.n, m.nj * c0), dtype=self.tdtype, device=torch.device("cuda", d)) for d in self.devices]
+        loc = (C.c_void_p * self.n)(*[o["tau"].data_ptr() for o in outs])
+        allp = (C.c_void_p * self.n)(*[t.data_ptr() for t in tau_all])
+        _check(lib().wbc_multi_allgather_tau(self._h, n_total, loc, allp), "wbc_multi_allgather_tau")
+        return tau_all
+
+    def step_host(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None, obs_r=None):
+        """Host-resident batch (numpy, component-major [ncomp, n_total] in the solver's dtype): scatter, tick, gather.
+        Observer state arrays are updated in place.  Returns dict(tau, f, status, iters)."""
+        nd = np.float64 if self.dtype == "f64" else np.float32
+        n_total = q.shape[1]
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=nd)
+        q, v, w_des, vdot_des, normals, mu, tau_prev, f_prev = map(c, (q, v, w_des, vdot_des, normals, mu, tau_prev, f_prev))
+        mask = np.ascontiguousarray(mask, dtype=np.int32)
+        for a in (obs_integ, obs_r):
+            assert a is None or (a.dtype == nd and a.flags.c_contiguous)
+        m = self.model
+        out = dict(tau=np.zeros((m.nj, n_total), nd), f=np.zeros((3 * m.nf, n_total), nd), status=np.zeros(n_total, np.int32),
+                   iters=np.zeros(n_total, np.int32))
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        bi = _BatchIn(p(q), p(v), p(w_des), p(vdot_des), p(normals), p(mu), p(mask), p(tau_prev), p(f_prev))
+        bo = _BatchOut(p(out["tau"]), p(out["f"]), p(out["status"]), p(out["iters"]), None, None, None, None)
+        ob = _ObsState(p(obs_integ), p(obs_r))
+        _check(lib().wbc_multi_step_host(self._h, n_total, C.byref(bi), C.byref(bo), C.byref(ob)), "wbc_multi_step_host")
         return out

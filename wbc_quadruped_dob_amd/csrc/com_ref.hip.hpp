@@ -16,23 +16,6 @@
 
 namespace wbc {
 
-template <class T> struct DevRefParams {
-  T kp_com[3], kd_com[3], kp_rot[3], kd_rot[3];
-  T kp_joint, kd_joint;
-  T inertia_nom[3];
-  T q_nom[12];  // in the caller's joint ordering
-};
-
-constexpr int PLAN_WORDS = 12;
-
-template <class T> struct RefArgs {
-  size_t N;
-  const T* q; const T* v; const T* plan;
-  T t;
-  T* w_des; T* vdot_des;
-  T* com;   // [6][N] or null
-};
-
 // EXT (persistent rollout kernel, fused_tick.hip.hpp): one wavefront of a larger workgroup, tables already in LDS.
 template <class T, bool EXT, int SPW = 16>
 WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const DevRefParams<T>* __restrict__ G, const RefArgs<T>& a,

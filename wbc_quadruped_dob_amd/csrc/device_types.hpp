@@ -64,4 +64,45 @@ template <class T> struct QpArgs {
   T* tau; T* f; int* status; int* iters;
 };
 
+struct QpJidx { int j[12]; };  // caller's joint index of leg-major joint 3l+k
+
+// forward dynamics + integrator (integrate.hip.hpp)
+template <class T> struct IntegrateArgs {
+  size_t N;
+  T* q; T* v;                       // in/out
+  const T* M; const T* h; const T* Jc;   // from the sweep of the same tick
+  const T* tau; const T* f;         // this tick's outputs
+  const T* tau_ext;                 // [nv][N] or null
+  T* tau_traj;                      // [nj][N] slice for this tick, or null
+  T dt;
+};
+
+// CoM reference generator (com_ref.hip.hpp)
+template <class T> struct DevRefParams {
+  T kp_com[3], kd_com[3], kp_rot[3], kd_rot[3];
+  T kp_joint, kd_joint;
+  T inertia_nom[3];
+  T q_nom[12];  // in the caller's joint ordering
+};
+constexpr int PLAN_WORDS = 12;
+template <class T> struct RefArgs {
+  size_t N;
+  const T* q; const T* v; const T* plan;
+  T t;
+  T* w_des; T* vdot_des;
+  T* com;   // [6][N] or null
+};
+
+// MODE bits of dyn_sweep_kernel (dyn_sweep.hip.hpp)
+constexpr int SW_MATS = 1;  // write M, h, Jc
+constexpr int SW_STEP = 2;  // write the step workspace (d, b, taup, JcL)
+constexpr int SW_OBS = 4;   // momentum observer update (needs SW_STEP) / p, beta outputs
+// MODE bits of rnea_step_kernel (dyn_split.hip.hpp)
+constexpr int RS_H = 1;     // write h (bias forces)
+constexpr int RS_STEP = 2;  // write the step workspace (d, b, taup, JcL)
+constexpr int RS_OBS = 4;   // momentum / gravity recursions: p, beta outputs and the observer update
+constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
+constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, without RS_STEP / RS_H): no force recursion, the
+                            // momentum observer is updated and rhat (18 words) goes to the LDS image at WS_RHAT
+
 }  // namespace wbc

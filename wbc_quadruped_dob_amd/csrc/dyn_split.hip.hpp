@@ -28,13 +28,6 @@
 
 namespace wbc {
 
-// MODE bits of rnea_step_kernel
-constexpr int RS_H = 1;     // write h (bias forces)
-constexpr int RS_STEP = 2;  // write the step workspace (d, b, taup, JcL)
-constexpr int RS_OBS = 4;   // momentum / gravity recursions: p, beta outputs and the observer update
-constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
-constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, without RS_STEP / RS_H): no force recursion, the
-                            // momentum observer is updated and rhat (18 words) goes to the LDS image at WS_RHAT
 
 // The work-item id passes through an empty asm at the top of every body: inside the persistent rollout kernel the bodies
 // sit in the horizon loop, and without this every lane-derived predicate, LDS address and table index (hundreds of

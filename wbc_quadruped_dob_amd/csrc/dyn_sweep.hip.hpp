@@ -180,9 +180,6 @@ WBC_DEV float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
 __host__ __device__ constexpr int midx18(int i, int j) { return i * 18 - i * (i - 1) / 2 + (j - i); }
 
 // MODE bits
-constexpr int SW_MATS = 1;  // write M, h, Jc
-constexpr int SW_STEP = 2;  // write the step workspace (d, b, taup, JcL)
-constexpr int SW_OBS = 4;   // momentum observer update (needs SW_STEP) / p, beta outputs
 
 #ifndef WBC_SWEEP_WAVES
 #define WBC_SWEEP_WAVES 2

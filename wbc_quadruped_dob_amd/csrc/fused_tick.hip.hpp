@@ -109,7 +109,7 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
 #else
     const QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN};   // the QP waits for each piece where it first needs it
 #endif
-    qp_group16_body<T, false, 4, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
+    qp_group16_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
   }
 }
 
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #else
       const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
-      if (wave * 4 < SPW) qp_group16_body<T, false, 4, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
+      if (wave * 4 < SPW) qp_group16_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
     }
     __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator
     __syncthreads();   // barrier B: q, v of the next tick

@@ -15,16 +15,6 @@
 
 namespace wbc {
 
-template <class T> struct IntegrateArgs {
-  size_t N;
-  T* q; T* v;                       // in/out
-  const T* M; const T* h; const T* Jc;   // from the sweep of the same tick
-  const T* tau; const T* f;         // this tick's outputs
-  const T* tau_ext;                 // [nv][N] or null
-  T* tau_traj;                      // [nj][N] slice for this tick, or null
-  T dt;
-};
-
 // (also called as one wavefront of the persistent rollout kernel, fused_tick.hip.hpp: same mapping, no LDS.)
 // Two phases.  Phase 1 needs only M and Jc: the leg blocks' inverses, the base Schur complement and its Cholesky factor.
 // `between()` runs after it (nothing in the stand-alone kernel; the tick barrier in the rollout kernel, where phase 1

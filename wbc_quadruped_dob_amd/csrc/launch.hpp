@@ -1,0 +1,35 @@
+// Host-callable launchers of the gfx950 kernels.  Each kernel family is its own translation unit (k_*.hip), compiled
+// once per scalar type (-DWBC_SCALAR=double|float), so the library builds in parallel and a change to one kernel
+// recompiles only the units that contain it.  The host side (wbc_api.hip, wbc_multi.cpp) sees nothing but these
+// declarations and the plain-data argument structs of device_types.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+namespace wbc {
+
+// stream of the launch + (optionally) the events that receive the dispatch's own start / stop timestamps
+struct LaunchCtx {
+  hipStream_t st = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+// dyn_sweep_kernel<T, MODE>: MODE = SW_MATS | SW_STEP | SW_OBS bits (device_types.hpp); workgroup size chosen from N
+template <class T> hipError_t k_dyn_sweep(const LaunchCtx& L, int mode, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
+// rnea_step_kernel<T, MODE>: CRBA-free front half of ticks whose caller passes no M/h/Jc buffers; MODE = RS_STEP [| RS_OBS] [| RS_PF]
+template <class T> hipError_t k_rnea_step(const LaunchCtx& L, int mode, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
+// observer_kernel<T>: the momentum-observer update as its own kernel (large observer-on batches, second stream)
+template <class T> hipError_t k_observer(const LaunchCtx& L, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
+// qp_group16_kernel<T, RHAT>: GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran)
+template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap);
+// fused_tick_kernel<T, OBSERVER, MATS>: the whole tick of a small batch as one launch
+template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bool mats, const DevModel<T>* model, const DevParams<T>& prm,
+                                          const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);
+// rollout_kernel<T, OBSERVER, TRACK, SPW>: `horizon` dependent ticks incl. forward dynamics (and the planner) as one launch
+template <class T> hipError_t k_rollout(const LaunchCtx& L, bool observer, bool track, int spw, const DevModel<T>* model, const DevParams<T>& prm,
+                                       const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap, const IntegrateArgs<T>& ia, int horizon,
+                                       const DevRefParams<T>* G, const RefArgs<T>& ra);
+template <class T> hipError_t k_integrate(const LaunchCtx& L, const DevModel<T>* model, const IntegrateArgs<T>& a);
+template <class T> hipError_t k_reference(const LaunchCtx& L, const DevModel<T>* model, const DevRefParams<T>* G, const RefArgs<T>& a);
+
+}  // namespace wbc

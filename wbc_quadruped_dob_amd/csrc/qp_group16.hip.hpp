@@ -19,9 +19,17 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "device_types.hpp"
-#include "qp_wave.hip.hpp"  // Lim<>, QpJidx, sqrt_t/fabs_t
 
 namespace wbc {
+
+#ifndef WBC_DEV
+#define WBC_DEV __device__ __forceinline__
+#endif
+template <class T> struct Lim;
+template <> struct Lim<double> { static constexpr double eps = 2.220446049250313e-16; static constexpr double inf = __builtin_huge_val(); };
+template <> struct Lim<float> { static constexpr float eps = 1.1920929e-07f; static constexpr float inf = __builtin_huge_valf(); };
+WBC_DEV double fabs_t(double x) { return fabs(x); }
+WBC_DEV float fabs_t(float x) { return fabsf(x); }
 
 template <int I, int N, class F> WBC_DEV void sfor(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
@@ -119,13 +127,9 @@ template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]
 #ifndef WBC_QP_WAVES
 #define WBC_QP_WAVES 2
 #endif
-// REGROUP (large batches): after the set-up the 16 QPs of a workgroup are re-dealt to the 16 DPP rows in order of
-// their number of violated constraints at the unconstrained minimum, which predicts the iteration count (correlation
-// 0.89 on the bench data): rows of one wavefront then finish together instead of waiting for their slowest row
-// (mean trips per wave 5.0 -> 3.6).  The hand-over goes through the LDS images the kernel keeps anyway.
-// WPB = wavefronts per workgroup.  1 (default): every wavefront is its own workgroup, so its LDS and wave slot are
-// released the moment ITS four QPs are done and the CU backfills -- with 4-wave workgroups the slot lived as long as
-// the slowest of 16 QPs.  Workgroups that share a 128-byte line of the inputs are mapped to the same XCD (L2).
+// One-wave workgroups (stand-alone kernel): every wavefront is its own workgroup, so its LDS and wave slot are released the
+// moment ITS four QPs are done and the CU backfills.  Workgroups that share a 128-byte line of the inputs are mapped to the
+// same XCD (L2).
 // WSLDS (fused_tick.hip.hpp): the step workspace of the workgroup's 16 states is read from LDS (wsl[word][16], written
 // by the sweep phase of the same workgroup) instead of from HBM.
 // RHAT (with WSLDS, observer-on fused tick): the observer role left rhat in the LDS image; b and tau_partial are
@@ -154,10 +158,9 @@ WBC_DEV void qp_wait(int* flag, int need) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <class T, bool REGROUP, int WPB, bool WSLDS, bool RHAT = false, int SPW = 16>
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16>
 WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr) {
-  static_assert(!REGROUP || WPB == 4, "re-dealing needs the 16 rows of a 4-wave workgroup");
-  static_assert(!WSLDS || (WPB == 4 && !REGROUP), "the fused tick pairs one sweep wavefront with four QP wavefronts");
+  constexpr int WPB = WSLDS ? 4 : 1;   // the fused kernels pair their producer wavefronts with four QP wavefronts
   __shared__ G16Lds<T> lds_all[WPB];
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
@@ -307,52 +310,13 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     else { cAx = -nx; cAy = -ny; cAz = -nz; rA = -prm.fn_max; }
   }
 
-  if constexpr (!REGROUP) {
+  {
     T* c = Cl + 3 * (2 * l16);
     c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if constexpr (WSLDS) solve_x0();
-  } else {
-    __shared__ int rg_key[16];
-    __shared__ T rg_x[16][16];
-    __shared__ int rg_i[16][2];
-    const int slot = (int)(tx >> 4);  // my row among the 16 of the workgroup
-    // violated constraints at the unconstrained minimum
-    const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
-    const T sA0 = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA, sB0 = cBx * xq0 + cBy * xq1 + cBz * xq2;
-    const float cnt = ((on && sA0 < -prm.qp_tol) ? 1.0f : 0.0f) + ((on && hasB && sB0 < -prm.qp_tol) ? 1.0f : 0.0f);
-    const int key = live ? (int)gsum(cnt) : 1000;  // rows beyond N go last
-    if (l16 == 0) { rg_key[slot] = key; }
-    __syncthreads();
-    int rank = 0;
-#pragma unroll
-    for (int g2 = 0; g2 < 16; ++g2) { const int k2 = rg_key[g2]; rank += ((k2 < key) || (k2 == key && g2 < slot)) ? 1 : 0; }
-    // hand my QP to row `rank`: J through its J0 image, constraint rows through its table, x and ids through small buffers
-    {
-      T* dJ = lds_all[rank >> 2].J0[rank & 3];
-      if (isvar) sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; dJ[i * 12 + v] = Jc[i]; });
-      T* dc = lds_all[rank >> 2].C[rank & 3] + 3 * (2 * l16);
-      dc[0] = cAx; dc[1] = cAy; dc[2] = cAz; dc[3] = cBx; dc[4] = cBy; dc[5] = cBz;
-      rg_x[rank][l16] = x_me;
-      if (l16 == 0) { rg_i[rank][0] = (int)s32; rg_i[rank][1] = mask | (live ? 256 : 0); }
-    }
-    __syncthreads();
-    if (isvar) {
-      sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; Jc[i] = J0[i * 12 + v]; });
-      sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; Jr[c] = J0[v * 12 + c]; });
-    }
-    {
-      const T* c = Cl + 3 * (2 * l16);
-      cAx = c[0]; cAy = c[1]; cAz = c[2]; cBx = c[3]; cBy = c[4]; cBz = c[5];
-    }
-    x_me = rg_x[slot][l16];
-    s32 = (unsigned)rg_i[slot][0];
-    const int mi = rg_i[slot][1];
-    mask = mi & 0xF;
-    live = (mi & 256) != 0;
-    on = (mask >> f) & 1;
   }
 
   // ------------------------------------------------------------------ dual active-set iterations (a8)
@@ -612,9 +576,9 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
 }
 
 // RHAT: rhat comes from the separate observer kernel through the HBM workspace (large observer-on batches)
-template <class T, bool REGROUP, int WPB, bool RHAT = false>
-__global__ __launch_bounds__(64 * WPB, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
-  qp_group16_body<T, REGROUP, WPB, false, RHAT>(prm, a, jmap, nullptr);
+template <class T, bool RHAT = false>
+__global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+  qp_group16_body<T, false, RHAT>(prm, a, jmap, nullptr);
 }
 
 }  // namespace wbc

@@ -1,9 +1,9 @@
-// C-ABI implementation (include/wbc_hip.h): host side of the HIP path.  No CPU compute fallback
-// exists: without a usable gfx950 device every solver entry point fails with WBC_E_NODEVICE/WBC_E_HIP.
+// C-ABI implementation (include/wbc_hip.h): host side of the HIP path.  Pure host code -- the kernels live in the
+// k_*.hip translation units behind launch.hpp.  No CPU compute fallback exists: without a usable gfx950 device every
+// solver entry point fails with WBC_E_NODEVICE/WBC_E_HIP.
 #include "../../include/wbc_hip.h"
 
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -14,20 +14,14 @@
 #include <vector>
 
 #include "device_types.hpp"
-#include "dyn_sweep.hip.hpp"
-#include "dyn_split.hip.hpp"
+#include "host_internal.hpp"
+#include "launch.hpp"
 #include "model.hpp"
-#include "qp_wave.hip.hpp"
-#include "qp_group16.hip.hpp"
-#include "integrate.hip.hpp"
-#include "com_ref.hip.hpp"
-#include "fused_tick.hip.hpp"
-#include "observer.hip.hpp"
 
 using namespace wbc;
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int wbc::fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 #define HIP_TRY(expr)                                                                                     \
   do {                                                                                                    \
@@ -35,52 +29,57 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     if (e_ != hipSuccess) return fail(WBC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
   } while (0)
 
+// Every entry point runs on the solver's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = (err == hipSuccess); }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(s_)                                                                                     \
+  DeviceGuard guard_((s_)->device);                                                                       \
+  if (guard_.err != hipSuccess) return fail(WBC_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err))
+
 struct wbc_model { FlatModel fm; };
+
+constexpr size_t TIMING_MAX_SPANS = 4096;   // bounded ring: samples beyond it are dropped until the next collect
 
 struct wbc_solver {
   int dtype = WBC_F64;
   int device = 0;
   size_t max_batch = 0;
   wbc_params params;
+  wbc_solver_options opt;
   int leg_body[4][3];
   void* d_model = nullptr;  // DevModel<T>
   void* d_ws = nullptr;     // WS_LDS_WORDS * max_batch * sizeof(T): the 66 step words + 18 words of rhat (separate observer kernel)
   QpJidx jmap;
-  int qp_kernel = 0;  // 0 = qp_group16 (default), 1 = qp_wave; env WBC_QP_KERNEL=wave selects 1
-  int qp_wpb = 1;           // wavefronts per QP workgroup: 1 (default) or 4 (env WBC_QP_WPB=4)
-  bool qp_regroup = false;  // env WBC_QP_REGROUP=1 with WBC_QP_WPB=4: re-deal the 16 QPs of a workgroup by predicted work (A/B; measured: no gain)
-  int sweep_mode = 1; // 1 = fused dyn_sweep (default), 0 = split (mass_jac on a second stream || rnea_step -> QP); env WBC_SWEEP=split
-                      // measured on MI355X: split is 5-20 % slower (two kernels pay the fixed latencies twice), kept for A/B
-  bool rollout_persistent = true;  // wbc_rollout_batch of at most fused_max states: the whole horizon in one launch; env WBC_ROLLOUT_PERSISTENT=0 disables
-  size_t obs_split_min = (size_t)-1;  // opt-in (env WBC_OBS_SPLIT_MIN): observer-on ticks of at least this many states run the observer
-                                      // as its own kernel on the second stream beside dyn_sweep<no observer> (observer.hip.hpp).
-                                      // Measured at N = 262 144: fp32 0.482 -> 0.441 ms per tick, fp64 0.713 -> 0.810 ms (slower), and
-                                      // slower for both at N = 32 768 -> not the default
-  size_t fused_max = 4096;  // ticks / rollouts of at most this many states (one workgroup per CU) run as ONE kernel (fused_tick.hip.hpp); env WBC_FUSED_MAX, 0 = never
-  int rollout_spw = 0;   // states per workgroup of the persistent rollout kernel: 0 = auto (4 up to 1 024 states, else 16); env WBC_ROLLOUT_SPW = 4 | 16
-  size_t fused_max_noobs = 8192;  // observer-off (and all fp32) ticks: the fused kernel still wins with two rounds of workgroups (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on); WBC_FUSED_MAX sets both
+  // resolved options
+  size_t fused_max = 4096;        // observer-on fp64 ticks of at most this many states run as ONE kernel (fused_tick.hip.hpp)
+  size_t fused_max_noobs = 8192;  // observer-off (and all fp32) ticks: the fused kernel still wins with two rounds of workgroups
+                                  // (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on)
+  size_t obs_split_min = (size_t)-1;
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
   // N=1 convenience buffers
   void* d_one = nullptr;
-  void* h_one = nullptr;   // pinned host image of d_one: the single-robot calls move it with ONE copy each way
-  void* h_one_dev = nullptr;   // device address of h_one (mapped): WBC_ONE_ZEROCOPY=1 lets the N = 1 kernels read / write it directly
-  bool one_zerocopy = false;
+  void* h_one = nullptr;       // pinned host image of d_one: the single-robot calls move it with ONE copy each way
+  void* h_one_dev = nullptr;   // device address of h_one (mapped): one_zerocopy lets the N = 1 kernels read / write it directly
   size_t one_bytes = 0;
-  // timing
+  // timing: a ring of event pairs allocated by wbc_solver_enable_timing (never inside a tick)
   bool timing = false;
-  int timing_period = 1;   // instrument every timing_period-th launch pair
+  int timing_period = 1;   // instrument every timing_period-th tick
   unsigned long long calls = 0;
   bool sample_now = false;
-  std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_pool;   // 2 * TIMING_MAX_SPANS once timing has been enabled
   struct Span { int kind; hipEvent_t a, b; };
   std::vector<Span> spans;
-  size_t ev_next = 0;
-  // timing source: true = the dispatch's own begin/end timestamps (hipExtLaunchKernelGGL start/stop events, what
-  // rocprofv3 reports); false (env WBC_TIMING=pair) = an event pair recorded around the launch (+2-3 us per span)
-  bool timing_ext = true;
-  hipEvent_t cur_a = nullptr, cur_b = nullptr;   // events the next launch inside the open span attaches to
+  size_t dropped = 0;
 };
 
 // ------------------------------------------------------------------------------------------ model
@@ -261,14 +260,35 @@ static int check_params(const wbc_params* p) {
   return WBC_OK;
 }
 
-extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
-                                 wbc_solver** out) {
+extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = sizeof(*o);
+  o->fused_max = -1;
+  o->rollout_persistent = 1;
+  o->rollout_spw = 0;
+  o->obs_split_min = -1;
+  o->one_zerocopy = 0;
+  o->timing_mode = WBC_TIMING_DISPATCH;
+}
+
+extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
+                                    const wbc_solver_options* opt, wbc_solver** out) {
   if (!m || !out || max_batch == 0 || (dtype != WBC_F64 && dtype != WBC_F32)) return fail(WBC_E_INVALID, "bad argument");
   *out = nullptr;
   if (max_batch > ((size_t)1 << 21))  // keeps every component-major array below 4 GiB (32-bit lane offsets)
     return fail(WBC_E_CAPACITY, "max_batch above 2^21 states per solver: shard the batch over more solvers");
   int rc = check_params(p);
   if (rc) return rc;
+  wbc_solver_options o;
+  wbc_solver_options_default(&o);
+  if (opt) {
+    if (opt->struct_size == 0 || opt->struct_size > sizeof(o)) return fail(WBC_E_INVALID, "wbc_solver_options.struct_size is not set (call wbc_solver_options_default first)");
+    std::memcpy(&o, opt, opt->struct_size);   // a caller built against an older, shorter struct keeps the newer defaults
+    o.struct_size = sizeof(o);
+  }
+  if (o.rollout_spw != 0 && o.rollout_spw != 4 && o.rollout_spw != 16) return fail(WBC_E_INVALID, "rollout_spw must be 0 (auto), 4 or 16");
+  if (o.timing_mode != WBC_TIMING_DISPATCH && o.timing_mode != WBC_TIMING_EVENT_PAIR) return fail(WBC_E_INVALID, "bad timing_mode");
   int leg_body[4][3];
   std::string err;
   rc = quadruped_topology(m->fm, leg_body, err);
@@ -277,35 +297,30 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(WBC_E_NODEVICE, "no HIP device: the WBC hot path has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(WBC_E_INVALID, "device index out of range");
-  HIP_TRY(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(WBC_E_NODEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
   wbc_solver* s = new (std::nothrow) wbc_solver;
   if (!s) return fail(WBC_E_INVALID, "out of memory");
-  s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p;
-  if (const char* e = std::getenv("WBC_QP_KERNEL")) s->qp_kernel = (std::strcmp(e, "wave") == 0) ? 1 : 0;
-  if (const char* e = std::getenv("WBC_QP_WPB")) s->qp_wpb = (std::strcmp(e, "4") == 0) ? 4 : 1;
-  if (const char* e = std::getenv("WBC_QP_REGROUP")) s->qp_regroup = (std::strcmp(e, "1") == 0);
-  if (const char* e = std::getenv("WBC_ROLLOUT_PERSISTENT")) s->rollout_persistent = std::strcmp(e, "0") != 0;
-  if (const char* e = std::getenv("WBC_ROLLOUT_SPW")) s->rollout_spw = std::atoi(e);
-  if (const char* e = std::getenv("WBC_OBS_SPLIT_MIN")) s->obs_split_min = (size_t)std::strtoull(e, nullptr, 10);
-  if (const char* e = std::getenv("WBC_TIMING")) s->timing_ext = std::strcmp(e, "pair") != 0;
-  if (const char* e = std::getenv("WBC_FUSED_MAX")) s->fused_max = s->fused_max_noobs = (size_t)std::strtoull(e, nullptr, 10);
-  if (const char* e = std::getenv("WBC_SWEEP")) s->sweep_mode = (std::strcmp(e, "split") == 0) ? 0 : 1;
+  s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p; s->opt = o;
+  if (o.fused_max >= 0) s->fused_max = s->fused_max_noobs = (size_t)o.fused_max;
+  if (o.obs_split_min >= 0) s->obs_split_min = (size_t)o.obs_split_min;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
-  hipError_t e;
-  if (dtype == WBC_F64) {
-    DevModel<double> dm; build_dev_model(m->fm, leg_body, dm);
-    e = hipMalloc(&s->d_model, sizeof(dm));
-    if (e == hipSuccess) e = hipMemcpy(s->d_model, &dm, sizeof(dm), hipMemcpyHostToDevice);
-  } else {
-    DevModel<float> dm; build_dev_model(m->fm, leg_body, dm);
-    e = hipMalloc(&s->d_model, sizeof(dm));
-    if (e == hipSuccess) e = hipMemcpy(s->d_model, &dm, sizeof(dm), hipMemcpyHostToDevice);
+  DeviceGuard guard(device);
+  hipError_t e = guard.err;
+  if (e == hipSuccess) {
+    if (dtype == WBC_F64) {
+      DevModel<double> dm; build_dev_model(m->fm, leg_body, dm);
+      e = hipMalloc(&s->d_model, sizeof(dm));
+      if (e == hipSuccess) e = hipMemcpy(s->d_model, &dm, sizeof(dm), hipMemcpyHostToDevice);
+    } else {
+      DevModel<float> dm; build_dev_model(m->fm, leg_body, dm);
+      e = hipMalloc(&s->d_model, sizeof(dm));
+      if (e == hipSuccess) e = hipMemcpy(s->d_model, &dm, sizeof(dm), hipMemcpyHostToDevice);
+    }
   }
   if (e == hipSuccess) e = hipMalloc(&s->d_ws, (size_t)WS_LDS_WORDS * max_batch * ts);
   // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
@@ -313,7 +328,6 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&s->h_one, s->one_bytes, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(&s->h_one_dev, s->h_one, 0);
-  if (const char* z = std::getenv("WBC_ONE_ZEROCOPY")) s->one_zerocopy = std::atoi(z) != 0;
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
@@ -326,9 +340,14 @@ extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dt
   return WBC_OK;
 }
 
+extern "C" int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
+                                 wbc_solver** out) {
+  return wbc_solver_create_ex(m, p, dtype, device, max_batch, nullptr, out);
+}
+
 extern "C" void wbc_solver_destroy(wbc_solver* s) {
   if (!s) return;
-  (void)hipSetDevice(s->device);
+  DeviceGuard guard(s->device);
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_ws) (void)hipFree(s->d_ws);
   if (s->d_one) (void)hipFree(s->d_one);
@@ -349,61 +368,60 @@ extern "C" int wbc_solver_set_params(wbc_solver* s, const wbc_params* p) {
   return WBC_OK;
 }
 
-// ---- timing helpers
-static int span_begin(wbc_solver* s, int kind, hipStream_t st) {
-  if (!s->timing || !s->sample_now) return WBC_OK;
-  if (s->ev_next + 2 > s->ev_pool.size()) {
-    for (int i = 0; i < 64; ++i) {
+extern "C" int wbc_solver_device(const wbc_solver* s) { return s ? s->device : -1; }
+
+// ---- timing: spans borrow event pairs from a ring that wbc_solver_enable_timing allocated; nothing is created inside a tick
+struct SpanScope {   // one instrumented kernel launch
+  wbc_solver* s;
+  LaunchCtx L;
+  bool active = false;
+  hipError_t err = hipSuccess;
+  SpanScope(wbc_solver* s_, int kind, hipStream_t st) : s(s_) {
+    L.st = st;
+    if (!s->timing || !s->sample_now) return;
+    if (s->spans.size() >= TIMING_MAX_SPANS) { ++s->dropped; return; }
+    const size_t i = 2 * s->spans.size();
+    wbc_solver::Span sp{kind, s->ev_pool[i], s->ev_pool[i + 1]};
+    if (s->opt.timing_mode == WBC_TIMING_DISPATCH) { L.ev_start = sp.a; L.ev_stop = sp.b; }   // the dispatch's own timestamps
+    else err = hipEventRecord(sp.a, st);
+    s->spans.push_back(sp);
+    active = true;
+  }
+  hipError_t end() {   // after the launch
+    if (active && s->opt.timing_mode != WBC_TIMING_DISPATCH) return hipEventRecord(s->spans.back().b, L.st);
+    return hipSuccess;
+  }
+  void cancel() { if (active) { s->spans.pop_back(); active = false; } }   // the launch failed
+};
+static void timing_tick(wbc_solver* s) {  // once per API call: is this tick instrumented?
+  s->sample_now = s->timing && (s->calls++ % (unsigned long long)s->timing_period) == 0;
+}
+
+extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
+  if (!s) return fail(WBC_E_INVALID, "null solver");
+  if (on && s->ev_pool.empty()) {
+    ON_DEVICE(s);
+    s->ev_pool.reserve(2 * TIMING_MAX_SPANS);
+    s->spans.reserve(TIMING_MAX_SPANS);
+    for (size_t i = 0; i < 2 * TIMING_MAX_SPANS; ++i) {
       hipEvent_t ev;
       HIP_TRY(hipEventCreate(&ev));
       s->ev_pool.push_back(ev);
     }
   }
-  wbc_solver::Span sp{kind, s->ev_pool[s->ev_next], s->ev_pool[s->ev_next + 1]};
-  s->ev_next += 2;
-  if (s->timing_ext) { s->cur_a = sp.a; s->cur_b = sp.b; }   // WBC_LAUNCH hands them to the one launch of this span
-  else HIP_TRY(hipEventRecord(sp.a, st));
-  s->spans.push_back(sp);
-  return WBC_OK;
-}
-static void timing_tick(wbc_solver* s) {  // once per API call: is this tick instrumented?
-  s->sample_now = s->timing && (s->calls++ % (unsigned long long)s->timing_period) == 0;
-}
-static int span_end(wbc_solver* s, hipStream_t st) {
-  if (!s->timing || !s->sample_now) return WBC_OK;
-  if (s->timing_ext) {
-    if (s->cur_a) { s->cur_a = s->cur_b = nullptr; s->spans.pop_back(); }   // no launch happened inside the span
-    return WBC_OK;
-  }
-  HIP_TRY(hipEventRecord(s->spans.back().b, st));
-  return WBC_OK;
-}
-
-// every kernel launch of this file: inside an instrumented span the dispatch carries the span's start/stop events
-#define WBC_LAUNCH(kern, grid, block, shmem, st, ...)                                                          \
-  do {                                                                                                         \
-    if (s->cur_a) {                                                                                            \
-      hipExtLaunchKernelGGL(kern, grid, block, shmem, st, s->cur_a, s->cur_b, 0, __VA_ARGS__);                 \
-      s->cur_a = s->cur_b = nullptr;                                                                           \
-    } else {                                                                                                   \
-      hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                           \
-    }                                                                                                          \
-  } while (0)
-
-extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
-  if (!s) return fail(WBC_E_INVALID, "null solver");
   s->timing = on != 0;
   s->timing_period = on > 1 ? on : 1;  // on = k > 1: sample every k-th tick (keeps the event cost out of the rest)
   s->calls = 0;
   s->sample_now = false;
   s->spans.clear();
-  s->ev_next = 0;
+  s->dropped = 0;
   return WBC_OK;
 }
 
 extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launches[4]) {
   if (!s || !ms || !launches) return fail(WBC_E_INVALID, "null argument");
   for (int k = 0; k < 4; ++k) { ms[k] = 0; launches[k] = 0; }
+  ON_DEVICE(s);
   for (auto& sp : s->spans) {
     HIP_TRY(hipEventSynchronize(sp.b));
     float t = 0;
@@ -412,84 +430,23 @@ extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launch
     launches[sp.kind]++;
   }
   s->spans.clear();
-  s->ev_next = 0;
+  s->dropped = 0;
   return WBC_OK;
 }
 
-// ---- launches
-template <class T, int MODE>
-static hipError_t launch_sweep(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
-  const size_t threads = a.N * 4;
-  if constexpr ((MODE & SW_OBS) == 0) {  // the observer variants park too much per wave for 256-thread workgroups
-    if (threads >= (size_t)256 * 8 * 64 * 2) {  // enough work for two full rounds of 8 waves per CU: share the tables
-      const unsigned blocks = (unsigned)((threads + 255) / 256);
-      WBC_LAUNCH((dyn_sweep_kernel<T, MODE, 256>), dim3(blocks), dim3(256), 0, st,
-                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
-      return hipGetLastError();
-    }
-  }
-  {
-    const unsigned blocks = (unsigned)((threads + 63) / 64);
-    WBC_LAUNCH((dyn_sweep_kernel<T, MODE, 64>), dim3(blocks), dim3(64), 0, st, (const DevModel<T>*)s->d_model,
-                       to_dev_params<T>(s->params), a);
-  }
-  return hipGetLastError();
-}
+// one instrumented launch: kind = index into the timing arrays (0 dyn_sweep, 1 QP, 2 rnea_step / observer, 3 fused tick)
+#define TIMED_LAUNCH(kind_, stream_, what_, call_)                                                          \
+  do {                                                                                                      \
+    SpanScope sc_(s, kind_, stream_);                                                                       \
+    if (sc_.err != hipSuccess) return fail(WBC_E_HIP, std::string("hipEventRecord: ") + hipGetErrorString(sc_.err)); \
+    const LaunchCtx& L = sc_.L;                                                                             \
+    hipError_t le_ = (call_);                                                                               \
+    if (le_ != hipSuccess) { sc_.cancel(); return fail(WBC_E_HIP, std::string(what_ " launch: ") + hipGetErrorString(le_)); } \
+    le_ = sc_.end();                                                                                        \
+    if (le_ != hipSuccess) return fail(WBC_E_HIP, std::string("hipEventRecord: ") + hipGetErrorString(le_)); \
+  } while (0)
 
-template <class T>
-static hipError_t launch_mass_jac(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
-  const size_t threads = a.N * 4;
-  if (threads >= (size_t)256 * 8 * 64 * 2) {
-    WBC_LAUNCH((mass_jac_kernel<T, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                       (const DevModel<T>*)s->d_model, a);
-  } else {
-    WBC_LAUNCH((mass_jac_kernel<T, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
-                       (const DevModel<T>*)s->d_model, a);
-  }
-  return hipGetLastError();
-}
-
-template <class T, int MODE>
-static hipError_t launch_rnea_step_mode(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
-  const size_t threads = a.N * 4;
-  // 256-thread workgroups only where four waves' parked state fits the CU twice (one force chain, no observer)
-  if constexpr ((MODE & RS_OBS) == 0 && !((MODE & RS_STEP) && (MODE & RS_H))) {
-    if (threads >= (size_t)256 * 8 * 64 * 2) {
-      WBC_LAUNCH((rnea_step_kernel<T, MODE, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
-      return hipGetLastError();
-    }
-  }
-  WBC_LAUNCH((rnea_step_kernel<T, MODE, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st,
-                     (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
-  return hipGetLastError();
-}
-
-template <class T>
-static hipError_t launch_rnea_step(wbc_solver* s, int mode, const SweepArgs<T>& a, hipStream_t st) {
-  switch (mode) {
-#define RS_CASE(M) case M: return launch_rnea_step_mode<T, M>(s, a, st);
-    RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7)
-    RS_CASE(8) RS_CASE(9) RS_CASE(10) RS_CASE(11) RS_CASE(12) RS_CASE(13) RS_CASE(14) RS_CASE(15)
-#undef RS_CASE
-    default: return hipErrorInvalidValue;
-  }
-}
-
-// fork the store-heavy mass_jac kernel onto the solver's second stream; the caller's stream waits for it at the end
-template <class T>
-static int fork_mass_jac(wbc_solver* s, const SweepArgs<T>& a, hipStream_t st) {
-  HIP_TRY(hipEventRecord(s->ev_fork, st));
-  HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
-  int rc = span_begin(s, 0, s->aux);
-  if (rc) return rc;
-  hipError_t e = launch_mass_jac<T>(s, a, s->aux);
-  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("mass_jac launch: ") + hipGetErrorString(e));
-  rc = span_end(s, s->aux);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(s->ev_join, s->aux));
-  return WBC_OK;
-}
+template <class T> static const DevModel<T>* dev_model(const wbc_solver* s) { return (const DevModel<T>*)s->d_model; }
 
 template <class T>
 static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc, void* pf,
@@ -498,41 +455,20 @@ static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, 
   std::memset(&a, 0, sizeof(a));
   a.N = N; a.q = (const T*)q; a.v = (const T*)v;
   a.M = (T*)M; a.h = (T*)h; a.Jc = (T*)Jc; a.pf = (T*)pf; a.p = (T*)p; a.beta = (T*)beta;
-  const bool mats = M != nullptr, obs = p || beta;
+  const int mode = (M ? SW_MATS : 0) | ((p || beta) ? SW_OBS : 0);
   timing_tick(s);
-  if (s->sweep_mode == 0) {
-    int rc = WBC_OK;
-    if (mats) { rc = fork_mass_jac<T>(s, a, st); if (rc) return rc; }
-    const int mode = (mats ? RS_H : 0) | (obs ? RS_OBS : 0) | ((!mats && pf) ? RS_PF : 0);
-    if (mode) {
-      rc = span_begin(s, 2, st);
-      if (rc) return rc;
-      hipError_t e2 = launch_rnea_step<T>(s, mode, a, st);
-      if (e2 != hipSuccess) return fail(WBC_E_HIP, std::string("rnea_step launch: ") + hipGetErrorString(e2));
-      rc = span_end(s, st);
-      if (rc) return rc;
-    }
-    if (mats) HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));
-    return WBC_OK;
-  }
-  int rc = span_begin(s, 0, st);
-  if (rc) return rc;
-  hipError_t e;
-  if (mats && obs) e = launch_sweep<T, SW_MATS | SW_OBS>(s, a, st);
-  else if (mats) e = launch_sweep<T, SW_MATS>(s, a, st);
-  else if (obs) e = launch_sweep<T, SW_OBS>(s, a, st);
-  else e = launch_sweep<T, 0>(s, a, st);
-  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
-  return span_end(s, st);
+  TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, mode, dev_model<T>(s), to_dev_params<T>(s->params), a));
+  return WBC_OK;
 }
 
 extern "C" int wbc_dynamics_batch(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc,
                                   void* pf, void* p, void* beta, void* stream) {
   if (!s || !q || !v) return fail(WBC_E_INVALID, "null argument");
   if (N == 0) return WBC_OK;
+  if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");   // (also keeps the 32-bit lane offsets in range)
   if ((M || h || Jc) && !(M && h && Jc)) return fail(WBC_E_INVALID, "M, h, Jc must be given together");
   if (!M && !pf && !p && !beta) return fail(WBC_E_INVALID, "no output requested");
-  HIP_TRY(hipSetDevice(s->device));
+  ON_DEVICE(s);
   hipStream_t st = (hipStream_t)stream;
   return s->dtype == WBC_F64 ? dynamics_impl<double>(s, N, q, v, M, h, Jc, pf, p, beta, st)
                              : dynamics_impl<float>(s, N, q, v, M, h, Jc, pf, p, beta, st);
@@ -551,107 +487,38 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   a.ws = (T*)s->d_ws;
   const bool mats = out->M != nullptr, ob = s->params.observer_order > 0;
   timing_tick(s);
-  int rc;
-  hipError_t e;
-  bool obs_split = false;
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
   // two-kernel tick with M/h/Jc outputs: the QP takes its geometry from Jc and the sweep skips those workspace words
-  const bool geom_from_jc = mats && s->sweep_mode == 1 && s->qp_kernel == 0;
-  qa.Jc = geom_from_jc ? (const T*)out->Jc : nullptr;
-  a.ws_geom = geom_from_jc ? 0 : 1;
-  if ((mats || !out->pf) && s->sweep_mode == 1 && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1 &&
-      N <= ((ob && s->dtype == WBC_F64) ? s->fused_max : s->fused_max_noobs)) {   // fp32: half the LDS, 8 192 also with the observer on (29.7 vs 36.9 us)
+  qa.Jc = mats ? (const T*)out->Jc : nullptr;
+  a.ws_geom = mats ? 0 : 1;
+  const DevParams<T> dp = to_dev_params<T>(s->params);
+  if ((mats || !out->pf) && N <= ((ob && s->dtype == WBC_F64) ? s->fused_max : s->fused_max_noobs)) {   // fp32: half the LDS, 8 192 also with the observer on (29.7 vs 36.9 us)
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
-    rc = span_begin(s, 3, st);
-    if (rc) return rc;
-    const dim3 grid((unsigned)((N + 15) / 16));
-    const DevModel<T>* dm = (const DevModel<T>*)s->d_model;
-    const DevParams<T> dp = to_dev_params<T>(s->params);
-    constexpr unsigned obs_threads = 384 + 64 * FUSED_OBS_WAVES;
-    if (ob && mats) WBC_LAUNCH((fused_tick_kernel<T, true, true>), grid, dim3(obs_threads), 0, st, dm, dp, a, qa, s->jmap);
-    else if (ob) WBC_LAUNCH((fused_tick_kernel<T, true, false>), grid, dim3(obs_threads), 0, st, dm, dp, a, qa, s->jmap);
-    else if (mats) WBC_LAUNCH((fused_tick_kernel<T, false, true>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
-    else WBC_LAUNCH((fused_tick_kernel<T, false, false>), grid, dim3(384), 0, st, dm, dp, a, qa, s->jmap);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("fused tick launch: ") + hipGetErrorString(e));
-    return span_end(s, st);
+    TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap));
+    return WBC_OK;
   }
-  if (s->sweep_mode == 0 || !mats) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
-    if (mats) { rc = fork_mass_jac<T>(s, a, st); if (rc) return rc; }
-    const int mode = RS_STEP | (mats ? RS_H : 0) | (ob ? RS_OBS : 0) | ((!mats && out->pf) ? RS_PF : 0);
-    rc = span_begin(s, 2, st);
-    if (rc) return rc;
-    e = launch_rnea_step<T>(s, mode, a, st);
-    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rnea_step launch: ") + hipGetErrorString(e));
-    rc = span_end(s, st);
-    if (rc) return rc;
-  } else if (mats && ob && N >= s->obs_split_min && s->qp_kernel == 0 && s->qp_wpb == 1 && !s->qp_regroup) {
+  bool obs_split = false;
+  if (!mats) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
+    const int mode = RS_STEP | (ob ? RS_OBS : 0) | (out->pf ? RS_PF : 0);
+    TIMED_LAUNCH(2, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
+  } else if (ob && N >= s->obs_split_min) {
     // large observer-on batch: the observer update runs as its own light kernel on the second stream while dyn_sweep
     // WITHOUT the observer passes (252 instead of 370 VGPRs: two waves per SIMD, shared tables) writes M, h, Jc; rhat
     // travels through 18 extra workspace words and the QP kernel completes b and tau_partial with it
     obs_split = true;
     HIP_TRY(hipEventRecord(s->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
-    rc = span_begin(s, 2, s->aux);
-    if (rc) return rc;
-    if (N * 4 >= (size_t)256 * 8 * 64 * 2)
-      WBC_LAUNCH((observer_kernel<T, 256>), dim3((unsigned)((N * 4 + 255) / 256)), dim3(256), 0, s->aux,
-                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
-    else
-      WBC_LAUNCH((observer_kernel<T, 64>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, s->aux,
-                         (const DevModel<T>*)s->d_model, to_dev_params<T>(s->params), a);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("observer launch: ") + hipGetErrorString(e));
-    rc = span_end(s, s->aux);
-    if (rc) return rc;
+    TIMED_LAUNCH(2, s->aux, "observer", k_observer<T>(L, dev_model<T>(s), dp, a));
     HIP_TRY(hipEventRecord(s->ev_join, s->aux));
-    rc = span_begin(s, 0, st);
-    if (rc) return rc;
-    e = launch_sweep<T, SW_MATS | SW_STEP>(s, a, st);
-    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
-    rc = span_end(s, st);
-    if (rc) return rc;
+    TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP, dev_model<T>(s), dp, a));
     HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));   // the QP needs rhat
   } else {
-    rc = span_begin(s, 0, st);
-    if (rc) return rc;
-    if (mats && ob) e = launch_sweep<T, SW_MATS | SW_STEP | SW_OBS>(s, a, st);
-    else if (mats) e = launch_sweep<T, SW_MATS | SW_STEP>(s, a, st);
-    else if (ob) e = launch_sweep<T, SW_STEP | SW_OBS>(s, a, st);
-    else e = launch_sweep<T, SW_STEP>(s, a, st);
-    if (e != hipSuccess) return fail(WBC_E_HIP, std::string("dyn_sweep launch: ") + hipGetErrorString(e));
-    rc = span_end(s, st);
-    if (rc) return rc;
+    TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | (ob ? SW_OBS : 0), dev_model<T>(s), dp, a));
   }
-
-  rc = span_begin(s, 1, st);
-  if (rc) return rc;
-  if (s->qp_kernel == 1) {  // one QP per wavefront, factors in LDS (north-star sketch; kept for A/B)
-    const unsigned blocks = (unsigned)((N + 3) / 4);
-    WBC_LAUNCH((qp_wave_kernel<T>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
-  } else {                  // one QP per 16-lane DPP row, factors in registers
-    if (s->qp_wpb == 4) {
-      const unsigned blocks = (unsigned)((N + 15) / 16);
-      if (s->qp_regroup)
-        WBC_LAUNCH((qp_group16_kernel<T, true, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
-      else
-        WBC_LAUNCH((qp_group16_kernel<T, false, 4>), dim3(blocks), dim3(256), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
-    } else {
-      const unsigned blocks = (unsigned)((N + 3) / 4);
-      if (obs_split)
-        WBC_LAUNCH((qp_group16_kernel<T, false, 1, true>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
-      else
-        WBC_LAUNCH((qp_group16_kernel<T, false, 1>), dim3(blocks), dim3(64), 0, st, to_dev_params<T>(s->params), qa, s->jmap);
-    }
-  }
-  e = hipGetLastError();
-  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("qp launch: ") + hipGetErrorString(e));
-  rc = span_end(s, st);
-  if (rc) return rc;
-  if (s->sweep_mode == 0 && mats) HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));  // join: M, Jc, pf are complete
+  TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, dp, qa, s->jmap));
   return WBC_OK;
 }
 
@@ -669,7 +536,7 @@ extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, c
     if (!obs || !obs->integ || !obs->r) return fail(WBC_E_INVALID, "observer on: observer state buffers required");
     if (!in->tau_prev || !in->f_prev) return fail(WBC_E_INVALID, "observer on: tau_prev and f_prev required");
   }
-  HIP_TRY(hipSetDevice(s->device));
+  ON_DEVICE(s);
   hipStream_t st = (hipStream_t)stream;
   return s->dtype == WBC_F64 ? step_impl<double>(s, N, in, out, obs, st) : step_impl<float>(s, N, in, out, obs, st);
 }
@@ -681,9 +548,8 @@ static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void*
   a.N = N; a.q = (T*)q; a.v = (T*)v; a.M = (const T*)M; a.h = (const T*)h; a.Jc = (const T*)Jc;
   a.tau = (const T*)tau; a.f = (const T*)f; a.tau_ext = (const T*)tau_ext; a.tau_traj = (T*)tau_traj;
   a.dt = (T)s->params.dt;
-  WBC_LAUNCH((integrate_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
-                     (const DevModel<T>*)s->d_model, a);
-  hipError_t e = hipGetLastError();
+  LaunchCtx L; L.st = st;
+  hipError_t e = k_integrate<T>(L, dev_model<T>(s), a);
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("integrate launch: ") + hipGetErrorString(e));
   return WBC_OK;
 }
@@ -693,7 +559,7 @@ extern "C" int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, co
   if (!s || !q || !v || !M || !h || !Jc || !tau || !f) return fail(WBC_E_INVALID, "null argument");
   if (N == 0) return WBC_OK;
   if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
-  HIP_TRY(hipSetDevice(s->device));
+  ON_DEVICE(s);
   hipStream_t st = (hipStream_t)stream;
   return s->dtype == WBC_F64 ? integrate_impl<double>(s, N, q, v, M, h, Jc, tau, f, tau_ext, nullptr, st)
                              : integrate_impl<float>(s, N, q, v, M, h, Jc, tau, f, tau_ext, nullptr, st);
@@ -721,44 +587,34 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   ia.tau = (const T*)out->tau; ia.f = (const T*)out->f; ia.tau_ext = (const T*)tau_ext; ia.tau_traj = (T*)tau_traj;
   ia.dt = (T)s->params.dt;
   // states per workgroup: 4 while that still fits one workgroup per CU (a tick then waits for the slowest of 4 QPs, not 16)
-  const int spw = (s->rollout_spw == 4 || (s->rollout_spw == 0 && N <= 1024)) ? 4 : 16;
-  const unsigned blocks = (unsigned)((N + spw - 1) / spw);
+  const int spw = (s->opt.rollout_spw == 4 || (s->opt.rollout_spw == 0 && N <= 1024)) ? 4 : 16;
   RefArgs<T> ra;
   std::memset(&ra, 0, sizeof(ra));
   ra.N = N; ra.q = (const T*)in->q; ra.v = (const T*)in->v; ra.plan = (const T*)plan; ra.t = (T)0;
   ra.w_des = (T*)in->w_des; ra.vdot_des = (T*)in->vdot_des; ra.com = (T*)com_traj;
-  const DevModel<T>* dm = (const DevModel<T>*)s->d_model;
-  const DevParams<T> dp = to_dev_params<T>(s->params);
-  const DevRefParams<T>* G = (const DevRefParams<T>*)s->d_ref;
-  const bool ob = s->params.observer_order > 0;
-#define WBC_ROLLOUT(OB_, TRK_, SPW_) WBC_LAUNCH((rollout_kernel<T, OB_, TRK_, SPW_>), dim3(blocks), dim3(OB_ ? 512 : 448), 0, st, dm, dp, a, qa, s->jmap, ia, horizon, G, ra)
-  if (spw == 4) {
-    if (plan) { if (ob) WBC_ROLLOUT(true, true, 4); else WBC_ROLLOUT(false, true, 4); }
-    else { if (ob) WBC_ROLLOUT(true, false, 4); else WBC_ROLLOUT(false, false, 4); }
-  } else {
-    if (plan) { if (ob) WBC_ROLLOUT(true, true, 16); else WBC_ROLLOUT(false, true, 16); }
-    else { if (ob) WBC_ROLLOUT(true, false, 16); else WBC_ROLLOUT(false, false, 16); }
-  }
-#undef WBC_ROLLOUT
-  hipError_t e = hipGetLastError();
+  LaunchCtx L; L.st = st;
+  hipError_t e = k_rollout<T>(L, s->params.observer_order > 0, plan != nullptr, spw, dev_model<T>(s), to_dev_params<T>(s->params), a, qa,
+                              s->jmap, ia, horizon, (const DevRefParams<T>*)s->d_ref, ra);
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
   return WBC_OK;
 }
+
+static bool rollout_as_one_launch(const wbc_solver* s, size_t N) { return N <= s->fused_max && s->opt.rollout_persistent; }
 
 extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                                  const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, void* stream) {
   if (!s || !in || !out) return fail(WBC_E_INVALID, "null argument");
   if (horizon < 1) return fail(WBC_E_INVALID, "horizon must be >= 1");
   if (!out->M || !out->h || !out->Jc) return fail(WBC_E_INVALID, "rollouts need the M, h, Jc buffers (forward dynamics reads them)");
-  if (s->sweep_mode == 0) return fail(WBC_E_INVALID, "rollouts need the fused sweep (unset WBC_SWEEP=split)");
-  if (N > 0 && N <= s->fused_max && s->rollout_persistent && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1) {
+  if (N == 0) return WBC_OK;   // empty shard
+  if (rollout_as_one_launch(s, N)) {
     if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
     if (!in->q || !in->v || !in->w_des || !in->vdot_des || !in->normals || !in->mu || !in->mask)
       return fail(WBC_E_INVALID, "null input buffer");
     if (!out->tau || !out->f || !out->status) return fail(WBC_E_INVALID, "null output buffer");
     if (s->params.observer_order > 0 && (!obs || !obs->integ || !obs->r))
       return fail(WBC_E_INVALID, "observer on: observer state buffers required");
-    HIP_TRY(hipSetDevice(s->device));
+    ON_DEVICE(s);
     hipStream_t st0 = (hipStream_t)stream;
     return s->dtype == WBC_F64 ? rollout_persistent<double>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0)
                                : rollout_persistent<float>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0);
@@ -768,6 +624,7 @@ extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc
   tick.f_prev = out->f;      // before the QP kernel of the same tick overwrites them
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const size_t nj = 12;
+  ON_DEVICE(s);
   for (int t = 0; t < horizon; ++t) {
     int rc = wbc_step_batch(s, N, &tick, out, obs, stream);
     if (rc) return rc;
@@ -808,7 +665,7 @@ extern "C" int wbc_solver_set_ref_params(wbc_solver* s, const wbc_ref_params* g)
   if (!s || !g) return fail(WBC_E_INVALID, "null argument");
   for (int i = 0; i < 3; ++i)
     if (!(g->inertia_nom[i] >= 0)) return fail(WBC_E_INVALID, "inertia_nom must be non-negative");
-  HIP_TRY(hipSetDevice(s->device));
+  ON_DEVICE(s);
   return s->dtype == WBC_F64 ? upload_ref<double>(s, g) : upload_ref<float>(s, g);
 }
 
@@ -818,9 +675,8 @@ static int reference_impl(wbc_solver* s, size_t N, const void* q, const void* v,
   RefArgs<T> a;
   a.N = N; a.q = (const T*)q; a.v = (const T*)v; a.plan = (const T*)plan; a.t = (T)t;
   a.w_des = (T*)w_des; a.vdot_des = (T*)vdot_des; a.com = (T*)com;
-  WBC_LAUNCH((com_reference_kernel<T>), dim3((unsigned)((N + 15) / 16)), dim3(64), 0, st,
-                     (const DevModel<T>*)s->d_model, (const DevRefParams<T>*)s->d_ref, a);
-  hipError_t e = hipGetLastError();
+  LaunchCtx L; L.st = st;
+  hipError_t e = k_reference<T>(L, dev_model<T>(s), (const DevRefParams<T>*)s->d_ref, a);
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("reference launch: ") + hipGetErrorString(e));
   return WBC_OK;
 }
@@ -831,7 +687,7 @@ extern "C" int wbc_reference_batch(wbc_solver* s, size_t N, const void* q, const
   if (!s->d_ref) return fail(WBC_E_INVALID, "call wbc_solver_set_ref_params first");
   if (N == 0) return WBC_OK;
   if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
-  HIP_TRY(hipSetDevice(s->device));
+  ON_DEVICE(s);
   hipStream_t st = (hipStream_t)stream;
   return s->dtype == WBC_F64 ? reference_impl<double>(s, N, q, v, plan, t, w_des, vdot_des, com, st)
                              : reference_impl<float>(s, N, q, v, plan, t, w_des, vdot_des, com, st);
@@ -843,16 +699,16 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
   if (!s || !in || !out || !plan) return fail(WBC_E_INVALID, "null argument");
   if (horizon < 1) return fail(WBC_E_INVALID, "horizon must be >= 1");
   if (!out->M || !out->h || !out->Jc) return fail(WBC_E_INVALID, "rollouts need the M, h, Jc buffers (forward dynamics reads them)");
-  if (s->sweep_mode == 0) return fail(WBC_E_INVALID, "rollouts need the fused sweep (unset WBC_SWEEP=split)");
   if (!in->q || !in->v || !in->w_des || !in->vdot_des) return fail(WBC_E_INVALID, "null input buffer");
   if (!s->d_ref) return fail(WBC_E_INVALID, "call wbc_solver_set_ref_params first");
-  if (N > 0 && N <= s->fused_max && s->rollout_persistent && s->qp_kernel == 0 && !s->qp_regroup && s->qp_wpb == 1) {
+  if (N == 0) return WBC_OK;   // empty shard
+  if (rollout_as_one_launch(s, N)) {
     if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
     if (!in->normals || !in->mu || !in->mask) return fail(WBC_E_INVALID, "null input buffer");
     if (!out->tau || !out->f || !out->status) return fail(WBC_E_INVALID, "null output buffer");
     if (s->params.observer_order > 0 && (!obs || !obs->integ || !obs->r))
       return fail(WBC_E_INVALID, "observer on: observer state buffers required");
-    HIP_TRY(hipSetDevice(s->device));
+    ON_DEVICE(s);
     hipStream_t st0 = (hipStream_t)stream;
     return s->dtype == WBC_F64 ? rollout_persistent<double>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0, plan, com_traj)
                                : rollout_persistent<float>(s, N, horizon, in, out, obs, tau_ext, tau_traj, st0, plan, com_traj);
@@ -862,6 +718,7 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
   tick.f_prev = out->f;
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const size_t nj = 12;
+  ON_DEVICE(s);
   for (int t = 0; t < horizon; ++t) {
     void* com = com_traj ? (void*)((char*)com_traj + (size_t)t * 6 * N * ts) : nullptr;
     int rc = wbc_reference_batch(s, N, in->q, in->v, plan, (double)t * s->params.dt, (void*)in->w_des, (void*)in->vdot_des, com,
@@ -887,7 +744,7 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
     return fail(WBC_E_INVALID, "null argument");
   const bool ob = s->params.observer_order > 0;
   if (ob && (!tau_prev || !f_prev || !obs_integ || !obs_r)) return fail(WBC_E_INVALID, "observer on: state required");
-  HIP_TRY(hipSetDevice(s->device));
+  ON_DEVICE(s);
   // host staging in the solver's dtype: a pinned image of the device scratch (doubles/floats, then mask | status | iters),
   // one asynchronous copy each way around the launch and one synchronisation (was four blocking copies from pageable memory)
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
@@ -904,7 +761,7 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   put(off[5], mu, 4); put(off[6], tau_prev, 12); put(off[7], f_prev, 12); put(off[8], obs_integ, 18); put(off[9], obs_r, 18);
   put(off[10], nullptr, 12); put(off[11], nullptr, 12);
   hints[0] = mask; hints[1] = 0; hints[2] = 0;
-  const bool zc = s->one_zerocopy;
+  const bool zc = s->opt.one_zerocopy != 0;
   unsigned char* d = (unsigned char*)(zc ? s->h_one_dev : s->d_one);
   int* dints = (int*)(d + 200 * sizeof(double));
   if (!zc) HIP_TRY(hipMemcpyAsync(d, hb, s->one_bytes, hipMemcpyHostToDevice, nullptr));
@@ -931,11 +788,32 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   return WBC_OK;
 }
 
+// Observer start-up for the single-robot host-pointer loop: integ(0) = p(0) = M(q) v, r(0) = 0 (see wbc_observer_state).
+extern "C" int wbc_observer_init(wbc_solver* s, const double* q, const double* v, double* obs_integ, double* obs_r) {
+  if (!s || !q || !v || !obs_integ || !obs_r) return fail(WBC_E_INVALID, "null argument");
+  ON_DEVICE(s);
+  const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
+  unsigned char* hb = (unsigned char*)s->h_one;   // pinned staging: q at word 0, v at 19, p = M v at 37
+  for (int i = 0; i < 19; ++i) { if (s->dtype == WBC_F64) ((double*)hb)[i] = q[i]; else ((float*)hb)[i] = (float)q[i]; }
+  for (int i = 0; i < 18; ++i) { if (s->dtype == WBC_F64) ((double*)hb)[19 + i] = v[i]; else ((float*)hb)[19 + i] = (float)v[i]; }
+  unsigned char* d = (unsigned char*)s->d_one;
+  HIP_TRY(hipMemcpyAsync(d, hb, 37 * ts, hipMemcpyHostToDevice, nullptr));
+  int rc = wbc_dynamics_batch(s, 1, d, d + 19 * ts, nullptr, nullptr, nullptr, nullptr, d + 37 * ts, nullptr, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(hb + 37 * ts, d + 37 * ts, 18 * ts, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  for (int i = 0; i < 18; ++i) {
+    obs_integ[i] = s->dtype == WBC_F64 ? ((double*)hb)[37 + i] : (double)((float*)hb)[37 + i];
+    obs_r[i] = 0.0;
+  }
+  return WBC_OK;
+}
+
 extern "C" int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const double* plan, double t,
                                      double* w_des, double* vdot_des, double* com) {
   if (!s || !q || !v || !plan || !w_des || !vdot_des) return fail(WBC_E_INVALID, "null argument");
   if (!s->d_ref) return fail(WBC_E_INVALID, "call wbc_solver_set_ref_params first");
-  HIP_TRY(hipSetDevice(s->device));
+  ON_DEVICE(s);
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const int off[] = {0, 19, 37, 49, 55, 73, 79};  // q v plan | w_des vdot_des com end
   unsigned char* hb = (unsigned char*)s->h_one;   // pinned staging, one copy each way
@@ -976,4 +854,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 2; }  // 2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points
+extern "C" int wbc_abi_version(void) { return 3; }  // 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
