@@ -558,6 +558,36 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, obs, d
         assert relerr(a["tau"], ref["tau"]) < TIGHT64 and relerr(a["f"], ref["f"]) < TIGHT64
 
 
+@pytest.mark.parametrize("obs,dtype,n,tile,split", [(0, "f64", 1003, 64, -1), (1, "f64", 70001, 256, -1), (0, "f32", 5000, 128, -1),
+                                                   (2, "f64", 2051, 512, 1), (1, "f32", 66000, 256, 1), (0, "f64", 3, 256, -1)])
+def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtype, n, tile, split):
+    """Large batches deal the QPs of a tile to the wavefronts by predicted work (qp_tile_kernel: predictor, LDS counting
+    sort, groups pulled from a queue); the arithmetic per state is the same body, so tau, f, status and iteration counts
+    must equal the one-wavefront-workgroup kernel's -- bit for bit in fp64; in fp32 to rounding (the compiler pairs fp32
+    operations into packed instructions and then contracts a*b + c*d the other way round in one of the two instantiations) --
+    for ragged sizes, every tile size, with rhat arriving through the workspace (split observer) too."""
+    torch = torch_cuda
+    B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=53)
+    nd = _np_dtype(dtype)
+    res = {}
+    for tag, qt in (("tiled", tile), ("plain", -1)):
+        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n, options={"fused_max": 0, "qp_tile": qt, "obs_split_min": split})
+        integ = r = None
+        if obs:
+            td = torch.float64 if dtype == "f64" else torch.float32
+            integ = to_host(solver.dynamics(to_dev(B["q"], torch, td), to_dev(B["v"], torch, td), want=("p",))["p"]).astype(nd)
+            r = np.zeros((n, 18), nd)
+        res[tag] = _run_step(torch, solver, B, dtype, integ, r, want_mats=True)
+    assert np.array_equal(res["tiled"]["status"], res["plain"]["status"])
+    if dtype == "f64":
+        for k in ("tau", "f", "iters"):
+            assert np.array_equal(res["tiled"][k], res["plain"][k]), k
+    else:
+        assert np.mean(res["tiled"]["iters"] != res["plain"]["iters"]) < 1e-2
+        assert relerr(res["tiled"]["tau"], res["plain"]["tau"]) < 1e-3 and relerr(res["tiled"]["f"], res["plain"]["f"]) < 1e-3
+    assert res["plain"]["iters"].max() >= (3 if n > 100 else 0)
+
+
 @pytest.mark.parametrize("obs,dtype,n", [(1, "f64", 3001), (2, "f64", 130), (1, "f32", 2048), (1, "f64", 70000)])
 def test_separate_observer_kernel_matches(torch_cuda, gpu_model, oracle, obs, dtype, n):
     """Large observer-on batches run {observer kernel on the second stream || dyn_sweep without the observer} -> QP that

@@ -1,5 +1,5 @@
 """Diagnostic: timeline of the fused tick's wavefront roles (needs the -DWBC_FUSED_STAMP build:
-   hipcc ... -DWBC_FUSED_STAMP -o lib/libwbc_hip_fstamp.so;  WBC_LIB=.../libwbc_hip_fstamp.so python tools/fused_stamp.py).
+   make -C wbc_quadruped_dob_amd/csrc -j8 LIBDIR=../lib_fstamp EXTRA=-DWBC_FUSED_STAMP;  WBC_LIB=$PWD/wbc_quadruped_dob_amd/lib_fstamp/libwbc_hip.so python tools/fused_stamp.py).
 In that build the `pf` output carries 100 MHz timestamps (wall_clock64) per workgroup instead of foot positions."""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")

@@ -31,6 +31,8 @@ template <class T> struct DevModel {
 
 template <class T> struct DevParams {
   T S[6];
+  T sS[6];                        // sqrt(S)
+  T sqrt_alpha, rsqrt_alpha;      // sqrt(alpha), 1 / sqrt(alpha)
   T alpha, fn_min, fn_max, mu_scale, dt, qp_tol;
   int observer_order, max_iter;
   T K1[18], K2[18];

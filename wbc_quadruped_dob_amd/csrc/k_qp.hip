@@ -4,9 +4,22 @@
 
 namespace wbc {
 
-template <>
-hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
+template <int TILE>
+static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
   using T = Scalar;
+  const dim3 grid((unsigned)((a.N + TILE - 1) / TILE));
+  if (rhat) WBC_KLAUNCH(L, (qp_tile_kernel<T, true, TILE>), grid, dim3(256), prm, a, jmap);
+  else WBC_KLAUNCH(L, (qp_tile_kernel<T, false, TILE>), grid, dim3(256), prm, a, jmap);
+  return hipGetLastError();
+}
+
+template <>
+hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
+  using T = Scalar;
+  if (tile == 64) return qp_tiled<64>(L, rhat, prm, a, jmap);
+  if (tile == 128) return qp_tiled<128>(L, rhat, prm, a, jmap);
+  if (tile == 256) return qp_tiled<256>(L, rhat, prm, a, jmap);
+  if (tile == 512) return qp_tiled<512>(L, rhat, prm, a, jmap);
   const dim3 grid((unsigned)((a.N + 3) / 4));   // one wavefront (four QPs) per workgroup
   if (rhat) WBC_KLAUNCH(L, (qp_group16_kernel<T, true>), grid, dim3(64), prm, a, jmap);
   else WBC_KLAUNCH(L, (qp_group16_kernel<T, false>), grid, dim3(64), prm, a, jmap);

@@ -20,8 +20,10 @@ template <class T> hipError_t k_dyn_sweep(const LaunchCtx& L, int mode, const De
 template <class T> hipError_t k_rnea_step(const LaunchCtx& L, int mode, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
 // observer_kernel<T>: the momentum-observer update as its own kernel (large observer-on batches, second stream)
 template <class T> hipError_t k_observer(const LaunchCtx& L, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
-// qp_group16_kernel<T, RHAT>: GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran)
-template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap);
+// GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran).
+// tile = 0: qp_group16_kernel, one wavefront per workgroup, four consecutive states per wavefront;
+// tile = 64 | 128 | 256 | 512: qp_tile_kernel, workgroups of four wavefronts deal a tile of that many states by predicted work
+template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, int tile, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap);
 // fused_tick_kernel<T, OBSERVER, MATS>: the whole tick of a small batch as one launch
 template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bool mats, const DevModel<T>* model, const DevParams<T>& prm,
                                           const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);

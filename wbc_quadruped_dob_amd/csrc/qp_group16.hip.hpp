@@ -158,9 +158,14 @@ WBC_DEV void qp_wait(int* flag, int need) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <class T, bool WSLDS, bool RHAT = false, int SPW = 16>
-WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr) {
-  constexpr int WPB = WSLDS ? 4 : 1;   // the fused kernels pair their producer wavefronts with four QP wavefronts
+// TILED (qp_tile_kernel below): the four rows of the wavefront solve the states `who` names (dealt by predicted work)
+// instead of four consecutive ones; the workgroup is four such wavefronts.
+struct QpWho { size_t state; bool live; };
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false>
+WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
+                             const QpWho who = QpWho{0, false}) {
+  static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
+  constexpr int WPB = (WSLDS || TILED) ? 4 : 1;   // the fused kernels pair their producer wavefronts with four QP wavefronts
   __shared__ G16Lds<T> lds_all[WPB];
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
@@ -181,9 +186,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   size_t wg = blockIdx.x;
   if (WPB == 1 && (gridDim.x & 31) == 0) wg = (wg & ~(size_t)31) + ((wg & 7) << 2) + ((wg >> 3) & 3);
   static_assert(SPW == 16 || WSLDS, "fewer states per workgroup only inside the fused kernels");
-  const size_t qp_raw = WSLDS ? (size_t)blockIdx.x * SPW + (tx >> 4)   // fused tick: QP wavefronts are threads 0..255 of a larger workgroup
-                              : (wg * blockDim.x + tx) >> 4;
-  bool live = qp_raw < N && (SPW == 16 || (int)(tx >> 4) < SPW);
+  const size_t qp_raw = TILED ? who.state
+                              : WSLDS ? (size_t)blockIdx.x * SPW + (tx >> 4)   // fused tick: QP wavefronts are threads 0..255 of a larger workgroup
+                                      : (wg * blockDim.x + tx) >> 4;
+  bool live = TILED ? who.live : (qp_raw < N && (SPW == 16 || (int)(tx >> 4) < SPW));
   unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
   const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
 #define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
@@ -208,67 +214,124 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     if (isvar) d_me = GLD(a.Jc, comp);
   } else if (isvar) d_me = WSLD(WS_D + v);
 
-  // ------------------------------------------------------------------ H row (a7) : H = A^T S A + alpha I
-  // A = [I ; [d_f]x] per stance foot.  u = column c3 of [d_f]x for my own foot; w_j likewise for column j.
-  const T dqx = dppx<0x00>(d_me), dqy = dppx<0x55>(d_me), dqz = dppx<0xAA>(d_me);  // quad_perm [0000],[1111],[2222]
-  const T onf = on ? (T)1 : (T)0;
-  T u0, u1, u2;  // [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]] column c3
+  // ------------------------------------------------------------------ a square root of H^-1 (a7), from the structure of H
+  // H = alpha I + B^T B,  B = S^(1/2) A (6 x 12),  A = [I ; [d_f]x] per stance foot (zero columns for swing feet).
+  // The dual active-set method needs ANY J with J J^T = H^-1 -- it only ever applies orthogonal transformations to the
+  // columns of J -- so the dense 12x12 Cholesky factor and its inverse are not needed.  With the 6x6 matrix
+  //     G = alpha I + B B^T = L L^T                         (B B^T = S^(1/2) [nc I, -[sd]x ; [sd]x, sum(|d|^2 I - d d^T)] S^(1/2))
+  //     J = (I - B^T K B) / sqrt(alpha),   K = (G + sqrt(alpha) L^T)^-1 = L^-T (L + sqrt(alpha) I)^-1
+  // because J J^T = (I - B^T (K + K^T - K (G - alpha I) K^T) B) / alpha and K + K^T - K (G - alpha I) K^T = G^-1 (Woodbury).
+  // Every lane forms G and its factor redundantly from the twelve broadcast lever-arm components -- no cross-lane step,
+  // six pivots instead of twelve -- then applies K and K^T to ITS column b_v of B; entries of J are three FMAs each.
+  // Accuracy: the alpha-dominated directions are handled analytically, which in fp32 is ~100x closer to H^-1 than the
+  // 12x12 Cholesky route (cond(H) ~ 1e4).
+  const T dqx = dppx<0x00>(d_me), dqy = dppx<0x55>(d_me), dqz = dppx<0xAA>(d_me);  // quad_perm [0000],[1111],[2222]: my foot's lever arm
+  const T onv = (on && isvar) ? (T)1 : (T)0;
+  T u0, u1, u2;  // column c3 of [d_f]x for my own foot: [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]]
   u0 = (c3 == 0) ? (T)0 : (c3 == 1 ? -dqz : dqy);
   u1 = (c3 == 0) ? dqz : (c3 == 1 ? (T)0 : -dqx);
   u2 = (c3 == 0) ? -dqy : (c3 == 1 ? dqx : (T)0);
-  u0 *= onf * prm.S[3]; u1 *= onf * prm.S[4]; u2 *= onf * prm.S[5];  // fold S(3..5) and the stance flag in
-  const T Sme = (c3 == 0 ? prm.S[0] : (c3 == 1 ? prm.S[1] : prm.S[2])) * onf;
-  T Hr[12];
-  sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
-    constexpr int j = decltype(jc)::value;
-    constexpr int fj = j / 3, aj = j % 3;
-    const T onj = ((mask >> fj) & 1) ? (T)1 : (T)0;
-    const T dx = gbc<3 * fj>(d_me), dy = gbc<3 * fj + 1>(d_me), dz = gbc<3 * fj + 2>(d_me);  // CSE'd per foot
-    T w0, w1, w2;
-    if (aj == 0) { w0 = 0; w1 = dz; w2 = -dy; } else if (aj == 1) { w0 = -dz; w1 = 0; w2 = dx; } else { w0 = dy; w1 = -dx; w2 = 0; }
-    T h = (u0 * w0 + u1 * w1 + u2 * w2) + ((c3 == aj) ? Sme : (T)0);
-    h *= onj;
-    if (isvar && v == j) h += prm.alpha;
-    Hr[j] = isvar ? h : (T)0;  // spare lanes: zeros
+  // (the weights pass through an empty asm: they are kernel-uniform, so inside the persistent rollout kernel and the tile
+  // loop every product of two of them would otherwise be hoisted out of the loop and held in registers for the whole kernel)
+  T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
+  T alpha_l = prm.alpha, sqa = prm.sqrt_alpha, rsa = prm.rsqrt_alpha;
+  if constexpr (WSLDS || TILED) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(sqa), "+v"(rsa));
+  // my column of B: bf on the force rows (one non-zero, at row c3), bm on the moment rows
+  const T bfs = onv * (c3 == 0 ? s0 : (c3 == 1 ? s1 : s2));
+  const T bm0 = onv * s3 * u0, bm1 = onv * s4 * u1, bm2 = onv * s5 * u2;
+  T Dx[4], Dy[4], Dz[4], Of[4];   // lever arms of the four feet, zeroed for swing feet; stance flags
+  sfor<0, 4>([&](auto fc) __attribute__((always_inline)) {
+    constexpr int fj = decltype(fc)::value;
+    const bool onj = (mask >> fj) & 1;
+    Of[fj] = onj ? (T)1 : (T)0;
+    Dx[fj] = onj ? gbc<3 * fj>(d_me) : (T)0; Dy[fj] = onj ? gbc<3 * fj + 1>(d_me) : (T)0; Dz[fj] = onj ? gbc<3 * fj + 2>(d_me) : (T)0;
   });
-  // ------------------------------------------------------------------ Cholesky H = L L^T, rows in lanes
-  T linv_me = 0;  // 1 / L[me][me]
-  sfor<0, 12>([&](auto jc) __attribute__((always_inline)) {
-    constexpr int j = decltype(jc)::value;
-    const T piv = gbc<j>(Hr[j]);
-    const T inv = rsqrt_nr(piv);
-    linv_me = (isvar && v == j) ? inv : linv_me;
-    Hr[j] *= inv;
-    sfor<j + 1, 12>([&](auto kc) __attribute__((always_inline)) {
-      constexpr int k = decltype(kc)::value;
-      const T lkj = gbc<k>(Hr[j]);
-      Hr[k] -= Hr[j] * lkj;
+  // lower factor L of G: rows 0..2 diagonal (l0 l1 l2); row 3: [0 a01 a02 | l3]; row 4: [a10 0 a12 | b10 l4]; row 5: [a20 a21 0 | b20 b21 l5]
+  T a01, a02, a10, a12, a20, a21, b10, b20, b21;
+  T il[6], ia[6];   // 1 / L_kk and 1 / (L_kk + sqrt(alpha))
+  {
+    const T nc = (Of[0] + Of[1]) + (Of[2] + Of[3]);
+    const T sx = (Dx[0] + Dx[1]) + (Dx[2] + Dx[3]), sy = (Dy[0] + Dy[1]) + (Dy[2] + Dy[3]), sz = (Dz[0] + Dz[1]) + (Dz[2] + Dz[3]);
+    T Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
+    sfor<0, 4>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int fj = decltype(fc)::value;
+      Pxx += Dx[fj] * Dx[fj]; Pxy += Dx[fj] * Dy[fj]; Pxz += Dx[fj] * Dz[fj];
+      Pyy += Dy[fj] * Dy[fj]; Pyz += Dy[fj] * Dz[fj]; Pzz += Dz[fj] * Dz[fj];
     });
-  });
-  // ------------------------------------------------------------------ J0 = L^-T : my column by back-substitution
+    const T g00 = alpha_l + s0 * s0 * nc, g11 = alpha_l + s1 * s1 * nc, g22 = alpha_l + s2 * s2 * nc;
+    // moment-force block s_(3+i) s_j [sd]x_ij, moment-moment block alpha I + s_(3+i) s_(3+j) (|d|^2 I - d d^T)_ij summed over stance feet
+    const T gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
+    const T m00 = alpha_l + (s3 * s3) * (Pyy + Pzz), m11 = alpha_l + (s4 * s4) * (Pxx + Pzz), m22 = alpha_l + (s5 * s5) * (Pxx + Pyy);
+    const T m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
+    il[0] = rsqrt_nr(g00); il[1] = rsqrt_nr(g11); il[2] = rsqrt_nr(g22);
+    a01 = gm01 * il[1]; a02 = gm02 * il[2]; a10 = gm10 * il[0]; a12 = gm12 * il[2]; a20 = gm20 * il[0]; a21 = gm21 * il[1];
+    const T c00 = m00 - a01 * a01 - a02 * a02, c11 = m11 - a10 * a10 - a12 * a12, c22 = m22 - a20 * a20 - a21 * a21;
+    const T c10 = m10 - a12 * a02, c20 = m20 - a21 * a01, c21 = m21 - a20 * a10;
+    il[3] = rsqrt_nr(c00);
+    b10 = c10 * il[3]; b20 = c20 * il[3];
+    const T t11 = c11 - b10 * b10;
+    il[4] = rsqrt_nr(t11);
+    b21 = (c21 - b20 * b10) * il[4];
+    const T t22 = c22 - b20 * b20 - b21 * b21;
+    il[5] = rsqrt_nr(t22);
+    ia[0] = rcp_nr(g00 * il[0] + sqa); ia[1] = rcp_nr(g11 * il[1] + sqa); ia[2] = rcp_nr(g22 * il[2] + sqa);
+    ia[3] = rcp_nr(c00 * il[3] + sqa); ia[4] = rcp_nr(t11 * il[4] + sqa); ia[5] = rcp_nr(t22 * il[5] + sqa);
+  }
+  // w = (L [+ sqrt(alpha) I])^-1 r  and  y = (L [+ sqrt(alpha) I])^-T w, the diagonal given through its reciprocals `inv`
+  auto fwd = [&](const T* inv, T r0, T r1, T r2, T r3, T r4, T r5, T* w) __attribute__((always_inline)) {
+    w[0] = r0 * inv[0]; w[1] = r1 * inv[1]; w[2] = r2 * inv[2];
+    w[3] = (r3 - a01 * w[1] - a02 * w[2]) * inv[3];
+    w[4] = (r4 - a10 * w[0] - a12 * w[2] - b10 * w[3]) * inv[4];
+    w[5] = (r5 - a20 * w[0] - a21 * w[1] - b20 * w[3] - b21 * w[4]) * inv[5];
+  };
+  auto bwd = [&](const T* inv, const T* w, T* y) __attribute__((always_inline)) {
+    y[5] = w[5] * inv[5];
+    y[4] = (w[4] - b21 * y[5]) * inv[4];
+    y[3] = (w[3] - b10 * y[4] - b20 * y[5]) * inv[3];
+    y[2] = (w[2] - a02 * y[3] - a12 * y[4]) * inv[2];
+    y[1] = (w[1] - a01 * y[3] - a21 * y[5]) * inv[1];
+    y[0] = (w[0] - a10 * y[4] - a20 * y[5]) * inv[0];
+  };
+  const T bf0 = (c3 == 0) ? bfs : (T)0, bf1 = (c3 == 1) ? bfs : (T)0, bf2 = (c3 == 2) ? bfs : (T)0;
+  // ------------------------------------------------------------------ unconstrained minimum x0 = -H^-1 g = B^T G^-1 S^(1/2) b
+  // (b = w_des - rhat_base).  Stand-alone kernel: b is there, one 6x6 solve with the factor at hand.  Inside the fused
+  // kernels (WSLDS) b may still be on its way from the observer role: x0 = -J J^T g is formed later from J alone, after
+  // the constraint rows below are set up (those need the terrain only).
+  T x_me = 0;
+  if constexpr (!WSLDS) {
+    const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
+    T w[6], z[6];
+    fwd(il, s0 * dppx<0x150 + 0>(b_ld), s1 * dppx<0x150 + 1>(b_ld), s2 * dppx<0x150 + 2>(b_ld), s3 * dppx<0x150 + 3>(b_ld),
+        s4 * dppx<0x150 + 4>(b_ld), s5 * dppx<0x150 + 5>(b_ld), w);
+    bwd(il, w, z);
+    x_me = (bf0 * z[0] + bf1 * z[1] + bf2 * z[2]) + (bm0 * z[3] + bm1 * z[4] + bm2 * z[5]);
+  }
+  // ------------------------------------------------------------------ my column and my row of J
   T Jc[12], Jr[12];
-  sfor_down<0, 12>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int i = decltype(ic)::value;
-    T acc = (isvar && v == i) ? (T)1 : (T)0;
-    sfor<i + 1, 12>([&](auto kc) __attribute__((always_inline)) {
-      constexpr int k = decltype(kc)::value;
-      acc -= gbc<k>(Hr[i]) * Jc[k];
+  {
+    T w[6], y[6], yt[6];
+    fwd(ia, bf0, bf1, bf2, bm0, bm1, bm2, w);   // y = K b_v = L^-T (L + sqrt(alpha) I)^-1 b_v
+    bwd(il, w, y);
+    fwd(il, bf0, bf1, bf2, bm0, bm1, bm2, w);   // yt = K^T b_v = (L + sqrt(alpha) I)^-T L^-1 b_v
+    bwd(ia, w, yt);
+    const T yf[3] = {s0 * rsa * y[0], s1 * rsa * y[1], s2 * rsa * y[2]}, ym[3] = {s3 * rsa * y[3], s4 * rsa * y[4], s5 * rsa * y[5]};
+    const T tf[3] = {s0 * rsa * yt[0], s1 * rsa * yt[1], s2 * rsa * yt[2]}, tm[3] = {s3 * rsa * yt[3], s4 * rsa * yt[4], s5 * rsa * yt[5]};
+    sfor<0, 12>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int fi = i / 3, ai = i % 3;
+      const T dlt = (isvar && v == i) ? rsa : (T)0;
+      // b_i . y with b_i = on_i [s_ai e_ai ; s_(3..5) * column ai of [d_i]x]   (Dx.. are already zero for swing feet)
+      T cj = dlt - Of[fi] * yf[ai], rj = dlt - Of[fi] * tf[ai];
+      if (ai == 0) { cj = cj - Dz[fi] * ym[1] + Dy[fi] * ym[2]; rj = rj - Dz[fi] * tm[1] + Dy[fi] * tm[2]; }
+      else if (ai == 1) { cj = cj + Dz[fi] * ym[0] - Dx[fi] * ym[2]; rj = rj + Dz[fi] * tm[0] - Dx[fi] * tm[2]; }
+      else { cj = cj - Dy[fi] * ym[0] + Dx[fi] * ym[1]; rj = rj - Dy[fi] * tm[0] + Dx[fi] * tm[1]; }
+      Jc[i] = cj;   // J[i][v]
+      Jr[i] = rj;   // J[v][i]
     });
-    Jc[i] = acc * gbc<i>(linv_me);
-  });
-  if (!isvar) sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { Jc[decltype(ic)::value] = 0; });
-  // keep J0 in LDS (for rebuilds) and read my row back: one transposition through LDS per QP
+  }
+  // keep the initial J in LDS: dropping a constraint (rare) restores it from there
   if (isvar) sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; J0[i * 12 + v] = Jc[i]; });
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; Jr[c] = isvar ? J0[v * 12 + c] : (T)0; });
-
-  // ------------------------------------------------------------------ g = -A^T S b (b = w_des - rhat_base enters here)
-  // and the unconstrained minimum x = -J J^T g.  Inside the fused kernels (WSLDS) this runs AFTER the constraint rows
-  // below are set up: those need the terrain only, and b may still be on its way from the observer role.
-  T g_me = 0, x_me = 0;
-  auto solve_x0 = [&]() __attribute__((always_inline)) {
+  auto solve_x0 = [&]() __attribute__((always_inline)) {   // fused kernels only: x0 = -J J^T g once b has arrived
     WBC_QSTAMP(3);
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
     if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
@@ -277,15 +340,14 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     T b[6];
     b[0] = dppx<0x150 + 0>(b_ld); b[1] = dppx<0x150 + 1>(b_ld); b[2] = dppx<0x150 + 2>(b_ld);
     b[3] = dppx<0x150 + 3>(b_ld); b[4] = dppx<0x150 + 4>(b_ld); b[5] = dppx<0x150 + 5>(b_ld);
-    const T bs = (c3 == 0 ? b[0] : (c3 == 1 ? b[1] : b[2]));
-    g_me = isvar ? -(Sme * bs + u0 * b[3] + u1 * b[4] + u2 * b[5]) : (T)0;
+    // g = -A^T S b = -B^T S^(1/2) b
+    const T g_me = -((bf0 * (s0 * b[0]) + bf1 * (s1 * b[1]) + bf2 * (s2 * b[2])) + (bm0 * (s3 * b[3]) + bm1 * (s4 * b[4]) + bm2 * (s5 * b[5])));
     T t_me = 0;
     sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; t_me += Jc[i] * gbc<i>(g_me); });
     T acc = 0;
     sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; acc += Jr[c] * gbc<c>(t_me); });
     x_me = -acc;
   };
-  if constexpr (!WSLDS) solve_x0();
 
   // ------------------------------------------------------------------ my constraints (friction pyramid, force box)
   T cAx, cAy, cAz, rA, cBx = 0, cBy = 0, cBz = 0;
@@ -313,9 +375,9 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   {
     T* c = Cl + 3 * (2 * l16);
     c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // (LDS hand-over inside the wavefront: no global traffic to wait for)
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     if constexpr (WSLDS) solve_x0();
   }
 
@@ -579,6 +641,151 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
 template <class T, bool RHAT = false>
 __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
   qp_group16_body<T, false, RHAT>(prm, a, jmap, nullptr);
+}
+
+// ======================================================================================================================
+// qp_tile_kernel: the same QPs, DEALT BY PREDICTED WORK (large batches).
+// A wavefront runs until the slowest of its four rows is done, and iteration counts of neighbouring states differ a lot
+// (0 ... 13, mean 2.5 on the bench data): with four consecutive states per wavefront the loop runs 5.0 trips per group
+// for 2.5 iterations per QP -- half of the row-iterations idle.  Here a 256-thread workgroup owns a TILE of consecutive
+// states and
+//   1. predicts each state's work, one state per LANE: the unconstrained minimum x0 = B^T G^-1 S^(1/2) b from the same 6x6
+//      factor the solver uses (a few hundred instructions per 64 states) and the number of constraints x0 violates
+//      (correlation with the iteration count 0.86-0.89 on the bench data);
+//   2. sorts the tile by that key in LDS (counting sort, hardest first);
+//   3. its four wavefronts pull groups of four similar states from an LDS counter until the tile is empty -- no wavefront
+//      waits for another, rows of a group finish together (3.2-3.3 trips per group instead of 5.0), and the short groups
+//      at the end of the queue level the tail.
+// Results per state are those of qp_group16_kernel (same body, another assignment of states to rows).
+template <class T, bool RHAT>
+WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned s32, unsigned N32) {
+#define PLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+  const int mask = a.mask[s32] & 0xF;
+  const T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
+  T Dx[4], Dy[4], Dz[4], Of[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const bool on = (mask >> f) & 1;
+    T dx, dy, dz;
+    if (a.Jc) { dx = PLD(a.Jc, (3 * f + 1) * 18 + 5); dy = PLD(a.Jc, (3 * f + 2) * 18 + 3); dz = PLD(a.Jc, (3 * f) * 18 + 4); }
+    else { dx = PLD(a.ws, WS_D + 3 * f); dy = PLD(a.ws, WS_D + 3 * f + 1); dz = PLD(a.ws, WS_D + 3 * f + 2); }
+    Of[f] = on ? (T)1 : (T)0; Dx[f] = on ? dx : (T)0; Dy[f] = on ? dy : (T)0; Dz[f] = on ? dz : (T)0;
+  }
+  T bt[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bt[k] = PLD(a.ws, WS_B + k) - (RHAT ? PLD(a.ws, WS_RHAT + k) : (T)0);
+  // G = alpha I + B B^T and its factor, as in qp_group16_body (selection only: seed-accuracy reciprocal square roots)
+  const T nc = (Of[0] + Of[1]) + (Of[2] + Of[3]);
+  const T sx = (Dx[0] + Dx[1]) + (Dx[2] + Dx[3]), sy = (Dy[0] + Dy[1]) + (Dy[2] + Dy[3]), sz = (Dz[0] + Dz[1]) + (Dz[2] + Dz[3]);
+  T Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    Pxx += Dx[f] * Dx[f]; Pxy += Dx[f] * Dy[f]; Pxz += Dx[f] * Dz[f]; Pyy += Dy[f] * Dy[f]; Pyz += Dy[f] * Dz[f]; Pzz += Dz[f] * Dz[f];
+  }
+  const T g00 = prm.alpha + s0 * s0 * nc, g11 = prm.alpha + s1 * s1 * nc, g22 = prm.alpha + s2 * s2 * nc;
+  const T gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
+  const T m00 = prm.alpha + (s3 * s3) * (Pyy + Pzz), m11 = prm.alpha + (s4 * s4) * (Pxx + Pzz), m22 = prm.alpha + (s5 * s5) * (Pxx + Pyy);
+  const T m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
+  auto rs = [](T x) __attribute__((always_inline)) -> T {
+    if constexpr (std::is_same<T, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
+  };
+  T il[6];
+  il[0] = rs(g00); il[1] = rs(g11); il[2] = rs(g22);
+  const T a01 = gm01 * il[1], a02 = gm02 * il[2], a10 = gm10 * il[0], a12 = gm12 * il[2], a20 = gm20 * il[0], a21 = gm21 * il[1];
+  const T c00 = m00 - a01 * a01 - a02 * a02, c11 = m11 - a10 * a10 - a12 * a12, c22 = m22 - a20 * a20 - a21 * a21;
+  const T c10 = m10 - a12 * a02, c20 = m20 - a21 * a01, c21 = m21 - a20 * a10;
+  il[3] = rs(c00);
+  const T b10 = c10 * il[3], b20 = c20 * il[3];
+  il[4] = rs(c11 - b10 * b10);
+  const T b21 = (c21 - b20 * b10) * il[4];
+  il[5] = rs(c22 - b20 * b20 - b21 * b21);
+  T w[6], z[6];   // z = G^-1 S^(1/2) b
+  w[0] = s0 * bt[0] * il[0]; w[1] = s1 * bt[1] * il[1]; w[2] = s2 * bt[2] * il[2];
+  w[3] = (s3 * bt[3] - a01 * w[1] - a02 * w[2]) * il[3];
+  w[4] = (s4 * bt[4] - a10 * w[0] - a12 * w[2] - b10 * w[3]) * il[4];
+  w[5] = (s5 * bt[5] - a20 * w[0] - a21 * w[1] - b20 * w[3] - b21 * w[4]) * il[5];
+  z[5] = w[5] * il[5];
+  z[4] = (w[4] - b21 * z[5]) * il[4];
+  z[3] = (w[3] - b10 * z[4] - b20 * z[5]) * il[3];
+  z[2] = (w[2] - a02 * z[3] - a12 * z[4]) * il[2];
+  z[1] = (w[1] - a01 * z[3] - a21 * z[5]) * il[1];
+  z[0] = (w[0] - a10 * z[4] - a20 * z[5]) * il[0];
+  const T zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
+  int key = 0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    // x0 of foot f = on (s_f z_f + (s_m z_m) x d_f)
+    const T x0 = Of[f] * zf0 + (zm1 * Dz[f] - zm2 * Dy[f]);
+    const T x1 = Of[f] * zf1 + (zm2 * Dx[f] - zm0 * Dz[f]);
+    const T x2 = Of[f] * zf2 + (zm0 * Dy[f] - zm1 * Dx[f]);
+    T nx = PLD(a.normals, 3 * f), ny = PLD(a.normals, 3 * f + 1), nz = PLD(a.normals, 3 * f + 2);
+    const T iln = rs(nx * nx + ny * ny + nz * nz);
+    nx *= iln; ny *= iln; nz *= iln;
+    const bool usex = fabs_t(nx) < (T)0.9;
+    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
+    const T rd = rx * nx + ry * ny;
+    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
+    const T it = rs(t1x * t1x + t1y * t1y + t1z * t1z);
+    t1x *= it; t1y *= it; t1z *= it;
+    const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    const T fn = nx * x0 + ny * x1 + nz * x2, f1 = t1x * x0 + t1y * x1 + t1z * x2, f2 = t2x * x0 + t2y * x1 + t2z * x2;
+    const T mf = PLD(a.mu, f) * prm.mu_scale * fn, tol = -prm.qp_tol;
+    const int cnt = (mf - f1 < tol) + (mf + f1 < tol) + (mf - f2 < tol) + (mf + f2 < tol) + (fn - prm.fn_min < tol) + (prm.fn_max - fn < tol);
+    key += ((mask >> f) & 1) ? cnt : 0;
+  }
+#undef PLD
+  return key;   // 0 ... 24
+}
+
+template <class T, bool RHAT, int TILE>
+__global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+  static_assert(TILE % 4 == 0 && TILE <= 1024, "tile of whole four-state groups");
+  __shared__ unsigned short order[TILE];
+  __shared__ int hist[32];
+  __shared__ int next_grp;
+  const unsigned tid = threadIdx.x;
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  const size_t base = (size_t)blockIdx.x * TILE;
+  if (tid < 32) hist[tid] = 0;
+  if (tid == 0) next_grp = 0;
+  __syncthreads();
+  // 1. keys: bucket 0 = most violated constraints ... 24 = none; 25 = beyond the end of the batch (dealt last, not solved)
+  int bucket[(TILE + 255) / 256], rank[(TILE + 255) / 256];
+#pragma unroll
+  for (int r = 0; r < (TILE + 255) / 256; ++r) {
+    const unsigned i = tid + 256u * r;
+    bucket[r] = 25; rank[r] = 0;
+    if (i < TILE) {
+      const size_t s = base + i;
+      if (s < N) bucket[r] = 24 - qp_predict_key<T, RHAT>(prm, a, (unsigned)s, N32);
+      rank[r] = __hip_atomic_fetch_add(&hist[bucket[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  // 2. counting sort: position = states in harder buckets + my arrival rank in mine
+#pragma unroll
+  for (int r = 0; r < (TILE + 255) / 256; ++r) {
+    const unsigned i = tid + 256u * r;
+    if (i < TILE) {
+      int pos = rank[r];
+      for (int j = 0; j < bucket[r]; ++j) pos += hist[j];
+      order[pos] = (unsigned short)i;
+    }
+  }
+  __syncthreads();
+  // 3. the four wavefronts pull groups of four states, hardest first
+  const int row = (int)((tid & 63) >> 4);
+  for (;;) {
+    int g = 0;
+    if ((tid & 63) == 0) g = __hip_atomic_fetch_add(&next_grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= TILE / 4) break;
+    const size_t s0 = base + order[4 * g];   // first (hardest) state of the group
+    if (s0 >= N) break;                      // the rest of the queue lies beyond the end of the batch
+    const size_t s = base + order[4 * g + row];
+    qp_group16_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{s, s < N});
+  }
 }
 
 }  // namespace wbc
