@@ -110,9 +110,9 @@ typedef struct wbc_solver_options {
                              kernel on a second stream beside the sweep; -1 = never (default) */
   int one_zerocopy;       /* 1: the single-robot host-pointer calls let the kernel read/write the pinned staging image directly */
   int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */
-  int qp_tile;            /* GRF-QP kernel of the two-kernel tick: 0 = auto (tiles of 256 states dealt to the wavefronts by
-                             predicted work from 131072 states on, one-wavefront workgroups below), -1 = never tiles,
-                             64 | 128 | 256 | 512 = always tiles of that many states */
+  int qp_tile;            /* GRF-QP kernel of the two-kernel tick: 0 = auto (tiles of 32 / 64 states dealt to the wavefronts by
+                             predicted work from 12288 / 20480 states on, one-wavefront workgroups below), -1 = never tiles,
+                             32 | 64 | 128 | 256 | 512 = always tiles of that many states */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,

@@ -1,17 +1,17 @@
 #!/bin/bash
-# SQ counter passes (<= 8 SQ counters per pass) for the bench at a given batch: tools/sq_profile.sh <batch> <tag>
+# SQ counter passes (<= 8 SQ counters per pass) for the bench at a given batch: tools/sq_profile.sh <batch> <tag> [passes]
+# (kernel-selection switches travel through the WBC_* variables the Python binding turns into wbc_solver_options)
 set -u
 export TMPDIR=/tmp
-R="$GRAFT_REPO_ROOT"; B=${1:-262144}; TAG=${2:-sq}
+R="$GRAFT_REPO_ROOT"; B=${1:-262144}; TAG=${2:-sq}; PASSES=${3:-"1 2 3 4"}
 OUT="$R/gpurun_out/$TAG"; rm -rf "$OUT"; mkdir -p "$OUT"; cd /tmp
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"
 P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR"
 P3="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 P4="SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
-i=0
-for P in "$P1" "$P2" "$P3" "$P4"; do
-  i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT" -o p$i -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu --no-latency --large-batch 0 --batch $B > "$OUT/p$i.log" 2>&1
+for i in $PASSES; do
+  eval P=\$P$i
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$OUT" -o p$i -- python3 "$R/bench.py" --steps 6 --warmup 2 --no-cpu --no-latency --large-batch 0 --batch $B ${EXTRA:-} > "$OUT/p$i.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv,glob,sys,collections,json,os

@@ -16,6 +16,7 @@ static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar
 template <>
 hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
   using T = Scalar;
+  if (tile == 32) return qp_tiled<32>(L, rhat, prm, a, jmap);
   if (tile == 64) return qp_tiled<64>(L, rhat, prm, a, jmap);
   if (tile == 128) return qp_tiled<128>(L, rhat, prm, a, jmap);
   if (tile == 256) return qp_tiled<256>(L, rhat, prm, a, jmap);

@@ -119,10 +119,10 @@ WBC_DEV float rcp_nr(float x) {
   return y;
 }
 
-// per wave: four 12x12 images of J0 ([i*12 + c]) and four images of R ([position*16 + lane]: row `me` of R is
+// per wave: four 12x12 images of J0 ([i*12 + c]) and four images of R ([position*12 + variable]: row `me` of R is
 // addressed by a run-time position, which LDS allows and a register array does not)
 // ... and the 32 constraint rows (3 coefficients each) so that a candidate's normal is three broadcast reads
-template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 16]; T C[4][32 * 3]; };
+template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 12]; T C[4][32 * 3]; };
 
 #ifndef WBC_QP_WAVES
 #define WBC_QP_WAVES 2
@@ -177,7 +177,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   const bool isvar = c3 < 3;
   const int v = 3 * f + (isvar ? c3 : 0);  // variable index of this lane (spare lanes: unused)
   T* J0 = lds_all[tx >> 6].J0[grp];
-  T* Rl = lds_all[tx >> 6].R[grp] + l16;  // my row of R: Rl[16 * position]
+  T* Rl = lds_all[tx >> 6].R[grp] + v;  // my row of R: Rl[12 * position] (spare lanes alias a variable lane; they never write)
   T* Cl = lds_all[tx >> 6].C[grp];        // constraint rows by id
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
@@ -248,7 +248,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   });
   // lower factor L of G: rows 0..2 diagonal (l0 l1 l2); row 3: [0 a01 a02 | l3]; row 4: [a10 0 a12 | b10 l4]; row 5: [a20 a21 0 | b20 b21 l5]
   T a01, a02, a10, a12, a20, a21, b10, b20, b21;
-  T il[6], ia[6];   // 1 / L_kk and 1 / (L_kk + sqrt(alpha))
+  T il[6], ld[6];   // 1 / L_kk and L_kk
   {
     const T nc = (Of[0] + Of[1]) + (Of[2] + Of[3]);
     const T sx = (Dx[0] + Dx[1]) + (Dx[2] + Dx[3]), sy = (Dy[0] + Dy[1]) + (Dy[2] + Dy[3]), sz = (Dz[0] + Dz[1]) + (Dz[2] + Dz[3]);
@@ -274,8 +274,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     b21 = (c21 - b20 * b10) * il[4];
     const T t22 = c22 - b20 * b20 - b21 * b21;
     il[5] = rsqrt_nr(t22);
-    ia[0] = rcp_nr(g00 * il[0] + sqa); ia[1] = rcp_nr(g11 * il[1] + sqa); ia[2] = rcp_nr(g22 * il[2] + sqa);
-    ia[3] = rcp_nr(c00 * il[3] + sqa); ia[4] = rcp_nr(t11 * il[4] + sqa); ia[5] = rcp_nr(t22 * il[5] + sqa);
+    ld[0] = g00 * il[0]; ld[1] = g11 * il[1]; ld[2] = g22 * il[2]; ld[3] = c00 * il[3]; ld[4] = t11 * il[4]; ld[5] = t22 * il[5];
   }
   // w = (L [+ sqrt(alpha) I])^-1 r  and  y = (L [+ sqrt(alpha) I])^-T w, the diagonal given through its reciprocals `inv`
   auto fwd = [&](const T* inv, T r0, T r1, T r2, T r3, T r4, T r5, T* w) __attribute__((always_inline)) {
@@ -307,8 +306,12 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     x_me = (bf0 * z[0] + bf1 * z[1] + bf2 * z[2]) + (bm0 * z[3] + bm1 * z[4] + bm2 * z[5]);
   }
   // ------------------------------------------------------------------ my column and my row of J
+  // (stand-alone kernels build J only when some row of the wavefront has a violated constraint at x0: a wavefront whose
+  // four unconstrained minima are feasible -- common once tiles are dealt by predicted work -- is done after the 6x6 solve)
   T Jc[12], Jr[12];
-  {
+  auto build_J = [&]() __attribute__((always_inline)) {
+    T ia[6];   // 1 / (L_kk + sqrt(alpha))
+    sfor<0, 6>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; ia[k] = rcp_nr(ld[k] + sqa); });
     T w[6], y[6], yt[6];
     fwd(ia, bf0, bf1, bf2, bm0, bm1, bm2, w);   // y = K b_v = L^-T (L + sqrt(alpha) I)^-1 b_v
     bwd(il, w, y);
@@ -328,9 +331,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
       Jc[i] = cj;   // J[i][v]
       Jr[i] = rj;   // J[v][i]
     });
-  }
-  // keep the initial J in LDS: dropping a constraint (rare) restores it from there
-  if (isvar) sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; J0[i * 12 + v] = Jc[i]; });
+    // keep the initial J in LDS: dropping a constraint (rare) restores it from there
+    if (isvar) sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; J0[i * 12 + v] = Jc[i]; });
+  };
+  if constexpr (WSLDS) build_J();   // fused kernels: J is built while b is still on its way
   auto solve_x0 = [&]() __attribute__((always_inline)) {   // fused kernels only: x0 = -J J^T g once b has arrived
     WBC_QSTAMP(3);
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
@@ -429,7 +433,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Jr[j] -= y_me * gbc<j>(w_me); });
     sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; Jc[i] -= gbc<i>(y_me) * w_me; });
     const T newr = (v < pos) ? dd : -sg * nr;
-    if (doit && isvar && v <= pos) Rl[16 * pos] = newr;
+    if (doit && isvar && v <= pos) Rl[12 * pos] = newr;
     if (doit && isvar && v == pos) rdinv = -sg * inr;
     nr_out = nr;
   };
@@ -453,6 +457,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   const long long st_t1 = __builtin_readcyclecounter();
 #endif
   pick();
+  if constexpr (!WSLDS) { if (__ballot(!done && ip >= 0) != 0ull) build_J(); }
   int guard = 0;
 #ifdef WBC_QP_STAMP
   long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -489,7 +494,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     {
       T acc = (isvar && v < iq) ? dd : (T)0;
       T Rrow[12];  // my row of R, fetched up front so that no LDS latency sits inside the dependent chain
-      sfor<0, 12>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rrow[k] = Rl[16 * k]; });
+      sfor<0, 12>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rrow[k] = Rl[12 * k]; });
       // wave-uniform bound: the largest active-set size among the four rows (one readlane per row, scalar max)
       const int iqg = go ? iq : 0;
       int iqmax = __builtin_amdgcn_readlane(iqg, 0);
@@ -650,11 +655,11 @@ __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<
 // for 2.5 iterations per QP -- half of the row-iterations idle.  Here a 256-thread workgroup owns a TILE of consecutive
 // states and
 //   1. predicts each state's work, one state per LANE: the unconstrained minimum x0 = B^T G^-1 S^(1/2) b from the same 6x6
-//      factor the solver uses (a few hundred instructions per 64 states) and the number of constraints x0 violates
-//      (correlation with the iteration count 0.86-0.89 on the bench data);
+//      factor the solver uses (a few hundred instructions per 64 states), the number of constraints x0 violates and by how
+//      much (count alone: correlation with the iteration count 0.86-0.89 on the bench data);
 //   2. sorts the tile by that key in LDS (counting sort, hardest first);
 //   3. its four wavefronts pull groups of four similar states from an LDS counter until the tile is empty -- no wavefront
-//      waits for another, rows of a group finish together (3.2-3.3 trips per group instead of 5.0), and the short groups
+//      waits for another, rows of a group finish together (about 3 trips per group instead of 5.0), and the short groups
 //      at the end of the queue level the tail.
 // Results per state are those of qp_group16_kernel (same body, another assignment of states to rows).
 template <class T, bool RHAT>
@@ -711,7 +716,8 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned
   z[1] = (w[1] - a01 * z[3] - a21 * z[5]) * il[1];
   z[0] = (w[0] - a10 * z[4] - a20 * z[5]) * il[0];
   const T zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
-  int key = 0;
+  int cnt_all = 0;
+  T mag = 0;   // summed violation of the violated constraints
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     // x0 of foot f = on (s_f z_f + (s_m z_m) x d_f)
@@ -730,35 +736,48 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned
     const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
     const T fn = nx * x0 + ny * x1 + nz * x2, f1 = t1x * x0 + t1y * x1 + t1z * x2, f2 = t2x * x0 + t2y * x1 + t2z * x2;
     const T mf = PLD(a.mu, f) * prm.mu_scale * fn, tol = -prm.qp_tol;
-    const int cnt = (mf - f1 < tol) + (mf + f1 < tol) + (mf - f2 < tol) + (mf + f2 < tol) + (fn - prm.fn_min < tol) + (prm.fn_max - fn < tol);
-    key += ((mask >> f) & 1) ? cnt : 0;
+    const T sl[6] = {mf - f1, mf + f1, mf - f2, mf + f2, fn - prm.fn_min, prm.fn_max - fn};
+    int cnt = 0;
+    T mg = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { cnt += (sl[c] < tol) ? 1 : 0; mg += (sl[c] < tol) ? -sl[c] : (T)0; }
+    const bool on = (mask >> f) & 1;
+    cnt_all += on ? cnt : 0;
+    mag += on ? mg : (T)0;
   }
 #undef PLD
-  return key;   // 0 ... 24
+  // fitted on the bench data (least squares on the iteration count): 0.52 count + 0.70 ln(1 + summed violation); three
+  // buckets per predicted iteration.  Sorting by it: 2.96 trips per group (count alone 3.25, perfect knowledge 2.51).
+  const float kf = 1.56f * (float)cnt_all + 2.1f * __logf(1.0f + (float)mag);
+  const int key = (int)kf;
+  return key > 61 ? 61 : key;   // 0 ... 61
 }
 
+#ifndef WBC_QP_TILE_WAVES
+#define WBC_QP_TILE_WAVES 2
+#endif
 template <class T, bool RHAT, int TILE>
-__global__ __launch_bounds__(256, WBC_QP_WAVES) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+__global__ __launch_bounds__(256, WBC_QP_TILE_WAVES) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
   static_assert(TILE % 4 == 0 && TILE <= 1024, "tile of whole four-state groups");
   __shared__ unsigned short order[TILE];
-  __shared__ int hist[32];
+  __shared__ int hist[64];
   __shared__ int next_grp;
   const unsigned tid = threadIdx.x;
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   const size_t base = (size_t)blockIdx.x * TILE;
-  if (tid < 32) hist[tid] = 0;
+  if (tid < 64) hist[tid] = 0;
   if (tid == 0) next_grp = 0;
   __syncthreads();
-  // 1. keys: bucket 0 = most violated constraints ... 24 = none; 25 = beyond the end of the batch (dealt last, not solved)
+  // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = beyond the end of the batch (dealt last, not solved)
   int bucket[(TILE + 255) / 256], rank[(TILE + 255) / 256];
 #pragma unroll
   for (int r = 0; r < (TILE + 255) / 256; ++r) {
     const unsigned i = tid + 256u * r;
-    bucket[r] = 25; rank[r] = 0;
+    bucket[r] = 62; rank[r] = 0;
     if (i < TILE) {
       const size_t s = base + i;
-      if (s < N) bucket[r] = 24 - qp_predict_key<T, RHAT>(prm, a, (unsigned)s, N32);
+      if (s < N) bucket[r] = 61 - qp_predict_key<T, RHAT>(prm, a, (unsigned)s, N32);
       rank[r] = __hip_atomic_fetch_add(&hist[bucket[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }

@@ -63,7 +63,6 @@ struct wbc_solver {
   size_t fused_max_noobs = 8192;  // observer-off (and all fp32) ticks: the fused kernel still wins with two rounds of workgroups
                                   // (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on)
   size_t obs_split_min = (size_t)-1;
-  size_t qp_tile_min = 131072;    // two-kernel ticks of at least this many states deal the QPs in sorted tiles
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
@@ -291,8 +290,8 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
     o.struct_size = sizeof(o);
   }
   if (o.rollout_spw != 0 && o.rollout_spw != 4 && o.rollout_spw != 16) return fail(WBC_E_INVALID, "rollout_spw must be 0 (auto), 4 or 16");
-  if (o.qp_tile != 0 && o.qp_tile != -1 && o.qp_tile != 64 && o.qp_tile != 128 && o.qp_tile != 256 && o.qp_tile != 512)
-    return fail(WBC_E_INVALID, "qp_tile must be 0 (auto), -1 (off), 64, 128, 256 or 512");
+  if (o.qp_tile != 0 && o.qp_tile != -1 && o.qp_tile != 32 && o.qp_tile != 64 && o.qp_tile != 128 && o.qp_tile != 256 && o.qp_tile != 512)
+    return fail(WBC_E_INVALID, "qp_tile must be 0 (auto), -1 (off), 32, 64, 128, 256 or 512");
   if (o.timing_mode != WBC_TIMING_DISPATCH && o.timing_mode != WBC_TIMING_EVENT_PAIR) return fail(WBC_E_INVALID, "bad timing_mode");
   int leg_body[4][3];
   std::string err;
@@ -523,10 +522,12 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   } else {
     TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | (ob ? SW_OBS : 0), dev_model<T>(s), dp, a));
   }
-  // large batches: tiles of states dealt to the wavefronts by predicted work (qp_tile_kernel); below that the tiles
-  // would not fill the device and the one-wavefront workgroups of qp_group16_kernel are the better fit
+  // two-kernel ticks deal tiles of states to the wavefronts by predicted work (qp_tile_kernel).  Measured on MI355X, fp64,
+  // QP kernel alone, one-wavefront workgroups -> tiles: 34.7 -> 32.7 us at 12 288 states (tiles of 32), 62.4 -> 48.3 at
+  // 32 768, 109.6 -> 93.1 at 65 536, 408 -> 350 at 262 144 (tiles of 64; 128 and 256 lose to the workgroup lifetime);
+  // below 12 288 states the tiles do not fill the device
   int tile = s->opt.qp_tile;
-  if (tile == 0) tile = N >= s->qp_tile_min ? 256 : 0;
+  if (tile == 0) tile = N >= 20480 ? 64 : (N >= 12288 ? 32 : 0);
   if (tile < 0) tile = 0;
   TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, tile, dp, qa, s->jmap));
   return WBC_OK;
