@@ -1,0 +1,195 @@
+"""GPU: checks of the HIP path that need NO oracle, and the fp32 (BASELINE.json configs[3]) workload at its real sizes.
+
+* KKT residuals of the GRF QP solution computed on the GPU in torch from the kernel's own outputs (M/h/Jc/pf, f) and
+  the inputs: stationarity of the Lagrangian with non-negative multipliers on the active rows (found per foot by
+  projected-gradient NNLS), primal feasibility, complementarity -- on >= 10^5 random QPs with mixed stance masks, tilted
+  terrain and mixed friction.  This is algorithmically independent of the Goldfarb-Idnani code in both the kernel and
+  the oracle.
+* configs[3] per-GPU size: fp32, 32 768 states, trot masks, observer on, vs the fp32 run of the oracle; the fraction of
+  states whose status differs is asserted, not just excluded.
+* configs[3] total size: fp32, 262 144 states, real masks and observer, through size-independent properties.
+"""
+import numpy as np
+import pytest
+
+from tests.util import relerr, to_dev, to_host
+from wbc_quadruped_dob_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+def _solver(gpu_model, dtype, obs, n, **kw):
+    import wbc_quadruped_dob_amd as W
+    P = synth.default_params(observer_order=obs, dtype=dtype)
+    P.update(kw)
+    return W.Solver(gpu_model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n, options={}), P
+
+
+def _tangents(torch, nrm):
+    """t1, t2 of the friction pyramid, the convention of DESIGN.md section 2 (restated here in torch)."""
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    usex = (nrm[..., 0].abs() < 0.9).unsqueeze(-1)
+    ex = torch.tensor([1.0, 0.0, 0.0], dtype=nrm.dtype, device=nrm.device)
+    ey = torch.tensor([0.0, 1.0, 0.0], dtype=nrm.dtype, device=nrm.device)
+    e = torch.where(usex, ex, ey)
+    t1 = e - nrm * (e * nrm).sum(-1, keepdim=True)
+    t1 = t1 / t1.norm(dim=-1, keepdim=True)
+    t2 = torch.linalg.cross(nrm, t1)
+    return nrm, t1, t2
+
+
+def kkt_residuals(torch, P, q, pf, w_des, rhat_base, normals, mu, mask, f, act_tol=1e-6):
+    """All arguments component-major device tensors as the C-ABI takes them.  Returns per-state (stationarity residual
+    relative to the gradient scale, worst constraint violation [N], worst complementarity product)."""
+    n = q.shape[1]
+    dt = torch.float64
+    d = (pf.to(dt).T.reshape(n, 4, 3) - q.to(dt).T[:, None, 0:3])                      # lever arms
+    on = ((mask.long()[:, None] >> torch.arange(4, device=mask.device)[None, :]) & 1).to(dt)
+    x = f.to(dt).T.reshape(n, 4, 3)
+    S = torch.tensor(np.asarray(P["S"], np.float64), device=q.device)
+    b = w_des.to(dt).T - (rhat_base.to(dt).T if rhat_base is not None else 0.0)
+    # residual wrench e = A f - b,  A f = [sum f ; sum d x f]   (swing feet: f = 0 and their columns of A are zero)
+    xf = x * on[..., None]
+    Af = torch.cat([xf.sum(1), torch.linalg.cross(d, xf).sum(1)], dim=1)
+    e = (Af - b) * S
+    # gradient of the cost per foot: alpha f_k + e_force + e_moment x d_k   ( [d]x^T y = y x d )
+    grad = P["alpha"] * x + (e[:, None, 0:3] + torch.linalg.cross(e[:, None, 3:6].expand(n, 4, 3), d)) * on[..., None]
+    nrm, t1, t2 = _tangents(torch, normals.to(dt).T.reshape(n, 4, 3))
+    mt = mu.to(dt).T * P["mu_scale"]
+    # constraint rows c_i . f >= rhs_i per foot (6 rows): friction pyramid (4), fn >= fn_min, -fn >= -fn_max
+    C = torch.stack([mt[..., None] * nrm - t1, mt[..., None] * nrm + t1, mt[..., None] * nrm - t2, mt[..., None] * nrm + t2, nrm, -nrm], dim=2)
+    rhs = torch.zeros((n, 4, 6), dtype=dt, device=q.device)
+    rhs[..., 4] = P["fn_min"]
+    rhs[..., 5] = -P["fn_max"]
+    slack = (C * x[:, :, None, :]).sum(-1) - rhs                                        # >= 0 when feasible
+    scale = grad.abs().amax(dim=(1, 2)).clamp_min(1.0) + x.abs().amax(dim=(1, 2))
+    active = (slack < act_tol * scale[:, None, None]) & (on[..., None] > 0)
+    # stationarity: grad_k = sum_i u_i c_i over the ACTIVE rows with u >= 0  -> NNLS per foot by projected gradient
+    Ca = C * active[..., None].to(dt)                                                   # inactive rows zeroed
+    G = Ca @ Ca.transpose(-1, -2)                                                       # [n,4,6,6]
+    rhs_u = (Ca * grad[:, :, None, :]).sum(-1)                                          # [n,4,6]
+    L = G.diagonal(dim1=-2, dim2=-1).sum(-1).clamp_min(1e-12)[..., None]                # trace >= largest eigenvalue
+    u = torch.zeros_like(rhs_u)
+    for _ in range(3000):
+        u = (u - ((G @ u[..., None])[..., 0] - rhs_u) / L).clamp_min(0.0)
+    stat = (grad - (Ca * u[..., None]).sum(2)) * on[..., None]
+    # swing feet must carry no force
+    swing = (x.abs() * (1 - on)[..., None]).amax(dim=(1, 2))
+    viol = (-(slack * on[..., None])).clamp_min(0.0).amax(dim=(1, 2))
+    comp = (u * slack.clamp_min(0.0) * active.to(dt)).amax(dim=(1, 2))
+    return stat.abs().amax(dim=(1, 2)) / scale, torch.maximum(viol, swing), comp / scale
+
+
+@pytest.mark.parametrize("dtype,obs,n", [("f64", 0, 131072), ("f64", 1, 20000), ("f32", 1, 32768)])
+def test_kkt_residuals_of_the_gpu_solution(torch_cuda, gpu_model, dtype, obs, n):
+    torch = torch_cuda
+    solver, P = _solver(gpu_model, dtype, obs, n)
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=61)
+    rng = np.random.default_rng(5)
+    B["w_des"][:, 0:2] += rng.uniform(-120, 120, (n, 2))      # strong lateral demands: many active friction rows
+    td = torch.float64 if dtype == "f64" else torch.float32
+    dv = lambda k: to_dev(B[k], torch, td)
+    mask = torch.from_numpy(B["mask"]).cuda()
+    q, v, w_des, normals, mu = dv("q"), dv("v"), dv("w_des"), dv("normals"), dv("mu")
+    ig = rr = None
+    if obs:
+        ig = solver.dynamics(q, v, want=("p",))["p"].clone()
+        rr = torch.zeros_like(ig)
+        rr[:6] = torch.from_numpy(rng.uniform(-10, 10, (6, n))).to(td).cuda()          # a disturbance estimate already in place
+    out = solver.step(q, v, w_des, dv("vdot_des"), normals, mu, mask, dv("tau_prev"), dv("f_prev"), ig, rr, want_mats=True)
+    torch.cuda.synchronize()
+    ok = out["status"] == 0
+    assert ok.double().mean().item() > 0.999
+    rhat_base = rr[:6] if obs else None     # the tick left the NEW estimate in rr; b = w_des - rhat used exactly that
+    stat, viol, comp = kkt_residuals(torch, P, q, out["pf"], w_des, rhat_base, normals, mu, mask, out["f"],
+                                    act_tol=1e-6 if dtype == "f64" else 2e-3)
+    stat, viol, comp = stat[ok], viol[ok], comp[ok]
+    tol = 1e-7 if dtype == "f64" else 5e-3   # fp32: rows within qp_tol = 1e-3 N of their bound count as active
+    assert stat.max().item() < tol, stat.max().item()
+    assert viol.max().item() < (1e-6 if dtype == "f64" else 5e-2), viol.max().item()     # N; qp_tol is 1e-9 / 1e-3
+    assert comp.max().item() < tol, comp.max().item()
+    assert (out["iters"][ok] > 3).double().mean().item() > 0.05                          # the batch exercises the active set
+
+
+def test_fp32_config4_at_per_gpu_size_vs_fp32_oracle(torch_cuda, gpu_model, oracle):
+    """configs[3] per GPU: 32 768 states, fp32, tilted normals, mixed friction, trot masks, observer on, pushes.
+    Against the fp32 oracle: identical status on (almost) every state -- the fraction that flips is ASSERTED -- and torques
+    / forces / observer state of the rest within the stated fp32 tolerance."""
+    torch = torch_cuda
+    n = 32768
+    solver, P = _solver(gpu_model, "f32", 1, n)
+    B = synth.make_batch(4, n, gpu_model.total_mass)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    r = 0.05 * np.sin(np.arange(n * 18, dtype=np.float64).reshape(n, 18))
+    ig32, r32 = f32(integ), f32(r)
+    ref = oracle.step(P, f32(B["q"]), f32(B["v"]), f32(B["w_des"]), f32(B["vdot_des"]), f32(B["normals"]), f32(B["mu"]), B["mask"],
+                      f32(B["tau_prev"]), f32(B["f_prev"]), ig32, r32, nthreads=8)
+    td = torch.float32
+    dv = lambda k: to_dev(B[k], torch, td)
+    ig, rr = to_dev(integ, torch, td), to_dev(r, torch, td)
+    out = solver.step(dv("q"), dv("v"), dv("w_des"), dv("vdot_des"), dv("normals"), dv("mu"), torch.from_numpy(B["mask"]).cuda(),
+                      dv("tau_prev"), dv("f_prev"), ig, rr)
+    torch.cuda.synchronize()
+    st = out["status"].cpu().numpy()
+    flips = float(np.mean(st != ref["status"]))
+    assert flips < 1e-3, flips
+    same = st == ref["status"]
+    good = same & (st == 0)
+    assert good.mean() > 0.995
+    assert relerr(to_host(out["tau"])[good], ref["tau"][good]) < 1e-3
+    assert relerr(to_host(out["f"])[good], ref["f"][good]) < 1e-3
+    assert relerr(to_host(ig), ig32) < 1e-4 and relerr(to_host(rr), r32) < 1e-3
+    assert np.mean(out["iters"].cpu().numpy()[good] != ref["iters"][good]) < 5e-2
+
+
+def test_fp32_full_size_properties_with_masks_and_observer(torch_cuda, gpu_model):
+    """configs[3] total size (262 144 states) in fp32 with its real inputs: trot masks, tilted normals, friction 0.4/0.6/0.8,
+    observer on.  Size-independent properties: status ok, swing feet carry no force, friction pyramid and force box hold,
+    the observer update is linear in its state (r changes by K1 dt-consistent amounts), torque map affine in vdot_des."""
+    torch = torch_cuda
+    n = 262144
+    solver, P = _solver(gpu_model, "f32", 1, n)
+    B = synth.make_batch(4, n, gpu_model.total_mass)
+    td = torch.float32
+    dv = lambda k: to_dev(B[k], torch, td)
+    mask = torch.from_numpy(B["mask"]).cuda()
+    q, v = dv("q"), dv("v")
+    args = [q, v, dv("w_des"), dv("vdot_des"), dv("normals"), dv("mu"), mask, dv("tau_prev"), dv("f_prev")]
+    ig0 = solver.dynamics(q, v, want=("p",))["p"].clone()
+    ig, rr = ig0.clone(), torch.zeros_like(ig0)
+    out = solver.step(*args, ig, rr)
+    torch.cuda.synchronize()
+    assert (out["status"] == 0).double().mean().item() > 0.9999
+    f = out["f"].T.reshape(n, 4, 3).double()
+    on = ((mask.long()[:, None] >> torch.arange(4, device="cuda")[None, :]) & 1).double()
+    assert (f.abs() * (1 - on)[..., None]).max().item() == 0.0                     # swing feet: exactly zero
+    nrm = args[4].T.reshape(n, 4, 3).double()
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    fn = (f * nrm).sum(-1)
+    assert fn.min().item() > -5e-2 and fn.max().item() < P["fn_max"] + 5e-2
+    ft = f - fn[..., None] * nrm
+    mu = args[5].T.double()
+    assert ((ft.norm(dim=-1) - np.sqrt(2) * mu * fn) * on).max().item() < 5e-2      # inside the circumscribed cone of the pyramid
+    # observer: integ advanced, r = K1 (M v - integ_new) for order 1 -> recompute r from the outputs
+    p = solver.dynamics(q, v, want=("p",))["p"]
+    K1 = torch.tensor(np.asarray(P["K1"][:18], np.float32), device="cuda")[:, None]
+    assert relerr((K1 * (p - ig)).T.cpu().numpy(), rr.T.cpu().numpy()) < 1e-3
+    # torque map affine in vdot_des on a slice
+    m = 16384
+    sl = [a[..., :m].contiguous() for a in args]
+    taus = []
+    a1 = sl[3].clone()
+    a2 = torch.roll(a1, 1, dims=1)
+    for a in (a1 + a2, a1, a2, torch.zeros_like(a1)):
+        sl[3] = a
+        taus.append(solver.step(*sl, ig0[:, :m].clone(), torch.zeros_like(ig0[:, :m]))["tau"].double())
+    comb = taus[0] - taus[1] - taus[2] + taus[3]
+    assert comb.abs().max().item() < 2e-4 * taus[0].abs().max().item()
