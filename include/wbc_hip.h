@@ -107,12 +107,15 @@ typedef struct wbc_solver_options {
   int rollout_persistent; /* 1 (default): rollouts of at most fused_max states = one launch per rollout; 0: per-tick launches */
   int rollout_spw;        /* states per workgroup of the rollout kernel: 0 = auto (4 up to 1024 states, else 16), 4, 16 */
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
-                             kernel on a second stream beside the sweep; -1 = never (default) */
+                             kernel instead of inside the sweep; -1 = auto (fp32: from 98304 states on, fp64: never),
+                             -2 = never */
   int one_zerocopy;       /* 1: the single-robot host-pointer calls let the kernel read/write the pinned staging image directly */
   int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */
   int qp_tile;            /* GRF-QP kernel of the two-kernel tick: 0 = auto (tiles of 32 / 64 states dealt to the wavefronts by
                              predicted work from 12288 / 20480 states on, one-wavefront workgroups below), -1 = never tiles,
                              32 | 64 | 128 | 256 | 512 = always tiles of that many states */
+  int obs_split_serial;   /* that observer kernel runs 1 (default) = on the caller's stream before the sweep, 0 = beside it on a
+                             second stream (measured slower: the two compete for the same SIMDs) */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,

@@ -558,8 +558,8 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, obs, d
         assert relerr(a["tau"], ref["tau"]) < TIGHT64 and relerr(a["f"], ref["f"]) < TIGHT64
 
 
-@pytest.mark.parametrize("obs,dtype,n,tile,split", [(0, "f64", 1003, 64, -1), (1, "f64", 70001, 256, -1), (0, "f32", 5000, 128, -1),
-                                                   (2, "f64", 2051, 512, 1), (1, "f32", 66000, 256, 1), (0, "f64", 3, 256, -1)])
+@pytest.mark.parametrize("obs,dtype,n,tile,split", [(0, "f64", 1003, 64, -2), (1, "f64", 70001, 256, -2), (0, "f32", 5000, 128, -2),
+                                                   (2, "f64", 2051, 512, 1), (1, "f32", 66000, 256, 1), (0, "f64", 3, 256, -2)])
 def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtype, n, tile, split):
     """Large batches deal the QPs of a tile to the wavefronts by predicted work (qp_tile_kernel: predictor, LDS counting
     sort, groups pulled from a queue); the arithmetic per state is the same body, so tau, f, status and iteration counts
@@ -599,7 +599,7 @@ def test_separate_observer_kernel_matches(torch_cuda, gpu_model, oracle, obs, dt
     nd = _np_dtype(dtype)
     integ0 = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"].astype(nd)
     res = {}
-    for tag, split_min in (("split", 1), ("one_sweep", -1)):
+    for tag, split_min in (("split", 1), ("one_sweep", -2)):
         solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n, options={"fused_max": 0, "obs_split_min": split_min})
         res[tag] = _run_step(torch, solver, B, dtype, integ0.copy(), np.zeros((n, 18), nd), want_mats=True)
         res[tag + "_2"] = _run_step(torch, solver, B, dtype, res[tag]["integ"], res[tag]["r"], want_mats=True)

@@ -1,4 +1,6 @@
-"""Diagnostic: per-segment cycle shares of the QP kernel (needs the -DWBC_QP_STAMP build: WBC_LIB=.../libwbc_hip_stamp.so)."""
+"""Diagnostic: per-segment cycle shares of the QP kernel (needs the -DWBC_QP_STAMP build:
+   make -C wbc_quadruped_dob_amd/csrc -j8 LIBDIR=../lib_qstamp EXTRA=-DWBC_QP_STAMP; WBC_LIB=$PWD/wbc_quadruped_dob_amd/lib_qstamp/libwbc_hip.so python tools/qp_stamp.py).
+The stamps come from the one-wavefront-workgroup kernel (two-kernel tick, no tiles)."""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import wbc_quadruped_dob_amd as W
@@ -6,7 +8,7 @@ from wbc_quadruped_dob_amd import synth
 m = W.Model.from_urdf(W.SYNTHETIC_URDF)
 names = ["setup", "np,d,dn2", "z", "backsub", "steplen+commit", "add", "drop", "pick"]
 for n in (4096, 262144):
-    P = synth.default_params(); s = W.Solver(m, W.Params.from_dict(P), max_batch=n)
+    P = synth.default_params(); s = W.Solver(m, W.Params.from_dict(P), max_batch=n, options={"fused_max": 0, "qp_tile": -1})
     B = synth.make_batch(2, n, m.total_mass)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda()
     inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")}
@@ -17,4 +19,5 @@ for n in (4096, 262144):
     it = out["iters"].cpu().numpy().astype(np.int64).reshape(-1, 4)
     vals = np.stack([it[:, g] & 0xFFFF if h == 0 else (it[:, g] >> 16) & 0x7FFF for g in range(4) for h in range(2)], 1) * 16
     tot = vals.sum(1)
+    real = (vals[:, 0] > 0)
     print("N", n, "mean cycles per wave:", {k: int(v) for k, v in zip(names, vals.mean(0))}, "total", int(tot.mean()))
