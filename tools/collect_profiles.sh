@@ -6,7 +6,15 @@ for f in bench_cfg2_n262144 bench_cfg2_n4096 bench_cfg2_n4096_nomats bench_cfg3_
          bench_cfg5_h20_n128 bench_cfg5_h20_n32768 bench_cfg5_tracking_h20_n1024 bench_under_rocprof_n262144 bench_under_rocprof_n4096 bench_torchrun_1rank; do
   cp "$O/$f.json" "$P/${T}_$f.json"
 done
-for f in abi_smoke bw_probe fma_probe pytest_gpu; do cp "$O/$f.log" "$P/${T}_$f.log"; done
+for f in abi_smoke bw_probe fma_probe pytest_gpu mfma_probe; do cp "$O/$f.log" "$P/${T}_$f.log"; done
+for f in bench_cfg3_n262144 bench_cfg4_f32_n262144 bench_cfg2_n32768 bench_single_process_2shards bench_under_rocprof_n32768 bench_under_rocprof_cfg4_n32768 sq_counters_n262144 sq_counters_n4096; do
+  [ -f "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
+done
+[ -f "$O/bench_gpus2_bare.err" ] && cp "$O/bench_gpus2_bare.err" "$P/${T}_bench_gpus2_bare.log"
+[ -f "$O/n_sweep.csv" ] && cp "$O/n_sweep.csv" "$P/${T}_n_sweep.csv"
+[ -f "$O/qp_segments.txt" ] && cp "$O/qp_segments.txt" "$P/${T}_qp_segments.txt"
+[ -f "$O/stats_n32768_kernel_stats.csv" ] && cp "$O/stats_n32768_kernel_stats.csv" "$P/${T}_kernel_stats_cfg2_n32768.csv"
+[ -f "$O/stats_cfg4_n32768_kernel_stats.csv" ] && cp "$O/stats_cfg4_n32768_kernel_stats.csv" "$P/${T}_kernel_stats_cfg4_f32_n32768.csv"
 [ -f "$O/fused_timeline.txt" ] && cp "$O/fused_timeline.txt" "$P/${T}_fused_timeline.txt"
 cp "$O/pmc_summary.json" "$P/${T}_pmc_summary.json"; cp "$O/pmc_summary.json" "$P/pmc_latest.json"
 cp "$O/stats_n4096_kernel_stats.csv" "$P/${T}_kernel_stats_cfg2_n4096.csv"

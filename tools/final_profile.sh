@@ -19,21 +19,35 @@ python bench.py --config 5 --steps 100 --warmup 10 --batch 128 > "$O/bench_cfg5_
 python bench.py --config 5 --tracking --steps 100 --warmup 10 > "$O/bench_cfg5_tracking_h20_n1024.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 20 --warmup 3 --batch 32768 > "$O/bench_cfg5_h20_n32768.json" 2>> "$O/bench.err"
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu --no-latency --large-batch 0 > "$O/bench_torchrun_1rank.json" 2>> "$O/bench.err"
-# role timeline of the fused tick (diagnostic build, made beforehand: hipcc ... -DWBC_FUSED_STAMP -o lib/libwbc_hip_fstamp.so)
-if [ -f wbc_quadruped_dob_amd/lib/libwbc_hip_fstamp.so ]; then
-  WBC_LIB=$R/wbc_quadruped_dob_amd/lib/libwbc_hip_fstamp.so python tools/fused_stamp.py > "$O/fused_timeline.txt" 2>> "$O/bench.err"
+python bench.py --steps 50 --warmup 5 --batch 262144 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n262144.json" 2>> "$O/bench.err"
+python bench.py --steps 50 --warmup 5 --batch 262144 --config 4 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n262144.json" 2>> "$O/bench.err"
+python bench.py --steps 100 --warmup 10 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n32768.json" 2>> "$O/bench.err"
+python bench.py --gpus 2 --steps 20 --warmup 5 > "$O/bench_gpus2_bare.json" 2> "$O/bench_gpus2_bare.err"; echo "exit $?" >> "$O/bench_gpus2_bare.err"
+python bench.py --gpus 2 --single-process --steps 100 --warmup 10 > "$O/bench_single_process_2shards.json" 2>> "$O/bench.err"
+./tools/mfma_probe.bin > "$O/mfma_probe.log" 2>&1
+bash tools/n_sweep.sh 2>/dev/null > "$O/n_sweep.csv"
+# role timeline of the fused tick (diagnostic build, made beforehand: make -C wbc_quadruped_dob_amd/csrc -j8 LIBDIR=../lib_fstamp EXTRA=-DWBC_FUSED_STAMP)
+if [ -f wbc_quadruped_dob_amd/lib_fstamp/libwbc_hip.so ]; then
+  WBC_LIB=$R/wbc_quadruped_dob_amd/lib_fstamp/libwbc_hip.so python tools/fused_stamp.py > "$O/fused_timeline.txt" 2>> "$O/bench.err"
+fi
+if [ -f wbc_quadruped_dob_amd/lib_qstamp/libwbc_hip.so ]; then
+  WBC_LIB=$R/wbc_quadruped_dob_amd/lib_qstamp/libwbc_hip.so python tools/qp_stamp.py > "$O/qp_segments.txt" 2>> "$O/bench.err"
 fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- python3 "$R/bench.py" --config 5 --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5trk -- python3 "$R/bench.py" --config 5 --tracking --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n32768 -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch 32768 > "$O/bench_under_rocprof_n32768.json" 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg4_n32768 -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch 32768 --config 4 > "$O/bench_under_rocprof_cfg4_n32768.json" 2>> "$O/rocprof.err"
 # the default bench command itself (incl. its N = 262 144 characterisation legs: tick sweep and the dynamics stage alone)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_default -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency > "$O/bench_under_rocprof_default.json" 2>> "$O/rocprof.err"
 find "$O" -name "*kernel_trace.csv" -delete
 cd "$R"
 bash tools/pmc_profile.sh > "$O/pmc.log" 2>&1
 cp gpurun_out/pmc/summary.json "$O/pmc_summary.json"
+bash tools/sq_profile.sh 262144 sq_n262144 "1 2 3" > "$O/sq_n262144.log" 2>&1; cp gpurun_out/sq_n262144/summary.json "$O/sq_counters_n262144.json"
+bash tools/sq_profile.sh 4096 sq_n4096 "1 2 3" > "$O/sq_n4096.log" 2>&1; cp gpurun_out/sq_n4096/summary.json "$O/sq_counters_n4096.json"
 cat "$O/pytest_gpu.log" "$O/smoke.log" "$O/abi_smoke.log" "$O/fma_probe.log"
 for f in "$O"/bench_cfg[234]_n*[0-9].json; do echo "== $f"; python3 -c "
 import json,sys

@@ -25,13 +25,9 @@ gm = W.Model.from_urdf(W.SYNTHETIC_URDF)
 orc = oracle_py.Oracle(urdf_model.load_urdf(W.SYNTHETIC_URDF))
 
 
-def solver_with(env, **kw):
-    for k, v in env.items():
-        os.environ[k] = v
-    s = _solver(gm, **kw)
-    for k in env:
-        del os.environ[k]
-    return s
+def solver_with(options, **kw):
+    """options: wbc_solver_options overrides of this variant"""
+    return _solver(gm, options=options, **kw)
 
 
 bad, worst, t0 = [], 0.0, time.time()
@@ -46,7 +42,7 @@ for c in range(cases):
     z = lambda: (None if integ0 is None else integ0.copy(), None if integ0 is None else np.zeros((n, 18)))
     if c % 3 != 2 or DT == "f32":   # ---- one tick: fused vs two-kernel, two consecutive ticks (observer state carried)
         res = {}
-        for tag, env in (("fused", {}), ("two", {"WBC_FUSED_MAX": "0"})):
+        for tag, env in (("fused", {}), ("two", {"fused_max": 0})):
             s, P = solver_with(env, obs=obs, max_batch=n, dtype=DT)
             zz = tuple(None if t is None else t.astype(np.float32 if DT == "f32" else np.float64) for t in z())
             a1 = _run_step(torch, s, B, DT, *zz, want_mats=bool(c % 2))
@@ -88,7 +84,7 @@ for c in range(cases):
         H = int(rng.integers(2, 12))
         tau_ext = np.zeros((n, 18)); tau_ext[:, 0:3] = B["push"] if cfg > 2 else 5.0
         res = {}
-        for tag, env in (("persistent", {}), ("per_tick", {"WBC_ROLLOUT_PERSISTENT": "0"})):
+        for tag, env in (("persistent", {}), ("per_tick", {"rollout_persistent": 0})):
             s, P = solver_with(env, obs=obs, max_batch=n)
             res[tag] = _gpu_rollout(torch, s, P, H, B, tau_ext, None if integ0 is None else integ0.copy(), np.zeros((n, 18)) if obs else None)
         a, b = res["persistent"], res["per_tick"]
