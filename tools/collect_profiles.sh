@@ -22,6 +22,6 @@ cp "$O/stats_n262144_kernel_stats.csv" "$P/${T}_kernel_stats_cfg2_n262144.csv"
 cp "$O/stats_cfg5_kernel_stats.csv" "$P/${T}_kernel_stats_cfg5_h20_n1024.csv"
 cp "$O/stats_cfg5trk_kernel_stats.csv" "$P/${T}_kernel_stats_cfg5_tracking_h20_n1024.csv"
 [ -f "$O/stats_default_kernel_stats.csv" ] && cp "$O/stats_default_kernel_stats.csv" "$P/${T}_kernel_stats_default_bench.csv" && cp "$O/bench_under_rocprof_default.json" "$P/${T}_bench_under_rocprof_default.json"
-for f in "$O"/bench_*.json; do python3 -c "
+for f in "$O"/bench_*.json; do [ -s "$f" ] && python3 -c "
 import json,sys; r=json.load(open('$f')); print('%-46s ms/step %.5f  value %.4e' % ('$(basename $f)', r['ms_per_step'], r['value']))"; done
 grep -h "wbc::" "$P/${T}_kernel_stats_default_bench.csv" "$P/${T}_kernel_stats_cfg2_n4096.csv" "$P/${T}_kernel_stats_cfg2_n262144.csv" "$P/${T}_kernel_stats_cfg5_h20_n1024.csv" | awk -F'",' '{split($1,a,"("); print a[1], $2}' | cut -c1-140
