@@ -37,10 +37,31 @@ for c in range(cases):
     n = int(rng.choice([1, 7, 16, 17, 100, 1000, 2048, 4096, 5000, 8192][: (10 if obs == 0 else 8)]))
     if rng.random() < 0.3:
         n = int(rng.integers(1, 4097))
+    big = DT == "f64" and c % 7 == 3   # a larger batch: the tiled QP kernel (dealt by predicted work) against the one-wave kernel
+    if big:
+        n = int(rng.integers(12288, 60000))
     B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
     integ0 = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
     z = lambda: (None if integ0 is None else integ0.copy(), None if integ0 is None else np.zeros((n, 18)))
-    if c % 3 != 2 or DT == "f32":   # ---- one tick: fused vs two-kernel, two consecutive ticks (observer state carried)
+    if big:
+        res = {}
+        for tag, opt in (("tiled", {"qp_tile": int(rng.choice([0, 32, 64, 128]))}), ("plain", {"qp_tile": -1})):
+            s, P = solver_with(opt, obs=obs, max_batch=n)
+            a1 = _run_step(torch, s, B, "f64", *z(), want_mats=bool(c % 2))
+            a2 = _run_step(torch, s, B, "f64", a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
+            res[tag] = (a1, a2)
+        for i in (0, 1):
+            for k in res["plain"][i]:
+                if not np.array_equal(res["tiled"][i][k], res["plain"][i][k]):
+                    bad.append((c, "tiled " + k, n, obs, cfg))
+        if c % 2:
+            ig, r = z()
+            ref = orc.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"], ig, r, nthreads=8)
+            e = max(relerr(res["tiled"][0]["tau"], ref["tau"]), relerr(res["tiled"][0]["f"], ref["f"]))
+            worst = max(worst, e)
+            if not e < 1e-9 or not np.array_equal(res["tiled"][0]["status"], ref["status"]):
+                bad.append((c, "oracle (tiled)", n, obs, cfg, e))
+    elif c % 3 != 2 or DT == "f32":   # ---- one tick: fused vs two-kernel, two consecutive ticks (observer state carried)
         res = {}
         for tag, env in (("fused", {}), ("two", {"fused_max": 0})):
             s, P = solver_with(env, obs=obs, max_batch=n, dtype=DT)
