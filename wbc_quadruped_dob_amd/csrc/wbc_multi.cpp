@@ -82,6 +82,7 @@ struct wbc_multi {
   size_t max_total = 0;
   int backend = WBC_GATHER_NONE;
   int rccl_ranks = 0;
+  int observer_order = 0;
   Rccl rccl;
   std::vector<Shard> sh;
   size_t ts() const { return dtype == WBC_F64 ? 8 : 4; }
@@ -126,7 +127,7 @@ extern "C" int wbc_multi_create(const wbc_model* m, const wbc_params* p, int dty
           return fail(WBC_E_INVALID, "RCCL needs distinct devices (one rank per GPU); use WBC_GATHER_PEER_COPY for shards that share a device");
   wbc_multi* mm = new (std::nothrow) wbc_multi;
   if (!mm) return fail(WBC_E_INVALID, "out of memory");
-  mm->dtype = dtype; mm->max_total = max_batch_total; mm->backend = gather_backend;
+  mm->dtype = dtype; mm->max_total = max_batch_total; mm->backend = gather_backend; mm->observer_order = p->observer_order;
   int rc = wbc_model_dims(m, nullptr, &mm->nq, &mm->nv, &mm->nj, &mm->nf);
   if (rc) { delete mm; return rc; }
   mm->sh.resize((size_t)n_devices);
@@ -186,6 +187,7 @@ extern "C" int wbc_multi_device(const wbc_multi* mm, int shard) {
 extern "C" int wbc_multi_set_params(wbc_multi* mm, const wbc_params* p) {
   if (!mm) return fail(WBC_E_INVALID, "null argument");
   for (Shard& s : mm->sh) { int rc = wbc_solver_set_params(s.solver, p); if (rc) return rc; }
+  mm->observer_order = p->observer_order;
   return WBC_OK;
 }
 
@@ -304,6 +306,7 @@ extern "C" int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batc
   if (hout->M || hout->h || hout->Jc || hout->pf) return fail(WBC_E_INVALID, "the host-batch call returns tau, f, status, iters only");
   if (mm->nq != 19 || mm->nv != 18 || mm->nj != 12 || mm->nf != 4) return fail(WBC_E_TOPOLOGY, "unexpected model dimensions");
   const bool ob = hobs && hobs->integ && hobs->r;
+  if (mm->observer_order > 0 && !ob) return fail(WBC_E_INVALID, "observer on: host observer state (integ, r) required");
   if (ob && (!hin->tau_prev || !hin->f_prev)) return fail(WBC_E_INVALID, "observer state given without tau_prev / f_prev");
   const int n = (int)mm->sh.size();
   const size_t ts = mm->ts();
