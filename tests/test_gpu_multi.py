@@ -177,6 +177,9 @@ def test_multi_step_host_numpy_batch(torch_cuda, gpu_model, oracle):
     assert np.array_equal(out["status"], ref["status"])
     assert relerr(out["tau"].T, ref["tau"]) < 1e-9 and relerr(out["f"].T, ref["f"]) < 1e-9
     assert relerr(ig.T, ig_ref) < 1e-9 and relerr(rr.T, r_ref) < 1e-9
+    with pytest.raises(W.WbcError):   # observer on but no host observer state: refused, never run on stale device scratch
+        ms.step_host(cm(B["q"]), cm(B["v"]), cm(B["w_des"]), cm(B["vdot_des"]), cm(B["normals"]), cm(B["mu"]), B["mask"],
+                     cm(B["tau_prev"]), cm(B["f_prev"]))
     with pytest.raises(W.WbcError):   # capacity is checked
         big = np.zeros((19, n + 1))
         ms.step_host(big, np.zeros((18, n + 1)), np.zeros((6, n + 1)), np.zeros((18, n + 1)), np.zeros((12, n + 1)),
