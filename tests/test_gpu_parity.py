@@ -700,11 +700,11 @@ def test_tick_is_graph_capturable(torch_cuda, gpu_model, mode):
             assert torch.equal(want[k], got[k]), (mode, k)
 
 
-def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle):
+@pytest.mark.parametrize("n", [512, 20992])   # the fused tick; the two-kernel tick with the tiled QP kernel (predictor + LDS sort)
+def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle, n):
     """Quaternions and terrain normals are normalised inside (as in the oracle); a NaN in one state's inputs must not
     hang the kernels nor disturb any other state."""
     torch = torch_cuda
-    n = 512
     solver, P = _solver(gpu_model, max_batch=n)
     B = synth.make_batch(4, n, gpu_model.total_mass, rank=51)
     ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
@@ -714,8 +714,9 @@ def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle):
     got = _run_step(torch, solver, B2, "f64")
     assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
     B3 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}
-    bad = [5, 130, 131, 400]
+    bad = [5, 130, 131, 400, n - 1]
     B3["w_des"][bad[0], 2] = np.nan
+    B3["w_des"][bad[4], 0] = np.inf
     B3["q"][bad[1], 9] = np.nan
     B3["normals"][bad[2], 4] = np.inf
     B3["mu"][bad[3], 1] = np.nan

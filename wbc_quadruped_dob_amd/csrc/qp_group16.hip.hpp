@@ -749,8 +749,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned
   // fitted on the bench data (least squares on the iteration count): 0.52 count + 0.70 ln(1 + summed violation); three
   // buckets per predicted iteration.  Sorting by it: 2.96 trips per group (count alone 3.25, perfect knowledge 2.51).
   const float kf = 1.56f * (float)cnt_all + 2.1f * __logf(1.0f + (float)mag);
-  const int key = (int)kf;
-  return key > 61 ? 61 : key;   // 0 ... 61
+  return (kf > 0.0f) ? (int)fminf(kf, 61.0f) : 0;   // 0 ... 61; a NaN / Inf state (garbage in) sorts as "no work", never out of range
 }
 
 #ifndef WBC_QP_TILE_WAVES
