@@ -201,6 +201,7 @@ def main():
         fused = tm.get("fused_launches", 0) > 0   # small batches: sweep + QP run as ONE kernel (fused_tick_kernel)
         dyn_s = (tm["fused_ms"] * 1e-3 / tm["fused_launches"]) if fused else tm["dyn_ms"] * 1e-3 / max(1, tm["dyn_launches"])
         qp_s = tm["qp_ms"] * 1e-3 / max(1, tm["qp_launches"])
+        qpl_s = tm.get("qp_lane_ms", 0.0) * 1e-3 / max(1, tm.get("qp_lane_launches", 0))
         rnea_s = tm["rnea_ms"] * 1e-3 / max(1, tm["rnea_launches"])
         # algorithmic words per state of the timed launch: the dynamics stage alone is 443 (in q 19 + v 18,
         # out M 171 + h 18 + Jc 216, + 1); the fused tick launch does the WHOLE tick: in 78 (q, v, w_des, vdot_des, normals,
@@ -245,6 +246,7 @@ def main():
             "kernels": {"dyn_sweep_us": None if fused else dyn_s * 1e6, "fused_tick_us": dyn_s * 1e6 if fused else None,
                         "rnea_step_us": rnea_s * 1e6 if tm["rnea_launches"] else None,
                         "qp_us": None if fused else qp_s * 1e6,
+                        "qp_lane_us": (qpl_s * 1e6) if tm.get("qp_lane_launches", 0) else None,
                         "qp_us_per_state_amortized": None if fused else qp_s * 1e6 / n,
                         "qp_kernel": os.environ.get("WBC_QP_KERNEL", "group16"),
                         "sweep": ("one launch: rnea_step | mass_jac | qp_group16 as wavefront roles (fused_tick_kernel)" if fused

@@ -116,11 +116,17 @@ typedef struct wbc_solver_options {
                              32 | 64 | 128 | 256 | 512 = always tiles of that many states */
   int obs_split_serial;   /* that observer kernel runs 1 (default) = on the caller's stream before the sweep, 0 = beside it on a
                              second stream (measured slower: the two compete for the same SIMDs) */
+  int qp_lane;            /* two-kernel ticks solve the QPs one state per LANE first (semismooth Newton on the residual wrench)
+                             and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches from
+                             131072 states on), 1 = always, -1 = never.  States solved per lane report status 0 and
+                             iters = Newton iterations (<= 3); the others the dense kernel's status / iteration count */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
                          const wbc_solver_options* opt /* NULL = defaults */, wbc_solver** out);
 int wbc_solver_device(const wbc_solver* s); /* HIP device index, -1 for NULL */
+/* diagnostics (synchronises the device): states of the last two-kernel tick that the per-lane QP kernel handed to the dense one */
+int wbc_solver_qp_handover(wbc_solver* s, int* count);
 void wbc_solver_destroy(wbc_solver* s);
 int wbc_solver_set_params(wbc_solver* s, const wbc_params* p);
 
@@ -237,10 +243,12 @@ int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const
  * 4096 event pairs once; samples beyond it are dropped until wbc_solver_collect_timing drains the ring, so a tick never
  * allocates.  While timing is on, the instrumented dispatches are not hipGraph-capturable. ---- */
 int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 every kernel launch; k > 1: every k-th tick */
+#define WBC_TIMING_KINDS 5
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed
  * 0 = dyn_sweep kernel, 1 = QP kernel, 2 = rnea_step kernel (no-M/h/Jc ticks) / stand-alone observer kernel,
- * 3 = fused tick kernel (sweep + QP of small batches in one launch); resets the accumulators. */
-int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launches[4]);
+ * 3 = fused tick kernel (sweep + QP of small batches in one launch), 4 = per-lane QP kernel (then 1 = the dense kernel's
+ * pass over the states the per-lane kernel handed over); resets the accumulators. */
+int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KINDS], int launches[WBC_TIMING_KINDS]);
 
 /* ---- multi-device: ONE host process, one solver per GPU of the node.  The reference is a single C++
  * process (/root/reference/README.md:58-60); this is how that process shards a batch over the node without Python.

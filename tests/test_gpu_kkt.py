@@ -25,11 +25,11 @@ def torch_cuda():
     return torch
 
 
-def _solver(gpu_model, dtype, obs, n, **kw):
+def _solver(gpu_model, dtype, obs, n, options=None, **kw):
     import wbc_quadruped_dob_amd as W
     P = synth.default_params(observer_order=obs, dtype=dtype)
     P.update(kw)
-    return W.Solver(gpu_model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n, options={}), P
+    return W.Solver(gpu_model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n, options=options or {}), P
 
 
 def _tangents(torch, nrm):
@@ -87,10 +87,12 @@ def kkt_residuals(torch, P, q, pf, w_des, rhat_base, normals, mu, mask, f, act_t
     return stat.abs().amax(dim=(1, 2)) / scale, torch.maximum(viol, swing), comp / scale
 
 
-@pytest.mark.parametrize("dtype,obs,n", [("f64", 0, 131072), ("f64", 1, 20000), ("f32", 1, 32768)])
-def test_kkt_residuals_of_the_gpu_solution(torch_cuda, gpu_model, dtype, obs, n):
+@pytest.mark.parametrize("dtype,obs,n,lane", [("f64", 0, 131072, 0), ("f64", 1, 20000, -1), ("f64", 1, 20000, 1), ("f32", 1, 32768, 0)])
+def test_kkt_residuals_of_the_gpu_solution(torch_cuda, gpu_model, dtype, obs, n, lane):
+    """(131 072 fp64 states take the default dispatch = per-lane QP kernel + dense kernel over its hand-over list; 20 000
+    states are run through the dense kernel alone and through the forced per-lane path)"""
     torch = torch_cuda
-    solver, P = _solver(gpu_model, dtype, obs, n)
+    solver, P = _solver(gpu_model, dtype, obs, n, options={"qp_lane": lane})
     B = synth.make_batch(4, n, gpu_model.total_mass, rank=61)
     rng = np.random.default_rng(5)
     B["w_des"][:, 0:2] += rng.uniform(-120, 120, (n, 2))      # strong lateral demands: many active friction rows

@@ -588,6 +588,46 @@ def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtyp
     assert res["plain"]["iters"].max() >= (3 if n > 100 else 0)
 
 
+@pytest.mark.parametrize("cfg,obs,dtype,n,mats,split", [(2, 0, "f64", 20001, True, -2), (3, 1, "f64", 16500, True, -2), (4, 2, "f64", 30000, False, -2),
+                                                       (4, 1, "f64", 9000, True, 1), (4, 1, "f32", 20000, True, -2), (3, 0, "f64", 5, True, -2)])
+def test_per_lane_qp_kernel_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, dtype, n, mats, split):
+    """qp_lane_kernel (one state per lane: semismooth Newton on the 6-dimensional residual wrench, line search, states it
+    does not finish handed to the dense active-set kernel through a device-side list) is a different ALGORITHM from the
+    oracle's Goldfarb-Idnani and must land on the same unique solution: status equal, tau / f within the fp64 gate, with and
+    without M/h/Jc outputs (geometry from Jc or from the workspace), with rhat arriving through the workspace, ragged sizes.
+    Also pins that the hand-over stays a small fraction and that the dense path agrees with it."""
+    torch = torch_cuda
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=63)
+    B["w_des"][: n // 2, 0:2] += np.random.default_rng(9).uniform(-100, 100, (n // 2, 2))    # half of the batch with strong lateral demands
+    nd = _np_dtype(dtype)
+    c = lambda a: np.ascontiguousarray(a, nd)
+    P0 = synth.default_params(observer_order=obs, dtype=dtype)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    r = 0.05 * np.cos(np.arange(n * 18).reshape(n, 18)) if obs else None
+    ig_ref = None if integ is None else c(integ).copy()
+    r_ref = None if r is None else c(r).copy()
+    ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], c(B["tau_prev"]),
+                      c(B["f_prev"]), ig_ref, r_ref, nthreads=8)
+    res = {}
+    for tag, lane in (("lane", 1), ("dense", -1)):
+        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n, options={"fused_max": 0, "qp_lane": lane, "obs_split_min": split})
+        res[tag] = _run_step(torch, solver, B, dtype, None if integ is None else c(integ).copy(), None if r is None else c(r).copy(), want_mats=mats)
+        if lane == 1:
+            handed = solver.qp_handover()
+    a, b = res["lane"], res["dense"]
+    assert handed <= max(4, 0.25 * n), handed
+    tol = TIGHT64 if dtype == "f64" else 1e-3
+    if dtype == "f64":
+        assert np.array_equal(a["status"], ref["status"]) and np.array_equal(a["status"], b["status"])
+    ok = (a["status"] == 0) & (ref["status"] == 0) & (b["status"] == 0)
+    assert ok.mean() > 0.995
+    assert relerr(a["tau"][ok], ref["tau"][ok]) < tol and relerr(a["f"][ok], ref["f"][ok]) < tol
+    assert relerr(a["tau"][ok], b["tau"][ok]) < tol and relerr(a["f"][ok], b["f"][ok]) < tol
+    if obs:
+        assert np.array_equal(a["integ"], b["integ"]) and np.array_equal(a["r"], b["r"])     # the front half is the same kernel
+    assert a["iters"].max() <= P["max_iter"]
+
+
 @pytest.mark.parametrize("obs,dtype,n", [(1, "f64", 3001), (2, "f64", 130), (1, "f32", 2048), (1, "f64", 70000)])
 def test_separate_observer_kernel_matches(torch_cuda, gpu_model, oracle, obs, dtype, n):
     """Large observer-on batches run {observer kernel on the second stream || dyn_sweep without the observer} -> QP that
@@ -641,15 +681,17 @@ def test_prepared_tick_equals_step(torch_cuda, gpu_model):
     assert torch.equal(r_a, r_b) and torch.equal(a["tau"], b["tau"])
 
 
-@pytest.mark.parametrize("mode", ["fused", "two_kernel", "no_mats", "obs_split", "rollout"])
+@pytest.mark.parametrize("mode", ["fused", "two_kernel", "no_mats", "obs_split", "lane", "rollout"])
 def test_tick_is_graph_capturable(torch_cuda, gpu_model, mode):
     """Every dispatch variant of the tick (and a persistent rollout) can be captured into a hipGraph: no allocation, no
     synchronisation, no host read inside the C call.  Replaying the graph must reproduce the eager results bit for bit."""
     torch = torch_cuda
     n = 1000
     opt = {}
-    if mode in ("two_kernel", "obs_split"):
+    if mode in ("two_kernel", "obs_split", "lane"):
         opt["fused_max"] = 0
+    if mode == "lane":
+        opt["qp_lane"] = 1     # memset of the hand-over counter + per-lane kernel + dense kernel over the list
     if mode == "obs_split":
         opt["obs_split_min"] = 1
     solver, P = _solver(gpu_model, obs=1, max_batch=n, options=opt)
@@ -700,12 +742,12 @@ def test_tick_is_graph_capturable(torch_cuda, gpu_model, mode):
             assert torch.equal(want[k], got[k]), (mode, k)
 
 
-@pytest.mark.parametrize("n", [512, 20992])   # the fused tick; the two-kernel tick with the tiled QP kernel (predictor + LDS sort)
-def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle, n):
+@pytest.mark.parametrize("n,lane", [(512, 0), (20992, 0), (20992, 1)])   # the fused tick; the two-kernel tick with the tiled QP kernel (predictor
+def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle, n, lane):   # + LDS sort); with the per-lane QP kernel in front
     """Quaternions and terrain normals are normalised inside (as in the oracle); a NaN in one state's inputs must not
     hang the kernels nor disturb any other state."""
     torch = torch_cuda
-    solver, P = _solver(gpu_model, max_batch=n)
+    solver, P = _solver(gpu_model, max_batch=n, options={"qp_lane": lane})
     B = synth.make_batch(4, n, gpu_model.total_mass, rank=51)
     ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
     B2 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}

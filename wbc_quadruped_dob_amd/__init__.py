@@ -97,10 +97,10 @@ class SolverOptions(C.Structure):
     the environment; Solver(options=None) builds them from the defaults overridden by the WBC_* variables below -- a
     convenience of THIS binding for the A/B scripts under tools/ and bench.py."""
     _fields_ = [("struct_size", C.c_size_t), ("fused_max", C.c_longlong), ("rollout_persistent", C.c_int),
-                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int)]
+                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int)]
     ENV = {"WBC_FUSED_MAX": ("fused_max", int), "WBC_ROLLOUT_PERSISTENT": ("rollout_persistent", int),
            "WBC_ROLLOUT_SPW": ("rollout_spw", int), "WBC_OBS_SPLIT_MIN": ("obs_split_min", int),
-           "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int),
+           "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int), "WBC_QP_LANE": ("qp_lane", int),
            "WBC_TIMING": ("timing_mode", lambda v: 1 if v == "pair" else 0)}
 
     @staticmethod
@@ -470,15 +470,21 @@ class Solver:
                "wbc_compute_reference")
         return w, vd, com
 
+    def qp_handover(self):
+        """states of the last two-kernel tick that the per-lane QP kernel handed to the dense active-set kernel (synchronises)"""
+        c = C.c_int(0)
+        _check(lib().wbc_solver_qp_handover(self._h, C.byref(c)), "wbc_solver_qp_handover")
+        return c.value
+
     def enable_timing(self, on=1):
         """0 = off, 1 = HIP events around every kernel, k > 1 = around the kernels of every k-th tick."""
         _check(lib().wbc_solver_enable_timing(self._h, int(on)), "wbc_solver_enable_timing")
 
     def collect_timing(self):
-        ms = (C.c_double * 4)()
-        cnt = (C.c_int * 4)()
+        ms = (C.c_double * 5)()
+        cnt = (C.c_int * 5)()
         _check(lib().wbc_solver_collect_timing(self._h, ms, cnt), "wbc_solver_collect_timing")
-        names = ("dyn", "qp", "rnea", "fused")  # fused = one-kernel tick of small batches; dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
+        names = ("dyn", "qp", "rnea", "fused", "qp_lane")  # fused = one-kernel tick of small batches; dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
         out = {}
         for i, n in enumerate(names):
             out[n + "_ms"] = ms[i]

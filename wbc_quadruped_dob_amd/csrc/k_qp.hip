@@ -1,6 +1,7 @@
 // qp_group16_kernel launches: GRF QP + torque map (units a7-a9; qp_group16.hip.hpp).
 #include "k_common.hip.hpp"
 #include "qp_group16.hip.hpp"
+#include "qp_lane.hip.hpp"
 
 namespace wbc {
 
@@ -14,8 +15,14 @@ static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar
 }
 
 template <>
-hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
+hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* list) {
   using T = Scalar;
+  if (list) {   // the hand-over list of the per-lane kernel: one wavefront per four listed states, grid-stride
+    const dim3 grid((unsigned)((a.N + 31) / 32));
+    if (rhat) WBC_KLAUNCH(L, (qp_list_kernel<T, true>), grid, dim3(64), prm, a, jmap, list);
+    else WBC_KLAUNCH(L, (qp_list_kernel<T, false>), grid, dim3(64), prm, a, jmap, list);
+    return hipGetLastError();
+  }
   if (tile == 32) return qp_tiled<32>(L, rhat, prm, a, jmap);
   if (tile == 64) return qp_tiled<64>(L, rhat, prm, a, jmap);
   if (tile == 128) return qp_tiled<128>(L, rhat, prm, a, jmap);
@@ -24,6 +31,16 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
   const dim3 grid((unsigned)((a.N + 3) / 4));   // one wavefront (four QPs) per workgroup
   if (rhat) WBC_KLAUNCH(L, (qp_group16_kernel<T, true>), grid, dim3(64), prm, a, jmap);
   else WBC_KLAUNCH(L, (qp_group16_kernel<T, false>), grid, dim3(64), prm, a, jmap);
+  return hipGetLastError();
+}
+
+template <>
+hipError_t k_qp_lane<Scalar>(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* todo) {
+  using T = Scalar;
+  hipLaunchKernelGGL((qp_list_reset_kernel<T>), dim3(1), dim3(1), 0, L.st, todo);
+  const dim3 grid((unsigned)((a.N + 255) / 256));   // one state per lane
+  if (rhat) WBC_KLAUNCH(L, (qp_lane_kernel<T, true>), grid, dim3(256), prm, a, jmap, todo);
+  else WBC_KLAUNCH(L, (qp_lane_kernel<T, false>), grid, dim3(256), prm, a, jmap, todo);
   return hipGetLastError();
 }
 

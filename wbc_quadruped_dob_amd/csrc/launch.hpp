@@ -23,7 +23,12 @@ template <class T> hipError_t k_observer(const LaunchCtx& L, const DevModel<T>* 
 // GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran).
 // tile = 0: qp_group16_kernel, one wavefront per workgroup, four consecutive states per wavefront;
 // tile = 64 | 128 | 256 | 512: qp_tile_kernel, workgroups of four wavefronts deal a tile of that many states by predicted work
-template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, int tile, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap);
+// list (optional): solve the states list[4 .. 4 + list[0]) instead of the whole batch (qp_list_kernel, which also resets the list)
+template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, int tile, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap,
+                                  int* list = nullptr);
+// qp_lane_kernel<T, RHAT>: the GRF QP one state per LANE (semismooth Newton on the 6-dimensional residual wrench); states it
+// does not finish are appended to todo (todo[0] = count, todo[4 ...] = indices) for k_qp(..., list = todo), which empties it again
+template <class T> hipError_t k_qp_lane(const LaunchCtx& L, bool rhat, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int* todo);
 // fused_tick_kernel<T, OBSERVER, MATS>: the whole tick of a small batch as one launch
 template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bool mats, const DevModel<T>* model, const DevParams<T>& prm,
                                           const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);

@@ -161,11 +161,11 @@ WBC_DEV void qp_wait(int* flag, int need) {
 // TILED (qp_tile_kernel below): the four rows of the wavefront solve the states `who` names (dealt by predicted work)
 // instead of four consecutive ones; the workgroup is four such wavefronts.
 struct QpWho { size_t state; bool live; };
-template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false>
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1>
 WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
                              const QpWho who = QpWho{0, false}) {
   static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
-  constexpr int WPB = (WSLDS || TILED) ? 4 : 1;   // the fused kernels pair their producer wavefronts with four QP wavefronts
+  // WPB: wavefronts of the workgroup that run this body (the fused kernels pair their producer wavefronts with four QP wavefronts)
   __shared__ G16Lds<T> lds_all[WPB];
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
@@ -763,12 +763,12 @@ __global__ __launch_bounds__(256, WBC_QP_TILE_WAVES) void qp_tile_kernel(DevPara
   __shared__ int next_grp;
   const unsigned tid = threadIdx.x;
   const size_t N = a.N;
-  const unsigned N32 = (unsigned)N;
+  const unsigned N32 = (unsigned)a.N;
   const size_t base = (size_t)blockIdx.x * TILE;
   if (tid < 64) hist[tid] = 0;
   if (tid == 0) next_grp = 0;
   __syncthreads();
-  // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = beyond the end of the batch (dealt last, not solved)
+  // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = beyond the end (dealt last, not solved)
   int bucket[(TILE + 255) / 256], rank[(TILE + 255) / 256];
 #pragma unroll
   for (int r = 0; r < (TILE + 255) / 256; ++r) {
@@ -799,10 +799,31 @@ __global__ __launch_bounds__(256, WBC_QP_TILE_WAVES) void qp_tile_kernel(DevPara
     if ((tid & 63) == 0) g = __hip_atomic_fetch_add(&next_grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     g = __builtin_amdgcn_readfirstlane(g);
     if (g >= TILE / 4) break;
-    const size_t s0 = base + order[4 * g];   // first (hardest) state of the group
-    if (s0 >= N) break;                      // the rest of the queue lies beyond the end of the batch
+    if (base + order[4 * g] >= N) break;     // first (hardest) state of the group lies beyond the end: so does the rest of the queue
     const size_t s = base + order[4 * g + row];
-    qp_group16_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{s, s < N});
+    const bool live = s < N;
+    qp_group16_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
+  }
+}
+
+// qp_list_kernel: the dense active-set solver over a LIST of states (list[0] = how many, list[4 ...] = their indices): the
+// states qp_lane_kernel (qp_lane.hip.hpp) did not finish.  One wavefront per workgroup, four listed states per wavefront,
+// grid-stride over the list (the launch cannot know its length: it lives on the device).  list[2] keeps the length for
+// wbc_solver_qp_handover.  The count is zeroed by qp_list_reset_kernel (qp_lane.hip.hpp) in front of qp_lane_kernel, a kernel of its own:
+//   * a 4-byte hipMemsetAsync did the job in eager mode, but as a memset node of a captured hipGraph it did not reliably run
+//     in front of the next kernel on this stack (the list overflowed after a few replays);
+//   * letting the last workgroup of this kernel reset it (one agent-scope atomic per workgroup to count them, an agent-scope
+//     load of the length) serialises on that one address: 8192 workgroups took 330 us instead of 65 us (N = 262 144).
+template <class T, bool RHAT>
+__global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_list_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ list) {
+  const int n = min(list[0], (int)a.N);
+  const int ngroups = (n + 3) >> 2;
+  const int row = (int)((threadIdx.x & 63) >> 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0) list[2] = n;
+  for (int g = (int)blockIdx.x; g < ngroups; g += (int)gridDim.x) {
+    const int i = 4 * g + row;
+    const bool live = i < n;
+    qp_group16_body<T, false, RHAT, 16, true, 1>(prm, a, jmap, nullptr, nullptr, QpWho{live ? (size_t)list[4 + i] : (size_t)0, live});
   }
 }
 

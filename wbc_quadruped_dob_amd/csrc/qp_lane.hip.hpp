@@ -1,0 +1,365 @@
+// GRF QP + torque map, ONE STATE PER LANE (round 2): SURVEY.md 8(a) units a7-a9 for large batches.
+//
+// qp_group16.hip.hpp solves the QP with a dense dual active-set method whose 12x12 factor J is spread over a 16-lane row
+// (four QPs per wavefront; 12 of 16 lanes carry data, a third of the instructions are predication of four independent
+// rows): about 510 vector instructions per QP.  The structure that section 4.2 of DESIGN.md uses for the initial factor goes
+// further: with e = B f - beta (the residual wrench, 6 numbers) the problem
+//     min 1/2 alpha |f|^2 + 1/2 |B f - beta|^2   s.t.  f_k in K_k  (friction pyramid and normal-force box of stance foot k)
+// separates per foot once e is known,  f_k(e) = Proj_{K_k}(-B_k^T e / alpha)  (Euclidean projection of a 3-vector onto a
+// pyramid frustum: closed form in the foot's contact frame), and e solves the piecewise-linear, strongly monotone equation
+//     F(e) = e + beta - sum_k B_k Proj_{K_k}(-B_k^T e / alpha) = 0,        F = grad psi,  psi convex.
+// Semismooth Newton on F = primal-dual active set on the QP: with the faces the projections sit on (P_k = projector onto
+// the face's tangent space, f_k^p = its offset) the Newton iterate solves the 6x6 SPD system
+//     (alpha I + sum_k B_k P_k B_k^T) e+ = alpha (sum_k B_k f_k^p - beta),
+// i.e. the same matrix family as G of section 4.2.  Every lane runs this for ITS state in registers -- no cross-lane traffic,
+// 64 QPs per wavefront, loads and stores coalesced.  Undamped the iteration can cycle (under-determined stances), so the step
+// is globalised by a line search on phi'(t) = F(e + t dir) . dir (bracketing, a few projections), and a lane that has not
+// converged after QPL_MAX_NEWTON iterations hands its state to the dense active-set kernel through a list (a few per cent of
+// the bench data; NaN inputs end up there too and get their status from that kernel).  At convergence the faces are consistent
+// with the multipliers, so the result is the QP's unique solution: same f, tau as the oracle to rounding (1e-12 in fp64).
+// status = 0, iters = Newton iterations for the states solved here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "device_types.hpp"
+#include "qp_group16.hip.hpp"   // rsqrt_nr / rcp_nr, Lim, WBC_DEV
+
+namespace wbc {
+
+// Iteration caps: measured on MI355X at N = 262 144 (fp64; per-lane kernel + dense kernel over the hand-over list, us):
+// (1 Newton, 0 line-search steps) 129 + 237, (2, 0) 139 + 160, (2, 2) 153 + 160, (3, 2) 174 + 64, (5, 3) 220 + 33; the dense
+// kernel alone: 349.
+#ifndef QPL_MAX_NEWTON
+#define QPL_MAX_NEWTON 3
+#endif
+#ifndef QPL_LS_STEPS
+#define QPL_LS_STEPS 2
+#endif
+
+#ifndef QPL_F32_WAVES
+#define QPL_F32_WAVES 1
+#endif
+constexpr int QPL_FREE = 1 | (1 << 2) | (1 << 4);   // no face active
+template <class T> struct QplFoot {   // contact frame and data of one foot (all zero for a swing foot)
+  T n[3], t1[3], d[3];
+  T m;          // mu * mu_scale
+  T i1, i2;     // 1 / (1 + m^2), 1 / (1 + 2 m^2)
+  T on;         // 1 stance, 0 swing
+};
+
+template <class T> WBC_DEV void qpl_cross(const T* a, const T* b, T* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// projection of (a0, b0, c0) onto {|a| <= m c, |b| <= m c, fmin <= c <= fmax}; face code = (sa+1) | (sb+1) << 2 | (sc+1) << 4
+template <class T> WBC_DEV int qpl_project(const QplFoot<T>& k, T a0, T b0, T c0, T fmin, T fmax, T* loc) {
+  const T A = fabs_t(a0), B = fabs_t(b0);
+  const T hi = A > B ? A : B, lo = A > B ? B : A;
+  const T c_one = (c0 + k.m * hi) * k.i1, c_two = (c0 + k.m * (hi + lo)) * k.i2;
+  const T cu = (k.m * c0 >= hi) ? c0 : ((k.m * c_one >= lo) ? c_one : c_two);
+  const T c = cu > fmax ? fmax : (cu < fmin ? fmin : cu);
+  const int sc = cu > fmax ? 1 : (cu < fmin ? -1 : 0);
+  const T lim = k.m * c;
+  const bool apex = !(lim > (T)0);
+  const T a = a0 > lim ? lim : (a0 < -lim ? -lim : a0), b = b0 > lim ? lim : (b0 < -lim ? -lim : b0);
+  const int sa = apex ? 1 : (A > lim ? (a0 > 0 ? 1 : -1) : 0), sb = apex ? 1 : (B > lim ? (b0 > 0 ? 1 : -1) : 0);
+  loc[0] = a; loc[1] = b; loc[2] = c;
+  return (sa + 1) | ((sb + 1) << 2) | ((sc + 1) << 4);
+}
+
+// F(e) and the projections behind it.  fl[k] = forces in the contact frames, code[k] = faces.
+template <class T>
+WBC_DEV void qpl_eval(const QplFoot<T>* ft, const T* sS, T ralpha, T fmin, T fmax, const T* beta, const T* e, T (*fl)[3], int* code, T* F) {
+  T sf[3] = {0, 0, 0}, sm[3] = {0, 0, 0};   // sum of forces, sum of d x f
+  const T ef[3] = {sS[0] * e[0], sS[1] * e[1], sS[2] * e[2]}, em[3] = {sS[3] * e[3], sS[4] * e[4], sS[5] * e[5]};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const QplFoot<T>& q = ft[k];
+    T t2[3], cx[3];
+    qpl_cross(q.n, q.t1, t2);
+    qpl_cross(em, q.d, cx);                               // B_k^T e = s_f e_f + (s_m e_m) x d_k
+    const T y0 = -(ef[0] + cx[0]) * ralpha, y1 = -(ef[1] + cx[1]) * ralpha, y2 = -(ef[2] + cx[2]) * ralpha;
+    const T a0 = q.t1[0] * y0 + q.t1[1] * y1 + q.t1[2] * y2, b0 = t2[0] * y0 + t2[1] * y1 + t2[2] * y2, c0 = q.n[0] * y0 + q.n[1] * y1 + q.n[2] * y2;
+    T loc[3];
+    const int cd = qpl_project(q, a0, b0, c0, fmin, fmax, loc);
+    const bool on = q.on > (T)0;
+    code[k] = on ? cd : QPL_FREE;                          // interior (a swing foot has no faces)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) fl[k][c] = on ? loc[c] : (T)0;
+    T fw[3], dxf[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) fw[c] = fl[k][0] * q.t1[c] + fl[k][1] * t2[c] + fl[k][2] * q.n[c];
+    qpl_cross(q.d, fw, dxf);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sf[c] += fw[c]; sm[c] += dxf[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { F[c] = e[c] + beta[c] - sS[c] * sf[c]; F[3 + c] = e[3 + c] + beta[3 + c] - sS[3 + c] * sm[c]; }
+}
+
+// Newton iterate for the faces in `code`: solves (alpha I + sum B_k P_k B_k^T) eN = alpha (sum B_k f_k^p - beta)
+template <class T>
+WBC_DEV void qpl_newton(const QplFoot<T>* ft, const T* sS, T alpha, T fmin, T fmax, const T* beta, const int* code, T* eN) {
+  // lower triangle of the 6x6 matrix, force rows 0..2, moment rows 3..5 (unscaled; S^(1/2) is applied at the end)
+  T Pff[6] = {0, 0, 0, 0, 0, 0};       // sum P                (xx xy xz yy yz zz)
+  T X[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // sum D P  (row-major: moment row i, force column j)
+  T Y[6] = {0, 0, 0, 0, 0, 0};         // sum D P D^T
+  T pf[3] = {0, 0, 0}, pm[3] = {0, 0, 0};   // sum f^p, sum d x f^p
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const QplFoot<T>& q = ft[k];
+    const int cd = code[k];
+    const int sa = (cd & 3) - 1, sb = ((cd >> 2) & 3) - 1, sc = (cd >> 4) - 1;
+    const bool Aa = sa != 0, Ba = sb != 0, Ca = sc != 0;
+    T t2[3];
+    qpl_cross(q.n, q.t1, t2);
+    // tangent space of the face set: [not A] t1, [not B] t2, [not C] u = (sa m, sb m, 1) / |.| (zeros where the face is not active)
+    const T ua = Aa ? (T)sa * q.m : (T)0, ub = Ba ? (T)sb * q.m : (T)0;
+    const T iu = rsqrt_nr(ua * ua + ub * ub + (T)1);
+    const T wA = (Aa ? (T)0 : (T)1) * q.on, wB = (Ba ? (T)0 : (T)1) * q.on, wC = (Ca ? (T)0 : (T)1) * q.on;
+    T uw[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) uw[c] = (ua * q.t1[c] + ub * t2[c] + q.n[c]) * iu;
+    T P[6];   // xx xy xz yy yz zz
+    {
+      int o = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) P[o++] = wA * q.t1[i] * q.t1[j] + wB * t2[i] * t2[j] + wC * uw[i] * uw[j];
+    }
+    const T Pc[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};   // columns (= rows) of P
+    T Xk[3][3];   // Xk[.][j] = d x (column j of P):  D P
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { T c_[3]; qpl_cross(q.d, Pc[j], c_); Xk[0][j] = c_[0]; Xk[1][j] = c_[1]; Xk[2][j] = c_[2]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Pff[i] += P[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) X[3 * i + j] += Xk[i][j];
+    // D P D^T: row i = d x (row i of D P)
+    {
+      T r0[3], r1[3], r2[3];
+      qpl_cross(q.d, Xk[0], r0); qpl_cross(q.d, Xk[1], r1); qpl_cross(q.d, Xk[2], r2);
+      Y[0] += r0[0]; Y[1] += r0[1]; Y[2] += r0[2]; Y[3] += r1[1]; Y[4] += r1[2]; Y[5] += r2[2];
+    }
+    // offset of the face set: only a fixed normal force contributes (friction faces pass through the origin)
+    const T cbar = (sc > 0 ? fmax : fmin) * (Ca ? q.on : (T)0);
+    const T fa = Aa ? (T)sa * q.m * cbar : (T)0, fb = Ba ? (T)sb * q.m * cbar : (T)0;
+    T fpw[3], dxf[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) fpw[c] = fa * q.t1[c] + fb * t2[c] + cbar * q.n[c];
+    qpl_cross(q.d, fpw, dxf);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pf[c] += fpw[c]; pm[c] += dxf[c]; }
+  }
+  // G (lower triangle, row-major packed: 00 | 10 11 | 20 21 22 | 30 .. 33 | 40 .. 44 | 50 .. 55)
+  T G[21];
+  G[0] = alpha + sS[0] * sS[0] * Pff[0];
+  G[1] = sS[1] * sS[0] * Pff[1]; G[2] = alpha + sS[1] * sS[1] * Pff[3];
+  G[3] = sS[2] * sS[0] * Pff[2]; G[4] = sS[2] * sS[1] * Pff[4]; G[5] = alpha + sS[2] * sS[2] * Pff[5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int r = 3 + i, o = r * (r + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[o + j] = sS[3 + i] * sS[j] * X[3 * i + j];
+  }
+  G[6 + 3] = alpha + sS[3] * sS[3] * Y[0];
+  G[10 + 3] = sS[4] * sS[3] * Y[1]; G[10 + 4] = alpha + sS[4] * sS[4] * Y[3];
+  G[15 + 3] = sS[5] * sS[3] * Y[2]; G[15 + 4] = sS[5] * sS[4] * Y[4]; G[15 + 5] = alpha + sS[5] * sS[5] * Y[5];
+  T rhs[6];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { rhs[c] = alpha * (sS[c] * pf[c] - beta[c]); rhs[3 + c] = alpha * (sS[3 + c] * pm[c] - beta[3 + c]); }
+  // dense 6x6 Cholesky in place (L overwrites G), reciprocal pivots in il
+  T il[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int oj = j * (j + 1) / 2;
+    T piv = G[oj + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) piv -= G[oj + k] * G[oj + k];
+    il[j] = rsqrt_nr(piv);
+    G[oj + j] = piv * il[j];
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      const int oi = i * (i + 1) / 2;
+      T v = G[oi + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= G[oi + k] * G[oj + k];
+      G[oi + j] = v * il[j];
+    }
+  }
+  T w[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int oi = i * (i + 1) / 2;
+    T v = rhs[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= G[oi + k] * w[k];
+    w[i] = v * il[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    T v = w[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v -= G[k * (k + 1) / 2 + i] * eN[k];
+    eN[i] = v * il[i];
+  }
+}
+
+// todo[0] = number of states handed to the dense kernel (zeroed by qp_list_reset_kernel, launched in front of this kernel),
+// todo[2] = that number of the last tick (diagnostics), todo[4 ...] = their indices
+template <class T, bool RHAT>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_lane_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ todo) {
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  const size_t s_raw = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
+#define LLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define LST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
+  const int mask = a.mask[s32] & 0xF;
+  const bool geom_jc = a.Jc != nullptr;
+  QplFoot<T> ft[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool on = (mask >> k) & 1;
+    T dx, dy, dz;
+    if (geom_jc) { dx = LLD(a.Jc, (3 * k + 1) * 18 + 5); dy = LLD(a.Jc, (3 * k + 2) * 18 + 3); dz = LLD(a.Jc, (3 * k) * 18 + 4); }
+    else { dx = LLD(a.ws, WS_D + 3 * k); dy = LLD(a.ws, WS_D + 3 * k + 1); dz = LLD(a.ws, WS_D + 3 * k + 2); }
+    T nx = LLD(a.normals, 3 * k), ny = LLD(a.normals, 3 * k + 1), nz = LLD(a.normals, 3 * k + 2);
+    const T iln = rsqrt_nr(nx * nx + ny * ny + nz * nz);
+    nx *= iln; ny *= iln; nz *= iln;
+    const bool usex = fabs_t(nx) < (T)0.9;
+    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
+    const T rd = rx * nx + ry * ny;
+    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
+    const T it = rsqrt_nr(t1x * t1x + t1y * t1y + t1z * t1z);
+    QplFoot<T>& q = ft[k];
+    q.on = on ? (T)1 : (T)0;
+    q.n[0] = nx; q.n[1] = ny; q.n[2] = nz;
+    q.t1[0] = t1x * it; q.t1[1] = t1y * it; q.t1[2] = t1z * it;
+    q.d[0] = on ? dx : (T)0; q.d[1] = on ? dy : (T)0; q.d[2] = on ? dz : (T)0;
+    q.m = LLD(a.mu, k) * prm.mu_scale;
+    q.i1 = rcp_nr((T)1 + q.m * q.m); q.i2 = rcp_nr((T)1 + (T)2 * q.m * q.m);
+  }
+  T sS[6], beta[6];
+  T bmax = 0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    sS[c] = prm.sS[c];
+    const T b = LLD(a.ws, WS_B + c) - (RHAT ? LLD(a.ws, WS_RHAT + c) : (T)0);
+    beta[c] = sS[c] * b;
+    bmax = fabs_t(beta[c]) > bmax ? fabs_t(beta[c]) : bmax;
+  }
+  const T alpha = prm.alpha, ralpha = prm.rsqrt_alpha * prm.rsqrt_alpha, fmin = prm.fn_min, fmax = prm.fn_max;
+  const T tolF = (std::is_same<T, double>::value ? (T)1e-11 : (T)2e-5) * ((T)1 + bmax);
+
+  // start: all faces free (the unconstrained minimum)
+  int code[4] = {QPL_FREE, QPL_FREE, QPL_FREE, QPL_FREE};
+  T e[6], F[6], fl[4][3];
+  qpl_newton(ft, sS, alpha, fmin, fmax, beta, code, e);
+  qpl_eval(ft, sS, ralpha, fmin, fmax, beta, e, fl, code, F);
+  int iters = 0;
+  bool conv = false;
+  auto fnorm = [](const T* v) __attribute__((always_inline)) -> T {
+    T m = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { const T x = v[c] < 0 ? -v[c] : v[c]; m = x > m ? x : m; }   // (NaN never compares greater: a NaN state stays unconverged by the test below)
+    return m;
+  };
+  auto nan6 = [](const T* v) __attribute__((always_inline)) -> bool { bool n = false;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) n = n || !(v[c] == v[c]);
+    return n; };
+  for (int itn = 0; itn < QPL_MAX_NEWTON; ++itn) {
+    conv = conv || (fnorm(F) <= tolF && !nan6(F));
+    const bool act = live && !conv;
+    if (__ballot(act) == 0ull) break;
+    iters += act ? 1 : 0;
+    T eN[6], dir[6];
+    qpl_newton(ft, sS, alpha, fmin, fmax, beta, code, eN);
+    T g0 = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { dir[c] = eN[c] - e[c]; g0 += F[c] * dir[c]; }
+    // full step
+    T Ft[6], flt[4][3], et[6];
+    int codet[4];
+    qpl_eval(ft, sS, ralpha, fmin, fmax, beta, eN, flt, codet, Ft);
+    T g1 = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { et[c] = eN[c]; g1 += Ft[c] * dir[c]; }
+    const bool same = codet[0] == code[0] && codet[1] == code[1] && codet[2] == code[2] && codet[3] == code[3];
+    const T ag0 = g0 < 0 ? -g0 : g0;
+    bool need = act && !same && (g1 > (T)1e-12 * ag0);     // phi'(1) > 0: the step overshoots, bracket the root of phi' in (0, 1)
+    T tl = 0, gl = g0, th = 1, gh = g1;
+    // the trial point becomes the current point for every active lane; lanes that line-search overwrite it below
+    auto take = [&](bool who) __attribute__((always_inline)) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { e[c] = who ? et[c] : e[c]; F[c] = who ? Ft[c] : F[c]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        code[k] = who ? codet[k] : code[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fl[k][c] = who ? flt[k][c] : fl[k][c];
+      }
+    };
+    take(act);
+    conv = conv || (act && same && !nan6(Ft));     // faces unchanged by a full Newton step: eN IS the solution for those faces
+#pragma unroll 1
+    for (int ls = 0; ls < QPL_LS_STEPS; ++ls) {
+      if (__ballot(need) == 0ull) break;
+      T t = tl - gl * (th - tl) * rcp_nr(gh - gl);
+      const T lo = tl + (T)0.1 * (th - tl), hi = th - (T)0.1 * (th - tl);
+      t = t < lo ? lo : (t > hi ? hi : t);
+      t = (t == t) ? t : (T)0.5 * (tl + th);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) et[c] = (eN[c] - dir[c]) + t * dir[c];   // e_old + t dir  (e_old = eN - dir)
+      qpl_eval(ft, sS, ralpha, fmin, fmax, beta, et, flt, codet, Ft);
+      T gt = 0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) gt += Ft[c] * dir[c];
+      const bool pos = gt > 0;
+      th = (need && pos) ? t : th; gh = (need && pos) ? gt : gh;
+      tl = (need && !pos) ? t : tl; gl = (need && !pos) ? gt : gl;
+      take(need);
+      const T agt = gt < 0 ? -gt : gt;
+      need = need && (agt > (T)1e-3 * ag0);
+    }
+  }
+  conv = conv || (fnorm(F) <= tolF && !nan6(F));
+  // ---- outputs of the states solved here; the others go to the dense active-set kernel
+  if (live && conv) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const QplFoot<T>& q = ft[k];
+      T t2[3], fw[3];
+      qpl_cross(q.n, q.t1, t2);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { fw[c] = fl[k][0] * q.t1[c] + fl[k][1] * t2[c] + fl[k][2] * q.n[c]; LST(a.f, 3 * k + c, fw[c]); }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {   // tau of joint j of leg k = tau_partial - (own-leg Jacobian column) . f
+        const int jm = jmap.j[3 * k + j];
+        T j0, j1, j2;
+        if (geom_jc) { j0 = LLD(a.Jc, (3 * k + 0) * 18 + 6 + jm); j1 = LLD(a.Jc, (3 * k + 1) * 18 + 6 + jm); j2 = LLD(a.Jc, (3 * k + 2) * 18 + 6 + jm); }
+        else { j0 = LLD(a.ws, WS_JCL + 9 * k + 0 + j); j1 = LLD(a.ws, WS_JCL + 9 * k + 3 + j); j2 = LLD(a.ws, WS_JCL + 9 * k + 6 + j); }
+        const T taup = LLD(a.ws, WS_TAUP + 3 * k + j) - (RHAT ? LLD(a.ws, WS_RHAT + 6 + 3 * k + j) : (T)0);
+        LST(a.tau, jm, taup - (j0 * fw[0] + j1 * fw[1] + j2 * fw[2]));
+      }
+    }
+    a.status[s32] = 0;
+    if (a.iters) a.iters[s32] = iters;
+  } else if (live) {
+    const int slot = atomicAdd(&todo[0], 1);
+    if (slot < (int)a.N) todo[4 + slot] = (int)s32;   // (always, while the count starts a tick at zero: the guard keeps a stale count from writing past the list)
+  }
+#undef LLD
+#undef LST
+}
+
+// one thread: empties the hand-over list (see qp_list_kernel for why this is a kernel).  A template only so that the two
+// scalar-type objects of k_qp.hip may both carry it.
+template <class T> __global__ void qp_list_reset_kernel(int* __restrict__ todo) { todo[0] = 0; }
+
+}  // namespace wbc

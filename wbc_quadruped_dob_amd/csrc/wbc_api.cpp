@@ -57,6 +57,7 @@ struct wbc_solver {
   int leg_body[4][3];
   void* d_model = nullptr;  // DevModel<T>
   void* d_ws = nullptr;     // WS_LDS_WORDS * max_batch * sizeof(T): the 66 step words + 18 words of rhat (separate observer kernel)
+  int* d_todo = nullptr;    // 4 + max_batch ints: states the per-lane QP kernel hands to the dense active-set kernel (count, workgroups done, count of the last tick, pad; indices)
   QpJidx jmap;
   // resolved options
   size_t fused_max = 4096;        // observer-on fp64 ticks of at most this many states run as ONE kernel (fused_tick.hip.hpp)
@@ -273,6 +274,7 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->timing_mode = WBC_TIMING_DISPATCH;
   o->qp_tile = 0;
   o->obs_split_serial = 1;
+  o->qp_lane = 0;
 }
 
 extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -332,6 +334,8 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
     }
   }
   if (e == hipSuccess) e = hipMalloc(&s->d_ws, (size_t)WS_LDS_WORDS * max_batch * ts);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_todo, (max_batch + 4) * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(s->d_todo, 0, 4 * sizeof(int));
   // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
   s->one_bytes = 200 * sizeof(double) + 4 * sizeof(int);
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
@@ -359,6 +363,7 @@ extern "C" void wbc_solver_destroy(wbc_solver* s) {
   DeviceGuard guard(s->device);
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_ws) (void)hipFree(s->d_ws);
+  if (s->d_todo) (void)hipFree(s->d_todo);
   if (s->d_one) (void)hipFree(s->d_one);
   if (s->h_one) (void)hipHostFree(s->h_one);
   if (s->d_ref) (void)hipFree(s->d_ref);
@@ -378,6 +383,15 @@ extern "C" int wbc_solver_set_params(wbc_solver* s, const wbc_params* p) {
 }
 
 extern "C" int wbc_solver_device(const wbc_solver* s) { return s ? s->device : -1; }
+
+// diagnostics: how many states of the LAST two-kernel tick the per-lane QP kernel handed to the dense kernel (synchronises)
+extern "C" int wbc_solver_qp_handover(wbc_solver* s, int* count) {
+  if (!s || !count) return fail(WBC_E_INVALID, "null argument");
+  ON_DEVICE(s);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(count, s->d_todo + 2, sizeof(int), hipMemcpyDeviceToHost));   // [2]: what qp_list_kernel saw before it emptied the list
+  return WBC_OK;
+}
 
 // ---- timing: spans borrow event pairs from a ring that wbc_solver_enable_timing allocated; nothing is created inside a tick
 struct SpanScope {   // one instrumented kernel launch
@@ -427,9 +441,9 @@ extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
   return WBC_OK;
 }
 
-extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launches[4]) {
+extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KINDS], int launches[WBC_TIMING_KINDS]) {
   if (!s || !ms || !launches) return fail(WBC_E_INVALID, "null argument");
-  for (int k = 0; k < 4; ++k) { ms[k] = 0; launches[k] = 0; }
+  for (int k = 0; k < WBC_TIMING_KINDS; ++k) { ms[k] = 0; launches[k] = 0; }
   ON_DEVICE(s);
   for (auto& sp : s->spans) {
     HIP_TRY(hipEventSynchronize(sp.b));
@@ -443,7 +457,7 @@ extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[4], int launch
   return WBC_OK;
 }
 
-// one instrumented launch: kind = index into the timing arrays (0 dyn_sweep, 1 QP, 2 rnea_step / observer, 3 fused tick)
+// one instrumented launch: kind = index into the timing arrays (0 dyn_sweep, 1 QP (dense active set), 2 rnea_step / observer, 3 fused tick, 4 QP one state per lane)
 #define TIMED_LAUNCH(kind_, stream_, what_, call_)                                                          \
   do {                                                                                                      \
     SpanScope sc_(s, kind_, stream_);                                                                       \
@@ -539,6 +553,20 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   int tile = s->opt.qp_tile;
   if (tile == 0) tile = N >= 20480 ? 64 : (N >= 12288 ? 32 : 0);
   if (tile < 0) tile = 0;
+  // Very large fp64 batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench,
+  // 64 QPs per wavefront, no cross-lane traffic); the few per cent it does not finish within its iteration cap go through a
+  // device-side list to the dense active-set kernel.  No host read: the list length stays on the device, the second launch is
+  // grid-stride over it.  Measured on MI355X, QP stage, dense kernel alone -> per-lane + list: configs[1] data 349 -> 174 + 64 us
+  // at 262 144 states, 176 -> 84 + 46 at 131 072, 92 -> 40 + 37 at 65 536, 48 -> 35 + 26 at 32 768 (a wavefront of the
+  // per-lane kernel takes ~35 us whatever the batch: it needs several rounds of wavefronts per SIMD to pay); observer-on data
+  // (easier QPs) 225 -> 162 + 31 at 262 144 but 52 -> 37 + 20 at 65 536.  fp32 does not gain (its per-lane kernel is no faster
+  // than the fp64 one, its dense kernel is).  Hence the default: fp64 from 131 072 states on.
+  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && s->dtype == WBC_F64 && N >= 131072);
+  if (lane) {
+    TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, obs_split, dp, qa, s->jmap, s->d_todo));
+    TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, 0, dp, qa, s->jmap, s->d_todo));
+    return WBC_OK;
+  }
   TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, tile, dp, qa, s->jmap));
   return WBC_OK;
 }
