@@ -221,14 +221,33 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
 #define LST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
   const int mask = a.mask[s32] & 0xF;
   const bool geom_jc = a.Jc != nullptr;
+  // every input of the solve is requested before the first one is used: a wavefront is alone on its SIMD (register budget),
+  // so a load that waits exposes its whole latency
+  T in_d[12], in_n[12], in_mu[4], in_b[6], in_r[6];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (geom_jc) { in_d[3 * k] = LLD(a.Jc, (3 * k + 1) * 18 + 5); in_d[3 * k + 1] = LLD(a.Jc, (3 * k + 2) * 18 + 3); in_d[3 * k + 2] = LLD(a.Jc, (3 * k) * 18 + 4); }
+    else { in_d[3 * k] = LLD(a.ws, WS_D + 3 * k); in_d[3 * k + 1] = LLD(a.ws, WS_D + 3 * k + 1); in_d[3 * k + 2] = LLD(a.ws, WS_D + 3 * k + 2); }
+  }
+#pragma unroll
+  for (int c = 0; c < 12; ++c) in_n[c] = LLD(a.normals, c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) in_mu[k] = LLD(a.mu, k);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { in_b[c] = LLD(a.ws, WS_B + c); in_r[c] = RHAT ? LLD(a.ws, WS_RHAT + c) : (T)0; }
+  // (the empty asm statements keep the compiler from sinking a load down to its first use)
+#pragma unroll
+  for (int c = 0; c < 12; ++c) { asm volatile("" : "+v"(in_d[c])); asm volatile("" : "+v"(in_n[c])); }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { asm volatile("" : "+v"(in_b[c])); if (RHAT) asm volatile("" : "+v"(in_r[c])); }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(in_mu[c]));
   QplFoot<T> ft[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool on = (mask >> k) & 1;
-    T dx, dy, dz;
-    if (geom_jc) { dx = LLD(a.Jc, (3 * k + 1) * 18 + 5); dy = LLD(a.Jc, (3 * k + 2) * 18 + 3); dz = LLD(a.Jc, (3 * k) * 18 + 4); }
-    else { dx = LLD(a.ws, WS_D + 3 * k); dy = LLD(a.ws, WS_D + 3 * k + 1); dz = LLD(a.ws, WS_D + 3 * k + 2); }
-    T nx = LLD(a.normals, 3 * k), ny = LLD(a.normals, 3 * k + 1), nz = LLD(a.normals, 3 * k + 2);
+    const T dx = in_d[3 * k], dy = in_d[3 * k + 1], dz = in_d[3 * k + 2];
+    T nx = in_n[3 * k], ny = in_n[3 * k + 1], nz = in_n[3 * k + 2];
     const T iln = rsqrt_nr(nx * nx + ny * ny + nz * nz);
     nx *= iln; ny *= iln; nz *= iln;
     const bool usex = fabs_t(nx) < (T)0.9;
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
     q.n[0] = nx; q.n[1] = ny; q.n[2] = nz;
     q.t1[0] = t1x * it; q.t1[1] = t1y * it; q.t1[2] = t1z * it;
     q.d[0] = on ? dx : (T)0; q.d[1] = on ? dy : (T)0; q.d[2] = on ? dz : (T)0;
-    q.m = LLD(a.mu, k) * prm.mu_scale;
+    q.m = in_mu[k] * prm.mu_scale;
     q.i1 = rcp_nr((T)1 + q.m * q.m); q.i2 = rcp_nr((T)1 + (T)2 * q.m * q.m);
   }
   T sS[6], beta[6];
@@ -249,8 +268,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     sS[c] = prm.sS[c];
-    const T b = LLD(a.ws, WS_B + c) - (RHAT ? LLD(a.ws, WS_RHAT + c) : (T)0);
-    beta[c] = sS[c] * b;
+    beta[c] = sS[c] * (in_b[c] - in_r[c]);
     bmax = fabs_t(beta[c]) > bmax ? fabs_t(beta[c]) : bmax;
   }
   const T alpha = prm.alpha, ralpha = prm.rsqrt_alpha * prm.rsqrt_alpha, fmin = prm.fn_min, fmax = prm.fn_max;
@@ -331,6 +349,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
   conv = conv || (fnorm(F) <= tolF && !nan6(F));
   // ---- outputs of the states solved here; the others go to the dense active-set kernel
   if (live && conv) {
+    T jl[36], tp[12], tr[12];   // own-leg Jacobian columns and tau_partial: all requested before the first store (same reason as above)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int jm = jmap.j[3 * k + j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) jl[9 * k + 3 * j + c] = geom_jc ? LLD(a.Jc, (3 * k + c) * 18 + 6 + jm) : LLD(a.ws, WS_JCL + 9 * k + 3 * c + j);
+        tp[3 * k + j] = LLD(a.ws, WS_TAUP + 3 * k + j);
+        tr[3 * k + j] = RHAT ? LLD(a.ws, WS_RHAT + 6 + 3 * k + j) : (T)0;
+      }
+#pragma unroll
+    for (int c = 0; c < 36; ++c) asm volatile("" : "+v"(jl[c]));
+#pragma unroll
+    for (int c = 0; c < 12; ++c) { asm volatile("" : "+v"(tp[c])); if (RHAT) asm volatile("" : "+v"(tr[c])); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const QplFoot<T>& q = ft[k];
@@ -339,14 +372,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
 #pragma unroll
       for (int c = 0; c < 3; ++c) { fw[c] = fl[k][0] * q.t1[c] + fl[k][1] * t2[c] + fl[k][2] * q.n[c]; LST(a.f, 3 * k + c, fw[c]); }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {   // tau of joint j of leg k = tau_partial - (own-leg Jacobian column) . f
-        const int jm = jmap.j[3 * k + j];
-        T j0, j1, j2;
-        if (geom_jc) { j0 = LLD(a.Jc, (3 * k + 0) * 18 + 6 + jm); j1 = LLD(a.Jc, (3 * k + 1) * 18 + 6 + jm); j2 = LLD(a.Jc, (3 * k + 2) * 18 + 6 + jm); }
-        else { j0 = LLD(a.ws, WS_JCL + 9 * k + 0 + j); j1 = LLD(a.ws, WS_JCL + 9 * k + 3 + j); j2 = LLD(a.ws, WS_JCL + 9 * k + 6 + j); }
-        const T taup = LLD(a.ws, WS_TAUP + 3 * k + j) - (RHAT ? LLD(a.ws, WS_RHAT + 6 + 3 * k + j) : (T)0);
-        LST(a.tau, jm, taup - (j0 * fw[0] + j1 * fw[1] + j2 * fw[2]));
-      }
+      for (int j = 0; j < 3; ++j)   // tau of joint j of leg k = tau_partial - (own-leg Jacobian column) . f
+        LST(a.tau, jmap.j[3 * k + j], (tp[3 * k + j] - tr[3 * k + j]) - (jl[9 * k + 3 * j] * fw[0] + jl[9 * k + 3 * j + 1] * fw[1] + jl[9 * k + 3 * j + 2] * fw[2]));
     }
     a.status[s32] = 0;
     if (a.iters) a.iters[s32] = iters;
