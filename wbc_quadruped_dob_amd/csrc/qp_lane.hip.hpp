@@ -36,97 +36,146 @@ namespace wbc {
 #define QPL_LS_STEPS 2
 #endif
 
-#ifndef QPL_F32_WAVES
-#define QPL_F32_WAVES 1
+#ifndef QPL_F64_WAVES
+#define QPL_F64_WAVES 2
 #endif
+#ifndef QPL_F32_WAVES
+#define QPL_F32_WAVES 2
+#endif
+#ifndef QPL_UNROLL_EVAL
+#define QPL_UNROLL_EVAL 1
+#endif
+#ifndef QPL_UNROLL_NEWTON
+#define QPL_UNROLL_NEWTON 1
+#endif
+constexpr int QPL_WG = 128;                          // threads per workgroup (LDS below: 36 kB fp64, 20 kB fp32)
 constexpr int QPL_FREE = 1 | (1 << 2) | (1 << 4);   // no face active
-template <class T> struct QplFoot {   // contact frame and data of one foot (all zero for a swing foot)
-  T n[3], t1[3], d[3];
-  T m;          // mu * mu_scale
-  T i1, i2;     // 1 / (1 + m^2), 1 / (1 + 2 m^2)
-  T on;         // 1 stance, 0 swing
+
+// The contact frames live in LDS, one slot per lane ([component][foot][lane]: conflict-free), and the loops over the feet are
+// NOT unrolled: kept in registers the frames (52 values) plus the temporaries of four interleaved feet need ~430 registers --
+// one wavefront per SIMD, nothing to hide a dependent fp64 chain behind.  From LDS, one foot at a time, the kernel fits 256
+// registers and two wavefronts share a SIMD.  Stored per foot: unit normal, lever arm (zero for a swing foot), mu, the
+// normalisation of the first tangent (the tangent is rebuilt from the normal: 6 flops) and fp32 seeds of 1/(1+mu^2), 1/(1+2mu^2)
+// (two Newton steps make them exact doubles again).
+template <class T> struct QplLds {
+  T n[3][4][QPL_WG], d[3][4][QPL_WG], m[4][QPL_WG], it[4][QPL_WG];
+  float i12[2][4][QPL_WG];
 };
+template <class T> struct QplFrame { T n[3], t1[3], t2[3], d[3], m, i1, i2; };
 
 template <class T> WBC_DEV void qpl_cross(const T* a, const T* b, T* o) {
   o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
 }
+WBC_DEV double qpl_refine(float seed, double den) {
+  double y = (double)seed;
+  double r = fma(-den, y, 1.0); y = fma(y, r, y);
+  r = fma(-den, y, 1.0); y = fma(y, r, y);
+  return y;
+}
+WBC_DEV float qpl_refine(float seed, float) { return seed; }
+
+// first tangent of the contact frame from the unit normal (the oracle's convention: e_x, or e_y for a normal along x, made
+// orthogonal to n); `it` = 1 / its length before normalisation
+template <class T> WBC_DEV void qpl_tangent(const T* n, T it, T* t1) {
+  const bool usex = fabs_t(n[0]) < (T)0.9;
+  const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
+  const T rd = rx * n[0] + ry * n[1];
+  t1[0] = (rx - n[0] * rd) * it; t1[1] = (ry - n[1] * rd) * it; t1[2] = (-n[2] * rd) * it;
+}
+
+template <class T> WBC_DEV void qpl_frame(const QplLds<T>& L, int k, unsigned tid, QplFrame<T>& q) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { q.n[c] = L.n[c][k][tid]; q.d[c] = L.d[c][k][tid]; }
+  q.m = L.m[k][tid];
+  qpl_tangent(q.n, L.it[k][tid], q.t1);
+  qpl_cross(q.n, q.t1, q.t2);
+  q.i1 = qpl_refine(L.i12[0][k][tid], (T)1 + q.m * q.m);
+  q.i2 = qpl_refine(L.i12[1][k][tid], (T)1 + (T)2 * q.m * q.m);
+}
 
 // projection of (a0, b0, c0) onto {|a| <= m c, |b| <= m c, fmin <= c <= fmax}; face code = (sa+1) | (sb+1) << 2 | (sc+1) << 4
-template <class T> WBC_DEV int qpl_project(const QplFoot<T>& k, T a0, T b0, T c0, T fmin, T fmax, T* loc) {
+WBC_DEV double qpl_max(double a, double b) { return __builtin_fmax(a, b); }
+WBC_DEV float qpl_max(float a, float b) { return __builtin_fmaxf(a, b); }
+WBC_DEV double qpl_min(double a, double b) { return __builtin_fmin(a, b); }
+WBC_DEV float qpl_min(float a, float b) { return __builtin_fminf(a, b); }
+// (v_max / v_min: one instruction where a compare-and-select on a double takes three.  They drop a NaN operand instead of
+// passing it on -- harmless here: a NaN input reaches F through e and beta as well, and F decides convergence.)
+template <class T> WBC_DEV int qpl_project(const QplFrame<T>& k, T a0, T b0, T c0, T fmin, T fmax, T* loc) {
   const T A = fabs_t(a0), B = fabs_t(b0);
-  const T hi = A > B ? A : B, lo = A > B ? B : A;
+  const T hi = qpl_max(A, B), lo = qpl_min(A, B);
   const T c_one = (c0 + k.m * hi) * k.i1, c_two = (c0 + k.m * (hi + lo)) * k.i2;
   const T cu = (k.m * c0 >= hi) ? c0 : ((k.m * c_one >= lo) ? c_one : c_two);
-  const T c = cu > fmax ? fmax : (cu < fmin ? fmin : cu);
+  const T c = qpl_min(qpl_max(cu, fmin), fmax);
   const int sc = cu > fmax ? 1 : (cu < fmin ? -1 : 0);
   const T lim = k.m * c;
   const bool apex = !(lim > (T)0);
-  const T a = a0 > lim ? lim : (a0 < -lim ? -lim : a0), b = b0 > lim ? lim : (b0 < -lim ? -lim : b0);
+  const T a = qpl_max(qpl_min(a0, lim), -lim), b = qpl_max(qpl_min(b0, lim), -lim);
   const int sa = apex ? 1 : (A > lim ? (a0 > 0 ? 1 : -1) : 0), sb = apex ? 1 : (B > lim ? (b0 > 0 ? 1 : -1) : 0);
   loc[0] = a; loc[1] = b; loc[2] = c;
   return (sa + 1) | ((sb + 1) << 2) | ((sc + 1) << 4);
 }
 
-// F(e) and the projections behind it.  fl[k] = forces in the contact frames, code[k] = faces.
-template <class T>
-WBC_DEV void qpl_eval(const QplFoot<T>* ft, const T* sS, T ralpha, T fmin, T fmax, const T* beta, const T* e, T (*fl)[3], int* code, T* F) {
+// F(e) and the faces of the projections behind it (6 bits per foot in `codes`).  FW: also leaves the forces (world frame)
+// in the LDS slots of the normals -- the frame of a foot is dead once its force is known -- for the torque map.
+template <class T, bool FW>
+WBC_DEV void qpl_eval(QplLds<T>& L, unsigned tid, int mask, const T* sS, T ralpha, T fmin, T fmax, const T* beta, const T* e, int& codes, T* F) {
   T sf[3] = {0, 0, 0}, sm[3] = {0, 0, 0};   // sum of forces, sum of d x f
   const T ef[3] = {sS[0] * e[0], sS[1] * e[1], sS[2] * e[2]}, em[3] = {sS[3] * e[3], sS[4] * e[4], sS[5] * e[5]};
-#pragma unroll
+  int cds = 0;
+#pragma unroll QPL_UNROLL_EVAL
   for (int k = 0; k < 4; ++k) {
-    const QplFoot<T>& q = ft[k];
-    T t2[3], cx[3];
-    qpl_cross(q.n, q.t1, t2);
+    QplFrame<T> q;
+    qpl_frame(L, k, tid, q);
+    T cx[3];
     qpl_cross(em, q.d, cx);                               // B_k^T e = s_f e_f + (s_m e_m) x d_k
     const T y0 = -(ef[0] + cx[0]) * ralpha, y1 = -(ef[1] + cx[1]) * ralpha, y2 = -(ef[2] + cx[2]) * ralpha;
-    const T a0 = q.t1[0] * y0 + q.t1[1] * y1 + q.t1[2] * y2, b0 = t2[0] * y0 + t2[1] * y1 + t2[2] * y2, c0 = q.n[0] * y0 + q.n[1] * y1 + q.n[2] * y2;
+    const T a0 = q.t1[0] * y0 + q.t1[1] * y1 + q.t1[2] * y2, b0 = q.t2[0] * y0 + q.t2[1] * y1 + q.t2[2] * y2, c0 = q.n[0] * y0 + q.n[1] * y1 + q.n[2] * y2;
     T loc[3];
     const int cd = qpl_project(q, a0, b0, c0, fmin, fmax, loc);
-    const bool on = q.on > (T)0;
-    code[k] = on ? cd : QPL_FREE;                          // interior (a swing foot has no faces)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) fl[k][c] = on ? loc[c] : (T)0;
+    const bool on = (mask >> k) & 1;
+    cds |= (on ? cd : QPL_FREE) << (6 * k);               // a swing foot has no faces
     T fw[3], dxf[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) fw[c] = fl[k][0] * q.t1[c] + fl[k][1] * t2[c] + fl[k][2] * q.n[c];
+    for (int c = 0; c < 3; ++c) { fw[c] = loc[0] * q.t1[c] + loc[1] * q.t2[c] + loc[2] * q.n[c]; fw[c] = on ? fw[c] : (T)0; }
     qpl_cross(q.d, fw, dxf);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { sf[c] += fw[c]; sm[c] += dxf[c]; }
+    for (int c = 0; c < 3; ++c) { sf[c] += fw[c]; sm[c] += dxf[c]; if (FW) L.n[c][k][tid] = fw[c]; }
   }
+  codes = cds;
 #pragma unroll
   for (int c = 0; c < 3; ++c) { F[c] = e[c] + beta[c] - sS[c] * sf[c]; F[3 + c] = e[3 + c] + beta[3 + c] - sS[3 + c] * sm[c]; }
 }
 
-// Newton iterate for the faces in `code`: solves (alpha I + sum B_k P_k B_k^T) eN = alpha (sum B_k f_k^p - beta)
+// Newton iterate for the faces in `codes`: solves (alpha I + sum B_k P_k B_k^T) eN = alpha (sum B_k f_k^p - beta)
 template <class T>
-WBC_DEV void qpl_newton(const QplFoot<T>* ft, const T* sS, T alpha, T fmin, T fmax, const T* beta, const int* code, T* eN) {
+WBC_DEV void qpl_newton(const QplLds<T>& L, unsigned tid, int mask, const T* sS, T alpha, T fmin, T fmax, const T* beta, int codes, T* eN) {
   // lower triangle of the 6x6 matrix, force rows 0..2, moment rows 3..5 (unscaled; S^(1/2) is applied at the end)
   T Pff[6] = {0, 0, 0, 0, 0, 0};       // sum P                (xx xy xz yy yz zz)
   T X[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // sum D P  (row-major: moment row i, force column j)
   T Y[6] = {0, 0, 0, 0, 0, 0};         // sum D P D^T
   T pf[3] = {0, 0, 0}, pm[3] = {0, 0, 0};   // sum f^p, sum d x f^p
-#pragma unroll
+#pragma unroll QPL_UNROLL_NEWTON
   for (int k = 0; k < 4; ++k) {
-    const QplFoot<T>& q = ft[k];
-    const int cd = code[k];
+    QplFrame<T> q;
+    qpl_frame(L, k, tid, q);
+    const int cd = (codes >> (6 * k)) & 63;
     const int sa = (cd & 3) - 1, sb = ((cd >> 2) & 3) - 1, sc = (cd >> 4) - 1;
     const bool Aa = sa != 0, Ba = sb != 0, Ca = sc != 0;
-    T t2[3];
-    qpl_cross(q.n, q.t1, t2);
     // tangent space of the face set: [not A] t1, [not B] t2, [not C] u = (sa m, sb m, 1) / |.| (zeros where the face is not active)
     const T ua = Aa ? (T)sa * q.m : (T)0, ub = Ba ? (T)sb * q.m : (T)0;
-    const T iu = rsqrt_nr(ua * ua + ub * ub + (T)1);
-    const T wA = (Aa ? (T)0 : (T)1) * q.on, wB = (Ba ? (T)0 : (T)1) * q.on, wC = (Ca ? (T)0 : (T)1) * q.on;
+    const bool on = (mask >> k) & 1;
+    const T iu2 = (Aa && Ba) ? q.i2 : ((Aa || Ba) ? q.i1 : (T)1);     // 1 / |u|^2: |u|^2 is 1, 1 + m^2 or 1 + 2 m^2
+    const T wA = (on && !Aa) ? (T)1 : (T)0, wB = (on && !Ba) ? (T)1 : (T)0, wC = (on && !Ca) ? iu2 : (T)0;
     T uw[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) uw[c] = (ua * q.t1[c] + ub * t2[c] + q.n[c]) * iu;
+    for (int c = 0; c < 3; ++c) uw[c] = ua * q.t1[c] + ub * q.t2[c] + q.n[c];
     T P[6];   // xx xy xz yy yz zz
     {
       int o = 0;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = i; j < 3; ++j) P[o++] = wA * q.t1[i] * q.t1[j] + wB * t2[i] * t2[j] + wC * uw[i] * uw[j];
+        for (int j = i; j < 3; ++j) P[o++] = wA * q.t1[i] * q.t1[j] + wB * q.t2[i] * q.t2[j] + wC * uw[i] * uw[j];
     }
     const T Pc[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};   // columns (= rows) of P
     T Xk[3][3];   // Xk[.][j] = d x (column j of P):  D P
@@ -145,11 +194,11 @@ WBC_DEV void qpl_newton(const QplFoot<T>* ft, const T* sS, T alpha, T fmin, T fm
       Y[0] += r0[0]; Y[1] += r0[1]; Y[2] += r0[2]; Y[3] += r1[1]; Y[4] += r1[2]; Y[5] += r2[2];
     }
     // offset of the face set: only a fixed normal force contributes (friction faces pass through the origin)
-    const T cbar = (sc > 0 ? fmax : fmin) * (Ca ? q.on : (T)0);
+    const T cbar = (Ca && on) ? (sc > 0 ? fmax : fmin) : (T)0;
     const T fa = Aa ? (T)sa * q.m * cbar : (T)0, fb = Ba ? (T)sb * q.m * cbar : (T)0;
     T fpw[3], dxf[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) fpw[c] = fa * q.t1[c] + fb * t2[c] + cbar * q.n[c];
+    for (int c = 0; c < 3; ++c) fpw[c] = fa * q.t1[c] + fb * q.t2[c] + cbar * q.n[c];
     qpl_cross(q.d, fpw, dxf);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { pf[c] += fpw[c]; pm[c] += dxf[c]; }
@@ -211,18 +260,19 @@ WBC_DEV void qpl_newton(const QplFoot<T>* ft, const T* sS, T alpha, T fmin, T fm
 // todo[0] = number of states handed to the dense kernel (zeroed by qp_list_reset_kernel, launched in front of this kernel),
 // todo[2] = that number of the last tick (diagnostics), todo[4 ...] = their indices
 template <class T, bool RHAT>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_lane_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ todo) {
+__global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_WAVES)) void qp_lane_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ todo) {
+  __shared__ QplLds<T> L;
+  const unsigned tid = threadIdx.x;
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
-  const size_t s_raw = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t s_raw = (size_t)blockIdx.x * QPL_WG + tid;
   const bool live = s_raw < N;
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
 #define LLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define LST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
   const int mask = a.mask[s32] & 0xF;
   const bool geom_jc = a.Jc != nullptr;
-  // every input of the solve is requested before the first one is used: a wavefront is alone on its SIMD (register budget),
-  // so a load that waits exposes its whole latency
+  // every input of the solve is requested before the first one is used: a load that waits exposes its whole latency
   T in_d[12], in_n[12], in_mu[4], in_b[6], in_r[6];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -242,26 +292,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
   for (int c = 0; c < 6; ++c) { asm volatile("" : "+v"(in_b[c])); if (RHAT) asm volatile("" : "+v"(in_r[c])); }
 #pragma unroll
   for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(in_mu[c]));
-  QplFoot<T> ft[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool on = (mask >> k) & 1;
-    const T dx = in_d[3 * k], dy = in_d[3 * k + 1], dz = in_d[3 * k + 2];
-    T nx = in_n[3 * k], ny = in_n[3 * k + 1], nz = in_n[3 * k + 2];
-    const T iln = rsqrt_nr(nx * nx + ny * ny + nz * nz);
-    nx *= iln; ny *= iln; nz *= iln;
-    const bool usex = fabs_t(nx) < (T)0.9;
-    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
-    const T rd = rx * nx + ry * ny;
-    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
-    const T it = rsqrt_nr(t1x * t1x + t1y * t1y + t1z * t1z);
-    QplFoot<T>& q = ft[k];
-    q.on = on ? (T)1 : (T)0;
-    q.n[0] = nx; q.n[1] = ny; q.n[2] = nz;
-    q.t1[0] = t1x * it; q.t1[1] = t1y * it; q.t1[2] = t1z * it;
-    q.d[0] = on ? dx : (T)0; q.d[1] = on ? dy : (T)0; q.d[2] = on ? dz : (T)0;
-    q.m = in_mu[k] * prm.mu_scale;
-    q.i1 = rcp_nr((T)1 + q.m * q.m); q.i2 = rcp_nr((T)1 + (T)2 * q.m * q.m);
+    T n[3] = {in_n[3 * k], in_n[3 * k + 1], in_n[3 * k + 2]};
+    const T iln = rsqrt_nr(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    n[0] *= iln; n[1] *= iln; n[2] *= iln;
+    T t1[3];
+    qpl_tangent(n, (T)1, t1);
+    const T m = in_mu[k] * prm.mu_scale;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { L.n[c][k][tid] = n[c]; L.d[c][k][tid] = on ? in_d[3 * k + c] : (T)0; }
+    L.m[k][tid] = m;
+    L.it[k][tid] = rsqrt_nr(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+    L.i12[0][k][tid] = (float)rcp_nr((T)1 + m * m);
+    L.i12[1][k][tid] = (float)rcp_nr((T)1 + (T)2 * m * m);
   }
   T sS[6], beta[6];
   T bmax = 0;
@@ -275,56 +320,61 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
   const T tolF = (std::is_same<T, double>::value ? (T)1e-11 : (T)2e-5) * ((T)1 + bmax);
 
   // start: all faces free (the unconstrained minimum)
-  int code[4] = {QPL_FREE, QPL_FREE, QPL_FREE, QPL_FREE};
-  T e[6], F[6], fl[4][3];
-  qpl_newton(ft, sS, alpha, fmin, fmax, beta, code, e);
-  qpl_eval(ft, sS, ralpha, fmin, fmax, beta, e, fl, code, F);
+  int code = QPL_FREE | (QPL_FREE << 6) | (QPL_FREE << 12) | (QPL_FREE << 18);
+  T e[6], F[6];
+  qpl_newton(L, tid, mask, sS, alpha, fmin, fmax, beta, code, e);
+  qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, e, code, F);
   int iters = 0;
   bool conv = false;
   auto fnorm = [](const T* v) __attribute__((always_inline)) -> T {
     T m = 0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { const T x = v[c] < 0 ? -v[c] : v[c]; m = x > m ? x : m; }   // (NaN never compares greater: a NaN state stays unconverged by the test below)
+    for (int c = 0; c < 6; ++c) m = qpl_max(m, fabs_t(v[c]));   // (drops NaN components: nan6 below catches those)
     return m;
   };
-  auto nan6 = [](const T* v) __attribute__((always_inline)) -> bool { bool n = false;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) n = n || !(v[c] == v[c]);
-    return n; };
+  auto nan6 = [](const T* v) __attribute__((always_inline)) -> bool {   // a NaN (or an Inf - Inf) among the components
+    const T t = ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
+    return !(t - t == (T)0); };
+  // Live across an iteration: the current point e, F(e), its faces, the Newton direction; a trial point e + t dir with its
+  // F and faces; the accepted step length.  (No forces, no second copy of the point.)
+#pragma unroll 1
   for (int itn = 0; itn < QPL_MAX_NEWTON; ++itn) {
     conv = conv || (fnorm(F) <= tolF && !nan6(F));
     const bool act = live && !conv;
     if (__ballot(act) == 0ull) break;
     iters += act ? 1 : 0;
-    T eN[6], dir[6];
-    qpl_newton(ft, sS, alpha, fmin, fmax, beta, code, eN);
+    T dir[6];
+    {
+      T eN[6];
+      qpl_newton(L, tid, mask, sS, alpha, fmin, fmax, beta, code, eN);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dir[c] = eN[c] - e[c];
+    }
     T g0 = 0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { dir[c] = eN[c] - e[c]; g0 += F[c] * dir[c]; }
+    for (int c = 0; c < 6; ++c) g0 += F[c] * dir[c];
+    T Ft[6], et[6];
+    int codet;
+    T tacc = 0;
+    auto take = [&](bool who, T t) __attribute__((always_inline)) {   // the trial point becomes the current one
+      tacc = who ? t : tacc;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) F[c] = who ? Ft[c] : F[c];
+      code = who ? codet : code;
+    };
     // full step
-    T Ft[6], flt[4][3], et[6];
-    int codet[4];
-    qpl_eval(ft, sS, ralpha, fmin, fmax, beta, eN, flt, codet, Ft);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) et[c] = e[c] + dir[c];
+    qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, et, codet, Ft);
     T g1 = 0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { et[c] = eN[c]; g1 += Ft[c] * dir[c]; }
-    const bool same = codet[0] == code[0] && codet[1] == code[1] && codet[2] == code[2] && codet[3] == code[3];
+    for (int c = 0; c < 6; ++c) g1 += Ft[c] * dir[c];
+    const bool same = codet == code;
     const T ag0 = g0 < 0 ? -g0 : g0;
     bool need = act && !same && (g1 > (T)1e-12 * ag0);     // phi'(1) > 0: the step overshoots, bracket the root of phi' in (0, 1)
     T tl = 0, gl = g0, th = 1, gh = g1;
-    // the trial point becomes the current point for every active lane; lanes that line-search overwrite it below
-    auto take = [&](bool who) __attribute__((always_inline)) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) { e[c] = who ? et[c] : e[c]; F[c] = who ? Ft[c] : F[c]; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        code[k] = who ? codet[k] : code[k];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) fl[k][c] = who ? flt[k][c] : fl[k][c];
-      }
-    };
-    take(act);
-    conv = conv || (act && same && !nan6(Ft));     // faces unchanged by a full Newton step: eN IS the solution for those faces
+    take(act, (T)1);     // every active lane moves to the full step; lanes that line-search move again below
+    conv = conv || (act && same && !nan6(Ft));     // faces unchanged by a full Newton step: it IS the solution for those faces
 #pragma unroll 1
     for (int ls = 0; ls < QPL_LS_STEPS; ++ls) {
       if (__ballot(need) == 0ull) break;
@@ -333,18 +383,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
       t = t < lo ? lo : (t > hi ? hi : t);
       t = (t == t) ? t : (T)0.5 * (tl + th);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) et[c] = (eN[c] - dir[c]) + t * dir[c];   // e_old + t dir  (e_old = eN - dir)
-      qpl_eval(ft, sS, ralpha, fmin, fmax, beta, et, flt, codet, Ft);
+      for (int c = 0; c < 6; ++c) et[c] = e[c] + t * dir[c];
+      qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, et, codet, Ft);
       T gt = 0;
 #pragma unroll
       for (int c = 0; c < 6; ++c) gt += Ft[c] * dir[c];
       const bool pos = gt > 0;
       th = (need && pos) ? t : th; gh = (need && pos) ? gt : gh;
       tl = (need && !pos) ? t : tl; gl = (need && !pos) ? gt : gl;
-      take(need);
+      take(need, t);
       const T agt = gt < 0 ? -gt : gt;
       need = need && (agt > (T)1e-3 * ag0);
     }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { const T en = (tacc == (T)1) ? e[c] + dir[c] : e[c] + tacc * dir[c]; e[c] = act ? en : e[c]; }   // same expressions as the trial points
   }
   conv = conv || (fnorm(F) <= tolF && !nan6(F));
   // ---- outputs of the states solved here; the others go to the dense active-set kernel
@@ -360,17 +412,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? QPL_F32_WAVES : 1)) void qp_
         tp[3 * k + j] = LLD(a.ws, WS_TAUP + 3 * k + j);
         tr[3 * k + j] = RHAT ? LLD(a.ws, WS_RHAT + 6 + 3 * k + j) : (T)0;
       }
+    // the forces at the solution go to LDS while those loads are in flight (the frames live in LDS: there are registers to spare)
+    qpl_eval<T, true>(L, tid, mask, sS, ralpha, fmin, fmax, beta, e, code, F);
 #pragma unroll
     for (int c = 0; c < 36; ++c) asm volatile("" : "+v"(jl[c]));
 #pragma unroll
     for (int c = 0; c < 12; ++c) { asm volatile("" : "+v"(tp[c])); if (RHAT) asm volatile("" : "+v"(tr[c])); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const QplFoot<T>& q = ft[k];
-      T t2[3], fw[3];
-      qpl_cross(q.n, q.t1, t2);
+      const T fw[3] = {L.n[0][k][tid], L.n[1][k][tid], L.n[2][k][tid]};
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { fw[c] = fl[k][0] * q.t1[c] + fl[k][1] * t2[c] + fl[k][2] * q.n[c]; LST(a.f, 3 * k + c, fw[c]); }
+      for (int c = 0; c < 3; ++c) LST(a.f, 3 * k + c, fw[c]);
 #pragma unroll
       for (int j = 0; j < 3; ++j)   // tau of joint j of leg k = tau_partial - (own-leg Jacobian column) . f
         LST(a.tau, jmap.j[3 * k + j], (tp[3 * k + j] - tr[3 * k + j]) - (jl[9 * k + 3 * j] * fw[0] + jl[9 * k + 3 * j + 1] * fw[1] + jl[9 * k + 3 * j + 2] * fw[2]));

@@ -553,15 +553,18 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   int tile = s->opt.qp_tile;
   if (tile == 0) tile = N >= 20480 ? 64 : (N >= 12288 ? 32 : 0);
   if (tile < 0) tile = 0;
-  // Very large fp64 batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench,
+  // Very large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench,
   // 64 QPs per wavefront, no cross-lane traffic); the few per cent it does not finish within its iteration cap go through a
   // device-side list to the dense active-set kernel.  No host read: the list length stays on the device, the second launch is
-  // grid-stride over it.  Measured on MI355X, QP stage, dense kernel alone -> per-lane + list: configs[1] data 349 -> 174 + 64 us
-  // at 262 144 states, 176 -> 84 + 46 at 131 072, 92 -> 40 + 37 at 65 536, 48 -> 35 + 26 at 32 768 (a wavefront of the
-  // per-lane kernel takes ~35 us whatever the batch: it needs several rounds of wavefronts per SIMD to pay); observer-on data
-  // (easier QPs) 225 -> 162 + 31 at 262 144 but 52 -> 37 + 20 at 65 536.  fp32 does not gain (its per-lane kernel is no faster
-  // than the fp64 one, its dense kernel is).  Hence the default: fp64 from 131 072 states on.
-  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && s->dtype == WBC_F64 && N >= 131072);
+  // grid-stride over it.  Measured on MI355X, QP stage, dense kernel alone -> per-lane + list (us): configs[1] data
+  // 347 -> 119 + 66 at 262 144 states, 258 -> 106 + 56 at 196 608, 176 -> 60 + 46 at 131 072, 134 -> 55 + 41 at 98 304,
+  // 92 -> 51 + 34 at 65 536 (a wavefront of the per-lane kernel takes ~35 us whatever the batch, two share a SIMD: it needs
+  // 131 072 states to fill the device once); observer-on data (easier QPs) 225 -> 112 + 28 at 262 144, 103 -> 58 + 22 at
+  // 131 072, but 76 -> 54 + 23 at 98 304 and 52 -> 51 + 21 at 65 536; fp32 (configs[3]) 144 -> 94 + 28 at 262 144 but
+  // 101 -> 78 + 24 at 196 608 and 68 -> 49 + 23 at 131 072 (the per-lane kernel issues the same number of instructions in
+  // either precision, the dense kernel's fp32 instructions are cheaper).  Hence the default: fp64 from 131 072 states on,
+  // fp32 from 262 144.
+  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)131072 : (size_t)262144));
   if (lane) {
     TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, obs_split, dp, qa, s->jmap, s->d_todo));
     TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, 0, dp, qa, s->jmap, s->d_todo));
