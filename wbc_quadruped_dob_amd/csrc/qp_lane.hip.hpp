@@ -11,13 +11,12 @@
 // Semismooth Newton on F = primal-dual active set on the QP: with the faces the projections sit on (P_k = projector onto
 // the face's tangent space, f_k^p = its offset) the Newton iterate solves the 6x6 SPD system
 //     (alpha I + sum_k B_k P_k B_k^T) e+ = alpha (sum_k B_k f_k^p - beta),
-// i.e. the same matrix family as G of section 4.2.  Every lane runs this for ITS state in registers -- no cross-lane traffic,
-// 64 QPs per wavefront, loads and stores coalesced.  Undamped the iteration can cycle (under-determined stances), so the step
-// is globalised by a line search on phi'(t) = F(e + t dir) . dir (bracketing, a few projections), and a lane that has not
-// converged after QPL_MAX_NEWTON iterations hands its state to the dense active-set kernel through a list (a few per cent of
-// the bench data; NaN inputs end up there too and get their status from that kernel).  At convergence the faces are consistent
-// with the multipliers, so the result is the QP's unique solution: same f, tau as the oracle to rounding (1e-12 in fp64).
-// status = 0, iters = Newton iterations for the states solved here.
+// i.e. the same matrix family as G of section 4.2.  Every lane runs this for ITS state -- no cross-lane traffic,
+// 64 QPs per wavefront, loads and stores coalesced.  Undamped the iteration can cycle (under-determined stances): a lane that
+// has not converged when its wavefront stops iterating (policy below) hands its state to the dense active-set kernel through a
+// list (a few per cent of the bench data; NaN inputs end up there too and get their status from that kernel).  At
+// convergence the faces are consistent with the multipliers, so the result is the QP's unique solution: same f, tau as the
+// oracle to rounding (1e-12 in fp64).  status = 0, iters = Newton iterations (<= QPL_MAX_NEWTON) for the states solved here.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -26,14 +25,30 @@
 
 namespace wbc {
 
-// Iteration caps: measured on MI355X at N = 262 144 (fp64; per-lane kernel + dense kernel over the hand-over list, us):
-// (1 Newton, 0 line-search steps) 129 + 237, (2, 0) 139 + 160, (2, 2) 153 + 160, (3, 2) 174 + 64, (5, 3) 220 + 33; the dense
-// kernel alone: 349.
+// Iteration policy.  Every wavefront runs QPL_MIN_NEWTON iterations (fewer if all its lanes are done) and goes on, up to
+// QPL_MAX_NEWTON, only while at least QPL_MORE_LANES of its 64 lanes are still unconverged: one more iteration costs the
+// whole wavefront ~4 ns (of the device's time), a state handed to the dense kernel ~2.8 ns, and about half of the stragglers
+// converge in the next iteration.  Full steps, no line search: measured on MI355X (per-lane kernel + dense kernel over the
+// hand-over list, us, N = 262 144, fp64 configs[1] / fp64 observer-on / fp32 configs[3] data; dense kernel alone 347 / 225 / 144):
+//   fixed 3 iterations, 2 line-search steps   116 + 66 | 110 + 29 |  93 + 28
+//   fixed 3, 1 step                           107 + 68 | 101 + 32 |  86 + 30
+//   fixed 3, none                             110 + 71 | 100 + 35 |  85 + 34
+//   fixed 4, 2 steps                          132 + 33 | 124 + 25 | 109 + 26
+//   fixed 4, none                             109 + 40 | 113 + 34 |  96 + 34
+//   3 ... 5 while >= 4 lanes, 1 step          121 + 36 | 109 + 31 |  93 + 29
+//   3 ... 5 while >= 4 lanes, none            109 + 42 | 105 + 34 |  90 + 33
+//   3 ... 5 while >= 6 lanes, none            104 + 54 | 100 + 35 |  84 + 33
+// A bracketing line search on phi'(t) = F(e + t dir) . dir rescues a few per cent of the stragglers and costs every wavefront
+// an evaluation per step: it does not pay.  (An undamped semismooth Newton iteration can cycle on under-determined stances;
+// such a lane simply ends up in the hand-over list.)
 #ifndef QPL_MAX_NEWTON
-#define QPL_MAX_NEWTON 3
+#define QPL_MAX_NEWTON 5
 #endif
-#ifndef QPL_LS_STEPS
-#define QPL_LS_STEPS 2
+#ifndef QPL_MIN_NEWTON
+#define QPL_MIN_NEWTON 3
+#endif
+#ifndef QPL_MORE_LANES
+#define QPL_MORE_LANES 5
 #endif
 
 #ifndef QPL_F64_WAVES
@@ -335,68 +350,22 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
   auto nan6 = [](const T* v) __attribute__((always_inline)) -> bool {   // a NaN (or an Inf - Inf) among the components
     const T t = ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
     return !(t - t == (T)0); };
-  // Live across an iteration: the current point e, F(e), its faces, the Newton direction; a trial point e + t dir with its
-  // F and faces; the accepted step length.  (No forces, no second copy of the point.)
+  // Live across an iteration: the current point e, F(e) and its faces (no forces: they are recomputed once from the final e).
 #pragma unroll 1
   for (int itn = 0; itn < QPL_MAX_NEWTON; ++itn) {
     conv = conv || (fnorm(F) <= tolF && !nan6(F));
     const bool act = live && !conv;
-    if (__ballot(act) == 0ull) break;
+    const unsigned long long todo_lanes = __ballot(act);
+    if (todo_lanes == 0ull || (itn >= QPL_MIN_NEWTON && __popcll(todo_lanes) < QPL_MORE_LANES)) break;
     iters += act ? 1 : 0;
-    T dir[6];
-    {
-      T eN[6];
-      qpl_newton(L, tid, mask, sS, alpha, fmin, fmax, beta, code, eN);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) dir[c] = eN[c] - e[c];
-    }
-    T g0 = 0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) g0 += F[c] * dir[c];
-    T Ft[6], et[6];
+    T eN[6], Ft[6];
     int codet;
-    T tacc = 0;
-    auto take = [&](bool who, T t) __attribute__((always_inline)) {   // the trial point becomes the current one
-      tacc = who ? t : tacc;
+    qpl_newton(L, tid, mask, sS, alpha, fmin, fmax, beta, code, eN);
+    qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, eN, codet, Ft);
+    conv = conv || (act && codet == code && !nan6(Ft));     // faces unchanged by a full Newton step: it IS the solution for those faces
 #pragma unroll
-      for (int c = 0; c < 6; ++c) F[c] = who ? Ft[c] : F[c];
-      code = who ? codet : code;
-    };
-    // full step
-#pragma unroll
-    for (int c = 0; c < 6; ++c) et[c] = e[c] + dir[c];
-    qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, et, codet, Ft);
-    T g1 = 0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) g1 += Ft[c] * dir[c];
-    const bool same = codet == code;
-    const T ag0 = g0 < 0 ? -g0 : g0;
-    bool need = act && !same && (g1 > (T)1e-12 * ag0);     // phi'(1) > 0: the step overshoots, bracket the root of phi' in (0, 1)
-    T tl = 0, gl = g0, th = 1, gh = g1;
-    take(act, (T)1);     // every active lane moves to the full step; lanes that line-search move again below
-    conv = conv || (act && same && !nan6(Ft));     // faces unchanged by a full Newton step: it IS the solution for those faces
-#pragma unroll 1
-    for (int ls = 0; ls < QPL_LS_STEPS; ++ls) {
-      if (__ballot(need) == 0ull) break;
-      T t = tl - gl * (th - tl) * rcp_nr(gh - gl);
-      const T lo = tl + (T)0.1 * (th - tl), hi = th - (T)0.1 * (th - tl);
-      t = t < lo ? lo : (t > hi ? hi : t);
-      t = (t == t) ? t : (T)0.5 * (tl + th);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) et[c] = e[c] + t * dir[c];
-      qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, et, codet, Ft);
-      T gt = 0;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) gt += Ft[c] * dir[c];
-      const bool pos = gt > 0;
-      th = (need && pos) ? t : th; gh = (need && pos) ? gt : gh;
-      tl = (need && !pos) ? t : tl; gl = (need && !pos) ? gt : gl;
-      take(need, t);
-      const T agt = gt < 0 ? -gt : gt;
-      need = need && (agt > (T)1e-3 * ag0);
-    }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) { const T en = (tacc == (T)1) ? e[c] + dir[c] : e[c] + tacc * dir[c]; e[c] = act ? en : e[c]; }   // same expressions as the trial points
+    for (int c = 0; c < 6; ++c) { e[c] = act ? eN[c] : e[c]; F[c] = act ? Ft[c] : F[c]; }
+    code = act ? codet : code;
   }
   conv = conv || (fnorm(F) <= tolF && !nan6(F));
   // ---- outputs of the states solved here; the others go to the dense active-set kernel
