@@ -118,7 +118,7 @@ typedef struct wbc_solver_options {
                              second stream (measured slower: the two compete for the same SIMDs) */
   int qp_lane;            /* two-kernel ticks solve the QPs one state per LANE first (semismooth Newton on the residual wrench)
                              and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches from
-                             131072 states on, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
+                             65536 states on, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
                              iters = Newton iterations (<= 5); the others the dense kernel's status / iteration count */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);

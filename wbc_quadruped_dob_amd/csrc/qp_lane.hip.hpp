@@ -63,7 +63,10 @@ namespace wbc {
 #ifndef QPL_UNROLL_NEWTON
 #define QPL_UNROLL_NEWTON 1
 #endif
-constexpr int QPL_WG = 128;                          // threads per workgroup (LDS below: 36 kB fp64, 20 kB fp32)
+#ifndef QPL_WG_THREADS
+#define QPL_WG_THREADS 256   // measured 64 / 128 / 256: equal at 262 144 states (100-105 us); at 65 536 the 256-thread workgroups land one
+#endif                       // wavefront on every SIMD (36 us), the smaller ones double up on some CUs and leave others idle (44-45 us)
+constexpr int QPL_WG = QPL_WG_THREADS;   // threads per workgroup (LDS below: 72 kB fp64, 40 kB fp32)
 constexpr int QPL_FREE = 1 | (1 << 2) | (1 << 4);   // no face active
 
 // The contact frames live in LDS, one slot per lane ([component][foot][lane]: conflict-free), and the loops over the feet are

@@ -553,18 +553,18 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   int tile = s->opt.qp_tile;
   if (tile == 0) tile = N >= 20480 ? 64 : (N >= 12288 ? 32 : 0);
   if (tile < 0) tile = 0;
-  // Very large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench,
-  // 64 QPs per wavefront, no cross-lane traffic); the few per cent it does not finish within its iteration cap go through a
-  // device-side list to the dense active-set kernel.  No host read: the list length stays on the device, the second launch is
-  // grid-stride over it.  Measured on MI355X, QP stage, dense kernel alone -> per-lane + list (us): configs[1] data
-  // 347 -> 119 + 66 at 262 144 states, 258 -> 106 + 56 at 196 608, 176 -> 60 + 46 at 131 072, 134 -> 55 + 41 at 98 304,
-  // 92 -> 51 + 34 at 65 536 (a wavefront of the per-lane kernel takes ~35 us whatever the batch, two share a SIMD: it needs
-  // 131 072 states to fill the device once); observer-on data (easier QPs) 225 -> 112 + 28 at 262 144, 103 -> 58 + 22 at
-  // 131 072, but 76 -> 54 + 23 at 98 304 and 52 -> 51 + 21 at 65 536; fp32 (configs[3]) 144 -> 94 + 28 at 262 144 but
-  // 101 -> 78 + 24 at 196 608 and 68 -> 49 + 23 at 131 072 (the per-lane kernel issues the same number of instructions in
-  // either precision, the dense kernel's fp32 instructions are cheaper).  Hence the default: fp64 from 131 072 states on,
-  // fp32 from 262 144.
-  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)131072 : (size_t)262144));
+  // Large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench, 64 QPs
+  // per wavefront, no cross-lane traffic); the few per cent it does not finish go through a device-side list to the dense
+  // active-set kernel.  No host read: the list length stays on the device, the second launch is grid-stride over it.
+  // Measured on MI355X, QP stage, dense kernel alone -> per-lane + list (us), fp64 configs[1] data: 356 -> 101 + 45 at
+  // 262 144 states, 175 -> 54 + 34 at 131 072, 133 -> 50 + 33 at 98 304, 91 -> 36 + 32 at 65 536, 78 -> 32 + 26 at 49 152
+  // (32 768: 48 -> 31 + 25: a wavefront of the per-lane kernel takes ~32 us whatever the batch, and the list kernel at least
+  // the ~20 us of its longest QP); fp64 observer-on data (easier QPs): 223 -> 97 + 34 at 262 144, 102 -> 51 + 23 at 131 072,
+  // 76 -> 47 + 24 at 98 304, but 51 -> 35 + 21 at 65 536 and 43 -> 32 + 20 at 49 152; fp32 (configs[3]): 144 -> 84 + 34 at
+  // 262 144 but 101 -> 78 + 24 at 196 608 and 68 -> 49 + 23 at 131 072 (the per-lane kernel issues the same number of
+  // instructions in either precision, the dense kernel's fp32 instructions are cheaper).  Hence the default: fp64 from
+  // 65 536 states on (+19 % per tick on the harder data, -6 % on the easier), fp32 from 262 144.
+  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)65536 : (size_t)262144));
   if (lane) {
     TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, obs_split, dp, qa, s->jmap, s->d_todo));
     TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, 0, dp, qa, s->jmap, s->d_todo));
