@@ -37,7 +37,7 @@ for c in range(cases):
     n = int(rng.choice([1, 7, 16, 17, 100, 1000, 2048, 4096, 5000, 8192][: (10 if obs == 0 else 8)]))
     if rng.random() < 0.3:
         n = int(rng.integers(1, 4097))
-    big = DT == "f64" and c % 7 == 3   # a larger batch: the tiled QP kernel (dealt by predicted work) against the one-wave kernel
+    big = DT == "f64" and c % 7 == 3   # a larger batch: the tiled QP kernel (dealt by predicted work) and the per-lane kernel against the one-wave kernel
     if big:
         n = int(rng.integers(12288, 60000))
     B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
@@ -45,7 +45,7 @@ for c in range(cases):
     z = lambda: (None if integ0 is None else integ0.copy(), None if integ0 is None else np.zeros((n, 18)))
     if big:
         res = {}
-        for tag, opt in (("tiled", {"qp_tile": int(rng.choice([0, 32, 64, 128]))}), ("plain", {"qp_tile": -1})):
+        for tag, opt in (("tiled", {"qp_tile": int(rng.choice([0, 32, 64, 128])), "qp_lane": -1}), ("plain", {"qp_tile": -1, "qp_lane": -1}), ("lane", {"qp_lane": 1})):
             s, P = solver_with(opt, obs=obs, max_batch=n)
             a1 = _run_step(torch, s, B, "f64", *z(), want_mats=bool(c % 2))
             a2 = _run_step(torch, s, B, "f64", a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
@@ -54,6 +54,17 @@ for c in range(cases):
             for k in res["plain"][i]:
                 if not np.array_equal(res["tiled"][i][k], res["plain"][i][k]):
                     bad.append((c, "tiled " + k, n, obs, cfg))
+        for i in (0, 1):   # per-lane semismooth Newton + hand-over list: another algorithm, same unique solution
+            a, b = res["lane"][i], res["plain"][i]
+            if not np.array_equal(a["status"], b["status"]):
+                bad.append((c, "lane status", n, obs, cfg))
+            for k in b:
+                if k in ("status", "iters"):
+                    continue
+                e = relerr(a[k], b[k])
+                worst = max(worst, e)
+                if not e < 1e-9:
+                    bad.append((c, "lane " + k, n, obs, cfg, e))
         if c % 2:
             ig, r = z()
             ref = orc.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"], ig, r, nthreads=8)
