@@ -196,8 +196,18 @@ __host__ __device__ constexpr int midx18(int i, int j) { return i * 18 - i * (i 
 template <class T, int MODE, int BLOCK>
 WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0;
-  __shared__ T cst[CST_WORDS];
-  __shared__ int zidx_s[64];
+  // ONE LDS object with the constant table first: ds_read / ds_write reach base + 16-bit offset, and the compiler places
+  // separate __shared__ arrays largest-first -- behind the 74 kB parking area of a 256-thread workgroup every table word
+  // needed an address register of its own (150 v_or_b32 in the tick's sweep, and the registers to hold them)
+  constexpr int PW = 15;                   // parked words per joint: E 9 + body wrench 6
+  constexpr int PB = 6;                    // parked words of the base body's own wrench
+  constexpr int PE2 = OBS ? 9 : 0;         // observer: E of joint 2 too (the momentum pass walks the leg again)
+  struct Lds { T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; T park[2 * PW + PB + PE2][BLOCK]; };
+  __shared__ Lds lds;
+  T (&cst)[CST_WORDS] = lds.cst;
+  int (&zidx_s)[64] = lds.zidx_s;
+  T (&kgain)[OBS ? 36 : 2] = lds.kgain;
+  T (&park)[2 * PW + PB + PE2][BLOCK] = lds.park;
 #ifdef WBC_SWEEP_STAMP  // diagnostic build only: cycle stamps per phase, written over the pf output
   long long stp[13];
   int stn = 0;
@@ -255,7 +265,6 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   if (MATS && threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
   // observer gains of the joint rows are indexed by a run-time joint number: from LDS (a dynamic index into the
   // kernel-argument struct can end up as a private copy of the whole struct)
-  __shared__ T kgain[OBS ? 36 : 1];
   if (OBS && threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < 18; ++i) { kgain[i] = prm.K1[i]; kgain[18 + i] = prm.K2[i]; }  // static indices only
@@ -337,10 +346,6 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
   bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
   // the base body's own wrench / momentum / weight are formed now, so that om0, v0, aL0 die after joint 0
-  constexpr int PW = 15;                   // parked words per joint: E 9 + body wrench 6
-  constexpr int PB = 6;                    // parked words of the base body's own wrench
-  constexpr int PE2 = OBS ? 9 : 0;         // observer: E of joint 2 too (the momentum pass walks the leg again)
-  __shared__ T park[2 * PW + PB + PE2][BLOCK];
   const int ln = threadIdx.x;
 #define XSUM(arr, K) xrow_sum_k<T, K>(arr)
   V3<T> omp, vp, aAp, aLp;

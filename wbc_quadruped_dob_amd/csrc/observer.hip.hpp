@@ -1,13 +1,17 @@
 // Momentum-observer update as its own kernel (unit a5/a6 without the rest of the sweep) for LARGE observer-on batches.
 // The all-in-one observer sweep (dyn_sweep_kernel<.., SW_OBS>) needs 370 VGPRs and 28 kB of LDS per wavefront, i.e. one
 // wave per SIMD; without the observer passes the sweep runs at two.  Here the observer is a light kernel -- per leg only
-// the kinematics, body momenta, gravity terms and the own-leg Jacobian, everything in registers, no parking -- that runs
-// on the solver's second stream beside dyn_sweep<M, h, Jc + step>.  It reads q, v, tau_prev, f_prev and the observer
-// state, writes the new state and rhat (18 words at WS_RHAT of the step workspace); the QP kernel completes
-// b = w_des - rhat_base and tau_partial - rhat_joint itself (qp_group16_body<.., RHAT>).
-// OPT-IN (WBC_OBS_SPLIT_MIN): measured at N = 262 144 it helps fp32 (0.482 -> 0.441 ms per tick) and hurts fp64 (0.713 ->
-// 0.810 ms: this kernel alone takes as long as the sweep it runs beside -- 256 VGPRs + a 324-byte spill, and both
-// compete for the same VALUs); at N = 32 768 it loses for both.  Kept parity-green as the starting point for round 2.
+// the kinematics, body momenta, gravity terms and the own-leg Jacobian -- that runs in front of dyn_sweep<M, h, Jc + step>.
+// It reads q, v, tau_prev, f_prev and the observer state, writes the new state and rhat (18 words at WS_RHAT of the step
+// workspace); the QP kernel completes b = w_des - rhat_base and tau_partial - rhat_joint itself (qp_group16_body<.., RHAT>).
+// Round 1 measured this kernel at 236 us (N = 262 144, fp64: 255 VGPRs + a 324-byte spill), as long as the sweep it was
+// meant to relieve.  What held the registers was not the algorithm but two things the compiler did with it (found by a
+// liveness scan of the ISA, round 2): (1) the sweep's results only feed stores guarded by `live`, so the arithmetic was sunk
+// into that guarded region and the ~160 LDS reads of the whole return sweep were left in one row in front of it; (2) in a
+// 256-thread workgroup the constant table sat behind a 68 kB array in LDS, out of reach of the 16-bit ds_read offset.  With
+// the carried values pinned per joint, one LDS object (table first) and the forward sweep's per-joint state parked in LDS:
+// 170 VGPRs, no scratch, 112 us fp64 / 57 us fp32 -- default for fp64 observer-on batches from 65 536 states on
+// (fp32: 98 304); see wbc_api.cpp for the A/B.
 // Same lane mapping as the sweep (lane = 16*leg + state), same formulas as the observer role of the fused tick
 // (rnea_step_body<RS_OBS | RS_OBSW>): beta = C^T v - g from the momentum recursion, see DESIGN.md section 3.
 #pragma once
@@ -28,7 +32,14 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   static_assert(EXT == 0 || BLOCK == 64, "one wavefront");
   static_assert(PART == 0 || EXT != 0, "split parts exist only as roles");
   constexpr bool BASE = PART != 2, JOINTS = PART != 1;
-  __shared__ T cst_own[EXT ? 1 : CST_WORDS];
+  // (one LDS object, constant table first: see dyn_sweep.hip.hpp)
+  constexpr bool PARK = EXT == 0;
+  constexpr int PKW = 11;
+  struct Lds { T cst_own[EXT ? 1 : CST_WORDS]; T kgain[EXT ? 1 : 36]; T park[PARK ? 3 * PKW : 1][PARK ? BLOCK : 1]; };
+  __shared__ Lds lds;
+  T (&cst_own)[EXT ? 1 : CST_WORDS] = lds.cst_own;
+  T (&kgain)[EXT ? 1 : 36] = lds.kgain;
+  T (&park)[PARK ? 3 * PKW : 1][PARK ? BLOCK : 1] = lds.park;
   const T* cst = EXT ? cst_ext : cst_own;
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
@@ -69,6 +80,12 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
       const int i = min(i0 + (int)tx, CST_WORDS - 1);
       cst_own[i] = model->cst[i];
     }
+    // the gains of the joint rows are indexed by a run-time joint number: from LDS (as a chain of selects on the kernel
+    // arguments they were 24 doubles moved into vector registers per joint)
+    if (tx == 0) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) { kgain[i] = prm.K1[i]; kgain[18 + i] = prm.K2[i]; }  // static indices only
+    }
     __syncthreads();
   }
   if constexpr (EXT == 2) __syncthreads();
@@ -78,25 +95,40 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
     const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
-  M3<T> R;
-  {
+  // base rotation, base body inertia, base velocity / gravity in base coordinates.  The stand-alone kernel forms them twice --
+  // here for the forward sweep and again after the return sweep, from the (laundered) quaternion and a second read of v --
+  // so that 34 values do not live through both sweeps; the roles keep them.
+  auto base_state = [&](const T* vbx, M3<T>& R, T& bm, V3<T>& bh, S3<T>& bI, V3<T>& om0, V3<T>& v0, V3<T>& gneg) __attribute__((always_inline)) {
     const T x = qx, y = qy, z = qz, w = qw;
     R.a[0] = 1 - 2 * (y * y + z * z); R.a[1] = 2 * (x * y - z * w);     R.a[2] = 2 * (x * z + y * w);
     R.a[3] = 2 * (x * y + z * w);     R.a[4] = 1 - 2 * (x * x + z * z); R.a[5] = 2 * (y * z - x * w);
     R.a[6] = 2 * (x * z - y * w);     R.a[7] = 2 * (y * z + x * w);     R.a[8] = 1 - 2 * (x * x + y * y);
-  }
-  const T bm = model->base_m;
-  const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
+    bm = model->base_m;
+    bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
+    bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
+    bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
+    om0 = tmul(R, mk<T>(vbx[3], vbx[4], vbx[5]));
+    v0 = tmul(R, mk<T>(vbx[0], vbx[1], vbx[2]));
+    gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));   // R^T (-g)
+  };
+  M3<T> R;
+  T bm;
+  V3<T> bh, om0, v0, gneg;
   S3<T> bI;
-  bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
-  bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
-  const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
-  const V3<T> v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
-  const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));   // R^T (-g)
+  base_state(vb, R, bm, bh, bI, om0, v0, gneg);
 
-  // ---- forward sweep down the leg: joint rotations, body velocities, body momenta, weights (all kept in registers)
-  M3<T> E[3];
-  V3<T> om[3], vv[3], gL[3];   // body momenta / weights are re-formed from these in the return sweep (fewer live registers)
+  // ---- forward sweep down the leg: joint rotations, body velocities, weights.
+  // Roles (EXT != 0) keep them in registers.  The stand-alone kernel PARKS what the return sweep needs in LDS
+  // ([word][lane], conflict-free): sin/cos of the joint angle (E is rebuilt from them: 18 FMAs on constants that are read from
+  // LDS anyway) and the body's velocity and gravity direction -- 11 words per joint instead of 54 live values through both
+  // sweeps, which was 255 VGPRs + a 324-byte spill at two wavefronts per SIMD (236 us at N = 262 144, fp64).
+  M3<T> E[PARK ? 1 : 3];
+  V3<T> om[PARK ? 1 : 3], vv[PARK ? 1 : 3], gL[PARK ? 1 : 3];   // body momenta / weights are re-formed from these in the return sweep (fewer live registers)
+  auto joint_E = [&](int k, T sn, T cs, M3<T>& Ek) __attribute__((always_inline)) {
+    const int o = JOINT_WORDS * k;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Ek.a[e] = OCS(o + e) + cs * OCS(o + 9 + e) + sn * OCS(o + 18 + e);
+  };
   {
     V3<T> omp = om0, vp = v0, gp = gneg;
 #pragma unroll
@@ -104,16 +136,29 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
       const int o = JOINT_WORDS * k;
       T sn, cs;
       sincos_t(ql[k], &sn, &cs);
-#pragma unroll
-      for (int e = 0; e < 9; ++e) E[k].a[e] = OCS(o + e) + cs * OCS(o + 9 + e) + sn * OCS(o + 18 + e);
+      M3<T> Ek;
+      joint_E(k, sn, cs, Ek);
       const V3<T> r = mk<T>(OCS(o + 27), OCS(o + 28), OCS(o + 29));
       const V3<T> ax = mk<T>(OCS(o + 30), OCS(o + 31), OCS(o + 32));
-      om[k] = tmul(E[k], omp) + ax * vl[k];
-      vv[k] = tmul(E[k], vp + cross(omp, r));
-      gL[k] = tmul(E[k], gp);
-      omp = om[k]; vp = vv[k]; gp = gL[k];
+      const V3<T> omk = tmul(Ek, omp) + ax * vl[k];
+      const V3<T> vvk = tmul(Ek, vp + cross(omp, r));
+      const V3<T> gk = tmul(Ek, gp);
+      if constexpr (PARK) {
+        T* pk = &park[PKW * k][tx];
+        pk[0] = sn; pk[BLOCK] = cs;
+        pk[BLOCK * 2] = omk.x; pk[BLOCK * 3] = omk.y; pk[BLOCK * 4] = omk.z;
+        pk[BLOCK * 5] = vvk.x; pk[BLOCK * 6] = vvk.y; pk[BLOCK * 7] = vvk.z;
+        pk[BLOCK * 8] = gk.x; pk[BLOCK * 9] = gk.y; pk[BLOCK * 10] = gk.z;
+      } else {
+        E[k] = Ek; om[k] = omk; vv[k] = vvk; gL[k] = gk;
+      }
+      omp = omk; vp = vvk; gp = gk;
+      if constexpr (PARK) __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // (without this the compiler keeps the forward sweep's 99 table words in registers for the return sweep instead of reading
+  // them from LDS again)
+  if constexpr (PARK) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
   // ---- return sweep: subtree momentum / weight, their projections on the joint axes, foot geometry
   T p_leg[3], beta_l[3];
   V3<T> dft = mk<T>(OCS(129), OCS(130), OCS(131));
@@ -128,86 +173,133 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
     const V3<T> h = mk<T>(OCS(o + 34), OCS(o + 35), OCS(o + 36));
     S3<T> Io;
     Io.xx = OCS(o + 37); Io.xy = OCS(o + 38); Io.xz = OCS(o + 39); Io.yy = OCS(o + 40); Io.yz = OCS(o + 41); Io.zz = OCS(o + 42);
-    SF<T> mk_ = inertia_mul(m, h, Io, om[k], vv[k]), gk;
-    gk.n = cross(h, gL[k]);
-    gk.f = gL[k] * m;
+    M3<T> Ek;
+    V3<T> omk, vvk, glk;
+    if constexpr (PARK) {
+      const T* pk = &park[PKW * k][tx];
+      joint_E(k, pk[0], pk[BLOCK], Ek);
+      omk = mk<T>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]);
+      vvk = mk<T>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]);
+      glk = mk<T>(pk[BLOCK * 8], pk[BLOCK * 9], pk[BLOCK * 10]);
+    } else {
+      Ek = E[k]; omk = om[k]; vvk = vv[k]; glk = gL[k];
+    }
+    SF<T> mk_ = inertia_mul(m, h, Io, omk, vvk), gk;
+    gk.n = cross(h, glk);
+    gk.f = glk * m;
     if (k < 2) { mk_.n = mk_.n + macc.n; mk_.f = mk_.f + macc.f; gk.n = gk.n + gacc.n; gk.f = gk.f + gacc.f; }
     p_leg[k] = dot(ax, mk_.n);
-    beta_l[k] = -dot(ax, cross(om[k], mk_.n) + cross(vv[k], mk_.f)) - dot(ax, gk.n);   // (C^T v)_k - g_k
+    beta_l[k] = -dot(ax, cross(omk, mk_.n) + cross(vvk, mk_.f)) - dot(ax, gk.n);   // (C^T v)_k - g_k
     jc[k] = cross(ax, dft);
-    dft = r + mul(E[k], dft);
+    dft = r + mul(Ek, dft);
 #pragma unroll
-    for (int j = k; j < 3; ++j) jc[j] = mul(E[k], jc[j]);
-    macc = to_parent(E[k], r, mk_);
-    gacc = to_parent(E[k], r, gk);
+    for (int j = k; j < 3; ++j) jc[j] = mul(Ek, jc[j]);
+    macc = to_parent(Ek, r, mk_);
+    gacc = to_parent(Ek, r, gk);
+    // One joint at a time.  The results of the sweep only feed stores guarded by `live`, so the compiler sinks the whole
+    // arithmetic into that guarded region and leaves the LDS reads of all three iterations (~160 doubles: table words and
+    // parked values) in a row in front of it.  Passing the carried values through an empty asm statement pins each
+    // iteration's arithmetic where it is written.
+    if constexpr (PARK) {
+      asm volatile("" : "+v"(macc.n.x), "+v"(macc.n.y), "+v"(macc.n.z), "+v"(macc.f.x), "+v"(macc.f.y), "+v"(macc.f.z));
+      asm volatile("" : "+v"(gacc.n.x), "+v"(gacc.n.y), "+v"(gacc.n.z), "+v"(gacc.f.x), "+v"(gacc.f.y), "+v"(gacc.f.z));
+      asm volatile("" : "+v"(dft.x), "+v"(dft.y), "+v"(dft.z), "+v"(p_leg[k]), "+v"(beta_l[k]));
+#pragma unroll
+      for (int j = k; j < 3; ++j) asm volatile("" : "+v"(jc[j].x), "+v"(jc[j].y), "+v"(jc[j].z));
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  const V3<T> dw = mul(R, dft);
-  V3<T> jw[3];
+  if constexpr (EXT == 0) {   // see base_state
+    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
+    asm volatile("" ::: "memory");
 #pragma unroll
-  for (int k = 0; k < 3; ++k) jw[k] = mul(R, jc[k]);
-
-  // ---- base rows: the four legs + the base body itself
-  T p_b[6] = {0, 0, 0, 0, 0, 0}, beta_b[6] = {0, 0, 0, 0, 0, 0};
-  if constexpr (BASE) {
-    const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
-    T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
-    xrow_sum_k<T, 12>(xb);
-    const V3<T> m0n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n, m0f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
-    const V3<T> g0n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg), g0f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
-    const V3<T> Pl = mul(R, m0f), Pa = mul(R, m0n);
-    const V3<T> gl = mul(R, g0f), ga = mul(R, g0n);
-    const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
-    p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
-    beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
-    beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
+    for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
+    base_state(vb, R, bm, bh, bI, om0, v0, gneg);
   }
-  // ---- observer update (order 1 or 2) and rhat for the QP kernel
-  T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
-  if (prm.observer_order > 0) {
-    const V3<T> fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
-    const T dt = prm.dt;
-    const bool o1 = prm.observer_order == 1;
-    if constexpr (BASE) {
-      const V3<T> dxf = cross(dw, fp);
-      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
-      xrow_sum_k<T, 6>(ub);
+  // ---- observer update (order 1 or 2) and rhat for the QP kernel, in two phases.  The stand-alone kernel finishes the joint
+  // rows first (their inputs -- Jacobian columns, leg momenta -- die there) and forms the base rows afterwards; with both in
+  // flight at once the tail of the kernel was its register peak.
+  const bool obs_on = prm.observer_order > 0;
+  const T dt = prm.dt;
+  const bool o1 = prm.observer_order == 1;
+  V3<T> fp = mk<T>(0, 0, 0);
+  if (obs_on) fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
+  auto joint_rows = [&]() __attribute__((always_inline)) {
+    if constexpr (JOINTS) {
+      T rl[3] = {0, 0, 0};
+      if (obs_on) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const T r0 = OLDU(a.obs_r, c);
-        const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
-        const T e = p_b[c] - ig;
-        rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
-        p_b[c] = ig;
+        for (int k = 0; k < 3; ++k) {
+          const int c = 6 + jx[k];
+          const T r0 = OLDV(a.obs_r, c);
+          const T u = OLDV(a.tau_prev, jx[k]) + dot(mul(R, jc[k]), fp);
+          const T ig = OLDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
+          const T e = p_leg[k] - ig;
+          T k1, k2;
+          if constexpr (EXT == 0) { k1 = kgain[c]; k2 = kgain[18 + c]; }
+          else {
+            k1 = prm.K1[6]; k2 = prm.K2[6];   // roles: gains of joint row c by a select (no run-time index into the kernel arguments)
+#pragma unroll
+            for (int j = 1; j < 12; ++j) { k1 = (jx[k] == j) ? prm.K1[6 + j] : k1; k2 = (jx[k] == j) ? prm.K2[6 + j] : k2; }
+          }
+          rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
+          OSTV(a.obs_integ, c, ig);
+          OSTV(a.obs_r, c, rl[k]);
+        }
       }
-      // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
-      // of the wave before any lane stores to it
-      OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
-      if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
-      OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
-      if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
     }
+  };
+  auto base_rows = [&]() __attribute__((always_inline)) {
+    if constexpr (BASE) {
+      // the four legs + the base body itself
+      T p_b[6], beta_b[6];
+      {
+        const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+        T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
+        xrow_sum_k<T, 12>(xb);
+        const V3<T> m0n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n, m0f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
+        const V3<T> g0n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg), g0f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
+        const V3<T> Pl = mul(R, m0f), Pa = mul(R, m0n);
+        const V3<T> gl = mul(R, g0f), ga = mul(R, g0n);
+        const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
+        p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
+        beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
+        beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
+      }
+      T rb[6] = {0, 0, 0, 0, 0, 0};
+      if (obs_on) {
+        const V3<T> dxf = cross(mul(R, dft), fp);
+        T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+        xrow_sum_k<T, 6>(ub);
 #pragma unroll
-    for (int k = 0; k < (JOINTS ? 3 : 0); ++k) {
-      const int c = 6 + jx[k];
-      const T r0 = OLDV(a.obs_r, c);
-      const T u = OLDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
-      const T ig = OLDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
-      const T e = p_leg[k] - ig;
-      T k1 = prm.K1[6], k2 = prm.K2[6];   // gains of joint row c by a select (no run-time index into the kernel arguments)
-#pragma unroll
-      for (int j = 1; j < 12; ++j) { k1 = (jx[k] == j) ? prm.K1[6 + j] : k1; k2 = (jx[k] == j) ? prm.K2[6 + j] : k2; }
-      rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
-      OSTV(a.obs_integ, c, ig);
-      OSTV(a.obs_r, c, rl[k]);
+        for (int c = 0; c < 6; ++c) {
+          const T r0 = OLDU(a.obs_r, c);
+          const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
+          const T e = p_b[c] - ig;
+          rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+          p_b[c] = ig;
+        }
+        // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
+        // of the wave before any lane stores to it
+        OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+        if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+        OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+        if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+      }
+      ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
+      if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
     }
-  }
-  if constexpr (BASE) {
-    ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
-    if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
-  }
-  if constexpr (JOINTS) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
+  };
+  if constexpr (EXT == 0) {
+    joint_rows();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    base_rows();
+  } else {
+    base_rows();
+    joint_rows();
   }
 #undef ORHAT
 #undef OST4
@@ -217,8 +309,11 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 #undef OCS
 }
 
+#ifndef WBC_OBS_WAVES
+#define WBC_OBS_WAVES 2
+#endif
 template <class T, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void observer_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a) {
+__global__ __launch_bounds__(BLOCK, WBC_OBS_WAVES) void observer_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a) {
   observer_body<T, BLOCK, 0>(model, prm, a, nullptr, nullptr);
 }
 

@@ -312,11 +312,12 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (!s) return fail(WBC_E_INVALID, "out of memory");
   s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p; s->opt = o;
   if (o.fused_max >= 0) s->fused_max = s->fused_max_noobs = (size_t)o.fused_max;
-  // observer as its own kernel before the sweep: measured on MI355X at 262 144 states, fp32: sweep 296 -> 159 + 83 us (the
-  // all-in-one observer sweep runs one wavefront per SIMD); fp64: 457 -> 273 + 236 us (the fp64 observer kernel is as slow
-  // as the sweep: 255 VGPRs + spill) -- so the default splits fp32 batches from 98 304 states on and fp64 never
+  // observer as its own kernel before the sweep (the all-in-one observer sweep runs one wavefront per SIMD).  Measured on
+  // MI355X, front half of the tick, all-in-one -> observer kernel + observer-free sweep (us): fp64 464 -> 112 + 279 at
+  // 262 144 states, 111 -> 34 + 57 at 65 536, but 48 -> 25 + 33 at 32 768; fp32 298 -> 57 + 168 at 262 144, 45 -> 17 + 27 at
+  // 65 536 (a tie per tick), 26 -> 13 + 16 at 32 768.  Default: fp64 from 65 536 states on, fp32 from 98 304.
   if (o.obs_split_min >= 0) s->obs_split_min = (size_t)o.obs_split_min;
-  else if (o.obs_split_min == -1 && dtype == WBC_F32) s->obs_split_min = 98304;
+  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 98304 : 65536;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
@@ -528,9 +529,9 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     const int mode = RS_STEP | (ob ? RS_OBS : 0) | (out->pf ? RS_PF : 0);
     TIMED_LAUNCH(2, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
   } else if (ob && N >= s->obs_split_min) {
-    // large observer-on batch: the observer update runs as its own light kernel on the second stream while dyn_sweep
-    // WITHOUT the observer passes (252 instead of 370 VGPRs: two waves per SIMD, shared tables) writes M, h, Jc; rhat
-    // travels through 18 extra workspace words and the QP kernel completes b and tau_partial with it
+    // large observer-on batch: the observer update runs as its own light kernel in front of (option: beside, on the second
+    // stream) a dyn_sweep WITHOUT the observer passes (252 instead of 370 VGPRs: two waves per SIMD, shared tables), which writes
+    // M, h, Jc; rhat travels through 18 extra workspace words and the QP kernel completes b and tau_partial with it
     obs_split = true;
     if (s->opt.obs_split_serial) {   // same stream, one after the other
       TIMED_LAUNCH(2, st, "observer", k_observer<T>(L, dev_model<T>(s), dp, a));
