@@ -199,15 +199,21 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   // ONE LDS object with the constant table first: ds_read / ds_write reach base + 16-bit offset, and the compiler places
   // separate __shared__ arrays largest-first -- behind the 74 kB parking area of a 256-thread workgroup every table word
   // needed an address register of its own (150 v_or_b32 in the tick's sweep, and the registers to hold them)
-  constexpr int PW = 15;                   // parked words per joint: E 9 + body wrench 6
+  // Parked per lane ([word][lane], conflict-free): for joints 0 and 1 sin / cos of the joint angle (E is rebuilt from them in
+  // the return sweep: 18 FMAs on table words; parking E itself took 9 words) and the body wrench; the base body's wrench; and
+  // the inputs the END of the kernel needs -- base acceleration and base position -- which are loaded with everything else at
+  // the top: a wavefront that loads them where it uses them exposes a whole memory latency each time (two wavefronts per SIMD
+  // do not hide it), measured 251-264 -> 224-226 us at N = 262 144.
+  constexpr int PW = 8;                    // parked words per joint: sin, cos + body wrench 6
   constexpr int PB = 6;                    // parked words of the base body's own wrench
-  constexpr int PE2 = OBS ? 9 : 0;         // observer: E of joint 2 too (the momentum pass walks the leg again)
-  struct Lds { T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; T park[2 * PW + PB + PE2][BLOCK]; };
+  constexpr int PE2 = OBS ? 2 : 0;         // observer: sin, cos of joint 2 too (the momentum pass walks the leg again)
+  constexpr int PX = 9;                    // vdot_des base rows 6, base position 3
+  struct Lds { T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; T park[2 * PW + PB + PE2 + PX][BLOCK]; };
   __shared__ Lds lds;
   T (&cst)[CST_WORDS] = lds.cst;
   int (&zidx_s)[64] = lds.zidx_s;
   T (&kgain)[OBS ? 36 : 2] = lds.kgain;
-  T (&park)[2 * PW + PB + PE2][BLOCK] = lds.park;
+  T (&park)[2 * PW + PB + PE2 + PX][BLOCK] = lds.park;
 #ifdef WBC_SWEEP_STAMP  // diagnostic build only: cycle stamps per phase, written over the pf output
   long long stp[13];
   int stn = 0;
@@ -257,6 +263,15 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   for (int k = 0; k < 3; ++k) {
     ql[k] = *(const T*)((const char*)(a.q + (size_t)7 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
     vl[k] = *(const T*)((const char*)(a.v + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+  }
+  // desired accelerations: needed in and after the return sweep, requested here (see the parking comment above)
+  T al[3] = {0, 0, 0}, ad_in[6] = {0, 0, 0, 0, 0, 0};
+  if (STEP) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      al[k] = *(const T*)((const char*)(a.vdot_des + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ad_in[c] = LDU(a.vdot_des, c);
   }
 
   SSTAMP();  // 1: state loads issued
@@ -347,6 +362,12 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
   // the base body's own wrench / momentum / weight are formed now, so that om0, v0, aL0 die after joint 0
   const int ln = threadIdx.x;
+  T* const px = &park[2 * PW + PB + PE2][ln];
+  {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) px[BLOCK * c] = ad_in[c];
+    px[BLOCK * 6] = qb[0]; px[BLOCK * 7] = qb[1]; px[BLOCK * 8] = qb[2];
+  }
 #define XSUM(arr, K) xrow_sum_k<T, K>(arr)
   V3<T> omp, vp, aAp, aLp;
   {
@@ -400,16 +421,14 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     fk.f = Ia.f + cross(om, Iv.f);
     if (k < 2) {
       T* pk = &park[PW * k][ln];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) pk[BLOCK * e] = E.a[e];
-      pk[BLOCK * 9] = fk.n.x; pk[BLOCK * 10] = fk.n.y; pk[BLOCK * 11] = fk.n.z;
-      pk[BLOCK * 12] = fk.f.x; pk[BLOCK * 13] = fk.f.y; pk[BLOCK * 14] = fk.f.z;
+      pk[0] = sn; pk[BLOCK] = cs;
+      pk[BLOCK * 2] = fk.n.x; pk[BLOCK * 3] = fk.n.y; pk[BLOCK * 4] = fk.n.z;
+      pk[BLOCK * 5] = fk.f.x; pk[BLOCK * 6] = fk.f.y; pk[BLOCK * 7] = fk.f.z;
     } else {
       E2 = E; f2 = fk;
       if (OBS) {
         T* pe = &park[2 * PW + PB][ln];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) pe[BLOCK * e] = E.a[e];
+        pe[0] = sn; pe[BLOCK] = cs;
       }
     }
     omp = om; vp = vv; aAp = aA; aLp = aL;
@@ -417,12 +436,6 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 
   SSTAMP();  // 5: forward sweep done
   // ------------------------------------------------------------------ return sweep up the leg
-  T al[3] = {0, 0, 0};
-  if (STEP) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      al[k] = *(const T*)((const char*)(a.vdot_des + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
-  }
   T taup[3] = {0, 0, 0};  // (M vdot_des) joint rows of this leg, accumulated as M entries appear
   T cm; V3<T> ch; S3<T> cI;  // composite inertia of the subtree rooted at joint k, in frame k
   V3<T> dft = mk<T>(CS(129), CS(130), CS(131));  // foot relative to the current frame origin
@@ -444,10 +457,14 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       E = E2; fk = f2;
     } else {
       const T* pk = &park[PW * k][ln];
+      const T sn = pk[0], cs = pk[BLOCK];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) E.a[e] = pk[BLOCK * e];
-      fk.n = mk<T>(pk[BLOCK * 9], pk[BLOCK * 10], pk[BLOCK * 11]) + facc.n;
-      fk.f = mk<T>(pk[BLOCK * 12], pk[BLOCK * 13], pk[BLOCK * 14]) + facc.f;
+      for (int e = 0; e < 9; ++e) {
+        E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+        asm volatile("" : "+v"(E.a[e]));   // one entry at a time: 27 table words in flight at once would not fit the return sweep's registers
+      }
+      fk.n = mk<T>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]) + facc.n;
+      fk.f = mk<T>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]) + facc.f;
     }
     // RNEA projection on the joint axis
     {
@@ -507,7 +524,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     T ad[6] = {0, 0, 0, 0, 0, 0};
     if (STEP) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
+      for (int c = 0; c < 6; ++c) ad[c] = px[BLOCK * c];   // parked at the top of the kernel
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -536,10 +553,10 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       STLX(a.Jc, 2 * 18 + 6, 54, jxN[k], jw[k].z);
     }
   }
-  if (a.pf) {
-    STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
-    STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
-    STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
+  if (a.pf) {   // base position: parked at the top of the kernel
+    STL(a.pf, 0, 3, px[BLOCK * 6] + dw.x);
+    STL(a.pf, 1, 3, px[BLOCK * 7] + dw.y);
+    STL(a.pf, 2, 3, px[BLOCK * 8] + dw.z);
   }
   // the QP's geometry (foot lever arms, own-leg Jacobian blocks: 48 of the 66 workspace words) is a subset of Jc; when
   // Jc is being written anyway the QP kernel reads it from there and these stores are skipped (-9 % store bytes)
@@ -603,8 +620,11 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         const int o = JOINT_WORDS * k;
         const T* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];
         M3<T> Ek;
+        {
+          const T sn = pe[0], cs = pe[BLOCK];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) Ek.a[e] = pe[BLOCK * e];
+          for (int e = 0; e < 9; ++e) Ek.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+        }
         const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
         const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
         S3<T> Io;
@@ -634,10 +654,13 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       ct_leg[k] = -dot(ax, cross(omk[k], mk_.n) + cross(vvk[k], mk_.f));
       g_leg[k] = dot(ax, gk.n);
       {
-        const T* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];  // E again, from LDS rather than from 27 registers
+        const T* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];  // E again, rebuilt rather than held in 27 registers
         M3<T> Ek;
+        {
+          const T sn = pe[0], cs = pe[BLOCK];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) Ek.a[e] = pe[BLOCK * e];
+          for (int e = 0; e < 9; ++e) Ek.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+        }
         macc = to_parent(Ek, r, mk_);
         gacc = to_parent(Ek, r, gk);
       }
@@ -693,7 +716,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         const T r0 = LDU(a.obs_r, c);
         const T ig = LDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
         const T e = p_b[c] - ig;
-        rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);   // (from LDS: 72 SGPRs of gains held to the end of the kernel meant SGPR spills read back 800 times)
         p_b[c] = ig;  // reuse as the new integ for the store below
       }
       // every lane's loads of the replicated rows feed its own store values, so all loads of a row have

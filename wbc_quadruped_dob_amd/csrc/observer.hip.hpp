@@ -278,7 +278,8 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
           const T r0 = OLDU(a.obs_r, c);
           const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
           const T e = p_b[c] - ig;
-          rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+          if constexpr (EXT == 0) rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
+          else rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
           p_b[c] = ig;
         }
         // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
