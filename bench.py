@@ -588,6 +588,10 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
             "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dyn_kernel_name(split), n, dtype),
             "algorithmic_words_per_state": dyn_words(split), "avg_launch_us": dyn_s * 1e6,
             "rnea_step_us": tm["rnea_ms"] * 1e3 / max(1, tm["rnea_launches"]), "qp_us": qp_s * 1e6,
+            "qp_lane_us": (tm.get("qp_lane_ms", 0.0) * 1e3 / tm["qp_lane_launches"]) if tm.get("qp_lane_launches", 0) else None,
+            "qp_note": ("GRF QP stage = qp_lane_kernel (one state per lane, semismooth Newton; qp_lane_us) + qp_list_kernel (dense active-set "
+                        "solver over the states the first did not finish; qp_us)" if tm.get("qp_lane_launches", 0) else
+                        "GRF QP stage = the dense active-set kernel (qp_us)"),
             "steps_per_s": K * n / el, "ms_per_step": el / K * 1e3}
 
 
