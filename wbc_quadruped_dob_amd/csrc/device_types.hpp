@@ -57,6 +57,7 @@ template <class T> struct SweepArgs {
   T* obs_integ; T* obs_r;
   T* ws;
   int ws_geom;   // 1: also write d and the own-leg Jacobian blocks to the workspace; 0: the QP reads them from Jc (M/h/Jc ticks)
+  int* qp_todo;  // non-null: the hand-over list of the per-lane QP kernel that follows; this kernel empties it (qp_lane.hip.hpp)
 };
 
 template <class T> struct QpArgs {

@@ -637,6 +637,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 template <class T, int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a) {
+  if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
   rnea_step_body<T, MODE, BLOCK, 0>(model, prm, a, nullptr, nullptr);
 }
 

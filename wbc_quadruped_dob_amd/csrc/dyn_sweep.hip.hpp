@@ -774,6 +774,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 template <class T, int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                         SweepArgs<T> a) {
+  if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
   dyn_sweep_body<T, MODE, BLOCK>(model, prm, a);
 }
 

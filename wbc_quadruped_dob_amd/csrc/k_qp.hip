@@ -37,7 +37,6 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
 template <>
 hipError_t k_qp_lane<Scalar>(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* todo) {
   using T = Scalar;
-  hipLaunchKernelGGL((qp_list_reset_kernel<T>), dim3(1), dim3(1), 0, L.st, todo);
   const dim3 grid((unsigned)((a.N + QPL_WG - 1) / QPL_WG));   // one state per lane
   if (rhat) WBC_KLAUNCH(L, (qp_lane_kernel<T, true>), grid, dim3(QPL_WG), prm, a, jmap, todo);
   else WBC_KLAUNCH(L, (qp_lane_kernel<T, false>), grid, dim3(QPL_WG), prm, a, jmap, todo);

@@ -809,11 +809,13 @@ __global__ __launch_bounds__(256, WBC_QP_TILE_WAVES) void qp_tile_kernel(DevPara
 // qp_list_kernel: the dense active-set solver over a LIST of states (list[0] = how many, list[4 ...] = their indices): the
 // states qp_lane_kernel (qp_lane.hip.hpp) did not finish.  One wavefront per workgroup, four listed states per wavefront,
 // grid-stride over the list (the launch cannot know its length: it lives on the device).  list[2] keeps the length for
-// wbc_solver_qp_handover.  The count is zeroed by qp_list_reset_kernel (qp_lane.hip.hpp) in front of qp_lane_kernel, a kernel of its own:
+// wbc_solver_qp_handover.  The count is zeroed by one thread of the tick's front-half kernel (dyn_sweep / rnea_step, which
+// run between this kernel and the next qp_lane_kernel on the stream).  What did not work:
 //   * a 4-byte hipMemsetAsync did the job in eager mode, but as a memset node of a captured hipGraph it did not reliably run
 //     in front of the next kernel on this stack (the list overflowed after a few replays);
 //   * letting the last workgroup of this kernel reset it (one agent-scope atomic per workgroup to count them, an agent-scope
-//     load of the length) serialises on that one address: 8192 workgroups took 330 us instead of 65 us (N = 262 144).
+//     load of the length) serialises on that one address: 8192 workgroups took 330 us instead of 65 us (N = 262 144);
+//   * a one-thread kernel of its own: correct, 4.7 us per tick.
 template <class T, bool RHAT>
 __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_list_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ list) {
   const int n = min(list[0], (int)a.N);

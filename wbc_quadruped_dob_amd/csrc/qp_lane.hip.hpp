@@ -275,7 +275,7 @@ WBC_DEV void qpl_newton(const QplLds<T>& L, unsigned tid, int mask, const T* sS,
   }
 }
 
-// todo[0] = number of states handed to the dense kernel (zeroed by qp_list_reset_kernel, launched in front of this kernel),
+// todo[0] = number of states handed to the dense kernel (zeroed by the front-half kernel of the same tick: SweepArgs::qp_todo),
 // todo[2] = that number of the last tick (diagnostics), todo[4 ...] = their indices
 template <class T, bool RHAT>
 __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_WAVES)) void qp_lane_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ todo) {
@@ -408,9 +408,5 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
 #undef LLD
 #undef LST
 }
-
-// one thread: empties the hand-over list (see qp_list_kernel for why this is a kernel).  A template only so that the two
-// scalar-type objects of k_qp.hip may both carry it.
-template <class T> __global__ void qp_list_reset_kernel(int* __restrict__ todo) { todo[0] = 0; }
 
 }  // namespace wbc

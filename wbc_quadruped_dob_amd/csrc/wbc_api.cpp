@@ -524,6 +524,19 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap));
     return WBC_OK;
   }
+  // Large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench, 64 QPs
+  // per wavefront, no cross-lane traffic); the few per cent it does not finish go through a device-side list to the dense
+  // active-set kernel.  No host read: the list length stays on the device, the second launch is grid-stride over it.
+  // Measured on MI355X, QP stage, dense kernel alone -> per-lane + list (us), fp64 configs[1] data: 356 -> 101 + 45 at
+  // 262 144 states, 175 -> 54 + 34 at 131 072, 133 -> 50 + 33 at 98 304, 91 -> 36 + 32 at 65 536, 78 -> 32 + 26 at 49 152
+  // (32 768: 48 -> 31 + 25: a wavefront of the per-lane kernel takes ~32 us whatever the batch, and the list kernel at least
+  // the ~20 us of its longest QP); fp64 observer-on data (easier QPs): 223 -> 97 + 34 at 262 144, 102 -> 51 + 23 at 131 072,
+  // 76 -> 47 + 24 at 98 304, but 51 -> 35 + 21 at 65 536 and 43 -> 32 + 20 at 49 152; fp32 (configs[3]): 144 -> 84 + 34 at
+  // 262 144 but 101 -> 78 + 24 at 196 608 and 68 -> 49 + 23 at 131 072 (the per-lane kernel issues the same number of
+  // instructions in either precision, the dense kernel's fp32 instructions are cheaper).  Hence the default: fp64 from
+  // 65 536 states on (+19 % per tick on the harder data, -6 % on the easier), fp32 from 262 144.
+  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)65536 : (size_t)262144));
+  a.qp_todo = lane ? s->d_todo : nullptr;   // the front-half kernel empties the hand-over list (one thread; a kernel of its own took 4.7 us per tick)
   bool obs_split = false;
   if (!mats) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
     const int mode = RS_STEP | (ob ? RS_OBS : 0) | (out->pf ? RS_PF : 0);
@@ -554,18 +567,6 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   int tile = s->opt.qp_tile;
   if (tile == 0) tile = N >= 20480 ? 64 : (N >= 12288 ? 32 : 0);
   if (tile < 0) tile = 0;
-  // Large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench, 64 QPs
-  // per wavefront, no cross-lane traffic); the few per cent it does not finish go through a device-side list to the dense
-  // active-set kernel.  No host read: the list length stays on the device, the second launch is grid-stride over it.
-  // Measured on MI355X, QP stage, dense kernel alone -> per-lane + list (us), fp64 configs[1] data: 356 -> 101 + 45 at
-  // 262 144 states, 175 -> 54 + 34 at 131 072, 133 -> 50 + 33 at 98 304, 91 -> 36 + 32 at 65 536, 78 -> 32 + 26 at 49 152
-  // (32 768: 48 -> 31 + 25: a wavefront of the per-lane kernel takes ~32 us whatever the batch, and the list kernel at least
-  // the ~20 us of its longest QP); fp64 observer-on data (easier QPs): 223 -> 97 + 34 at 262 144, 102 -> 51 + 23 at 131 072,
-  // 76 -> 47 + 24 at 98 304, but 51 -> 35 + 21 at 65 536 and 43 -> 32 + 20 at 49 152; fp32 (configs[3]): 144 -> 84 + 34 at
-  // 262 144 but 101 -> 78 + 24 at 196 608 and 68 -> 49 + 23 at 131 072 (the per-lane kernel issues the same number of
-  // instructions in either precision, the dense kernel's fp32 instructions are cheaper).  Hence the default: fp64 from
-  // 65 536 states on (+19 % per tick on the harder data, -6 % on the easier), fp32 from 262 144.
-  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)65536 : (size_t)262144));
   if (lane) {
     TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, obs_split, dp, qa, s->jmap, s->d_todo));
     TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, 0, dp, qa, s->jmap, s->d_todo));
