@@ -19,6 +19,34 @@ def test_no_masked_spill_stores(tmp_path):
     assert not bad, bad[:5]
 
 
+# Kernels whose speed depends on a register budget: no scratch at all, at most this many registers (arch + accumulation).
+# A change elsewhere in a shared body once pushed the observer-on fused tick into a 300-byte spill (+2.5 us per tick) and
+# no functional test noticed.
+BUDGET = [
+    (r"fused_tick_kernelI[df]", 256),
+    (r"dyn_sweep_kernelIdLi1ELi256", 256), (r"dyn_sweep_kernelIdLi3ELi256", 256), (r"dyn_sweep_kernelIfLi[13]ELi256", 256),
+    (r"observer_kernelI[df]", 256),
+    (r"qp_lane_kernelI[df]", 256),
+    (r"qp_tile_kernelI[df]Lb[01]ELi(32|64)E", 256), (r"qp_group16_kernelI[df]", 256), (r"qp_list_kernelI[df]", 256),
+    (r"rnea_step_kernelIdLi(2|10)ELi256", 256),
+]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_hot_kernels_keep_their_register_budget(tmp_path):
+    import re
+    spec = importlib.util.spec_from_file_location("spill_lint", os.path.join(ROOT, "tools", "spill_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.resources(mod.compile_asm(str(tmp_path / "wbc.s")))
+    for pat, regs in BUDGET:
+        hits = {k: v for k, v in res.items() if re.search(pat, k)}
+        assert hits, pat
+        for k, v in hits.items():
+            assert v["scratch"] == 0, (k, v)
+            assert v["vgpr"] + v["agpr"] <= regs, (k, v)
+
+
 def test_lint_flags_the_pattern(tmp_path):
     spec = importlib.util.spec_from_file_location("spill_lint", os.path.join(ROOT, "tools", "spill_lint.py"))
     mod = importlib.util.module_from_spec(spec)

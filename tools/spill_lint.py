@@ -46,6 +46,18 @@ def compile_asm(out="/tmp/asm/wbc_lint.s", extra=()):
     return out
 
 
+def resources(path):
+    """{kernel symbol: dict(vgpr, agpr, scratch, lds)} from the .amdhsa_kernel blocks of `path`."""
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, flags=re.S):
+        b = m.group(2)
+        g = lambda k: int(re.search(k + r"\s+(\d+)", b).group(1))
+        nv, acc = g("amdhsa_next_free_vgpr"), g("amdhsa_accum_offset")
+        out[m.group(1)] = dict(vgpr=min(nv, acc), agpr=max(0, nv - acc), scratch=g("amdhsa_private_segment_fixed_size"), lds=g("amdhsa_group_segment_fixed_size"))
+    return out
+
+
 def lint(path):
     """Returns [(kernel, label, line_no, text)] for every masked spill store."""
     bad = []

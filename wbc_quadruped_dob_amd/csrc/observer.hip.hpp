@@ -21,7 +21,8 @@
 
 namespace wbc {
 
-// EXT = 0: the stand-alone kernel below.  EXT = 1 / 2: the observer ROLE of the fused tick / persistent rollout kernels
+// observer_body: the observer ROLE of the fused tick / persistent rollout kernels, EXT = 1 / 2 (EXT = 0 also compiles: the
+// form the stand-alone kernel had in round 1; the kernel itself is observer_park_body below)
 // (fused_tick.hip.hpp): one wavefront of a larger workgroup that owns 16 states, constant table staged by other wavefronts
 // (EXT = 2: this body joins the workgroup barrier after issuing its state loads), rhat goes to the LDS image wsl.
 // PART (roles only): 0 = the whole update; 1 = base rows only (momentum / gravity sums over the legs, rhat_base: what the QP's
@@ -31,6 +32,205 @@ template <class T, int BLOCK, int EXT, int PART = 0, int SPW = 16>
 WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext, T* wsl) {
   static_assert(EXT == 0 || BLOCK == 64, "one wavefront");
   static_assert(PART == 0 || EXT != 0, "split parts exist only as roles");
+  constexpr bool BASE = PART != 2, JOINTS = PART != 1;
+  __shared__ T cst_own[EXT ? 1 : CST_WORDS];
+  const T* cst = EXT ? cst_ext : cst_own;
+  unsigned tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  const int leg = (int)((tx & 63) >> 4);
+  const size_t s_raw = EXT ? (size_t)blockIdx.x * SPW + (tx & 15) : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);
+  const bool slot_ok = SPW == 16 || (int)(tx & 15) < SPW;   // (roles: SPW <= 16 states per workgroup, see WBC_ADDR_MACROS)
+  const bool live = slot_ok && s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));
+#define OCS(i) cst[(i) * 4 + leg]
+#define OLDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
+#define OLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define OSTV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define OST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) OSTV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+  // rhat: HBM workspace (stand-alone kernel) or the workgroup's LDS image (role)
+#define ORHAT(comp, val) do { if constexpr (EXT != 0) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else OSTV(a.ws, comp, val); } while (0)
+  // state loads first, table staging while they are in flight
+  T qq[4], vb[6];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) qq[c] = OLDU(a.q, 3 + c);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
+  int jx[3];
+  T ql[3], vl[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    jx[k] = model->jidx[leg][k];
+    ql[k] = OLDV(a.q, 7 + jx[k]);
+    vl[k] = OLDV(a.v, 6 + jx[k]);
+  }
+  if constexpr (EXT == 0) {
+    // branch-free (clamped index, the tail lanes rewrite the last word): with a divergent staging loop here hipcc 7.2 put
+    // VGPR spill stores of the fp64 build into the loop's exit block BEFORE exec is restored, i.e. with no lane enabled
+    // (found by parity: rhat garbage in every state; tools/spill_lint.py now scans the ISA for that pattern)
+#pragma unroll
+    for (int i0 = 0; i0 < CST_WORDS; i0 += BLOCK) {
+      const int i = min(i0 + (int)tx, CST_WORDS - 1);
+      cst_own[i] = model->cst[i];
+    }
+    __syncthreads();
+  }
+  if constexpr (EXT == 2) __syncthreads();
+
+  T qx, qy, qz, qw;
+  {
+    const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
+  }
+  M3<T> R;
+  {
+    const T x = qx, y = qy, z = qz, w = qw;
+    R.a[0] = 1 - 2 * (y * y + z * z); R.a[1] = 2 * (x * y - z * w);     R.a[2] = 2 * (x * z + y * w);
+    R.a[3] = 2 * (x * y + z * w);     R.a[4] = 1 - 2 * (x * x + z * z); R.a[5] = 2 * (y * z - x * w);
+    R.a[6] = 2 * (x * z - y * w);     R.a[7] = 2 * (y * z + x * w);     R.a[8] = 1 - 2 * (x * x + y * y);
+  }
+  const T bm = model->base_m;
+  const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
+  S3<T> bI;
+  bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
+  bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
+  const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
+  const V3<T> v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
+  const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));   // R^T (-g)
+
+  // ---- forward sweep down the leg: joint rotations, body velocities, body momenta, weights (all kept in registers)
+  M3<T> E[3];
+  V3<T> om[3], vv[3], gL[3];   // body momenta / weights are re-formed from these in the return sweep (fewer live registers)
+  {
+    V3<T> omp = om0, vp = v0, gp = gneg;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int o = JOINT_WORDS * k;
+      T sn, cs;
+      sincos_t(ql[k], &sn, &cs);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) E[k].a[e] = OCS(o + e) + cs * OCS(o + 9 + e) + sn * OCS(o + 18 + e);
+      const V3<T> r = mk<T>(OCS(o + 27), OCS(o + 28), OCS(o + 29));
+      const V3<T> ax = mk<T>(OCS(o + 30), OCS(o + 31), OCS(o + 32));
+      om[k] = tmul(E[k], omp) + ax * vl[k];
+      vv[k] = tmul(E[k], vp + cross(omp, r));
+      gL[k] = tmul(E[k], gp);
+      omp = om[k]; vp = vv[k]; gp = gL[k];
+    }
+  }
+  // ---- return sweep: subtree momentum / weight, their projections on the joint axes, foot geometry
+  T p_leg[3], beta_l[3];
+  V3<T> dft = mk<T>(OCS(129), OCS(130), OCS(131));
+  V3<T> jc[3];
+  SF<T> macc, gacc;
+#pragma unroll
+  for (int k = 2; k >= 0; --k) {
+    const int o = JOINT_WORDS * k;
+    const V3<T> r = mk<T>(OCS(o + 27), OCS(o + 28), OCS(o + 29));
+    const V3<T> ax = mk<T>(OCS(o + 30), OCS(o + 31), OCS(o + 32));
+    const T m = OCS(o + 33);
+    const V3<T> h = mk<T>(OCS(o + 34), OCS(o + 35), OCS(o + 36));
+    S3<T> Io;
+    Io.xx = OCS(o + 37); Io.xy = OCS(o + 38); Io.xz = OCS(o + 39); Io.yy = OCS(o + 40); Io.yz = OCS(o + 41); Io.zz = OCS(o + 42);
+    SF<T> mk_ = inertia_mul(m, h, Io, om[k], vv[k]), gk;
+    gk.n = cross(h, gL[k]);
+    gk.f = gL[k] * m;
+    if (k < 2) { mk_.n = mk_.n + macc.n; mk_.f = mk_.f + macc.f; gk.n = gk.n + gacc.n; gk.f = gk.f + gacc.f; }
+    p_leg[k] = dot(ax, mk_.n);
+    beta_l[k] = -dot(ax, cross(om[k], mk_.n) + cross(vv[k], mk_.f)) - dot(ax, gk.n);   // (C^T v)_k - g_k
+    jc[k] = cross(ax, dft);
+    dft = r + mul(E[k], dft);
+#pragma unroll
+    for (int j = k; j < 3; ++j) jc[j] = mul(E[k], jc[j]);
+    macc = to_parent(E[k], r, mk_);
+    gacc = to_parent(E[k], r, gk);
+  }
+  const V3<T> dw = mul(R, dft);
+  V3<T> jw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) jw[k] = mul(R, jc[k]);
+
+  // ---- base rows: the four legs + the base body itself
+  T p_b[6] = {0, 0, 0, 0, 0, 0}, beta_b[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (BASE) {
+    const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+    T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
+    xrow_sum_k<T, 12>(xb);
+    const V3<T> m0n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n, m0f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
+    const V3<T> g0n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg), g0f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
+    const V3<T> Pl = mul(R, m0f), Pa = mul(R, m0n);
+    const V3<T> gl = mul(R, g0f), ga = mul(R, g0n);
+    const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
+    p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
+    beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
+    beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
+  }
+  // ---- observer update (order 1 or 2) and rhat for the QP kernel
+  T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
+  if (prm.observer_order > 0) {
+    const V3<T> fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
+    const T dt = prm.dt;
+    const bool o1 = prm.observer_order == 1;
+    if constexpr (BASE) {
+      const V3<T> dxf = cross(dw, fp);
+      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+      xrow_sum_k<T, 6>(ub);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const T r0 = OLDU(a.obs_r, c);
+        const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
+        const T e = p_b[c] - ig;
+        rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        p_b[c] = ig;
+      }
+      // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
+      // of the wave before any lane stores to it
+      OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+      if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+    }
+#pragma unroll
+    for (int k = 0; k < (JOINTS ? 3 : 0); ++k) {
+      const int c = 6 + jx[k];
+      const T r0 = OLDV(a.obs_r, c);
+      const T u = OLDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
+      const T ig = OLDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
+      const T e = p_leg[k] - ig;
+      T k1 = prm.K1[6], k2 = prm.K2[6];   // gains of joint row c by a select (no run-time index into the kernel arguments)
+#pragma unroll
+      for (int j = 1; j < 12; ++j) { k1 = (jx[k] == j) ? prm.K1[6 + j] : k1; k2 = (jx[k] == j) ? prm.K2[6 + j] : k2; }
+      rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
+      OSTV(a.obs_integ, c, ig);
+      OSTV(a.obs_r, c, rl[k]);
+    }
+  }
+  if constexpr (BASE) {
+    ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
+    if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
+  }
+  if constexpr (JOINTS) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
+  }
+#undef ORHAT
+#undef OST4
+#undef OSTV
+#undef OLDV
+#undef OLDU
+#undef OCS
+}
+
+// ======================================================================================================================
+// The stand-alone kernel: the same recursion with the forward sweep's per-joint state parked in LDS (see the file header).
+// ======================================================================================================================
+template <class T, int BLOCK>
+WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
+  constexpr int EXT = 0, PART = 0, SPW = 16;
+  const T* cst_ext = nullptr;
+  T* wsl = nullptr;
+  (void)cst_ext; (void)wsl;
   constexpr bool BASE = PART != 2, JOINTS = PART != 1;
   // (one LDS object, constant table first: see dyn_sweep.hip.hpp)
   constexpr bool PARK = EXT == 0;
@@ -315,7 +515,7 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 #endif
 template <class T, int BLOCK>
 __global__ __launch_bounds__(BLOCK, WBC_OBS_WAVES) void observer_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a) {
-  observer_body<T, BLOCK, 0>(model, prm, a, nullptr, nullptr);
+  observer_park_body<T, BLOCK>(model, prm, a);
 }
 
 }  // namespace wbc
