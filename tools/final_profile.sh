@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/final"; rm -rf "$O"; mkdir -p "$O"
 cd "$R"
-python -m pytest tests -q -m gpu 2>&1 | tail -4 > "$O/pytest_gpu.log"
+python -m pytest tests -q -m gpu > "$O/pytest_gpu_full.log" 2>&1; grep -E "passed|failed|error" "$O/pytest_gpu_full.log" | tail -3 > "$O/pytest_gpu.log"
 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 ./tools/abi_smoke.bin > "$O/abi_smoke.log" 2>&1
 ./tools/fma_probe.bin > "$O/fma_probe.log" 2>&1
