@@ -64,6 +64,7 @@ template <class T> struct QpArgs {
   size_t N;
   const T* ws; const T* normals; const T* mu; const int* mask;
   const T* Jc;   // non-null: foot lever arms and own-leg Jacobian blocks come from the Jacobian the sweep wrote, not from ws
+  const T* wdes; // non-null: the target wrench b is read from the caller's w_des (the front half forwarded nothing to WS_B)
   T* tau; T* f; int* status; int* iters;
 };
 
@@ -100,6 +101,7 @@ template <class T> struct RefArgs {
 constexpr int SW_MATS = 1;  // write M, h, Jc
 constexpr int SW_STEP = 2;  // write the step workspace (d, b, taup, JcL)
 constexpr int SW_OBS = 4;   // momentum observer update (needs SW_STEP) / p, beta outputs
+constexpr int SW_NOB = 8;   // step mode without forwarding w_des to the workspace: the QP kernel reads the caller's w_des (QpArgs::wdes)
 // MODE bits of rnea_step_kernel (dyn_split.hip.hpp)
 constexpr int RS_H = 1;     // write h (bias forces)
 constexpr int RS_STEP = 2;  // write the step workspace (d, b, taup, JcL)
@@ -107,5 +109,6 @@ constexpr int RS_OBS = 4;   // momentum / gravity recursions: p, beta outputs an
 constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
 constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, without RS_STEP / RS_H): no force recursion, the
                             // momentum observer is updated and rhat (18 words) goes to the LDS image at WS_RHAT
+constexpr int RS_NOB = 32;  // (stand-alone kernel, observer off) w_des is not forwarded to the workspace: see SW_NOB
 
 }  // namespace wbc

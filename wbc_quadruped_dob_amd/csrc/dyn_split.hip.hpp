@@ -254,7 +254,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
                             T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom()) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   WBC_LAUNDERED_TID(tx);
-  constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0;
+  constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0, FWD_B = (MODE & RS_NOB) == 0;
   constexpr bool OBSW = (MODE & RS_OBSW) != 0;
   static_assert(!OBSW || (EXT != 0 && OBS && !STEP && !WH), "the observer role exists only inside the fused tick");
   constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
@@ -296,7 +296,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 #pragma unroll
       for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
     }
-    if (STEP && !OBS) {  // observer off: the QP target wrench is just w_des
+    if (STEP && !OBS && FWD_B) {  // observer off: the QP target wrench is just w_des (RS_NOB: the QP kernel reads it itself)
 #pragma unroll
       for (int c = 0; c < 6; ++c) bw[c] = LDU(a.w_des, c);
     }
@@ -304,7 +304,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   if constexpr (!LATE_REFS) load_refs();
   if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
   if constexpr (!EARLY) {   // (EARLY: w_des is stored after the lever arms, so that those do not wait for its load)
-    if (STEP && !OBS) {
+    if (STEP && !OBS && FWD_B) {
       WST4(WS_B + 0, bw[0], WS_B + 1, bw[1], WS_B + 2, bw[2], WS_B + 3, bw[3]);
       if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? bw[4] : bw[5]);
     }
@@ -341,7 +341,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     WSTL(WS_D + 2, 3, dw0.z);
     after_geom();   // first call: lever arms are out
     if constexpr (LATE_REFS) load_refs();
-    if (STEP && !OBS) {
+    if (STEP && !OBS && FWD_B) {
       WST4(WS_B + 0, bw[0], WS_B + 1, bw[1], WS_B + 2, bw[2], WS_B + 3, bw[3]);
       if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? bw[4] : bw[5]);
     }

@@ -195,7 +195,7 @@ __host__ __device__ constexpr int midx18(int i, int j) { return i * 18 - i * (i 
 // on; superseded by the role-split fused tick in fused_tick.hip.hpp, which does not use this body.)
 template <class T, int MODE, int BLOCK>
 WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
-  constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0;
+  constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0, FWD_B = (MODE & SW_NOB) == 0;
   // ONE LDS object with the constant table first: ds_read / ds_write reach base + 16-bit offset, and the compiler places
   // separate __shared__ arrays largest-first -- behind the 74 kB parking area of a 256-thread workgroup every table word
   // needed an address register of its own (150 v_or_b32 in the tick's sweep, and the registers to hold them)
@@ -287,8 +287,11 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   __syncthreads();
   SSTAMP();  // 2: table staged (barrier passed)
 
-  // observer off: the QP target wrench is just w_des -- forward it now, while the loads are in flight anyway
-  if (STEP && !OBS) {
+  // observer off: the QP target wrench is just w_des.  The two-kernel ticks run the SW_NOB variants: their QP kernels read the
+  // caller's w_des themselves (QpArgs::wdes).  Forwarding it here -- six loads and two stores at the top of the kernel, the
+  // stores waiting for the loads -- held back every store behind them: 234 -> 177 us for this kernel at N = 262 144 (a
+  // run-time test instead of a variant keeps most of the damage: 214 us).
+  if (STEP && !OBS && FWD_B) {
     T b[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c);

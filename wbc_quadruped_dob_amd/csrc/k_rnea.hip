@@ -25,6 +25,8 @@ hipError_t k_rnea_step<Scalar>(const LaunchCtx& L, int mode, const DevModel<Scal
     case RS_STEP: return rnea_mode<RS_STEP>(L, model, prm, a);
     case RS_STEP | RS_OBS: return rnea_mode<RS_STEP | RS_OBS>(L, model, prm, a);
     case RS_STEP | RS_PF: return rnea_mode<RS_STEP | RS_PF>(L, model, prm, a);
+    case RS_STEP | RS_NOB: return rnea_mode<RS_STEP | RS_NOB>(L, model, prm, a);
+    case RS_STEP | RS_PF | RS_NOB: return rnea_mode<RS_STEP | RS_PF | RS_NOB>(L, model, prm, a);
     case RS_STEP | RS_OBS | RS_PF: return rnea_mode<RS_STEP | RS_OBS | RS_PF>(L, model, prm, a);
     default: return hipErrorInvalidValue;
   }

@@ -27,6 +27,7 @@ hipError_t k_dyn_sweep<Scalar>(const LaunchCtx& L, int mode, const DevModel<Scal
     case SW_MATS | SW_OBS: return sweep_mode<SW_MATS | SW_OBS>(L, model, prm, a);
     case SW_STEP: return sweep_mode<SW_STEP>(L, model, prm, a);
     case SW_MATS | SW_STEP: return sweep_mode<SW_MATS | SW_STEP>(L, model, prm, a);
+    case SW_MATS | SW_STEP | SW_NOB: return sweep_mode<SW_MATS | SW_STEP | SW_NOB>(L, model, prm, a);
     case SW_STEP | SW_OBS: return sweep_mode<SW_STEP | SW_OBS>(L, model, prm, a);
     case SW_MATS | SW_STEP | SW_OBS: return sweep_mode<SW_MATS | SW_STEP | SW_OBS>(L, model, prm, a);
     default: return hipErrorInvalidValue;

@@ -194,6 +194,8 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
 #define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define WSLD(comp) (WSLDS ? wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
+  // target wrench: LDS image (roles), the caller's w_des (two-kernel ticks whose front half does not change it) or the workspace
+#define BLD(c) (WSLDS ? wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
 #define GST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
 
 #ifdef WBC_QP_STAMP
@@ -298,7 +300,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   // the constraint rows below are set up (those need the terrain only).
   T x_me = 0;
   if constexpr (!WSLDS) {
-    const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
+    const T b_ld = (l16 < 6) ? BLD(l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
     T w[6], z[6];
     fwd(il, s0 * dppx<0x150 + 0>(b_ld), s1 * dppx<0x150 + 1>(b_ld), s2 * dppx<0x150 + 2>(b_ld), s3 * dppx<0x150 + 3>(b_ld),
         s4 * dppx<0x150 + 4>(b_ld), s5 * dppx<0x150 + 5>(b_ld), w);
@@ -340,7 +342,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
     if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
     WBC_QSTAMP(4);
-    const T b_ld = (l16 < 6) ? WSLD(WS_B + l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
+    const T b_ld = (l16 < 6) ? BLD(l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
     T b[6];
     b[0] = dppx<0x150 + 0>(b_ld); b[1] = dppx<0x150 + 1>(b_ld); b[2] = dppx<0x150 + 2>(b_ld);
     b[3] = dppx<0x150 + 3>(b_ld); b[4] = dppx<0x150 + 4>(b_ld); b[5] = dppx<0x150 + 5>(b_ld);
@@ -639,6 +641,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   WBC_QSTAMP(11);
 #undef GST
 #undef WSLD
+#undef BLD
 #undef GLD
 }
 
@@ -678,7 +681,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned
   }
   T bt[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) bt[k] = PLD(a.ws, WS_B + k) - (RHAT ? PLD(a.ws, WS_RHAT + k) : (T)0);
+  for (int k = 0; k < 6; ++k) bt[k] = (a.wdes ? PLD(a.wdes, k) : PLD(a.ws, WS_B + k)) - (RHAT ? PLD(a.ws, WS_RHAT + k) : (T)0);
   // G = alpha I + B B^T and its factor, as in qp_group16_body (selection only: seed-accuracy reciprocal square roots)
   const T nc = (Of[0] + Of[1]) + (Of[2] + Of[3]);
   const T sx = (Dx[0] + Dx[1]) + (Dx[2] + Dx[3]), sy = (Dy[0] + Dy[1]) + (Dy[2] + Dy[3]), sz = (Dz[0] + Dz[1]) + (Dz[2] + Dz[3]);

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
 #pragma unroll
   for (int k = 0; k < 4; ++k) in_mu[k] = LLD(a.mu, k);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) { in_b[c] = LLD(a.ws, WS_B + c); in_r[c] = RHAT ? LLD(a.ws, WS_RHAT + c) : (T)0; }
+  for (int c = 0; c < 6; ++c) { in_b[c] = a.wdes ? LLD(a.wdes, c) : LLD(a.ws, WS_B + c); in_r[c] = RHAT ? LLD(a.ws, WS_RHAT + c) : (T)0; }
   // (the empty asm statements keep the compiler from sinking a load down to its first use)
 #pragma unroll
   for (int c = 0; c < 12; ++c) { asm volatile("" : "+v"(in_d[c])); asm volatile("" : "+v"(in_n[c])); }

@@ -516,6 +516,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
   // two-kernel tick with M/h/Jc outputs: the QP takes its geometry from Jc and the sweep skips those workspace words
   qa.Jc = mats ? (const T*)out->Jc : nullptr;
+  qa.wdes = nullptr;
   a.ws_geom = mats ? 0 : 1;
   const DevParams<T> dp = to_dev_params<T>(s->params);
   if ((mats || !out->pf) && N <= ((ob && s->dtype == WBC_F64) ? s->fused_max : s->fused_max_noobs)) {   // fp32: half the LDS, 8 192 also with the observer on (29.7 vs 36.9 us)
@@ -536,10 +537,13 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   // instructions in either precision, the dense kernel's fp32 instructions are cheaper).  Hence the default: fp64 from
   // 65 536 states on (+19 % per tick on the harder data, -6 % on the easier), fp32 from 262 144.
   const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)65536 : (size_t)262144));
+  // front halves that do not change the target wrench leave it to the QP kernels to read the caller's w_des (QpArgs::wdes)
+  const bool front_writes_b = ob && !(mats && N >= s->obs_split_min);   // the all-in-one observer forms: b = w_des - rhat_base
+  qa.wdes = front_writes_b ? nullptr : (const T*)in->w_des;   // (those front halves run their SW_NOB / RS_NOB variants)
   a.qp_todo = lane ? s->d_todo : nullptr;   // the front-half kernel empties the hand-over list (one thread; a kernel of its own took 4.7 us per tick)
   bool obs_split = false;
   if (!mats) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
-    const int mode = RS_STEP | (ob ? RS_OBS : 0) | (out->pf ? RS_PF : 0);
+    const int mode = RS_STEP | (ob ? RS_OBS : RS_NOB) | (out->pf ? RS_PF : 0);
     TIMED_LAUNCH(2, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
   } else if (ob && N >= s->obs_split_min) {
     // large observer-on batch: the observer update runs as its own light kernel in front of (option: beside, on the second
@@ -548,17 +552,17 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     obs_split = true;
     if (s->opt.obs_split_serial) {   // same stream, one after the other
       TIMED_LAUNCH(2, st, "observer", k_observer<T>(L, dev_model<T>(s), dp, a));
-      TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP, dev_model<T>(s), dp, a));
+      TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | SW_NOB, dev_model<T>(s), dp, a));
     } else {
       HIP_TRY(hipEventRecord(s->ev_fork, st));
       HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
       TIMED_LAUNCH(2, s->aux, "observer", k_observer<T>(L, dev_model<T>(s), dp, a));
       HIP_TRY(hipEventRecord(s->ev_join, s->aux));
-      TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP, dev_model<T>(s), dp, a));
+      TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | SW_NOB, dev_model<T>(s), dp, a));
       HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));   // the QP needs rhat
     }
   } else {
-    TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | (ob ? SW_OBS : 0), dev_model<T>(s), dp, a));
+    TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | (ob ? SW_OBS : SW_NOB), dev_model<T>(s), dp, a));
   }
   // two-kernel ticks deal tiles of states to the wavefronts by predicted work (qp_tile_kernel).  Measured on MI355X, fp64,
   // QP kernel alone, one-wavefront workgroups -> tiles: 34.7 -> 32.7 us at 12 288 states (tiles of 32), 62.4 -> 48.3 at
@@ -634,7 +638,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   a.ws = (T*)s->d_ws;
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
-  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters; qa.Jc = nullptr;
+  qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters; qa.Jc = nullptr; qa.wdes = nullptr;
   a.ws_geom = 1;
   IntegrateArgs<T> ia;
   ia.N = N; ia.q = (T*)in->q; ia.v = (T*)in->v; ia.M = (const T*)out->M; ia.h = (const T*)out->h; ia.Jc = (const T*)out->Jc;
