@@ -562,12 +562,12 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
         rr = torch.zeros_like(integ)
     out = solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
                       inp["f_prev"], integ, rr, want_mats=True)
-    for _ in range(10):   # clocks and TLBs settle: the first few launches at this size read 5-8 % slower
+    for _ in range(40):   # clocks and TLBs settle: the first launches at this size read 5-8 % slower
         solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
                     inp["f_prev"], integ, rr, out=out, want_mats=True)
     torch.cuda.synchronize()
     solver.enable_timing(1)
-    K = 30
+    K = 40
     t0 = time.perf_counter()
     for _ in range(K):
         solver.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
