@@ -26,9 +26,13 @@
 namespace wbc {
 
 // Iteration policy.  Every wavefront runs QPL_MIN_NEWTON iterations (fewer if all its lanes are done) and goes on, up to
-// QPL_MAX_NEWTON, only while at least QPL_MORE_LANES of its 64 lanes are still unconverged: one more iteration costs the
-// whole wavefront ~4 ns (of the device's time), a state handed to the dense kernel ~2.8 ns, and about half of the stragglers
-// converge in the next iteration.  Full steps, no line search: measured on MI355X (per-lane kernel + dense kernel over the
+// QPL_MAX_NEWTON, only while at least QPL_MORE_LANES of its 64 lanes are still unconverged AND the last iteration finished
+// at least 40 % of the lanes it started with: one more iteration costs the whole wavefront ~4 ns (of the device's time), a
+// state handed to the dense kernel ~2.8 ns.  On 4-contact data about half of the stragglers converge in the next iteration
+// (unconverged lanes after iteration 2 / 3 / 4 / 5: 28 / 9.4 / 3.9 / 3.9 %); stances with swing feet leave ~20 % of the
+// lanes in a DIVERGING face cycle (alpha = 1e-3 against O(1) entries of B^T B: a face set with few free directions makes the
+// full step huge) that no further full step ends (25 / 19.8 / 18.9 / 18.8 %) -- the dense kernel solves those in 2-5 of its
+// iterations.  Full steps, no line search: measured on MI355X (per-lane kernel + dense kernel over the
 // hand-over list, us, N = 262 144, fp64 configs[1] / fp64 observer-on / fp32 configs[3] data; dense kernel alone 347 / 225 / 144):
 //   fixed 3 iterations, 2 line-search steps   116 + 66 | 110 + 29 |  93 + 28
 //   fixed 3, 1 step                           107 + 68 | 101 + 32 |  86 + 30
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
   T e[6], F[6];
   qpl_newton(L, tid, mask, sS, alpha, fmin, fmax, beta, code, e);
   qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, e, code, F);
-  int iters = 0;
+  int iters = 0, prev_cnt = 64;
   bool conv = false;
   auto fnorm = [](const T* v) __attribute__((always_inline)) -> T {
     T m = 0;
@@ -359,7 +363,11 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
     conv = conv || (fnorm(F) <= tolF && !nan6(F));
     const bool act = live && !conv;
     const unsigned long long todo_lanes = __ballot(act);
-    if (todo_lanes == 0ull || (itn >= QPL_MIN_NEWTON && __popcll(todo_lanes) < QPL_MORE_LANES)) break;
+    const int todo_cnt = __popcll(todo_lanes);
+    // beyond the minimum: only while enough lanes are left AND the last iteration finished at least 40 % of those it started with
+    // (stances with swing feet leave ~20 % of the lanes in a diverging face cycle that no further full step ends)
+    if (todo_cnt == 0 || (itn >= QPL_MIN_NEWTON && (todo_cnt < QPL_MORE_LANES || 5 * todo_cnt > 3 * prev_cnt))) break;
+    prev_cnt = todo_cnt;
     iters += act ? 1 : 0;
     T eN[6], Ft[6];
     int codet;
