@@ -61,13 +61,15 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400):
+def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min_blocks=3):
     """Times blocks of EXACTLY `steps` ticks, each bracketed by barrier + synchronize on both sides, until at least
-    `min_total_s` has been measured; returns the per-block seconds (max over ranks).  A 20-tick block at the bench
-    default lasts 0.5 ms -- one scheduler hiccup moves a single sample by > 5 %, the median of ~100 blocks does not."""
+    `min_total_s` has been measured AND at least `min_blocks` blocks exist; returns the per-block seconds (max over ranks).
+    A 20-tick block at the bench default lasts 0.5 ms -- one scheduler hiccup moves a single sample by > 5 %, the median of
+    ~100 blocks does not.  (min_blocks: a one-off stall of ~70 ms was seen in about one in twelve fp32 runs, always in the first
+    or second block; with one or two blocks it WAS the median.)"""
     times = []
     total = 0.0
-    while len(times) < max_blocks and (total < min_total_s or not times):
+    while len(times) < max_blocks and (total < min_total_s or len(times) < min_blocks):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

@@ -107,7 +107,7 @@ typedef struct wbc_solver_options {
   int rollout_persistent; /* 1 (default): rollouts of at most fused_max states = one launch per rollout; 0: per-tick launches */
   int rollout_spw;        /* states per workgroup of the rollout kernel: 0 = auto (4 up to 1024 states, else 16), 4, 16 */
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
-                             kernel instead of inside the sweep; -1 = auto (fp32: from 98304 states on, fp64: from 65536),
+                             kernel instead of inside the sweep; -1 = auto (fp32: from 49152 states on, fp64: from 24576),
                              -2 = never */
   int one_zerocopy;       /* 1: the single-robot host-pointer calls let the kernel read/write the pinned staging image directly */
   int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */
@@ -118,7 +118,7 @@ typedef struct wbc_solver_options {
                              second stream (measured slower: the two compete for the same SIMDs) */
   int qp_lane;            /* two-kernel ticks solve the QPs one state per LANE first (semismooth Newton on the residual wrench)
                              and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches from
-                             65536 states on, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
+                             49152 states on, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
                              iters = Newton iterations (<= 5); the others the dense kernel's status / iteration count */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);

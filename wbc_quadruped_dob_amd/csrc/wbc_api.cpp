@@ -315,9 +315,12 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   // observer as its own kernel before the sweep (the all-in-one observer sweep runs one wavefront per SIMD).  Measured on
   // MI355X, front half of the tick, all-in-one -> observer kernel + observer-free sweep (us): fp64 464 -> 112 + 279 at
   // 262 144 states, 111 -> 34 + 57 at 65 536, but 48 -> 25 + 33 at 32 768; fp32 298 -> 57 + 168 at 262 144, 45 -> 17 + 27 at
-  // 65 536 (a tie per tick), 26 -> 13 + 16 at 32 768.  Default: fp64 from 65 536 states on, fp32 from 98 304.
+  // 65 536 (a tie per tick), 26 -> 13 + 16 at 32 768.  After the sweep lost its forwarding of w_des (SW_NOB) the observer-free
+  // sweep got faster still; per tick, all-in-one -> split (M steps/s): fp64 417 -> 467 at 49 152, 425 -> 430 at 32 768,
+  // 330 -> 386 at 24 576, but 315 -> 289 at 16 384; fp32 824 -> 891 at 98 304, 777 -> 822 at 65 536, 651 -> 690 at 49 152,
+  // but 607 -> 569 at 32 768.  Default: fp64 from 24 576 states on, fp32 from 49 152.
   if (o.obs_split_min >= 0) s->obs_split_min = (size_t)o.obs_split_min;
-  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 98304 : 65536;
+  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 49152 : 24576;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
@@ -534,9 +537,12 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   // the ~20 us of its longest QP); fp64 observer-on data (easier QPs): 223 -> 97 + 34 at 262 144, 102 -> 51 + 23 at 131 072,
   // 76 -> 47 + 24 at 98 304, but 51 -> 35 + 21 at 65 536 and 43 -> 32 + 20 at 49 152; fp32 (configs[3]): 144 -> 84 + 34 at
   // 262 144 but 101 -> 78 + 24 at 196 608 and 68 -> 49 + 23 at 131 072 (the per-lane kernel issues the same number of
-  // instructions in either precision, the dense kernel's fp32 instructions are cheaper).  Hence the default: fp64 from
-  // 65 536 states on (+19 % per tick on the harder data, -6 % on the easier), fp32 from 262 144.
-  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)65536 : (size_t)262144));
+  // instructions in either precision, the dense kernel's fp32 instructions are cheaper).  Per tick at the final code
+  // (M steps/s, dense -> per-lane): fp64 configs[1] data 441 -> 526 at 65 536, 431 -> 507 at 49 152, 439 -> 393 at 32 768;
+  // observer-on data (trot masks: a fifth of the states end in the hand-over list) 462 -> 456 at 65 536, 467 -> 430 at
+  // 49 152.  Hence the default: fp64 from 49 152 states on (+18 % on the 4-contact data, -8 % on the trot data there, even
+  // from 65 536 on), fp32 from 262 144.
+  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)49152 : (size_t)262144));
   // front halves that do not change the target wrench leave it to the QP kernels to read the caller's w_des (QpArgs::wdes)
   const bool front_writes_b = ob && !(mats && N >= s->obs_split_min);   // the all-in-one observer forms: b = w_des - rhat_base
   qa.wdes = front_writes_b ? nullptr : (const T*)in->w_des;   // (those front halves run their SW_NOB / RS_NOB variants)
