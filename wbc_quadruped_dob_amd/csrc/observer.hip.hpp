@@ -227,36 +227,26 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 // ======================================================================================================================
 template <class T, int BLOCK>
 WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
-  constexpr int EXT = 0, PART = 0, SPW = 16;
-  const T* cst_ext = nullptr;
-  T* wsl = nullptr;
-  (void)cst_ext; (void)wsl;
-  constexpr bool BASE = PART != 2, JOINTS = PART != 1;
-  // (one LDS object, constant table first: see dyn_sweep.hip.hpp)
-  constexpr bool PARK = EXT == 0;
-  constexpr int PKW = 11;
-  struct Lds { T cst_own[EXT ? 1 : CST_WORDS]; T kgain[EXT ? 1 : 36]; T park[PARK ? 3 * PKW : 1][PARK ? BLOCK : 1]; };
+  constexpr int PKW = 11;   // parked words per joint: sin, cos, body angular / linear velocity, gravity direction
+  // one LDS object, constant table first (see dyn_sweep.hip.hpp)
+  struct Lds { T cst[CST_WORDS]; T kgain[36]; T park[3 * PKW][BLOCK]; };
   __shared__ Lds lds;
-  T (&cst_own)[EXT ? 1 : CST_WORDS] = lds.cst_own;
-  T (&kgain)[EXT ? 1 : 36] = lds.kgain;
-  T (&park)[PARK ? 3 * PKW : 1][PARK ? BLOCK : 1] = lds.park;
-  const T* cst = EXT ? cst_ext : cst_own;
+  T (&cst)[CST_WORDS] = lds.cst;
+  T (&kgain)[36] = lds.kgain;
+  T (&park)[3 * PKW][BLOCK] = lds.park;
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   const int leg = (int)((tx & 63) >> 4);
-  const size_t s_raw = EXT ? (size_t)blockIdx.x * SPW + (tx & 15) : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);
-  const bool slot_ok = SPW == 16 || (int)(tx & 15) < SPW;   // (roles: SPW <= 16 states per workgroup, see WBC_ADDR_MACROS)
-  const bool live = slot_ok && s_raw < N;
-  const unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));
+  const size_t s_raw = ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);
+  const bool live = s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
 #define OCS(i) cst[(i) * 4 + leg]
 #define OLDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define OLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define OSTV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define OST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) OSTV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
-  // rhat: HBM workspace (stand-alone kernel) or the workgroup's LDS image (role)
-#define ORHAT(comp, val) do { if constexpr (EXT != 0) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else OSTV(a.ws, comp, val); } while (0)
   // state loads first, table staging while they are in flight
   T qq[4], vb[6];
 #pragma unroll
@@ -271,33 +261,30 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
     ql[k] = OLDV(a.q, 7 + jx[k]);
     vl[k] = OLDV(a.v, 6 + jx[k]);
   }
-  if constexpr (EXT == 0) {
-    // branch-free (clamped index, the tail lanes rewrite the last word): with a divergent staging loop here hipcc 7.2 put
-    // VGPR spill stores of the fp64 build into the loop's exit block BEFORE exec is restored, i.e. with no lane enabled
-    // (found by parity: rhat garbage in every state; tools/spill_lint.py now scans the ISA for that pattern)
+  // branch-free staging (clamped index, the tail lanes rewrite the last word): with a divergent staging loop here hipcc 7.2 put
+  // VGPR spill stores of the fp64 build into the loop's exit block BEFORE exec is restored, i.e. with no lane enabled
+  // (found by parity: rhat garbage in every state; tools/spill_lint.py scans the ISA for that pattern)
 #pragma unroll
-    for (int i0 = 0; i0 < CST_WORDS; i0 += BLOCK) {
-      const int i = min(i0 + (int)tx, CST_WORDS - 1);
-      cst_own[i] = model->cst[i];
-    }
-    // the gains of the joint rows are indexed by a run-time joint number: from LDS (as a chain of selects on the kernel
-    // arguments they were 24 doubles moved into vector registers per joint)
-    if (tx == 0) {
-#pragma unroll
-      for (int i = 0; i < 18; ++i) { kgain[i] = prm.K1[i]; kgain[18 + i] = prm.K2[i]; }  // static indices only
-    }
-    __syncthreads();
+  for (int i0 = 0; i0 < CST_WORDS; i0 += BLOCK) {
+    const int i = min(i0 + (int)tx, CST_WORDS - 1);
+    cst[i] = model->cst[i];
   }
-  if constexpr (EXT == 2) __syncthreads();
+  // the gains are read from LDS: those of the joint rows are indexed by a run-time joint number, and 72 SGPRs of gains held to
+  // the end of a kernel are SGPR spills
+  if (tx == 0) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { kgain[i] = prm.K1[i]; kgain[18 + i] = prm.K2[i]; }  // static indices only
+  }
+  __syncthreads();
 
   T qx, qy, qz, qw;
   {
     const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
-  // base rotation, base body inertia, base velocity / gravity in base coordinates.  The stand-alone kernel forms them twice --
-  // here for the forward sweep and again after the return sweep, from the (laundered) quaternion and a second read of v --
-  // so that 34 values do not live through both sweeps; the roles keep them.
+  // base rotation, base body inertia, base velocity / gravity in base coordinates: formed twice -- here for the forward sweep
+  // and again after the return sweep, from the (laundered) quaternion and a second read of v -- so that 34 values do not live
+  // through both sweeps
   auto base_state = [&](const T* vbx, M3<T>& R, T& bm, V3<T>& bh, S3<T>& bI, V3<T>& om0, V3<T>& v0, V3<T>& gneg) __attribute__((always_inline)) {
     const T x = qx, y = qy, z = qz, w = qw;
     R.a[0] = 1 - 2 * (y * y + z * z); R.a[1] = 2 * (x * y - z * w);     R.a[2] = 2 * (x * z + y * w);
@@ -317,13 +304,9 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   S3<T> bI;
   base_state(vb, R, bm, bh, bI, om0, v0, gneg);
 
-  // ---- forward sweep down the leg: joint rotations, body velocities, weights.
-  // Roles (EXT != 0) keep them in registers.  The stand-alone kernel PARKS what the return sweep needs in LDS
-  // ([word][lane], conflict-free): sin/cos of the joint angle (E is rebuilt from them: 18 FMAs on constants that are read from
-  // LDS anyway) and the body's velocity and gravity direction -- 11 words per joint instead of 54 live values through both
-  // sweeps, which was 255 VGPRs + a 324-byte spill at two wavefronts per SIMD (236 us at N = 262 144, fp64).
-  M3<T> E[PARK ? 1 : 3];
-  V3<T> om[PARK ? 1 : 3], vv[PARK ? 1 : 3], gL[PARK ? 1 : 3];   // body momenta / weights are re-formed from these in the return sweep (fewer live registers)
+  // ---- forward sweep down the leg: joint rotations, body velocities, weights.  What the return sweep needs is PARKED in LDS
+  // ([word][lane], conflict-free): sin / cos of the joint angle (E is rebuilt from them: 18 FMAs on constants that are read from
+  // LDS anyway) and the body's velocity and gravity direction -- 11 words per joint instead of 54 live values through both sweeps.
   auto joint_E = [&](int k, T sn, T cs, M3<T>& Ek) __attribute__((always_inline)) {
     const int o = JOINT_WORDS * k;
 #pragma unroll
@@ -343,22 +326,19 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
       const V3<T> omk = tmul(Ek, omp) + ax * vl[k];
       const V3<T> vvk = tmul(Ek, vp + cross(omp, r));
       const V3<T> gk = tmul(Ek, gp);
-      if constexpr (PARK) {
-        T* pk = &park[PKW * k][tx];
-        pk[0] = sn; pk[BLOCK] = cs;
-        pk[BLOCK * 2] = omk.x; pk[BLOCK * 3] = omk.y; pk[BLOCK * 4] = omk.z;
-        pk[BLOCK * 5] = vvk.x; pk[BLOCK * 6] = vvk.y; pk[BLOCK * 7] = vvk.z;
-        pk[BLOCK * 8] = gk.x; pk[BLOCK * 9] = gk.y; pk[BLOCK * 10] = gk.z;
-      } else {
-        E[k] = Ek; om[k] = omk; vv[k] = vvk; gL[k] = gk;
-      }
+      T* pk = &park[PKW * k][tx];
+      pk[0] = sn; pk[BLOCK] = cs;
+      pk[BLOCK * 2] = omk.x; pk[BLOCK * 3] = omk.y; pk[BLOCK * 4] = omk.z;
+      pk[BLOCK * 5] = vvk.x; pk[BLOCK * 6] = vvk.y; pk[BLOCK * 7] = vvk.z;
+      pk[BLOCK * 8] = gk.x; pk[BLOCK * 9] = gk.y; pk[BLOCK * 10] = gk.z;
       omp = omk; vp = vvk; gp = gk;
-      if constexpr (PARK) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // (without this the compiler keeps the forward sweep's 99 table words in registers for the return sweep instead of reading
+  // (without this the compiler keeps the forward sweep's table words in registers for the return sweep instead of reading
   // them from LDS again)
-  if constexpr (PARK) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
   // ---- return sweep: subtree momentum / weight, their projections on the joint axes, foot geometry
   T p_leg[3], beta_l[3];
   V3<T> dft = mk<T>(OCS(129), OCS(130), OCS(131));
@@ -373,17 +353,12 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
     const V3<T> h = mk<T>(OCS(o + 34), OCS(o + 35), OCS(o + 36));
     S3<T> Io;
     Io.xx = OCS(o + 37); Io.xy = OCS(o + 38); Io.xz = OCS(o + 39); Io.yy = OCS(o + 40); Io.yz = OCS(o + 41); Io.zz = OCS(o + 42);
+    const T* pk = &park[PKW * k][tx];
     M3<T> Ek;
-    V3<T> omk, vvk, glk;
-    if constexpr (PARK) {
-      const T* pk = &park[PKW * k][tx];
-      joint_E(k, pk[0], pk[BLOCK], Ek);
-      omk = mk<T>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]);
-      vvk = mk<T>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]);
-      glk = mk<T>(pk[BLOCK * 8], pk[BLOCK * 9], pk[BLOCK * 10]);
-    } else {
-      Ek = E[k]; omk = om[k]; vvk = vv[k]; glk = gL[k];
-    }
+    joint_E(k, pk[0], pk[BLOCK], Ek);
+    const V3<T> omk = mk<T>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]);
+    const V3<T> vvk = mk<T>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]);
+    const V3<T> glk = mk<T>(pk[BLOCK * 8], pk[BLOCK * 9], pk[BLOCK * 10]);
     SF<T> mk_ = inertia_mul(m, h, Io, omk, vvk), gk;
     gk.n = cross(h, glk);
     gk.f = glk * m;
@@ -400,109 +375,87 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
     // arithmetic into that guarded region and leaves the LDS reads of all three iterations (~160 doubles: table words and
     // parked values) in a row in front of it.  Passing the carried values through an empty asm statement pins each
     // iteration's arithmetic where it is written.
-    if constexpr (PARK) {
-      asm volatile("" : "+v"(macc.n.x), "+v"(macc.n.y), "+v"(macc.n.z), "+v"(macc.f.x), "+v"(macc.f.y), "+v"(macc.f.z));
-      asm volatile("" : "+v"(gacc.n.x), "+v"(gacc.n.y), "+v"(gacc.n.z), "+v"(gacc.f.x), "+v"(gacc.f.y), "+v"(gacc.f.z));
-      asm volatile("" : "+v"(dft.x), "+v"(dft.y), "+v"(dft.z), "+v"(p_leg[k]), "+v"(beta_l[k]));
+    asm volatile("" : "+v"(macc.n.x), "+v"(macc.n.y), "+v"(macc.n.z), "+v"(macc.f.x), "+v"(macc.f.y), "+v"(macc.f.z));
+    asm volatile("" : "+v"(gacc.n.x), "+v"(gacc.n.y), "+v"(gacc.n.z), "+v"(gacc.f.x), "+v"(gacc.f.y), "+v"(gacc.f.z));
+    asm volatile("" : "+v"(dft.x), "+v"(dft.y), "+v"(dft.z), "+v"(p_leg[k]), "+v"(beta_l[k]));
 #pragma unroll
-      for (int j = k; j < 3; ++j) asm volatile("" : "+v"(jc[j].x), "+v"(jc[j].y), "+v"(jc[j].z));
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int j = k; j < 3; ++j) asm volatile("" : "+v"(jc[j].x), "+v"(jc[j].y), "+v"(jc[j].z));
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if constexpr (EXT == 0) {   // see base_state
-    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
-    asm volatile("" ::: "memory");
+  // base quantities again (see base_state)
+  asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
+  asm volatile("" ::: "memory");
 #pragma unroll
-    for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
-    base_state(vb, R, bm, bh, bI, om0, v0, gneg);
-  }
-  // ---- observer update (order 1 or 2) and rhat for the QP kernel, in two phases.  The stand-alone kernel finishes the joint
-  // rows first (their inputs -- Jacobian columns, leg momenta -- die there) and forms the base rows afterwards; with both in
-  // flight at once the tail of the kernel was its register peak.
+  for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
+  base_state(vb, R, bm, bh, bI, om0, v0, gneg);
+
+  // ---- observer update (order 1 or 2) and rhat for the QP kernel (18 words at WS_RHAT of the step workspace), in two phases:
+  // the joint rows first (their inputs -- Jacobian columns, leg momenta -- die there), the base rows afterwards
   const bool obs_on = prm.observer_order > 0;
   const T dt = prm.dt;
   const bool o1 = prm.observer_order == 1;
   V3<T> fp = mk<T>(0, 0, 0);
   if (obs_on) fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
-  auto joint_rows = [&]() __attribute__((always_inline)) {
-    if constexpr (JOINTS) {
-      T rl[3] = {0, 0, 0};
-      if (obs_on) {
+  {
+    T rl[3] = {0, 0, 0};
+    if (obs_on) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int c = 6 + jx[k];
-          const T r0 = OLDV(a.obs_r, c);
-          const T u = OLDV(a.tau_prev, jx[k]) + dot(mul(R, jc[k]), fp);
-          const T ig = OLDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
-          const T e = p_leg[k] - ig;
-          T k1, k2;
-          if constexpr (EXT == 0) { k1 = kgain[c]; k2 = kgain[18 + c]; }
-          else {
-            k1 = prm.K1[6]; k2 = prm.K2[6];   // roles: gains of joint row c by a select (no run-time index into the kernel arguments)
-#pragma unroll
-            for (int j = 1; j < 12; ++j) { k1 = (jx[k] == j) ? prm.K1[6 + j] : k1; k2 = (jx[k] == j) ? prm.K2[6 + j] : k2; }
-          }
-          rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
-          OSTV(a.obs_integ, c, ig);
-          OSTV(a.obs_r, c, rl[k]);
-        }
+      for (int k = 0; k < 3; ++k) {
+        const int c = 6 + jx[k];
+        const T r0 = OLDV(a.obs_r, c);
+        const T u = OLDV(a.tau_prev, jx[k]) + dot(mul(R, jc[k]), fp);
+        const T ig = OLDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
+        const T e = p_leg[k] - ig;
+        const T k1 = kgain[c], k2 = kgain[18 + c];
+        rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
+        OSTV(a.obs_integ, c, ig);
+        OSTV(a.obs_r, c, rl[k]);
       }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
     }
-  };
-  auto base_rows = [&]() __attribute__((always_inline)) {
-    if constexpr (BASE) {
-      // the four legs + the base body itself
-      T p_b[6], beta_b[6];
-      {
-        const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
-        T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
-        xrow_sum_k<T, 12>(xb);
-        const V3<T> m0n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n, m0f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
-        const V3<T> g0n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg), g0f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
-        const V3<T> Pl = mul(R, m0f), Pa = mul(R, m0n);
-        const V3<T> gl = mul(R, g0f), ga = mul(R, g0n);
-        const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
-        p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
-        beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
-        beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
-      }
-      T rb[6] = {0, 0, 0, 0, 0, 0};
-      if (obs_on) {
-        const V3<T> dxf = cross(mul(R, dft), fp);
-        T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
-        xrow_sum_k<T, 6>(ub);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const T r0 = OLDU(a.obs_r, c);
-          const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
-          const T e = p_b[c] - ig;
-          if constexpr (EXT == 0) rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
-          else rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
-          p_b[c] = ig;
-        }
-        // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
-        // of the wave before any lane stores to it
-        OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
-        if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
-        OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
-        if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
-      }
-      ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
-      if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
-    }
-  };
-  if constexpr (EXT == 0) {
-    joint_rows();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    base_rows();
-  } else {
-    base_rows();
-    joint_rows();
+    for (int k = 0; k < 3; ++k) OSTV(a.ws, WS_RHAT + 6 + 3 * leg + k, rl[k]);
   }
-#undef ORHAT
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    // the four legs + the base body itself
+    T p_b[6], beta_b[6];
+    {
+      const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+      T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
+      xrow_sum_k<T, 12>(xb);
+      const V3<T> m0n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n, m0f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
+      const V3<T> g0n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg), g0f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
+      const V3<T> Pl = mul(R, m0f), Pa = mul(R, m0n);
+      const V3<T> gl = mul(R, g0f), ga = mul(R, g0n);
+      const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
+      p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
+      beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
+      beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
+    }
+    T rb[6] = {0, 0, 0, 0, 0, 0};
+    if (obs_on) {
+      const V3<T> dxf = cross(mul(R, dft), fp);
+      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+      xrow_sum_k<T, 6>(ub);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const T r0 = OLDU(a.obs_r, c);
+        const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
+        const T e = p_b[c] - ig;
+        rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
+        p_b[c] = ig;
+      }
+      // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
+      // of the wave before any lane stores to it
+      OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+      if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+    }
+    OSTV(a.ws, sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
+    if (leg < 2) OSTV(a.ws, WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
+  }
 #undef OST4
 #undef OSTV
 #undef OLDV
