@@ -339,6 +339,20 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   // them from LDS again)
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  // The inputs of the update -- previous forces and torques, the observer state -- are requested HERE, so that they arrive
+  // during the return sweep: loaded where they are used, after it, each exposed a memory latency (two wavefronts per SIMD).
+  const bool obs_on = prm.observer_order > 0;
+  V3<T> fp = mk<T>(0, 0, 0);
+  T in_r[3] = {0, 0, 0}, in_ig[3] = {0, 0, 0}, in_tp[3] = {0, 0, 0}, in_rb[6] = {0, 0, 0, 0, 0, 0}, in_igb[6] = {0, 0, 0, 0, 0, 0};
+  if (obs_on) {
+    fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { in_r[k] = OLDV(a.obs_r, 6 + jx[k]); in_ig[k] = OLDV(a.obs_integ, 6 + jx[k]); in_tp[k] = OLDV(a.tau_prev, jx[k]); }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { in_rb[c] = OLDU(a.obs_r, c); in_igb[c] = OLDU(a.obs_integ, c); }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);   // the base velocity again, for base_state after the sweep
   // ---- return sweep: subtree momentum / weight, their projections on the joint axes, foot geometry
   T p_leg[3], beta_l[3];
   V3<T> dft = mk<T>(OCS(129), OCS(130), OCS(131));
@@ -384,27 +398,29 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   }
   // base quantities again (see base_state)
   asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
-  asm volatile("" ::: "memory");
 #pragma unroll
-  for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
+  for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(vb[c]));
   base_state(vb, R, bm, bh, bI, om0, v0, gneg);
 
   // ---- observer update (order 1 or 2) and rhat for the QP kernel (18 words at WS_RHAT of the step workspace), in two phases:
   // the joint rows first (their inputs -- Jacobian columns, leg momenta -- die there), the base rows afterwards
-  const bool obs_on = prm.observer_order > 0;
   const T dt = prm.dt;
   const bool o1 = prm.observer_order == 1;
-  V3<T> fp = mk<T>(0, 0, 0);
-  if (obs_on) fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
+  // (pins: the loads above stay where they are issued)
+  asm volatile("" : "+v"(fp.x), "+v"(fp.y), "+v"(fp.z));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(in_r[k]), "+v"(in_ig[k]), "+v"(in_tp[k]));
+#pragma unroll
+  for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(in_rb[c]), "+v"(in_igb[c]));
   {
     T rl[3] = {0, 0, 0};
     if (obs_on) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = 6 + jx[k];
-        const T r0 = OLDV(a.obs_r, c);
-        const T u = OLDV(a.tau_prev, jx[k]) + dot(mul(R, jc[k]), fp);
-        const T ig = OLDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
+        const T r0 = in_r[k];
+        const T u = in_tp[k] + dot(mul(R, jc[k]), fp);
+        const T ig = in_ig[k] + dt * (u + beta_l[k] + r0);
         const T e = p_leg[k] - ig;
         const T k1 = kgain[c], k2 = kgain[18 + c];
         rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
@@ -440,14 +456,13 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
       xrow_sum_k<T, 6>(ub);
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        const T r0 = OLDU(a.obs_r, c);
-        const T ig = OLDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
+        const T r0 = in_rb[c];
+        const T ig = in_igb[c] + dt * (ub[c] + beta_b[c] + r0);
         const T e = p_b[c] - ig;
         rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
         p_b[c] = ig;
       }
-      // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
-      // of the wave before any lane stores to it
+      // (the replicated rows were read by every lane of the wave long before any lane stores to them)
       OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
       if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
       OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
