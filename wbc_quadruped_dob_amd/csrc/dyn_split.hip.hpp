@@ -277,6 +277,11 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   for (int c = 0; c < 4; ++c) qq[c] = LDU(a.q, 3 + c);
 #pragma unroll
   for (int c = 0; c < 6; ++c) vb[c] = LDU(a.v, c);
+  T qpos[3] = {0, 0, 0};   // base position for pf: requested with the rest (loaded where it is used it exposed a memory latency)
+  if (WPF && a.pf) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) qpos[c] = LDU(a.q, c);
+  }
   int jx[3];
   unsigned jxN[3];
 #pragma unroll
@@ -520,9 +525,9 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     for (int k = 0; k < 3; ++k) jw[k] = mul(R, jc[k]);
   }
   if (WPF && a.pf) {
-    STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
-    STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
-    STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
+    STL(a.pf, 0, 3, qpos[0] + dw.x);
+    STL(a.pf, 1, 3, qpos[1] + dw.y);
+    STL(a.pf, 2, 3, qpos[2] + dw.z);
   }
   if (STEP) {
     if constexpr (!EARLY) {
