@@ -107,7 +107,7 @@ typedef struct wbc_solver_options {
   int rollout_persistent; /* 1 (default): rollouts of at most fused_max states = one launch per rollout; 0: per-tick launches */
   int rollout_spw;        /* states per workgroup of the rollout kernel: 0 = auto (4 up to 1024 states, else 16), 4, 16 */
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
-                             kernel instead of inside the sweep; -1 = auto (fp32: from 49152 states on, fp64: from 24576),
+                             kernel instead of inside the sweep; -1 = auto (fp32: from 40960 states on, fp64: from 20480),
                              -2 = never */
   int one_zerocopy;       /* 1: the single-robot host-pointer calls let the kernel read/write the pinned staging image directly */
   int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */

@@ -24,7 +24,7 @@ def test_no_masked_spill_stores(tmp_path):
 # no functional test noticed.
 BUDGET = [
     (r"fused_tick_kernelI[df]", 256),
-    (r"dyn_sweep_kernelIdLi1ELi256", 256), (r"dyn_sweep_kernelIdLi(3|11)ELi256", 256), (r"dyn_sweep_kernelIfLi(1|3|11)ELi256", 256),
+    (r"dyn_sweep_kernelIdLi1ELi256", 256), (r"dyn_sweep_kernelIdLi11ELi256", 256), (r"dyn_sweep_kernelIfLi(1|11)ELi256", 256),
     (r"observer_kernelI[df]", 256),
     (r"qp_lane_kernelI[df]", 256),
     (r"qp_tile_kernelI[df]Lb[01]ELi(32|64)E", 256), (r"qp_group16_kernelI[df]", 256), (r"qp_list_kernelI[df]", 256),

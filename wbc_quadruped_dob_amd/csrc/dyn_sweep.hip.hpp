@@ -273,6 +273,24 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 #pragma unroll
     for (int c = 0; c < 6; ++c) ad_in[c] = LDU(a.vdot_des, c);
   }
+  // observer variants: the inputs of the update are requested here as well.  These variants run one wavefront per SIMD with
+  // registers to spare (the occupancy is LDS-bound), and at the batch sizes that still use them a wavefront is alone on its
+  // SIMD: every load issued where it is used (eight places in the observer pass) exposed its whole latency.
+  const bool obs_upd = OBS && STEP && prm.observer_order > 0;
+  T ob_fp[3] = {0, 0, 0}, ob_rb[6] = {0, 0, 0, 0, 0, 0}, ob_igb[6] = {0, 0, 0, 0, 0, 0}, ob_rl[3] = {0, 0, 0}, ob_igl[3] = {0, 0, 0}, ob_tp[3] = {0, 0, 0};
+  T ob_wd[6] = {0, 0, 0, 0, 0, 0};
+  if (obs_upd) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ob_fp[c] = LDV(a.f_prev, 3 * leg + c);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { ob_rb[c] = LDU(a.obs_r, c); ob_igb[c] = LDU(a.obs_integ, c); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ob_rl[k] = LDV(a.obs_r, 6 + jx[k]); ob_igl[k] = LDV(a.obs_integ, 6 + jx[k]); ob_tp[k] = LDV(a.tau_prev, jx[k]); }
+  }
+  if (OBS && STEP) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ob_wd[c] = LDU(a.w_des, c);
+  }
 
   SSTAMP();  // 1: state loads issued
   // the per-leg constant table is staged AFTER the state loads have been issued: one memory round trip, not two
@@ -614,8 +632,8 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     SF<T> ivk[3];
     V3<T> om0, v0, gneg;
     {
-      om0 = tmul(R, mk<T>(LDU(a.v, 3), LDU(a.v, 4), LDU(a.v, 5)));
-      v0 = tmul(R, mk<T>(LDU(a.v, 0), LDU(a.v, 1), LDU(a.v, 2)));
+      om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));   // (vb, vl: kept from the top of the kernel in these variants)
+      v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
       gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));
       V3<T> omp2 = om0, vp2 = v0, gp2 = gneg;
 #pragma unroll
@@ -632,7 +650,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
         S3<T> Io;
         Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
-        const T qd = *(const T*)((const char*)(a.v + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+        const T qd = vl[k];
         omk[k] = tmul(Ek, omp2) + ax * qd;
         vvk[k] = tmul(Ek, vp2 + cross(omp2, r));
         glk[k] = tmul(Ek, gp2);
@@ -683,7 +701,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   if (OBS) {
     const V3<T> Pl = mul(R, mom0.f), Pa = mul(R, mom0.n);
     const V3<T> gl = mul(R, grv0.f), ga = mul(R, grv0.n);
-    const V3<T> cx = cross(mk<T>(LDU(a.v, 0), LDU(a.v, 1), LDU(a.v, 2)), Pl);
+    const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
     p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
     beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
     beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
@@ -708,7 +726,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
     if (OBS && prm.observer_order > 0) {
       // generalized force of the previous commands at the current configuration
-      const V3<T> fp = mk<T>(LDV(a.f_prev, 3 * leg + 0), LDV(a.f_prev, 3 * leg + 1), LDV(a.f_prev, 3 * leg + 2));
+      const V3<T> fp = mk<T>(ob_fp[0], ob_fp[1], ob_fp[2]);
       const V3<T> dxf = cross(dw, fp);
       T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
       XSUM(ub, 6);
@@ -716,14 +734,13 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       const bool o1 = prm.observer_order == 1;
 #pragma unroll
       for (int c = 0; c < 6; ++c) {  // replicated over the quad (same values in all four lanes)
-        const T r0 = LDU(a.obs_r, c);
-        const T ig = LDU(a.obs_integ, c) + dt * (ub[c] + beta_b[c] + r0);
+        const T r0 = ob_rb[c];
+        const T ig = ob_igb[c] + dt * (ub[c] + beta_b[c] + r0);
         const T e = p_b[c] - ig;
         rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);   // (from LDS: 72 SGPRs of gains held to the end of the kernel meant SGPR spills read back 800 times)
         p_b[c] = ig;  // reuse as the new integ for the store below
       }
-      // every lane's loads of the replicated rows feed its own store values, so all loads of a row have
-      // returned in every lane of the wave before any lane can store to it
+      // (the replicated rows were read by every lane of the wave at the top of the kernel, long before any lane stores to them)
       ST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
       if (leg < 2) STV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
       ST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
@@ -731,9 +748,9 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = 6 + jx[k];
-        const T r0 = LDV(a.obs_r, c);
-        const T u = LDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
-        const T ig = LDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
+        const T r0 = ob_rl[k];
+        const T u = ob_tp[k] + dot(jw[k], fp);
+        const T ig = ob_igl[k] + dt * (u + beta_l[k] + r0);
         const T e = p_leg[k] - ig;
         rl[k] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
         STV(a.obs_integ, c, ig);
@@ -743,7 +760,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     if (OBS) {
       T b[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
+      for (int c = 0; c < 6; ++c) b[c] = ob_wd[c] - rb[c];
       WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
       if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
     }

@@ -20,15 +20,12 @@ static hipError_t sweep_mode(const LaunchCtx& L, const DevModel<Scalar>* model, 
 
 template <>
 hipError_t k_dyn_sweep<Scalar>(const LaunchCtx& L, int mode, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {
-  switch (mode) {
+  switch (mode) {   // (the combinations the host side launches: wbc_api.cpp)
     case 0: return sweep_mode<0>(L, model, prm, a);                                   // pf only
     case SW_MATS: return sweep_mode<SW_MATS>(L, model, prm, a);
     case SW_OBS: return sweep_mode<SW_OBS>(L, model, prm, a);
     case SW_MATS | SW_OBS: return sweep_mode<SW_MATS | SW_OBS>(L, model, prm, a);
-    case SW_STEP: return sweep_mode<SW_STEP>(L, model, prm, a);
-    case SW_MATS | SW_STEP: return sweep_mode<SW_MATS | SW_STEP>(L, model, prm, a);
     case SW_MATS | SW_STEP | SW_NOB: return sweep_mode<SW_MATS | SW_STEP | SW_NOB>(L, model, prm, a);
-    case SW_STEP | SW_OBS: return sweep_mode<SW_STEP | SW_OBS>(L, model, prm, a);
     case SW_MATS | SW_STEP | SW_OBS: return sweep_mode<SW_MATS | SW_STEP | SW_OBS>(L, model, prm, a);
     default: return hipErrorInvalidValue;
   }

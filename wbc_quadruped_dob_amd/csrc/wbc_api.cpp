@@ -315,12 +315,13 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   // observer as its own kernel before the sweep (the all-in-one observer sweep runs one wavefront per SIMD).  Measured on
   // MI355X, front half of the tick, all-in-one -> observer kernel + observer-free sweep (us): fp64 464 -> 112 + 279 at
   // 262 144 states, 111 -> 34 + 57 at 65 536, but 48 -> 25 + 33 at 32 768; fp32 298 -> 57 + 168 at 262 144, 45 -> 17 + 27 at
-  // 65 536 (a tie per tick), 26 -> 13 + 16 at 32 768.  After the sweep lost its forwarding of w_des (SW_NOB) the observer-free
-  // sweep got faster still; per tick, all-in-one -> split (M steps/s): fp64 417 -> 467 at 49 152, 425 -> 430 at 32 768,
-  // 330 -> 386 at 24 576, but 315 -> 289 at 16 384; fp32 824 -> 891 at 98 304, 777 -> 822 at 65 536, 651 -> 690 at 49 152,
-  // but 607 -> 569 at 32 768.  Default: fp64 from 24 576 states on, fp32 from 49 152.
+  // 65 536 (a tie per tick), 26 -> 13 + 16 at 32 768.  At the final kernels (observer-free sweep without the w_des forwarding,
+  // both observer forms with their inputs requested up front) per tick, all-in-one -> split (M steps/s): fp64 437 -> 472 at
+  // 65 536, 428 -> 446 at 49 152, 405 -> 439 at 40 960, 451 -> 460 at 32 768, 360 -> 398 at 24 576, 308 -> 341 at 20 480, but
+  // 330 -> 289 at 16 384; fp32 855 -> 934 at 98 304, 784 -> 798 at 65 536, 681 -> 717 at 49 152, 594 -> 629 at 40 960, but
+  // 625 -> 587 at 32 768.  Default: fp64 from 20 480 states on, fp32 from 40 960.
   if (o.obs_split_min >= 0) s->obs_split_min = (size_t)o.obs_split_min;
-  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 49152 : 24576;
+  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 40960 : 20480;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
