@@ -107,6 +107,46 @@ def test_step_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n):
         assert relerr(got[k], d[k]) < TIGHT64, k
 
 
+# The defaults switch kernels with the batch size (wbc_api.cpp): fused tick up to 4 096 / 8 192 states, the dense QP dealt in
+# tiles from 12 288, the split observer from 20 480 (fp64) / 40 960 (fp32), the per-lane QP path from 49 152 (fp64).  One batch
+# either side of every switch, DEFAULT options, against the oracle.
+@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 0, 2, 8192), ("f64", 0, 2, 8200), ("f64", 1, 3, 4100), ("f64", 0, 2, 12300),
+                                             ("f64", 1, 3, 20470), ("f64", 1, 3, 20490), ("f64", 0, 2, 49100), ("f64", 0, 4, 49200),
+                                             ("f64", 2, 3, 49200), ("f32", 1, 4, 40950), ("f32", 1, 4, 40970), ("f32", 0, 2, 8200)])
+def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
+    torch = torch_cuda
+    nd = _np_dtype(dtype)
+    c = lambda a: np.ascontiguousarray(a, nd)
+    solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=17)
+    integ = r = None
+    if obs:
+        integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] - 0.02
+        r = 0.2 * np.cos(np.arange(n * 18).reshape(n, 18))
+    P0 = synth.default_params(observer_order=obs, dtype=dtype)
+    ig_ref = None if integ is None else c(integ).copy()
+    r_ref = None if r is None else c(r).copy()
+    ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], c(B["tau_prev"]),
+                      c(B["f_prev"]), ig_ref, r_ref, nthreads=8)
+    got = _run_step(torch, solver, B, dtype, None if integ is None else c(integ).copy(), None if r is None else c(r).copy(), want_mats=True)
+    if dtype == "f64":
+        np.testing.assert_array_equal(got["status"], ref["status"])
+        ok = ref["status"] == 0
+        assert ok.mean() > 0.999
+        tol = TIGHT64
+    else:
+        ok = (got["status"] == 0) & (ref["status"] == 0)
+        assert ok.mean() > 0.995
+        tol = 2e-3
+    assert relerr(got["tau"][ok], ref["tau"][ok]) < tol and relerr(got["f"][ok], ref["f"][ok]) < tol
+    if obs:
+        assert relerr(got["integ"], ig_ref) < (TIGHT64 if dtype == "f64" else 1e-4)
+        assert relerr(got["r"], r_ref) < (TIGHT64 if dtype == "f64" else 2e-3)
+    d = oracle.dynamics(c(B["q"]), c(B["v"]), nthreads=8)
+    for k in ("M", "h", "Jc", "pf"):
+        assert relerr(got[k], d[k]) < (TIGHT64 if dtype == "f64" else 1e-4), k
+
+
 def test_step_vs_golden(torch_cuda, gpu_model, golden):
     torch = torch_cuda
     for case in ("cfg2", "cfg3", "cfg4o2"):
