@@ -54,7 +54,7 @@ constexpr int FUSED_OBS_WAVES = 2;
 template <class T, bool OBSERVER, bool MATS>
 __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
-  __shared__ T cst[CST_WORDS];
+  __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready, gready, oready;   // rnea role done / its lever arms are out / observer role done
@@ -138,7 +138,7 @@ template <class T, bool OBSERVER, bool TRACK, int SPW = 16>
 __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,
                                                                          int horizon, const DevRefParams<T>* __restrict__ G, RefArgs<T> ra) {
-  __shared__ T cst[CST_WORDS];
+  __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready, gready, oready, mready, rready;
