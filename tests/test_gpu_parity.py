@@ -782,6 +782,27 @@ def test_tick_is_graph_capturable(torch_cuda, gpu_model, mode):
             assert torch.equal(want[k], got[k]), (mode, k)
 
 
+def test_hand_over_list_takes_a_whole_batch_and_empties_itself(torch_cuda, gpu_model, oracle):
+    """Worst case of the per-lane QP path: EVERY state ends in the hand-over list (garbage target wrench in all of them).  The
+    list must hold the batch (capacity = max_batch), the tick must return, and the next tick on clean inputs must start from
+    an empty list and reproduce the oracle."""
+    torch = torch_cuda
+    n = 50000
+    solver, P = _solver(gpu_model, max_batch=n, options={"fused_max": 0, "qp_lane": 1})
+    B = synth.make_batch(2, n, gpu_model.total_mass, rank=77)
+    Bn = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}
+    Bn["w_des"][:, 1] = np.nan
+    got = _run_step(torch, solver, Bn, "f64")
+    assert solver.qp_handover() == n
+    assert (got["status"] != 0).all() or np.isnan(got["tau"]).any(axis=1).all()   # nothing pretends to be a solution
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
+    for _ in range(2):   # twice: the second tick also starts from what the first one left
+        got2 = _run_step(torch, solver, B, "f64")
+        assert 0 < solver.qp_handover() < 0.2 * n
+        np.testing.assert_array_equal(got2["status"], ref["status"])
+        assert relerr(got2["tau"], ref["tau"]) < TIGHT64 and relerr(got2["f"], ref["f"]) < TIGHT64
+
+
 @pytest.mark.parametrize("n,lane", [(512, 0), (20992, 0), (20992, 1)])   # the fused tick; the two-kernel tick with the tiled QP kernel (predictor
 def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle, n, lane):   # + LDS sort); with the per-lane QP kernel in front
     """Quaternions and terrain normals are normalised inside (as in the oracle); a NaN in one state's inputs must not
