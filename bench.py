@@ -101,7 +101,9 @@ def main():
     ap.add_argument("--tracking", action="store_true", help="config 5: CoM planner in the loop (reference kernel every tick)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-oracle baseline leg")
     ap.add_argument("--no-mats", action="store_true", help="do not write M,h,Jc to HBM (fused-only variant)")
-    ap.add_argument("--sample-every", type=int, default=10, help="HIP-event instrumentation period inside the timed region")
+    ap.add_argument("--sample-every", type=int, default=47,
+                    help="HIP-event instrumentation period inside the timed region (a sampled launch costs ~2 us more: every 10-th "
+                         "took 2 %% off `value`; a prime, so that with short blocks the samples fall on every position of a block)")
     ap.add_argument("--large-batch", type=int, default=262144, help="extra roofline characterisation batch (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-state latency leg (p50 over 1000 ticks)")
     ap.add_argument("--single-process", action="store_true",
