@@ -53,6 +53,47 @@ __global__ __launch_bounds__(64) void k_soa_write_legmajor(double* __restrict__ 
     *(double*)((char*)out + (size_t)((comp * N + s) * 8u)) = v + r;
   }
 }
+// the same leg-major lanes, but the rows are tiled: [tile of T states][component][T] -- every tile is one contiguous
+// ROWS*T*8-byte region, so the workgroups in flight touch a few regions instead of ROWS streams 8N bytes apart
+template <int ROWS>
+__global__ __launch_bounds__(64) void k_soa_write_tiled(double* __restrict__ out, unsigned N, unsigned T) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned leg = lane >> 4;
+  const unsigned s = blockIdx.x * 16 + (lane & 15);
+  if (s >= N) return;
+  const unsigned tile = s / T, st = s % T;
+  const double v = (double)lane;
+  char* base = (char*)out + (size_t)tile * ROWS * T * 8u;
+#pragma unroll 8
+  for (int r = 0; r < ROWS / 4; ++r) {
+    const unsigned comp = 4 * r + leg;
+    *(double*)(base + (size_t)((comp * T + st) * 8u)) = v + r;
+  }
+}
+// one component row per store instruction: the 64 lanes hold 64 consecutive states (512 contiguous bytes per instruction)
+template <int ROWS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_soa_write_row64(double* __restrict__ out, unsigned N) {
+  const unsigned s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= N) return;
+  const double v = (double)threadIdx.x;
+#pragma unroll 8
+  for (int r = 0; r < ROWS / 4; ++r)
+    *(double*)((char*)out + (size_t)((((unsigned)r * 4u + (blockIdx.y & 3u)) * N + s) * 8u)) = v + r;
+}
+// leg-major lanes as above in 256-thread workgroups (4 wavefronts = 64 consecutive states)
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_soa_write_legmajor256(double* __restrict__ out, unsigned N) {
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned leg = lane >> 4;
+  const unsigned s = blockIdx.x * 64 + w * 16 + (lane & 15);
+  if (s >= N) return;
+  const double v = (double)lane;
+#pragma unroll 8
+  for (int r = 0; r < ROWS / 4; ++r) {
+    const unsigned comp = 4 * r + leg;
+    *(double*)((char*)out + (size_t)((comp * N + s) * 8u)) = v + r;
+  }
+}
 // 16 bytes per lane: lane pairs (state s, s+1) merged: 32 lanes x 16 B cover the same 4 x 128 B per instruction pair
 template <int ROWS>
 __global__ __launch_bounds__(64) void k_soa_write_x4(double* __restrict__ out, unsigned N) {
@@ -101,6 +142,17 @@ int main() {
     printf("SoA 444 rows N=%6u xcd  : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
     t = timeit([&] { hipLaunchKernelGGL((k_soa_write_legmajor<444>), dim3((N + 15) / 16), dim3(64), 0, 0, b, N); }, 20);
     printf("SoA 444 rows N=%6u legmajor lanes : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
+    for (unsigned T : {64u, 1024u, 4096u, 16384u}) {
+      if (T > N) continue;
+      t = timeit([&] { hipLaunchKernelGGL((k_soa_write_tiled<444>), dim3((N + 15) / 16), dim3(64), 0, 0, b, N, T); }, 20);
+      printf("SoA 444 rows N=%6u legmajor lanes, tiles of %5u states : %.1f us  %.0f GB/s\n", N, T, t * 1e3, wb / t / 1e6);
+    }
+    t = timeit([&] { hipLaunchKernelGGL((k_soa_write_row64<444, 64>), dim3((N + 63) / 64, 4), dim3(64), 0, 0, b, N); }, 20);
+    printf("SoA 444 rows N=%6u one row x 64 states per instruction, 64-thread wg : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
+    t = timeit([&] { hipLaunchKernelGGL((k_soa_write_row64<444, 256>), dim3((N + 255) / 256, 4), dim3(256), 0, 0, b, N); }, 20);
+    printf("SoA 444 rows N=%6u one row x 64 states per instruction, 256-thread wg: %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
+    t = timeit([&] { hipLaunchKernelGGL((k_soa_write_legmajor256<444>), dim3((N + 63) / 64), dim3(256), 0, 0, b, N); }, 20);
+    printf("SoA 444 rows N=%6u legmajor lanes, 256-thread wg : %.1f us  %.0f GB/s\n", N, t * 1e3, wb / t / 1e6);
     t = timeit([&] { hipLaunchKernelGGL((k_soa_write_x4<440>), dim3((N + 15) / 16), dim3(64), 0, 0, b, N); }, 20);
     printf("SoA 440 rows N=%6u 16B/lane pairs : %.1f us  %.0f GB/s\n", N, t * 1e3, (size_t)440 * N * 8 / t / 1e6);
   }
