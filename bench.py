@@ -64,6 +64,10 @@ def self_launch(args):
 def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min_blocks=3):
     """Times blocks of EXACTLY `steps` ticks, each bracketed by barrier + synchronize on both sides, until at least
     `min_total_s` has been measured AND at least `min_blocks` blocks exist; returns the per-block seconds (max over ranks).
+    The ranks leave the opening barrier together and do not talk to each other inside a block (no data-path collective), so
+    the job's time for the block is the slowest rank's t1 - t0 with t1 read after that rank's synchronize: the MAX over
+    ranks below.  The closing barrier follows the clock read -- its own latency (a one-element RCCL all-reduce plus a host
+    wait, tens of microseconds) is not part of the K ticks and would be 10 % of a 20-tick block.
     A 20-tick block at the bench default lasts 0.5 ms -- one scheduler hiccup moves a single sample by > 5 %, the median of
     ~100 blocks does not.  (min_blocks: a one-off stall of ~70 ms was seen in about one in twelve fp32 runs, always in the first
     or second block; with one or two blocks it WAS the median.)"""
@@ -77,9 +81,9 @@ def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
+        dt = time.perf_counter() - t0     # this rank's K ticks, finished on its device
         if dist is not None:
             dist.barrier()
-        dt = time.perf_counter() - t0
         if dist is not None:   # every rank takes the same decision: the slowest rank's clock
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -91,7 +91,8 @@ def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None):
         tau = get_tau(step_fn())
         dist.all_gather_into_tensor(flat, tau.contiguous())
     sync()
+    dt = time.perf_counter() - t0   # read before the closing barrier: the MAX over ranks below is the job's time
     dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=tau.device)
+    el = torch.tensor([dt], dtype=torch.float64, device=tau.device)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     return float(el.item()), gathered
