@@ -40,6 +40,14 @@ def dyn_kernel_name(split):
     return "mass_jac_kernel" if split else "dyn_sweep_kernel"
 
 
+def tick_sweep_symbol(dtype, obs, n):
+    """rocprofv3 name prefix of the sweep a two-kernel tick with M/h/Jc outputs launches (wbc_api.cpp): MODE 11 = MATS | STEP | NOB
+    (observer off, or the observer as its own kernel from obs_split_min states on), MODE 7 = MATS | STEP | OBS"""
+    split_min = 20480 if dtype == "f64" else 40960
+    mode = 7 if (obs and n < split_min) else 11
+    return "dyn_sweep_kernel<%s, %d," % ("double" if dtype == "f64" else "float", mode)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks as a child process.  Nothing in THIS process
     initialises the GPU (device_count() does not, on this image) and nothing is exec'ed: the child is a subprocess and
@@ -126,7 +134,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("WBC_BENCH_FORCE_DIST"):   # (the variable: a one-rank job that still takes the N > 1 path, for the tests)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -180,6 +188,16 @@ def main():
     tm = solver.collect_timing()
     solver.enable_timing(0)
     elapsed = float(np.median(blocks))   # seconds per block of exactly args.steps ticks
+    long_blocks = None
+    if dist is not None:
+        # N > 1: the driver's K may be 20 ticks = 0.4 ms per block, where one late rank moves the maximum by several per cent.
+        # The same ticks again in blocks of >= 5 ms (same bracketing, same max over ranks), reported BESIDE `value`.
+        k_long = max(args.steps, int(np.ceil(5e-3 / max(elapsed / args.steps, 1e-7))))
+        lb = timed_blocks(step, k_long, dist, torch)
+        el_long = float(np.median(lb))
+        long_blocks = {"value": k_long * n * world / el_long, "ms_per_step": el_long / k_long * 1e3, "steps_per_block": k_long,
+                       "blocks": len(lb), "block_ms_median": el_long * 1e3,
+                       "note": "blocks of >= 5 ms so that rank skew at the barriers is < 1 % of a block; `value` keeps the contract's K"}
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
     # the optional consumer-side collective (every rank receives all torques), reported BESIDE `value`
@@ -216,7 +234,21 @@ def main():
         # mu, mask) + out 24 (tau, f) + M/h/Jc 405 = 507; observer on adds 60 in (state, tau_prev, f_prev) + 36 out = 603
         words = (507 + (96 if obs else 0) - (0 if want_mats else 405)) if fused else dyn_words(split)
         dyn_bytes = words * ts * n
+        # The span the roofline is priced on must fit inside a step.  The sampled launches carry their own start / stop events
+        # (hipExtLaunchKernelGGL), which makes THEM ~2 us slower than the un-sampled launches that `value` is made of (round 2:
+        # 22.1 us sampled vs 21.05 us per step vs 19.96 us by rocprofv3).  Back-to-back launches of one kernel per step on one
+        # stream have period = kernel duration + dispatch gap >= kernel duration, so for the one-launch tick the un-perturbed
+        # bound is the step period itself; for a multi-kernel tick the sampled spans are scaled down when their sum exceeds it.
+        period_s = elapsed / args.steps
+        event_span_s = dyn_s
+        spans_sum = dyn_s + (0.0 if fused else qp_s + qpl_s + rnea_s)
+        span_scale = min(1.0, period_s / spans_sum) if spans_sum > 0 else 1.0
+        dyn_s = dyn_s * span_scale
         achieved = dyn_bytes / dyn_s / 1e9 if ((want_mats or fused) and dyn_s > 0) else None
+        # SURVEY.md 8(d) whole-path algorithmic bytes: in 78 words + out 24 (observer: + 60 in, + 36 out)
+        path_words = 102 + (96 if obs else 0)
+        path_gbs = path_words * ts * (args.steps * n / elapsed) / 1e9
+        devinfo = device_probe(torch) if world == 1 else None
         res = {
             "metric": "WBC control-steps/sec (batched DogBot)",
             "value": args.steps * n * world / elapsed,
@@ -239,10 +271,15 @@ def main():
             "roofline": {"kernel": ("fused_tick_kernel" if fused else dyn_kernel_name(split)),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": pmc_traffic(("fused_tick" if fused else dyn_kernel_name(split)), n, dtype),
+                         "traffic": pmc_traffic(("fused_tick" if fused else tick_sweep_symbol(dtype, obs, n)), n, dtype),
                          "traffic_source": PMC_SOURCE,
                          "algorithmic_words_per_state": words,
                          "algorithmic_bytes_per_launch": dyn_bytes, "avg_launch_us": dyn_s * 1e6,
+                         "event_span_us": event_span_s * 1e6, "step_period_us": period_s * 1e6,
+                         "avg_launch_source": ("sampled dispatch spans (start/stop events of the dispatch) scaled by %.3f so that the "
+                                               "tick's kernels fit inside the measured step period: a sampled launch is slower than "
+                                               "the un-sampled ones `value` is made of" % span_scale),
+                         "frac_of_measured_copy_bw": (achieved / devinfo["hbm_copy_gbs"]) if (achieved and devinfo) else None,
                          "launches_timed": tm["fused_launches"] if fused else tm["dyn_launches"],
                          "event_pair_overhead_us": ev_overhead_us,
                          "note": ("HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on the launch stream, every "
@@ -268,13 +305,27 @@ def main():
                                "sides of every block, max over ranks); blocks repeat until >= 50 ms are measured"},
             "with_tau_allgather": gather_res,
             "rccl_ranks": world if dist is not None else None,
+            "roofline_whole_path_bytes": {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": path_gbs / HBM_PEAK_GBS / world, "bytes_per_step": path_words * ts,
+                                          "note": "SURVEY.md 8(d) whole-path algorithmic bytes per control step (inputs + tau, f%s) x "
+                                                  "control-steps/s, per GPU against 8 TB/s: the path is latency / issue-bound long before "
+                                                  "it is bound by these bytes" % (" + observer state" if obs else "")},
+            "device": devinfo,
         }
+        if long_blocks is not None:
+            res["value_long_blocks"] = long_blocks
         if not args.no_latency and world == 1:
             res["qp_latency"] = qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs)
         if fused and world == 1:
             res["roofline_dyn_sweep_alone"] = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
         if args.large_batch and world == 1:
             res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split)
+        lb_ = res.get("roofline_large_batch")
+        if lb_ and isinstance(res.get("device"), dict) and dtype == "f64" and not obs and args.large_batch == 262144:
+            # the pool's devices fall into two classes on the HBM-bound tick at identical clocks (sweep 182-187 us on
+            # four of five devices probed, 208-213 us on the fifth): which kind this run drew, by the sweep's own time
+            res["device"]["pool_class"] = "fast" if lb_["avg_launch_us"] <= 196.0 else "slow"
+            res["device"]["pool_class_basis"] = "dyn_sweep<double, 11> at 262 144 states: %.1f us (<= 196 us = fast)" % lb_["avg_launch_us"]
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
             fl = res["cpu_baseline"].get("flops_per_step")
@@ -290,9 +341,115 @@ def main():
                     tfl = fl * lb["steps_per_s"] / 1e12
                     lb["whole_path_tflops"] = tfl
                     lb["whole_path_frac_of_valu_f64_peak"] = tfl / VALU_F64_PEAK_TFLOPS
+    # N > 1: BASELINE.json's 8-GPU configs as extra legs of the SAME line (the driver runs one command per N)
+    legs = None
+    if dist is not None and not os.environ.get("WBC_BENCH_NO_SCALE_LEGS"):
+        torch.cuda.empty_cache()
+        legs = scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model)
+    if rank == 0:
+        if legs:
+            res.update(legs)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def device_probe(torch):
+    """What this device's memory system delivers on a plain copy (the pool's devices differ by up to 12 % on the HBM-bound
+    tick at identical clocks): 1 GiB device-to-device copy, read + write bytes over the median of 10 copies."""
+    n = 1 << 28
+    try:
+        a = torch.empty(n, dtype=torch.float32, device="cuda")
+        b = torch.empty(n, dtype=torch.float32, device="cuda")
+        a.fill_(1.0)
+        for _ in range(3):
+            b.copy_(a)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for e0, e1 in ev:
+            e0.record(); b.copy_(a); e1.record()
+        torch.cuda.synchronize()
+        ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[len(ev) // 2]
+        gbs = 2.0 * 4 * n / (ms * 1e-3) / 1e9
+        del a, b
+        torch.cuda.empty_cache()
+        return {"name": torch.cuda.get_device_name(), "hbm_copy_gbs": gbs, "hbm_copy_frac_of_peak": gbs / HBM_PEAK_GBS,
+                "note": "torch 1 GiB device-to-device copy, read + write bytes, median of 10 (what 'achievable' means on this device)"}
+    except Exception as e:   # never lose the main line to the probe
+        return {"error": repr(e)[:200]}
+
+
+def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
+    """BASELINE.json configs[3] (batch 262 144 fp32 sharded over 8 GPUs = 32 768 states per GPU, tilted terrain, observer on)
+    and configs[4] (horizon-20 rollouts, 1 024 per GPU and 1 024 in total = 128 per GPU) measured by the driver's own N > 1
+    command: per leg steps/s over all ranks in blocks of >= 5 ms, the same with an all-gather of tau after every tick
+    (configs[3]), and the RCCL rank count.  Every rank keeps its slice for all ticks: no data-path collective."""
+    from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather
+    res = {}
+    td = torch.float32
+    n3 = 32768
+    try:
+        P = synth.default_params(observer_order=1, dtype="f32")
+        solver = W.Solver(model, W.Params.from_dict(P, "f32"), dtype="f32", device=local_rank, max_batch=n3)
+        B = synth.make_batch(4, n3, model.total_mass, rank=rank)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
+        inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+        mask = torch.from_numpy(B["mask"]).cuda()
+        integ = solver.dynamics(inp["q"], inp["v"], want=("p",))["p"].clone()
+        rr = torch.zeros_like(integ)
+        tick, out = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
+                                        inp["tau_prev"], inp["f_prev"], integ, rr, want_mats=True)
+
+        def step():
+            tick()
+            return out
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        k3 = max(20, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 20, 1e-7))))
+        bl = timed_blocks(step, k3, dist, torch)
+        el = float(np.median(bl))
+        el_g, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, k3, torch.cuda.synchronize)
+        ok = float((out["status"] == 0).double().mean().item())
+        res["scale_config3"] = {
+            "workload": "configs[3]: batch=%d fp32 = %d states per GPU x %d, tilted terrain normals + disturbances, observer on, M/h/Jc written"
+                        % (n3 * world, n3, world),
+            "value": k3 * n3 * world / el, "unit": "control-steps/s", "ms_per_step": el / k3 * 1e3, "steps_per_block": k3, "blocks": len(bl),
+            "with_tau_allgather": {"value": k3 * n3 * world / el_g, "ms_per_step": el_g / k3 * 1e3,
+                                   "collective": "all_gather_into_tensor(tau) after every step, RCCL, %d B per rank per step" % (12 * n3 * 4)},
+            "rccl_ranks": world, "dtype": "f32", "status_ok_frac_rank0": ok}
+        del solver, tick, out, inp, integ, rr
+        torch.cuda.empty_cache()
+    except Exception as e:   # never lose the headline to an extra leg
+        res["scale_config3"] = {"error": repr(e)[:300]}
+    for name, n5 in (("per_gpu_1024", 1024), ("total_1024_over_8", 128)):
+        try:
+            r5 = rollout_setup(args, W, synth, torch, np, model, "f64", n5, args.horizon, rank, local_rank, False)
+            for _ in range(3):
+                r5["one_rollout"]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                r5["one_rollout"]()
+            torch.cuda.synchronize()
+            k5 = max(3, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 3, 1e-7))))
+            bl = timed_blocks(r5["one_rollout"], k5, dist, torch)
+            el = float(np.median(bl))
+            res.setdefault("scale_config5", {})[name] = {
+                "workload": "configs[4]: horizon=%d x %d rollouts per GPU x %d GPUs, trot masks, observer on, pushes, fp64, rank-local for all ticks"
+                            % (args.horizon, n5, world),
+                "value": k5 * args.horizon * n5 * world / el, "unit": "control-steps/s", "ms_per_rollout": el / k5 * 1e3,
+                "us_per_tick": el / k5 / args.horizon * 1e6, "rollouts_per_block": k5, "blocks": len(bl), "rccl_ranks": world,
+                "with_tau_allgather": None, "dtype": "f64",
+                "note": "no gather leg: a rollout keeps tau of 20 ticks on its rank; the consumer-side collective is configs[3]'s"}
+            del r5
+            torch.cuda.empty_cache()
+        except Exception as e:
+            res.setdefault("scale_config5", {})[name] = {"error": repr(e)[:300]}
+    return res
 
 
 def multi_capi_bench(args, W, synth, torch, np):
@@ -361,15 +518,9 @@ def multi_capi_bench(args, W, synth, torch, np):
         "rccl_ranks": ms.rccl_ranks, "qp": {"status_ok_frac": ok}, "roofline": None, "cpu_baseline": None}))
 
 
-def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
-    """BASELINE.json configs[4]: MPC-style WBC-in-the-loop rollouts, horizon 20 x 1024 states per GPU (the config does
-    not say whether 1024 is per GPU or total; per GPU here, --batch overrides).  One "step" = one rollout = `horizon`
-    dependent ticks of {dyn_sweep, QP, forward dynamics + integrator}; value is still control-steps/s."""
-    dtype = args.dtype or "f64"
+def rollout_setup(args, W, synth, torch, np, model, dtype, n, H, rank, local_rank, tracking):
+    """buffers + the one-rollout closure of configs[4] (used by the --config 5 bench and by the N > 1 scale legs)"""
     td = torch.float64 if dtype == "f64" else torch.float32
-    n = args.batch if args.batch != 4096 else 1024
-    H = args.horizon
-    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
     P = synth.default_params(observer_order=1, dtype=dtype)
     solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=local_rank, max_batch=n)
     B = synth.make_batch(3, n, model.total_mass, rank=rank)
@@ -385,9 +536,8 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
     out = dict(tau=torch.zeros((12, n), dtype=td, device="cuda"), f=torch.zeros((12, n), dtype=td, device="cuda"),
                status=torch.zeros(n, dtype=torch.int32, device="cuda"), iters=torch.zeros(n, dtype=torch.int32, device="cuda"),
                M=solver.empty(171, n), h=solver.empty(18, n), Jc=solver.empty(216, n), pf=solver.empty(12, n))
-
     plan = None
-    if args.tracking:
+    if tracking:
         solver.set_ref_params(synth.default_ref_params())
         plan = dev(synth.make_plan(B, rank=rank))
 
@@ -399,6 +549,19 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
         else:
             solver.rollout(H, inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, out, integ,
                            rr, tau_ext)
+    return {"one_rollout": one_rollout, "out": out, "solver": solver, "keep": (inp, q0, v0, mask, tau_ext, integ0, integ, rr, plan)}
+
+
+def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
+    """BASELINE.json configs[4]: MPC-style WBC-in-the-loop rollouts, horizon 20 x 1024 states per GPU (the config does
+    not say whether 1024 is per GPU or total; per GPU here, --batch overrides).  One "step" = one rollout = `horizon`
+    dependent ticks of {dyn_sweep, QP, forward dynamics + integrator}; value is still control-steps/s."""
+    dtype = args.dtype or "f64"
+    n = args.batch if args.batch != 4096 else 1024
+    H = args.horizon
+    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    r5 = rollout_setup(args, W, synth, torch, np, model, dtype, n, H, rank, local_rank, args.tracking)
+    one_rollout, out = r5["one_rollout"], r5["out"]
 
     for _ in range(max(1, args.warmup)):
         one_rollout()
@@ -421,6 +584,7 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
             "us_per_tick": elapsed / args.steps / H * 1e6, "qp": {"status_ok_frac_last_tick": ok},
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_min": min(blocks) * 1e3,
                        "block_ms_median": elapsed * 1e3, "block_ms_max": max(blocks) * 1e3},
+            "rccl_ranks": world if dist is not None else None,
             "roofline": None, "cpu_baseline": None}))
     if dist is not None:
         dist.destroy_process_group()
@@ -531,7 +695,8 @@ def sweep_alone_roofline(solver, torch, inp, n, dtype, ts):
     ach = DYN_WORDS_FUSED * ts * n / t / 1e9
     return {"kernel": "dyn_sweep_kernel (M, h, Jc only)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "avg_launch_us": t * 1e6, "launches_timed": tm["dyn_launches"],
-            "traffic": pmc_traffic("dyn_sweep_kernel", n, dtype), "algorithmic_words_per_state": DYN_WORDS_FUSED}
+            "traffic": pmc_traffic("dyn_sweep_kernel<%s, 1," % ("double" if dtype == "f64" else "float"), n, dtype),
+            "algorithmic_words_per_state": DYN_WORDS_FUSED}
 
 
 PMC_SOURCE = ("profiles/pmc_latest.json: committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs) of this "
@@ -544,10 +709,10 @@ def pmc_traffic(kernel, n, dtype):
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         d = json.load(open(path))
-        key = "n%d" % n
-        for k, v in d.get(key, {}).items():
-            if kernel in k and ("double" in k) == (dtype == "f64"):
-                return v.get("hbm_bytes_per_launch")
+        for key in (("n%d" % n, "n%d_f32" % n) if dtype != "f64" else ("n%d" % n,)):
+            for k, v in d.get(key, {}).items():
+                if kernel in k and ("double" in k) == (dtype == "f64"):
+                    return v.get("hbm_bytes_per_launch")
     except Exception:
         pass
     return None
@@ -590,10 +755,10 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
     ach = dyn_words(split) * ts * n / dyn_s / 1e9
     # the dynamics stage exactly as SURVEY.md 8(d) defines it (q, v -> M, h, Jc as its own kernel, no step prologue)
     alone = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
-    alone["traffic"] = None   # no PMC pass of this variant at this size is committed
+    alone["traffic"] = pmc_traffic("dyn_sweep_kernel<%s, 1," % ("double" if dtype == "f64" else "float"), n, dtype)
     return {"batch": n, "kernel": dyn_kernel_name(split), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "dynamics_stage_alone": alone,
-            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dyn_kernel_name(split), n, dtype),
+            "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(tick_sweep_symbol(dtype, obs, n), n, dtype),
             "algorithmic_words_per_state": dyn_words(split), "avg_launch_us": dyn_s * 1e6,
             "rnea_step_us": tm["rnea_ms"] * 1e3 / max(1, tm["rnea_launches"]), "qp_us": qp_s * 1e6,
             "qp_lane_us": (tm.get("qp_lane_ms", 0.0) * 1e3 / tm["qp_lane_launches"]) if tm.get("qp_lane_launches", 0) else None,

@@ -119,7 +119,12 @@ typedef struct wbc_solver_options {
   int qp_lane;            /* two-kernel ticks solve the QPs one state per LANE first (semismooth Newton on the residual wrench)
                              and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches from
                              49152 states on, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
-                             iters = Newton iterations (<= 5); the others the dense kernel's status / iteration count */
+                             iters = Newton iterations (<= 5); the others the dense kernel's status / iteration count.
+                             wbc_params.qp_tol and max_iter govern the DENSE kernel only: the per-lane kernel accepts a state when
+                             the residual of its optimality equation is below 1e-11 (fp32: 2e-5) x (1 + |target wrench|) or a full
+                             Newton step leaves the active faces unchanged (then the point is the exact solution for those faces) */
+  int f32_pack2;          /* fp32 dynamics sweep with TWO states per lane (packed v_pk_* arithmetic, whole 128-byte lines per 16-lane
+                             row, half the wavefronts): 0 = auto (even batches from 8192 states on), 1 = every even batch, -1 = never */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -267,7 +272,12 @@ void wbc_multi_destroy(wbc_multi* mm);
 int wbc_multi_size(const wbc_multi* mm);                    /* number of shards */
 int wbc_multi_device(const wbc_multi* mm, int shard);       /* HIP device of a shard */
 wbc_solver* wbc_multi_solver(wbc_multi* mm, int shard);     /* the shard's solver (dynamics, timing, reference ... on its device) */
-void* wbc_multi_stream(wbc_multi* mm, int shard);           /* hipStream_t the shard's work is enqueued on */
+/* hipStream_t the shard's work is enqueued on.  These are hipStreamNonBlocking streams: they do NOT synchronise with the
+ * null stream or with any stream of the caller.  Buffers produced elsewhere (copies, fills, a previous consumer) must be
+ * complete -- or ordered with hipStreamWaitEvent on this stream -- before wbc_multi_step_batch / wbc_multi_rollout_batch /
+ * wbc_multi_allgather_tau are called, and results are visible to other streams only after wbc_multi_synchronize (or an
+ * event recorded on this stream). */
+void* wbc_multi_stream(wbc_multi* mm, int shard);
 int wbc_multi_rccl_ranks(const wbc_multi* mm);              /* ranks of the RCCL communicator; 0 when RCCL is not in use */
 int wbc_multi_set_params(wbc_multi* mm, const wbc_params* p);
 /* One control tick of n_total states.  in[k] / out[k] / obs[k] (arrays of wbc_multi_size entries; obs may be NULL when

@@ -157,6 +157,41 @@ def test_python_multisolver_equals_single_solver(torch_cuda, gpu_model, obs, gat
         assert ta.shape == (ms.n, 12 * c0)
 
 
+def test_rccl_gather_over_more_than_one_device_or_says_it_did_not_run(torch_cuda, gpu_model):
+    """States plainly in the test log whether RCCL ran with N > 1 ranks.  With one visible GPU every rccl assertion of this
+    file holds with a ONE-rank communicator (rccl_ranks == device_count == 1): that exercises the code path, not the
+    collective.  With >= 2 devices: shards over all of them (ragged), ncclCommInitAll + one grouped ncclAllGather, gathered
+    torques on EVERY device equal the single solver's bit for bit."""
+    import wbc_quadruped_dob_amd as W
+    torch = torch_cuda
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("RCCL with N > 1 ranks NOT exercised: %d GPU visible on this box (rccl_ranks == device_count was asserted with "
+                    "1 rank only); the multi-GPU node runs it through `bench.py --gpus N` (keys rccl_ranks, with_tau_allgather)" % ndev)
+    n = 4099   # ragged over any device count
+    prm = W.Params.from_dict(synth.default_params(observer_order=0))
+    B = synth.make_batch(2, n, gpu_model.total_mass, rank=31)
+    full = {k: to_dev(B[k], torch, torch.float64) for k in ROWS}
+    mask = torch.from_numpy(B["mask"]).cuda()
+    single = W.Solver(gpu_model, prm, device=0, max_batch=n, options={})
+    ref = single.step(full["q"], full["v"], full["w_des"], full["vdot_des"], full["normals"], full["mu"], mask, full["tau_prev"], full["f_prev"])
+    torch.cuda.synchronize()
+    ms = W.MultiSolver(gpu_model, prm, devices=list(range(ndev)), max_batch_total=n, gather="rccl", options={})
+    assert ms.rccl_ranks == ndev and ndev >= 2
+    ins = {k: ms.scatter(full[k], ROWS[k], n) for k in ROWS}
+    ins["mask"] = ms.scatter(mask, 1, n)
+    tick, outs = ms.prepare_step(n, ins, None)
+    for _ in range(3):
+        tick()
+        tau_all = ms.allgather_tau(n, outs)
+    ms.synchronize()
+    for d, ta in enumerate(tau_all):
+        assert ta.device.index == d
+        for j in range(ms.n):
+            st, cnt = W.shard_range(n, ms.n, j)
+            assert torch.equal(ta[j, :12 * cnt].reshape(12, cnt).to("cuda:0"), ref["tau"][:, st:st + cnt]), (d, j)
+
+
 def test_multi_step_host_numpy_batch(torch_cuda, gpu_model, oracle):
     """wbc_multi_step_host: host-resident component-major batch in, tau / f / status / observer state back (pitched copies)."""
     import wbc_quadruped_dob_amd as W

@@ -631,7 +631,7 @@ def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtyp
 @pytest.mark.parametrize("cfg,obs,dtype,n,mats,split", [(2, 0, "f64", 20001, True, -2), (3, 1, "f64", 16500, True, -2), (4, 2, "f64", 30000, False, -2),
                                                        (4, 1, "f64", 9000, True, 1), (4, 1, "f32", 20000, True, -2), (3, 0, "f64", 5, True, -2)])
 def test_per_lane_qp_kernel_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, dtype, n, mats, split):
-    """qp_lane_kernel (one state per lane: semismooth Newton on the 6-dimensional residual wrench, line search, states it
+    """qp_lane_kernel (one state per lane: semismooth Newton on the 6-dimensional residual wrench, full steps, states it
     does not finish handed to the dense active-set kernel through a device-side list) is a different ALGORITHM from the
     oracle's Goldfarb-Idnani and must land on the same unique solution: status equal, tau / f within the fp64 gate, with and
     without M/h/Jc outputs (geometry from Jc or from the workspace), with rhat arriving through the workspace, ragged sizes.
@@ -731,7 +731,7 @@ def test_tick_is_graph_capturable(torch_cuda, gpu_model, mode):
     if mode in ("two_kernel", "obs_split", "lane"):
         opt["fused_max"] = 0
     if mode == "lane":
-        opt["qp_lane"] = 1     # memset of the hand-over counter + per-lane kernel + dense kernel over the list
+        opt["qp_lane"] = 1     # front-half kernel zeroes the hand-over counter, then per-lane kernel + dense kernel over the list
     if mode == "obs_split":
         opt["obs_split_min"] = 1
     solver, P = _solver(gpu_model, obs=1, max_batch=n, options=opt)

@@ -73,19 +73,36 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_gloo_matches_single_process():
-    n_total = 1001  # ragged: 501 + 500
+def _run_world(world, n_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    err, stats, ok, isum, imax, cnt0 = q.get(timeout=100)
+    got = q.get(timeout=150)
     for p in procs:
-        p.join(30)
+        p.join(60)
         assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_matches_single_process():
+    n_total = 1001  # ragged: 501 + 500
+    err, stats, ok, isum, imax, cnt0 = _run_world(2, n_total)
     assert err == 0.0  # same code, same inputs, same slices: bit-identical
+    assert cnt0 == 501
+    assert stats["ok"] == ok == n_total and stats["iters_sum"] == isum and stats["iters_max"] == imax
+
+
+@pytest.mark.timeout(240)
+def test_eight_rank_gloo_ragged_matches_single_process():
+    """The node's shape (8 ranks, BASELINE.json configs[3] / [4]) with a ragged split: 4 003 states = 3 ranks of 501 + 5 of 500;
+    the timed all-gather leg runs on the equal first 500 states of every rank (what bench.py's N > 1 legs do)."""
+    n_total = 4003
+    assert [shard_range(n_total, 8, r)[1] for r in range(8)] == [501] * 3 + [500] * 5
+    err, stats, ok, isum, imax, cnt0 = _run_world(8, n_total)
+    assert err == 0.0
     assert cnt0 == 501
     assert stats["ok"] == ok == n_total and stats["iters_sum"] == isum and stats["iters_max"] == imax

@@ -35,17 +35,18 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if ("copy<float>" in k and c == "FETCH_SIZE") or ("write<float>" in k and c == "WRITE_SIZE"):
             scale[c + "_f32"] = GIB / (v * 1024.0) if v else None
 res["scale"] = scale
-for prefix in ("n4096", "n262144"):
-    r = {}
+for prefix, key, sfx in (("n4096", "n4096", "_f64"), ("n262144", "n262144", "_f64"), ("n262144dyn", "n262144", "_f64"),
+                         ("n32768f32", "n32768_f32", "_f32"), ("n262144f32", "n262144_f32", "_f32"), ("n262144dynf32", "n262144_f32", "_f32")):
+    r = res.get(key, {})
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, (avg, cnt) in per_kernel(prefix, c).items():
             e = r.setdefault(k, {})
             e[c + "_raw_KiB"] = avg
             e["dispatches_" + c] = cnt
-            s = scale.get(c + "_f64")
+            s = scale.get(c + sfx)
             e[c + "_bytes_corrected"] = avg * 1024.0 * s if s else None
     for k, e in r.items():
         if e.get("FETCH_SIZE_bytes_corrected") is not None and e.get("WRITE_SIZE_bytes_corrected") is not None:
             e["hbm_bytes_per_launch"] = e["FETCH_SIZE_bytes_corrected"] + e["WRITE_SIZE_bytes_corrected"]
-    res[prefix] = r
+    res[key] = r
 print(json.dumps(res, indent=1))

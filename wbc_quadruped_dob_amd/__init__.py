@@ -97,10 +97,10 @@ class SolverOptions(C.Structure):
     the environment; Solver(options=None) builds them from the defaults overridden by the WBC_* variables below -- a
     convenience of THIS binding for the A/B scripts under tools/ and bench.py."""
     _fields_ = [("struct_size", C.c_size_t), ("fused_max", C.c_longlong), ("rollout_persistent", C.c_int),
-                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int)]
+                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int), ("f32_pack2", C.c_int)]
     ENV = {"WBC_FUSED_MAX": ("fused_max", int), "WBC_ROLLOUT_PERSISTENT": ("rollout_persistent", int),
            "WBC_ROLLOUT_SPW": ("rollout_spw", int), "WBC_OBS_SPLIT_MIN": ("obs_split_min", int),
-           "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int), "WBC_QP_LANE": ("qp_lane", int),
+           "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int), "WBC_QP_LANE": ("qp_lane", int), "WBC_F32_PACK2": ("f32_pack2", int),
            "WBC_TIMING": ("timing_mode", lambda v: 1 if v == "pair" else 0)}
 
     @staticmethod
@@ -540,6 +540,12 @@ class MultiSolver:
     def synchronize(self):
         _check(lib().wbc_multi_synchronize(self._h), "wbc_multi_synchronize")
 
+    def sync_torch_streams(self):
+        """Wait for torch's current stream on every shard device: the shard streams (wbc_multi_stream) do not synchronise
+        with torch's streams or the null stream, so buffers produced there must be complete before the first tick."""
+        for dev in sorted(set(self.devices)):
+            self.torch.cuda.current_stream(self.torch.device("cuda", dev)).synchronize()
+
     def scatter(self, full, rows, n_total, dtype=None):
         """host/any-device [rows, n_total] tensor -> list of per-shard contiguous [rows, count_k] tensors on devices[k]"""
         outs = []
@@ -577,6 +583,9 @@ class MultiSolver:
             outs.append(o)
         keep = (ins, obs, outs, BI, BO, OS)
         fn, h, has_obs = lib().wbc_multi_step_batch, self._h, obs is not None
+        # The shard streams are library-created non-blocking streams: nothing orders them behind the torch streams that
+        # produced these buffers (scatter()'s copies, the zero-fills above, a caller's observer state).  One-off cost.
+        self.sync_torch_streams()
 
         def tick(_keep=keep):
             rc = fn(h, n_total, BI, BO, OS if has_obs else None)
@@ -590,6 +599,7 @@ class MultiSolver:
         _, c0 = shard_range(n_total, self.n, 0)
         if tau_all is None:
             tau_all = [torch.zeros((self.n, m.nj * c0), dtype=self.tdtype, device=torch.device("cuda", d)) for d in self.devices]
+            self.sync_torch_streams()   # the zero-fills run on torch's streams, the gather on the shard streams
         loc = (C.c_void_p * self.n)(*[o["tau"].data_ptr() for o in outs])
         allp = (C.c_void_p * self.n)(*[t.data_ptr() for t in tau_all])
         _check(lib().wbc_multi_allgather_tau(self._h, n_total, loc, allp), "wbc_multi_allgather_tau")

@@ -179,6 +179,61 @@ WBC_DEV float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
 
 __host__ __device__ constexpr int midx18(int i, int j) { return i * 18 - i * (i - 1) / 2 + (j - i); }
 
+// ---- two fp32 states per lane: a packed pair that the compiler maps onto v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (gfx90a+:
+// full rate, two fp32 results per lane and instruction).  Scalars of the model (one VGPR) enter through op_sel broadcasts, so
+// a splat costs no register and no move.
+typedef float wbc_f2v __attribute__((ext_vector_type(2)));
+typedef int wbc_i2v __attribute__((ext_vector_type(2)));
+struct alignas(8) Pk2f {
+  wbc_f2v v;
+  Pk2f() = default;
+  WBC_DEV Pk2f(float s) : v{s, s} {}
+  WBC_DEV Pk2f(wbc_f2v x) : v(x) {}
+  WBC_DEV Pk2f& operator+=(Pk2f o) { v += o.v; return *this; }
+  WBC_DEV Pk2f& operator-=(Pk2f o) { v -= o.v; return *this; }
+};
+WBC_DEV Pk2f operator+(Pk2f a, Pk2f b) { return Pk2f(a.v + b.v); }
+WBC_DEV Pk2f operator-(Pk2f a, Pk2f b) { return Pk2f(a.v - b.v); }
+WBC_DEV Pk2f operator*(Pk2f a, Pk2f b) { return Pk2f(a.v * b.v); }
+WBC_DEV Pk2f operator-(Pk2f a) { return Pk2f(-a.v); }
+WBC_DEV Pk2f operator+(Pk2f a, float b) { return a + Pk2f(b); }
+WBC_DEV Pk2f operator+(float a, Pk2f b) { return Pk2f(a) + b; }
+WBC_DEV Pk2f operator-(Pk2f a, float b) { return a - Pk2f(b); }
+WBC_DEV Pk2f operator-(float a, Pk2f b) { return Pk2f(a) - b; }
+WBC_DEV Pk2f operator*(Pk2f a, float b) { return a * Pk2f(b); }
+WBC_DEV Pk2f operator*(float a, Pk2f b) { return Pk2f(a) * b; }
+template <class T, int W> struct LaneT { static_assert(W == 1, "two states per lane: fp32 only"); using type = T; };
+template <> struct LaneT<float, 2> { using type = Pk2f; };
+WBC_DEV Pk2f xrow_sum(Pk2f x) { wbc_f2v r; r.x = xrow_sum(x.v.x); r.y = xrow_sum(x.v.y); return Pk2f(r); }
+// sin / cos of a pair, straight-line: two-term Cody-Waite reduction by pi/2 with FMA, the classic single-precision minimax
+// kernels on |r| <= pi/4 (cephes sinf / cosf coefficients, < 1 ulp there), quadrant fix-up on the bits.  Joint angles only
+// (|x| up to ~1e4 rad keeps the reduction exact enough: the second term carries 24 more bits of pi/2).
+WBC_DEV void sincos_t(Pk2f x, Pk2f* sp, Pk2f* cp) {
+  const wbc_f2v xv = x.v;
+  wbc_f2v n;
+  n.x = __builtin_rintf(xv.x * 0.63661977236758134f); n.y = __builtin_rintf(xv.y * 0.63661977236758134f);
+  wbc_f2v r = __builtin_elementwise_fma(-n, wbc_f2v{1.5707963705062866f, 1.5707963705062866f}, xv);
+  r = __builtin_elementwise_fma(-n, wbc_f2v{-4.3711388286737929e-08f, -4.3711388286737929e-08f}, r);
+  const wbc_f2v z = r * r;
+  const auto K = [](float c) __attribute__((always_inline)) { return wbc_f2v{c, c}; };
+  wbc_f2v ps = __builtin_elementwise_fma(K(-1.9515295891e-4f), z, K(8.3321608736e-3f));
+  ps = __builtin_elementwise_fma(ps, z, K(-1.6666654611e-1f));
+  const wbc_f2v sr = __builtin_elementwise_fma(r * z, ps, r);
+  wbc_f2v pc = __builtin_elementwise_fma(K(2.443315711809948e-5f), z, K(-1.388731625493765e-3f));
+  pc = __builtin_elementwise_fma(pc, z, K(4.166664568298827e-2f));
+  const wbc_f2v cr = __builtin_elementwise_fma(z * z, pc, __builtin_elementwise_fma(K(-0.5f), z, K(1.0f)));
+  wbc_i2v q;
+  q.x = (int)n.x; q.y = (int)n.y;
+  wbc_f2v s1, c1;
+  s1.x = (q.x & 1) ? cr.x : sr.x; s1.y = (q.y & 1) ? cr.y : sr.y;
+  c1.x = (q.x & 1) ? sr.x : cr.x; c1.y = (q.y & 1) ? sr.y : cr.y;
+  wbc_f2v so, co;   // sign: sin flips in quadrants 2, 3; cos in quadrants 1, 2
+  so.x = __int_as_float(__float_as_int(s1.x) ^ ((q.x & 2) << 30)); so.y = __int_as_float(__float_as_int(s1.y) ^ ((q.y & 2) << 30));
+  co.x = __int_as_float(__float_as_int(c1.x) ^ (((q.x + 1) & 2) << 30)); co.y = __int_as_float(__float_as_int(c1.y) ^ (((q.y + 1) & 2) << 30));
+  *sp = Pk2f(so); *cp = Pk2f(co);
+}
+WBC_DEV Pk2f rsqrt_t(Pk2f x) { wbc_f2v r; r.x = 1.0f / sqrtf(x.v.x); r.y = 1.0f / sqrtf(x.v.y); return Pk2f(r); }
+
 // MODE bits
 
 #ifndef WBC_SWEEP_WAVES
@@ -193,8 +248,13 @@ __host__ __device__ constexpr int midx18(int i, int j) { return i * 18 - i * (i 
 // SLOWER at N = 1 024 ... 4 096, the sweep wave is bound by its dependent fp64 chain, not by store issue; (2) this body as
 // wave 0 of a fused sweep+QP workgroup with the workspace in LDS: -7 % per tick with the observer off, nothing with it
 // on; superseded by the role-split fused tick in fused_tick.hip.hpp, which does not use this body.)
-template <class T, int MODE, int BLOCK>
+// W = states per lane.  W = 2 (fp32 only, even N): a lane owns TWO consecutive states as one packed pair (Pk2f above), so
+// every 16-lane row still moves whole 128-byte lines (16 lanes x 8 B) and the arithmetic is v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 -- a wavefront then carries 32 states and the batch needs half the wavefronts.  With one fp32 state per lane a
+// row moved half a line per instruction and the kernel took as long as the fp64 one (round 2: 24.1 vs 24.7 us at 32 768 states).
+template <class T, int MODE, int BLOCK, int W = 1>
 WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
+  using V = typename LaneT<T, W>::type;   // what a lane computes with: T, or a packed pair of T
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0, FWD_B = (MODE & SW_NOB) == 0;
   // ONE LDS object with the constant table first: ds_read / ds_write reach base + 16-bit offset, and the compiler places
   // separate __shared__ arrays largest-first -- behind the 74 kB parking area of a 256-thread workgroup every table word
@@ -208,12 +268,12 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr int PB = 6;                    // parked words of the base body's own wrench
   constexpr int PE2 = OBS ? 2 : 0;         // observer: sin, cos of joint 2 too (the momentum pass walks the leg again)
   constexpr int PX = 9;                    // vdot_des base rows 6, base position 3
-  struct Lds { T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; T park[2 * PW + PB + PE2 + PX][BLOCK]; };
+  struct Lds { T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; V park[2 * PW + PB + PE2 + PX][BLOCK]; };
   __shared__ Lds lds;
   T (&cst)[CST_WORDS] = lds.cst;
   int (&zidx_s)[64] = lds.zidx_s;
   T (&kgain)[OBS ? 36 : 2] = lds.kgain;
-  T (&park)[2 * PW + PB + PE2 + PX][BLOCK] = lds.park;
+  V (&park)[2 * PW + PB + PE2 + PX][BLOCK] = lds.park;
 #ifdef WBC_SWEEP_STAMP  // diagnostic build only: cycle stamps per phase, written over the pf output
   long long stp[13];
   int stn = 0;
@@ -227,29 +287,29 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   const unsigned N32 = (unsigned)N;
   // lane = 16*leg + (state within the wave): each 16-lane row owns one leg of 16 consecutive states
   const int leg = (int)((threadIdx.x & 63) >> 4);
-  const size_t s_raw = ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15);
-  const bool live = s_raw < N;
-  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);  // dead lanes recompute the last state, stores are masked
+  const size_t s_raw = (((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15)) * W;   // first state of this lane
+  const bool live = s_raw < N;                            // (W = 2: N is even, so both states of a lane are in range together)
+  const unsigned s32 = (unsigned)(live ? s_raw : N - W);  // dead lanes recompute the last state(s), stores are masked
   const unsigned legN = (unsigned)leg * N32;
 #define CS(i) cst[(i) * 4 + leg]
   // Addressing: every array is < 4 GiB (max_batch is capped at create), so a component row is reached as
   // (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): no 64-bit vector address arithmetic.
   //   LDU/STU: component index is wave-uniform;  LDV/STV: component index differs per lane.
-#define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
-#define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
-#define STU(ptr, comp, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))) = (val); } while (0)
-#define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define LDU(ptr, comp) (*(const V*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
+#define LDV(ptr, comp) (*(const V*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define STU(ptr, comp, val) do { if (live) *(V*)((char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))) = (val); } while (0)
+#define STV(ptr, comp, val) do { if (live) *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   // leg-strided component: comp = c0 + stride*leg (+ per-lane extra element offset xN = x*N)
-#define STL(ptr, c0, stride, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
-#define STLX(ptr, c0, stride, xN, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STL(ptr, c0, stride, val) do { if (live) *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STLX(ptr, c0, stride, xN, val) do { if (live) *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   // four base-replicated values, one per lane of the quad
-#define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
 #define WSTV(comp, val) STV(a.ws, comp, val)   /* step workspace */
-#define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
 #define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
 
   // ------------------------------------------------------------------ loads
-  T qb[7], vb[6];
+  V qb[7], vb[6];
 #pragma unroll
   for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
 #pragma unroll
@@ -258,18 +318,18 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   unsigned jxN[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { jx[k] = model->jidx[leg][k]; jxN[k] = (unsigned)jx[k] * N32; }
-  T ql[3], vl[3];
+  V ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    ql[k] = *(const T*)((const char*)(a.q + (size_t)7 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
-    vl[k] = *(const T*)((const char*)(a.v + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+    ql[k] = *(const V*)((const char*)(a.q + (size_t)7 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+    vl[k] = *(const V*)((const char*)(a.v + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
   }
   // desired accelerations: needed in and after the return sweep, requested here (see the parking comment above)
-  T al[3] = {0, 0, 0}, ad_in[6] = {0, 0, 0, 0, 0, 0};
+  V al[3] = {0, 0, 0}, ad_in[6] = {0, 0, 0, 0, 0, 0};
   if (STEP) {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      al[k] = *(const T*)((const char*)(a.vdot_des + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
+      al[k] = *(const V*)((const char*)(a.vdot_des + (size_t)6 * N) + (size_t)((jxN[k] + s32) * (unsigned)sizeof(T)));
 #pragma unroll
     for (int c = 0; c < 6; ++c) ad_in[c] = LDU(a.vdot_des, c);
   }
@@ -277,8 +337,8 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   // registers to spare (the occupancy is LDS-bound), and at the batch sizes that still use them a wavefront is alone on its
   // SIMD: every load issued where it is used (eight places in the observer pass) exposed its whole latency.
   const bool obs_upd = OBS && STEP && prm.observer_order > 0;
-  T ob_fp[3] = {0, 0, 0}, ob_rb[6] = {0, 0, 0, 0, 0, 0}, ob_igb[6] = {0, 0, 0, 0, 0, 0}, ob_rl[3] = {0, 0, 0}, ob_igl[3] = {0, 0, 0}, ob_tp[3] = {0, 0, 0};
-  T ob_wd[6] = {0, 0, 0, 0, 0, 0};
+  V ob_fp[3] = {0, 0, 0}, ob_rb[6] = {0, 0, 0, 0, 0, 0}, ob_igb[6] = {0, 0, 0, 0, 0, 0}, ob_rl[3] = {0, 0, 0}, ob_igl[3] = {0, 0, 0}, ob_tp[3] = {0, 0, 0};
+  V ob_wd[6] = {0, 0, 0, 0, 0, 0};
   if (obs_upd) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) ob_fp[c] = LDV(a.f_prev, 3 * leg + c);
@@ -310,7 +370,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   // stores waiting for the loads -- held back every store behind them: 234 -> 177 us for this kernel at N = 262 144 (a
   // run-time test instead of a variant keeps most of the damage: 214 us).
   if (STEP && !OBS && FWD_B) {
-    T b[6];
+    V b[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c);
     WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
@@ -320,14 +380,14 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   // ------------------------------------------------------------------ data-independent stores first:
   // structural zeros and ones of M and Jc go out while the sweeps compute (they overlap the VALU work).
   if (MATS) {
-    const T Z = (T)0;
-    if ((N & 1) == 0) {
-      // 16 bytes per lane: lanes (s, s+1) of a row are neighbours, the even one takes the even-numbered constants and
-      // the odd one the odd-numbered ones, each for BOTH states -- half the store instructions for the same bytes
-      // (a wave store instruction costs ~90 cycles to issue whatever its width)
-      struct alignas(16) T2 { T a, b; };
-      const unsigned odd = s32 & 1u, s2 = s32 & ~1u;
-      const bool live2 = live;  // N even: both states of a pair are in range together
+    const V Z = (T)0;
+    if ((N & (2 * W - 1)) == 0) {
+      // 16 bytes per lane (W = 1; 2 x 8 bytes with W = 2): neighbouring lanes (l, l+1) of a row pair up, the even one takes the
+      // even-numbered constants and the odd one the odd-numbered ones, each for the states of BOTH lanes -- half the store
+      // instructions for the same bytes (a wave store instruction costs ~90 cycles to issue whatever its width)
+      struct alignas(2 * sizeof(V)) T2 { V a, b; };
+      const unsigned odd = (s32 / W) & 1u, s2 = s32 & ~(unsigned)(2 * W - 1);
+      const bool live2 = live;  // N a multiple of 2 W: the states of a lane pair are in range together
 #define ST2C(ptr, comp, val) do { if (live2) *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
       for (int e = 2 * leg + (int)odd; e < 64; e += 8) {
         const int zi = zidx_s[e];
@@ -367,45 +427,45 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   }
   SSTAMP();  // 3: early stores issued
   // unit quaternion kept (4 words); R is rebuilt after the sweeps instead of living through them (9 words)
-  T qx, qy, qz, qw;
+  V qx, qy, qz, qw;
   {
-    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    const V n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
     qx = qb[3] * n; qy = qb[4] * n; qz = qb[5] * n; qw = qb[6] * n;
   }
-#define MAKE_R(R_) do { const T x = qx, y = qy, z = qz, w = qw; \
+#define MAKE_R(R_) do { const V x = qx, y = qy, z = qz, w = qw; \
     R_.a[0] = 1 - 2 * (y * y + z * z); R_.a[1] = 2 * (x * y - z * w);     R_.a[2] = 2 * (x * z + y * w); \
     R_.a[3] = 2 * (x * y + z * w);     R_.a[4] = 1 - 2 * (x * x + z * z); R_.a[5] = 2 * (y * z - x * w); \
     R_.a[6] = 2 * (x * z - y * w);     R_.a[7] = 2 * (y * z + x * w);     R_.a[8] = 1 - 2 * (x * x + y * y); } while (0)
-  const T bm = model->base_m;
-  const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
-  S3<T> bI;
+  const V bm = model->base_m;
+  const V3<V> bh = mk<V>(model->base_h[0], model->base_h[1], model->base_h[2]);
+  S3<V> bI;
   bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
   bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
   // the base body's own wrench / momentum / weight are formed now, so that om0, v0, aL0 die after joint 0
   const int ln = threadIdx.x;
-  T* const px = &park[2 * PW + PB + PE2][ln];
+  V* const px = &park[2 * PW + PB + PE2][ln];
   {
 #pragma unroll
     for (int c = 0; c < 6; ++c) px[BLOCK * c] = ad_in[c];
     px[BLOCK * 6] = qb[0]; px[BLOCK * 7] = qb[1]; px[BLOCK * 8] = qb[2];
   }
-#define XSUM(arr, K) xrow_sum_k<T, K>(arr)
-  V3<T> omp, vp, aAp, aLp;
+#define XSUM(arr, K) xrow_sum_k<V, K>(arr)
+  V3<V> omp, vp, aAp, aLp;
   {
-    M3<T> R;
+    M3<V> R;
     MAKE_R(R);
-    SF<T> bw;
-    const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
-    const V3<T> v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
-    const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));  // R^T (-g)
-    const V3<T> aL0 = gneg - cross(om0, v0);  // bias pass: vdot = 0, gravity folded in
-    const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
-    const SF<T> Ia0 = inertia_mul(bm, bh, bI, mk<T>(0, 0, 0), aL0);
+    SF<V> bw;
+    const V3<V> om0 = tmul(R, mk<V>(vb[3], vb[4], vb[5]));
+    const V3<V> v0 = tmul(R, mk<V>(vb[0], vb[1], vb[2]));
+    const V3<V> gneg = tmul(R, mk<V>(-model->grav[0], -model->grav[1], -model->grav[2]));  // R^V (-g)
+    const V3<V> aL0 = gneg - cross(om0, v0);  // bias pass: vdot = 0, gravity folded in
+    const SF<V> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+    const SF<V> Ia0 = inertia_mul(bm, bh, bI, mk<V>(0, 0, 0), aL0);
     bw.n = Ia0.n + cross(om0, Iv0.n) + cross(v0, Iv0.f);
     bw.f = Ia0.f + cross(om0, Iv0.f);
-    T* pb = &park[2 * PW][ln];
+    V* pb = &park[2 * PW][ln];
     pb[0] = bw.n.x; pb[BLOCK] = bw.n.y; pb[BLOCK * 2] = bw.n.z; pb[BLOCK * 3] = bw.f.x; pb[BLOCK * 4] = bw.f.y; pb[BLOCK * 5] = bw.f.z;
-    omp = om0; vp = v0; aAp = mk<T>(0, 0, 0); aLp = aL0;
+    omp = om0; vp = v0; aAp = mk<V>(0, 0, 0); aLp = aL0;
   }
 
   SSTAMP();  // 4: base quantities done (state loads have arrived)
@@ -414,41 +474,41 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   // ([word][lane]: conflict-free), which keeps the kernel at two waves per SIMD without scratch; joint 2's stay in
   // registers.  The observer's momentum / gravity recursions run as a SECOND pass over the leg after the main
   // outputs are stored (their registers are free by then), re-using the parked E matrices.
-  M3<T> E2;
-  SF<T> f2;
+  M3<V> E2;
+  SF<V> f2;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int o = JOINT_WORDS * k;
-    T sn, cs;
+    V sn, cs;
     sincos_t(ql[k], &sn, &cs);
-    M3<T> E;
+    M3<V> E;
 #pragma unroll
     for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
-    const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
-    const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
-    const T m = CS(o + 33);
-    const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
-    S3<T> Io;
+    const V3<V> r = mk<V>(CS(o + 27), CS(o + 28), CS(o + 29));
+    const V3<V> ax = mk<V>(CS(o + 30), CS(o + 31), CS(o + 32));
+    const V m = CS(o + 33);
+    const V3<V> h = mk<V>(CS(o + 34), CS(o + 35), CS(o + 36));
+    S3<V> Io;
     Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
-    const T qd = vl[k];
-    const V3<T> om = tmul(E, omp) + ax * qd;
-    const V3<T> vv = tmul(E, vp + cross(omp, r));
-    const V3<T> aA = tmul(E, aAp) + cross(om, ax) * qd;
-    const V3<T> aL = tmul(E, aLp + cross(aAp, r)) + cross(vv, ax) * qd;
-    const SF<T> Iv = inertia_mul(m, h, Io, om, vv);
-    const SF<T> Ia = inertia_mul(m, h, Io, aA, aL);
-    SF<T> fk;
+    const V qd = vl[k];
+    const V3<V> om = tmul(E, omp) + ax * qd;
+    const V3<V> vv = tmul(E, vp + cross(omp, r));
+    const V3<V> aA = tmul(E, aAp) + cross(om, ax) * qd;
+    const V3<V> aL = tmul(E, aLp + cross(aAp, r)) + cross(vv, ax) * qd;
+    const SF<V> Iv = inertia_mul(m, h, Io, om, vv);
+    const SF<V> Ia = inertia_mul(m, h, Io, aA, aL);
+    SF<V> fk;
     fk.n = Ia.n + cross(om, Iv.n) + cross(vv, Iv.f);
     fk.f = Ia.f + cross(om, Iv.f);
     if (k < 2) {
-      T* pk = &park[PW * k][ln];
+      V* pk = &park[PW * k][ln];
       pk[0] = sn; pk[BLOCK] = cs;
       pk[BLOCK * 2] = fk.n.x; pk[BLOCK * 3] = fk.n.y; pk[BLOCK * 4] = fk.n.z;
       pk[BLOCK * 5] = fk.f.x; pk[BLOCK * 6] = fk.f.y; pk[BLOCK * 7] = fk.f.z;
     } else {
       E2 = E; f2 = fk;
       if (OBS) {
-        T* pe = &park[2 * PW + PB][ln];
+        V* pe = &park[2 * PW + PB][ln];
         pe[0] = sn; pe[BLOCK] = cs;
       }
     }
@@ -457,39 +517,39 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 
   SSTAMP();  // 5: forward sweep done
   // ------------------------------------------------------------------ return sweep up the leg
-  T taup[3] = {0, 0, 0};  // (M vdot_des) joint rows of this leg, accumulated as M entries appear
-  T cm; V3<T> ch; S3<T> cI;  // composite inertia of the subtree rooted at joint k, in frame k
-  V3<T> dft = mk<T>(CS(129), CS(130), CS(131));  // foot relative to the current frame origin
-  V3<T> jc[3];                                   // foot Jacobian columns, rotated progressively towards the base
-  SF<T> Fp[3];                                   // CRBA force columns of joints >= k, carried frame by frame
-  SF<T> facc;                                    // children's wrench in the current frame
+  V taup[3] = {0, 0, 0};  // (M vdot_des) joint rows of this leg, accumulated as M entries appear
+  V cm; V3<V> ch; S3<V> cI;  // composite inertia of the subtree rooted at joint k, in frame k
+  V3<V> dft = mk<V>(CS(129), CS(130), CS(131));  // foot relative to the current frame origin
+  V3<V> jc[3];                                   // foot Jacobian columns, rotated progressively towards the base
+  SF<V> Fp[3];                                   // CRBA force columns of joints >= k, carried frame by frame
+  SF<V> facc;                                    // children's wrench in the current frame
 #pragma unroll
   for (int k = 2; k >= 0; --k) {
     const int o = JOINT_WORDS * k;
-    const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
-    const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
-    const T m = CS(o + 33);
-    const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
-    S3<T> Io;
+    const V3<V> r = mk<V>(CS(o + 27), CS(o + 28), CS(o + 29));
+    const V3<V> ax = mk<V>(CS(o + 30), CS(o + 31), CS(o + 32));
+    const V m = CS(o + 33);
+    const V3<V> h = mk<V>(CS(o + 34), CS(o + 35), CS(o + 36));
+    S3<V> Io;
     Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
-    M3<T> E;
-    SF<T> fk;
+    M3<V> E;
+    SF<V> fk;
     if (k == 2) {
       E = E2; fk = f2;
     } else {
-      const T* pk = &park[PW * k][ln];
-      const T sn = pk[0], cs = pk[BLOCK];
+      const V* pk = &park[PW * k][ln];
+      const V sn = pk[0], cs = pk[BLOCK];
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
         E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
         asm volatile("" : "+v"(E.a[e]));   // one entry at a time: 27 table words in flight at once would not fit the return sweep's registers
       }
-      fk.n = mk<T>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]) + facc.n;
-      fk.f = mk<T>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]) + facc.f;
+      fk.n = mk<V>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]) + facc.n;
+      fk.f = mk<V>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]) + facc.f;
     }
     // RNEA projection on the joint axis
     {
-      const T hk = dot(ax, fk.n);
+      const V hk = dot(ax, fk.n);
       if (MATS) STLX(a.h, 6, 0, jxN[k], hk);
       if (STEP) taup[k] += hk;
     }
@@ -503,7 +563,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     Fp[k].f = cross(ax, ch);
 #pragma unroll
     for (int j = k; j < 3; ++j) {  // M[k][j] for this leg: columns j >= k are all in frame k now
-      const T mkj = dot(ax, Fp[j].n);
+      const V mkj = dot(ax, Fp[j].n);
       if (MATS) {
         int i = 6 + jx[k], jj = 6 + jx[j];
         if (i > jj) { const int t = i; i = jj; jj = t; }
@@ -519,10 +579,10 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
     for (int j = k; j < 3; ++j) { jc[j] = mul(E, jc[j]); Fp[j] = to_parent(E, r, Fp[j]); }
     facc = to_parent(E, r, fk);
     {
-      const V3<T> hr = mul(E, ch);
-      const S3<T> Ir = congr(E, cI);
-      const V3<T> w = hr + r * (cm * (T)0.5);
-      const T sc = 2 * dot(w, r);
+      const V3<V> hr = mul(E, ch);
+      const S3<V> Ir = congr(E, cI);
+      const V3<V> w = hr + r * (cm * (T)0.5);
+      const V sc = 2 * dot(w, r);
       cI.xx = Ir.xx + sc - 2 * w.x * r.x;
       cI.yy = Ir.yy + sc - 2 * w.y * r.y;
       cI.zz = Ir.zz + sc - 2 * w.z * r.z;
@@ -535,21 +595,21 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   SSTAMP();  // 6: return sweep done
   // now: facc (macc, gacc) = leg wrench at the base, base coords; (cm,ch,cI) = leg composite in base
   // coords; dft = foot relative to base origin in base coords; jc[], Fp[] in base coords.
-  M3<T> R;
+  M3<V> R;
   MAKE_R(R);
-  const V3<T> dw = mul(R, dft);
-  V3<T> jw[3];
+  const V3<V> dw = mul(R, dft);
+  V3<V> jw[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) jw[k] = mul(R, jc[k]);
   {
-    T ad[6] = {0, 0, 0, 0, 0, 0};
+    V ad[6] = {0, 0, 0, 0, 0, 0};
     if (STEP) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) ad[c] = px[BLOCK * c];   // parked at the top of the kernel
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const V3<T> Mf = mul(R, Fp[k].f), Mn = mul(R, Fp[k].n);  // base-leg column, world axes
+      const V3<V> Mf = mul(R, Fp[k].f), Mn = mul(R, Fp[k].n);  // base-leg column, world axes
       if (MATS) {
         const unsigned x = jxN[k];
         STLX(a.M, 6, 0, x, Mf.x);                       // midx18(0, 6+j) = 6 + j
@@ -596,77 +656,77 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   SSTAMP();  // 7: leg outputs stored
   // ------------------------------------------------------------------ quad reductions into the base
   if (MATS) {
-    const T* pb = &park[2 * PW][ln];
-    T xa[16] = {facc.n.x, facc.n.y, facc.n.z, facc.f.x, facc.f.y, facc.f.z, cm, ch.x, ch.y, ch.z,
+    const V* pb = &park[2 * PW][ln];
+    V xa[16] = {facc.n.x, facc.n.y, facc.n.z, facc.f.x, facc.f.y, facc.f.z, cm, ch.x, ch.y, ch.z,
                 cI.xx, cI.xy, cI.xz, cI.yy, cI.yz, cI.zz};
     XSUM(xa, 16);   // the four legs' contributions to the base: bias wrench 6, composite mass 1, first moment 3, inertia 6
-    const V3<T> bfn = mk<T>(xa[0], xa[1], xa[2]) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);   // total bias wrench, base coords
-    const V3<T> bff = mk<T>(xa[3], xa[4], xa[5]) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
-    const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);  // h base rows (force, moment), world
+    const V3<V> bfn = mk<V>(xa[0], xa[1], xa[2]) + mk<V>(pb[0], pb[BLOCK], pb[BLOCK * 2]);   // total bias wrench, base coords
+    const V3<V> bff = mk<V>(xa[3], xa[4], xa[5]) + mk<V>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
+    const V3<V> hb_f = mul(R, bff), hb_n = mul(R, bfn);  // h base rows (force, moment), world
     ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
     if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
-    const T tm = xa[6] + bm;
-    const V3<T> th = mk<T>(xa[7], xa[8], xa[9]) + bh;
-    S3<T> tI;
+    const V tm = xa[6] + bm;
+    const V3<V> th = mk<V>(xa[7], xa[8], xa[9]) + bh;
+    S3<V> tI;
     tI.xx = xa[10] + bI.xx; tI.xy = xa[11] + bI.xy; tI.xz = xa[12] + bI.xz;
     tI.yy = xa[13] + bI.yy; tI.yz = xa[14] + bI.yz; tI.zz = xa[15] + bI.zz;
-    const V3<T> hw = mul(R, th);
-    const S3<T> Iw = congr(R, tI);
+    const V3<V> hw = mul(R, th);
+    const S3<V> Iw = congr(R, tI);
     // base 6x6 block: 15 data-dependent entries (the 6 structural zeros went out with the early stores)
     T* M = a.M;
     ST4(M, midx18(0, 0), tm, midx18(1, 1), tm, midx18(2, 2), tm, midx18(0, 4), hw.z);
     ST4(M, midx18(0, 5), -hw.y, midx18(1, 3), -hw.z, midx18(1, 5), hw.x, midx18(2, 3), hw.y);
     ST4(M, midx18(2, 4), -hw.x, midx18(3, 3), Iw.xx, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz);
-    if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
+    if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<V>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
   }
   // ------------------------------------------------------------------ observer: second pass over the leg
   // body momenta I v, gravity-only forces and their leaf->root accumulation (a5): velocities are re-propagated
   // with the parked E matrices (cheap), so nothing of this lived in registers during the first pass.
-  SF<T> mom0, grv0;
-  T p_leg[3], ct_leg[3], g_leg[3];
+  SF<V> mom0, grv0;
+  V p_leg[3], ct_leg[3], g_leg[3];
   if (OBS) {
     // keep the compiler from hoisting this pass's loads into the first pass (that is what made the one-pass form spill)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    V3<T> omk[3], vvk[3], glk[3];
-    SF<T> ivk[3];
-    V3<T> om0, v0, gneg;
+    V3<V> omk[3], vvk[3], glk[3];
+    SF<V> ivk[3];
+    V3<V> om0, v0, gneg;
     {
-      om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));   // (vb, vl: kept from the top of the kernel in these variants)
-      v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
-      gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));
-      V3<T> omp2 = om0, vp2 = v0, gp2 = gneg;
+      om0 = tmul(R, mk<V>(vb[3], vb[4], vb[5]));   // (vb, vl: kept from the top of the kernel in these variants)
+      v0 = tmul(R, mk<V>(vb[0], vb[1], vb[2]));
+      gneg = tmul(R, mk<V>(-model->grav[0], -model->grav[1], -model->grav[2]));
+      V3<V> omp2 = om0, vp2 = v0, gp2 = gneg;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int o = JOINT_WORDS * k;
-        const T* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];
-        M3<T> Ek;
+        const V* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];
+        M3<V> Ek;
         {
-          const T sn = pe[0], cs = pe[BLOCK];
+          const V sn = pe[0], cs = pe[BLOCK];
 #pragma unroll
           for (int e = 0; e < 9; ++e) Ek.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
         }
-        const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
-        const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
-        S3<T> Io;
+        const V3<V> r = mk<V>(CS(o + 27), CS(o + 28), CS(o + 29));
+        const V3<V> ax = mk<V>(CS(o + 30), CS(o + 31), CS(o + 32));
+        S3<V> Io;
         Io.xx = CS(o + 37); Io.xy = CS(o + 38); Io.xz = CS(o + 39); Io.yy = CS(o + 40); Io.yz = CS(o + 41); Io.zz = CS(o + 42);
-        const T qd = vl[k];
+        const V qd = vl[k];
         omk[k] = tmul(Ek, omp2) + ax * qd;
         vvk[k] = tmul(Ek, vp2 + cross(omp2, r));
         glk[k] = tmul(Ek, gp2);
-        ivk[k] = inertia_mul(CS(o + 33), mk<T>(CS(o + 34), CS(o + 35), CS(o + 36)), Io, omk[k], vvk[k]);
+        ivk[k] = inertia_mul(V(CS(o + 33)), mk<V>(CS(o + 34), CS(o + 35), CS(o + 36)), Io, omk[k], vvk[k]);
         omp2 = omk[k]; vp2 = vvk[k]; gp2 = glk[k];
       }
     }
-    SF<T> macc, gacc;
+    SF<V> macc, gacc;
 #pragma unroll
     for (int k = 2; k >= 0; --k) {
       const int o = JOINT_WORDS * k;
-      const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
-      const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
-      const T m = CS(o + 33);
-      const V3<T> h = mk<T>(CS(o + 34), CS(o + 35), CS(o + 36));
-      SF<T> mk_, gk;
+      const V3<V> r = mk<V>(CS(o + 27), CS(o + 28), CS(o + 29));
+      const V3<V> ax = mk<V>(CS(o + 30), CS(o + 31), CS(o + 32));
+      const V m = CS(o + 33);
+      const V3<V> h = mk<V>(CS(o + 34), CS(o + 35), CS(o + 36));
+      SF<V> mk_, gk;
       mk_ = ivk[k];
       gk.n = cross(h, glk[k]);
       gk.f = glk[k] * m;
@@ -675,10 +735,10 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       ct_leg[k] = -dot(ax, cross(omk[k], mk_.n) + cross(vvk[k], mk_.f));
       g_leg[k] = dot(ax, gk.n);
       {
-        const T* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];  // E again, rebuilt rather than held in 27 registers
-        M3<T> Ek;
+        const V* pe = (k < 2) ? &park[PW * k][ln] : &park[2 * PW + PB][ln];  // E again, rebuilt rather than held in 27 registers
+        M3<V> Ek;
         {
-          const T sn = pe[0], cs = pe[BLOCK];
+          const V sn = pe[0], cs = pe[BLOCK];
 #pragma unroll
           for (int e = 0; e < 9; ++e) Ek.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
         }
@@ -686,22 +746,22 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         gacc = to_parent(Ek, r, gk);
       }
     }
-    const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
-    T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
+    const SF<V> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+    V xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
     XSUM(xb, 12);
-    mom0.n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n;
-    mom0.f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
-    grv0.n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg);
-    grv0.f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
+    mom0.n = mk<V>(xb[0], xb[1], xb[2]) + Iv0.n;
+    mom0.f = mk<V>(xb[3], xb[4], xb[5]) + Iv0.f;
+    grv0.n = mk<V>(xb[6], xb[7], xb[8]) + cross(bh, gneg);
+    grv0.f = mk<V>(xb[9], xb[10], xb[11]) + gneg * bm;
   }
 
   SSTAMP();  // 8: base block stored
   // ------------------------------------------------------------------ momentum, beta = C^T v - g
-  T p_b[6], beta_b[6], beta_l[3];
+  V p_b[6], beta_b[6], beta_l[3];
   if (OBS) {
-    const V3<T> Pl = mul(R, mom0.f), Pa = mul(R, mom0.n);
-    const V3<T> gl = mul(R, grv0.f), ga = mul(R, grv0.n);
-    const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
+    const V3<V> Pl = mul(R, mom0.f), Pa = mul(R, mom0.n);
+    const V3<V> gl = mul(R, grv0.f), ga = mul(R, grv0.n);
+    const V3<V> cx = cross(mk<V>(vb[0], vb[1], vb[2]), Pl);
     p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
     beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
     beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
@@ -723,20 +783,20 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 
   // ------------------------------------------------------------------ step-mode prologue for the QP
   if (STEP) {
-    T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
+    V rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
     if (OBS && prm.observer_order > 0) {
       // generalized force of the previous commands at the current configuration
-      const V3<T> fp = mk<T>(ob_fp[0], ob_fp[1], ob_fp[2]);
-      const V3<T> dxf = cross(dw, fp);
-      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+      const V3<V> fp = mk<V>(ob_fp[0], ob_fp[1], ob_fp[2]);
+      const V3<V> dxf = cross(dw, fp);
+      V ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
       XSUM(ub, 6);
-      const T dt = prm.dt;
+      const V dt = prm.dt;
       const bool o1 = prm.observer_order == 1;
 #pragma unroll
       for (int c = 0; c < 6; ++c) {  // replicated over the quad (same values in all four lanes)
-        const T r0 = ob_rb[c];
-        const T ig = ob_igb[c] + dt * (ub[c] + beta_b[c] + r0);
-        const T e = p_b[c] - ig;
+        const V r0 = ob_rb[c];
+        const V ig = ob_igb[c] + dt * (ub[c] + beta_b[c] + r0);
+        const V e = p_b[c] - ig;
         rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);   // (from LDS: 72 SGPRs of gains held to the end of the kernel meant SGPR spills read back 800 times)
         p_b[c] = ig;  // reuse as the new integ for the store below
       }
@@ -748,17 +808,17 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = 6 + jx[k];
-        const T r0 = ob_rl[k];
-        const T u = ob_tp[k] + dot(jw[k], fp);
-        const T ig = ob_igl[k] + dt * (u + beta_l[k] + r0);
-        const T e = p_leg[k] - ig;
+        const V r0 = ob_rl[k];
+        const V u = ob_tp[k] + dot(jw[k], fp);
+        const V ig = ob_igl[k] + dt * (u + beta_l[k] + r0);
+        const V e = p_leg[k] - ig;
         rl[k] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
         STV(a.obs_integ, c, ig);
         STV(a.obs_r, c, rl[k]);
       }
     }
     if (OBS) {
-      T b[6];
+      V b[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) b[c] = ob_wd[c] - rb[c];
       WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
@@ -791,11 +851,11 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 #undef CS
 }
 
-template <class T, int MODE, int BLOCK>
+template <class T, int MODE, int BLOCK, int W = 1>
 __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                         SweepArgs<T> a) {
   if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
-  dyn_sweep_body<T, MODE, BLOCK>(model, prm, a);
+  dyn_sweep_body<T, MODE, BLOCK, W>(model, prm, a);
 }
 
 }  // namespace wbc

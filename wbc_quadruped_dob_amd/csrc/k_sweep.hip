@@ -1,21 +1,36 @@
 // dyn_sweep_kernel launches (units a1-a6 + the a7/a9 prologue; dyn_sweep.hip.hpp).
 #include "k_common.hip.hpp"
+#include <type_traits>
 #include "dyn_sweep.hip.hpp"
 
 namespace wbc {
 
-template <int MODE>
-static hipError_t sweep_mode(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {
+template <int MODE, int W>
+static hipError_t sweep_launch(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {
   using T = Scalar;
-  const size_t threads = a.N * 4;
+  const size_t threads = ((a.N + W - 1) / W) * 4;   // one lane per leg and per W consecutive states
   if constexpr ((MODE & SW_OBS) == 0) {  // the observer variants park too much per wave for 256-thread workgroups
     if (threads >= BIG_GRID_THREADS) {
-      WBC_KLAUNCH(L, (dyn_sweep_kernel<T, MODE, 256>), dim3((unsigned)((threads + 255) / 256)), dim3(256), model, prm, a);
+      WBC_KLAUNCH(L, (dyn_sweep_kernel<T, MODE, 256, W>), dim3((unsigned)((threads + 255) / 256)), dim3(256), model, prm, a);
       return hipGetLastError();
     }
   }
-  WBC_KLAUNCH(L, (dyn_sweep_kernel<T, MODE, 64>), dim3((unsigned)((threads + 63) / 64)), dim3(64), model, prm, a);
+  WBC_KLAUNCH(L, (dyn_sweep_kernel<T, MODE, 64, W>), dim3((unsigned)((threads + 63) / 64)), dim3(64), model, prm, a);
   return hipGetLastError();
+}
+
+// fp32, even N: two states per lane as packed pairs (whole 128-byte lines per 16-lane row, v_pk_* arithmetic, half the
+// wavefronts).  Below PACK2_MIN_STATES the batch does not fill the SIMDs with one state per lane either, and the shorter
+// dependent chain per state of the unpacked form wins.
+#ifndef WBC_PACK2_MIN_STATES
+#define WBC_PACK2_MIN_STATES 8192
+#endif
+template <int MODE>
+static hipError_t sweep_mode(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {
+  if constexpr (std::is_same<Scalar, float>::value) {
+    if ((a.N & 1) == 0 && L.f32_pack2 >= 0 && (L.f32_pack2 > 0 || a.N >= (size_t)WBC_PACK2_MIN_STATES)) return sweep_launch<MODE, 2>(L, model, prm, a);
+  }
+  return sweep_launch<MODE, 1>(L, model, prm, a);
 }
 
 template <>

@@ -12,6 +12,7 @@ namespace wbc {
 struct LaunchCtx {
   hipStream_t st = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  int f32_pack2 = 0;   // wbc_solver_options.f32_pack2 (dyn_sweep launches only)
 };
 
 // dyn_sweep_kernel<T, MODE>: MODE = SW_MATS | SW_STEP | SW_OBS bits (device_types.hpp); workgroup size chosen from N
@@ -23,7 +24,8 @@ template <class T> hipError_t k_observer(const LaunchCtx& L, const DevModel<T>* 
 // GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran).
 // tile = 0: qp_group16_kernel, one wavefront per workgroup, four consecutive states per wavefront;
 // tile = 64 | 128 | 256 | 512: qp_tile_kernel, workgroups of four wavefronts deal a tile of that many states by predicted work
-// list (optional): solve the states list[4 .. 4 + list[0]) instead of the whole batch (qp_list_kernel, which also resets the list)
+// list (optional): solve the states list[4 .. 4 + list[0]) instead of the whole batch (qp_list_kernel; the count is reset by the
+// NEXT tick's front-half kernel, SweepArgs::qp_todo -- not here)
 template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, int tile, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap,
                                   int* list = nullptr);
 // qp_lane_kernel<T, RHAT>: the GRF QP one state per LANE (semismooth Newton on the 6-dimensional residual wrench); states it

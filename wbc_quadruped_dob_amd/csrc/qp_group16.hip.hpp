@@ -127,6 +127,14 @@ template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 12]; T C[4][32 * 3]
 #ifndef WBC_QP_WAVES
 #define WBC_QP_WAVES 2
 #endif
+// WBC_QP_RINV = 1: the active-set factor is kept as U = R^-1 (row `me` of U per variable lane, in the LDS image that held R).
+// The dual step r = R^-1 d1 is then a matrix-vector product -- twelve broadcasts and FMAs in three independent chains --
+// instead of a back-substitution whose iq steps each wait for the one before (round 2 stamps: 610 of the ~3 200 cycles of an
+// iteration).  Appending a constraint needs nothing new: with r = R^-1 d1 at hand the new column of U is
+// [-r / delta ; 1 / delta], delta = the new diagonal entry of R.
+#ifndef WBC_QP_RINV
+#define WBC_QP_RINV 1
+#endif
 // One-wave workgroups (stand-alone kernel): every wavefront is its own workgroup, so its LDS and wave slot are released the
 // moment ITS four QPs are done and the CU backfills.  Workgroups that share a 128-byte line of the inputs are mapped to the
 // same XCD (L2).
@@ -381,6 +389,11 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   {
     T* c = Cl + 3 * (2 * l16);
     c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
+#if WBC_QP_RINV
+    // the image of U starts at zero for EVERY QP: columns beyond the active set enter the dual step multiplied by a masked
+    // zero, so whatever they hold must be finite -- a NaN left by an earlier state of this row slot (tiles, rollouts) must not leak
+    if (isvar) sfor<0, 12>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rl[12 * k] = (T)0; });
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // (LDS hand-over inside the wavefront: no global traffic to wait for)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -391,7 +404,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   int iq = 0, ip = -1, status = 0, iter = 0;
   bool done = !live;
   bool actA = false, actB = false;
-  T sip = 0, Rnorm = 1, u_me = 0, rdinv = 0;
+  T sip = 0, Rnorm = 1, u_me = 0;
+#if !WBC_QP_RINV
+  T rdinv = 0;
+#endif
   T u_c = 0;  // multiplier of the candidate constraint (row-uniform; it has no position until it is added)
   int Aid = -1;
 
@@ -420,7 +436,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   };
   // add constraint with normal (np0,np1,np2) on foot fp at position `pos` for rows where `doit`;
   // dd = J^T np of my column (valid when isvar), dn2 = |dd[pos..)|^2.  Householder on J[:, pos..12).
-  auto add_column = [&](bool doit, int pos, T dd, T dn2, T& nr_out) __attribute__((always_inline)) {
+  auto add_column = [&](bool doit, int pos, T dd, T dn2, T& nr_out, T r_in) __attribute__((always_inline)) {
     const T a0 = gsum((isvar && v == pos) ? dd : (T)0);  // d[pos]: row sum of a one-hot, no LDS round trip
     const T inr = rsqrt_nr(dn2 > 0 ? dn2 : (T)1);
     const T nr = dn2 * inr;  // |d2| = dn2 / sqrt(dn2)
@@ -434,9 +450,14 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     y_me = doit ? y_me * beta : (T)0;
     sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Jr[j] -= y_me * gbc<j>(w_me); });
     sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; Jc[i] -= gbc<i>(y_me) * w_me; });
+#if WBC_QP_RINV
+    const T rdn = -sg * inr;   // 1 / (new diagonal entry of R)
+    if (doit && isvar) Rl[12 * pos] = (v < pos) ? -r_in * rdn : (v == pos ? rdn : (T)0);   // column `pos` of U = R^-1, every row
+#else
     const T newr = (v < pos) ? dd : -sg * nr;
     if (doit && isvar && v <= pos) Rl[12 * pos] = newr;
     if (doit && isvar && v == pos) rdinv = -sg * inr;
+#endif
     nr_out = nr;
   };
   // d = J^T np for my column, np = (n0,n1,n2) on the variables of foot fp
@@ -449,6 +470,20 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     const T j2 = m0 * Jc[2] + m1 * Jc[5] + m2 * Jc[8] + m3 * Jc[11];
     return isvar ? j0 * n0 + j1 * n1 + j2 * n2 : (T)0;
   };
+#if WBC_QP_RINV
+  // r = U d1 (U = R^-1 by rows, d1 = d[0 .. q)); kmax = wave-uniform bound on q
+  auto dual_step = [&](T dd, int q, int kmax) __attribute__((always_inline)) -> T {
+    T Urow[12];
+    sfor<0, 12>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Urow[k] = Rl[12 * k]; });
+    const T ddm = (isvar && v < q) ? dd : (T)0;   // masked at the source lane: columns >= q of the image are stale
+    T ra[3] = {0, 0, 0};
+    sfor<0, 12>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int k = decltype(kc)::value;
+      if (k < kmax) ra[k % 3] += Urow[k] * gbc<k>(ddm);
+    });
+    return (isvar && v < q) ? (ra[0] + ra[1]) + ra[2] : (T)0;
+  };
+#endif
   // normal of constraint id: its three coefficients live in lane (id >> 1)
   auto normal_of = [&](int id, T& n0, T& n1, T& n2) __attribute__((always_inline)) {
     const T* c = Cl + 3 * (id & 31);
@@ -493,6 +528,15 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     SEG(1);
     // r = R^-1 d1 : column-oriented back-substitution, row k of R lives in variable lane k
     T r_me = 0;
+#if WBC_QP_RINV
+    {
+      const int iqg = go ? iq : 0;
+      int iqmax = __builtin_amdgcn_readlane(iqg, 0);
+      { const int b1 = __builtin_amdgcn_readlane(iqg, 16), b2 = __builtin_amdgcn_readlane(iqg, 32), b3 = __builtin_amdgcn_readlane(iqg, 48);
+        iqmax = iqmax > b1 ? iqmax : b1; iqmax = iqmax > b2 ? iqmax : b2; iqmax = iqmax > b3 ? iqmax : b3; }
+      r_me = dual_step(dd, iq, iqmax);
+    }
+#else
     {
       T acc = (isvar && v < iq) ? dd : (T)0;
       T Rrow[12];  // my row of R, fetched up front so that no LDS latency sits inside the dependent chain
@@ -512,6 +556,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
         }
       });
     }
+#endif
     SEG(2);
     // step lengths
     T t1 = INF;
@@ -540,7 +585,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     const bool addg = go && full;
     {
       T nr;
-      add_column(addg, iq, dd, dn2, nr);
+      add_column(addg, iq, dd, dn2, nr, r_me);
       if (addg) {
         Rnorm = (nr > Rnorm) ? nr : Rnorm;
         if (l16 == lp) { if (ipc & 1) actB = true; else actA = true; }
@@ -585,7 +630,12 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
         const T dp = jt_np(((idc >> 1) & 15) >> 2, m0, m1, m2);
         const T dp2 = gsum((isvar && v >= p) ? dp * dp : (T)0);
         T nr;
-        add_column(rg, p, dp, dp2, nr);
+#if WBC_QP_RINV
+        const T rp = dual_step(dp, rg ? p : 0, p);
+#else
+        const T rp = 0;
+#endif
+        add_column(rg, p, dp, dp2, nr, rp);
         if (rg) Rnorm = (nr > Rnorm) ? nr : Rnorm;
       }
       {  // a partial step moved x: refresh the candidate's slack (cross-lane ops stay unconditional)

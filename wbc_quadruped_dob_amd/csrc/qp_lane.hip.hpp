@@ -412,6 +412,7 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
   } else if (live) {
     const int slot = atomicAdd(&todo[0], 1);
     if (slot < (int)a.N) todo[4 + slot] = (int)s32;   // (always, while the count starts a tick at zero: the guard keeps a stale count from writing past the list)
+    else { a.status[s32] = 1; if (a.iters) a.iters[s32] = iters; }   // list overflow (the count did not start at zero): reported, never silent -- tau, f of this state are NOT this tick's
   }
 #undef LLD
 #undef LST

@@ -262,6 +262,8 @@ static int check_params(const wbc_params* p) {
   return WBC_OK;
 }
 
+int wbc::check_params_public(const wbc_params* p) { return check_params(p); }
+
 extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
@@ -275,6 +277,7 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->qp_tile = 0;
   o->obs_split_serial = 1;
   o->qp_lane = 0;
+  o->f32_pack2 = 0;
 }
 
 extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -296,6 +299,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (o.qp_tile != 0 && o.qp_tile != -1 && o.qp_tile != 32 && o.qp_tile != 64 && o.qp_tile != 128 && o.qp_tile != 256 && o.qp_tile != 512)
     return fail(WBC_E_INVALID, "qp_tile must be 0 (auto), -1 (off), 32, 64, 128, 256 or 512");
   if (o.timing_mode != WBC_TIMING_DISPATCH && o.timing_mode != WBC_TIMING_EVENT_PAIR) return fail(WBC_E_INVALID, "bad timing_mode");
+  if (o.f32_pack2 < -1 || o.f32_pack2 > 1) return fail(WBC_E_INVALID, "f32_pack2 must be -1, 0 or 1");
   int leg_body[4][3];
   std::string err;
   rc = quadruped_topology(m->fm, leg_body, err);
@@ -406,6 +410,7 @@ struct SpanScope {   // one instrumented kernel launch
   hipError_t err = hipSuccess;
   SpanScope(wbc_solver* s_, int kind, hipStream_t st) : s(s_) {
     L.st = st;
+    L.f32_pack2 = s->opt.f32_pack2;
     if (!s->timing || !s->sample_now) return;
     if (s->spans.size() >= TIMING_MAX_SPANS) { ++s->dropped; return; }
     const size_t i = 2 * s->spans.size();
@@ -427,15 +432,24 @@ static void timing_tick(wbc_solver* s) {  // once per API call: is this tick ins
 
 extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
   if (!s) return fail(WBC_E_INVALID, "null solver");
-  if (on && s->ev_pool.empty()) {
+  if (on && s->ev_pool.size() != 2 * TIMING_MAX_SPANS) {
     ON_DEVICE(s);
-    s->ev_pool.reserve(2 * TIMING_MAX_SPANS);
-    s->spans.reserve(TIMING_MAX_SPANS);
+    // built in a local vector and swapped in only when complete: a pool left short by a failed hipEventCreate would be
+    // indexed past its end by the next SpanScope
+    std::vector<hipEvent_t> pool;
+    pool.reserve(2 * TIMING_MAX_SPANS);
     for (size_t i = 0; i < 2 * TIMING_MAX_SPANS; ++i) {
       hipEvent_t ev;
-      HIP_TRY(hipEventCreate(&ev));
-      s->ev_pool.push_back(ev);
+      const hipError_t e = hipEventCreate(&ev);
+      if (e != hipSuccess) {
+        for (hipEvent_t x : pool) (void)hipEventDestroy(x);
+        return fail(WBC_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+      }
+      pool.push_back(ev);
     }
+    for (hipEvent_t x : s->ev_pool) (void)hipEventDestroy(x);
+    s->ev_pool.swap(pool);
+    s->spans.reserve(TIMING_MAX_SPANS);
   }
   s->timing = on != 0;
   s->timing_period = on > 1 ? on : 1;  // on = k > 1: sample every k-th tick (keeps the event cost out of the rest)
@@ -587,8 +601,9 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   return WBC_OK;
 }
 
-extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
-                              const wbc_observer_state* obs, void* stream) {
+// argument checks of one tick (no HIP call): shared with wbc_multi_*, which validates every shard before it enqueues any
+int wbc::check_step_args(const wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
+                         const wbc_observer_state* obs, bool rollout) {
   if (!s || !in || !out) return fail(WBC_E_INVALID, "null argument");
   if (N == 0) return WBC_OK;
   if (N > s->max_batch) return fail(WBC_E_CAPACITY, "N exceeds the solver's max_batch");
@@ -597,10 +612,19 @@ extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, c
   if (!out->tau || !out->f || !out->status) return fail(WBC_E_INVALID, "null output buffer");
   if ((out->M || out->h || out->Jc) && !(out->M && out->h && out->Jc))
     return fail(WBC_E_INVALID, "M, h, Jc must be given together");
+  if (rollout && !out->M) return fail(WBC_E_INVALID, "rollouts need the M, h, Jc buffers (forward dynamics reads them)");
   if (s->params.observer_order > 0) {
     if (!obs || !obs->integ || !obs->r) return fail(WBC_E_INVALID, "observer on: observer state buffers required");
-    if (!in->tau_prev || !in->f_prev) return fail(WBC_E_INVALID, "observer on: tau_prev and f_prev required");
+    if (!rollout && (!in->tau_prev || !in->f_prev)) return fail(WBC_E_INVALID, "observer on: tau_prev and f_prev required");
   }
+  return WBC_OK;
+}
+
+extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
+                              const wbc_observer_state* obs, void* stream) {
+  const int rc0 = check_step_args(s, N, in, out, obs, false);
+  if (rc0) return rc0;
+  if (N == 0) return WBC_OK;
   ON_DEVICE(s);
   hipStream_t st = (hipStream_t)stream;
   return s->dtype == WBC_F64 ? step_impl<double>(s, N, in, out, obs, st) : step_impl<float>(s, N, in, out, obs, st);
@@ -863,7 +887,11 @@ extern "C" int wbc_observer_init(wbc_solver* s, const double* q, const double* v
   for (int i = 0; i < 18; ++i) { if (s->dtype == WBC_F64) ((double*)hb)[19 + i] = v[i]; else ((float*)hb)[19 + i] = (float)v[i]; }
   unsigned char* d = (unsigned char*)s->d_one;
   HIP_TRY(hipMemcpyAsync(d, hb, 37 * ts, hipMemcpyHostToDevice, nullptr));
+  const unsigned long long calls0 = s->calls;   // start-up helper, not a tick: the every-k-th-tick sampling phase stays as it is
+  const bool timing0 = s->timing;
+  s->timing = false;
   int rc = wbc_dynamics_batch(s, 1, d, d + 19 * ts, nullptr, nullptr, nullptr, nullptr, d + 37 * ts, nullptr, nullptr);
+  s->timing = timing0; s->calls = calls0;
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(hb + 37 * ts, d + 37 * ts, 18 * ts, hipMemcpyDeviceToHost, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));

@@ -186,7 +186,9 @@ extern "C" int wbc_multi_device(const wbc_multi* mm, int shard) {
 
 extern "C" int wbc_multi_set_params(wbc_multi* mm, const wbc_params* p) {
   if (!mm) return fail(WBC_E_INVALID, "null argument");
-  for (Shard& s : mm->sh) { int rc = wbc_solver_set_params(s.solver, p); if (rc) return rc; }
+  int rc = wbc::check_params_public(p);   // checked once, then applied to every shard: the shards never disagree about the parameters
+  if (rc) return rc;
+  for (Shard& s : mm->sh) { rc = wbc_solver_set_params(s.solver, p); if (rc) return rc; }
   mm->observer_order = p->observer_order;
   return WBC_OK;
 }
@@ -196,6 +198,12 @@ extern "C" int wbc_multi_step_batch(wbc_multi* mm, size_t n_total, const wbc_bat
   if (!mm || !in || !out) return fail(WBC_E_INVALID, "null argument");
   if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
   const int n = (int)mm->sh.size();
+  for (int k = 0; k < n; ++k) {   // every shard's arguments are checked before any shard is enqueued: a bad shard k must not
+    size_t st, cnt;               // leave shards 0..k-1 one tick ahead (their observer state advanced) of the others
+    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
+    int rc = wbc::check_step_args(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, false);
+    if (rc) return rc;
+  }
   for (int k = 0; k < n; ++k) {   // enqueue every shard before looking at any: the devices run concurrently
     size_t st, cnt;
     (void)wbc_shard_range(n_total, n, k, &st, &cnt);
@@ -210,6 +218,13 @@ extern "C" int wbc_multi_rollout_batch(wbc_multi* mm, size_t n_total, int horizo
   if (!mm || !in || !out) return fail(WBC_E_INVALID, "null argument");
   if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
   const int n = (int)mm->sh.size();
+  if (horizon < 1) return fail(WBC_E_INVALID, "horizon must be >= 1");
+  for (int k = 0; k < n; ++k) {   // validate all shards first (see wbc_multi_step_batch)
+    size_t st, cnt;
+    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
+    int rc = wbc::check_step_args(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, true);
+    if (rc) return rc;
+  }
   for (int k = 0; k < n; ++k) {   // rank-local for all ticks
     size_t st, cnt;
     (void)wbc_shard_range(n_total, n, k, &st, &cnt);
