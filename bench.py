@@ -48,6 +48,9 @@ def tick_sweep_symbol(dtype, obs, n):
     return "dyn_sweep_kernel<%s, %d," % ("double" if dtype == "f64" else "float", mode)
 
 
+print_line = lambda obj: print(json.dumps(obj))   # replaced in main() once descriptor 1 has been pointed at stderr
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks as a child process.  Nothing in THIS process
     initialises the GPU (device_count() does not, on this image) and nothing is exec'ed: the child is a subprocess and
@@ -124,6 +127,18 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         sys.exit(self_launch(args))
+
+    # ONE line on stdout, whatever the libraries underneath print: RCCL writes its version banner (and, with NCCL_DEBUG set on
+    # the box, more) to file descriptor 1 when the process group comes up.  From here on descriptor 1 IS stderr; the JSON
+    # line goes to the saved original through emit().
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(_real_stdout, (json.dumps(obj) + "\n").encode())
+    global print_line
+    print_line = emit
 
     import numpy as np
     import torch
@@ -349,7 +364,7 @@ def main():
     if rank == 0:
         if legs:
             res.update(legs)
-        print(json.dumps(res))
+        print_line(res)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -503,7 +518,7 @@ def multi_capi_bench(args, W, synth, torch, np):
     gblocks = run(True)
     el, gel = float(np.median(blocks)), float(np.median(gblocks))
     ok = float(np.mean([(o["status"] == 0).double().mean().item() for o in outs]))
-    print(json.dumps({
+    print_line({
         "metric": "WBC control-steps/sec (batched DogBot)", "value": args.steps * n_total / el, "unit": "control-steps/s",
         "n_gpus": k, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
@@ -515,7 +530,7 @@ def multi_capi_bench(args, W, synth, torch, np):
                    "block_ms_max": max(blocks) * 1e3},
         "with_tau_allgather": {"value": args.steps * n_total / gel, "ms_per_step": gel / args.steps * 1e3,
                                "collective": ("RCCL ncclAllGather (ncclCommInitAll, one group call)" if distinct else "peer copies (shards share a device)")},
-        "rccl_ranks": ms.rccl_ranks, "qp": {"status_ok_frac": ok}, "roofline": None, "cpu_baseline": None}))
+        "rccl_ranks": ms.rccl_ranks, "qp": {"status_ok_frac": ok}, "roofline": None, "cpu_baseline": None})
 
 
 def rollout_setup(args, W, synth, torch, np, model, dtype, n, H, rank, local_rank, tracking):
@@ -570,7 +585,7 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
     elapsed = float(np.median(blocks))
     ok = float((out["status"].cpu().numpy() == 0).mean())
     if rank == 0:
-        print(json.dumps({
+        print_line({
             "metric": "WBC control-steps/sec (batched DogBot)", "value": args.steps * H * n * world / elapsed,
             "unit": "control-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -585,7 +600,7 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_min": min(blocks) * 1e3,
                        "block_ms_median": elapsed * 1e3, "block_ms_max": max(blocks) * 1e3},
             "rccl_ranks": world if dist is not None else None,
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": None, "cpu_baseline": None})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -666,11 +681,38 @@ def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):
         t0 = time.perf_counter()
         ct()
         cwall.append(time.perf_counter() - t0)
+    # the same loop on the solver's pinned image (wbc_one_map / wbc_one_tick: no staging copies), per completion mode
+    one = {}
+    if dtype == "f64":
+        for zc, label in ((0, "copies+sync"), (1, "zerocopy+sync"), (2, "zerocopy+stream_ticket"), (3, "zerocopy+kernel_ticket")):
+            try:
+                sz = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=1,
+                              options={"one_zerocopy": zc})
+                img = sz.one_image()
+                for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev"):
+                    img[k][:] = h[k]
+                img["mask"][0] = int(B["mask"][0])
+                if obs:
+                    ig0, r0 = sz.observer_init(h["q"], h["v"])
+                    img["obs_integ"][:] = ig0
+                    img["obs_r"][:] = r0
+                for _ in range(50):
+                    sz.one_tick()
+                ow = []
+                for _ in range(1000):
+                    t0 = time.perf_counter()
+                    sz.one_tick()
+                    ow.append(time.perf_counter() - t0)
+                one[label] = {"p50_us": float(np.median(ow)) * 1e6, "p99_us": float(np.percentile(ow, 99)) * 1e6, "status": int(img["status"][0])}
+                del sz
+            except Exception as e:
+                one[label] = {"error": repr(e)[:200]}
     return {"ticks": 1000, "tick_p50_us": float(np.median(wall)) * 1e6, "tick_p99_us": float(np.percentile(wall, 99)) * 1e6,
             "compute_torques_p50_us": float(np.median(cwall)) * 1e6, "compute_torques_p99_us": float(np.percentile(cwall, 99)) * 1e6,
             "tick_kernel_p50_us": float(np.median(fusk)) * 1e3 if fused else None,
             "qp_kernel_p50_us": float(np.median(qp2)) * 1e3, "qp_kernel_p99_us": float(np.percentile(qp2, 99)) * 1e3,
             "front_kernel_p50_us": float(np.median(front2)) * 1e3,
+            "one_tick_on_pinned_image": one,
             "note": "N=1 per launch, synchronous wbc_step_batch without M/h/Jc outputs; tick = host wall time incl. launch + stream "
                     "sync of the default dispatch (%s); tick_kernel = its kernel span over 200 further ticks; qp_kernel / "
                     "front_kernel = the GRF QP (assembly + solve + torque map) and the rnea_step front half as their own kernels, "

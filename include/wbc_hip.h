@@ -109,7 +109,10 @@ typedef struct wbc_solver_options {
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
                              kernel instead of inside the sweep; -1 = auto (fp32: from 40960 states on, fp64: from 20480),
                              -2 = never */
-  int one_zerocopy;       /* 1: the single-robot host-pointer calls let the kernel read/write the pinned staging image directly */
+  int one_zerocopy;       /* single-robot host-pointer calls: 0 = staging copies + hipStreamSynchronize; 1 = the kernel reads / writes the
+                             pinned image directly (mapped host memory); 2 = as 1, and completion is a ticket the stream writes into the
+                             image behind the tick (hipStreamWriteValue32), polled by the host in memory: no runtime call on the wait
+                             path; 3 = as 2 with a one-thread kernel writing the ticket.  2 / 3 fall back to 1 when the stack refuses */
   int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */
   int qp_tile;            /* GRF-QP kernel of the two-kernel tick: 0 = auto (tiles of 32 / 64 states dealt to the wavefronts by
                              predicted work from 12288 / 20480 states on, one-wavefront workgroups below), -1 = never tiles,
@@ -124,7 +127,7 @@ typedef struct wbc_solver_options {
                              the residual of its optimality equation is below 1e-11 (fp32: 2e-5) x (1 + |target wrench|) or a full
                              Newton step leaves the active faces unchanged (then the point is the exact solution for those faces) */
   int f32_pack2;          /* fp32 dynamics sweep with TWO states per lane (packed v_pk_* arithmetic, whole 128-byte lines per 16-lane
-                             row, half the wavefronts): 0 = auto (even batches from 8192 states on), 1 = every even batch, -1 = never */
+                             row, half the wavefronts): 0 = auto (even batches from 32768 states on), 1 = every even batch, -1 = never */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -233,6 +236,19 @@ int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const d
                         const double* vdot_des, const double* normals, const double* mu, int mask,
                         const double* tau_prev, const double* f_prev, double* obs_integ, double* obs_r,
                         double* tau, double* f, int* status);
+
+/* The single-robot loop without staging copies (fp64 solvers): wbc_one_map hands out HOST pointers into the solver's pinned
+ * image -- the caller keeps q, v, references, terrain and the observer state there and rewrites only what changed -- and
+ * wbc_one_tick runs one tick on the image in place and returns when tau, f, status, iters (and the updated observer state) are
+ * in it.  The wait follows wbc_solver_options.one_zerocopy (2: polled ticket, no hipStreamSynchronize).  Stands for the same
+ * per-tick entry point as wbc_compute_torques (name [UNVERIFIED]); one solver = one robot = one image. */
+typedef struct wbc_one_image {
+  double *q, *v, *w_des, *vdot_des, *normals, *mu, *tau_prev, *f_prev, *obs_integ, *obs_r;   /* inputs (observer state: in/out) */
+  double *tau, *f;                                                                           /* outputs */
+  int *mask, *status, *iters;
+} wbc_one_image;
+int wbc_one_map(wbc_solver* s, wbc_one_image* img);
+int wbc_one_tick(wbc_solver* s);
 
 /* Observer start-up for the single-robot host-pointer loop (see wbc_observer_state): writes integ = M(q) v and r = 0
  * (host arrays of nv doubles).  Synchronises. */

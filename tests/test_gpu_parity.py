@@ -259,6 +259,47 @@ def test_compute_torques_single_robot(torch_cuda, gpu_model, oracle):
     assert relerr(tau, ref["tau"][0]) < TIGHT64 and relerr(f, ref["f"][0]) < TIGHT64
 
 
+@pytest.mark.parametrize("zc", [0, 1, 2, 3])
+def test_single_robot_loop_on_the_pinned_image(torch_cuda, gpu_model, oracle, zc):
+    """wbc_one_map / wbc_one_tick: the one-robot loop with its state kept in the solver's pinned image (only changed fields
+    rewritten between ticks), for every completion mode of wbc_solver_options.one_zerocopy -- staging copies + stream
+    synchronise, zero-copy + synchronise, zero-copy + a ticket written by the stream / by a one-thread kernel and polled in host
+    memory.  30 closed-loop ticks with the observer on (tau_prev / f_prev fed back in place) against the oracle run the same way,
+    and against wbc_compute_torques on a second solver."""
+    solver, P = _solver(gpu_model, obs=1, max_batch=1, options={"one_zerocopy": zc})
+    other, _ = _solver(gpu_model, obs=1, max_batch=1)
+    B = synth.make_batch(3, 1, gpu_model.total_mass, rank=12)
+    img = solver.one_image()
+    for k in ("q", "v", "w_des", "vdot_des", "normals", "mu"):
+        img[k][:] = B[k][0]
+    img["mask"][0] = int(B["mask"][0])
+    img["tau_prev"][:] = 0.0
+    img["f_prev"][:] = 0.0
+    ig, rr = solver.observer_init(B["q"][0], B["v"][0])
+    img["obs_integ"][:] = ig
+    img["obs_r"][:] = rr
+    ig_o, r_o = ig[None, :].copy(), rr[None, :].copy()          # oracle's copy of the observer state
+    ig_c, r_c = ig.copy(), rr.copy()                            # wbc_compute_torques' copy
+    tp, fp = np.zeros((1, 12)), np.zeros((1, 12))
+    rng = np.random.default_rng(5)
+    for t in range(30):
+        ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], tp, fp, ig_o, r_o)
+        tau_c, f_c, st_c = other.compute_torques(B["q"][0], B["v"][0], B["w_des"][0], B["vdot_des"][0], B["normals"][0], B["mu"][0],
+                                                 int(B["mask"][0]), tp[0], fp[0], ig_c, r_c)
+        solver.one_tick()
+        assert img["status"][0] == ref["status"][0] == st_c == 0
+        assert relerr(img["tau"], ref["tau"][0]) < TIGHT64 and relerr(img["f"], ref["f"][0]) < TIGHT64
+        assert np.array_equal(img["tau"], tau_c) and np.array_equal(img["f"], f_c)      # same kernels, same inputs
+        assert relerr(img["obs_r"], r_o[0]) < 1e-8
+        # next tick: feed the outputs back and move the state a little -- in place, nothing else is rewritten
+        tp, fp = ref["tau"].copy(), ref["f"].copy()
+        img["tau_prev"][:] = img["tau"]
+        img["f_prev"][:] = img["f"]
+        dq = rng.uniform(-0.01, 0.01, 12)
+        B["q"][0, 7:] += dq
+        img["q"][7:] = B["q"][0, 7:]
+
+
 def test_capacity_and_argument_errors(torch_cuda, gpu_model):
     import wbc_quadruped_dob_amd as W
     torch = torch_cuda

@@ -165,6 +165,8 @@ def lib():
         L.wbc_solver_options_default.argtypes = [C.c_void_p]
         L.wbc_solver_options_default.restype = None
         L.wbc_observer_init.argtypes = [C.c_void_p] * 5
+        L.wbc_one_map.argtypes = [C.c_void_p, C.c_void_p]
+        L.wbc_one_tick.argtypes = [C.c_void_p]
         L.wbc_shard_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.wbc_multi_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.wbc_multi_destroy.argtypes = [C.c_void_p]
@@ -450,6 +452,24 @@ class Solver:
                                          p(tau_prev), p(f_prev), p(obs_integ), p(obs_r), p(tau), p(f), C.byref(st)),
                "wbc_compute_torques")
         return tau, f, st.value
+
+    def one_image(self):
+        """wbc_one_map: numpy views of the solver's pinned single-robot image (fp64 solvers).  Write q, v, w_des, vdot_des, normals,
+        mu, mask[0] (and tau_prev, f_prev, obs_integ, obs_r with the observer on) in place, call one_tick(), read tau, f, status[0]."""
+        class _Img(C.Structure):
+            _fields_ = [(k, C.POINTER(C.c_double)) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev", "obs_integ", "obs_r", "tau", "f")] + \
+                       [(k, C.POINTER(C.c_int)) for k in ("mask", "status", "iters")]
+        img = _Img()
+        _check(lib().wbc_one_map(self._h, C.byref(img)), "wbc_one_map")
+        m = self.model
+        sizes = dict(q=m.nq, v=m.nv, w_des=6, vdot_des=m.nv, normals=3 * m.nf, mu=m.nf, tau_prev=m.nj, f_prev=3 * m.nf, obs_integ=m.nv,
+                     obs_r=m.nv, tau=m.nj, f=3 * m.nf, mask=1, status=1, iters=1)
+        return {k: np.ctypeslib.as_array(getattr(img, k), shape=(n,)) for k, n in sizes.items()}
+
+    def one_tick(self):
+        rc = lib().wbc_one_tick(self._h)
+        if rc:
+            _check(rc, "wbc_one_tick")
 
     def observer_init(self, q, v):
         """Observer start-up of the single-robot loop: returns (integ = M(q) v, r = 0) as numpy float64 arrays."""

@@ -72,7 +72,66 @@ namespace wbc {
 // tables are staged by other wavefronts of the workgroup (cst_ext, zidx_ext).  EXT = 1: they are complete on entry, the
 // body contains no barrier.  EXT = 2: the body issues its state loads first and THEN joins the workgroup barrier behind
 // which the tables are complete (one memory round trip instead of two at the head of the tick).
-template <class T, int BLOCK, int EXT, int SPW = 16>
+// Structural zeros / ones of M and Jc (54 + 6 packed-M entries, 39 Jc entries per foot: ~55 store instructions per wavefront of
+// 16 states -- ~4 us of store issue when ONE wavefront does them, as mass_jac_body does).  Inside the fused tick the four QP
+// wavefronts are idle until the lever arms arrive: each takes a quarter of these stores there (wavefronts 0..2 one row of every
+// foot's Jc block, wavefront 3 the zeros of M), and the mass_jac role (ZEROS = false) is left with the data-dependent entries.
+// tx = thread index within the four QP wavefronts (0..255): state slot tx & 15, leg (tx >> 4) & 3, quarter tx >> 6.
+template <class T>
+WBC_DEV void structural_consts_quarter(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const int* zidx_s, unsigned tx) {
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  const int leg = (int)((tx >> 4) & 3), part = (int)(tx >> 6);
+  const size_t s_raw = (size_t)blockIdx.x * 16 + (tx & 15);
+  const bool live = s_raw < N;
+  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
+  const T Z = (T)0;
+  const int j0 = model->jidx[leg][0], j1 = model->jidx[leg][1], j2 = model->jidx[leg][2];
+  if ((N & 1) == 0) {
+    // 16 bytes per lane: neighbouring lanes pair up, the even one takes the even-numbered constants, the odd one the odd-numbered
+    // ones, each for both states (as in dyn_sweep_kernel): half the store instructions
+    struct alignas(2 * sizeof(T)) T2 { T a, b; };
+    const unsigned odd = s32 & 1u, s2 = s32 & ~1u;
+#define ST2C(ptr, comp, val) do { if (live) *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
+    if (part == 3) {
+      for (int e = 2 * leg + (int)odd; e < 64; e += 8) {
+        const int zi = zidx_s[e];
+        if (zi >= 0) ST2C(a.M, zi, Z);
+      }
+    } else {
+      const int mrow = part;
+      const int rb = 54 * leg + 18 * mrow;
+      ST2C(a.Jc, rb + (odd ? 1 : 0), ((odd ? 1 : 0) == mrow) ? (T)1 : Z);
+      ST2C(a.Jc, rb + (odd ? 3 + mrow : 2), (!odd && mrow == 2) ? (T)1 : Z);
+#pragma unroll
+      for (int c = 6; c < 18; c += 2) {
+        const int col = c + (int)odd - 6;
+        if (col != j0 && col != j1 && col != j2) ST2C(a.Jc, rb + c + (int)odd, Z);
+      }
+    }
+#undef ST2C
+  } else {
+#define ST1C(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+    if (part == 3) {
+      for (int e = leg; e < 64; e += 4) {
+        const int zi = zidx_s[e];
+        if (zi >= 0) ST1C(a.M, zi, Z);
+      }
+    } else {
+      const int mrow = part;
+      const int rb = 54 * leg + 18 * mrow;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ST1C(a.Jc, rb + c, (c == mrow) ? (T)1 : Z);
+      ST1C(a.Jc, rb + 3 + mrow, Z);
+#pragma unroll
+      for (int c = 0; c < 12; ++c)
+        if (c != j0 && c != j1 && c != j2) ST1C(a.Jc, rb + 6 + c, Z);
+    }
+#undef ST1C
+  }
+}
+
+template <class T, int BLOCK, int EXT, int SPW = 16, bool ZEROS = true>
 WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   static_assert(SPW == 16 || EXT != 0, "fewer states per workgroup only for roles");
@@ -100,8 +159,8 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   for (int k = 0; k < 3; ++k) ql[k] = LDX(a.q, 7, jxN[k]);
   if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
 
-  // structural zeros / ones first: they drain while the sweeps compute
-  {
+  // structural zeros / ones first: they drain while the sweeps compute (ZEROS = false: other wavefronts write them)
+  if constexpr (ZEROS) {
     const T Z = (T)0;
     for (int e = leg; e < 64; e += 4) {
       const int zi = zidx_s[e];

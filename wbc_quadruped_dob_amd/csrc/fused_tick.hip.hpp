@@ -27,6 +27,11 @@ namespace wbc {
 #else
 #define WBC_OBS_ROLE(EXT_, ARGS_) observer_body<T, 64, EXT_>(model, prm, ARGS_, cst, wsl)
 #endif
+// 1 (default): the structural zeros / ones of M and Jc are written by the four QP wavefronts while they wait for the lever arms,
+// not by the mass_jac role (~55 store instructions = ~4 us of store issue off that role's path); 0: by the mass_jac role
+#ifndef WBC_FUSED_ZEROS_BY_QP
+#define WBC_FUSED_ZEROS_BY_QP 1
+#endif
 // fused tick, observer on: the observer role is TWO wavefronts (base rows -> rhat_base, which the QP's b waits for; joint
 // rows -> rhat_joint, needed only in the torque map); -DWBC_OBS_ONE_WAVE: one wavefront does both
 #ifdef WBC_OBS_ONE_WAVE
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
   } else if (wave == 5) {
-    if constexpr (MATS) mass_jac_body<T, 64, 2>(model, a, cst, zidx_s);
+    if constexpr (MATS) mass_jac_body<T, 64, 2, 16, !WBC_FUSED_ZEROS_BY_QP>(model, a, cst, zidx_s);
     else __syncthreads();
     FSTAMP(9);
   } else if (OBSERVER && wave == 6) {
@@ -108,6 +113,14 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
     const QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN, stamp, stampN};
 #else
     const QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN};   // the QP waits for each piece where it first needs it
+#endif
+#if WBC_FUSED_ZEROS_BY_QP
+    if constexpr (MATS) {
+      const int* const zs = zidx_s;
+      const unsigned tq = threadIdx.x;
+      qp_group16_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy, QpWho{0, false},
+                                         [=] __device__() { structural_consts_quarter<T>(model, a, zs, tq); });
+    } else
 #endif
     qp_group16_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
   }

@@ -28,4 +28,14 @@ hipError_t k_reference<Scalar>(const LaunchCtx& L, const DevModel<Scalar>* model
   return hipGetLastError();
 }
 
+#ifdef WBC_SCALAR_IS_DOUBLE   // (defined once: this unit is compiled per scalar type)
+__global__ void flag_kernel(unsigned* ptr, unsigned value) {
+  __hip_atomic_store(ptr, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t k_flag(hipStream_t st, unsigned* ptr, unsigned value) {
+  hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, st, ptr, value);
+  return hipGetLastError();
+}
+#endif
+
 }  // namespace wbc

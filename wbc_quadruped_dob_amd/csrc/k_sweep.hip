@@ -23,7 +23,7 @@ static hipError_t sweep_launch(const LaunchCtx& L, const DevModel<Scalar>* model
 // wavefronts).  Below PACK2_MIN_STATES the batch does not fill the SIMDs with one state per lane either, and the shorter
 // dependent chain per state of the unpacked form wins.
 #ifndef WBC_PACK2_MIN_STATES
-#define WBC_PACK2_MIN_STATES 8192
+#define WBC_PACK2_MIN_STATES 32768
 #endif
 template <int MODE>
 static hipError_t sweep_mode(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {

@@ -39,6 +39,8 @@ template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bo
 template <class T> hipError_t k_rollout(const LaunchCtx& L, bool observer, bool track, int spw, const DevModel<T>* model, const DevParams<T>& prm,
                                        const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap, const IntegrateArgs<T>& ia, int horizon,
                                        const DevRefParams<T>* G, const RefArgs<T>& ra);
+// one thread: *ptr = value, system scope (the completion ticket of the flag-polled single-robot tick)
+hipError_t k_flag(hipStream_t st, unsigned* ptr, unsigned value);
 template <class T> hipError_t k_integrate(const LaunchCtx& L, const DevModel<T>* model, const IntegrateArgs<T>& a);
 template <class T> hipError_t k_reference(const LaunchCtx& L, const DevModel<T>* model, const DevRefParams<T>* G, const RefArgs<T>& a);
 

@@ -169,9 +169,12 @@ WBC_DEV void qp_wait(int* flag, int need) {
 // TILED (qp_tile_kernel below): the four rows of the wavefront solve the states `who` names (dealt by predicted work)
 // instead of four consecutive ones; the workgroup is four such wavefronts.
 struct QpWho { size_t state; bool live; };
-template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1>
+struct QpNoIdle { WBC_DEV void operator()() const {} };
+// `idle()` (fused tick) runs after this wavefront has requested its own inputs and before it first waits for the producer roles:
+// work that would otherwise sit on a producer's critical path (the structural constants of M and Jc, dyn_split.hip.hpp).
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
 WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
-                             const QpWho who = QpWho{0, false}) {
+                             const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
   static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
   // WPB: wavefronts of the workgroup that run this body (the fused kernels pair their producer wavefronts with four QP wavefronts)
   __shared__ G16Lds<T> lds_all[WPB];
@@ -216,6 +219,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
   const T mu_f = GLD(a.mu, f);
   WBC_QSTAMP(1);
+  idle();
   if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
   WBC_QSTAMP(2);
   T d_me = 0;

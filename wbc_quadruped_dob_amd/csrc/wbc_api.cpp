@@ -72,6 +72,8 @@ struct wbc_solver {
   void* h_one = nullptr;       // pinned host image of d_one: the single-robot calls move it with ONE copy each way
   void* h_one_dev = nullptr;   // device address of h_one (mapped): one_zerocopy lets the N = 1 kernels read / write it directly
   size_t one_bytes = 0;
+  unsigned one_seq = 0;        // completion tickets of the flag-polled single-robot ticks (one_zerocopy >= 2)
+  bool one_flag_ok = true;     // cleared when the stream write-value / flag kernel is refused: back to hipStreamSynchronize
   // timing: a ring of event pairs allocated by wbc_solver_enable_timing (never inside a tick)
   bool timing = false;
   int timing_period = 1;   // instrument every timing_period-th tick
@@ -300,6 +302,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
     return fail(WBC_E_INVALID, "qp_tile must be 0 (auto), -1 (off), 32, 64, 128, 256 or 512");
   if (o.timing_mode != WBC_TIMING_DISPATCH && o.timing_mode != WBC_TIMING_EVENT_PAIR) return fail(WBC_E_INVALID, "bad timing_mode");
   if (o.f32_pack2 < -1 || o.f32_pack2 > 1) return fail(WBC_E_INVALID, "f32_pack2 must be -1, 0 or 1");
+  if (o.one_zerocopy < 0 || o.one_zerocopy > 3) return fail(WBC_E_INVALID, "one_zerocopy must be 0 ... 3");
   int leg_body[4][3];
   std::string err;
   rc = quadruped_topology(m->fm, leg_body, err);
@@ -825,34 +828,25 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
   return WBC_OK;
 }
 
-extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const double* w_des,
-                                   const double* vdot_des, const double* normals, const double* mu, int mask,
-                                   const double* tau_prev, const double* f_prev, double* obs_integ, double* obs_r,
-                                   double* tau, double* f, int* status) {
-  if (!s || !q || !v || !w_des || !vdot_des || !normals || !mu || !tau || !f || !status)
-    return fail(WBC_E_INVALID, "null argument");
-  const bool ob = s->params.observer_order > 0;
-  if (ob && (!tau_prev || !f_prev || !obs_integ || !obs_r)) return fail(WBC_E_INVALID, "observer on: state required");
-  ON_DEVICE(s);
-  // host staging in the solver's dtype: a pinned image of the device scratch (doubles/floats, then mask | status | iters),
-  // one asynchronous copy each way around the launch and one synchronisation (was four blocking copies from pageable memory)
+// ---- single-robot tick on the solver's pinned image.  Layout (scalars of the solver's dtype, then ints):
+static const int ONE_OFF[] = {0, 19, 37, 43, 61, 73, 77, 89, 101, 119, 137, 149, 161};  // q v w a n mu tp fp ig r tau f end
+// ints behind the 200 scalars: [0] mask, [1] status, [2] iters, [3] completion ticket (one_zerocopy >= 2)
+
+// Runs wbc_step_batch(N = 1) on the image and returns when tau, f, status (and the observer state) are in the HOST image.
+//   one_zerocopy = 0: copy the image to the device scratch, tick, copy back, hipStreamSynchronize
+//   one_zerocopy = 1: the kernels read / write the pinned image directly (mapped host memory), hipStreamSynchronize
+//   one_zerocopy = 2: as 1, but completion is a 32-bit ticket that the STREAM writes into the image behind the tick
+//                     (hipStreamWriteValue32) and the host polls in memory -- no runtime call on the wait path
+//   one_zerocopy = 3: as 2 with a one-thread kernel writing the ticket (for stacks that refuse the stream write)
+static int one_tick_on_image(wbc_solver* s) {
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
-  const int off[] = {0, 19, 37, 43, 61, 73, 77, 89, 101, 119, 137, 149, 161};  // q v w a n mu tp fp ig r tau f end
+  const int* off = ONE_OFF;
   unsigned char* hb = (unsigned char*)s->h_one;
-  int* hints = (int*)(hb + 200 * sizeof(double));
-  auto put = [&](int o, const double* src, int n) {
-    for (int i = 0; i < n; ++i) {
-      if (s->dtype == WBC_F64) ((double*)hb)[o + i] = src ? src[i] : 0.0;
-      else ((float*)hb)[o + i] = src ? (float)src[i] : 0.0f;
-    }
-  };
-  put(off[0], q, 19); put(off[1], v, 18); put(off[2], w_des, 6); put(off[3], vdot_des, 18); put(off[4], normals, 12);
-  put(off[5], mu, 4); put(off[6], tau_prev, 12); put(off[7], f_prev, 12); put(off[8], obs_integ, 18); put(off[9], obs_r, 18);
-  put(off[10], nullptr, 12); put(off[11], nullptr, 12);
-  hints[0] = mask; hints[1] = 0; hints[2] = 0;
-  const bool zc = s->opt.one_zerocopy != 0;
+  const int zcm = s->opt.one_zerocopy;
+  const bool zc = zcm != 0;
   unsigned char* d = (unsigned char*)(zc ? s->h_one_dev : s->d_one);
   int* dints = (int*)(d + 200 * sizeof(double));
+  int* hints = (int*)(hb + 200 * sizeof(double));
   if (!zc) HIP_TRY(hipMemcpyAsync(d, hb, s->one_bytes, hipMemcpyHostToDevice, nullptr));
   wbc_batch_in in;
   in.q = d + off[0] * ts; in.v = d + off[1] * ts; in.w_des = d + off[2] * ts; in.vdot_des = d + off[3] * ts;
@@ -865,7 +859,52 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   int rc = wbc_step_batch(s, 1, &in, &out, &os, nullptr);
   if (rc) return rc;
   if (!zc) HIP_TRY(hipMemcpyAsync(hb, d, s->one_bytes, hipMemcpyDeviceToHost, nullptr));
+  if (zcm >= 2 && s->one_flag_ok) {
+    const unsigned ticket = ++s->one_seq;
+    hipError_t e = zcm == 2 ? hipStreamWriteValue32(nullptr, dints + 3, ticket, 0) : k_flag(nullptr, (unsigned*)(dints + 3), ticket);
+    if (e == hipSuccess) {
+      // stream order puts the ticket behind the tick's kernels, whose writes to the (fine-grained) image are released at
+      // their end: ticket visible => outputs visible.  Bounded spin, then the runtime's wait (a stalled device must not hang us).
+      const unsigned* flag = (const unsigned*)(hints + 3);
+      for (long spin = 0; spin < 4000000; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) return WBC_OK;
+        __builtin_ia32_pause();
+      }
+    } else {
+      (void)hipGetLastError();
+      s->one_flag_ok = false;   // refused on this stack: the plain wait from now on
+    }
+  }
   HIP_TRY(hipStreamSynchronize(nullptr));
+  return WBC_OK;
+}
+
+extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double* v, const double* w_des,
+                                   const double* vdot_des, const double* normals, const double* mu, int mask,
+                                   const double* tau_prev, const double* f_prev, double* obs_integ, double* obs_r,
+                                   double* tau, double* f, int* status) {
+  if (!s || !q || !v || !w_des || !vdot_des || !normals || !mu || !tau || !f || !status)
+    return fail(WBC_E_INVALID, "null argument");
+  const bool ob = s->params.observer_order > 0;
+  if (ob && (!tau_prev || !f_prev || !obs_integ || !obs_r)) return fail(WBC_E_INVALID, "observer on: state required");
+  ON_DEVICE(s);
+  // host staging in the solver's dtype: a pinned image of the device scratch (doubles/floats, then mask | status | iters),
+  // one asynchronous copy each way around the launch and one synchronisation (was four blocking copies from pageable memory)
+  const int* off = ONE_OFF;
+  unsigned char* hb = (unsigned char*)s->h_one;
+  int* hints = (int*)(hb + 200 * sizeof(double));
+  auto put = [&](int o, const double* src, int n) {
+    for (int i = 0; i < n; ++i) {
+      if (s->dtype == WBC_F64) ((double*)hb)[o + i] = src ? src[i] : 0.0;
+      else ((float*)hb)[o + i] = src ? (float)src[i] : 0.0f;
+    }
+  };
+  put(off[0], q, 19); put(off[1], v, 18); put(off[2], w_des, 6); put(off[3], vdot_des, 18); put(off[4], normals, 12);
+  put(off[5], mu, 4); put(off[6], tau_prev, 12); put(off[7], f_prev, 12); put(off[8], obs_integ, 18); put(off[9], obs_r, 18);
+  put(off[10], nullptr, 12); put(off[11], nullptr, 12);
+  hints[0] = mask; hints[1] = 0; hints[2] = 0;
+  int rc = one_tick_on_image(s);
+  if (rc) return rc;
   auto get = [&](int o, double* dst, int n) {
     if (!dst) return;
     for (int i = 0; i < n; ++i)
@@ -875,6 +914,28 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   if (ob) { get(off[8], obs_integ, 18); get(off[9], obs_r, 18); }
   *status = hints[1];
   return WBC_OK;
+}
+
+// The single-robot loop WITHOUT staging copies: the caller keeps its state in the solver's pinned image and rewrites only
+// what changed between ticks (fp64 solvers: the image's scalars are doubles).
+extern "C" int wbc_one_map(wbc_solver* s, wbc_one_image* img) {
+  if (!s || !img) return fail(WBC_E_INVALID, "null argument");
+  if (s->dtype != WBC_F64) return fail(WBC_E_INVALID, "wbc_one_map: fp64 solvers only (the image holds the solver's scalar type)");
+  double* hb = (double*)s->h_one;
+  int* hints = (int*)((unsigned char*)s->h_one + 200 * sizeof(double));
+  const int* off = ONE_OFF;
+  img->q = hb + off[0]; img->v = hb + off[1]; img->w_des = hb + off[2]; img->vdot_des = hb + off[3]; img->normals = hb + off[4];
+  img->mu = hb + off[5]; img->tau_prev = hb + off[6]; img->f_prev = hb + off[7]; img->obs_integ = hb + off[8]; img->obs_r = hb + off[9];
+  img->tau = hb + off[10]; img->f = hb + off[11];
+  img->mask = hints; img->status = hints + 1; img->iters = hints + 2;
+  return WBC_OK;
+}
+
+extern "C" int wbc_one_tick(wbc_solver* s) {
+  if (!s) return fail(WBC_E_INVALID, "null solver");
+  if (s->dtype != WBC_F64) return fail(WBC_E_INVALID, "wbc_one_tick: fp64 solvers only");
+  ON_DEVICE(s);
+  return one_tick_on_image(s);
 }
 
 // Observer start-up for the single-robot host-pointer loop: integ(0) = p(0) = M(q) v, r(0) = 0 (see wbc_observer_state).
