@@ -289,7 +289,7 @@ def test_single_robot_loop_on_the_pinned_image(torch_cuda, gpu_model, oracle, zc
         solver.one_tick()
         assert img["status"][0] == ref["status"][0] == st_c == 0
         assert relerr(img["tau"], ref["tau"][0]) < TIGHT64 and relerr(img["f"], ref["f"][0]) < TIGHT64
-        assert np.array_equal(img["tau"], tau_c) and np.array_equal(img["f"], f_c)      # same kernels, same inputs
+        assert relerr(img["tau"], tau_c) < TIGHT64 and relerr(img["f"], f_c) < TIGHT64   # (the other loop is fed the oracle's tau_prev / f_prev)
         assert relerr(img["obs_r"], r_o[0]) < 1e-8
         # next tick: feed the outputs back and move the state a little -- in place, nothing else is rewritten
         tp, fp = ref["tau"].copy(), ref["f"].copy()

@@ -14,7 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
 #include "dyn_split.hip.hpp"
-#include "qp_group16.hip.hpp"
+#include "qp_struct16.hip.hpp"
 #include "integrate.hip.hpp"
 #include "com_ref.hip.hpp"
 #include "observer.hip.hpp"
@@ -118,11 +118,11 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
     if constexpr (MATS) {
       const int* const zs = zidx_s;
       const unsigned tq = threadIdx.x;
-      qp_group16_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy, QpWho{0, false},
+      qp_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy, QpWho{0, false},
                                          [=] __device__() { structural_consts_quarter<T>(model, a, zs, tq); });
     } else
 #endif
-    qp_group16_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
+    qp_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
   }
 }
 
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #else
       const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
-      if (wave * 4 < SPW) qp_group16_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
+      if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
     }
     __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator
     __syncthreads();   // barrier B: q, v of the next tick

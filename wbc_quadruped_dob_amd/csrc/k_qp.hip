@@ -1,6 +1,6 @@
 // qp_group16_kernel launches: GRF QP + torque map (units a7-a9; qp_group16.hip.hpp).
 #include "k_common.hip.hpp"
-#include "qp_group16.hip.hpp"
+#include "qp_kernels.hip.hpp"
 #include "qp_lane.hip.hpp"
 
 namespace wbc {

@@ -1,0 +1,196 @@
+// The stand-alone GRF-QP kernels: one-wavefront workgroups (qp_group16_kernel), tiles dealt by predicted work (qp_tile_kernel),
+// the dense solver over a device-side list (qp_list_kernel).  The per-QP body is qp_body (qp_struct16.hip.hpp): the structured
+// wrench-space form in fp64, the orthogonal-factor form (qp_group16.hip.hpp) in fp32.
+#pragma once
+#include "qp_struct16.hip.hpp"
+
+namespace wbc {
+
+// RHAT: rhat comes from the separate observer kernel through the HBM workspace (large observer-on batches)
+template <class T, bool RHAT = false>
+__global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+  qp_body<T, false, RHAT>(prm, a, jmap, nullptr);
+}
+
+// ======================================================================================================================
+// qp_tile_kernel: the same QPs, DEALT BY PREDICTED WORK (large batches).
+// A wavefront runs until the slowest of its four rows is done, and iteration counts of neighbouring states differ a lot
+// (0 ... 13, mean 2.5 on the bench data): with four consecutive states per wavefront the loop runs 5.0 trips per group
+// for 2.5 iterations per QP -- half of the row-iterations idle.  Here a 256-thread workgroup owns a TILE of consecutive
+// states and
+//   1. predicts each state's work, one state per LANE: the unconstrained minimum x0 = B^T G^-1 S^(1/2) b from the same 6x6
+//      factor the solver uses (a few hundred instructions per 64 states), the number of constraints x0 violates and by how
+//      much (count alone: correlation with the iteration count 0.86-0.89 on the bench data);
+//   2. sorts the tile by that key in LDS (counting sort, hardest first);
+//   3. its four wavefronts pull groups of four similar states from an LDS counter until the tile is empty -- no wavefront
+//      waits for another, rows of a group finish together (about 3 trips per group instead of 5.0), and the short groups
+//      at the end of the queue level the tail.
+// Results per state are those of qp_group16_kernel (same body, another assignment of states to rows).
+template <class T, bool RHAT>
+WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned s32, unsigned N32) {
+#define PLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+  const int mask = a.mask[s32] & 0xF;
+  const T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
+  T Dx[4], Dy[4], Dz[4], Of[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const bool on = (mask >> f) & 1;
+    T dx, dy, dz;
+    if (a.Jc) { dx = PLD(a.Jc, (3 * f + 1) * 18 + 5); dy = PLD(a.Jc, (3 * f + 2) * 18 + 3); dz = PLD(a.Jc, (3 * f) * 18 + 4); }
+    else { dx = PLD(a.ws, WS_D + 3 * f); dy = PLD(a.ws, WS_D + 3 * f + 1); dz = PLD(a.ws, WS_D + 3 * f + 2); }
+    Of[f] = on ? (T)1 : (T)0; Dx[f] = on ? dx : (T)0; Dy[f] = on ? dy : (T)0; Dz[f] = on ? dz : (T)0;
+  }
+  T bt[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bt[k] = (a.wdes ? PLD(a.wdes, k) : PLD(a.ws, WS_B + k)) - (RHAT ? PLD(a.ws, WS_RHAT + k) : (T)0);
+  // G = alpha I + B B^T and its factor, as in qp_group16_body (selection only: seed-accuracy reciprocal square roots)
+  const T nc = (Of[0] + Of[1]) + (Of[2] + Of[3]);
+  const T sx = (Dx[0] + Dx[1]) + (Dx[2] + Dx[3]), sy = (Dy[0] + Dy[1]) + (Dy[2] + Dy[3]), sz = (Dz[0] + Dz[1]) + (Dz[2] + Dz[3]);
+  T Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    Pxx += Dx[f] * Dx[f]; Pxy += Dx[f] * Dy[f]; Pxz += Dx[f] * Dz[f]; Pyy += Dy[f] * Dy[f]; Pyz += Dy[f] * Dz[f]; Pzz += Dz[f] * Dz[f];
+  }
+  const T g00 = prm.alpha + s0 * s0 * nc, g11 = prm.alpha + s1 * s1 * nc, g22 = prm.alpha + s2 * s2 * nc;
+  const T gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
+  const T m00 = prm.alpha + (s3 * s3) * (Pyy + Pzz), m11 = prm.alpha + (s4 * s4) * (Pxx + Pzz), m22 = prm.alpha + (s5 * s5) * (Pxx + Pyy);
+  const T m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
+  auto rs = [](T x) __attribute__((always_inline)) -> T {
+    if constexpr (std::is_same<T, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
+  };
+  T il[6];
+  il[0] = rs(g00); il[1] = rs(g11); il[2] = rs(g22);
+  const T a01 = gm01 * il[1], a02 = gm02 * il[2], a10 = gm10 * il[0], a12 = gm12 * il[2], a20 = gm20 * il[0], a21 = gm21 * il[1];
+  const T c00 = m00 - a01 * a01 - a02 * a02, c11 = m11 - a10 * a10 - a12 * a12, c22 = m22 - a20 * a20 - a21 * a21;
+  const T c10 = m10 - a12 * a02, c20 = m20 - a21 * a01, c21 = m21 - a20 * a10;
+  il[3] = rs(c00);
+  const T b10 = c10 * il[3], b20 = c20 * il[3];
+  il[4] = rs(c11 - b10 * b10);
+  const T b21 = (c21 - b20 * b10) * il[4];
+  il[5] = rs(c22 - b20 * b20 - b21 * b21);
+  T w[6], z[6];   // z = G^-1 S^(1/2) b
+  w[0] = s0 * bt[0] * il[0]; w[1] = s1 * bt[1] * il[1]; w[2] = s2 * bt[2] * il[2];
+  w[3] = (s3 * bt[3] - a01 * w[1] - a02 * w[2]) * il[3];
+  w[4] = (s4 * bt[4] - a10 * w[0] - a12 * w[2] - b10 * w[3]) * il[4];
+  w[5] = (s5 * bt[5] - a20 * w[0] - a21 * w[1] - b20 * w[3] - b21 * w[4]) * il[5];
+  z[5] = w[5] * il[5];
+  z[4] = (w[4] - b21 * z[5]) * il[4];
+  z[3] = (w[3] - b10 * z[4] - b20 * z[5]) * il[3];
+  z[2] = (w[2] - a02 * z[3] - a12 * z[4]) * il[2];
+  z[1] = (w[1] - a01 * z[3] - a21 * z[5]) * il[1];
+  z[0] = (w[0] - a10 * z[4] - a20 * z[5]) * il[0];
+  const T zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
+  int cnt_all = 0;
+  T mag = 0;   // summed violation of the violated constraints
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    // x0 of foot f = on (s_f z_f + (s_m z_m) x d_f)
+    const T x0 = Of[f] * zf0 + (zm1 * Dz[f] - zm2 * Dy[f]);
+    const T x1 = Of[f] * zf1 + (zm2 * Dx[f] - zm0 * Dz[f]);
+    const T x2 = Of[f] * zf2 + (zm0 * Dy[f] - zm1 * Dx[f]);
+    T nx = PLD(a.normals, 3 * f), ny = PLD(a.normals, 3 * f + 1), nz = PLD(a.normals, 3 * f + 2);
+    const T iln = rs(nx * nx + ny * ny + nz * nz);
+    nx *= iln; ny *= iln; nz *= iln;
+    const bool usex = fabs_t(nx) < (T)0.9;
+    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
+    const T rd = rx * nx + ry * ny;
+    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
+    const T it = rs(t1x * t1x + t1y * t1y + t1z * t1z);
+    t1x *= it; t1y *= it; t1z *= it;
+    const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    const T fn = nx * x0 + ny * x1 + nz * x2, f1 = t1x * x0 + t1y * x1 + t1z * x2, f2 = t2x * x0 + t2y * x1 + t2z * x2;
+    const T mf = PLD(a.mu, f) * prm.mu_scale * fn, tol = -prm.qp_tol;
+    const T sl[6] = {mf - f1, mf + f1, mf - f2, mf + f2, fn - prm.fn_min, prm.fn_max - fn};
+    int cnt = 0;
+    T mg = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { cnt += (sl[c] < tol) ? 1 : 0; mg += (sl[c] < tol) ? -sl[c] : (T)0; }
+    const bool on = (mask >> f) & 1;
+    cnt_all += on ? cnt : 0;
+    mag += on ? mg : (T)0;
+  }
+#undef PLD
+  // fitted on the bench data (least squares on the iteration count): 0.52 count + 0.70 ln(1 + summed violation); three
+  // buckets per predicted iteration.  Sorting by it: 2.96 trips per group (count alone 3.25, perfect knowledge 2.51).
+  const float kf = 1.56f * (float)cnt_all + 2.1f * __logf(1.0f + (float)mag);
+  return (kf > 0.0f) ? (int)fminf(kf, 61.0f) : 0;   // 0 ... 61; a NaN / Inf state (garbage in) sorts as "no work", never out of range
+}
+
+#ifndef WBC_QP_TILE_WAVES
+#define WBC_QP_TILE_WAVES 2
+#endif
+template <class T, bool RHAT, int TILE>
+__global__ __launch_bounds__(256, WBC_QP_TILE_WAVES) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+  static_assert(TILE % 4 == 0 && TILE <= 1024, "tile of whole four-state groups");
+  __shared__ unsigned short order[TILE];
+  __shared__ int hist[64];
+  __shared__ int next_grp;
+  const unsigned tid = threadIdx.x;
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)a.N;
+  const size_t base = (size_t)blockIdx.x * TILE;
+  if (tid < 64) hist[tid] = 0;
+  if (tid == 0) next_grp = 0;
+  __syncthreads();
+  // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = beyond the end (dealt last, not solved)
+  int bucket[(TILE + 255) / 256], rank[(TILE + 255) / 256];
+#pragma unroll
+  for (int r = 0; r < (TILE + 255) / 256; ++r) {
+    const unsigned i = tid + 256u * r;
+    bucket[r] = 62; rank[r] = 0;
+    if (i < TILE) {
+      const size_t s = base + i;
+      if (s < N) bucket[r] = 61 - qp_predict_key<T, RHAT>(prm, a, (unsigned)s, N32);
+      rank[r] = __hip_atomic_fetch_add(&hist[bucket[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  // 2. counting sort: position = states in harder buckets + my arrival rank in mine
+#pragma unroll
+  for (int r = 0; r < (TILE + 255) / 256; ++r) {
+    const unsigned i = tid + 256u * r;
+    if (i < TILE) {
+      int pos = rank[r];
+      for (int j = 0; j < bucket[r]; ++j) pos += hist[j];
+      order[pos] = (unsigned short)i;
+    }
+  }
+  __syncthreads();
+  // 3. the four wavefronts pull groups of four states, hardest first
+  const int row = (int)((tid & 63) >> 4);
+  for (;;) {
+    int g = 0;
+    if ((tid & 63) == 0) g = __hip_atomic_fetch_add(&next_grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= TILE / 4) break;
+    if (base + order[4 * g] >= N) break;     // first (hardest) state of the group lies beyond the end: so does the rest of the queue
+    const size_t s = base + order[4 * g + row];
+    const bool live = s < N;
+    qp_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
+  }
+}
+
+// qp_list_kernel: the dense active-set solver over a LIST of states (list[0] = how many, list[4 ...] = their indices): the
+// states qp_lane_kernel (qp_lane.hip.hpp) did not finish.  One wavefront per workgroup, four listed states per wavefront,
+// grid-stride over the list (the launch cannot know its length: it lives on the device).  list[2] keeps the length for
+// wbc_solver_qp_handover.  The count is zeroed by one thread of the tick's front-half kernel (dyn_sweep / rnea_step, which
+// run between this kernel and the next qp_lane_kernel on the stream).  What did not work:
+//   * a 4-byte hipMemsetAsync did the job in eager mode, but as a memset node of a captured hipGraph it did not reliably run
+//     in front of the next kernel on this stack (the list overflowed after a few replays);
+//   * letting the last workgroup of this kernel reset it (one agent-scope atomic per workgroup to count them, an agent-scope
+//     load of the length) serialises on that one address: 8192 workgroups took 330 us instead of 65 us (N = 262 144);
+//   * a one-thread kernel of its own: correct, 4.7 us per tick.
+template <class T, bool RHAT>
+__global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_list_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ list) {
+  const int n = min(list[0], (int)a.N);
+  const int ngroups = (n + 3) >> 2;
+  const int row = (int)((threadIdx.x & 63) >> 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0) list[2] = n;
+  for (int g = (int)blockIdx.x; g < ngroups; g += (int)gridDim.x) {
+    const int i = 4 * g + row;
+    const bool live = i < n;
+    qp_body<T, false, RHAT, 16, true, 1>(prm, a, jmap, nullptr, nullptr, QpWho{live ? (size_t)list[4 + i] : (size_t)0, live});
+  }
+}
+
+}  // namespace wbc

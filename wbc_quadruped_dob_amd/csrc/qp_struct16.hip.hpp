@@ -1,0 +1,487 @@
+// GRF QP + torque map, round 3: the SAME dual active-set method (Goldfarb-Idnani, same pivoting rules, tolerances and status
+// codes as qp_group16.hip.hpp and the oracle) with all its linear algebra done on the 6-dimensional WRENCH space instead of on
+// 12 x 12 factors.  fp64 only (the inverse below is kept by Sherman-Morrison updates; fp32 keeps the orthogonal-factor form).
+//
+//     min 1/2 alpha |f|^2 + 1/2 |B f - beta|^2,   B = S^(1/2) [I ; [d_k]x] per stance foot,   s.t. per-foot pyramid + box
+//
+// H = alpha I + B^T B has rank-6 structure and every constraint touches ONE foot (3 variables).  With N_k the active normals of
+// foot k (at most 3, linearly independent), P_k the projector onto their null space and
+//     G_A = alpha I + sum_k B_k P_k B_k^T                                   (6 x 6, SPD)
+// the quantities of a dual active-set iteration for the candidate normal n+ on foot kp are
+//     v = P_kp n+,   b = B_kp v,   y = G_A^-1 b,   w_k = B_k^T y
+//     primal step direction   z_k = (delta_{k,kp} v - P_k w_k) / alpha,        z . n+ = (|v|^2 - b . y) / alpha     ( = |d2|^2 of the dense method)
+//     dual step direction     r_k = N_k^+ (delta_{k,kp} n+ - w_k)              (rate at which the active multipliers of foot k fall)
+//     adding n+:   P_kp -= v v^T / |v|^2,   N_kp^+ gains the row v^T / |v|^2 (the others lose their n+ component),
+//                  G_A^-1 += y y^T / (alpha z . n+)           -- Sherman-Morrison with what the step already computed
+//     dropping a constraint of foot k:  P_k, N_k^+ rebuilt in closed form from the <= 2 remaining normals (cross products),
+//                  G_A^-1 -= (G_A^-1 bh)(G_A^-1 bh)^T / (1 + bh . G_A^-1 bh),   bh = B_k what,  what what^T = P_k(new) - P_k(old)
+// (derivation and a numpy restatement checked against the oracle iteration by iteration: tools/structured_gi.py).
+//
+// Why: the dense form spends ~440 vector instructions and ~3 200 cycles of dependent latency per iteration on 12 x 12 products,
+// a Householder update of two copies of J and a back-substitution (round 2 stamps); this form needs one 6 x 6 matrix-vector
+// product, a handful of 3-vector operations per lane and no factor update beyond a rank-one FMA per row.
+//
+// Mapping (same as qp_group16: one QP per 16-lane DPP row, four per wavefront; lane 4k + c of a row belongs to foot k):
+//   lane 4k + c, c < 3: variable (foot k, axis c); row c of P_k; slot c of foot k's active list (constraint id, multiplier,
+//                       row c of N_k^+); constraints 2 (4k + c) and 2 (4k + c) + 1 as in qp_group16
+//   lane i < 6 (and i + 6, i + 12): row i of G_A^-1   (y_i = row . b, then six row broadcasts from static lanes)
+//   LDS per QP: the 32 constraint normals (by id), P_k (6 words per foot) and d_k for the run-time foot index kp -- every lane
+//   fetches n+, P_kp, d_kp and forms v, b redundantly, so the step needs NO cross-lane reduction at all.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "device_types.hpp"
+#include "qp_group16.hip.hpp"
+
+namespace wbc {
+
+// per wave: four QPs x {32 constraint normals, P of the four feet (xx xy xz yy yz zz), lever arms of the four feet, scratch what}
+template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 6]; T D[4][4 * 3]; T W[4][4]; };
+
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
+WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
+                              const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
+  static_assert(std::is_same<T, double>::value, "the structured form keeps an explicit inverse by rank-one updates: fp64 only");
+  static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
+  __shared__ S16Lds<T> lds_all[WPB];
+  unsigned tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
+  const int lane = tx & 63;
+  const int l16 = lane & 15;
+  const int rowbase = lane & 48;
+  const int grp = lane >> 4;
+  const int f = l16 >> 2, c3 = l16 & 3;
+  const bool isvar = c3 < 3;
+  const int v = 3 * f + (isvar ? c3 : 0);
+  S16Lds<T>& L = lds_all[tx >> 6];
+  T* Cl = L.C[grp];
+  T* Pl = L.P[grp];
+  T* Dl = L.D[grp];
+  T* Wl = L.W[grp];
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  size_t wg = blockIdx.x;
+  if (WPB == 1 && (gridDim.x & 31) == 0) wg = (wg & ~(size_t)31) + ((wg & 7) << 2) + ((wg >> 3) & 3);   // XCD-aware (qp_group16.hip.hpp)
+  static_assert(SPW == 16 || WSLDS, "fewer states per workgroup only inside the fused kernels");
+  const size_t qp_raw = TILED ? who.state : WSLDS ? (size_t)blockIdx.x * SPW + (tx >> 4) : (wg * blockDim.x + tx) >> 4;
+  bool live = TILED ? who.live : (qp_raw < N && (SPW == 16 || (int)(tx >> 4) < SPW));
+  unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
+  const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
+#define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define WSLD(comp) (WSLDS ? wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
+#define BLD(c) (WSLDS ? wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
+#define GST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
+
+#ifdef WBC_QP_STAMP
+  const long long st_t0 = __builtin_readcyclecounter();
+#endif
+  // ------------------------------------------------------------------ inputs
+  int mask = a.mask[s32] & 0xF;
+  bool on = (mask >> f) & 1;
+  const bool geom_jc = !WSLDS && a.Jc != nullptr;
+  const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
+  const T mu_f = GLD(a.mu, f);
+  WBC_QSTAMP(1);
+  idle();
+  if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
+  WBC_QSTAMP(2);
+  T d_me = 0;
+  if (geom_jc) {
+    const int comp = c3 == 0 ? (3 * f + 1) * 18 + 5 : (c3 == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4);
+    if (isvar) d_me = GLD(a.Jc, comp);
+  } else if (isvar) d_me = WSLD(WS_D + v);
+
+  // ------------------------------------------------------------------ G = alpha I + B B^T and its factor (as in qp_group16_body)
+  const T onf = on ? (T)1 : (T)0;
+  const T dqx = onf * dppx<0x00>(d_me), dqy = onf * dppx<0x55>(d_me), dqz = onf * dppx<0xAA>(d_me);   // my foot's lever arm, zero for a swing foot
+  T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
+  T alpha_l = prm.alpha, ralpha = prm.rsqrt_alpha * prm.rsqrt_alpha;
+  if constexpr (WSLDS || TILED) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(ralpha));
+  T a01, a02, a10, a12, a20, a21, b10, b20, b21;
+  T il[6];
+  {
+    T Dx[4], Dy[4], Dz[4], Of[4];
+    sfor<0, 4>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int fj = decltype(fc)::value;
+      const bool onj = (mask >> fj) & 1;
+      Of[fj] = onj ? (T)1 : (T)0;
+      Dx[fj] = onj ? gbc<3 * fj>(d_me) : (T)0; Dy[fj] = onj ? gbc<3 * fj + 1>(d_me) : (T)0; Dz[fj] = onj ? gbc<3 * fj + 2>(d_me) : (T)0;
+    });
+    const T nc = (Of[0] + Of[1]) + (Of[2] + Of[3]);
+    const T sx = (Dx[0] + Dx[1]) + (Dx[2] + Dx[3]), sy = (Dy[0] + Dy[1]) + (Dy[2] + Dy[3]), sz = (Dz[0] + Dz[1]) + (Dz[2] + Dz[3]);
+    T Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
+    sfor<0, 4>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int fj = decltype(fc)::value;
+      Pxx += Dx[fj] * Dx[fj]; Pxy += Dx[fj] * Dy[fj]; Pxz += Dx[fj] * Dz[fj];
+      Pyy += Dy[fj] * Dy[fj]; Pyz += Dy[fj] * Dz[fj]; Pzz += Dz[fj] * Dz[fj];
+    });
+    const T g00 = alpha_l + s0 * s0 * nc, g11 = alpha_l + s1 * s1 * nc, g22 = alpha_l + s2 * s2 * nc;
+    const T gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
+    const T m00 = alpha_l + (s3 * s3) * (Pyy + Pzz), m11 = alpha_l + (s4 * s4) * (Pxx + Pzz), m22 = alpha_l + (s5 * s5) * (Pxx + Pyy);
+    const T m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
+    il[0] = rsqrt_nr(g00); il[1] = rsqrt_nr(g11); il[2] = rsqrt_nr(g22);
+    a01 = gm01 * il[1]; a02 = gm02 * il[2]; a10 = gm10 * il[0]; a12 = gm12 * il[2]; a20 = gm20 * il[0]; a21 = gm21 * il[1];
+    const T c00 = m00 - a01 * a01 - a02 * a02, c11 = m11 - a10 * a10 - a12 * a12, c22 = m22 - a20 * a20 - a21 * a21;
+    const T c10 = m10 - a12 * a02, c20 = m20 - a21 * a01, c21 = m21 - a20 * a10;
+    il[3] = rsqrt_nr(c00);
+    b10 = c10 * il[3]; b20 = c20 * il[3];
+    const T t11 = c11 - b10 * b10;
+    il[4] = rsqrt_nr(t11);
+    b21 = (c21 - b20 * b10) * il[4];
+    const T t22 = c22 - b20 * b20 - b21 * b21;
+    il[5] = rsqrt_nr(t22);
+  }
+  // ------------------------------------------------------------------ my row of G^-1 (row gi = l16 mod 6): G x = e_gi by the factor
+  const int gi = l16 < 6 ? l16 : (l16 < 12 ? l16 - 6 : l16 - 12);
+  T Gr[6];
+  {
+    const T e0 = gi == 0 ? (T)1 : (T)0, e1 = gi == 1 ? (T)1 : (T)0, e2 = gi == 2 ? (T)1 : (T)0, e3 = gi == 3 ? (T)1 : (T)0, e4 = gi == 4 ? (T)1 : (T)0,
+            e5 = gi == 5 ? (T)1 : (T)0;
+    T w[6];
+    w[0] = e0 * il[0]; w[1] = e1 * il[1]; w[2] = e2 * il[2];
+    w[3] = (e3 - a01 * w[1] - a02 * w[2]) * il[3];
+    w[4] = (e4 - a10 * w[0] - a12 * w[2] - b10 * w[3]) * il[4];
+    w[5] = (e5 - a20 * w[0] - a21 * w[1] - b20 * w[3] - b21 * w[4]) * il[5];
+    Gr[5] = w[5] * il[5];
+    Gr[4] = (w[4] - b21 * Gr[5]) * il[4];
+    Gr[3] = (w[3] - b10 * Gr[4] - b20 * Gr[5]) * il[3];
+    Gr[2] = (w[2] - a02 * Gr[3] - a12 * Gr[4]) * il[2];
+    Gr[1] = (w[1] - a01 * Gr[3] - a21 * Gr[5]) * il[1];
+    Gr[0] = (w[0] - a10 * Gr[4] - a20 * Gr[5]) * il[0];
+  }
+  // y = G_A^-1 b for a row-uniform b: my component from my row, then six broadcasts from the static lanes 0..5
+  T y[6];
+  auto ginv_mul = [&](const T* bb, T& yi) __attribute__((always_inline)) {
+    yi = ((Gr[0] * bb[0] + Gr[1] * bb[1]) + (Gr[2] * bb[2] + Gr[3] * bb[3])) + (Gr[4] * bb[4] + Gr[5] * bb[5]);
+    sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; y[j] = dppx<0x150 + j>(yi); });
+  };
+  // w_k = B_k^T y for my own foot (zero for a swing foot: dq* and onf are zero there)
+  auto bt_y = [&](T& w0, T& w1, T& w2) __attribute__((always_inline)) {
+    const T m0 = s3 * y[3], m1 = s4 * y[4], m2 = s5 * y[5];
+    w0 = onf * (s0 * y[0]) + (m1 * dqz - m2 * dqy);
+    w1 = onf * (s1 * y[1]) + (m2 * dqx - m0 * dqz);
+    w2 = onf * (s2 * y[2]) + (m0 * dqy - m1 * dqx);
+  };
+
+  // ------------------------------------------------------------------ my constraints (friction pyramid, force box): as in qp_group16_body
+  T cAx, cAy, cAz, rA, cBx = 0, cBy = 0, cBz = 0;
+  const bool hasB = c3 < 2;
+  {
+    T nx = dppx<0x00>(n_ld), ny = dppx<0x55>(n_ld), nz = dppx<0xAA>(n_ld);
+    const T iln = rsqrt_nr(nx * nx + ny * ny + nz * nz);
+    nx *= iln; ny *= iln; nz *= iln;
+    const bool usex = fabs_t(nx) < (T)0.9;
+    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
+    const T rd = rx * nx + ry * ny;
+    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
+    const T it = rsqrt_nr(t1x * t1x + t1y * t1y + t1z * t1z);
+    t1x *= it; t1y *= it; t1z *= it;
+    const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    const T mt = mu_f * prm.mu_scale;
+    const T ttx = (c3 == 0) ? t1x : t2x, tty = (c3 == 0) ? t1y : t2y, ttz = (c3 == 0) ? t1z : t2z;
+    if (hasB) {
+      cAx = mt * nx - ttx; cAy = mt * ny - tty; cAz = mt * nz - ttz; rA = 0;
+      cBx = mt * nx + ttx; cBy = mt * ny + tty; cBz = mt * nz + ttz;
+    } else if (c3 == 2) { cAx = nx; cAy = ny; cAz = nz; rA = prm.fn_min; }
+    else { cAx = -nx; cAy = -ny; cAz = -nz; rA = -prm.fn_max; }
+  }
+  // per-lane state of the active set: row c3 of P_k, slot c3 of foot k (N^+ row, multiplier, constraint id), |active set of foot k|
+  T Pr0 = c3 == 0 ? (T)1 : (T)0, Pr1 = c3 == 1 ? (T)1 : (T)0, Pr2 = c3 == 2 ? (T)1 : (T)0;
+  T Np0 = 0, Np1 = 0, Np2 = 0, u_s = 0;
+  int id_s = -1, qk = 0;
+  {
+    T* c = Cl + 3 * (2 * l16);
+    c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
+    // tables addressed by the run-time foot index kp: P_k = I, lever arm d_k (zero for a swing foot)
+    if (c3 == 0) { Pl[6 * f + 0] = (T)1; Pl[6 * f + 1] = (T)0; Pl[6 * f + 2] = (T)0; Dl[3 * f + 0] = dqx; Dl[3 * f + 1] = dqy; Dl[3 * f + 2] = dqz; }
+    if (c3 == 1) { Pl[6 * f + 3] = (T)1; Pl[6 * f + 4] = (T)0; }
+    if (c3 == 2) { Pl[6 * f + 5] = (T)1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+  // ------------------------------------------------------------------ unconstrained minimum x0 = B^T G^-1 S^(1/2) b   (b = w_des - rhat_base)
+  T x_me = 0;
+  {
+    WBC_QSTAMP(3);
+    if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
+    if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
+    WBC_QSTAMP(4);
+    const T b_ld = (l16 < 6) ? BLD(l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
+    T bb[6];
+    bb[0] = s0 * dppx<0x150 + 0>(b_ld); bb[1] = s1 * dppx<0x150 + 1>(b_ld); bb[2] = s2 * dppx<0x150 + 2>(b_ld);
+    bb[3] = s3 * dppx<0x150 + 3>(b_ld); bb[4] = s4 * dppx<0x150 + 4>(b_ld); bb[5] = s5 * dppx<0x150 + 5>(b_ld);
+    T yi;
+    ginv_mul(bb, yi);
+    T w0, w1, w2;
+    bt_y(w0, w1, w2);
+    x_me = c3 == 0 ? w0 : (c3 == 1 ? w1 : w2);
+  }
+
+  // ------------------------------------------------------------------ dual active-set iterations (a8)
+  int ip = -1, status = 0, iter = 0;
+  bool done = !live;
+  bool actA = false, actB = false;
+  T sip = 0, Rnorm = 1, u_c = 0;
+
+  auto slacks = [&](T& sA, T& sB) __attribute__((always_inline)) {
+    const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
+    sA = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA;
+    sB = cBx * xq0 + cBy * xq1 + cBz * xq2;
+  };
+  auto pick = [&]() __attribute__((always_inline)) {
+    T sA, sB;
+    slacks(sA, sB);
+    T val = KeyT<T>::BIG;
+    int id = 2 * l16;
+    if (on && !actA && sA < -prm.qp_tol) { val = sA; }
+    if (on && hasB && !actB && sB < -prm.qp_tol && sB < val) { val = sB; id = 2 * l16 + 1; }
+    const bool found = gargmin(val, id);
+    const bool need = !done && ip < 0;
+    if (need) {
+      if (found) { ip = id; sip = val; u_c = 0; }
+      else done = true;
+    }
+  };
+  // closed forms for <= 2 active normals n0 (, n1): my row of P, my slot's row of N^+
+  auto rebuild = [&](int q, T n00, T n01, T n02, T n10, T n11, T n12) __attribute__((always_inline)) {
+    const T i1 = rcp_nr(q >= 1 ? (n00 * n00 + n01 * n01 + n02 * n02) : (T)1);
+    const T wx = n01 * n12 - n02 * n11, wy = n02 * n10 - n00 * n12, wz = n00 * n11 - n01 * n10;    // n0 x n1
+    const T i2 = rcp_nr(q >= 2 ? (wx * wx + wy * wy + wz * wz) : (T)1);
+    const T ec0 = c3 == 0 ? (T)1 : (T)0, ec1 = c3 == 1 ? (T)1 : (T)0, ec2 = c3 == 2 ? (T)1 : (T)0;
+    const T n0c = c3 == 0 ? n00 : (c3 == 1 ? n01 : n02), wc = c3 == 0 ? wx : (c3 == 1 ? wy : wz);
+    // q = 0: I;  q = 1: I - n0 n0^T / |n0|^2;  q = 2: w w^T / |w|^2
+    if (q == 0) { Pr0 = ec0; Pr1 = ec1; Pr2 = ec2; Np0 = 0; Np1 = 0; Np2 = 0; }
+    else if (q == 1) {
+      const T g = n0c * i1;
+      Pr0 = ec0 - g * n00; Pr1 = ec1 - g * n01; Pr2 = ec2 - g * n02;
+      const T k0 = c3 == 0 ? i1 : (T)0;
+      Np0 = n00 * k0; Np1 = n01 * k0; Np2 = n02 * k0;
+    } else {
+      const T g = wc * i2;
+      Pr0 = g * wx; Pr1 = g * wy; Pr2 = g * wz;
+      // rows: (n1 x w) / |w|^2 and (w x n0) / |w|^2
+      const T r0x = n11 * wz - n12 * wy, r0y = n12 * wx - n10 * wz, r0z = n10 * wy - n11 * wx;
+      const T r1x = wy * n02 - wz * n01, r1y = wz * n00 - wx * n02, r1z = wx * n01 - wy * n00;
+      const T k0 = c3 == 0 ? i2 : (T)0, k1 = c3 == 1 ? i2 : (T)0;
+      Np0 = r0x * k0 + r1x * k1; Np1 = r0y * k0 + r1y * k1; Np2 = r0z * k0 + r1z * k1;
+    }
+  };
+  auto write_P_row = [&](bool doit) __attribute__((always_inline)) {   // my part of foot f's P in the LDS table (xx xy xz | yy yz | zz)
+    if (doit && c3 == 0) { Pl[6 * f + 0] = Pr0; Pl[6 * f + 1] = Pr1; Pl[6 * f + 2] = Pr2; }
+    if (doit && c3 == 1) { Pl[6 * f + 3] = Pr1; Pl[6 * f + 4] = Pr2; }
+    if (doit && c3 == 2) { Pl[6 * f + 5] = Pr2; }
+  };
+
+#ifdef WBC_QP_STAMP
+  const long long st_t1 = __builtin_readcyclecounter();
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_last = st_t1;
+#define SEG(i) do { const long long now_ = __builtin_readcyclecounter(); seg[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define SEG(i) do {} while (0)
+#endif
+  pick();
+  int guard = 0;
+  while (__ballot(!done && ip >= 0) != 0ull) {
+    if (++guard > 4 * prm.max_iter + 8) break;
+    bool go = !done && ip >= 0;
+    if (go && ++iter > prm.max_iter) { status = 1; done = true; go = false; }
+    const int ipc = ip < 0 ? 0 : ip;
+    const int lp = (ipc >> 1) & 15, kp = lp >> 2;
+    // ---- candidate normal, P and lever arm of its foot (LDS, run-time indices); v, b formed by every lane
+    const T np0 = Cl[3 * ipc], np1 = Cl[3 * ipc + 1], np2 = Cl[3 * ipc + 2];
+    const T pxx = Pl[6 * kp], pxy = Pl[6 * kp + 1], pxz = Pl[6 * kp + 2], pyy = Pl[6 * kp + 3], pyz = Pl[6 * kp + 4], pzz = Pl[6 * kp + 5];
+    const T dkx = Dl[3 * kp], dky = Dl[3 * kp + 1], dkz = Dl[3 * kp + 2];
+    const T v0 = pxx * np0 + pxy * np1 + pxz * np2, v1 = pxy * np0 + pyy * np1 + pyz * np2, v2 = pxz * np0 + pyz * np1 + pzz * np2;
+    const T vv = v0 * v0 + v1 * v1 + v2 * v2;
+    T bb[6];
+    bb[0] = s0 * v0; bb[1] = s1 * v1; bb[2] = s2 * v2;
+    bb[3] = s3 * (dky * v2 - dkz * v1); bb[4] = s4 * (dkz * v0 - dkx * v2); bb[5] = s5 * (dkx * v1 - dky * v0);
+    SEG(0);
+    T yi;
+    ginv_mul(bb, yi);
+    const T by = ((bb[0] * y[0] + bb[1] * y[1]) + (bb[2] * y[2] + bb[3] * y[3])) + (bb[4] * y[4] + bb[5] * y[5]);
+    const T znA = vv - by;                 // alpha (z . n+)
+    const T zn = znA * ralpha;
+    SEG(1);
+    // ---- step directions of my variable and my slot
+    T w0, w1, w2;
+    bt_y(w0, w1, w2);
+    const bool mine = f == kp;
+    const T vc = c3 == 0 ? v0 : (c3 == 1 ? v1 : v2);
+    const T z_me = ((mine ? vc : (T)0) - (Pr0 * w0 + Pr1 * w1 + Pr2 * w2)) * ralpha;
+    const T a_s = Np0 * np0 + Np1 * np1 + Np2 * np2;               // my slot's coefficient of n+ (foot kp only)
+    const T r_me = (mine ? a_s : (T)0) - (Np0 * w0 + Np1 * w1 + Np2 * w2);
+    const bool slot_act = isvar && c3 < qk;
+    SEG(2);
+    // ---- step lengths
+    T t1 = INF;
+    int kmin = l16;
+    {
+      T t1k = KeyT<T>::BIG;
+      if (slot_act && r_me > 0) t1k = u_s * rcp_nr(r_me);
+      const bool found = gargmin(t1k, kmin);
+      if (found) t1 = t1k;
+    }
+    T t2 = INF, rz = 0;
+    if (zn > (EPS * Rnorm) * (EPS * Rnorm)) { rz = rcp_nr(zn); t2 = -sip * rz; }
+    if (go && !(t1 < INF) && !(t2 < INF)) { status = 2; done = true; go = false; }
+    const bool dual_only = !(t2 < INF);
+    const bool full = !dual_only && !(t1 < t2);
+    const T t = full ? t2 : t1;
+    if (go) {
+      if (!dual_only) x_me += t * z_me;
+      if (slot_act) u_s -= t * r_me;
+      u_c += t;
+    }
+    SEG(3);
+    // ---- full step: the candidate joins the active set of its foot
+    const bool addg = go && full;
+    {
+      const T g = rz * ralpha;                                   // 1 / (alpha z . n+)
+      const T gy = addg ? yi * g : (T)0;
+      sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] += gy * y[j]; });
+      const T ivv = rcp_nr(vv > 0 ? vv : (T)1);
+      const T e0 = v0 * ivv, e1 = v1 * ivv, e2 = v2 * ivv;       // v / |v|^2: the new row of N^+
+      const bool upd = addg && mine;
+      if (upd) {
+        if (slot_act) { Np0 -= a_s * e0; Np1 -= a_s * e1; Np2 -= a_s * e2; }
+        if (isvar && c3 == qk) { Np0 = e0; Np1 = e1; Np2 = e2; u_s = u_c; id_s = ipc; }
+        Pr0 -= vc * e0; Pr1 -= vc * e1; Pr2 -= vc * e2;
+        ++qk;
+      }
+      write_P_row(upd);
+      if (addg) {
+        const T nr = zn * rsqrt_nr(zn);                          // |d2| of the dense method: the new diagonal entry of R
+        Rnorm = (nr > Rnorm) ? nr : Rnorm;
+        if (l16 == lp) { if (ipc & 1) actB = true; else actA = true; }
+        ip = -1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the P table is read by every lane of the row at the next candidate
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+    pick();
+    SEG(4);
+    // ---- partial / dual-only step: the blocking constraint leaves its foot's active set
+    const bool dropg = go && !full;
+    if (__ballot(dropg) != 0ull) {
+      const int kq = dropg ? kmin : 0;                 // lane (within the row) of the blocking slot
+      const int kd = kq >> 2, sd = kq & 3;             // its foot and slot
+      const int cid = gread(id_s, kq, rowbase);        // the constraint that leaves
+      if (dropg && l16 == ((cid >> 1) & 15)) { if (cid & 1) actB = false; else actA = false; }
+      const bool inq = dropg && f == kd;
+      const T Po0 = Pr0, Po1 = Pr1, Po2 = Pr2;
+      {  // close the hole in the slot list of foot kd
+        const T un = dppx<0xF9>(u_s);                  // quad_perm [1,2,3,3]: the next slot's values
+        const int idn = dppx<0xF9>(id_s);
+        if (inq && c3 >= sd && c3 < qk - 1) { u_s = un; id_s = idn; }
+        if (inq && c3 == qk - 1) { u_s = 0; id_s = -1; }
+        if (inq) --qk;
+      }
+      // remaining normals of foot kd (ids of slots 0, 1 after the shift) and the one that left
+      const int id0 = dppx<0x00>(id_s), id1 = dppx<0x55>(id_s);
+      const int i0 = (inq && qk >= 1) ? id0 : 0, i1 = (inq && qk >= 2) ? id1 : 0;
+      const T n00 = Cl[3 * i0], n01 = Cl[3 * i0 + 1], n02 = Cl[3 * i0 + 2];
+      const T n10 = Cl[3 * i1], n11 = Cl[3 * i1 + 1], n12 = Cl[3 * i1 + 2];
+      if (inq) rebuild(qk, n00, n01, n02, n10, n11, n12);
+      write_P_row(inq);
+      // what: the direction P_k gained, what what^T = P_k(new) - P_k(old): row c3 of that difference is what_c what; the lane of
+      // foot kd with the largest |what_c| normalises its row and publishes what through LDS
+      {
+        const T D0 = Pr0 - Po0, D1 = Pr1 - Po1, D2 = Pr2 - Po2;
+        const T dcc = c3 == 0 ? D0 : (c3 == 1 ? D1 : D2);                 // what_c^2
+        T key = (inq && isvar) ? -dcc : KeyT<T>::BIG;
+        int who_ = l16;
+        gargmin(key, who_);
+        if (inq && l16 == who_) {
+          const T sc = rsqrt_nr(dcc > 0 ? dcc : (T)1);
+          Wl[0] = D0 * sc; Wl[1] = D1 * sc; Wl[2] = D2 * sc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        // (rows that do not drop read whatever the scratch holds: zeroed, so that their G_A^-1 sees an update by exactly nothing)
+        const T h0 = dropg ? Wl[0] : (T)0, h1 = dropg ? Wl[1] : (T)0, h2 = dropg ? Wl[2] : (T)0;
+        const int kdc = dropg ? kd : 0;
+        const T ex = Dl[3 * kdc], ey = Dl[3 * kdc + 1], ez = Dl[3 * kdc + 2];
+        T bh[6];
+        bh[0] = s0 * h0; bh[1] = s1 * h1; bh[2] = s2 * h2;
+        bh[3] = s3 * (ey * h2 - ez * h1); bh[4] = s4 * (ez * h0 - ex * h2); bh[5] = s5 * (ex * h1 - ey * h0);
+        T ygi;
+        ginv_mul(bh, ygi);                                                // y = G_A^-1 bh (overwrites y: the step is over)
+        const T den = (T)1 + (((bh[0] * y[0] + bh[1] * y[1]) + (bh[2] * y[2] + bh[3] * y[3])) + (bh[4] * y[4] + bh[5] * y[5]));
+        const T gd = dropg ? ygi * rcp_nr(den) : (T)0;
+        sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] -= gd * y[j]; });
+      }
+      {  // a partial step moved x: refresh the candidate's slack (cross-lane ops stay unconditional)
+        T sA, sB;
+        slacks(sA, sB);
+        const T sv = gread((ipc & 1) ? sB : sA, lp, rowbase);
+        if (dropg && !dual_only) sip = sv;
+      }
+    }
+    SEG(5);
+  }
+
+  // ------------------------------------------------------------------ outputs: f, tau (a9), status
+  WBC_QSTAMP(5);
+  WBC_QSTAMP3(10);
+  if constexpr (WSLDS) { if (sync) qp_wait(sync->fin, sync->need_fin); }
+  WBC_QSTAMP(6);
+  if (live) {
+    T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;
+    int jm = 0;
+    sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
+    if (isvar) {
+      taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
+      if (geom_jc) {
+        jl0 = GLD(a.Jc, (3 * f + 0) * 18 + 6 + jm); jl1 = GLD(a.Jc, (3 * f + 1) * 18 + 6 + jm); jl2 = GLD(a.Jc, (3 * f + 2) * 18 + 6 + jm);
+      } else {
+        jl0 = WSLD(WS_JCL + 9 * f + 0 + c3); jl1 = WSLD(WS_JCL + 9 * f + 3 + c3); jl2 = WSLD(WS_JCL + 9 * f + 6 + c3);
+      }
+    }
+    const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
+    if (isvar) {
+      GST(a.f, v, on ? x_me : (T)0);
+      const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
+      GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+    }
+    if (l16 == 0) {
+      a.status[s32] = status;
+#ifdef WBC_QP_STAMP
+      {
+        const long long vals[8] = {st_t1 - st_t0, seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], seg[6]};
+        long long lo = vals[0], hi = vals[1];
+        if (grp == 1) { lo = vals[2]; hi = vals[3]; } else if (grp == 2) { lo = vals[4]; hi = vals[5]; } else if (grp == 3) { lo = vals[6]; hi = vals[7]; }
+        lo >>= 4; hi >>= 4;
+        if (lo > 0xFFFF) lo = 0xFFFF;
+        if (hi > 0x7FFF) hi = 0x7FFF;
+        if (a.iters) a.iters[s32] = (int)(lo | (hi << 16));
+      }
+#else
+      if (a.iters) a.iters[s32] = iter;
+#endif
+    }
+  }
+  WBC_QSTAMP(11);
+#undef SEG
+#undef GST
+#undef WSLD
+#undef BLD
+#undef GLD
+}
+
+// the QP body of a scalar type: the structured form for fp64, the orthogonal-factor form for fp32 (WBC_QP_STRUCT = 0: always the latter)
+#ifndef WBC_QP_STRUCT
+#define WBC_QP_STRUCT 1
+#endif
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
+WBC_DEV void qp_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
+                     const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
+  if constexpr (WBC_QP_STRUCT && std::is_same<T, double>::value) qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
+  else qp_group16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
+}
+
+}  // namespace wbc

@@ -47,6 +47,8 @@ struct DeviceGuard {
 struct wbc_model { FlatModel fm; };
 
 constexpr size_t TIMING_MAX_SPANS = 4096;   // bounded ring: samples beyond it are dropped until the next collect
+constexpr int ONE_SCRATCH = 200;        // first scalar of the helpers' scratch region of the single-robot image (88 scalars)
+constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints (the tick uses the first 161)
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -348,8 +350,10 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (e == hipSuccess) e = hipMalloc(&s->d_ws, (size_t)WS_LDS_WORDS * max_batch * ts);
   if (e == hipSuccess) e = hipMalloc((void**)&s->d_todo, (max_batch + 4) * sizeof(int));
   if (e == hipSuccess) e = hipMemset(s->d_todo, 0, 4 * sizeof(int));
-  // N = 1 scratch: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (doubles) + mask,status ints
-  s->one_bytes = 200 * sizeof(double) + 4 * sizeof(int);
+  // N = 1 image: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (scalars; 161 of ONE_TICK_SCALARS), a scratch region for
+  // the start-up / planner helpers (wbc_observer_init, wbc_compute_reference: they must not touch what a caller keeps in the
+  // image between ticks, wbc_one_map), then the ints mask | status | iters | completion ticket
+  s->one_bytes = ONE_SCALARS * sizeof(double) + 4 * sizeof(int);
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&s->h_one, s->one_bytes, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(&s->h_one_dev, s->h_one, 0);
@@ -845,8 +849,8 @@ static int one_tick_on_image(wbc_solver* s) {
   const int zcm = s->opt.one_zerocopy;
   const bool zc = zcm != 0;
   unsigned char* d = (unsigned char*)(zc ? s->h_one_dev : s->d_one);
-  int* dints = (int*)(d + 200 * sizeof(double));
-  int* hints = (int*)(hb + 200 * sizeof(double));
+  int* dints = (int*)(d + ONE_SCALARS * sizeof(double));
+  int* hints = (int*)(hb + ONE_SCALARS * sizeof(double));
   if (!zc) HIP_TRY(hipMemcpyAsync(d, hb, s->one_bytes, hipMemcpyHostToDevice, nullptr));
   wbc_batch_in in;
   in.q = d + off[0] * ts; in.v = d + off[1] * ts; in.w_des = d + off[2] * ts; in.vdot_des = d + off[3] * ts;
@@ -892,7 +896,7 @@ extern "C" int wbc_compute_torques(wbc_solver* s, const double* q, const double*
   // one asynchronous copy each way around the launch and one synchronisation (was four blocking copies from pageable memory)
   const int* off = ONE_OFF;
   unsigned char* hb = (unsigned char*)s->h_one;
-  int* hints = (int*)(hb + 200 * sizeof(double));
+  int* hints = (int*)(hb + ONE_SCALARS * sizeof(double));
   auto put = [&](int o, const double* src, int n) {
     for (int i = 0; i < n; ++i) {
       if (s->dtype == WBC_F64) ((double*)hb)[o + i] = src ? src[i] : 0.0;
@@ -922,7 +926,7 @@ extern "C" int wbc_one_map(wbc_solver* s, wbc_one_image* img) {
   if (!s || !img) return fail(WBC_E_INVALID, "null argument");
   if (s->dtype != WBC_F64) return fail(WBC_E_INVALID, "wbc_one_map: fp64 solvers only (the image holds the solver's scalar type)");
   double* hb = (double*)s->h_one;
-  int* hints = (int*)((unsigned char*)s->h_one + 200 * sizeof(double));
+  int* hints = (int*)((unsigned char*)s->h_one + ONE_SCALARS * sizeof(double));
   const int* off = ONE_OFF;
   img->q = hb + off[0]; img->v = hb + off[1]; img->w_des = hb + off[2]; img->vdot_des = hb + off[3]; img->normals = hb + off[4];
   img->mu = hb + off[5]; img->tau_prev = hb + off[6]; img->f_prev = hb + off[7]; img->obs_integ = hb + off[8]; img->obs_r = hb + off[9];
@@ -943,21 +947,22 @@ extern "C" int wbc_observer_init(wbc_solver* s, const double* q, const double* v
   if (!s || !q || !v || !obs_integ || !obs_r) return fail(WBC_E_INVALID, "null argument");
   ON_DEVICE(s);
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
-  unsigned char* hb = (unsigned char*)s->h_one;   // pinned staging: q at word 0, v at 19, p = M v at 37
-  for (int i = 0; i < 19; ++i) { if (s->dtype == WBC_F64) ((double*)hb)[i] = q[i]; else ((float*)hb)[i] = (float)q[i]; }
-  for (int i = 0; i < 18; ++i) { if (s->dtype == WBC_F64) ((double*)hb)[19 + i] = v[i]; else ((float*)hb)[19 + i] = (float)v[i]; }
+  const int o = ONE_SCRATCH;   // scratch region of the pinned image (q at +0, v at +19, p = M v at +37): the tick's part stays as the caller left it
+  unsigned char* hb = (unsigned char*)s->h_one;
+  for (int i = 0; i < 19; ++i) { if (s->dtype == WBC_F64) ((double*)hb)[o + i] = q[i]; else ((float*)hb)[o + i] = (float)q[i]; }
+  for (int i = 0; i < 18; ++i) { if (s->dtype == WBC_F64) ((double*)hb)[o + 19 + i] = v[i]; else ((float*)hb)[o + 19 + i] = (float)v[i]; }
   unsigned char* d = (unsigned char*)s->d_one;
-  HIP_TRY(hipMemcpyAsync(d, hb, 37 * ts, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(d + o * ts, hb + o * ts, 37 * ts, hipMemcpyHostToDevice, nullptr));
   const unsigned long long calls0 = s->calls;   // start-up helper, not a tick: the every-k-th-tick sampling phase stays as it is
   const bool timing0 = s->timing;
   s->timing = false;
-  int rc = wbc_dynamics_batch(s, 1, d, d + 19 * ts, nullptr, nullptr, nullptr, nullptr, d + 37 * ts, nullptr, nullptr);
+  int rc = wbc_dynamics_batch(s, 1, d + o * ts, d + (o + 19) * ts, nullptr, nullptr, nullptr, nullptr, d + (o + 37) * ts, nullptr, nullptr);
   s->timing = timing0; s->calls = calls0;
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(hb + 37 * ts, d + 37 * ts, 18 * ts, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipMemcpyAsync(hb + (o + 37) * ts, d + (o + 37) * ts, 18 * ts, hipMemcpyDeviceToHost, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   for (int i = 0; i < 18; ++i) {
-    obs_integ[i] = s->dtype == WBC_F64 ? ((double*)hb)[37 + i] : (double)((float*)hb)[37 + i];
+    obs_integ[i] = s->dtype == WBC_F64 ? ((double*)hb)[o + 37 + i] : (double)((float*)hb)[o + 37 + i];
     obs_r[i] = 0.0;
   }
   return WBC_OK;
@@ -969,7 +974,8 @@ extern "C" int wbc_compute_reference(wbc_solver* s, const double* q, const doubl
   if (!s->d_ref) return fail(WBC_E_INVALID, "call wbc_solver_set_ref_params first");
   ON_DEVICE(s);
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
-  const int off[] = {0, 19, 37, 49, 55, 73, 79};  // q v plan | w_des vdot_des com end
+  const int o0 = ONE_SCRATCH;   // scratch region of the pinned image: the tick's part stays as the caller left it
+  const int off[] = {o0 + 0, o0 + 19, o0 + 37, o0 + 49, o0 + 55, o0 + 73, o0 + 79};  // q v plan | w_des vdot_des com end
   unsigned char* hb = (unsigned char*)s->h_one;   // pinned staging, one copy each way
   auto put = [&](int o, const double* src, int n) {
     for (int i = 0; i < n; ++i) {
@@ -979,11 +985,11 @@ extern "C" int wbc_compute_reference(wbc_solver* s, const double* q, const doubl
   };
   put(off[0], q, 19); put(off[1], v, 18); put(off[2], plan, PLAN_WORDS);
   unsigned char* d = (unsigned char*)s->d_one;
-  HIP_TRY(hipMemcpyAsync(d, hb, 49 * ts, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(d + o0 * ts, hb + o0 * ts, 49 * ts, hipMemcpyHostToDevice, nullptr));
   int rc = wbc_reference_batch(s, 1, d + off[0] * ts, d + off[1] * ts, d + off[2] * ts, t, d + off[3] * ts, d + off[4] * ts,
                                d + off[5] * ts, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(hb + 49 * ts, d + 49 * ts, 30 * ts, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipMemcpyAsync(hb + (o0 + 49) * ts, d + (o0 + 49) * ts, 30 * ts, hipMemcpyDeviceToHost, nullptr));
   HIP_TRY(hipStreamSynchronize(nullptr));
   auto get = [&](int o, double* dst, int n) {
     if (!dst) return;
