@@ -104,6 +104,19 @@ def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min
     return times
 
 
+def long_blocks_of(step, k0, dist, torch, np, min_block_s=5e-3):
+    """timed_blocks with a block length that is raised until the median block lasts at least min_block_s (a first estimate of the
+    step time taken right after set-up can be off by an order of magnitude: module load, clocks)"""
+    k = max(1, int(k0))
+    for _ in range(4):
+        bl = timed_blocks(step, k, dist, torch)
+        el = float(np.median(bl))
+        if el >= min_block_s:
+            break
+        k = int(np.ceil(k * min_block_s / max(el, 1e-7) * 1.15))
+    return k, bl, el
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,9 +220,7 @@ def main():
     if dist is not None:
         # N > 1: the driver's K may be 20 ticks = 0.4 ms per block, where one late rank moves the maximum by several per cent.
         # The same ticks again in blocks of >= 5 ms (same bracketing, same max over ranks), reported BESIDE `value`.
-        k_long = max(args.steps, int(np.ceil(5e-3 / max(elapsed / args.steps, 1e-7))))
-        lb = timed_blocks(step, k_long, dist, torch)
-        el_long = float(np.median(lb))
+        k_long, lb, el_long = long_blocks_of(step, max(args.steps, int(np.ceil(5e-3 / max(elapsed / args.steps, 1e-7)))), dist, torch, np)
         long_blocks = {"value": k_long * n * world / el_long, "ms_per_step": el_long / k_long * 1e3, "steps_per_block": k_long,
                        "blocks": len(lb), "block_ms_median": el_long * 1e3,
                        "note": "blocks of >= 5 ms so that rank skew at the barriers is < 1 % of a block; `value` keeps the contract's K"}
@@ -424,9 +435,7 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
         for _ in range(20):
             step()
         torch.cuda.synchronize()
-        k3 = max(20, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 20, 1e-7))))
-        bl = timed_blocks(step, k3, dist, torch)
-        el = float(np.median(bl))
+        k3, bl, el = long_blocks_of(step, max(20, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 20, 1e-7)))), dist, torch, np)
         el_g, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, k3, torch.cuda.synchronize)
         ok = float((out["status"] == 0).double().mean().item())
         res["scale_config3"] = {
@@ -450,9 +459,7 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
             for _ in range(3):
                 r5["one_rollout"]()
             torch.cuda.synchronize()
-            k5 = max(3, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 3, 1e-7))))
-            bl = timed_blocks(r5["one_rollout"], k5, dist, torch)
-            el = float(np.median(bl))
+            k5, bl, el = long_blocks_of(r5["one_rollout"], max(3, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 3, 1e-7)))), dist, torch, np)
             res.setdefault("scale_config5", {})[name] = {
                 "workload": "configs[4]: horizon=%d x %d rollouts per GPU x %d GPUs, trot masks, observer on, pushes, fp64, rank-local for all ticks"
                             % (args.horizon, n5, world),

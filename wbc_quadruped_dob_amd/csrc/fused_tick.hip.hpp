@@ -56,8 +56,18 @@ constexpr int FUSED_OBS_WAVES = 2;
 // rhat follows from the observer role (`oready`,
 // first needed for g = -A^T S b) and tau_partial + the own-leg Jacobian blocks when the force recursions are done
 // (`ready`, first needed in the torque map).  Observer off, N = 4 096: 25.5 -> 22.5 us per tick.
+// Observer off, M/h/Jc wanted: the rnea role is TWO wavefronts (a seventh wavefront; with the observer on the CU's eight slots
+// are taken).  Wave 4 runs the ONE merged force recursion RNEA(q, v, vdot_des) -- tau_partial, all the QP's torque map waits
+// for -- and wave 6 the bias-force recursion whose only consumer is the caller's h buffer.  One wavefront doing both chains
+// (round 2) kept the QP wavefronts waiting for tau_partial until +9.1 us.
+#ifndef WBC_FUSED_SPLIT_H
+#define WBC_FUSED_SPLIT_H 0
+#endif
+// (fp64 only: the fp32 tick fits two six-wavefront workgroups on a CU -- 147 VGPRs, 49 kB LDS -- and a seventh wavefront would end that)
+template <class T, bool OBSERVER, bool MATS> constexpr bool fused_split_h() { return WBC_FUSED_SPLIT_H && !OBSERVER && MATS && sizeof(T) == 8; }
+template <class T, bool OBSERVER, bool MATS> constexpr int fused_threads() { return OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : (fused_split_h<T, OBSERVER, MATS>() ? 448 : 384); }
 template <class T, bool OBSERVER, bool MATS>
-__global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+__global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
   // barrier from inside their bodies (EXT = 2), so table staging and state loads share a memory round trip.
   if (wave == 4) {
     int* const gflag = &gready;
-    rnea_step_body<T, (MATS ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [=] __device__() {
+    rnea_step_body<T, ((MATS && !fused_split_h<T, OBSERVER, MATS>()) ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [=] __device__() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       FSTAMP(7);
@@ -89,6 +99,8 @@ __global__ __launch_bounds__(OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : 384, 1) voi
     if constexpr (MATS) mass_jac_body<T, 64, 2, 16, !WBC_FUSED_ZEROS_BY_QP>(model, a, cst, zidx_s);
     else __syncthreads();
     FSTAMP(9);
+  } else if (fused_split_h<T, OBSERVER, MATS>() && wave == 6) {
+    if constexpr (fused_split_h<T, OBSERVER, MATS>()) rnea_step_body<T, RS_H, 64, 2>(model, prm, a, cst, wsl);   // bias forces h -> HBM only
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
       if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 2, 1>(model, prm, a, cst, wsl);   // base rows

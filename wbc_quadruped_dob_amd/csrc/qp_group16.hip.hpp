@@ -67,14 +67,16 @@ template <> struct KeyT<double> {
   static WBC_DEV double pack(double v, int id) { return __longlong_as_double((__double_as_longlong(v) & ~63ll) | (long long)id); }
   static WBC_DEV int id(double k) { return (int)(__double_as_longlong(k) & 63ll); }
   static WBC_DEV double val(double k) { return __longlong_as_double(__double_as_longlong(k) & ~63ll); }
-  static WBC_DEV double mn(double a, double b) { return fmin(a, b); }
+  // (v_min_f64 itself: fmin() makes the compiler canonicalise both operands first -- two v_max_f64 per step of the reduction,
+  // eight dependent instructions per row argmin -- because it cannot know that the DPP-moved bit patterns are ordinary numbers)
+  static WBC_DEV double mn(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 };
 template <> struct KeyT<float> {
   static constexpr float BIG = 1e30f;
   static WBC_DEV float pack(float v, int id) { return __int_as_float((__float_as_int(v) & ~63) | id); }
   static WBC_DEV int id(float k) { return __float_as_int(k) & 63; }
   static WBC_DEV float val(float k) { return __int_as_float(__float_as_int(k) & ~63); }
-  static WBC_DEV float mn(float a, float b) { return fminf(a, b); }
+  static WBC_DEV float mn(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 };
 // in: v (BIG = none), id in [0,64).  out: row-uniform winner id in `id`, its value (low 6 mantissa bits cleared:
 // relative error < 2^-46 in f64, 2^-17 in f32) in `v`; returns whether any lane had a candidate

@@ -36,7 +36,7 @@
 namespace wbc {
 
 // per wave: four QPs x {32 constraint normals, P of the four feet (xx xy xz yy yz zz), lever arms of the four feet, scratch what}
-template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 6]; T D[4][4 * 3]; T W[4][4]; };
+template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 16]; T D[4][4 * 3]; T W[4][4]; };   // P: row c of foot k at 16 k + 4 c (row 3: the spare lane's dummy)
 
 template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
 WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
@@ -193,9 +193,8 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
     T* c = Cl + 3 * (2 * l16);
     c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
     // tables addressed by the run-time foot index kp: P_k = I, lever arm d_k (zero for a swing foot)
-    if (c3 == 0) { Pl[6 * f + 0] = (T)1; Pl[6 * f + 1] = (T)0; Pl[6 * f + 2] = (T)0; Dl[3 * f + 0] = dqx; Dl[3 * f + 1] = dqy; Dl[3 * f + 2] = dqz; }
-    if (c3 == 1) { Pl[6 * f + 3] = (T)1; Pl[6 * f + 4] = (T)0; }
-    if (c3 == 2) { Pl[6 * f + 5] = (T)1; }
+    { T* pr = Pl + 16 * f + 4 * c3; pr[0] = Pr0; pr[1] = Pr1; pr[2] = Pr2; }
+    if (isvar) Dl[3 * f + c3] = c3 == 0 ? dqx : (c3 == 1 ? dqy : dqz);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -219,38 +218,35 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
   }
 
   // ------------------------------------------------------------------ dual active-set iterations (a8)
+  // What a lone wavefront pays (tools/issue_probe.hip on MI355X): 13.5 cycles per DEPENDENT fp64 operation, ~5.5 per independent one,
+  // ~45 cycles per divergent `if` region (saveexec / branch / restore), 35 per step of a row argmin, 135 per LDS round trip.  So the
+  // loop below is written as ONE basic block of selects (no `if` with side effects outside the rare drop path), the two
+  // independent chains of a trip sit side by side -- the ratio test over the active multipliers, and the full step with the
+  // search for the NEXT candidate at its end point, which is speculative: it is used when the step turns out to be full
+  // (almost always) -- and per-row decisions are committed by selects at the end.
   int ip = -1, status = 0, iter = 0;
   bool done = !live;
   bool actA = false, actB = false;
-  T sip = 0, Rnorm = 1, u_c = 0;
+  T sip = 0, Rn2 = 1, u_c = 0;   // Rn2 = max(1, largest z . n+ of an added constraint) = Rnorm^2 of the dense method (its new R diagonal is |d2|)
+  const T ntol = -prm.qp_tol;
 
-  auto slacks = [&](T& sA, T& sB) __attribute__((always_inline)) {
-    const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
-    sA = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA;
-    sB = cBx * xq0 + cBy * xq1 + cBz * xq2;
+  // most violated inactive constraint of the row at the point whose foot components are (xq0, xq1, xq2) in my quad
+  auto most_violated = [&](T xq0, T xq1, T xq2, bool aA, bool aB, T& val, int& id) __attribute__((always_inline)) -> bool {
+    const T sA = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA;
+    const T sB = cBx * xq0 + cBy * xq1 + cBz * xq2;
+    const bool vA = on && !aA && sA < ntol;
+    const bool vB = on && hasB && !aB && sB < ntol && (!vA || sB < sA);
+    val = vB ? sB : (vA ? sA : KeyT<T>::BIG);
+    id = 2 * l16 + (vB ? 1 : 0);
+    return gargmin(val, id);
   };
-  auto pick = [&]() __attribute__((always_inline)) {
-    T sA, sB;
-    slacks(sA, sB);
-    T val = KeyT<T>::BIG;
-    int id = 2 * l16;
-    if (on && !actA && sA < -prm.qp_tol) { val = sA; }
-    if (on && hasB && !actB && sB < -prm.qp_tol && sB < val) { val = sB; id = 2 * l16 + 1; }
-    const bool found = gargmin(val, id);
-    const bool need = !done && ip < 0;
-    if (need) {
-      if (found) { ip = id; sip = val; u_c = 0; }
-      else done = true;
-    }
-  };
-  // closed forms for <= 2 active normals n0 (, n1): my row of P, my slot's row of N^+
+  // closed forms for <= 2 active normals n0 (, n1): my row of P, my slot's row of N^+   (drop path only)
   auto rebuild = [&](int q, T n00, T n01, T n02, T n10, T n11, T n12) __attribute__((always_inline)) {
     const T i1 = rcp_nr(q >= 1 ? (n00 * n00 + n01 * n01 + n02 * n02) : (T)1);
     const T wx = n01 * n12 - n02 * n11, wy = n02 * n10 - n00 * n12, wz = n00 * n11 - n01 * n10;    // n0 x n1
     const T i2 = rcp_nr(q >= 2 ? (wx * wx + wy * wy + wz * wz) : (T)1);
     const T ec0 = c3 == 0 ? (T)1 : (T)0, ec1 = c3 == 1 ? (T)1 : (T)0, ec2 = c3 == 2 ? (T)1 : (T)0;
     const T n0c = c3 == 0 ? n00 : (c3 == 1 ? n01 : n02), wc = c3 == 0 ? wx : (c3 == 1 ? wy : wz);
-    // q = 0: I;  q = 1: I - n0 n0^T / |n0|^2;  q = 2: w w^T / |w|^2
     if (q == 0) { Pr0 = ec0; Pr1 = ec1; Pr2 = ec2; Np0 = 0; Np1 = 0; Np2 = 0; }
     else if (q == 1) {
       const T g = n0c * i1;
@@ -260,18 +256,13 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
     } else {
       const T g = wc * i2;
       Pr0 = g * wx; Pr1 = g * wy; Pr2 = g * wz;
-      // rows: (n1 x w) / |w|^2 and (w x n0) / |w|^2
-      const T r0x = n11 * wz - n12 * wy, r0y = n12 * wx - n10 * wz, r0z = n10 * wy - n11 * wx;
-      const T r1x = wy * n02 - wz * n01, r1y = wz * n00 - wx * n02, r1z = wx * n01 - wy * n00;
+      const T r0x = n11 * wz - n12 * wy, r0y = n12 * wx - n10 * wz, r0z = n10 * wy - n11 * wx;   // (n1 x w) / |w|^2
+      const T r1x = wy * n02 - wz * n01, r1y = wz * n00 - wx * n02, r1z = wx * n01 - wy * n00;   // (w x n0) / |w|^2
       const T k0 = c3 == 0 ? i2 : (T)0, k1 = c3 == 1 ? i2 : (T)0;
       Np0 = r0x * k0 + r1x * k1; Np1 = r0y * k0 + r1y * k1; Np2 = r0z * k0 + r1z * k1;
     }
   };
-  auto write_P_row = [&](bool doit) __attribute__((always_inline)) {   // my part of foot f's P in the LDS table (xx xy xz | yy yz | zz)
-    if (doit && c3 == 0) { Pl[6 * f + 0] = Pr0; Pl[6 * f + 1] = Pr1; Pl[6 * f + 2] = Pr2; }
-    if (doit && c3 == 1) { Pl[6 * f + 3] = Pr1; Pl[6 * f + 4] = Pr2; }
-    if (doit && c3 == 2) { Pl[6 * f + 5] = Pr2; }
-  };
+  T* const prow = Pl + 16 * f + 4 * c3;   // my row of foot f's P in the LDS table (the spare lane owns a dummy row: no predicate on the write)
 
 #ifdef WBC_QP_STAMP
   const long long st_t1 = __builtin_readcyclecounter();
@@ -281,30 +272,39 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
 #else
 #define SEG(i) do {} while (0)
 #endif
-  pick();
-  int guard = 0;
-  while (__ballot(!done && ip >= 0) != 0ull) {
-    if (++guard > 4 * prm.max_iter + 8) break;
+  {  // first candidate, at x0
+    T val; int id;
+    const bool found = most_violated(dppx<0x00>(x_me), dppx<0x55>(x_me), dppx<0xAA>(x_me), false, false, val, id);
+    ip = (!done && found) ? id : -1;
+    sip = val;
+    done = done || !found;
+  }
+  while (__ballot(!done && ip >= 0) != 0ull) {   // (every trip counts against max_iter in every row that is still working)
     bool go = !done && ip >= 0;
-    if (go && ++iter > prm.max_iter) { status = 1; done = true; go = false; }
+    iter += go ? 1 : 0;
+    const bool over = go && iter > prm.max_iter;
+    status = over ? 1 : status;
+    done = done || over;
+    go = go && !over;
     const int ipc = ip < 0 ? 0 : ip;
     const int lp = (ipc >> 1) & 15, kp = lp >> 2;
     // ---- candidate normal, P and lever arm of its foot (LDS, run-time indices); v, b formed by every lane
     const T np0 = Cl[3 * ipc], np1 = Cl[3 * ipc + 1], np2 = Cl[3 * ipc + 2];
-    const T pxx = Pl[6 * kp], pxy = Pl[6 * kp + 1], pxz = Pl[6 * kp + 2], pyy = Pl[6 * kp + 3], pyz = Pl[6 * kp + 4], pzz = Pl[6 * kp + 5];
+    const T* pk_ = Pl + 16 * kp;
+    const T pxx = pk_[0], pxy = pk_[1], pxz = pk_[2], pyy = pk_[5], pyz = pk_[6], pzz = pk_[10];
     const T dkx = Dl[3 * kp], dky = Dl[3 * kp + 1], dkz = Dl[3 * kp + 2];
     const T v0 = pxx * np0 + pxy * np1 + pxz * np2, v1 = pxy * np0 + pyy * np1 + pyz * np2, v2 = pxz * np0 + pyz * np1 + pzz * np2;
     const T vv = v0 * v0 + v1 * v1 + v2 * v2;
+    const T nn = np0 * np0 + np1 * np1 + np2 * np2;
     T bb[6];
     bb[0] = s0 * v0; bb[1] = s1 * v1; bb[2] = s2 * v2;
     bb[3] = s3 * (dky * v2 - dkz * v1); bb[4] = s4 * (dkz * v0 - dkx * v2); bb[5] = s5 * (dkx * v1 - dky * v0);
-    SEG(0);
     T yi;
     ginv_mul(bb, yi);
     const T by = ((bb[0] * y[0] + bb[1] * y[1]) + (bb[2] * y[2] + bb[3] * y[3])) + (bb[4] * y[4] + bb[5] * y[5]);
     const T znA = vv - by;                 // alpha (z . n+)
     const T zn = znA * ralpha;
-    SEG(1);
+    SEG(0);
     // ---- step directions of my variable and my slot
     T w0, w1, w2;
     bt_y(w0, w1, w2);
@@ -314,58 +314,66 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
     const T a_s = Np0 * np0 + Np1 * np1 + Np2 * np2;               // my slot's coefficient of n+ (foot kp only)
     const T r_me = (mine ? a_s : (T)0) - (Np0 * w0 + Np1 * w1 + Np2 * w2);
     const bool slot_act = isvar && c3 < qk;
-    SEG(2);
-    // ---- step lengths
-    T t1 = INF;
+    // ---- chain 1: ratio test over the active multipliers
+    T t1k = (slot_act && r_me > 0) ? u_s * rcp_nr(r_me) : KeyT<T>::BIG;
     int kmin = l16;
-    {
-      T t1k = KeyT<T>::BIG;
-      if (slot_act && r_me > 0) t1k = u_s * rcp_nr(r_me);
-      const bool found = gargmin(t1k, kmin);
-      if (found) t1 = t1k;
-    }
-    T t2 = INF, rz = 0;
-    if (zn > (EPS * Rnorm) * (EPS * Rnorm)) { rz = rcp_nr(zn); t2 = -sip * rz; }
-    if (go && !(t1 < INF) && !(t2 < INF)) { status = 2; done = true; go = false; }
-    const bool dual_only = !(t2 < INF);
-    const bool full = !dual_only && !(t1 < t2);
+    const bool t1found = gargmin(t1k, kmin);
+    const T t1 = t1found ? t1k : INF;
+    // ---- chain 2: the full step and, at its end point, the next candidate (speculative: valid when the step is full).
+    // Linearly dependent on the active normals of its foot = no primal step: the dense method's test |d2| <= eps Rnorm, plus a
+    // purely local one (v = P n+ is rounding noise of n+: P is kept by rank-one downdates, exact only to ~1e-16)
+    const bool indep = zn > (EPS * EPS) * Rn2 && vv > (T)4e-28 * nn;
+    const T rz = rcp_nr(indep ? zn : (T)1);
+    const T t2 = indep ? -sip * rz : INF;
+    const T x_full = x_me + (indep ? t2 : (T)0) * z_me;
+    const bool own = l16 == lp;
+    const bool sA_act = actA || (own && !(ipc & 1)), sB_act = actB || (own && (ipc & 1));   // the candidate is active at that point
+    T nval; int nid;
+    const bool nfound = most_violated(dppx<0x00>(x_full), dppx<0x55>(x_full), dppx<0xAA>(x_full), sA_act, sB_act, nval, nid);
+    SEG(1);
+    // ---- decide and commit (selects)
+    const bool infeas = go && !t1found && !indep;
+    status = infeas ? 2 : status;
+    done = done || infeas;
+    go = go && !infeas;
+    const bool dual_only = !indep;
+    const bool full = indep && !(t1 < t2);
+    const bool addg = go && full, dropg = go && !full;
     const T t = full ? t2 : t1;
-    if (go) {
-      if (!dual_only) x_me += t * z_me;
-      if (slot_act) u_s -= t * r_me;
-      u_c += t;
-    }
-    SEG(3);
-    // ---- full step: the candidate joins the active set of its foot
-    const bool addg = go && full;
+    x_me = addg ? x_full : ((dropg && !dual_only) ? x_me + t1 * z_me : x_me);
+    u_s = (go && slot_act) ? u_s - t * r_me : u_s;
+    u_c = go ? u_c + t : u_c;
+    // full step: the candidate joins the active set of its foot
     {
-      const T g = rz * ralpha;                                   // 1 / (alpha z . n+)
-      const T gy = addg ? yi * g : (T)0;
+      const T gy = addg ? yi * (rz * ralpha) : (T)0;                 // y_i / (alpha z . n+)
       sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] += gy * y[j]; });
       const T ivv = rcp_nr(vv > 0 ? vv : (T)1);
       const T e0 = v0 * ivv, e1 = v1 * ivv, e2 = v2 * ivv;       // v / |v|^2: the new row of N^+
       const bool upd = addg && mine;
-      if (upd) {
-        if (slot_act) { Np0 -= a_s * e0; Np1 -= a_s * e1; Np2 -= a_s * e2; }
-        if (isvar && c3 == qk) { Np0 = e0; Np1 = e1; Np2 = e2; u_s = u_c; id_s = ipc; }
-        Pr0 -= vc * e0; Pr1 -= vc * e1; Pr2 -= vc * e2;
-        ++qk;
-      }
-      write_P_row(upd);
-      if (addg) {
-        const T nr = zn * rsqrt_nr(zn);                          // |d2| of the dense method: the new diagonal entry of R
-        Rnorm = (nr > Rnorm) ? nr : Rnorm;
-        if (l16 == lp) { if (ipc & 1) actB = true; else actA = true; }
-        ip = -1;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the P table is read by every lane of the row at the next candidate
+      const bool shrink = upd && slot_act, fresh = upd && isvar && c3 == qk;
+      Np0 = fresh ? e0 : (shrink ? Np0 - a_s * e0 : Np0);
+      Np1 = fresh ? e1 : (shrink ? Np1 - a_s * e1 : Np1);
+      Np2 = fresh ? e2 : (shrink ? Np2 - a_s * e2 : Np2);
+      u_s = fresh ? u_c : u_s;
+      id_s = fresh ? ipc : id_s;
+      const T vcu = upd ? vc : (T)0;
+      Pr0 -= vcu * e0; Pr1 -= vcu * e1; Pr2 -= vcu * e2;
+      qk += upd ? 1 : 0;
+      prow[0] = Pr0; prow[1] = Pr1; prow[2] = Pr2;                 // every lane, every trip: its (possibly unchanged) row
+      Rn2 = (addg && zn > Rn2) ? zn : Rn2;
+      actA = actA || (addg && own && !(ipc & 1));
+      actB = actB || (addg && own && (ipc & 1));
+      // the next candidate of the rows that added: the speculative search was made at their new point
+      ip = addg ? (nfound ? nid : -1) : ip;
+      sip = addg ? nval : sip;
+      u_c = addg ? (T)0 : u_c;
+      done = done || (addg && !nfound);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (LDS is in order within a wavefront: the table reads of the next trip follow these writes)
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    pick();
     SEG(4);
-    // ---- partial / dual-only step: the blocking constraint leaves its foot's active set
-    const bool dropg = go && !full;
+    // ---- partial / dual-only step: the blocking constraint leaves its foot's active set (rare: wave-uniform branch)
     if (__ballot(dropg) != 0ull) {
       const int kq = dropg ? kmin : 0;                 // lane (within the row) of the blocking slot
       const int kd = kq >> 2, sd = kq & 3;             // its foot and slot
@@ -380,13 +388,13 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
         if (inq && c3 == qk - 1) { u_s = 0; id_s = -1; }
         if (inq) --qk;
       }
-      // remaining normals of foot kd (ids of slots 0, 1 after the shift) and the one that left
+      // remaining normals of foot kd (ids of slots 0, 1 after the shift)
       const int id0 = dppx<0x00>(id_s), id1 = dppx<0x55>(id_s);
       const int i0 = (inq && qk >= 1) ? id0 : 0, i1 = (inq && qk >= 2) ? id1 : 0;
       const T n00 = Cl[3 * i0], n01 = Cl[3 * i0 + 1], n02 = Cl[3 * i0 + 2];
       const T n10 = Cl[3 * i1], n11 = Cl[3 * i1 + 1], n12 = Cl[3 * i1 + 2];
       if (inq) rebuild(qk, n00, n01, n02, n10, n11, n12);
-      write_P_row(inq);
+      prow[0] = Pr0; prow[1] = Pr1; prow[2] = Pr2;
       // what: the direction P_k gained, what what^T = P_k(new) - P_k(old): row c3 of that difference is what_c what; the lane of
       // foot kd with the largest |what_c| normalises its row and publishes what through LDS
       {
@@ -416,8 +424,8 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
         sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] -= gd * y[j]; });
       }
       {  // a partial step moved x: refresh the candidate's slack (cross-lane ops stay unconditional)
-        T sA, sB;
-        slacks(sA, sB);
+        const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
+        const T sA = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA, sB = cBx * xq0 + cBy * xq1 + cBz * xq2;
         const T sv = gread((ipc & 1) ? sB : sA, lp, rowbase);
         if (dropg && !dual_only) sip = sv;
       }
