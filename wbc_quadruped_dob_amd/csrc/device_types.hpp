@@ -2,6 +2,17 @@
 #pragma once
 #include <cstddef>
 
+// Stores of pure outputs by lanes beyond the batch: those lanes recompute the last state, so what they would store is a
+// bit-identical duplicate at the same address -- no guard, and so no exec region per store (-DWBC_GUARD_STORES=1: the round-2 form).
+#ifndef WBC_GUARD_STORES
+#define WBC_GUARD_STORES 0
+#endif
+#if WBC_GUARD_STORES
+#define WBC_OUT_GUARD if (live)
+#else
+#define WBC_OUT_GUARD
+#endif
+
 namespace wbc {
 
 // ---- per-leg model constants, as read by the dynamics-sweep kernel -------------------------

@@ -49,10 +49,14 @@ namespace wbc {
 #define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define LDX(ptr, c0, xN) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((xN) + s32) * (unsigned)sizeof(T))))
+// (pure-output stores keep their `if (live)` guard here: without it the roles save ~1 % in the fused tick but the persistent rollout
+// kernel, which sits at 256 registers, spills -- 19.5 -> 24.0 us per tick, measured)
 #define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STVG(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)   /* in/out state (observer): dead lanes of OTHER wavefronts would race with the live one */
 #define STL(ptr, c0, stride, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define STLX(ptr, c0, stride, xN, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define ST4G(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STVG(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 #define MAKE_R(R_, qx, qy, qz, qw) do { const T x = qx, y = qy, z = qz, w = qw; \
     R_.a[0] = 1 - 2 * (y * y + z * z); R_.a[1] = 2 * (x * y - z * w);     R_.a[2] = 2 * (x * z + y * w); \
     R_.a[3] = 2 * (x * y + z * w);     R_.a[4] = 1 - 2 * (x * x + z * z); R_.a[5] = 2 * (y * z - x * w); \
@@ -655,10 +659,10 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
         rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
         p_b[c] = ig;
       }
-      ST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
-      if (leg < 2) STV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
-      ST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
-      if (leg < 2) STV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+      ST4G(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) STVG(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      ST4G(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+      if (leg < 2) STVG(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = 6 + jx[k];
@@ -672,8 +676,8 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 #pragma unroll
         for (int j = 1; j < 12; ++j) { k1 = (jx[k] == j) ? prm.K1[6 + j] : k1; k2 = (jx[k] == j) ? prm.K2[6 + j] : k2; }
         rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
-        STV(a.obs_integ, c, ig);
-        STV(a.obs_r, c, rl[k]);
+        STVG(a.obs_integ, c, ig);
+        STVG(a.obs_r, c, rl[k]);
       }
     }
     if constexpr (OBSW) {   // hand rhat to the QP waves, which subtract it from b and tau_partial themselves
@@ -707,6 +711,8 @@ __global__ __launch_bounds__(BLOCK, WBC_RS_WAVES) void rnea_step_kernel(const De
 
 #undef MAKE_R
 #undef ST4
+#undef ST4G
+#undef STVG
 #undef STLX
 #undef STL
 #undef STV

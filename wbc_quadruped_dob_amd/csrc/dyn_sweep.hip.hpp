@@ -289,7 +289,11 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   const int leg = (int)((threadIdx.x & 63) >> 4);
   const size_t s_raw = (((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15)) * W;   // first state of this lane
   const bool live = s_raw < N;                            // (W = 2: N is even, so both states of a lane are in range together)
-  const unsigned s32 = (unsigned)(live ? s_raw : N - W);  // dead lanes recompute the last state(s), stores are masked
+  // Dead lanes (beyond the batch) recompute the last state(s) and STORE what they computed: bit-identical duplicates of the live
+  // lane's values at the same addresses.  Guarding every store with `if (live)` made each of the ~100 stores its own exec region
+  // (s_and_saveexec / s_cbranch_execz / s_or: ~45 cycles each for a lone wavefront, tools/issue_probe.hip).  Only the observer state,
+  // which is read-modified-written, keeps the guard (STVG): an all-dead wavefront could read it after the live one wrote it.
+  const unsigned s32 = (unsigned)(live ? s_raw : N - W);
   const unsigned legN = (unsigned)leg * N32;
 #define CS(i) cst[(i) * 4 + leg]
   // Addressing: every array is < 4 GiB (max_batch is capped at create), so a component row is reached as
@@ -297,13 +301,15 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   //   LDU/STU: component index is wave-uniform;  LDV/STV: component index differs per lane.
 #define LDU(ptr, comp) (*(const V*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define LDV(ptr, comp) (*(const V*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
-#define STU(ptr, comp, val) do { if (live) *(V*)((char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))) = (val); } while (0)
-#define STV(ptr, comp, val) do { if (live) *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STU(ptr, comp, val) do { WBC_OUT_GUARD *(V*)((char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))) = (val); } while (0)
+#define STV(ptr, comp, val) do { WBC_OUT_GUARD *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STVG(ptr, comp, val) do { if (live) *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)   /* in/out state (observer): dead lanes of OTHER wavefronts would race with the live one */
   // leg-strided component: comp = c0 + stride*leg (+ per-lane extra element offset xN = x*N)
-#define STL(ptr, c0, stride, val) do { if (live) *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
-#define STLX(ptr, c0, stride, xN, val) do { if (live) *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STL(ptr, c0, stride, val) do { WBC_OUT_GUARD *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STLX(ptr, c0, stride, xN, val) do { WBC_OUT_GUARD *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   // four base-replicated values, one per lane of the quad
 #define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
+#define ST4G(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STVG(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
 #define WSTV(comp, val) STV(a.ws, comp, val)   /* step workspace */
 #define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
 #define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
@@ -388,7 +394,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       struct alignas(2 * sizeof(V)) T2 { V a, b; };
       const unsigned odd = (s32 / W) & 1u, s2 = s32 & ~(unsigned)(2 * W - 1);
       const bool live2 = live;  // N a multiple of 2 W: the states of a lane pair are in range together
-#define ST2C(ptr, comp, val) do { if (live2) *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
+#define ST2C(ptr, comp, val) do { WBC_OUT_GUARD *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
       for (int e = 2 * leg + (int)odd; e < 64; e += 8) {
         const int zi = zidx_s[e];
         if (zi >= 0) ST2C(a.M, zi, Z);
@@ -801,10 +807,10 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         p_b[c] = ig;  // reuse as the new integ for the store below
       }
       // (the replicated rows were read by every lane of the wave at the top of the kernel, long before any lane stores to them)
-      ST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
-      if (leg < 2) STV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
-      ST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
-      if (leg < 2) STV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+      ST4G(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) STVG(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      ST4G(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+      if (leg < 2) STVG(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = 6 + jx[k];
@@ -813,8 +819,8 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
         const V ig = ob_igl[k] + dt * (u + beta_l[k] + r0);
         const V e = p_leg[k] - ig;
         rl[k] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
-        STV(a.obs_integ, c, ig);
-        STV(a.obs_r, c, rl[k]);
+        STVG(a.obs_integ, c, ig);
+        STVG(a.obs_r, c, rl[k]);
       }
     }
     if (OBS) {
@@ -842,6 +848,8 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 #undef WST4
 #undef WSTV
 #undef ST4
+#undef ST4G
+#undef STVG
 #undef STLX
 #undef STL
 #undef STV

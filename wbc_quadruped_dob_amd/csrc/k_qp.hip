@@ -2,13 +2,24 @@
 #include "k_common.hip.hpp"
 #include "qp_kernels.hip.hpp"
 #include "qp_lane.hip.hpp"
+#include <type_traits>
 
 namespace wbc {
 
+#ifndef WBC_F32_DENSE_TILE_MIN
+#define WBC_F32_DENSE_TILE_MIN 49152
+#endif
 template <int TILE>
 static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
   using T = Scalar;
   const dim3 grid((unsigned)((a.N + TILE - 1) / TILE));
+  if constexpr (std::is_same<T, float>::value && TILE == 64) {
+    if (a.N >= (size_t)WBC_F32_DENSE_TILE_MIN) {   // more than two tiles per CU: the leaner fp32 body wins on occupancy (qp_kernels.hip.hpp)
+      if (rhat) WBC_KLAUNCH(L, (qp_tile_kernel<T, true, TILE, true>), grid, dim3(256), prm, a, jmap);
+      else WBC_KLAUNCH(L, (qp_tile_kernel<T, false, TILE, true>), grid, dim3(256), prm, a, jmap);
+      return hipGetLastError();
+    }
+  }
   if (rhat) WBC_KLAUNCH(L, (qp_tile_kernel<T, true, TILE>), grid, dim3(256), prm, a, jmap);
   else WBC_KLAUNCH(L, (qp_tile_kernel<T, false, TILE>), grid, dim3(256), prm, a, jmap);
   return hipGetLastError();

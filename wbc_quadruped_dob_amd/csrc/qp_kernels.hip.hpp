@@ -119,8 +119,11 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned
 #ifndef WBC_QP_TILE_WAVES
 #define WBC_QP_TILE_WAVES 2
 #endif
-template <class T, bool RHAT, int TILE>
-__global__ __launch_bounds__(256, WBC_QP_TILE_WAVES) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
+// DENSE (fp32 only): the orthogonal-factor body in fp32 arithmetic instead of the structured body in fp64 arithmetic.  At 117 VGPRs
+// four workgroups share a CU where the structured body's 183 allow two: from ~49 152 fp32 states on (more than two tiles of 64 per
+// CU) the dense body wins (65 536: 38 vs 46 us, 131 072: 72 vs 92 us), below it loses (32 768: 26.0 vs 23.4 us).  Measured, MI355X.
+template <class T, bool RHAT, int TILE, bool DENSE = false>
+__global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
   static_assert(TILE % 4 == 0 && TILE <= 1024, "tile of whole four-state groups");
   __shared__ unsigned short order[TILE];
   __shared__ int hist[64];
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(256, WBC_QP_TILE_WAVES) void qp_tile_kernel(DevPara
     if (base + order[4 * g] >= N) break;     // first (hardest) state of the group lies beyond the end: so does the rest of the queue
     const size_t s = base + order[4 * g + row];
     const bool live = s < N;
-    qp_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
+    if constexpr (DENSE) qp_group16_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
+    else qp_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
   }
 }
 

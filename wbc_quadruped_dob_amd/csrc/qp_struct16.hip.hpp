@@ -38,10 +38,13 @@ namespace wbc {
 // per wave: four QPs x {32 constraint normals, P of the four feet (xx xy xz yy yz zz), lever arms of the four feet, scratch what}
 template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 16]; T D[4][4 * 3]; T W[4][4]; };   // P: row c of foot k at 16 k + 4 c (row 3: the spare lane's dummy)
 
-template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
-WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
+// TS = the solver's scalar type (what the batch arrays and the LDS workspace hold); the arithmetic is ALWAYS double: the inverse
+// is kept by rank-one updates (cond(G_A) ~ 1e4-1e5 is too much for fp32), and on gfx950 a dependent v_fma_f64 costs a lone
+// wavefront what a dependent v_fma_f32 costs (13.5 vs 13.1 cycles, tools/issue_probe.hip) -- the QP is latency-, not byte-bound.
+template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
+WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, const QpJidx& jmap, const TS* wsl, const QpSync* sync = nullptr,
                               const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
-  static_assert(std::is_same<T, double>::value, "the structured form keeps an explicit inverse by rank-one updates: fp64 only");
+  using T = double;
   static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
   __shared__ S16Lds<T> lds_all[WPB];
   unsigned tx = threadIdx.x;
@@ -67,10 +70,10 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
   bool live = TILED ? who.live : (qp_raw < N && (SPW == 16 || (int)(tx >> 4) < SPW));
   unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
   const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
-#define GLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
-#define WSLD(comp) (WSLDS ? wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
-#define BLD(c) (WSLDS ? wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
-#define GST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
+#define GLD(ptr, comp) ((T)(*(const TS*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS)))))
+#define WSLD(comp) (WSLDS ? (T)wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
+#define BLD(c) (WSLDS ? (T)wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
+#define GST(ptr, comp, val) (*(TS*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS))) = (TS)(val))
 
 #ifdef WBC_QP_STAMP
   const long long st_t0 = __builtin_readcyclecounter();
@@ -481,14 +484,15 @@ WBC_DEV void qp_struct16_body(const DevParams<T>& prm, const QpArgs<T>& a, const
 #undef GLD
 }
 
-// the QP body of a scalar type: the structured form for fp64, the orthogonal-factor form for fp32 (WBC_QP_STRUCT = 0: always the latter)
+// the QP body of a scalar type.  WBC_QP_STRUCT = 2 (default): the structured form for both scalar types (fp32 solvers: fp32 arrays,
+// fp64 arithmetic); 1: structured for fp64, the orthogonal-factor form (qp_group16.hip.hpp) for fp32; 0: always the latter
 #ifndef WBC_QP_STRUCT
-#define WBC_QP_STRUCT 1
+#define WBC_QP_STRUCT 2
 #endif
 template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
 WBC_DEV void qp_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
                      const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
-  if constexpr (WBC_QP_STRUCT && std::is_same<T, double>::value) qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
+  if constexpr (WBC_QP_STRUCT != 0 && (WBC_QP_STRUCT > 1 || std::is_same<T, double>::value)) qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
   else qp_group16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
 }
 
