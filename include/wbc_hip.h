@@ -109,7 +109,7 @@ typedef struct wbc_solver_options {
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
                              kernel instead of inside the sweep; -1 = auto (fp32: from 40960 states on, fp64: from 20480),
                              -2 = never */
-  int one_zerocopy;       /* single-robot host-pointer calls: 0 = staging copies + hipStreamSynchronize; 1 = the kernel reads / writes the
+  int one_zerocopy;       /* (default 3) single-robot host-pointer calls: 0 = staging copies + hipStreamSynchronize; 1 = the kernel reads / writes the
                              pinned image directly (mapped host memory); 2 = as 1, and completion is a ticket the stream writes into the
                              image behind the tick (hipStreamWriteValue32), polled by the host in memory: no runtime call on the wait
                              path; 3 = as 2 with a one-thread kernel writing the ticket.  2 / 3 fall back to 1 when the stack refuses */
@@ -318,7 +318,7 @@ int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batch_in* host_
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void); /* 3 */
+int wbc_abi_version(void); /* 4 */
 
 #ifdef __cplusplus
 }

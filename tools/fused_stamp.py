@@ -29,6 +29,16 @@ for cfg, obs in ((2, 0), (3, 1)):
     print("  workgroup entry spread: %.2f us" % ((t0.max() - t0.min()) * 1e-2))
     for i, nm in enumerate(names):
         print("  %-36s median %+7.2f us   p90 %+7.2f us" % (nm, np.median(rel[i]) * 1e-3, np.percentile(rel[i], 90) * 1e-3))
+    # QP wavefront 0 of a workgroup solves states 16 w .. 16 w + 3: time from "b seen" to "iterations done" against its trips
+    it = out["iters"].cpu().numpy().reshape(-1, 16)[:, :4].max(1)
+    dt = (rel[5] - rel[4]) * 1e-3
+    A = np.stack([np.ones_like(dt), it.astype(float)], 1)
+    coef = np.linalg.lstsq(A, dt, rcond=None)[0]
+    print("  QP wavefront 0: (iterations done - b seen) = %.2f us + %.3f us x trips  (trips: mean %.2f, max %d; slowest workgroup %.2f us after its entry)"
+          % (coef[0], coef[1], it.mean(), it.max(), rel[11].max() * 1e-3))
+    for k in sorted(set(it.tolist())):
+        sel = it == k
+        print("     trips %2d: %4d workgroups, median %.2f us" % (k, sel.sum(), np.median(dt[sel])))
 
 # ---- persistent rollout: the LAST tick of a horizon-20 rollout of 1 024 robots (observer on)
 rnames = ["tick start (after barrier B)", "QP0 inputs issued", "QP0 lever arms seen", "QP0 factor done", "QP0 rhat seen", "QP0 iterations done",

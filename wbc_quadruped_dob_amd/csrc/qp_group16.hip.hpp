@@ -115,6 +115,12 @@ WBC_DEV double rcp_nr(double x) {
 #endif
   return y;
 }
+// one Newton step: 2^-46 relative (where the result only scales a step or a projector row)
+WBC_DEV double rcp_nr1(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
 WBC_DEV float rcp_nr(float x) {
   float y = __builtin_amdgcn_rcpf(x);
   float e = fmaf(-x, y, 1.0f); y = fmaf(y, e, y);

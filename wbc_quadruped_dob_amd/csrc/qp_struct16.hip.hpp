@@ -298,7 +298,6 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     const T dkx = Dl[3 * kp], dky = Dl[3 * kp + 1], dkz = Dl[3 * kp + 2];
     const T v0 = pxx * np0 + pxy * np1 + pxz * np2, v1 = pxy * np0 + pyy * np1 + pyz * np2, v2 = pxz * np0 + pyz * np1 + pzz * np2;
     const T vv = v0 * v0 + v1 * v1 + v2 * v2;
-    const T nn = np0 * np0 + np1 * np1 + np2 * np2;
     T bb[6];
     bb[0] = s0 * v0; bb[1] = s1 * v1; bb[2] = s2 * v2;
     bb[3] = s3 * (dky * v2 - dkz * v1); bb[4] = s4 * (dkz * v0 - dkx * v2); bb[5] = s5 * (dkx * v1 - dky * v0);
@@ -318,14 +317,15 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     const T r_me = (mine ? a_s : (T)0) - (Np0 * w0 + Np1 * w1 + Np2 * w2);
     const bool slot_act = isvar && c3 < qk;
     // ---- chain 1: ratio test over the active multipliers
-    T t1k = (slot_act && r_me > 0) ? u_s * rcp_nr(r_me) : KeyT<T>::BIG;
+    T t1k = (slot_act && r_me > 0) ? u_s * rcp_nr1(r_me) : KeyT<T>::BIG;
     int kmin = l16;
     const bool t1found = gargmin(t1k, kmin);
     const T t1 = t1found ? t1k : INF;
     // ---- chain 2: the full step and, at its end point, the next candidate (speculative: valid when the step is full).
     // Linearly dependent on the active normals of its foot = no primal step: the dense method's test |d2| <= eps Rnorm, plus a
-    // purely local one (v = P n+ is rounding noise of n+: P is kept by rank-one downdates, exact only to ~1e-16)
-    const bool indep = zn > (EPS * EPS) * Rn2 && vv > (T)4e-28 * nn;
+    // purely local one (v = P n+ is rounding noise of n+: P is kept by rank-one downdates, exact only to ~1e-16; the constraint
+    // normals have |n|^2 between 1 and 1 + mu^2)
+    const bool indep = zn > (EPS * EPS) * Rn2 && vv > (T)8e-28;
     const T rz = rcp_nr(indep ? zn : (T)1);
     const T t2 = indep ? -sip * rz : INF;
     const T x_full = x_me + (indep ? t2 : (T)0) * z_me;
@@ -350,13 +350,14 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     {
       const T gy = addg ? yi * (rz * ralpha) : (T)0;                 // y_i / (alpha z . n+)
       sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] += gy * y[j]; });
-      const T ivv = rcp_nr(vv > 0 ? vv : (T)1);
+      const T ivv = rcp_nr1(vv > 0 ? vv : (T)1);
       const T e0 = v0 * ivv, e1 = v1 * ivv, e2 = v2 * ivv;       // v / |v|^2: the new row of N^+
       const bool upd = addg && mine;
       const bool shrink = upd && slot_act, fresh = upd && isvar && c3 == qk;
-      Np0 = fresh ? e0 : (shrink ? Np0 - a_s * e0 : Np0);
-      Np1 = fresh ? e1 : (shrink ? Np1 - a_s * e1 : Np1);
-      Np2 = fresh ? e2 : (shrink ? Np2 - a_s * e2 : Np2);
+      const T as_ = shrink ? a_s : (T)0;
+      Np0 = fresh ? e0 : Np0 - as_ * e0;
+      Np1 = fresh ? e1 : Np1 - as_ * e1;
+      Np2 = fresh ? e2 : Np2 - as_ * e2;
       u_s = fresh ? u_c : u_s;
       id_s = fresh ? ipc : id_s;
       const T vcu = upd ? vc : (T)0;

@@ -276,7 +276,7 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->rollout_persistent = 1;
   o->rollout_spw = 0;
   o->obs_split_min = -1;   // auto
-  o->one_zerocopy = 0;
+  o->one_zerocopy = 3;   // measured p50 of a one-robot tick on the image (us): 0: 23.0, 1: 20.6, 2: 18.8, 3: 17.1
   o->timing_mode = WBC_TIMING_DISPATCH;
   o->qp_tile = 0;
   o->obs_split_serial = 1;
@@ -597,7 +597,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   // 32 768, 109.6 -> 93.1 at 65 536, 408 -> 350 at 262 144 (tiles of 64; 128 and 256 lose to the workgroup lifetime);
   // below 12 288 states the tiles do not fill the device
   int tile = s->opt.qp_tile;
-  if (tile == 0) tile = N >= 20480 ? 64 : (N >= 12288 ? 32 : 0);
+  if (tile == 0) tile = N >= 28672 ? 64 : (N >= 14336 ? 32 : 0);   // (round 3, structured QP body: one-wave 20.1 vs tiles-of-32 22.1 us at 12 288; 32: 28.5 vs 64: 36.3 us at 24 576; 64: 36.1 vs 32: 39.5 at 32 768)
   if (tile < 0) tile = 0;
   if (lane) {
     TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, obs_split, dp, qa, s->jmap, s->d_todo));
@@ -1014,4 +1014,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 3; }  // 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
+extern "C" int wbc_abi_version(void) { return 4; }  // 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
