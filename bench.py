@@ -803,10 +803,40 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
     qp_s = tm["qp_ms"] * 1e-3 / tm["qp_launches"]
     ach = dyn_words(split) * ts * n / dyn_s / 1e9
     # the dynamics stage exactly as SURVEY.md 8(d) defines it (q, v -> M, h, Jc as its own kernel, no step prologue)
+    # the same ticks with wbc_solver_options.keep_structural = 1: the 162 structural words of M and Jc per state stay as the first
+    # tick wrote them (the caller's promise not to touch M / Jc between ticks); the sweep then stores 281 of the 443 words
+    kept = None
+    try:
+        s2 = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=n,
+                      options={"keep_structural": 1})
+        integ2 = None if integ is None else integ.clone()
+        rr2 = None if rr is None else torch.zeros_like(rr)
+        out2 = {k: out[k] for k in ("M", "h", "Jc", "pf")}
+        for _ in range(20):
+            o2 = s2.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                         inp["f_prev"], integ2, rr2, out=out2, want_mats=True)
+            out2.update(o2)
+        torch.cuda.synchronize()
+        s2.enable_timing(1)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            s2.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                    inp["f_prev"], integ2, rr2, out=out2, want_mats=True)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        tm2 = s2.collect_timing()
+        s2.enable_timing(0)
+        d2 = tm2["dyn_ms"] * 1e-3 / max(1, tm2["dyn_launches"])
+        kept = {"steps_per_s": K * n / el2, "ms_per_step": el2 / K * 1e3, "dyn_sweep_us": d2 * 1e6, "stored_words_per_state": 405 - 162,
+                "achieved_GBps_on_281_words": 281 * ts * n / d2 / 1e9,
+                "note": "wbc_solver_options.keep_structural = 1: M / Jc structural zeros and ones written by the first tick only"}
+        del s2
+    except Exception as e:
+        kept = {"error": repr(e)[:200]}
     alone = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
     alone["traffic"] = pmc_traffic("dyn_sweep_kernel<%s, 1," % ("double" if dtype == "f64" else "float"), n, dtype)
     return {"batch": n, "kernel": dyn_kernel_name(split), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "dynamics_stage_alone": alone,
+            "dynamics_stage_alone": alone, "keep_structural": kept,
             "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(tick_sweep_symbol(dtype, obs, n), n, dtype),
             "algorithmic_words_per_state": dyn_words(split), "avg_launch_us": dyn_s * 1e6,
             "rnea_step_us": tm["rnea_ms"] * 1e3 / max(1, tm["rnea_launches"]), "qp_us": qp_s * 1e6,

@@ -128,6 +128,11 @@ typedef struct wbc_solver_options {
                              Newton step leaves the active faces unchanged (then the point is the exact solution for those faces) */
   int f32_pack2;          /* fp32 dynamics sweep with TWO states per lane (packed v_pk_* arithmetic, whole 128-byte lines per 16-lane
                              row, half the wavefronts): 0 = auto (even batches from 32768 states on), 1 = every even batch, -1 = never */
+  int keep_structural;    /* 54 of the 171 packed-M words and 108 of the 216 Jc words per state are structural zeros / ones (cross-leg
+                             blocks, identity and skew-diagonal entries): 37 % of what the dynamics sweep stores.  1: a call that gets the
+                             SAME M and Jc buffers and the same N as the previous call on this solver does not rewrite them -- the caller
+                             promises not to touch M / Jc between ticks (any other pointer or N: written in full again).  0 (default):
+                             every call writes every word */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,

@@ -300,6 +300,44 @@ def test_single_robot_loop_on_the_pinned_image(torch_cuda, gpu_model, oracle, zc
         img["q"][7:] = B["q"][0, 7:]
 
 
+@pytest.mark.parametrize("dtype,n", [("f64", 1000), ("f64", 20000), ("f32", 40000), ("f64", 70000)])
+def test_keep_structural_skips_only_what_is_already_there(torch_cuda, gpu_model, oracle, dtype, n):
+    """wbc_solver_options.keep_structural: the structural zeros / ones of M and Jc (54 + 108 words per state) are written by the
+    first tick into a pair of buffers and NOT rewritten by later ticks into the same pair; new buffers or another N are written
+    in full.  Fused tick (1 000), two-kernel ticks with the tiled / per-lane QP, fp32 with the packed sweep."""
+    torch = torch_cuda
+    td = torch.float64 if dtype == "f64" else torch.float32
+    nd = _np_dtype(dtype)
+    solver, P = _solver(gpu_model, dtype=dtype, max_batch=n, options={"keep_structural": 1})
+    B = synth.make_batch(2, n, gpu_model.total_mass, rank=77)
+    dv = lambda k: to_dev(B[k], torch, td)
+    ins = [dv(k) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")]
+    mask = torch.from_numpy(B["mask"]).cuda()
+    ref = oracle.dynamics(B["q"].astype(nd), B["v"].astype(nd), nthreads=8)
+    tol = TIGHT64 if dtype == "f64" else 5e-5
+    nan = lambda r: torch.full((r, n), float("nan"), dtype=td, device="cuda")
+    out = dict(M=nan(171), h=nan(18), Jc=nan(216), pf=nan(12))
+    o1 = solver.step(*ins, mask, out=dict(out), want_mats=True)               # first tick: every word
+    torch.cuda.synchronize()
+    for k in ("M", "Jc"):
+        assert relerr(to_host(o1[k]), ref[k]) < tol, k
+    Mref = unpack_M(ref["M"][:1])[0]
+    zi = int(np.flatnonzero(ref["M"][0] == 0.0)[0])                            # a structural zero of the packed M
+    o1["M"][zi, :] = 7.0
+    o2 = solver.step(*ins, mask, out=dict(o1), want_mats=True)               # same buffers: constants are NOT rewritten ...
+    torch.cuda.synchronize()
+    assert torch.all(o2["M"][zi] == 7.0)
+    o2["M"][zi, :] = 0.0
+    for k in ("M", "Jc", "h"):
+        assert relerr(to_host(o2[k]), ref[k]) < tol, k                         # ... everything else is
+    fresh = dict(M=nan(171), h=nan(18), Jc=nan(216), pf=nan(12))
+    o3 = solver.step(*ins, mask, out=fresh, want_mats=True)                   # other buffers: written in full again
+    torch.cuda.synchronize()
+    for k in ("M", "Jc"):
+        assert torch.isfinite(o3[k]).all() and relerr(to_host(o3[k]), ref[k]) < tol, k
+    assert Mref.shape == (18, 18)
+
+
 def test_capacity_and_argument_errors(torch_cuda, gpu_model):
     import wbc_quadruped_dob_amd as W
     torch = torch_cuda

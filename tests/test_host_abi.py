@@ -133,7 +133,7 @@ def test_solver_options_struct_and_validation(hip_lib):
     """wbc_solver_options carries every kernel-selection switch (the library reads no environment variable)."""
     o = W.SolverOptions.default()
     assert o.struct_size == C.sizeof(W.SolverOptions)
-    assert (o.fused_max, o.rollout_persistent, o.rollout_spw, o.obs_split_min, o.one_zerocopy, o.timing_mode, o.qp_tile, o.obs_split_serial, o.qp_lane, o.f32_pack2) == (-1, 1, 0, -1, 3, 0, 0, 1, 0, 0)
+    assert (o.fused_max, o.rollout_persistent, o.rollout_spw, o.obs_split_min, o.one_zerocopy, o.timing_mode, o.qp_tile, o.obs_split_serial, o.qp_lane, o.f32_pack2, o.keep_structural) == (-1, 1, 0, -1, 3, 0, 0, 1, 0, 0, 0)
     good = W.Model.from_urdf(W.SYNTHETIC_URDF)
     h = C.c_void_p()
     prm = W.Params.default()

@@ -69,6 +69,7 @@ template <class T> struct SweepArgs {
   T* ws;
   int ws_geom;   // 1: also write d and the own-leg Jacobian blocks to the workspace; 0: the QP reads them from Jc (M/h/Jc ticks)
   int* qp_todo;  // non-null: the hand-over list of the per-lane QP kernel that follows; this kernel empties it (qp_lane.hip.hpp)
+  int skip_consts;  // 1: the structural zeros / ones of M and Jc are already in the caller's buffers (wbc_solver_options.keep_structural): not rewritten
 };
 
 template <class T> struct QpArgs {

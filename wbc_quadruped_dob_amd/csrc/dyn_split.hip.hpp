@@ -164,7 +164,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
 
   // structural zeros / ones first: they drain while the sweeps compute (ZEROS = false: other wavefronts write them)
-  if constexpr (ZEROS) {
+  if (ZEROS && !a.skip_consts) {
     const T Z = (T)0;
     for (int e = leg; e < 64; e += 4) {
       const int zi = zidx_s[e];

@@ -385,7 +385,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 
   // ------------------------------------------------------------------ data-independent stores first:
   // structural zeros and ones of M and Jc go out while the sweeps compute (they overlap the VALU work).
-  if (MATS) {
+  if (MATS && !a.skip_consts) {
     const V Z = (T)0;
     if ((N & (2 * W - 1)) == 0) {
       // 16 bytes per lane (W = 1; 2 x 8 bytes with W = 2): neighbouring lanes (l, l+1) of a row pair up, the even one takes the

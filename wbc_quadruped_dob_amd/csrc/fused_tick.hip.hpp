@@ -131,7 +131,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused
       const int* const zs = zidx_s;
       const unsigned tq = threadIdx.x;
       qp_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy, QpWho{0, false},
-                                         [=] __device__() { structural_consts_quarter<T>(model, a, zs, tq); });
+                                         [=] __device__() { if (!a.skip_consts) structural_consts_quarter<T>(model, a, zs, tq); });
     } else
 #endif
     qp_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy);

@@ -74,6 +74,8 @@ struct wbc_solver {
   void* h_one = nullptr;       // pinned host image of d_one: the single-robot calls move it with ONE copy each way
   void* h_one_dev = nullptr;   // device address of h_one (mapped): one_zerocopy lets the N = 1 kernels read / write it directly
   size_t one_bytes = 0;
+  // wbc_solver_options.keep_structural: the M / Jc buffers (and N) of the last call that wrote their structural constants
+  const void* kept_M = nullptr; const void* kept_Jc = nullptr; size_t kept_N = 0;
   unsigned one_seq = 0;        // completion tickets of the flag-polled single-robot ticks (one_zerocopy >= 2)
   bool one_flag_ok = true;     // cleared when the stream write-value / flag kernel is refused: back to hipStreamSynchronize
   // timing: a ring of event pairs allocated by wbc_solver_enable_timing (never inside a tick)
@@ -282,6 +284,7 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->obs_split_serial = 1;
   o->qp_lane = 0;
   o->f32_pack2 = 0;
+  o->keep_structural = 0;
 }
 
 extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -304,6 +307,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
     return fail(WBC_E_INVALID, "qp_tile must be 0 (auto), -1 (off), 32, 64, 128, 256 or 512");
   if (o.timing_mode != WBC_TIMING_DISPATCH && o.timing_mode != WBC_TIMING_EVENT_PAIR) return fail(WBC_E_INVALID, "bad timing_mode");
   if (o.f32_pack2 < -1 || o.f32_pack2 > 1) return fail(WBC_E_INVALID, "f32_pack2 must be -1, 0 or 1");
+  if (o.keep_structural != 0 && o.keep_structural != 1) return fail(WBC_E_INVALID, "keep_structural must be 0 or 1");
   if (o.one_zerocopy < 0 || o.one_zerocopy > 3) return fail(WBC_E_INVALID, "one_zerocopy must be 0 ... 3");
   int leg_body[4][3];
   std::string err;
@@ -497,6 +501,15 @@ extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KIN
 
 template <class T> static const DevModel<T>* dev_model(const wbc_solver* s) { return (const DevModel<T>*)s->d_model; }
 
+// keep_structural: 1 when this call may skip the structural zeros / ones of M and Jc (same buffers and N as the call that
+// last wrote them); records the buffers otherwise
+static int structural_kept(wbc_solver* s, const void* M, const void* Jc, size_t N) {
+  if (!M) return 0;
+  if (s->opt.keep_structural && M == s->kept_M && Jc == s->kept_Jc && N == s->kept_N) return 1;
+  s->kept_M = M; s->kept_Jc = Jc; s->kept_N = N;
+  return 0;
+}
+
 template <class T>
 static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc, void* pf,
                          void* p, void* beta, hipStream_t st) {
@@ -505,6 +518,7 @@ static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, 
   a.N = N; a.q = (const T*)q; a.v = (const T*)v;
   a.M = (T*)M; a.h = (T*)h; a.Jc = (T*)Jc; a.pf = (T*)pf; a.p = (T*)p; a.beta = (T*)beta;
   const int mode = (M ? SW_MATS : 0) | ((p || beta) ? SW_OBS : 0);
+  a.skip_consts = structural_kept(s, M, Jc, N);
   timing_tick(s);
   TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, mode, dev_model<T>(s), to_dev_params<T>(s->params), a));
   return WBC_OK;
@@ -535,6 +549,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   a.obs_integ = obs ? (T*)obs->integ : nullptr; a.obs_r = obs ? (T*)obs->r : nullptr;
   a.ws = (T*)s->d_ws;
   const bool mats = out->M != nullptr, ob = s->params.observer_order > 0;
+  a.skip_consts = structural_kept(s, out->M, out->Jc, N);
   timing_tick(s);
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
@@ -674,6 +689,8 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   a.tau_prev = (const T*)out->tau; a.f_prev = (const T*)out->f;
   a.obs_integ = obs ? (T*)obs->integ : nullptr; a.obs_r = obs ? (T*)obs->r : nullptr;
   a.ws = (T*)s->d_ws;
+  a.skip_consts = 0;   // (a persistent rollout writes M / Jc in full every tick: its mass_jac role is not on the tick's critical path)
+  s->kept_M = nullptr;
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters; qa.Jc = nullptr; qa.wdes = nullptr;
