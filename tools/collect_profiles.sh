@@ -10,6 +10,13 @@ for f in abi_smoke bw_probe fma_probe pytest_gpu mfma_probe; do cp "$O/$f.log" "
 for f in bench_cfg3_n262144 bench_cfg4_f32_n262144 bench_cfg2_n32768 bench_single_process_2shards bench_under_rocprof_n32768 bench_under_rocprof_cfg4_n32768 sq_counters_n262144 sq_counters_n4096; do
   [ -f "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
 done
+for f in bench_driver_flags_steps20 bench_cfg2_n262144_keep_structural bench_cfg2_n4096_keep_structural bench_scale_legs_1rank bench_under_rocprof_cfg4_n262144; do
+  [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
+done
+for f in issue_probe tile_sweep; do [ -f "$O/$f.log" ] && cp "$O/$f.log" "$P/${T}_$f.log"; done
+[ -f "$O/stats_cfg4_n262144_kernel_stats.csv" ] && cp "$O/stats_cfg4_n262144_kernel_stats.csv" "$P/${T}_kernel_stats_cfg4_f32_n262144.csv"
+[ -f "$O/stats_dyn_f32_kernel_stats.csv" ] && cp "$O/stats_dyn_f32_kernel_stats.csv" "$P/${T}_kernel_stats_dyn_alone_f32_n262144.csv"
+[ -f "$O/stats_dyn_f32_n32768_kernel_stats.csv" ] && cp "$O/stats_dyn_f32_n32768_kernel_stats.csv" "$P/${T}_kernel_stats_dyn_alone_f32_n32768.csv"
 [ -f "$O/bench_gpus2_bare.err" ] && cp "$O/bench_gpus2_bare.err" "$P/${T}_bench_gpus2_bare.log"
 [ -f "$O/n_sweep.csv" ] && cp "$O/n_sweep.csv" "$P/${T}_n_sweep.csv"
 [ -f "$O/qp_segments.txt" ] && cp "$O/qp_segments.txt" "$P/${T}_qp_segments.txt"

@@ -9,6 +9,12 @@ python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 ./tools/abi_smoke.bin > "$O/abi_smoke.log" 2>&1
 ./tools/fma_probe.bin > "$O/fma_probe.log" 2>&1
 ./tools/bw_probe.bin > "$O/bw_probe.log" 2>&1
+./tools/issue_probe.bin > "$O/issue_probe.log" 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver_flags_steps20.json" 2>> "$O/bench.err"
+WBC_KEEP_STRUCTURAL=1 python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144_keep_structural.json" 2>> "$O/bench.err"
+WBC_KEEP_STRUCTURAL=1 python bench.py --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n4096_keep_structural.json" 2>> "$O/bench.err"
+WBC_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-latency --large-batch 0 > "$O/bench_scale_legs_1rank.json" 2>> "$O/bench.err"
+bash tools/r03_tiles.sh > "$O/tile_sweep.log" 2>&1
 python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/bench.err"
 python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
 python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
@@ -39,6 +45,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5trk --
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n32768 -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch 32768 > "$O/bench_under_rocprof_n32768.json" 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg4_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 --config 4 > "$O/bench_under_rocprof_cfg4_n262144.json" 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_dyn_f32 -- python3 "$R/tools/dyn_only.py" 262144 f32 > /dev/null 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_dyn_f32_n32768 -- python3 "$R/tools/dyn_only.py" 32768 f32 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg4_n32768 -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch 32768 --config 4 > "$O/bench_under_rocprof_cfg4_n32768.json" 2>> "$O/rocprof.err"
 # the default bench command itself (incl. its N = 262 144 characterisation legs: tick sweep and the dynamics stage alone)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_default -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency > "$O/bench_under_rocprof_default.json" 2>> "$O/rocprof.err"

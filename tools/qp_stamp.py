@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import wbc_quadruped_dob_amd as W
 from wbc_quadruped_dob_amd import synth
 m = W.Model.from_urdf(W.SYNTHETIC_URDF)
-names = ["setup", "np,d,dn2", "z", "backsub", "steplen+commit", "add", "drop", "pick"]
+names = ["setup + x0 + first search", "candidate fetch, v, b, y = Ginv b, z.n", "directions, ratio test, speculative full step + next search", "-", "-", "commit + add (selects)", "drop path", "-"]   # structured body (qp_struct16.hip.hpp); the stamps themselves (s_memtime + lgkmcnt wait) cost ~100 cycles each
 for n in (4096, 262144):
     P = synth.default_params(); s = W.Solver(m, W.Params.from_dict(P), max_batch=n, options={"fused_max": 0, "qp_tile": -1})
     B = synth.make_batch(2, n, m.total_mass)
