@@ -316,12 +316,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     const T a_s = Np0 * np0 + Np1 * np1 + Np2 * np2;               // my slot's coefficient of n+ (foot kp only)
     const T r_me = (mine ? a_s : (T)0) - (Np0 * w0 + Np1 * w1 + Np2 * w2);
     const bool slot_act = isvar && c3 < qk;
-    // ---- chain 1: ratio test over the active multipliers
-    T t1k = (slot_act && r_me > 0) ? u_s * rcp_nr1(r_me) : KeyT<T>::BIG;
-    int kmin = l16;
-    const bool t1found = gargmin(t1k, kmin);
-    const T t1 = t1found ? t1k : INF;
-    // ---- chain 2: the full step and, at its end point, the next candidate (speculative: valid when the step is full).
+    // ---- the full step and, at its end point, the next candidate (speculative: valid when the step is full).
     // Linearly dependent on the active normals of its foot = no primal step: the dense method's test |d2| <= eps Rnorm, plus a
     // purely local one (v = P n+ is rounding noise of n+: P is kept by rank-one downdates, exact only to ~1e-16; the constraint
     // normals have |n|^2 between 1 and 1 + mu^2)
@@ -334,18 +329,19 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     T nval; int nid;
     const bool nfound = most_violated(dppx<0x00>(x_full), dppx<0x55>(x_full), dppx<0xAA>(x_full), sA_act, sB_act, nval, nid);
     SEG(1);
-    // ---- decide and commit (selects)
-    const bool infeas = go && !t1found && !indep;
-    status = infeas ? 2 : status;
-    done = done || infeas;
-    go = go && !infeas;
+    // ---- is the step full?  It is unless some active multiplier reaches zero first: u_j / r_j < t2 for a slot with r_j > 0 --
+    // tested as u_j < t2 r_j, no division, and "does any lane of my row say so" read off the wavefront's ballot.  The ratio
+    // test proper (reciprocal, row argmin for the blocking slot) is only needed when a row is NOT full: it lives in the rare
+    // branch below, off the path of the 98 % of the trips that add their candidate.
+    const bool pos = slot_act && r_me > 0;
+    const unsigned long long blk = __ballot(pos && (!indep || u_s < t2 * r_me));
+    const bool row_blk = (unsigned)((blk >> rowbase) & 0xFFFFull) != 0u;
+    const bool full = indep && !row_blk;
     const bool dual_only = !indep;
-    const bool full = indep && !(t1 < t2);
-    const bool addg = go && full, dropg = go && !full;
-    const T t = full ? t2 : t1;
-    x_me = addg ? x_full : ((dropg && !dual_only) ? x_me + t1 * z_me : x_me);
-    u_s = (go && slot_act) ? u_s - t * r_me : u_s;
-    u_c = go ? u_c + t : u_c;
+    const bool addg = go && full, slowg = go && !full;
+    x_me = addg ? x_full : x_me;
+    u_s = (addg && slot_act) ? u_s - t2 * r_me : u_s;
+    u_c = addg ? u_c + t2 : u_c;
     // full step: the candidate joins the active set of its foot
     {
       const T gy = addg ? yi * (rz * ralpha) : (T)0;                 // y_i / (alpha z . n+)
@@ -378,7 +374,19 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     }
     SEG(4);
     // ---- partial / dual-only step: the blocking constraint leaves its foot's active set (rare: wave-uniform branch)
-    if (__ballot(dropg) != 0ull) {
+    if (__ballot(slowg) != 0ull) {
+      // ratio test over the active multipliers of the rows that could not take their full step
+      T t1k = pos ? u_s * rcp_nr(r_me) : KeyT<T>::BIG;
+      int kmin = l16;
+      const bool t1found = gargmin(t1k, kmin);
+      const bool infeas = slowg && !t1found;           // (not full and nothing blocks: the step has no primal part and no bound)
+      status = infeas ? 2 : status;
+      done = done || infeas;
+      const bool dropg = slowg && t1found;
+      const T t1 = t1k;
+      x_me = (dropg && !dual_only) ? x_me + t1 * z_me : x_me;
+      u_s = (dropg && slot_act) ? u_s - t1 * r_me : u_s;
+      u_c = dropg ? u_c + t1 : u_c;
       const int kq = dropg ? kmin : 0;                 // lane (within the row) of the blocking slot
       const int kd = kq >> 2, sd = kq & 3;             // its foot and slot
       const int cid = gread(id_s, kq, rowbase);        // the constraint that leaves
