@@ -40,6 +40,27 @@ template <int CHAINS> __global__ void fma_f32(float* out, long long* cyc, float 
   out[threadIdx.x + blockIdx.x * blockDim.x] = s;
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// the same with only the first LANES lanes of the wavefront active (does the SIMD skip the idle quarters of a wave64 operation?)
+template <int CHAINS, int LANES> __global__ void fma_f64_masked(double* out, long long* cyc, double a, double b) {
+  double x[CHAINS];
+  for (int c = 0; c < CHAINS; ++c) x[c] = a + c + threadIdx.x;
+  long long t0 = 0, t1 = 0;
+  if (threadIdx.x < LANES) {
+    t0 = clock64();
+#pragma unroll 1
+    for (int i = 0; i < REP / CHAINS / 4; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) x[c] = __builtin_fma(x[c], b, a);
+    }
+    t1 = clock64();
+  }
+  double s = 0;
+  for (int c = 0; c < CHAINS; ++c) s += x[c];
+  out[threadIdx.x + blockIdx.x * blockDim.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 // dependent chain: dpp mov (32-bit x2) + min f64  (one step of the row argmin)
 __global__ void dpp_min(double* out, long long* cyc, double a) {
   double k = a + threadIdx.x;
@@ -132,6 +153,9 @@ int main() {
     RUN(fma_f64<2>, "v_fma_f64, 2 independent chains", REP, out, cyc, 1.0, 0.999);
     RUN(fma_f64<4>, "v_fma_f64, 4 independent chains", REP, out, cyc, 1.0, 0.999);
     RUN(fma_f64<8>, "v_fma_f64, 8 independent chains", REP, out, cyc, 1.0, 0.999);
+    RUN((fma_f64_masked<8, 32>), "v_fma_f64, 8 independent chains, 32 of 64 lanes active", REP, out, cyc, 1.0, 0.999);
+    RUN((fma_f64_masked<8, 16>), "v_fma_f64, 8 independent chains, 16 of 64 lanes active", REP, out, cyc, 1.0, 0.999);
+    RUN((fma_f64_masked<1, 16>), "v_fma_f64, 1 dependent chain, 16 of 64 lanes active", REP, out, cyc, 1.0, 0.999);
     RUN(fma_f32<1>, "v_fma_f32, 1 dependent chain", REP, outf, cyc, 1.0f, 0.999f);
     RUN(fma_f32<4>, "v_fma_f32, 4 independent chains", REP, outf, cyc, 1.0f, 0.999f);
     RUN(fma_f32<8>, "v_fma_f32, 8 independent chains", REP, outf, cyc, 1.0f, 0.999f);

@@ -26,37 +26,57 @@ __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<
 //      waits for another, rows of a group finish together (about 3 trips per group instead of 5.0), and the short groups
 //      at the end of the queue level the tail.
 // Results per state are those of qp_group16_kernel (same body, another assignment of states to rows).
+// WBC_QP_PRED_FINISH: a state whose unconstrained minimum x0 violates nothing IS solved (f = x0, zero iterations) -- the predictor
+// can write f, tau, status, iters itself (one state per lane) and report -1, and the row-form body, which pays its set-up per FOUR
+// states before it can tell, never sees it: 28 % of the states of the standing benchmark batch, 70 % of the trot / fp32 ones.
+// 1 (default): fp32 solvers only; 2: fp64 too; 0: off.  Measured on MI355X (QP stage, us, off -> on):
+//   fp32 trot batch  32 768: 24.3 -> 22.5    65 536: 38.5 -> 35.8    131 072: 74.9 -> 63.8
+//   fp64 standing    16 384: 22.2 -> 26.4    32 768: 35.2 -> 38.0    131 072 (tiles only): 120.6 -> 133.5    fp64 trot 32 768: 25.3 -> 23.6
+// fp64 loses: the predictor runs on ONE of the tile's four wavefronts, and full-accuracy fp64 reciprocal square roots (14 per state)
+// plus the finishing loads lengthen exactly that serial stretch by more than the skipped groups (set-up only, no trips) give back.
+// fp32 solvers, whose row form works in fp64, finish a state here only when every slack clears a 1e-3 N margin, so a decision fp32
+// rounding could flip is always left to the solver; the factor then uses Newton-refined reciprocal square roots.
+#ifndef WBC_PRED_UNROLL_C
+#define WBC_PRED_UNROLL_C 4
+#endif
+#ifndef WBC_PRED_UNROLL_F
+#define WBC_PRED_UNROLL_F 2   // feet per round of finishing loads (4: +38 VGPRs in fp64 -> two instead of three tiles per CU)
+#endif
+#ifndef WBC_QP_PRED_FINISH
+#define WBC_QP_PRED_FINISH 1
+#endif
 template <class T, bool RHAT>
-WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned s32, unsigned N32) {
+WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32) {
 #define PLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+  constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
   const int mask = a.mask[s32] & 0xF;
   const T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
-  T Dx[4], Dy[4], Dz[4], Of[4];
+  // (loops over the feet are NOT unrolled where they carry per-foot data: with Dx..Dz[4] and the four feet's normals in flight the
+  //  predictor needed 220-250 VGPRs -- more than the solver it serves; the lever arms are re-read, L2-hot, where they are needed)
+#define PLD_D(f_, dx_, dy_, dz_) do { \
+    if (a.Jc) { dx_ = PLD(a.Jc, (3 * (f_) + 1) * 18 + 5); dy_ = PLD(a.Jc, (3 * (f_) + 2) * 18 + 3); dz_ = PLD(a.Jc, (3 * (f_)) * 18 + 4); } \
+    else { dx_ = PLD(a.ws, WS_D + 3 * (f_)); dy_ = PLD(a.ws, WS_D + 3 * (f_) + 1); dz_ = PLD(a.ws, WS_D + 3 * (f_) + 2); } } while (0)
+  T nc = 0, sx = 0, sy = 0, sz = 0, Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const bool on = (mask >> f) & 1;
     T dx, dy, dz;
-    if (a.Jc) { dx = PLD(a.Jc, (3 * f + 1) * 18 + 5); dy = PLD(a.Jc, (3 * f + 2) * 18 + 3); dz = PLD(a.Jc, (3 * f) * 18 + 4); }
-    else { dx = PLD(a.ws, WS_D + 3 * f); dy = PLD(a.ws, WS_D + 3 * f + 1); dz = PLD(a.ws, WS_D + 3 * f + 2); }
-    Of[f] = on ? (T)1 : (T)0; Dx[f] = on ? dx : (T)0; Dy[f] = on ? dy : (T)0; Dz[f] = on ? dz : (T)0;
+    PLD_D(f, dx, dy, dz);
+    dx = on ? dx : (T)0; dy = on ? dy : (T)0; dz = on ? dz : (T)0;
+    nc += on ? (T)1 : (T)0; sx += dx; sy += dy; sz += dz;
+    Pxx += dx * dx; Pxy += dx * dy; Pxz += dx * dz; Pyy += dy * dy; Pyz += dy * dz; Pzz += dz * dz;
   }
   T bt[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) bt[k] = (a.wdes ? PLD(a.wdes, k) : PLD(a.ws, WS_B + k)) - (RHAT ? PLD(a.ws, WS_RHAT + k) : (T)0);
   // G = alpha I + B B^T and its factor, as in qp_group16_body (selection only: seed-accuracy reciprocal square roots)
-  const T nc = (Of[0] + Of[1]) + (Of[2] + Of[3]);
-  const T sx = (Dx[0] + Dx[1]) + (Dx[2] + Dx[3]), sy = (Dy[0] + Dy[1]) + (Dy[2] + Dy[3]), sz = (Dz[0] + Dz[1]) + (Dz[2] + Dz[3]);
-  T Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    Pxx += Dx[f] * Dx[f]; Pxy += Dx[f] * Dy[f]; Pxz += Dx[f] * Dz[f]; Pyy += Dy[f] * Dy[f]; Pyz += Dy[f] * Dz[f]; Pzz += Dz[f] * Dz[f];
-  }
   const T g00 = prm.alpha + s0 * s0 * nc, g11 = prm.alpha + s1 * s1 * nc, g22 = prm.alpha + s2 * s2 * nc;
   const T gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
   const T m00 = prm.alpha + (s3 * s3) * (Pyy + Pzz), m11 = prm.alpha + (s4 * s4) * (Pxx + Pzz), m22 = prm.alpha + (s5 * s5) * (Pxx + Pyy);
   const T m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
   auto rs = [](T x) __attribute__((always_inline)) -> T {
-    if constexpr (std::is_same<T, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
+    if constexpr (FIN) return rsqrt_nr(x);
+    else if constexpr (std::is_same<T, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
   };
   T il[6];
   il[0] = rs(g00); il[1] = rs(g11); il[2] = rs(g22);
@@ -81,13 +101,18 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned
   z[0] = (w[0] - a10 * z[4] - a20 * z[5]) * il[0];
   const T zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
   int cnt_all = 0;
+  bool fin_ok = true;   // every slack of every stance foot at or above the finishing threshold (false for a NaN state: the solver reports those)
+  const T fin_thr = std::is_same<T, double>::value ? -prm.qp_tol : (T)1e-3;
   T mag = 0;   // summed violation of the violated constraints
-#pragma unroll
+#pragma unroll WBC_PRED_UNROLL_C
   for (int f = 0; f < 4; ++f) {
     // x0 of foot f = on (s_f z_f + (s_m z_m) x d_f)
-    const T x0 = Of[f] * zf0 + (zm1 * Dz[f] - zm2 * Dy[f]);
-    const T x1 = Of[f] * zf1 + (zm2 * Dx[f] - zm0 * Dz[f]);
-    const T x2 = Of[f] * zf2 + (zm0 * Dy[f] - zm1 * Dx[f]);
+    const bool on = (mask >> f) & 1;
+    T dx, dy, dz;
+    PLD_D(f, dx, dy, dz);
+    const T x0 = on ? zf0 + (zm1 * dz - zm2 * dy) : (T)0;
+    const T x1 = on ? zf1 + (zm2 * dx - zm0 * dz) : (T)0;
+    const T x2 = on ? zf2 + (zm0 * dy - zm1 * dx) : (T)0;
     T nx = PLD(a.normals, 3 * f), ny = PLD(a.normals, 3 * f + 1), nz = PLD(a.normals, 3 * f + 2);
     const T iln = rs(nx * nx + ny * ny + nz * nz);
     nx *= iln; ny *= iln; nz *= iln;
@@ -105,10 +130,38 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, unsigned
     T mg = 0;
 #pragma unroll
     for (int c = 0; c < 6; ++c) { cnt += (sl[c] < tol) ? 1 : 0; mg += (sl[c] < tol) ? -sl[c] : (T)0; }
-    const bool on = (mask >> f) & 1;
+    bool okf = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) okf = okf && (sl[c] >= fin_thr);
+    fin_ok = fin_ok && (okf || !on);
     cnt_all += on ? cnt : 0;
     mag += on ? mg : (T)0;
   }
+  if (FIN && fin_ok) {   // solved: f = x0, tau = taup - rhat - Jc_leg^T f (the epilogue of qp_struct16_body, one state per lane)
+#define PST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
+#pragma unroll WBC_PRED_UNROLL_F
+    for (int f = 0; f < 4; ++f) {
+      const bool on = (mask >> f) & 1;
+      T dx, dy, dz;
+      PLD_D(f, dx, dy, dz);
+      const T fx = on ? zf0 + (zm1 * dz - zm2 * dy) : (T)0, fy = on ? zf1 + (zm2 * dx - zm0 * dz) : (T)0, fz = on ? zf2 + (zm0 * dy - zm1 * dx) : (T)0;
+      PST(a.f, 3 * f, fx); PST(a.f, 3 * f + 1, fy); PST(a.f, 3 * f + 2, fz);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int jm = jmap.j[3 * f + k];
+        const T taup = PLD(a.ws, WS_TAUP + 3 * f + k) - (RHAT ? PLD(a.ws, WS_RHAT + 6 + 3 * f + k) : (T)0);
+        T j0, j1, j2;
+        if (a.Jc) { j0 = PLD(a.Jc, (3 * f + 0) * 18 + 6 + jm); j1 = PLD(a.Jc, (3 * f + 1) * 18 + 6 + jm); j2 = PLD(a.Jc, (3 * f + 2) * 18 + 6 + jm); }
+        else { j0 = PLD(a.ws, WS_JCL + 9 * f + k); j1 = PLD(a.ws, WS_JCL + 9 * f + 3 + k); j2 = PLD(a.ws, WS_JCL + 9 * f + 6 + k); }
+        PST(a.tau, jm, taup - (j0 * fx + j1 * fy + j2 * fz));
+      }
+    }
+    a.status[s32] = 0;
+    if (a.iters) a.iters[s32] = 0;
+#undef PST
+    return -1;
+  }
+#undef PLD_D
 #undef PLD
   // fitted on the bench data (least squares on the iteration count): 0.52 count + 0.70 ln(1 + summed violation); three
   // buckets per predicted iteration.  Sorting by it: 2.96 trips per group (count alone 3.25, perfect knowledge 2.51).
@@ -135,7 +188,7 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
   if (tid < 64) hist[tid] = 0;
   if (tid == 0) next_grp = 0;
   __syncthreads();
-  // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = beyond the end (dealt last, not solved)
+  // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = finished by the predictor, or beyond the end (not dealt)
   int bucket[(TILE + 255) / 256], rank[(TILE + 255) / 256];
 #pragma unroll
   for (int r = 0; r < (TILE + 255) / 256; ++r) {
@@ -143,7 +196,10 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
     bucket[r] = 62; rank[r] = 0;
     if (i < TILE) {
       const size_t s = base + i;
-      if (s < N) bucket[r] = 61 - qp_predict_key<T, RHAT>(prm, a, (unsigned)s, N32);
+      if (s < N) {
+        const int key = qp_predict_key<T, RHAT>(prm, a, jmap, (unsigned)s, N32);
+        bucket[r] = key < 0 ? 62 : 61 - key;
+      }
       rank[r] = __hip_atomic_fetch_add(&hist[bucket[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
@@ -161,14 +217,14 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
   __syncthreads();
   // 3. the four wavefronts pull groups of four states, hardest first
   const int row = (int)((tid & 63) >> 4);
+  const int nsolve = TILE - hist[62];
   for (;;) {
     int g = 0;
     if ((tid & 63) == 0) g = __hip_atomic_fetch_add(&next_grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     g = __builtin_amdgcn_readfirstlane(g);
-    if (g >= TILE / 4) break;
-    if (base + order[4 * g] >= N) break;     // first (hardest) state of the group lies beyond the end: so does the rest of the queue
-    const size_t s = base + order[4 * g + row];
-    const bool live = s < N;
+    if (4 * g >= nsolve) break;
+    const bool live = 4 * g + row < nsolve;
+    const size_t s = base + order[live ? 4 * g + row : 0];
     if constexpr (DENSE) qp_group16_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
     else qp_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
   }
