@@ -342,6 +342,8 @@ def main():
             res["value_long_blocks"] = long_blocks
         if not args.no_latency and world == 1:
             res["qp_latency"] = qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs)
+        if not args.no_latency and world == 1:
+            res["qp_dense_general"] = qp_dense_general(W, torch, dtype)
         if fused and world == 1:
             res["roofline_dyn_sweep_alone"] = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
         if args.large_batch and world == 1:
@@ -610,6 +612,43 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
             "roofline": None, "cpu_baseline": None})
     if dist is not None:
         dist.destroy_process_group()
+
+
+def qp_dense_general(W, torch, dtype):
+    """The general dense QP kernel (wbc_qp_dense_batch: run-time sizes, one QP per wavefront, factors in LDS) on random strictly
+    convex problems generated on the device: the size of the controller's own GRF QP and the largest size it takes.  Reported beside
+    the structured path, not part of `value`."""
+    td = torch.float64 if dtype == "f64" else torch.float32
+    out = {}
+    for n, m, meq, N in ((12, 24, 0, 4096), (36, 48, 8, 4096)):
+        gen = torch.Generator(device="cuda").manual_seed(1234 + n)
+        A = torch.randn(N, n, n, dtype=torch.float64, device="cuda", generator=gen)
+        H = (A @ A.transpose(1, 2)) / n + torch.eye(n, dtype=torch.float64, device="cuda")
+        H = 0.5 * (H + H.transpose(1, 2))
+        xf = torch.randn(N, n, dtype=torch.float64, device="cuda", generator=gen)
+        Cm = torch.randn(N, m, n, dtype=torch.float64, device="cuda", generator=gen)
+        slack = torch.rand(N, m, dtype=torch.float64, device="cuda", generator=gen)
+        slack[:, :meq] = 0
+        d = torch.einsum("kij,kj->ki", Cm, xf) - slack
+        g = -torch.einsum("kij,kj->ki", H, xf + 2 * torch.randn(N, n, dtype=torch.float64, device="cuda", generator=gen))
+        H, g, Cm, d = (t.to(td).contiguous() for t in (H, g, Cm, d))
+        tol = 1e-9 if dtype == "f64" else 1e-3
+        for _ in range(3):
+            o = W.qp_dense_batch(H, g, Cm, d, meq=meq, max_iter=400, tol=tol)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            o = W.qp_dense_batch(H, g, Cm, d, meq=meq, max_iter=400, tol=tol)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out["n%d_m%d_meq%d" % (n, m, meq)] = {"batch": N, "launch_us": us, "qps_per_s": N / us * 1e6, "iters_mean": float(o["iters"].double().mean()),
+                                            "status_ok_frac": float((o["status"] == 0).double().mean())}
+    out["note"] = ("random feasible problems (H = A A^T / n + I, a third of the rows active at the optimum), same-stream back-to-back launches; the "
+                   "controller's own 12-variable GRF QP goes through the structured kernels instead (kernels.qp_us)")
+    return out
 
 
 def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):

@@ -321,9 +321,27 @@ int wbc_multi_synchronize(wbc_multi* mm);                   /* waits for every s
 int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batch_in* host_in, const wbc_batch_out* host_out,
                         const wbc_observer_state* host_obs);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Dense QPs of run-time size -- the general path beside the controller's own 12-variable GRF QP (which wbc_step_batch solves
+ * with kernels written around its structure).  Replaces: whatever QP library the reference controller links for its
+ * "optimization problem based on the modulation of ground reaction forces" (/root/reference/README.md:11; the source is an
+ * absent submodule, .gitmodules:4-6, so its variable set is unknown -- a formulation that also carries accelerations, slacks or
+ * joint-torque rows is assembled by the caller and solved here).
+ *
+ *     min 1/2 x^T H x + g^T x    s.t.   C_i x = d_i (i < meq),   C_i x >= d_i (meq <= i < m);    1 <= n <= 36, 0 <= m <= 48
+ *
+ * All pointers are DEVICE pointers on the current device, PROBLEM-major (one problem's data contiguous): H [N][n*n] row-major,
+ * symmetric positive definite (both triangles given, the lower one is read); g [N][n]; C [N][m*n] row-major; d [N][m]; x [N][n];
+ * lambda [N][m] or NULL (multipliers: >= 0 for inequality rows, any sign for equality rows; 0 for inactive rows); status [N]:
+ * 0 optimal, 1 iteration limit, 2 infeasible, 3 H not positive definite; iters [N] or NULL.  One QP per wavefront, factors and
+ * working set in LDS (Goldfarb-Idnani dual active set); enqueued on hipStream (NULL = the default stream), returns without
+ * synchronising.  dtype: WBC_F64 / WBC_F32 = the scalar type of every array and of the arithmetic. */
+int wbc_qp_dense_batch(int dtype, size_t N, int n, int m, int meq, const void* H, const void* g, const void* C, const void* d,
+                       int max_iter, double tol, void* x, void* lambda, int* status, int* iters, void* hipStream);
+
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void); /* 4 */
+int wbc_abi_version(void); /* 5 */
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ _LIB = os.path.join(_HERE, "_build", "libwbc_oracle.so")
 def build(force=False):
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
-            for f in ("wbc_oracle.hpp", "wbc_oracle_capi.cpp", "op_count.cpp")):
+            for f in ("wbc_oracle.hpp", "wbc_oracle_capi.cpp", "op_count.cpp", "qp_general.hpp")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB
 
@@ -284,6 +284,33 @@ def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9):
     fn.restype = C.c_int
     ct = C.c_double if dt == np.float64 else C.c_float
     it = fn(n, m, _p(H), _p(g), _p(Cm), _p(d), int(max_iter), ct(tol), _p(x), _p(lam), C.byref(st))
+    return x, lam[:m], st.value, it
+
+
+def qp_general(H, g, Cm, d, meq=0, max_iter=200, tol=1e-9):
+    """qp_general.hpp: min 1/2 x'Hx + g'x  s.t.  Cm[:meq] x = d[:meq], Cm[meq:] x >= d[meq:]   (n <= 36, m <= 48).
+    One problem (H[n,n]) or a batch (H[N,n,n], ...; fp64 only).  Returns x, lambda, status, iters."""
+    H = np.asarray(H)
+    if H.ndim == 3:
+        N, n = H.shape[0], H.shape[1]
+        m = np.asarray(d).shape[1]
+        c = lambda a: np.ascontiguousarray(a, np.float64)
+        H, g, Cm, d = c(H), c(g), c(Cm).reshape(N, max(m, 0) * n), c(d)
+        x, lam = np.zeros((N, n)), np.zeros((N, max(m, 1)))
+        st, it = np.zeros(N, np.int32), np.zeros(N, np.int32)
+        lib().wbco_qp_general_batch_f64(N, n, m, int(meq), _p(H), _p(g), _p(Cm), _p(d), int(max_iter), C.c_double(tol), _p(x), _p(lam) if m else _p(lam),
+                                        _p(st), _p(it), 8)
+        return x, lam[:, :m], st, it
+    dt = H.dtype if H.dtype in (np.float32, np.float64) else np.float64
+    n, m = len(g), len(d)
+    H, g, Cm, d = (np.ascontiguousarray(a, dtype=dt) for a in (H, g, Cm, d))
+    x = np.zeros(n, dt)
+    lam = np.zeros(max(m, 1), dt)
+    st = C.c_int(0)
+    fn = getattr(lib(), "wbco_qp_general_" + Oracle._suf(dt))
+    fn.restype = C.c_int
+    ct = C.c_double if dt == np.float64 else C.c_float
+    it = fn(n, m, int(meq), _p(H), _p(g), _p(Cm), _p(d), int(max_iter), ct(tol), _p(x), _p(lam), C.byref(st))
     return x, lam[:m], st.value, it
 
 

@@ -3,6 +3,7 @@
 // bench.py's cpu_baseline leg load this library; the product never does.
 // Batch layout here is row-per-state (AoS, numpy-natural): x[N][ncomp].
 #include "wbc_oracle.hpp"
+#include "qp_general.hpp"
 #include <chrono>
 #include <new>
 
@@ -191,6 +192,24 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
 
 DEF_API(f64, double, md)
 DEF_API(f32, float, mf)
+
+// general dense QP with equality rows (qp_general.hpp): C_i x = d_i for i < meq, C_i x >= d_i after
+int wbco_qp_general_f64(int n, int m, int meq, const double* H, const double* g, const double* C, const double* d, int max_iter,
+                        double tol, double* x, double* lambda, int* status) {
+  return qp_solve_gi_general<double>(n, m, meq, H, g, C, d, max_iter, tol, x, lambda, status);
+}
+int wbco_qp_general_f32(int n, int m, int meq, const float* H, const float* g, const float* C, const float* d, int max_iter,
+                        float tol, float* x, float* lambda, int* status) {
+  return qp_solve_gi_general<float>(n, m, meq, H, g, C, d, max_iter, tol, x, lambda, status);
+}
+// ... over a batch (arrays of N problems of one size, problem-major), OpenMP over problems
+void wbco_qp_general_batch_f64(int N, int n, int m, int meq, const double* H, const double* g, const double* C, const double* d,
+                               int max_iter, double tol, double* x, double* lambda, int* status, int* iters, int nthreads) {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int s = 0; s < N; ++s)
+    iters[s] = qp_solve_gi_general<double>(n, m, meq, H + (size_t)s * n * n, g + (size_t)s * n, C + (size_t)s * m * n, d + (size_t)s * m,
+                                           max_iter, tol, x + (size_t)s * n, lambda + (size_t)s * m, status + s);
+}
 
 // Per-QP wall time on one thread (SURVEY.md 8d "CPU: p50 of per-QP wall time over the batch"): for every state the
 // dynamics run untimed, then {a7 assembly + a8 solve} is timed with steady_clock; ns_out[N], iters_out[N] (may be null).

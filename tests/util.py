@@ -28,3 +28,19 @@ def to_dev(x, torch, dtype):
 def to_host(t):
     """component-major device tensor [c, N] -> row-per-state numpy [N, c]"""
     return t.detach().cpu().numpy().T.copy()
+
+
+def random_problem(rng, n, m, meq, cond=1e3):
+    """A feasible strictly convex QP (H, g, C, d) with m rows, the first meq of them equalities: H = Q diag(1 .. cond) Q^T, rows of C
+    random with a third of the inequalities tight or violated at the unconstrained minimum, feasibility guaranteed by construction
+    around a random point (d = C x_feas - nonnegative slack; equality rows hold exactly there; needs meq <= n)."""
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    H = (Q * np.geomspace(1.0, cond, n)) @ Q.T
+    H = 0.5 * (H + H.T)
+    xf = rng.normal(size=n)
+    C = rng.normal(size=(m, n))
+    slack = np.abs(rng.normal(size=m)) * (rng.random(m) < 0.7)
+    slack[:meq] = 0
+    d = C @ xf - slack
+    g = -H @ (xf + rng.normal(size=n) * 2.0)     # the unconstrained minimum sits away from the feasible point
+    return H, g, C, d

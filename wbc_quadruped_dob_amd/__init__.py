@@ -194,6 +194,7 @@ def lib():
         L.wbc_reference_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4
         L.wbc_compute_reference.argtypes = [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 3
         L.wbc_rollout_tracking_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 8
+        L.wbc_qp_dense_batch.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_double] + [C.c_void_p] * 5
         _lib = L
     return _lib
 
@@ -517,6 +518,37 @@ def shard_range(n_total, n_shards, shard):
     st, cnt = C.c_size_t(), C.c_size_t()
     _check(lib().wbc_shard_range(n_total, n_shards, shard, C.byref(st), C.byref(cnt)), "wbc_shard_range")
     return st.value, cnt.value
+
+
+def qp_dense_batch(H, g, Cm=None, d=None, meq=0, max_iter=200, tol=None, want_lambda=True, stream=None):
+    """wbc_qp_dense_batch: N dense QPs of one run-time size, one per wavefront (csrc/qp_general.hip.hpp).
+        min 1/2 x'Hx + g'x   s.t.   Cm[:, :meq] x = d[:, :meq],   Cm[:, meq:] x >= d[:, meq:]
+    H [N, n, n], g [N, n], Cm [N, m, n], d [N, m]: contiguous CUDA tensors of one dtype (float64 / float32), n <= 36, m <= 48.
+    Returns dict(x [N, n], lam [N, m] | None, status [N] int32 (0 ok, 1 iteration limit, 2 infeasible, 3 H not PD), iters [N]).
+    Enqueued on `stream` (default: torch's current stream); does not synchronise."""
+    import torch
+    if H.dtype not in (torch.float64, torch.float32):
+        raise TypeError("H must be float64 or float32")
+    N, n = int(H.shape[0]), int(H.shape[1])
+    m = 0 if Cm is None else int(Cm.shape[1])
+    ts = [H, g] + ([Cm, d] if m else [])
+    for t in ts:
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == H.dtype and int(t.shape[0]) == N):
+            raise ValueError("qp_dense_batch: contiguous CUDA tensors of one dtype and one batch size")
+    if tuple(H.shape) != (N, n, n) or tuple(g.shape) != (N, n) or (m and (tuple(Cm.shape) != (N, m, n) or tuple(d.shape) != (N, m))):
+        raise ValueError("qp_dense_batch: shapes H [N,n,n], g [N,n], Cm [N,m,n], d [N,m]")
+    if tol is None:
+        tol = 1e-9 if H.dtype == torch.float64 else 1e-4
+    x = torch.empty((N, n), dtype=H.dtype, device=H.device)
+    lam = torch.empty((N, m), dtype=H.dtype, device=H.device) if (want_lambda and m) else None
+    status = torch.empty(N, dtype=torch.int32, device=H.device)
+    iters = torch.empty(N, dtype=torch.int32, device=H.device)
+    st = (stream if stream is not None else torch.cuda.current_stream(H.device)).cuda_stream
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    with torch.cuda.device(H.device):
+        _check(lib().wbc_qp_dense_batch(0 if H.dtype == torch.float64 else 1, N, n, m, int(meq), p(H), p(g), p(Cm) if m else None, p(d) if m else None,
+                                        int(max_iter), float(tol), p(x), p(lam), p(status), p(iters), C.c_void_p(st)), "wbc_qp_dense_batch")
+    return {"x": x, "lam": lam, "status": status, "iters": iters}
 
 
 GATHER_NONE, GATHER_RCCL, GATHER_PEER_COPY = 0, 1, 2

@@ -1,0 +1,291 @@
+// qp_general_kernel: a strictly convex dense QP of RUN-TIME size, one per WAVEFRONT, factors and working set in LDS.
+//
+//     min 1/2 x^T H x + g^T x     s.t.   C_i x  = d_i  (i <  meq),     C_i x >= d_i  (meq <= i < m),      n <= 36,  m <= 48
+//
+// Why it exists: the GRF QP of this controller (units a7 / a8) is the structured 12-variable problem the kernels of
+// qp_struct16.hip.hpp / qp_lane.hip.hpp are written around, and that shape is a GUESS about the reference: README.md:11 says only
+// "optimization problem based on the modulation of ground reaction forces", the controller's source is an absent submodule
+// (.gitmodules:4-6).  A formulation with other variables (accelerations, slacks, joint-torque rows) does not fit those kernels at
+// all.  This one takes any (H, g, C, d) -- the survey's "parametric in nvar <= 36, ncon <= 48", and the north_star's "one QP per
+// wavefront with active-set iterations held in LDS" literally.  It is the general path, not the fast one (the 12-variable GRF QP
+// through it: see DESIGN.md section 4.2b for the measured factor).
+//
+// Method: Goldfarb-Idnani dual active set, as oracle/qp_general.hpp (same steps, same tests, same status codes, so iteration
+// counts agree) with the wavefront's 64 lanes as the vector unit:
+//   lane i  <-> variable i (x_i, row i of J), constraint i (its slack, d_i, active flag) and active-set SLOT i (constraint id, u, sign)
+//   LDS     <-> J = L^-T Q (n x n), R (n x n, upper), C (m x n), the vectors every lane reads (x, np, dd, z, rotation coefficients)
+//   matrices are stored with an ODD leading dimension: a lane-per-row access (stride ld) and a lane-per-column access (stride 1)
+//   are both bank-conflict-free.
+// Two places depart from the oracle's operation ORDER (not from its mathematics; results agree to rounding):
+//   * r = R^-1 d1 by column-oriented back substitution (one broadcast per column instead of a dot product per row);
+//   * the Givens chain that rotates d2 into its first component: its coefficients are c_j = d_{j-1} / s_{j-1}, s_j / s_{j-1} with the
+//     suffix norms s_j = |d_{j..n-1}| (s_{n-1} = d_{n-1}, signed), so they are all known up front (one reverse scan) and every lane then applies the whole chain to
+//     ITS row of J as a private recurrence -- no cross-lane dependency, LDS traffic pipelined -- instead of n - q - 1 dependent
+//     wavefront-wide steps.
+// One wavefront works alone on its QP: every branch below is wavefront-uniform, the only synchronisation is the program order of
+// one wavefront's LDS operations (made explicit for the compiler by wsync()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "qp_general_args.hpp"
+
+namespace wbc {
+
+template <class T> struct QpgLim;
+template <> struct QpgLim<double> { static constexpr double eps = 2.220446049250313e-16, big = 1.0e300; };
+template <> struct QpgLim<float> { static constexpr float eps = 1.1920929e-07f, big = 1.0e30f; };
+
+#define QPG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+template <class T> __device__ __forceinline__ T qpg_wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// minimum and the LOWEST lane that holds it (the oracle's "first smallest")
+template <class T> __device__ __forceinline__ void qpg_wave_argmin(T& v, int& idx) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const T ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    const bool take = ov < v || (ov == v && oi < idx);
+    v = take ? ov : v; idx = take ? oi : idx;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int lds_per_qp) {
+  extern __shared__ __align__(16) unsigned char qpg_lds_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const size_t qp = (size_t)blockIdx.x * wpb + wave;
+  if (qp >= a.N) return;   // (whole wavefronts leave: no workgroup barrier anywhere below)
+  const int n = a.n, m = a.m, meq = a.meq, ld = qpg_ld(n);
+  T* const S = (T*)qpg_lds_raw + (size_t)wave * lds_per_qp;
+  T* const J = S;                      // n x ld
+  T* const R = J + n * ld;             // n x ld   (holds H, then L, until the first constraint is added)
+  T* const Cm = R + n * ld;            // m x ld
+  T* const xs = Cm + m * ld;           // n+1 each:
+  T* const nps = xs + (n + 1);
+  T* const dds = nps + (n + 1);
+  T* const zs = dds + (n + 1);
+  T* const ccs = zs + (n + 1);
+  T* const sss = ccs + (n + 1);
+  T* const lam = sss + (n + 1);        // m+1
+  const T INF = QpgLim<T>::big, eps = QpgLim<T>::eps;
+
+  // ---- inputs (coalesced: consecutive lanes, consecutive elements of the problem's own block)
+  const T* Hq = a.H + qp * (size_t)n * n;
+  for (int e = lane; e < n * n; e += 64) { const int i = e / n, j = e - i * n; R[i * ld + j] = Hq[e]; }
+  const T* Cq = a.C + qp * (size_t)m * n;
+  for (int e = lane; e < m * n; e += 64) { const int i = e / n, j = e - i * n; Cm[i * ld + j] = Cq[e]; }
+  const T g_i = lane < n ? a.g[qp * n + lane] : (T)0;
+  const T d_i = lane < m ? a.d[qp * m + lane] : (T)0;
+  if (lane <= m) lam[lane] = 0;
+  int status = 0, iter = 0;
+  QPG_WSYNC();
+
+  // ---- Cholesky H = L L^T in place (lower triangle of the R area), column by column; lane i owns row i
+  bool notpd = false;
+  for (int j = 0; j < n; ++j) {
+    T s = 0;
+    if (lane >= j && lane < n) {
+      s = R[lane * ld + j];
+      for (int k = 0; k < j; ++k) s -= R[lane * ld + k] * R[j * ld + k];
+    }
+    const T sjj = __shfl(s, j, 64);
+    if (!(sjj > 0)) { notpd = true; break; }
+    const T ljj = sqrt(sjj);
+    if (lane >= j && lane < n) R[lane * ld + j] = (lane == j) ? ljj : s / ljj;
+    QPG_WSYNC();
+  }
+  if (notpd) {   // not positive definite: nothing to solve
+    if (lane < n) a.x[qp * n + lane] = 0;
+    if (a.lambda && lane < m) a.lambda[qp * m + lane] = 0;
+    if (lane == 0) { a.status[qp] = 3; if (a.iters) a.iters[qp] = 0; }
+    return;
+  }
+  // ---- J = L^-T (upper triangular): lane c solves L^T J[:, c] = e_c from the bottom up
+  if (lane < n) {
+    const int c = lane;
+    for (int i = n - 1; i >= 0; --i) {
+      T s = (i == c) ? (T)1 : (T)0;
+      if (i <= c) { for (int k = i + 1; k <= c; ++k) s -= R[k * ld + i] * J[k * ld + c]; s /= R[i * ld + i]; }
+      else s = 0;
+      J[i * ld + c] = s;
+    }
+  }
+  QPG_WSYNC();
+  // ---- unconstrained minimum x = -J J^T g
+  T x_i = 0;
+  {
+    if (lane < n) nps[lane] = g_i;
+    QPG_WSYNC();
+    T t = 0;
+    if (lane < n) for (int k = 0; k < n; ++k) t += J[k * ld + lane] * nps[k];
+    if (lane < n) zs[lane] = t;
+    QPG_WSYNC();
+    if (lane < n) { T s = 0; for (int k = 0; k < n; ++k) s += J[lane * ld + k] * zs[k]; x_i = -s; xs[lane] = x_i; }
+    QPG_WSYNC();
+  }
+
+  // ---- dual active-set iterations
+  int iq = 0, neq_in = 0, next_eq = 0;
+  bool active_i = false;        // constraint `lane` is in the active set
+  int A_s = -1;                 // slot `lane`: constraint id, multiplier, sign of its normal
+  T u_s = 0, sg_s = 1;
+  T Rnorm = 1;
+  bool finished = false;
+  while (!finished) {
+    // step 1: the next equality row, else the most violated inactive inequality
+    T s_i = 0;
+    if (lane < m) { s_i = -d_i; for (int k = 0; k < n; ++k) s_i += Cm[lane * ld + k] * xs[k]; }
+    int ip; T sip, sign = 1; bool is_eq = false;
+    if (next_eq < meq) {
+      const T s = __shfl(s_i, next_eq, 64);
+      ip = next_eq++; is_eq = true; sign = s > 0 ? (T)-1 : (T)1; sip = -fabs(s);
+    } else {
+      T v = (lane >= meq && lane < m && !active_i && s_i < -a.tol) ? s_i : INF;
+      int id = lane;
+      qpg_wave_argmin(v, id);
+      if (!(v < INF)) break;
+      ip = id; sip = v;
+    }
+    const T np_i = lane < n ? sign * Cm[ip * ld + lane] : (T)0;
+    if (lane < n) nps[lane] = np_i;
+    if (lane == iq) { A_s = ip; u_s = 0; sg_s = sign; }
+    QPG_WSYNC();
+    // step 2
+    for (;;) {
+      if (++iter > a.max_iter) { status = 1; finished = true; break; }
+      T dd_i = 0;
+      if (lane < n) for (int k = 0; k < n; ++k) dd_i += J[k * ld + lane] * nps[k];
+      if (lane < n) dds[lane] = dd_i;
+      QPG_WSYNC();
+      T z_i = 0;
+      if (lane < n) for (int j = iq; j < n; ++j) z_i += J[lane * ld + j] * dds[j];
+      // r = R^-1 d1 (column-oriented): lane i < iq
+      T r_s = 0;
+      {
+        T s = lane < iq ? dd_i : (T)0;
+        for (int j = iq - 1; j >= 0; --j) {
+          const T rj = __shfl(s, j, 64) / R[j * ld + j];
+          if (lane == j) r_s = rj;
+          if (lane < j) s -= R[lane * ld + j] * rj;
+        }
+      }
+      // ratio test over the inequality slots
+      T t1 = (lane >= neq_in && lane < iq && r_s > 0) ? u_s / r_s : INF;
+      int lslot = lane;
+      qpg_wave_argmin(t1, lslot);
+      const T dn2 = qpg_wave_sum((lane >= iq && lane < n) ? dd_i * dd_i : (T)0);
+      const T znp = qpg_wave_sum(z_i * np_i);
+      T t2 = INF;
+      if (dn2 > (eps * Rnorm) * (eps * Rnorm) && znp > 0) t2 = -sip / znp;
+      const bool no1 = !(t1 < INF), no2 = !(t2 < INF);
+      bool do_drop = false;
+      if (no1 && no2) {
+        if (is_eq && -sip <= a.tol) {   // dependent equality row that already holds: leave it out of the factors
+          if (lane == iq) { A_s = -1; u_s = 0; sg_s = 1; }
+          if (lane == ip) active_i = true;
+          break;
+        }
+        status = 2; finished = true; break;
+      }
+      if (no2) {   // dual step only
+        if (lane < iq) u_s -= t1 * r_s;
+        if (lane == iq) u_s += t1;
+        do_drop = true;
+      } else {
+        const bool full = !(t1 < t2);
+        const T t = full ? t2 : t1;
+        if (lane < n) { x_i += t * z_i; xs[lane] = x_i; }
+        if (lane < iq) u_s -= t * r_s;
+        if (lane == iq) u_s += t;
+        if (full) {
+          // rotate d2 = dd[iq .. n) into its first component; same rotations on the columns of J (see the header)
+          const T sq = (lane >= iq && lane < n) ? dd_i * dd_i : (T)0;
+          T suf = sq;   // suffix sums over lanes: suf_j = sum_{k >= j} dd_k^2
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) { const T up = __shfl_down(suf, o, 64); suf += (lane + o < 64) ? up : (T)0; }
+          const T sig = sqrt(suf);
+          const T sig_lo = __shfl_up(sig, 1, 64), dd_lo = __shfl_up(dd_i, 1, 64);   // sigma_{j-1}, dd_{j-1}
+          if (lane > iq && lane < n) {
+            const bool idn = !(sig_lo > 0);
+            ccs[lane] = idn ? (T)1 : dd_lo / sig_lo;
+            sss[lane] = idn ? (T)0 : (lane == n - 1 ? dd_i : sig) / sig_lo;   // (the chain starts from the LAST component itself, sign and all)
+          }
+          // the new R diagonal: the norm of d2 -- except when d2 has ONE component (iq = n - 1): no rotation happens, the component
+          // keeps its sign (R[iq][iq] must stay J[:, iq] . n+)
+          const T dq = (iq == n - 1) ? __shfl(dd_i, iq, 64) : __shfl(sig, iq, 64);
+          QPG_WSYNC();
+          if (lane < n) {
+            T t_hi = J[lane * ld + (n - 1)];
+            for (int j = n - 1; j > iq; --j) {
+              const T cc = ccs[j], ss = sss[j];
+              const T a1 = J[lane * ld + j - 1];
+              J[lane * ld + j] = -ss * a1 + cc * t_hi;
+              t_hi = cc * a1 + ss * t_hi;
+            }
+            J[lane * ld + iq] = t_hi;
+          }
+          if (lane < iq) R[lane * ld + iq] = dd_i;
+          if (lane == iq) R[iq * ld + iq] = dq;
+          Rnorm = fmax(Rnorm, fabs(dq));
+          if (lane == ip) active_i = true;
+          if (is_eq) ++neq_in;
+          ++iq;
+          QPG_WSYNC();
+          break;
+        }
+        do_drop = true;
+      }
+      if (do_drop) {   // slot lslot leaves the active set; the candidate moves down with the slots behind it
+        const int qq = lslot;
+        const int lcon = __shfl(A_s, qq, 64);
+        if (lane == lcon) active_i = false;
+        {
+          const int A_n = __shfl_down(A_s, 1, 64); const T u_n = __shfl_down(u_s, 1, 64), sg_n = __shfl_down(sg_s, 1, 64);
+          if (lane >= qq && lane < iq) { A_s = A_n; u_s = u_n; sg_s = sg_n; }
+          if (lane == iq) { A_s = -1; u_s = 0; sg_s = 1; }
+        }
+        if (lane < n) for (int c = qq; c < iq - 1; ++c) R[lane * ld + c] = R[lane * ld + c + 1];   // my row: columns shift left
+        --iq;
+        QPG_WSYNC();
+        for (int j = qq; j < iq; ++j) {   // re-triangularise the Hessenberg part
+          T cc = R[j * ld + j], ss = R[(j + 1) * ld + j];
+          const T h = sqrt(cc * cc + ss * ss);
+          if (h == 0) continue;
+          cc /= h; ss /= h;
+          QPG_WSYNC();   // every lane has read the pair before anybody overwrites it
+          if (lane == j) { R[(j + 1) * ld + j] = 0; R[j * ld + j] = h; }
+          if (lane > j && lane < iq) {
+            const T t1_ = R[j * ld + lane], t2_ = R[(j + 1) * ld + lane];
+            R[j * ld + lane] = cc * t1_ + ss * t2_;
+            R[(j + 1) * ld + lane] = -ss * t1_ + cc * t2_;
+          }
+          if (lane < n) {
+            const T t1_ = J[lane * ld + j], t2_ = J[lane * ld + j + 1];
+            J[lane * ld + j] = cc * t1_ + ss * t2_;
+            J[lane * ld + j + 1] = -ss * t1_ + cc * t2_;
+          }
+          QPG_WSYNC();
+        }
+        if (!no2) {   // it was a partial step: the candidate's slack at the new point
+          T s = 0;
+          if (lane < n) s = Cm[ip * ld + lane] * x_i;
+          s = qpg_wave_sum(s) - __shfl(d_i, ip, 64);
+          sip = sign * s;
+        }
+      }
+    }
+  }
+
+  // ---- outputs
+  if (lane < iq && A_s >= 0) lam[A_s] = sg_s * u_s;
+  QPG_WSYNC();
+  if (lane < n) a.x[qp * n + lane] = x_i;
+  if (a.lambda && lane < m) a.lambda[qp * m + lane] = lam[lane];
+  if (lane == 0) { a.status[qp] = status; if (a.iters) a.iters[qp] = iter; }
+}
+
+}  // namespace wbc

@@ -1017,6 +1017,34 @@ extern "C" int wbc_compute_reference(wbc_solver* s, const double* q, const doubl
   return WBC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dense QPs of run-time size (qp_general.hip.hpp); stateless: no solver handle, the current device
+template <class T>
+static int qp_dense_launch(size_t N, int n, int m, int meq, const void* H, const void* g, const void* C, const void* d, int max_iter, double tol,
+                           void* x, void* lambda, int* status, int* iters, hipStream_t st) {
+  wbc::QpGeneralArgs<T> a;
+  a.N = N; a.n = n; a.m = m; a.meq = meq; a.max_iter = max_iter; a.tol = (T)tol;
+  a.H = (const T*)H; a.g = (const T*)g; a.C = (const T*)C; a.d = (const T*)d;
+  a.x = (T*)x; a.lambda = (T*)lambda; a.status = status; a.iters = iters;
+  wbc::LaunchCtx L;
+  L.st = st;
+  HIP_TRY(wbc::k_qp_general<T>(L, a));
+  return WBC_OK;
+}
+extern "C" int wbc_qp_dense_batch(int dtype, size_t N, int n, int m, int meq, const void* H, const void* g, const void* C, const void* d,
+                                  int max_iter, double tol, void* x, void* lambda, int* status, int* iters, void* hipStream) {
+  if (dtype != WBC_F64 && dtype != WBC_F32) return fail(WBC_E_INVALID, "dtype must be WBC_F64 or WBC_F32");
+  if (n < 1 || n > wbc::QPG_MAXN || m < 0 || m > wbc::QPG_MAXM || meq < 0 || meq > m)
+    return fail(WBC_E_INVALID, "sizes: 1 <= n <= 36, 0 <= meq <= m <= 48");
+  if (!H || !g || !x || !status || (m > 0 && (!C || !d))) return fail(WBC_E_INVALID, "null argument");
+  if (max_iter < 0 || !(tol >= 0)) return fail(WBC_E_INVALID, "max_iter >= 0, tol >= 0");
+  if (N == 0) return WBC_OK;
+  if (N > (size_t)0x7FFFFFFF) return fail(WBC_E_CAPACITY, "N exceeds 2^31 - 1");
+  hipStream_t st = (hipStream_t)hipStream;
+  return dtype == WBC_F64 ? qp_dense_launch<double>(N, n, m, meq, H, g, C, d, max_iter, tol, x, lambda, status, iters, st)
+                          : qp_dense_launch<float>(N, n, m, meq, H, g, C, d, max_iter, tol, x, lambda, status, iters, st);
+}
+
 extern "C" const char* wbc_strerror(int st) {
   switch (st) {
     case WBC_OK: return "ok";
@@ -1031,4 +1059,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 4; }  // 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
+extern "C" int wbc_abi_version(void) { return 5; }  // 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
