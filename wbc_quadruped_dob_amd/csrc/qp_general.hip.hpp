@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "qp_general_args.hpp"
+#include "qp_group16.hip.hpp"   // dppx, gsum, KeyT (DPP helpers of the 16-lane solver)
 
 namespace wbc {
 
@@ -37,20 +38,68 @@ template <> struct QpgLim<float> { static constexpr float eps = 1.1920929e-07f, 
 
 #define QPG_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-template <class T> __device__ __forceinline__ T qpg_wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Cross-lane plumbing of one wavefront, DPP and v_readlane only (a ds_bpermute round trip costs ~10x a DPP move, and the loop below
+// is a chain of such steps): reductions go 4 DPP steps inside each 16-lane row, then the four row results are combined through
+// v_readlane (wavefront-uniform values).
+__device__ __forceinline__ double qpg_rl(double v, int lane) {   // `lane` must be wavefront-uniform
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xFFFFFFFFll), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// minimum and the LOWEST lane that holds it (the oracle's "first smallest")
+__device__ __forceinline__ float qpg_rl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int qpg_rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// value of a lane whose index every lane agrees on but the compiler cannot know to be uniform
+template <class T> __device__ __forceinline__ T qpg_rl_dyn(T v, int lane) { return qpg_rl(v, __builtin_amdgcn_readfirstlane(lane)); }
+template <class T> __device__ __forceinline__ T qpg_wave_sum(T v) {
+  v = gsum(v);
+  return (qpg_rl(v, 0) + qpg_rl(v, 16)) + (qpg_rl(v, 32) + qpg_rl(v, 48));
+}
+// minimum and (one of) the lane(s) that hold it, the lowest on an exact tie; BIG = "no candidate".  Selection by the packed key of
+// qp_group16.hip.hpp (lane id in the low mantissa bits), the EXACT value of the winner is then read from its lane.
 template <class T> __device__ __forceinline__ void qpg_wave_argmin(T& v, int& idx) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const T ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(idx, o, 64);
-    const bool take = ov < v || (ov == v && oi < idx);
-    v = take ? ov : v; idx = take ? oi : idx;
+  using K = KeyT<T>;
+  T k = K::pack(v, idx);
+  k = K::mn(k, dppx<0xB1>(k)); k = K::mn(k, dppx<0x4E>(k)); k = K::mn(k, dppx<0x141>(k)); k = K::mn(k, dppx<0x140>(k));
+  const T k0 = qpg_rl(k, 0), k1 = qpg_rl(k, 16), k2 = qpg_rl(k, 32), k3 = qpg_rl(k, 48);
+  const T ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
+  const T kk = ka < kb ? ka : kb;
+  idx = K::id(kk);
+  v = qpg_rl_dyn(v, idx);
+}
+// lane i <- lane i-1 / lane i+1 over the whole wavefront (wave_shr:1 / wave_shl:1; the end lane keeps its own value)
+template <class T> __device__ __forceinline__ T qpg_from_below(T v) { return dppx<0x138>(v); }
+template <class T> __device__ __forceinline__ T qpg_from_above(T v) { return dppx<0x130>(v); }
+// inclusive SUFFIX sum over the lanes: out_j = sum_{k >= j} v_k  (row_shl 1, 2, 4, 8 with zero fill inside the rows, then the totals of the
+// rows above -- lane 0 of each row holds its row's total)
+template <class T> __device__ __forceinline__ T qpg_suffix_sum(T v, int lane) {
+  auto shl = [](T x, auto ctl) __attribute__((always_inline)) {
+    constexpr int C = decltype(ctl)::value;
+    if constexpr (std::is_same<T, double>::value) {
+      const long long xi = __double_as_longlong(x);
+      return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, xi, C, 0xF, 0xF, true));
+    } else {
+      return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), C, 0xF, 0xF, true));
+    }
+  };
+  v += shl(v, std::integral_constant<int, 0x101>()); v += shl(v, std::integral_constant<int, 0x102>());
+  v += shl(v, std::integral_constant<int, 0x104>()); v += shl(v, std::integral_constant<int, 0x108>());
+  const T t1 = qpg_rl(v, 16), t2 = qpg_rl(v, 32), t3 = qpg_rl(v, 48);
+  const int row = lane >> 4;
+  return v + (row == 0 ? (t1 + t2) + t3 : (row == 1 ? t2 + t3 : (row == 2 ? t3 : (T)0)));
+}
+
+// sum_{k0 <= k < k1} a[k * sa] * b[k * sb] with four independent partial sums: the LDS reads of a trip are in flight together and the
+// FMA chain is a quarter as long (a lone accumulator pays ~80 cycles of LDS latency plus a dependent FMA per term)
+template <class T> __device__ __forceinline__ T qpg_dot(const T* a, int sa, const T* b, int sb, int k0, int k1) {
+  T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int k = k0;
+  for (; k + 4 <= k1; k += 4) {
+    s0 += a[k * sa] * b[k * sb]; s1 += a[(k + 1) * sa] * b[(k + 1) * sb];
+    s2 += a[(k + 2) * sa] * b[(k + 2) * sb]; s3 += a[(k + 3) * sa] * b[(k + 3) * sb];
   }
+  for (; k < k1; ++k) s0 += a[k * sa] * b[k * sb];
+  return (s0 + s1) + (s2 + s3);
 }
 
 template <class T>
@@ -70,7 +119,8 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
   T* const zs = dds + (n + 1);
   T* const ccs = zs + (n + 1);
   T* const sss = ccs + (n + 1);
-  T* const lam = sss + (n + 1);        // m+1
+  T* const rdg = sss + (n + 1);        // reciprocals of the diagonal of R
+  T* const lam = rdg + (n + 1);        // m+1
   const T INF = QpgLim<T>::big, eps = QpgLim<T>::eps;
 
   // ---- inputs (coalesced: consecutive lanes, consecutive elements of the problem's own block)
@@ -90,9 +140,9 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
     T s = 0;
     if (lane >= j && lane < n) {
       s = R[lane * ld + j];
-      for (int k = 0; k < j; ++k) s -= R[lane * ld + k] * R[j * ld + k];
+      s -= qpg_dot(R + lane * ld, 1, R + j * ld, 1, 0, j);
     }
-    const T sjj = __shfl(s, j, 64);
+    const T sjj = qpg_rl_dyn(s, j);
     if (!(sjj > 0)) { notpd = true; break; }
     const T ljj = sqrt(sjj);
     if (lane >= j && lane < n) R[lane * ld + j] = (lane == j) ? ljj : s / ljj;
@@ -121,10 +171,10 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
     if (lane < n) nps[lane] = g_i;
     QPG_WSYNC();
     T t = 0;
-    if (lane < n) for (int k = 0; k < n; ++k) t += J[k * ld + lane] * nps[k];
+    if (lane < n) t = qpg_dot(J + lane, ld, nps, 1, 0, n);
     if (lane < n) zs[lane] = t;
     QPG_WSYNC();
-    if (lane < n) { T s = 0; for (int k = 0; k < n; ++k) s += J[lane * ld + k] * zs[k]; x_i = -s; xs[lane] = x_i; }
+    if (lane < n) { x_i = -qpg_dot(J + lane * ld, 1, zs, 1, 0, n); xs[lane] = x_i; }
     QPG_WSYNC();
   }
 
@@ -138,10 +188,10 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
   while (!finished) {
     // step 1: the next equality row, else the most violated inactive inequality
     T s_i = 0;
-    if (lane < m) { s_i = -d_i; for (int k = 0; k < n; ++k) s_i += Cm[lane * ld + k] * xs[k]; }
+    if (lane < m) s_i = qpg_dot(Cm + lane * ld, 1, xs, 1, 0, n) - d_i;
     int ip; T sip, sign = 1; bool is_eq = false;
     if (next_eq < meq) {
-      const T s = __shfl(s_i, next_eq, 64);
+      const T s = qpg_rl_dyn(s_i, next_eq);
       ip = next_eq++; is_eq = true; sign = s > 0 ? (T)-1 : (T)1; sip = -fabs(s);
     } else {
       T v = (lane >= meq && lane < m && !active_i && s_i < -a.tol) ? s_i : INF;
@@ -158,17 +208,17 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
     for (;;) {
       if (++iter > a.max_iter) { status = 1; finished = true; break; }
       T dd_i = 0;
-      if (lane < n) for (int k = 0; k < n; ++k) dd_i += J[k * ld + lane] * nps[k];
+      if (lane < n) dd_i = qpg_dot(J + lane, ld, nps, 1, 0, n);
       if (lane < n) dds[lane] = dd_i;
       QPG_WSYNC();
       T z_i = 0;
-      if (lane < n) for (int j = iq; j < n; ++j) z_i += J[lane * ld + j] * dds[j];
+      if (lane < n) z_i = qpg_dot(J + lane * ld, 1, dds, 1, iq, n);
       // r = R^-1 d1 (column-oriented): lane i < iq
       T r_s = 0;
       {
         T s = lane < iq ? dd_i : (T)0;
         for (int j = iq - 1; j >= 0; --j) {
-          const T rj = __shfl(s, j, 64) / R[j * ld + j];
+          const T rj = qpg_rl_dyn(s, j) * rdg[j];
           if (lane == j) r_s = rj;
           if (lane < j) s -= R[lane * ld + j] * rj;
         }
@@ -204,11 +254,9 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
         if (full) {
           // rotate d2 = dd[iq .. n) into its first component; same rotations on the columns of J (see the header)
           const T sq = (lane >= iq && lane < n) ? dd_i * dd_i : (T)0;
-          T suf = sq;   // suffix sums over lanes: suf_j = sum_{k >= j} dd_k^2
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) { const T up = __shfl_down(suf, o, 64); suf += (lane + o < 64) ? up : (T)0; }
+          const T suf = qpg_suffix_sum(sq, lane);   // suf_j = sum_{k >= j} dd_k^2
           const T sig = sqrt(suf);
-          const T sig_lo = __shfl_up(sig, 1, 64), dd_lo = __shfl_up(dd_i, 1, 64);   // sigma_{j-1}, dd_{j-1}
+          const T sig_lo = qpg_from_below(sig), dd_lo = qpg_from_below(dd_i);   // sigma_{j-1}, dd_{j-1}
           if (lane > iq && lane < n) {
             const bool idn = !(sig_lo > 0);
             ccs[lane] = idn ? (T)1 : dd_lo / sig_lo;
@@ -216,7 +264,7 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
           }
           // the new R diagonal: the norm of d2 -- except when d2 has ONE component (iq = n - 1): no rotation happens, the component
           // keeps its sign (R[iq][iq] must stay J[:, iq] . n+)
-          const T dq = (iq == n - 1) ? __shfl(dd_i, iq, 64) : __shfl(sig, iq, 64);
+          const T dq = qpg_rl_dyn((iq == n - 1) ? dd_i : sig, iq);
           QPG_WSYNC();
           if (lane < n) {
             T t_hi = J[lane * ld + (n - 1)];
@@ -229,7 +277,7 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
             J[lane * ld + iq] = t_hi;
           }
           if (lane < iq) R[lane * ld + iq] = dd_i;
-          if (lane == iq) R[iq * ld + iq] = dq;
+          if (lane == iq) { R[iq * ld + iq] = dq; rdg[iq] = (T)1 / dq; }
           Rnorm = fmax(Rnorm, fabs(dq));
           if (lane == ip) active_i = true;
           if (is_eq) ++neq_in;
@@ -241,10 +289,10 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
       }
       if (do_drop) {   // slot lslot leaves the active set; the candidate moves down with the slots behind it
         const int qq = lslot;
-        const int lcon = __shfl(A_s, qq, 64);
+        const int lcon = qpg_rl_dyn(A_s, qq);
         if (lane == lcon) active_i = false;
         {
-          const int A_n = __shfl_down(A_s, 1, 64); const T u_n = __shfl_down(u_s, 1, 64), sg_n = __shfl_down(sg_s, 1, 64);
+          const int A_n = qpg_from_above(A_s); const T u_n = qpg_from_above(u_s), sg_n = qpg_from_above(sg_s);
           if (lane >= qq && lane < iq) { A_s = A_n; u_s = u_n; sg_s = sg_n; }
           if (lane == iq) { A_s = -1; u_s = 0; sg_s = 1; }
         }
@@ -257,7 +305,7 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
           if (h == 0) continue;
           cc /= h; ss /= h;
           QPG_WSYNC();   // every lane has read the pair before anybody overwrites it
-          if (lane == j) { R[(j + 1) * ld + j] = 0; R[j * ld + j] = h; }
+          if (lane == j) { R[(j + 1) * ld + j] = 0; R[j * ld + j] = h; rdg[j] = (T)1 / h; }
           if (lane > j && lane < iq) {
             const T t1_ = R[j * ld + lane], t2_ = R[(j + 1) * ld + lane];
             R[j * ld + lane] = cc * t1_ + ss * t2_;
@@ -273,7 +321,7 @@ __global__ __launch_bounds__(256) void qp_general_kernel(QpGeneralArgs<T> a, int
         if (!no2) {   // it was a partial step: the candidate's slack at the new point
           T s = 0;
           if (lane < n) s = Cm[ip * ld + lane] * x_i;
-          s = qpg_wave_sum(s) - __shfl(d_i, ip, 64);
+          s = qpg_wave_sum(s) - qpg_rl_dyn(d_i, ip);
           sip = sign * s;
         }
       }

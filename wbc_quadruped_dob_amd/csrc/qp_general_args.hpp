@@ -18,6 +18,6 @@ template <class T> struct QpGeneralArgs {
 
 __host__ __device__ inline int qpg_ld(int n) { return n | 1; }
 // LDS scalars per QP
-__host__ __device__ inline int qpg_lds_scalars(int n, int m) { const int ld = qpg_ld(n); return 2 * n * ld + m * ld + 6 * (n + 1) + (m + 1); }
+__host__ __device__ inline int qpg_lds_scalars(int n, int m) { const int ld = qpg_ld(n); return 2 * n * ld + m * ld + 7 * (n + 1) + (m + 1); }
 
 }  // namespace wbc
