@@ -681,10 +681,11 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, obs, d
                                                    (2, "f64", 2051, 512, 1), (1, "f32", 66000, 256, 1), (0, "f64", 3, 256, -2)])
 def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtype, n, tile, split):
     """Large batches deal the QPs of a tile to the wavefronts by predicted work (qp_tile_kernel: predictor, LDS counting
-    sort, groups pulled from a queue); the arithmetic per state is the same body, so tau, f, status and iteration counts
-    must equal the one-wavefront-workgroup kernel's -- bit for bit in fp64; in fp32 to rounding (the compiler pairs fp32
-    operations into packed instructions and then contracts a*b + c*d the other way round in one of the two instantiations) --
-    for ragged sizes, every tile size, with rhat arriving through the workspace (split observer) too."""
+    sort, groups pulled from a queue).  The solver body is the one-wavefront-workgroup kernel's, but it STARTS from what the
+    predictor computed one state per lane (fp64 tiles: G^-1 and x0 from the same 6x6 factor; fp32: states whose x0 is feasible
+    are finished there) -- the same numbers in another operation order.  So: status equal; iteration counts equal (a
+    rounding-level difference in x0 can flip a near-tie between two violated rows: at most 1 state in 1000); tau and f to
+    rounding (1e-10 in fp64: cond(G) ~ 1e4 times epsilon) -- for ragged sizes, every tile size, with rhat arriving through the workspace (split observer) too."""
     torch = torch_cuda
     B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=53)
     nd = _np_dtype(dtype)
@@ -699,8 +700,9 @@ def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtyp
         res[tag] = _run_step(torch, solver, B, dtype, integ, r, want_mats=True)
     assert np.array_equal(res["tiled"]["status"], res["plain"]["status"])
     if dtype == "f64":
-        for k in ("tau", "f", "iters"):
-            assert np.array_equal(res["tiled"][k], res["plain"][k]), k
+        assert np.mean(res["tiled"]["iters"] != res["plain"]["iters"]) < 1e-3
+        for k in ("tau", "f"):
+            assert relerr(res["tiled"][k], res["plain"][k]) < 1e-10, k      # cond(G) ~ 1e4 times the rounding of two operation orders
     else:
         assert np.mean(res["tiled"]["iters"] != res["plain"]["iters"]) < 1e-2
         assert relerr(res["tiled"]["tau"], res["plain"]["tau"]) < 1e-3 and relerr(res["tiled"]["f"], res["plain"]["f"]) < 1e-3

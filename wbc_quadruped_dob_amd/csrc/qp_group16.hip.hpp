@@ -176,7 +176,7 @@ WBC_DEV void qp_wait(int* flag, int need) {
 
 // TILED (qp_tile_kernel below): the four rows of the wavefront solve the states `who` names (dealt by predicted work)
 // instead of four consecutive ones; the workgroup is four such wavefronts.
-struct QpWho { size_t state; bool live; };
+struct QpWho { size_t state; bool live; const double* pre = nullptr; };   // pre: the tile predictor's record of this state (qp_kernels.hip.hpp), LDS
 struct QpNoIdle { WBC_DEV void operator()() const {} };
 // `idle()` (fused tick) runs after this wavefront has requested its own inputs and before it first waits for the producer roles:
 // work that would otherwise sit on a producer's critical path (the structural constants of M and Jc, dyn_split.hip.hpp).

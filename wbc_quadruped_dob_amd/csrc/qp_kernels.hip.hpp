@@ -45,8 +45,14 @@ __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<
 #ifndef WBC_QP_PRED_FINISH
 #define WBC_QP_PRED_FINISH 1
 #endif
-template <class T, bool RHAT>
-WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32) {
+// WBC_QP_TILE_PRE (default 1; fp64 tiles of <= 64 states): the predictor also leaves G^-1 (36 values) and x0 (12) of its state in LDS, and
+// the row-form body starts from them (qp_struct16_body<..., PRE>) instead of factorising G again in all 16 lanes of the state's row.
+#ifndef WBC_QP_TILE_PRE
+#define WBC_QP_TILE_PRE 1
+#endif
+constexpr int QP_PRE_WORDS = 48;
+template <class T, bool RHAT, bool PRE = false>
+WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32, double* pre = nullptr) {
 #define PLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
   constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
   const int mask = a.mask[s32] & 0xF;
@@ -75,7 +81,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   const T m00 = prm.alpha + (s3 * s3) * (Pyy + Pzz), m11 = prm.alpha + (s4 * s4) * (Pxx + Pzz), m22 = prm.alpha + (s5 * s5) * (Pxx + Pyy);
   const T m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
   auto rs = [](T x) __attribute__((always_inline)) -> T {
-    if constexpr (FIN) return rsqrt_nr(x);
+    if constexpr (FIN || PRE) return rsqrt_nr(x);
     else if constexpr (std::is_same<T, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
   };
   T il[6];
@@ -100,6 +106,26 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   z[1] = (w[1] - a01 * z[3] - a21 * z[5]) * il[1];
   z[0] = (w[0] - a10 * z[4] - a20 * z[5]) * il[0];
   const T zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
+  if constexpr (PRE) {   // G^-1, column by column (= row by row: symmetric): G x = e_c through the factor, zeros of e_c skipped by the compiler
+    sfor<0, 6>([&](auto cc_) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc_)::value;
+      const T e0 = c == 0 ? (T)1 : (T)0, e1 = c == 1 ? (T)1 : (T)0, e2 = c == 2 ? (T)1 : (T)0, e3 = c == 3 ? (T)1 : (T)0, e4 = c == 4 ? (T)1 : (T)0,
+              e5 = c == 5 ? (T)1 : (T)0;
+      T u[6], gc[6];
+      u[0] = e0 * il[0]; u[1] = e1 * il[1]; u[2] = e2 * il[2];
+      u[3] = (e3 - a01 * u[1] - a02 * u[2]) * il[3];
+      u[4] = (e4 - a10 * u[0] - a12 * u[2] - b10 * u[3]) * il[4];
+      u[5] = (e5 - a20 * u[0] - a21 * u[1] - b20 * u[3] - b21 * u[4]) * il[5];
+      gc[5] = u[5] * il[5];
+      gc[4] = (u[4] - b21 * gc[5]) * il[4];
+      gc[3] = (u[3] - b10 * gc[4] - b20 * gc[5]) * il[3];
+      gc[2] = (u[2] - a02 * gc[3] - a12 * gc[4]) * il[2];
+      gc[1] = (u[1] - a01 * gc[3] - a21 * gc[5]) * il[1];
+      gc[0] = (u[0] - a10 * gc[4] - a20 * gc[5]) * il[0];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) pre[6 * c + j] = (double)gc[j];
+    });
+  }
   int cnt_all = 0;
   bool fin_ok = true;   // every slack of every stance foot at or above the finishing threshold (false for a NaN state: the solver reports those)
   const T fin_thr = std::is_same<T, double>::value ? -prm.qp_tol : (T)1e-3;
@@ -113,6 +139,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
     const T x0 = on ? zf0 + (zm1 * dz - zm2 * dy) : (T)0;
     const T x1 = on ? zf1 + (zm2 * dx - zm0 * dz) : (T)0;
     const T x2 = on ? zf2 + (zm0 * dy - zm1 * dx) : (T)0;
+    if constexpr (PRE) { pre[36 + 3 * f] = (double)x0; pre[36 + 3 * f + 1] = (double)x1; pre[36 + 3 * f + 2] = (double)x2; }
     T nx = PLD(a.normals, 3 * f), ny = PLD(a.normals, 3 * f + 1), nz = PLD(a.normals, 3 * f + 2);
     const T iln = rs(nx * nx + ny * ny + nz * nz);
     nx *= iln; ny *= iln; nz *= iln;
@@ -178,6 +205,8 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
 template <class T, bool RHAT, int TILE, bool DENSE = false>
 __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
   static_assert(TILE % 4 == 0 && TILE <= 1024, "tile of whole four-state groups");
+  constexpr bool PRE = WBC_QP_TILE_PRE != 0 && std::is_same<T, double>::value && !DENSE && TILE <= 64;
+  __shared__ double pre[PRE ? TILE * QP_PRE_WORDS : 1];
   __shared__ unsigned short order[TILE];
   __shared__ int hist[64];
   __shared__ int next_grp;
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
     if (i < TILE) {
       const size_t s = base + i;
       if (s < N) {
-        const int key = qp_predict_key<T, RHAT>(prm, a, jmap, (unsigned)s, N32);
+        const int key = qp_predict_key<T, RHAT, PRE>(prm, a, jmap, (unsigned)s, N32, pre + (PRE ? i * QP_PRE_WORDS : 0));
         bucket[r] = key < 0 ? 62 : 61 - key;
       }
       rank[r] = __hip_atomic_fetch_add(&hist[bucket[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -224,9 +253,10 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
     g = __builtin_amdgcn_readfirstlane(g);
     if (4 * g >= nsolve) break;
     const bool live = 4 * g + row < nsolve;
-    const size_t s = base + order[live ? 4 * g + row : 0];
+    const unsigned oi = order[live ? 4 * g + row : 0];
+    const size_t s = base + oi;
     if constexpr (DENSE) qp_group16_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
-    else qp_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
+    else qp_body<T, false, RHAT, 16, true, 4, QpNoIdle, PRE>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live, pre + (PRE ? oi * QP_PRE_WORDS : 0)});
   }
 }
 

@@ -41,7 +41,10 @@ template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 16]; T D[4][4 * 3]
 // TS = the solver's scalar type (what the batch arrays and the LDS workspace hold); the arithmetic is ALWAYS double: the inverse
 // is kept by rank-one updates (cond(G_A) ~ 1e4-1e5 is too much for fp32), and on gfx950 a dependent v_fma_f64 costs a lone
 // wavefront what a dependent v_fma_f32 costs (13.5 vs 13.1 cycles, tools/issue_probe.hip) -- the QP is latency-, not byte-bound.
-template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
+// PRE (tiles only): G^-1 and the unconstrained minimum x0 of this state were computed by the tile's predictor, one state per lane, and wait
+// in LDS (who.pre: 36 + 12 doubles) -- the factorisation, the unit solves and the x0 solve below (~350 of the ~750 set-up instructions a
+// wavefront spends per four states) are skipped.
+template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false>
 WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, const QpJidx& jmap, const TS* wsl, const QpSync* sync = nullptr,
                               const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
   using T = double;
@@ -100,6 +103,11 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
   T alpha_l = prm.alpha, ralpha = prm.rsqrt_alpha * prm.rsqrt_alpha;
   if constexpr (WSLDS || TILED) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(ralpha));
+  const int gi = l16 < 6 ? l16 : (l16 < 12 ? l16 - 6 : l16 - 12);
+  T Gr[6];
+  if constexpr (PRE) {
+    sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = who.pre[6 * gi + j]; });
+  } else {
   T a01, a02, a10, a12, a20, a21, b10, b20, b21;
   T il[6];
   {
@@ -135,8 +143,6 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     il[5] = rsqrt_nr(t22);
   }
   // ------------------------------------------------------------------ my row of G^-1 (row gi = l16 mod 6): G x = e_gi by the factor
-  const int gi = l16 < 6 ? l16 : (l16 < 12 ? l16 - 6 : l16 - 12);
-  T Gr[6];
   {
     const T e0 = gi == 0 ? (T)1 : (T)0, e1 = gi == 1 ? (T)1 : (T)0, e2 = gi == 2 ? (T)1 : (T)0, e3 = gi == 3 ? (T)1 : (T)0, e4 = gi == 4 ? (T)1 : (T)0,
             e5 = gi == 5 ? (T)1 : (T)0;
@@ -151,6 +157,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     Gr[2] = (w[2] - a02 * Gr[3] - a12 * Gr[4]) * il[2];
     Gr[1] = (w[1] - a01 * Gr[3] - a21 * Gr[5]) * il[1];
     Gr[0] = (w[0] - a10 * Gr[4] - a20 * Gr[5]) * il[0];
+  }
   }
   // y = G_A^-1 b for a row-uniform b: my component from my row, then six broadcasts from the static lanes 0..5
   T y[6];
@@ -209,6 +216,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
     if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
     WBC_QSTAMP(4);
+    if constexpr (PRE) {
+      x_me = isvar ? who.pre[36 + v] : (T)0;
+    } else {
     const T b_ld = (l16 < 6) ? BLD(l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
     T bb[6];
     bb[0] = s0 * dppx<0x150 + 0>(b_ld); bb[1] = s1 * dppx<0x150 + 1>(b_ld); bb[2] = s2 * dppx<0x150 + 2>(b_ld);
@@ -218,6 +228,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     T w0, w1, w2;
     bt_y(w0, w1, w2);
     x_me = c3 == 0 ? w0 : (c3 == 1 ? w1 : w2);
+    }
   }
 
   // ------------------------------------------------------------------ dual active-set iterations (a8)
@@ -498,10 +509,10 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #ifndef WBC_QP_STRUCT
 #define WBC_QP_STRUCT 2
 #endif
-template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle>
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false>
 WBC_DEV void qp_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
                      const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
-  if constexpr (WBC_QP_STRUCT != 0 && (WBC_QP_STRUCT > 1 || std::is_same<T, double>::value)) qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
+  if constexpr (WBC_QP_STRUCT != 0 && (WBC_QP_STRUCT > 1 || std::is_same<T, double>::value)) qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle, PRE>(prm, a, jmap, wsl, sync, who, idle);
   else qp_group16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
 }
 
