@@ -53,48 +53,50 @@ __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<
 constexpr int QP_PRE_WORDS = 48;
 template <class T, bool RHAT, bool PRE = false>
 WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32, double* pre = nullptr) {
-#define PLD(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+  // A = the arithmetic type: the storage type T, except that a predictor that feeds the (fp64-arithmetic) solver works in double
+  using A = typename std::conditional<PRE, double, T>::type;
+#define PLD(ptr, comp) ((A)(*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T)))))
   constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
   const int mask = a.mask[s32] & 0xF;
-  const T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
+  const A s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
   // (loops over the feet are NOT unrolled where they carry per-foot data: with Dx..Dz[4] and the four feet's normals in flight the
   //  predictor needed 220-250 VGPRs -- more than the solver it serves; the lever arms are re-read, L2-hot, where they are needed)
 #define PLD_D(f_, dx_, dy_, dz_) do { \
     if (a.Jc) { dx_ = PLD(a.Jc, (3 * (f_) + 1) * 18 + 5); dy_ = PLD(a.Jc, (3 * (f_) + 2) * 18 + 3); dz_ = PLD(a.Jc, (3 * (f_)) * 18 + 4); } \
     else { dx_ = PLD(a.ws, WS_D + 3 * (f_)); dy_ = PLD(a.ws, WS_D + 3 * (f_) + 1); dz_ = PLD(a.ws, WS_D + 3 * (f_) + 2); } } while (0)
-  T nc = 0, sx = 0, sy = 0, sz = 0, Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
+  A nc = 0, sx = 0, sy = 0, sz = 0, Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const bool on = (mask >> f) & 1;
-    T dx, dy, dz;
+    A dx, dy, dz;
     PLD_D(f, dx, dy, dz);
-    dx = on ? dx : (T)0; dy = on ? dy : (T)0; dz = on ? dz : (T)0;
-    nc += on ? (T)1 : (T)0; sx += dx; sy += dy; sz += dz;
+    dx = on ? dx : (A)0; dy = on ? dy : (A)0; dz = on ? dz : (A)0;
+    nc += on ? (A)1 : (A)0; sx += dx; sy += dy; sz += dz;
     Pxx += dx * dx; Pxy += dx * dy; Pxz += dx * dz; Pyy += dy * dy; Pyz += dy * dz; Pzz += dz * dz;
   }
-  T bt[6];
+  A bt[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) bt[k] = (a.wdes ? PLD(a.wdes, k) : PLD(a.ws, WS_B + k)) - (RHAT ? PLD(a.ws, WS_RHAT + k) : (T)0);
-  // G = alpha I + B B^T and its factor, as in qp_group16_body (selection only: seed-accuracy reciprocal square roots)
-  const T g00 = prm.alpha + s0 * s0 * nc, g11 = prm.alpha + s1 * s1 * nc, g22 = prm.alpha + s2 * s2 * nc;
-  const T gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
-  const T m00 = prm.alpha + (s3 * s3) * (Pyy + Pzz), m11 = prm.alpha + (s4 * s4) * (Pxx + Pzz), m22 = prm.alpha + (s5 * s5) * (Pxx + Pyy);
-  const T m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
-  auto rs = [](T x) __attribute__((always_inline)) -> T {
+  for (int k = 0; k < 6; ++k) bt[k] = (a.wdes ? PLD(a.wdes, k) : PLD(a.ws, WS_B + k)) - (RHAT ? PLD(a.ws, WS_RHAT + k) : (A)0);
+  // G = alpha I + B B^A and its factor, as in qp_group16_body (selection only: seed-accuracy reciprocal square roots)
+  const A g00 = prm.alpha + s0 * s0 * nc, g11 = prm.alpha + s1 * s1 * nc, g22 = prm.alpha + s2 * s2 * nc;
+  const A gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
+  const A m00 = prm.alpha + (s3 * s3) * (Pyy + Pzz), m11 = prm.alpha + (s4 * s4) * (Pxx + Pzz), m22 = prm.alpha + (s5 * s5) * (Pxx + Pyy);
+  const A m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
+  auto rs = [](A x) __attribute__((always_inline)) -> A {
     if constexpr (FIN || PRE) return rsqrt_nr(x);
-    else if constexpr (std::is_same<T, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
+    else if constexpr (std::is_same<A, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
   };
-  T il[6];
+  A il[6];
   il[0] = rs(g00); il[1] = rs(g11); il[2] = rs(g22);
-  const T a01 = gm01 * il[1], a02 = gm02 * il[2], a10 = gm10 * il[0], a12 = gm12 * il[2], a20 = gm20 * il[0], a21 = gm21 * il[1];
-  const T c00 = m00 - a01 * a01 - a02 * a02, c11 = m11 - a10 * a10 - a12 * a12, c22 = m22 - a20 * a20 - a21 * a21;
-  const T c10 = m10 - a12 * a02, c20 = m20 - a21 * a01, c21 = m21 - a20 * a10;
+  const A a01 = gm01 * il[1], a02 = gm02 * il[2], a10 = gm10 * il[0], a12 = gm12 * il[2], a20 = gm20 * il[0], a21 = gm21 * il[1];
+  const A c00 = m00 - a01 * a01 - a02 * a02, c11 = m11 - a10 * a10 - a12 * a12, c22 = m22 - a20 * a20 - a21 * a21;
+  const A c10 = m10 - a12 * a02, c20 = m20 - a21 * a01, c21 = m21 - a20 * a10;
   il[3] = rs(c00);
-  const T b10 = c10 * il[3], b20 = c20 * il[3];
+  const A b10 = c10 * il[3], b20 = c20 * il[3];
   il[4] = rs(c11 - b10 * b10);
-  const T b21 = (c21 - b20 * b10) * il[4];
+  const A b21 = (c21 - b20 * b10) * il[4];
   il[5] = rs(c22 - b20 * b20 - b21 * b21);
-  T w[6], z[6];   // z = G^-1 S^(1/2) b
+  A w[6], z[6];   // z = G^-1 S^(1/2) b
   w[0] = s0 * bt[0] * il[0]; w[1] = s1 * bt[1] * il[1]; w[2] = s2 * bt[2] * il[2];
   w[3] = (s3 * bt[3] - a01 * w[1] - a02 * w[2]) * il[3];
   w[4] = (s4 * bt[4] - a10 * w[0] - a12 * w[2] - b10 * w[3]) * il[4];
@@ -105,13 +107,13 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   z[2] = (w[2] - a02 * z[3] - a12 * z[4]) * il[2];
   z[1] = (w[1] - a01 * z[3] - a21 * z[5]) * il[1];
   z[0] = (w[0] - a10 * z[4] - a20 * z[5]) * il[0];
-  const T zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
+  const A zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
   if constexpr (PRE) {   // G^-1, column by column (= row by row: symmetric): G x = e_c through the factor, zeros of e_c skipped by the compiler
     sfor<0, 6>([&](auto cc_) __attribute__((always_inline)) {
       constexpr int c = decltype(cc_)::value;
-      const T e0 = c == 0 ? (T)1 : (T)0, e1 = c == 1 ? (T)1 : (T)0, e2 = c == 2 ? (T)1 : (T)0, e3 = c == 3 ? (T)1 : (T)0, e4 = c == 4 ? (T)1 : (T)0,
-              e5 = c == 5 ? (T)1 : (T)0;
-      T u[6], gc[6];
+      const A e0 = c == 0 ? (A)1 : (A)0, e1 = c == 1 ? (A)1 : (A)0, e2 = c == 2 ? (A)1 : (A)0, e3 = c == 3 ? (A)1 : (A)0, e4 = c == 4 ? (A)1 : (A)0,
+              e5 = c == 5 ? (A)1 : (A)0;
+      A u[6], gc[6];
       u[0] = e0 * il[0]; u[1] = e1 * il[1]; u[2] = e2 * il[2];
       u[3] = (e3 - a01 * u[1] - a02 * u[2]) * il[3];
       u[4] = (e4 - a10 * u[0] - a12 * u[2] - b10 * u[3]) * il[4];
@@ -128,56 +130,56 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   }
   int cnt_all = 0;
   bool fin_ok = true;   // every slack of every stance foot at or above the finishing threshold (false for a NaN state: the solver reports those)
-  const T fin_thr = std::is_same<T, double>::value ? -prm.qp_tol : (T)1e-3;
-  T mag = 0;   // summed violation of the violated constraints
+  const A fin_thr = std::is_same<T, double>::value ? (A)-prm.qp_tol : (A)1e-3;
+  A mag = 0;   // summed violation of the violated constraints
 #pragma unroll WBC_PRED_UNROLL_C
   for (int f = 0; f < 4; ++f) {
     // x0 of foot f = on (s_f z_f + (s_m z_m) x d_f)
     const bool on = (mask >> f) & 1;
-    T dx, dy, dz;
+    A dx, dy, dz;
     PLD_D(f, dx, dy, dz);
-    const T x0 = on ? zf0 + (zm1 * dz - zm2 * dy) : (T)0;
-    const T x1 = on ? zf1 + (zm2 * dx - zm0 * dz) : (T)0;
-    const T x2 = on ? zf2 + (zm0 * dy - zm1 * dx) : (T)0;
+    const A x0 = on ? zf0 + (zm1 * dz - zm2 * dy) : (A)0;
+    const A x1 = on ? zf1 + (zm2 * dx - zm0 * dz) : (A)0;
+    const A x2 = on ? zf2 + (zm0 * dy - zm1 * dx) : (A)0;
     if constexpr (PRE) { pre[36 + 3 * f] = (double)x0; pre[36 + 3 * f + 1] = (double)x1; pre[36 + 3 * f + 2] = (double)x2; }
-    T nx = PLD(a.normals, 3 * f), ny = PLD(a.normals, 3 * f + 1), nz = PLD(a.normals, 3 * f + 2);
-    const T iln = rs(nx * nx + ny * ny + nz * nz);
+    A nx = PLD(a.normals, 3 * f), ny = PLD(a.normals, 3 * f + 1), nz = PLD(a.normals, 3 * f + 2);
+    const A iln = rs(nx * nx + ny * ny + nz * nz);
     nx *= iln; ny *= iln; nz *= iln;
-    const bool usex = fabs_t(nx) < (T)0.9;
-    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
-    const T rd = rx * nx + ry * ny;
-    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
-    const T it = rs(t1x * t1x + t1y * t1y + t1z * t1z);
+    const bool usex = fabs_t(nx) < (A)0.9;
+    const A rx = usex ? (A)1 : (A)0, ry = usex ? (A)0 : (A)1;
+    const A rd = rx * nx + ry * ny;
+    A t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
+    const A it = rs(t1x * t1x + t1y * t1y + t1z * t1z);
     t1x *= it; t1y *= it; t1z *= it;
-    const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
-    const T fn = nx * x0 + ny * x1 + nz * x2, f1 = t1x * x0 + t1y * x1 + t1z * x2, f2 = t2x * x0 + t2y * x1 + t2z * x2;
-    const T mf = PLD(a.mu, f) * prm.mu_scale * fn, tol = -prm.qp_tol;
-    const T sl[6] = {mf - f1, mf + f1, mf - f2, mf + f2, fn - prm.fn_min, prm.fn_max - fn};
+    const A t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    const A fn = nx * x0 + ny * x1 + nz * x2, f1 = t1x * x0 + t1y * x1 + t1z * x2, f2 = t2x * x0 + t2y * x1 + t2z * x2;
+    const A mf = PLD(a.mu, f) * prm.mu_scale * fn, tol = -prm.qp_tol;
+    const A sl[6] = {mf - f1, mf + f1, mf - f2, mf + f2, fn - prm.fn_min, prm.fn_max - fn};
     int cnt = 0;
-    T mg = 0;
+    A mg = 0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { cnt += (sl[c] < tol) ? 1 : 0; mg += (sl[c] < tol) ? -sl[c] : (T)0; }
+    for (int c = 0; c < 6; ++c) { cnt += (sl[c] < tol) ? 1 : 0; mg += (sl[c] < tol) ? -sl[c] : (A)0; }
     bool okf = true;
 #pragma unroll
     for (int c = 0; c < 6; ++c) okf = okf && (sl[c] >= fin_thr);
     fin_ok = fin_ok && (okf || !on);
     cnt_all += on ? cnt : 0;
-    mag += on ? mg : (T)0;
+    mag += on ? mg : (A)0;
   }
-  if (FIN && fin_ok) {   // solved: f = x0, tau = taup - rhat - Jc_leg^T f (the epilogue of qp_struct16_body, one state per lane)
-#define PST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val))
+  if (FIN && fin_ok) {   // solved: f = x0, tau = taup - rhat - Jc_leg^A f (the epilogue of qp_struct16_body, one state per lane)
+#define PST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (T)(val))
 #pragma unroll WBC_PRED_UNROLL_F
     for (int f = 0; f < 4; ++f) {
       const bool on = (mask >> f) & 1;
-      T dx, dy, dz;
+      A dx, dy, dz;
       PLD_D(f, dx, dy, dz);
-      const T fx = on ? zf0 + (zm1 * dz - zm2 * dy) : (T)0, fy = on ? zf1 + (zm2 * dx - zm0 * dz) : (T)0, fz = on ? zf2 + (zm0 * dy - zm1 * dx) : (T)0;
+      const A fx = on ? zf0 + (zm1 * dz - zm2 * dy) : (A)0, fy = on ? zf1 + (zm2 * dx - zm0 * dz) : (A)0, fz = on ? zf2 + (zm0 * dy - zm1 * dx) : (A)0;
       PST(a.f, 3 * f, fx); PST(a.f, 3 * f + 1, fy); PST(a.f, 3 * f + 2, fz);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int jm = jmap.j[3 * f + k];
-        const T taup = PLD(a.ws, WS_TAUP + 3 * f + k) - (RHAT ? PLD(a.ws, WS_RHAT + 6 + 3 * f + k) : (T)0);
-        T j0, j1, j2;
+        const A taup = PLD(a.ws, WS_TAUP + 3 * f + k) - (RHAT ? PLD(a.ws, WS_RHAT + 6 + 3 * f + k) : (A)0);
+        A j0, j1, j2;
         if (a.Jc) { j0 = PLD(a.Jc, (3 * f + 0) * 18 + 6 + jm); j1 = PLD(a.Jc, (3 * f + 1) * 18 + 6 + jm); j2 = PLD(a.Jc, (3 * f + 2) * 18 + 6 + jm); }
         else { j0 = PLD(a.ws, WS_JCL + 9 * f + k); j1 = PLD(a.ws, WS_JCL + 9 * f + 3 + k); j2 = PLD(a.ws, WS_JCL + 9 * f + 6 + k); }
         PST(a.tau, jm, taup - (j0 * fx + j1 * fy + j2 * fz));
@@ -205,7 +207,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
 template <class T, bool RHAT, int TILE, bool DENSE = false>
 __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
   static_assert(TILE % 4 == 0 && TILE <= 1024, "tile of whole four-state groups");
-  constexpr bool PRE = WBC_QP_TILE_PRE != 0 && std::is_same<T, double>::value && !DENSE && TILE <= 64;
+  constexpr bool PRE = WBC_QP_TILE_PRE != 0 && (WBC_QP_TILE_PRE > 1 || std::is_same<T, double>::value) && !DENSE && TILE <= 64 && (WBC_QP_STRUCT > 1 || (WBC_QP_STRUCT == 1 && std::is_same<T, double>::value));
   __shared__ double pre[PRE ? TILE * QP_PRE_WORDS : 1];
   __shared__ unsigned short order[TILE];
   __shared__ int hist[64];

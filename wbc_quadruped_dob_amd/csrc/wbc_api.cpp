@@ -612,7 +612,14 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   // 32 768, 109.6 -> 93.1 at 65 536, 408 -> 350 at 262 144 (tiles of 64; 128 and 256 lose to the workgroup lifetime);
   // below 12 288 states the tiles do not fill the device
   int tile = s->opt.qp_tile;
-  if (tile == 0) tile = N >= 28672 ? 64 : (N >= 14336 ? 32 : 0);   // (round 3, structured QP body: one-wave 20.1 vs tiles-of-32 22.1 us at 12 288; 32: 28.5 vs 64: 36.3 us at 24 576; 64: 36.1 vs 32: 39.5 at 32 768)
+  // (round 3, structured QP body, QP stage in us.  fp64 standing batch: one-wave 19.0 / tiles-of-32 19.6 at 12 288; 22.2 / 20.0 / 64: 23.9 at
+  //  16 384; 31.2 / 24.6 / 30.3 at 24 576; 32.4 / 31.9 / 29.9 at 28 672; 35.9 / 34.7 / 30.4 at 32 768.  fp32 -- whose tile kernel holds 180
+  //  registers, two workgroups per CU, where the one-wave kernel runs four wavefronts per SIMD -- trot batch: 17.0 / 20.8 / 20.5 at 16 384,
+  //  19.6 / 31.2 / 20.5 at 24 576, 22.1 / 33.4 / 22.0 at 28 672, 24.3 / 35.7 / 22.7 at 32 768; standing batch 31.3 / 44.1 / 37.2 at 24 576)
+  if (tile == 0) {
+    if (std::is_same<T, float>::value) tile = N >= 30720 ? 64 : 0;
+    else tile = N >= 28672 ? 64 : (N >= 14336 ? 32 : 0);
+  }
   if (tile < 0) tile = 0;
   if (lane) {
     TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, obs_split, dp, qa, s->jmap, s->d_todo));
