@@ -98,12 +98,13 @@ def test_cpp_consumer_matches_oracle_and_shards_match_single(torch_cuda, gpu_mod
 
 
 def test_abi_smoke_cpp_program_runs(torch_cuda, consumer):
-    """tools/abi_smoke.cpp: URDF -> single-robot tick, raw-buffer batch, 5-tick rollout and the header-only C++ host
-    class (planner + tick), each with its own physical sanity check; exit status 0 = all held."""
+    """tools/abi_smoke.cpp: URDF -> single-robot tick, raw-buffer batch, 5-tick rollout, the header-only C++ host
+    class (planner + tick) and the general dense QP, each with its own physical sanity check; exit status 0 = all held."""
     import wbc_quadruped_dob_amd as W
     run = subprocess.run([os.path.join(ROOT, "tools", "abi_smoke.bin"), W.SYNTHETIC_URDF], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "QuadrupedWBC plan+tick: status=0" in run.stdout
+    assert "wbc_qp_dense_batch: status=0 x=(0.800000 0.200000)" in run.stdout      # the general dense QP from plain C++
 
 
 @pytest.mark.parametrize("obs,gather", [(0, "peer"), (1, "peer"), (1, "rccl")])

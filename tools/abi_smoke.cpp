@@ -118,5 +118,29 @@ int main(int argc, char** argv) {
     std::printf("QuadrupedWBC: %s\n", e.what());
     return 5;
   }
+  // the general dense QP through the C-ABI with raw buffers: min 1/2 |x|^2 - x0 - x1  s.t.  x0 + x1 = 1 (equality), x0 >= 0.7  ->  x = (0.7, 0.3)
+  {
+    const size_t NQ = 3;
+    std::vector<double> H(NQ * 4), g(NQ * 2), C(NQ * 4), d(NQ * 2), x(NQ * 2), lam(NQ * 2);
+    std::vector<int> qs(NQ), qi(NQ);
+    for (size_t k = 0; k < NQ; ++k) {
+      H[4 * k] = 1; H[4 * k + 1] = 0; H[4 * k + 2] = 0; H[4 * k + 3] = 1; g[2 * k] = -1; g[2 * k + 1] = -1;
+      C[4 * k] = 1; C[4 * k + 1] = 1; C[4 * k + 2] = 1; C[4 * k + 3] = 0; d[2 * k] = 1; d[2 * k + 1] = 0.7 + 0.1 * k;
+    }
+    double *dH, *dg, *dC, *dd, *dx, *dl;
+    int *ds, *di;
+    hipMalloc(&dH, H.size() * 8); hipMalloc(&dg, g.size() * 8); hipMalloc(&dC, C.size() * 8); hipMalloc(&dd, d.size() * 8);
+    hipMalloc(&dx, x.size() * 8); hipMalloc(&dl, lam.size() * 8); hipMalloc(&ds, NQ * 4); hipMalloc(&di, NQ * 4);
+    hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dg, g.data(), g.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dC, C.data(), C.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dd, d.data(), d.size() * 8, hipMemcpyHostToDevice);
+    CK(wbc_qp_dense_batch(WBC_F64, NQ, 2, 2, 1, dH, dg, dC, dd, 50, 1e-10, dx, dl, ds, di, nullptr));
+    hipDeviceSynchronize();
+    hipMemcpy(x.data(), dx, x.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(qs.data(), ds, NQ * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(lam.data(), dl, lam.size() * 8, hipMemcpyDeviceToHost);
+    std::printf("wbc_qp_dense_batch: status=%d x=(%.6f %.6f) lambda=(%.4f %.4f)\n", qs[1], x[2], x[3], lam[2], lam[3]);
+    for (size_t k = 0; k < NQ; ++k)
+      if (qs[k] != 0 || std::fabs(x[2 * k] - (0.7 + 0.1 * k)) > 1e-9 || std::fabs(x[2 * k] + x[2 * k + 1] - 1) > 1e-9 || lam[2 * k + 1] < 0) return 6;
+    if (wbc_qp_dense_batch(WBC_F64, NQ, 37, 2, 1, dH, dg, dC, dd, 50, 1e-10, dx, dl, ds, di, nullptr) != WBC_E_INVALID) return 7;
+  }
   return 0;
 }
