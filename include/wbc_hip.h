@@ -114,14 +114,16 @@ typedef struct wbc_solver_options {
                              image behind the tick (hipStreamWriteValue32), polled by the host in memory: no runtime call on the wait
                              path; 3 = as 2 with a one-thread kernel writing the ticket.  2 / 3 fall back to 1 when the stack refuses */
   int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */
-  int qp_tile;            /* GRF-QP kernel of the two-kernel tick: 0 = auto (tiles of 32 / 64 states dealt to the wavefronts by
-                             predicted work from 12288 / 20480 states on, one-wavefront workgroups below), -1 = never tiles,
-                             32 | 64 | 128 | 256 | 512 = always tiles of that many states */
+  int qp_tile;            /* GRF-QP kernel of the two-kernel tick: 0 = auto (tiles of states dealt to the wavefronts by predicted work,
+                             sized so that the launch is ONE round of resident workgroups: fp64 from 14336 states on, 32 ... 64 states
+                             per tile; fp32 from 30720, 64 ... 128; one-wavefront workgroups below), -1 = never tiles, otherwise always
+                             tiles of that many states: 32 | 64 | 128 | 256 | 512, fp64 also 36 ... 60 in steps of 4, fp32 also
+                             72 ... 120 in steps of 8 */
   int obs_split_serial;   /* that observer kernel runs 1 (default) = on the caller's stream before the sweep, 0 = beside it on a
                              second stream (measured slower: the two compete for the same SIMDs) */
   int qp_lane;            /* two-kernel ticks solve the QPs one state per LANE first (semismooth Newton on the residual wrench)
-                             and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches from
-                             49152 states on, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
+                             and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches of more than
+                             49152 states, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
                              iters = Newton iterations (<= 5); the others the dense kernel's status / iteration count.
                              wbc_params.qp_tol and max_iter govern the DENSE kernel only: the per-lane kernel accepts a state when
                              the residual of its optimality equation is below 1e-11 (fp32: 2e-5) x (1 + |target wrench|) or a full

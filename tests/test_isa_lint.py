@@ -27,7 +27,10 @@ BUDGET = [
     (r"dyn_sweep_kernelIdLi1ELi256", 256), (r"dyn_sweep_kernelIdLi11ELi256", 256), (r"dyn_sweep_kernelIfLi(1|11)ELi256", 256),
     (r"observer_kernelI[df]", 256),
     (r"qp_lane_kernelI[df]", 256),
-    (r"qp_tile_kernelI[df]Lb[01]ELi(32|64)E", 256), (r"qp_group16_kernelI[df]", 256), (r"qp_list_kernelI[df]", 256),
+    (r"qp_tile_kernelI[df]Lb[01]ELi\d+E", 256), (r"qp_group16_kernelI[df]", 256), (r"qp_list_kernelI[df]", 256),
+    # the host sizes fp64 tiles for THREE resident workgroups per CU (wbc_api.cpp: one round of 768): that needs <= 168 registers
+    (r"qp_tile_kernelIdLb[01]ELi(32|36|40|44|48|52|56|60|64)ELb0E", 168),
+    (r"qp_general_kernelI[df]", 128),
     (r"rnea_step_kernelIdLi(2|10|34|42)ELi256", 256),
 ]
 

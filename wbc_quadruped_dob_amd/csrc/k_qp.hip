@@ -7,7 +7,7 @@
 namespace wbc {
 
 #ifndef WBC_F32_DENSE_TILE_MIN
-#define WBC_F32_DENSE_TILE_MIN 49152
+#define WBC_F32_DENSE_TILE_MIN 65537
 #endif
 template <int TILE>
 static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
@@ -34,11 +34,24 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
     else WBC_KLAUNCH(L, (qp_list_kernel<T, false>), grid, dim3(64), prm, a, jmap, list);
     return hipGetLastError();
   }
-  if (tile == 32) return qp_tiled<32>(L, rhat, prm, a, jmap);
-  if (tile == 64) return qp_tiled<64>(L, rhat, prm, a, jmap);
-  if (tile == 128) return qp_tiled<128>(L, rhat, prm, a, jmap);
-  if (tile == 256) return qp_tiled<256>(L, rhat, prm, a, jmap);
-  if (tile == 512) return qp_tiled<512>(L, rhat, prm, a, jmap);
+  // tile sizes in small steps so that the host can launch ONE round of resident workgroups (wbc_api.cpp): fp64 tiles keep three workgroups on a
+  // CU (768 at once) up to 64 states per tile, fp32 tiles two (512) -- hence steps of 4 from 32 to 64 for fp64, of 8 from 64 to 128 for fp32
+#define WBC_TILE_CASE(n) case n: return qp_tiled<n>(L, rhat, prm, a, jmap);
+  if constexpr (std::is_same<T, double>::value) {
+    switch (tile) {
+      WBC_TILE_CASE(32) WBC_TILE_CASE(36) WBC_TILE_CASE(40) WBC_TILE_CASE(44) WBC_TILE_CASE(48) WBC_TILE_CASE(52) WBC_TILE_CASE(56) WBC_TILE_CASE(60)
+      WBC_TILE_CASE(64) WBC_TILE_CASE(128) WBC_TILE_CASE(256) WBC_TILE_CASE(512)
+      default: break;
+    }
+  } else {
+    switch (tile) {
+      WBC_TILE_CASE(32) WBC_TILE_CASE(64) WBC_TILE_CASE(72) WBC_TILE_CASE(80) WBC_TILE_CASE(88) WBC_TILE_CASE(96) WBC_TILE_CASE(104) WBC_TILE_CASE(112)
+      WBC_TILE_CASE(120) WBC_TILE_CASE(128) WBC_TILE_CASE(256) WBC_TILE_CASE(512)
+      default: break;
+    }
+  }
+#undef WBC_TILE_CASE
+  if (tile > 0) return hipErrorInvalidValue;   // a size this scalar type has no kernel for (the host validates the option per type)
   const dim3 grid((unsigned)((a.N + 3) / 4));   // one wavefront (four QPs) per workgroup
   if (rhat) WBC_KLAUNCH(L, (qp_group16_kernel<T, true>), grid, dim3(64), prm, a, jmap);
   else WBC_KLAUNCH(L, (qp_group16_kernel<T, false>), grid, dim3(64), prm, a, jmap);

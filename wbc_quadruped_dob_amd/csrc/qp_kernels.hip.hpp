@@ -51,10 +51,16 @@ __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<
 #define WBC_QP_TILE_PRE 1
 #endif
 constexpr int QP_PRE_WORDS = 48;
+// The predictor's arithmetic: the 6x6 factor and z = G^-1 S^(1/2) b, then the feet of `fmask` (x0 of the foot, its six slacks: count, summed
+// violation, "every slack clears the finishing threshold") and the columns of G^-1 in `cmask` (PRE only).  (The masks exist because sharing
+// one state's work among the tile's four wavefronts was tried: see qp_tile_kernel.)
+// A = the arithmetic type: the storage type T, except that a predictor that feeds the (fp64-arithmetic) solver works in double.
+template <class T, bool PRE> struct PredA { using type = typename std::conditional<PRE, double, T>::type; };
+template <class A> struct PredPart { int cnt; A mag; bool fin_ok; A zf0, zf1, zf2, zm0, zm1, zm2; };
 template <class T, bool RHAT, bool PRE = false>
-WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32, double* pre = nullptr) {
-  // A = the arithmetic type: the storage type T, except that a predictor that feeds the (fp64-arithmetic) solver works in double
-  using A = typename std::conditional<PRE, double, T>::type;
+WBC_DEV void qp_predict_part(const DevParams<T>& prm, const QpArgs<T>& a, unsigned s32, unsigned N32, double* pre, int fmask, int cmask,
+                             PredPart<typename PredA<T, PRE>::type>& out) {
+  using A = typename PredA<T, PRE>::type;
 #define PLD(ptr, comp) ((A)(*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T)))))
   constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
   const int mask = a.mask[s32] & 0xF;
@@ -111,6 +117,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   if constexpr (PRE) {   // G^-1, column by column (= row by row: symmetric): G x = e_c through the factor, zeros of e_c skipped by the compiler
     sfor<0, 6>([&](auto cc_) __attribute__((always_inline)) {
       constexpr int c = decltype(cc_)::value;
+      if (!((cmask >> c) & 1)) return;      // (wavefront-uniform)
       const A e0 = c == 0 ? (A)1 : (A)0, e1 = c == 1 ? (A)1 : (A)0, e2 = c == 2 ? (A)1 : (A)0, e3 = c == 3 ? (A)1 : (A)0, e4 = c == 4 ? (A)1 : (A)0,
               e5 = c == 5 ? (A)1 : (A)0;
       A u[6], gc[6];
@@ -135,6 +142,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
 #pragma unroll WBC_PRED_UNROLL_C
   for (int f = 0; f < 4; ++f) {
     // x0 of foot f = on (s_f z_f + (s_m z_m) x d_f)
+    if (!((fmask >> f) & 1)) continue;      // (wavefront-uniform)
     const bool on = (mask >> f) & 1;
     A dx, dy, dz;
     PLD_D(f, dx, dy, dz);
@@ -166,7 +174,24 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
     cnt_all += on ? cnt : 0;
     mag += on ? mg : (A)0;
   }
-  if (FIN && fin_ok) {   // solved: f = x0, tau = taup - rhat - Jc_leg^A f (the epilogue of qp_struct16_body, one state per lane)
+  out.cnt = cnt_all; out.mag = mag; out.fin_ok = fin_ok;
+  out.zf0 = zf0; out.zf1 = zf1; out.zf2 = zf2; out.zm0 = zm0; out.zm1 = zm1; out.zm2 = zm2;
+#undef PLD_D
+#undef PLD
+}
+
+// a state whose x0 violates nothing: f = x0, tau = taup - rhat - Jc_leg^T f, status 0, no iterations (the epilogue of qp_struct16_body, one state per lane)
+template <class T, bool RHAT, bool PRE = false>
+WBC_DEV void qp_predict_finish(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32,
+                               const PredPart<typename PredA<T, PRE>::type>& pp) {
+  using A = typename PredA<T, PRE>::type;
+#define PLD(ptr, comp) ((A)(*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T)))))
+#define PLD_D(f_, dx_, dy_, dz_) do { \
+    if (a.Jc) { dx_ = PLD(a.Jc, (3 * (f_) + 1) * 18 + 5); dy_ = PLD(a.Jc, (3 * (f_) + 2) * 18 + 3); dz_ = PLD(a.Jc, (3 * (f_)) * 18 + 4); } \
+    else { dx_ = PLD(a.ws, WS_D + 3 * (f_)); dy_ = PLD(a.ws, WS_D + 3 * (f_) + 1); dz_ = PLD(a.ws, WS_D + 3 * (f_) + 2); } } while (0)
+  const int mask = a.mask[s32] & 0xF;
+  const A zf0 = pp.zf0, zf1 = pp.zf1, zf2 = pp.zf2, zm0 = pp.zm0, zm1 = pp.zm1, zm2 = pp.zm2;
+  {
 #define PST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (T)(val))
 #pragma unroll WBC_PRED_UNROLL_F
     for (int f = 0; f < 4; ++f) {
@@ -188,19 +213,32 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
     a.status[s32] = 0;
     if (a.iters) a.iters[s32] = 0;
 #undef PST
-    return -1;
   }
 #undef PLD_D
 #undef PLD
-  // fitted on the bench data (least squares on the iteration count): 0.52 count + 0.70 ln(1 + summed violation); three
-  // buckets per predicted iteration.  Sorting by it: 2.96 trips per group (count alone 3.25, perfect knowledge 2.51).
-  const float kf = 1.56f * (float)cnt_all + 2.1f * __logf(1.0f + (float)mag);
+}
+
+// fitted on the bench data (least squares on the iteration count): 0.52 count + 0.70 ln(1 + summed violation); three
+// buckets per predicted iteration.  Sorting by it: 2.96 trips per group (count alone 3.25, perfect knowledge 2.51).
+WBC_DEV int qp_predict_keyval(int cnt_all, float mag) {
+  const float kf = 1.56f * (float)cnt_all + 2.1f * __logf(1.0f + mag);
   return (kf > 0.0f) ? (int)fminf(kf, 61.0f) : 0;   // 0 ... 61; a NaN / Inf state (garbage in) sorts as "no work", never out of range
+}
+
+// the whole predictor by one lane (tiles of more than 64 states): key 0 ... 61, or -1 = finished here
+template <class T, bool RHAT, bool PRE = false>
+WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32, double* pre = nullptr) {
+  constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
+  PredPart<typename PredA<T, PRE>::type> pp;
+  qp_predict_part<T, RHAT, PRE>(prm, a, s32, N32, pre, 0xF, 0x3F, pp);
+  if (FIN && pp.fin_ok) { qp_predict_finish<T, RHAT, PRE>(prm, a, jmap, s32, N32, pp); return -1; }
+  return qp_predict_keyval(pp.cnt, (float)pp.mag);
 }
 
 #ifndef WBC_QP_TILE_WAVES
 #define WBC_QP_TILE_WAVES 2
 #endif
+
 // DENSE (fp32 only): the orthogonal-factor body in fp32 arithmetic instead of the structured body in fp64 arithmetic.  At 117 VGPRs
 // four workgroups share a CU where the structured body's 183 allow two: from ~49 152 fp32 states on (more than two tiles of 64 per
 // CU) the dense body wins (65 536: 38 vs 46 us, 131 072: 72 vs 92 us), below it loses (32 768: 26.0 vs 23.4 us).  Measured, MI355X.
@@ -221,6 +259,9 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
   __syncthreads();
   // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = finished by the predictor, or beyond the end (not dealt)
   int bucket[(TILE + 255) / 256], rank[(TILE + 255) / 256];
+  // (measured and not kept: sharing one state's predictor work among the four wavefronts -- feet / columns of G^-1 per wavefront after the
+  //  common 6x6 factor, partial counts combined through LDS -- 31.5 vs 31.1 us at 32 768 fp64 states, 25.2 vs 24.4 at 24 576: the kernel is
+  //  bound by instructions issued, not by the stretch in which three wavefronts wait for the first, and the shared stem is issued four times)
 #pragma unroll
   for (int r = 0; r < (TILE + 255) / 256; ++r) {
     const unsigned i = tid + 256u * r;

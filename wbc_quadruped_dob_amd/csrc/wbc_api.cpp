@@ -303,8 +303,14 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
     o.struct_size = sizeof(o);
   }
   if (o.rollout_spw != 0 && o.rollout_spw != 4 && o.rollout_spw != 16) return fail(WBC_E_INVALID, "rollout_spw must be 0 (auto), 4 or 16");
-  if (o.qp_tile != 0 && o.qp_tile != -1 && o.qp_tile != 32 && o.qp_tile != 64 && o.qp_tile != 128 && o.qp_tile != 256 && o.qp_tile != 512)
-    return fail(WBC_E_INVALID, "qp_tile must be 0 (auto), -1 (off), 32, 64, 128, 256 or 512");
+  {   // the tile sizes the kernels of this scalar type exist for (k_qp.hip)
+    const int ok64[] = {0, -1, 32, 36, 40, 44, 48, 52, 56, 60, 64, 128, 256, 512};
+    const int ok32[] = {0, -1, 32, 64, 72, 80, 88, 96, 104, 112, 120, 128, 256, 512};
+    bool found = false;
+    if (dtype == WBC_F64) { for (int v : ok64) found = found || o.qp_tile == v; }
+    else { for (int v : ok32) found = found || o.qp_tile == v; }
+    if (!found) return fail(WBC_E_INVALID, "qp_tile: 0 (auto), -1 (off), 32, 64, 128, 256, 512; fp64 also 36 ... 60 in steps of 4, fp32 also 72 ... 120 in steps of 8");
+  }
   if (o.timing_mode != WBC_TIMING_DISPATCH && o.timing_mode != WBC_TIMING_EVENT_PAIR) return fail(WBC_E_INVALID, "bad timing_mode");
   if (o.f32_pack2 < -1 || o.f32_pack2 > 1) return fail(WBC_E_INVALID, "f32_pack2 must be -1, 0 or 1");
   if (o.keep_structural != 0 && o.keep_structural != 1) return fail(WBC_E_INVALID, "keep_structural must be 0 or 1");
@@ -332,9 +338,10 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   // both observer forms with their inputs requested up front) per tick, all-in-one -> split (M steps/s): fp64 437 -> 472 at
   // 65 536, 428 -> 446 at 49 152, 405 -> 439 at 40 960, 451 -> 460 at 32 768, 360 -> 398 at 24 576, 308 -> 341 at 20 480, but
   // 330 -> 289 at 16 384; fp32 855 -> 934 at 98 304, 784 -> 798 at 65 536, 681 -> 717 at 49 152, 594 -> 629 at 40 960, but
-  // 625 -> 587 at 32 768.  Default: fp64 from 20 480 states on, fp32 from 40 960.
+  // 625 -> 587 at 32 768.  Round 3 (M steps/s): fp32 570 -> 593 at 34 816, 599 -> 614 at 36 864, 612 -> 638 at 38 912 (past 32 768 states the
+  // all-in-one fp32 sweep needs a second round of wavefronts: 23.7 -> 37 us).  Default: fp64 from 20 480 states on, fp32 from 33 792.
   if (o.obs_split_min >= 0) s->obs_split_min = (size_t)o.obs_split_min;
-  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 40960 : 20480;
+  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 33792 : 20480;
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
@@ -579,7 +586,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   // observer-on data (trot masks: a fifth of the states end in the hand-over list) 462 -> 456 at 65 536, 467 -> 430 at
   // 49 152.  Hence the default: fp64 from 49 152 states on (+18 % on the 4-contact data, -8 % on the trot data there, even
   // from 65 536 on), fp32 from 262 144.
-  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)49152 : (size_t)262144));
+  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)49153 : (size_t)262144));   // (fp64: 49 152 states are still one round of 64-state tiles: 38.9 us against 32 + 14 for the per-lane pair)
   // front halves that do not change the target wrench leave it to the QP kernels to read the caller's w_des (QpArgs::wdes)
   const bool front_writes_b = ob && !(mats && N >= s->obs_split_min);   // the all-in-one observer forms: b = w_des - rhat_base
   qa.wdes = front_writes_b ? nullptr : (const T*)in->w_des;   // (those front halves run their SW_NOB / RS_NOB variants)
@@ -616,9 +623,18 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   //  16 384; 31.2 / 24.6 / 30.3 at 24 576; 32.4 / 31.9 / 29.9 at 28 672; 35.9 / 34.7 / 30.4 at 32 768.  fp32 -- whose tile kernel holds 180
   //  registers, two workgroups per CU, where the one-wave kernel runs four wavefronts per SIMD -- trot batch: 17.0 / 20.8 / 20.5 at 16 384,
   //  19.6 / 31.2 / 20.5 at 24 576, 22.1 / 33.4 / 22.0 at 28 672, 24.3 / 35.7 / 22.7 at 32 768; standing batch 31.3 / 44.1 / 37.2 at 24 576)
+  // ONE ROUND OF RESIDENT WORKGROUPS: the tile kernel keeps three workgroups on a CU in fp64 (159 registers; 768 on the device), two in fp32
+  // (181; 512), and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
+  // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
+  // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
   if (tile == 0) {
-    if (std::is_same<T, float>::value) tile = N >= 30720 ? 64 : 0;
-    else tile = N >= 28672 ? 64 : (N >= 14336 ? 32 : 0);
+    if (std::is_same<T, float>::value) {
+      if (N >= 30720 && N <= 65536) { tile = (int)(((N + 511) / 512 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }
+      else tile = N > 65536 ? 64 : 0;          // (beyond: tiles of 64 through the leaner fp32 body, four workgroups per CU -- k_qp.hip)
+    } else if (N >= 14336) {
+      tile = (int)(((N + 767) / 768 + 3) / 4 * 4);
+      tile = tile < 32 ? 32 : (tile > 64 ? 64 : tile);
+    }
   }
   if (tile < 0) tile = 0;
   if (lane) {
