@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-KUNITS = [("k_sweep", ()), ("k_rnea", ()), ("k_qp", ()), ("k_misc", ()), ("k_fused", ()), ("k_rollout", ()),
+KUNITS = [("k_sweep", ()), ("k_rnea", ()), ("k_qp", ()), ("k_qp_general", ()), ("k_misc", ()), ("k_fused", ()), ("k_rollout", ()),
           ("k_rollout", ("-DWBC_ROLLOUT_TRACK=1",))]
 
 
