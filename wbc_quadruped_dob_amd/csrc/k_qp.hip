@@ -13,7 +13,7 @@ template <int TILE>
 static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
   using T = Scalar;
   const dim3 grid((unsigned)((a.N + TILE - 1) / TILE));
-  if constexpr (std::is_same<T, float>::value && TILE == 64) {
+  if constexpr (std::is_same<T, float>::value && TILE >= 64 && TILE <= 128) {
     if (a.N >= (size_t)WBC_F32_DENSE_TILE_MIN) {   // more than two tiles per CU: the leaner fp32 body wins on occupancy (qp_kernels.hip.hpp)
       if (rhat) WBC_KLAUNCH(L, (qp_tile_kernel<T, true, TILE, true>), grid, dim3(256), prm, a, jmap);
       else WBC_KLAUNCH(L, (qp_tile_kernel<T, false, TILE, true>), grid, dim3(256), prm, a, jmap);

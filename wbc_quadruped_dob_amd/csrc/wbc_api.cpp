@@ -630,7 +630,10 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   if (tile == 0) {
     if (std::is_same<T, float>::value) {
       if (N >= 30720 && N <= 65536) { tile = (int)(((N + 511) / 512 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }
-      else tile = N > 65536 ? 64 : 0;          // (beyond: tiles of 64 through the leaner fp32 body, four workgroups per CU -- k_qp.hip)
+      else if (N > 65536) {                    // (beyond: the leaner fp32 body, FOUR workgroups per CU -- k_qp.hip: one round is 1 024 tiles)
+        tile = (int)(((N + 1023) / 1024 + 7) / 8 * 8);
+        tile = tile > 128 ? 64 : tile;         // (more than one round of 128-state tiles: many rounds of 64-state ones)
+      }
     } else if (N >= 14336) {
       tile = (int)(((N + 767) / 768 + 3) / 4 * 4);
       tile = tile < 32 ? 32 : (tile > 64 ? 64 : tile);
