@@ -13,7 +13,7 @@ done
 for f in bench_driver_flags_steps20 bench_cfg2_n262144_keep_structural bench_cfg2_n4096_keep_structural bench_scale_legs_1rank bench_under_rocprof_cfg4_n262144; do
   [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
 done
-for f in issue_probe tile_sweep; do [ -f "$O/$f.log" ] && cp "$O/$f.log" "$P/${T}_$f.log"; done
+for f in issue_probe tile_sweep midrange; do [ -f "$O/$f.log" ] && cp "$O/$f.log" "$P/${T}_$f.log"; done
 [ -f "$O/stats_cfg4_n262144_kernel_stats.csv" ] && cp "$O/stats_cfg4_n262144_kernel_stats.csv" "$P/${T}_kernel_stats_cfg4_f32_n262144.csv"
 [ -f "$O/stats_dyn_f32_kernel_stats.csv" ] && cp "$O/stats_dyn_f32_kernel_stats.csv" "$P/${T}_kernel_stats_dyn_alone_f32_n262144.csv"
 [ -f "$O/stats_dyn_f32_n32768_kernel_stats.csv" ] && cp "$O/stats_dyn_f32_n32768_kernel_stats.csv" "$P/${T}_kernel_stats_dyn_alone_f32_n32768.csv"
