@@ -30,14 +30,14 @@ def solver_with(options, **kw):
     return _solver(gm, options=options, **kw)
 
 
-bad, worst, t0 = [], 0.0, time.time()
+bad, worst, worst_big, t0 = [], 0.0, 0.0, time.time()
 for c in range(cases):
     obs = int(rng.integers(0, 3))
     cfg = int(rng.choice([2, 3, 4]))
     n = int(rng.choice([1, 7, 16, 17, 100, 1000, 2048, 4096, 5000, 8192][: (10 if obs == 0 else 8)]))
     if rng.random() < 0.3:
         n = int(rng.integers(1, 4097))
-    big = DT == "f64" and c % 7 == 3   # a larger batch: the tiled QP kernel (dealt by predicted work) and the per-lane kernel against the one-wave kernel
+    big = c % 7 == 3   # a larger batch: the tiled QP kernel (dealt by predicted work; the predictor hands G^-1 / x0 to the solver or finishes the state) and the per-lane kernel against the one-wave kernel
     if big:
         n = int(rng.integers(12288, 60000))
     B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
@@ -45,15 +45,39 @@ for c in range(cases):
     z = lambda: (None if integ0 is None else integ0.copy(), None if integ0 is None else np.zeros((n, 18)))
     if big:
         res = {}
-        for tag, opt in (("tiled", {"qp_tile": int(rng.choice([0, 32, 64, 128])), "qp_lane": -1}), ("plain", {"qp_tile": -1, "qp_lane": -1}), ("lane", {"qp_lane": 1})):
-            s, P = solver_with(opt, obs=obs, max_batch=n)
-            a1 = _run_step(torch, s, B, "f64", *z(), want_mats=bool(c % 2))
-            a2 = _run_step(torch, s, B, "f64", a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
+        tiles = [0, 32, 44, 64, 128] if DT == "f64" else [0, 64, 96, 128]
+        if DT == "f32":
+            n = int(rng.integers(12288, 140000))     # (fp32: past 65 536 states the leaner fp32 body runs the tiles)
+            B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
+            integ0 = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+        zz = lambda: tuple(None if t is None else t.astype(np.float32 if DT == "f32" else np.float64) for t in z())
+        for tag, opt in (("tiled", {"qp_tile": int(rng.choice(tiles)), "qp_lane": -1}), ("plain", {"qp_tile": -1, "qp_lane": -1}), ("lane", {"qp_lane": 1})):
+            s, P = solver_with(opt, obs=obs, max_batch=n, dtype=DT)
+            a1 = _run_step(torch, s, B, DT, *zz(), want_mats=bool(c % 2))
+            a2 = _run_step(torch, s, B, DT, a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
             res[tag] = (a1, a2)
-        for i in (0, 1):
-            for k in res["plain"][i]:
-                if not np.array_equal(res["tiled"][i][k], res["plain"][i][k]):
-                    bad.append((c, "tiled " + k, n, obs, cfg))
+        for i in (0, 1):     # same solver body, started from the predictor's numbers: status equal, iteration counts equal up to near-ties, values to rounding
+            a, b = res["tiled"][i], res["plain"][i]
+            same = a["status"] == b["status"]
+            if not same.all():
+                if DT == "f64" or same.mean() < 0.995:
+                    bad.append((c, "tiled status", n, obs, cfg))
+                flips += int((~same).sum())
+            # (the standing batch is symmetric: equally violated rows on different feet are exact ties in one kernel and rounding-level
+            #  near-ties in the other -- 0.1-0.15 % of its states take another, equally valid pivot sequence to the same solution; fp32 batches
+            #  past 65 536 states run the tiles on the fp32-arithmetic body: 2-3 %)
+            if np.mean(a["iters"] != b["iters"]) > (5e-3 if DT == "f64" else 5e-2):
+                bad.append((c, "tiled iters", n, obs, cfg, float(np.mean(a["iters"] != b["iters"]))))
+            for k in b:
+                if k in ("status", "iters"):
+                    continue
+                x, y = (a[k][same], b[k][same]) if a[k].shape[0] == same.shape[0] else (a[k], b[k])
+                e = relerr(x, y)
+                worst_big = max(worst_big, e)
+                if not e < (1e-10 if DT == "f64" else TOL):
+                    bad.append((c, "tiled " + k, n, obs, cfg, e))
+        if DT == "f32":
+            continue
         for i in (0, 1):   # per-lane semismooth Newton + hand-over list: another algorithm, same unique solution
             a, b = res["lane"][i], res["plain"][i]
             if not np.array_equal(a["status"], b["status"]):
@@ -129,6 +153,6 @@ for c in range(cases):
             worst = max(worst, e)
             if not e < 1e-9:
                 bad.append((c, "rollout " + k, n, obs, cfg, H, e))
-print("soak: %d cases (%s), seed %d, %.0f s, worst relative difference between dispatch variants %.2e, status flips %d, mismatches: %d %s"
-      % (cases, DT, seed, time.time() - t0, worst, flips, len(bad), bad[:10]))
+print("soak: %d cases (%s), seed %d, %.0f s, worst relative difference between dispatch variants %.2e (tiled vs one-wave QP kernel: %.2e), status flips %d, mismatches: %d %s"
+      % (cases, DT, seed, time.time() - t0, worst, worst_big, flips, len(bad), bad[:10]))
 sys.exit(1 if bad else 0)
