@@ -393,7 +393,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       // instructions for the same bytes (a wave store instruction costs ~90 cycles to issue whatever its width)
       struct alignas(2 * sizeof(V)) T2 { V a, b; };
       const unsigned odd = (s32 / W) & 1u, s2 = s32 & ~(unsigned)(2 * W - 1);
-      const bool live2 = live;  // N a multiple of 2 W: the states of a lane pair are in range together
+      // (N is a multiple of 2 W here: the states of a lane pair are in range together, so the pair store needs no guard of its own)
 #define ST2C(ptr, comp, val) do { WBC_OUT_GUARD *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
       for (int e = 2 * leg + (int)odd; e < 64; e += 8) {
         const int zi = zidx_s[e];
