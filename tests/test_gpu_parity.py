@@ -678,7 +678,11 @@ def test_fused_tick_equals_two_kernel_tick(torch_cuda, gpu_model, oracle, obs, d
 
 
 @pytest.mark.parametrize("obs,dtype,n,tile,split", [(0, "f64", 1003, 64, -2), (1, "f64", 70001, 256, -2), (0, "f32", 5000, 128, -2),
-                                                   (2, "f64", 2051, 512, 1), (1, "f32", 66000, 256, 1), (0, "f64", 3, 256, -2)])
+                                                   (2, "f64", 2051, 512, 1), (1, "f32", 66000, 256, 1), (0, "f64", 3, 256, -2),
+                                                   # the in-between tile sizes of the one-round rule, the automatic choice on either side of a
+                                                   # round boundary (768 x 40 = 30 720 states in fp64), fp32 tiles on both bodies (<= / > 65 536 states)
+                                                   (0, "f64", 4001, 44, -2), (1, "f64", 9999, 52, 1), (0, "f64", 30720, 0, -2), (1, "f64", 30721, 0, -2),
+                                                   (0, "f32", 40001, 0, -2), (1, "f32", 9000, 96, -2), (1, "f32", 70000, 0, -2), (0, "f32", 66001, 120, -2)])
 def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtype, n, tile, split):
     """Large batches deal the QPs of a tile to the wavefronts by predicted work (qp_tile_kernel: predictor, LDS counting
     sort, groups pulled from a queue).  The solver body is the one-wavefront-workgroup kernel's, but it STARTS from what the
@@ -704,7 +708,7 @@ def test_tiled_qp_kernel_equals_one_wave_kernel(torch_cuda, gpu_model, obs, dtyp
         for k in ("tau", "f"):
             assert relerr(res["tiled"][k], res["plain"][k]) < 1e-10, k      # cond(G) ~ 1e4 times the rounding of two operation orders
     else:
-        assert np.mean(res["tiled"]["iters"] != res["plain"]["iters"]) < 1e-2
+        assert np.mean(res["tiled"]["iters"] != res["plain"]["iters"]) < (1e-2 if n <= 65536 else 5e-2)   # (past 65 536 states the tiles run the fp32-arithmetic body)
         assert relerr(res["tiled"]["tau"], res["plain"]["tau"]) < 1e-3 and relerr(res["tiled"]["f"], res["plain"]["f"]) < 1e-3
     assert res["plain"]["iters"].max() >= (3 if n > 100 else 0)
 
