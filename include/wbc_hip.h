@@ -330,7 +330,7 @@ int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batch_in* host_
  * absent submodule, .gitmodules:4-6, so its variable set is unknown -- a formulation that also carries accelerations, slacks or
  * joint-torque rows is assembled by the caller and solved here).
  *
- *     min 1/2 x^T H x + g^T x    s.t.   C_i x = d_i (i < meq),   C_i x >= d_i (meq <= i < m);    1 <= n <= 36, 0 <= m <= 48
+ *     min 1/2 x^T H x + g^T x    s.t.   C_i x = d_i (i < meq),   C_i x >= d_i (meq <= i < m);    1 <= n <= 36, 0 <= m <= 64
  *
  * All pointers are DEVICE pointers on the current device, PROBLEM-major (one problem's data contiguous): H [N][n*n] row-major,
  * symmetric positive definite (both triangles given, the lower one is read); g [N][n]; C [N][m*n] row-major; d [N][m]; x [N][n];

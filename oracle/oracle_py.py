@@ -288,7 +288,7 @@ def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9):
 
 
 def qp_general(H, g, Cm, d, meq=0, max_iter=200, tol=1e-9):
-    """qp_general.hpp: min 1/2 x'Hx + g'x  s.t.  Cm[:meq] x = d[:meq], Cm[meq:] x >= d[meq:]   (n <= 36, m <= 48).
+    """qp_general.hpp: min 1/2 x'Hx + g'x  s.t.  Cm[:meq] x = d[:meq], Cm[meq:] x >= d[meq:]   (n <= 36, m <= 64).
     One problem (H[n,n]) or a batch (H[N,n,n], ...; fp64 only).  Returns x, lambda, status, iters."""
     H = np.asarray(H)
     if H.ndim == 3:

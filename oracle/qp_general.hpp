@@ -22,7 +22,7 @@
 
 namespace wbco {
 
-constexpr int QPG_MAXN = 36, QPG_MAXM = 48;
+constexpr int QPG_MAXN = 36, QPG_MAXM = 64;   // (a constraint per lane: 64 is the wavefront)
 
 template <class T>
 int qp_solve_gi_general(int n, int m, int meq, const T* H, const T* g, const T* C, const T* d, int max_iter, T tol, T* x,

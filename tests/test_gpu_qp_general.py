@@ -1,4 +1,4 @@
-"""GPU: the general dense QP kernel (wbc_qp_dense_batch -> csrc/qp_general.hip.hpp: run-time sizes n <= 36, m <= 48, equality rows,
+"""GPU: the general dense QP kernel (wbc_qp_dense_batch -> csrc/qp_general.hip.hpp: run-time sizes n <= 36, m <= 64, equality rows,
 one QP per wavefront with its factors in LDS) against the oracle's general solver (oracle/qp_general.hpp), through the C-ABI.
 
 * random strictly convex problems of every size class, fp64: status and iteration counts EQUAL the oracle's (same method, same
@@ -39,7 +39,8 @@ def _gpu(torch, H, g, C, d, meq, dtype=None, **kw):
 
 
 @pytest.mark.parametrize("n,m,meq,N", [(1, 2, 0, 7), (3, 5, 1, 130), (12, 24, 0, 1001), (12, 24, 4, 300), (20, 30, 6, 257), (36, 48, 0, 301),
-                                       (36, 48, 10, 129), (30, 48, 30, 64), (9, 0, 0, 50), (7, 7, 7, 33)])
+                                       (36, 48, 10, 129), (30, 48, 30, 64), (9, 0, 0, 50), (7, 7, 7, 33),
+                                       (30, 58, 18, 200), (36, 64, 12, 130)])   # (the size of a whole-body QP over accelerations and forces; the largest)
 def test_random_problems_vs_oracle_fp64(torch_cuda, n, m, meq, N):
     from oracle import oracle_py as O
     rng = np.random.default_rng(100 * n + m + meq)

@@ -1,4 +1,4 @@
-"""CPU: the general dense QP of the oracle (oracle/qp_general.hpp: run-time sizes up to 36 x 48, equality rows) -- the checker of
+"""CPU: the general dense QP of the oracle (oracle/qp_general.hpp: run-time sizes up to 36 x 64, equality rows) -- the checker of
 the product's one-QP-per-wavefront kernel (csrc/qp_general.hip.hpp) -- pinned three ways: bit-equal to the 12-variable solver the
 rest of the oracle uses on the controller's own GRF QPs, KKT conditions on random problems of every size class, scipy."""
 import numpy as np
@@ -37,7 +37,7 @@ def test_equals_the_grf_solver_bit_for_bit(mask):
         assert np.array_equal(x0, x1) and np.array_equal(l0, l1)
 
 
-@pytest.mark.parametrize("n,m,meq", [(1, 0, 0), (1, 2, 0), (3, 5, 1), (12, 24, 0), (12, 24, 4), (20, 30, 6), (36, 48, 0), (36, 48, 10), (30, 48, 30)])
+@pytest.mark.parametrize("n,m,meq", [(1, 0, 0), (1, 2, 0), (3, 5, 1), (12, 24, 0), (12, 24, 4), (20, 30, 6), (36, 48, 0), (36, 48, 10), (30, 48, 30), (30, 58, 18), (36, 64, 12)])
 def test_kkt_on_random_problems(n, m, meq):
     rng = np.random.default_rng(1000 * n + m + meq)
     its = 0
@@ -90,6 +90,7 @@ def test_status_codes_and_edge_cases():
     Hn = np.diag([1.0, -1.0, 1.0])
     assert O.qp_general(Hn, g, C, np.zeros(2))[2] == 3
     assert O.qp_general(np.eye(37), np.zeros(37), np.zeros((1, 37)), np.zeros(1))[2] == -1
+    assert O.qp_general(np.eye(3), np.zeros(3), np.zeros((65, 3)), np.zeros(65))[2] == -1
     # no constraints: the unconstrained minimum
     x, lam, st, it = O.qp_general(Hr, gr, np.zeros((0, 12)), np.zeros(0))
     assert st == 0 and it == 0 and np.allclose(Hr @ x, -gr)

@@ -523,7 +523,7 @@ def shard_range(n_total, n_shards, shard):
 def qp_dense_batch(H, g, Cm=None, d=None, meq=0, max_iter=200, tol=None, want_lambda=True, stream=None):
     """wbc_qp_dense_batch: N dense QPs of one run-time size, one per wavefront (csrc/qp_general.hip.hpp).
         min 1/2 x'Hx + g'x   s.t.   Cm[:, :meq] x = d[:, :meq],   Cm[:, meq:] x >= d[:, meq:]
-    H [N, n, n], g [N, n], Cm [N, m, n], d [N, m]: contiguous CUDA tensors of one dtype (float64 / float32), n <= 36, m <= 48.
+    H [N, n, n], g [N, n], Cm [N, m, n], d [N, m]: contiguous CUDA tensors of one dtype (float64 / float32), n <= 36, m <= 64.
     Returns dict(x [N, n], lam [N, m] | None, status [N] int32 (0 ok, 1 iteration limit, 2 infeasible, 3 H not PD), iters [N]).
     Enqueued on `stream` (default: torch's current stream); does not synchronise."""
     import torch

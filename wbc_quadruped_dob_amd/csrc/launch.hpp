@@ -40,7 +40,7 @@ template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bo
 template <class T> hipError_t k_rollout(const LaunchCtx& L, bool observer, bool track, int spw, const DevModel<T>* model, const DevParams<T>& prm,
                                        const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap, const IntegrateArgs<T>& ia, int horizon,
                                        const DevRefParams<T>* G, const RefArgs<T>& ra);
-// qp_general_kernel<T>: dense QPs of run-time size (n <= 36 variables, m <= 48 rows, the first meq of them equalities), one per wavefront
+// qp_general_kernel<T>: dense QPs of run-time size (n <= 36 variables, m <= 64 rows, the first meq of them equalities), one per wavefront
 template <class T> hipError_t k_qp_general(const LaunchCtx& L, const QpGeneralArgs<T>& a);
 // one thread: *ptr = value, system scope (the completion ticket of the flag-polled single-robot tick)
 hipError_t k_flag(hipStream_t st, unsigned* ptr, unsigned value);

@@ -1,12 +1,12 @@
 // qp_general_kernel: a strictly convex dense QP of RUN-TIME size, one per WAVEFRONT, factors and working set in LDS.
 //
-//     min 1/2 x^T H x + g^T x     s.t.   C_i x  = d_i  (i <  meq),     C_i x >= d_i  (meq <= i < m),      n <= 36,  m <= 48
+//     min 1/2 x^T H x + g^T x     s.t.   C_i x  = d_i  (i <  meq),     C_i x >= d_i  (meq <= i < m),      n <= 36,  m <= 64
 //
 // Why it exists: the GRF QP of this controller (units a7 / a8) is the structured 12-variable problem the kernels of
 // qp_struct16.hip.hpp / qp_lane.hip.hpp are written around, and that shape is a GUESS about the reference: README.md:11 says only
 // "optimization problem based on the modulation of ground reaction forces", the controller's source is an absent submodule
 // (.gitmodules:4-6).  A formulation with other variables (accelerations, slacks, joint-torque rows) does not fit those kernels at
-// all.  This one takes any (H, g, C, d) -- the survey's "parametric in nvar <= 36, ncon <= 48", and the north_star's "one QP per
+// all.  This one takes any (H, g, C, d) -- the survey's "parametric in nvar <= 36, ncon <= 48" (64 rows here: a constraint per lane), and the north_star's "one QP per
 // wavefront with active-set iterations held in LDS" literally.  It is the general path, not the fast one (the 12-variable GRF QP
 // through it: see DESIGN.md section 4.2b for the measured factor).
 //

@@ -5,7 +5,7 @@
 
 namespace wbc {
 
-constexpr int QPG_MAXN = 36, QPG_MAXM = 48;
+constexpr int QPG_MAXN = 36, QPG_MAXM = 64;   // (a constraint per lane: 64 is the wavefront)
 
 template <class T> struct QpGeneralArgs {
   size_t N;

@@ -1061,7 +1061,7 @@ extern "C" int wbc_qp_dense_batch(int dtype, size_t N, int n, int m, int meq, co
                                   int max_iter, double tol, void* x, void* lambda, int* status, int* iters, void* hipStream) {
   if (dtype != WBC_F64 && dtype != WBC_F32) return fail(WBC_E_INVALID, "dtype must be WBC_F64 or WBC_F32");
   if (n < 1 || n > wbc::QPG_MAXN || m < 0 || m > wbc::QPG_MAXM || meq < 0 || meq > m)
-    return fail(WBC_E_INVALID, "sizes: 1 <= n <= 36, 0 <= meq <= m <= 48");
+    return fail(WBC_E_INVALID, "sizes: 1 <= n <= 36, 0 <= meq <= m <= 64");
   if (!H || !g || !x || !status || (m > 0 && (!C || !d))) return fail(WBC_E_INVALID, "null argument");
   if (max_iter < 0 || !(tol >= 0)) return fail(WBC_E_INVALID, "max_iter >= 0, tol >= 0");
   if (N == 0) return WBC_OK;
