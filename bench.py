@@ -616,11 +616,12 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
 
 def qp_dense_general(W, torch, dtype):
     """The general dense QP kernel (wbc_qp_dense_batch: run-time sizes, one QP per wavefront, factors in LDS) on random strictly
-    convex problems generated on the device: the size of the controller's own GRF QP and the largest size it takes.  Reported beside
-    the structured path, not part of `value`."""
+    convex problems generated on the device: the size of the controller's own GRF QP, the size of a whole-body QP over CoM / joint accelerations
+    and contact forces with torque bounds (30 variables, 58 rows, 18 of them equalities), the largest size it takes, and ONE such problem per
+    launch (a single robot's tick through the general path).  Reported beside the structured path, not part of `value`."""
     td = torch.float64 if dtype == "f64" else torch.float32
     out = {}
-    for n, m, meq, N in ((12, 24, 0, 4096), (36, 48, 8, 4096)):
+    for n, m, meq, N in ((12, 24, 0, 4096), (30, 58, 18, 4096), (36, 64, 12, 4096), (30, 58, 18, 1)):
         gen = torch.Generator(device="cuda").manual_seed(1234 + n)
         A = torch.randn(N, n, n, dtype=torch.float64, device="cuda", generator=gen)
         H = (A @ A.transpose(1, 2)) / n + torch.eye(n, dtype=torch.float64, device="cuda")
@@ -644,7 +645,7 @@ def qp_dense_general(W, torch, dtype):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        out["n%d_m%d_meq%d" % (n, m, meq)] = {"batch": N, "launch_us": us, "qps_per_s": N / us * 1e6, "iters_mean": float(o["iters"].double().mean()),
+        out["n%d_m%d_meq%d%s" % (n, m, meq, "" if N > 1 else "_single")] = {"batch": N, "launch_us": us, "qps_per_s": N / us * 1e6, "iters_mean": float(o["iters"].double().mean()),
                                             "status_ok_frac": float((o["status"] == 0).double().mean())}
     out["note"] = ("random feasible problems (H = A A^T / n + I, a third of the rows active at the optimum), same-stream back-to-back launches; the "
                    "controller's own 12-variable GRF QP goes through the structured kernels instead (kernels.qp_us)")
