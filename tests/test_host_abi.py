@@ -198,3 +198,13 @@ def test_bench_refuses_more_gpus_than_present():
     run = subprocess.run(["python", os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
                          capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
     assert run.returncode == 3 and "GPU(s) visible" in run.stderr
+
+
+def test_abi_version_is_the_same_everywhere(hip_lib):
+    """The number the library returns, the one the header documents and the one __graft_entry__.build() asserts (a bump that
+    forgot the last one would fail the driver's build check, not a test)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "wbc_hip.h")).read()
+    doc = int(re.search(r"int wbc_abi_version\(void\); /\* (\d+) \*/", hdr).group(1))
+    entry = int(re.search(r"wbc_abi_version\(\) == (\d+)", open(os.path.join(ROOT, "__graft_entry__.py")).read()).group(1))
+    assert hip_lib.wbc_abi_version() == doc == entry
