@@ -1,5 +1,5 @@
 #!/bin/bash
-# fp32 batches between one and two rounds of the dense-body tiles (four workgroups per CU): default tile rule against tiles of 64
+# (A/B behind the tile rule of wbc_api.cpp for fp32 batches past 65 536 states) fp32 batches between one and two rounds of the dense-body tiles (four workgroups per CU): default tile rule against tiles of 64
 set -u
 export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; cd "$R"
