@@ -888,19 +888,20 @@ def test_hand_over_list_takes_a_whole_batch_and_empties_itself(torch_cuda, gpu_m
         assert relerr(got2["tau"], ref["tau"]) < TIGHT64 and relerr(got2["f"], ref["f"]) < TIGHT64
 
 
-@pytest.mark.parametrize("n,lane", [(512, 0), (20992, 0), (20992, 1)])   # the fused tick; the two-kernel tick with the tiled QP kernel (predictor
-def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle, n, lane):   # + LDS sort); with the per-lane QP kernel in front
+@pytest.mark.parametrize("n,lane,dtype", [(512, 0, "f64"), (20992, 0, "f64"), (20992, 1, "f64"), (40000, 0, "f32")])   # the fused tick; the two-kernel tick with the tiled QP kernel (predictor
+def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle, n, lane, dtype):   # + LDS sort, hand-over of G^-1 / x0); with the per-lane QP kernel in front; fp32 tiles whose predictor finishes feasible states
     """Quaternions and terrain normals are normalised inside (as in the oracle); a NaN in one state's inputs must not
     hang the kernels nor disturb any other state."""
     torch = torch_cuda
-    solver, P = _solver(gpu_model, max_batch=n, options={"qp_lane": lane})
+    solver, P = _solver(gpu_model, dtype=dtype, max_batch=n, options={"qp_lane": lane})
+    tol = TIGHT64 if dtype == "f64" else 1e-3
     B = synth.make_batch(4, n, gpu_model.total_mass, rank=51)
     ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
     B2 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}
     B2["q"][:, 3:7] *= 0.37
     B2["normals"] *= 2.5
-    got = _run_step(torch, solver, B2, "f64")
-    assert relerr(got["tau"], ref["tau"]) < TIGHT64 and relerr(got["f"], ref["f"]) < TIGHT64
+    got = _run_step(torch, solver, B2, dtype)
+    assert relerr(got["tau"], ref["tau"]) < tol and relerr(got["f"], ref["f"]) < tol
     B3 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}
     bad = [5, 130, 131, 400, n - 1]
     B3["w_des"][bad[0], 2] = np.nan
@@ -908,8 +909,8 @@ def test_unnormalised_inputs_and_nan_isolation(torch_cuda, gpu_model, oracle, n,
     B3["q"][bad[1], 9] = np.nan
     B3["normals"][bad[2], 4] = np.inf
     B3["mu"][bad[3], 1] = np.nan
-    got3 = _run_step(torch, solver, B3, "f64")   # must return (the QP loop is bounded)
+    got3 = _run_step(torch, solver, B3, dtype)   # must return (the QP loop is bounded)
     good = np.ones(n, bool)
     good[bad] = False
-    assert relerr(got3["tau"][good], ref["tau"][good]) < TIGHT64
-    np.testing.assert_array_equal(got3["status"][good], ref["status"][good])
+    assert relerr(got3["tau"][good], ref["tau"][good]) < tol
+    assert np.mean(got3["status"][good] != ref["status"][good]) <= (0 if dtype == "f64" else 1e-3)
