@@ -185,6 +185,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     QpArgs<T> qat = qa;
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
+    if (t > 0) at.skip_consts = 1;   // the structural zeros / ones of M, Jc were written by tick 0 of THIS launch into the same buffers (the mass_jac role's
+                                     // ~55 store instructions per tick sit in front of the integrator's factorisation: wbc_api.cpp, rollout_persistent)
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the last tick's role timestamps go out through the pf output
     double* const rstamp = (t == horizon - 1) ? (double*)a.pf : nullptr;
     const unsigned rstampN = (unsigned)n_tick;

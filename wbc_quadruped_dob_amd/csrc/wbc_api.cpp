@@ -59,6 +59,7 @@ struct wbc_solver {
   int leg_body[4][3];
   void* d_model = nullptr;  // DevModel<T>
   void* d_ws = nullptr;     // WS_LDS_WORDS * max_batch * sizeof(T): the 66 step words + 18 words of rhat (separate observer kernel)
+  int in_rollout = 0;       // inside the per-tick loop of wbc_rollout_batch, past its first tick
   int* d_todo = nullptr;    // 4 + max_batch ints: states the per-lane QP kernel hands to the dense active-set kernel (count, workgroups done, count of the last tick, pad; indices)
   QpJidx jmap;
   // resolved options
@@ -512,7 +513,8 @@ template <class T> static const DevModel<T>* dev_model(const wbc_solver* s) { re
 // last wrote them); records the buffers otherwise
 static int structural_kept(wbc_solver* s, const void* M, const void* Jc, size_t N) {
   if (!M) return 0;
-  if (s->opt.keep_structural && M == s->kept_M && Jc == s->kept_Jc && N == s->kept_N) return 1;
+  // (in_rollout: ticks 1 .. horizon-1 of ONE wbc_rollout_batch call write the buffers tick 0 of the same call wrote)
+  if ((s->opt.keep_structural || s->in_rollout) && M == s->kept_M && Jc == s->kept_Jc && N == s->kept_N) return 1;
   s->kept_M = M; s->kept_Jc = Jc; s->kept_N = N;
   return 0;
 }
@@ -715,7 +717,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   a.tau_prev = (const T*)out->tau; a.f_prev = (const T*)out->f;
   a.obs_integ = obs ? (T*)obs->integ : nullptr; a.obs_r = obs ? (T*)obs->r : nullptr;
   a.ws = (T*)s->d_ws;
-  a.skip_consts = 0;   // (a persistent rollout writes M / Jc in full every tick: its mass_jac role is not on the tick's critical path)
+  a.skip_consts = 0;   // (tick 0 writes M / Jc in full; the later ticks of the launch leave their structural zeros / ones alone: rollout_kernel)
   s->kept_M = nullptr;
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
@@ -764,8 +766,11 @@ extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const size_t nj = 12;
   ON_DEVICE(s);
+  s->kept_M = nullptr;   // tick 0 writes M, Jc in full whatever an earlier call left there
   for (int t = 0; t < horizon; ++t) {
+    s->in_rollout = t > 0;
     int rc = wbc_step_batch(s, N, &tick, out, obs, stream);
+    s->in_rollout = 0;
     if (rc) return rc;
     void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -863,7 +868,10 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
     int rc = wbc_reference_batch(s, N, in->q, in->v, plan, (double)t * s->params.dt, (void*)in->w_des, (void*)in->vdot_des, com,
                                  stream);
     if (rc) return rc;
+    if (t == 0) s->kept_M = nullptr;
+    s->in_rollout = t > 0;
     rc = wbc_step_batch(s, N, &tick, out, obs, stream);
+    s->in_rollout = 0;
     if (rc) return rc;
     void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
     hipStream_t st = (hipStream_t)stream;
