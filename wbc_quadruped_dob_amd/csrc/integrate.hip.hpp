@@ -105,19 +105,28 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     }
   }
 
+  // the state of this tick (q, v: inputs of the tick, untouched until the stores at the end) is requested BEFORE the tick barrier: the loads
+  // complete while the wavefront waits there instead of after it
+  T ql[3], vl[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { ql[k] = LDV(a.q, 7 + jx[k]); vl[k] = LDV(a.v, 6 + jx[k]); }
+  T vb0[6], qb[7];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) vb0[c] = LDU(a.v, c);
+#pragma unroll
+  for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
+
   between();
 
   // ================================================================== phase 2: tau, f, h, q, v
   // ---- my leg: rhs_l = tau_l + JcL^T f_l + tau_ext_l - h_l
   const V3<T> fl = mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
-  T rl[3], ql[3], vl[3], taul[3];
+  T rl[3], taul[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     taul[k] = LDV(a.tau, jx[k]);
     rl[k] = taul[k] + jcl[0][k] * fl.x + jcl[1][k] * fl.y + jcl[2][k] * fl.z - LDV(a.h, 6 + jx[k]) +
             (a.tau_ext ? LDV(a.tau_ext, 6 + jx[k]) : (T)0);
-    ql[k] = LDV(a.q, 7 + jx[k]);
-    vl[k] = LDV(a.v, 6 + jx[k]);
   }
   // ---- base right-hand side rb = rhs_b - sum_legs W rl
   T rb[6];
@@ -173,11 +182,9 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     STV(a.q, 7 + jx[k], ql[k] + dt * vn);
     if (a.tau_traj) STV(a.tau_traj, jx[k], taul[k]);
   }
-  T vbn[6], qb[7];
+  T vbn[6];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) vbn[c] = LDU(a.v, c) + dt * vb[c];
-#pragma unroll
-  for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
+  for (int c = 0; c < 6; ++c) vbn[c] = vb0[c] + dt * vb[c];
   T qn[7];
 #pragma unroll
   for (int c = 0; c < 3; ++c) qn[c] = qb[c] + dt * vbn[c];
