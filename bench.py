@@ -108,6 +108,9 @@ def long_blocks_of(step, k0, dist, torch, np, min_block_s=5e-3):
     """timed_blocks with a block length that is raised until the median block lasts at least min_block_s (a first estimate of the
     step time taken right after set-up can be off by an order of magnitude: module load, clocks)"""
     k = max(1, int(k0))
+    if dist is not None:   # k0 comes from each rank's own clock: every rank must run the SAME number of steps (callers follow the blocks
+        from wbc_quadruped_dob_amd.sharding import agree_on_steps   # with per-step collectives; a different count per rank would hang them)
+        k = agree_on_steps(k, dist, "cuda")
     for _ in range(4):
         bl = timed_blocks(step, k, dist, torch)
         el = float(np.median(bl))

@@ -60,9 +60,12 @@ def _worker(rank, world, port, n_total, q):
         tau_all = sb.gather(out["tau"])
         stats = sb.status_counts(out["status"], out["iters"])
         # the bench's "with all-gather" leg needs equal slices: run it on the first 500 states of each rank
-        from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather
+        from wbc_quadruped_dob_amd.sharding import agree_on_steps, timed_steps_with_gather
         eq = {k: v[..., :500].contiguous() for k, v in loc.items()}
-        secs, gathered = timed_steps_with_gather(lambda: sb.step(eq), lambda o: o["tau"], dist, 2)
+        # each rank proposes its own step count (as bench.py's ranks do from their own clocks): the leg must run with the agreed one
+        k_steps = agree_on_steps(2 + (rank % 2), dist)
+        assert k_steps == (3 if world > 1 else 2)
+        secs, gathered = timed_steps_with_gather(lambda: sb.step(eq), lambda o: o["tau"], dist, k_steps)
         assert secs > 0 and tuple(gathered.shape) == (world, 12, 500)
         assert torch.equal(gathered[rank], sb.step(eq)["tau"])
         if rank == 0:

@@ -70,6 +70,18 @@ class ShardedBatch:
                     iters_max=int(mx[0]))
 
 
+def agree_on_steps(k, dist, device=None):
+    """Every rank derives its block length from its OWN clock; legs that follow each step with a collective (the all-gather below)
+    must run the same number of steps on every rank or they hang.  Returns the maximum of `k` over the ranks (k itself without a
+    process group)."""
+    if dist is None:
+        return int(k)
+    import torch
+    t = torch.tensor([int(k)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None):
     """SURVEY.md 8e "report steps/s with and without the all-gather": runs `steps` ticks where every tick is followed by
     an all-gather of this rank's tau ([nj, n_local], equal n_local on every rank) into a preallocated
