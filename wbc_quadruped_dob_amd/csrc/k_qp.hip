@@ -45,7 +45,8 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
     }
   } else {
     switch (tile) {
-      WBC_TILE_CASE(32) WBC_TILE_CASE(64) WBC_TILE_CASE(72) WBC_TILE_CASE(80) WBC_TILE_CASE(88) WBC_TILE_CASE(96) WBC_TILE_CASE(104) WBC_TILE_CASE(112)
+      WBC_TILE_CASE(32) WBC_TILE_CASE(36) WBC_TILE_CASE(40) WBC_TILE_CASE(44) WBC_TILE_CASE(48) WBC_TILE_CASE(52) WBC_TILE_CASE(56) WBC_TILE_CASE(60)
+      WBC_TILE_CASE(64) WBC_TILE_CASE(72) WBC_TILE_CASE(80) WBC_TILE_CASE(88) WBC_TILE_CASE(96) WBC_TILE_CASE(104) WBC_TILE_CASE(112)
       WBC_TILE_CASE(120) WBC_TILE_CASE(128) WBC_TILE_CASE(256) WBC_TILE_CASE(512)
       default: break;
     }

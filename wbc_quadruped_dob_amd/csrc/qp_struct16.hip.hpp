@@ -100,9 +100,13 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   // ------------------------------------------------------------------ G = alpha I + B B^T and its factor (as in qp_group16_body)
   const T onf = on ? (T)1 : (T)0;
   const T dqx = onf * dppx<0x00>(d_me), dqy = onf * dppx<0x55>(d_me), dqz = onf * dppx<0xAA>(d_me);   // my foot's lever arm, zero for a swing foot
-  T s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
-  T alpha_l = prm.alpha, ralpha = prm.rsqrt_alpha * prm.rsqrt_alpha;
-  if constexpr (WSLDS || TILED) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(ralpha));
+  // (kernel-uniform weights pass through an empty asm so that products of two of them are not hoisted out of the tile / horizon loop and held
+  //  in registers for the whole kernel.  Tiles launder the raw values as SCALARS, before any conversion: sixteen vector registers less)
+  TS r0 = prm.sS[0], r1 = prm.sS[1], r2 = prm.sS[2], r3 = prm.sS[3], r4 = prm.sS[4], r5 = prm.sS[5], ra = prm.alpha, rq = prm.rsqrt_alpha;
+  if constexpr (TILED) asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3), "+s"(r4), "+s"(r5), "+s"(ra), "+s"(rq));
+  T s0 = r0, s1 = r1, s2 = r2, s3 = r3, s4 = r4, s5 = r5;
+  T alpha_l = ra, ralpha = (T)rq * (T)rq;
+  if constexpr (WSLDS) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(ralpha));
   const int gi = l16 < 6 ? l16 : (l16 < 12 ? l16 - 6 : l16 - 12);
   T Gr[6];
   if constexpr (PRE) {

@@ -306,7 +306,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (o.rollout_spw != 0 && o.rollout_spw != 4 && o.rollout_spw != 16) return fail(WBC_E_INVALID, "rollout_spw must be 0 (auto), 4 or 16");
   {   // the tile sizes the kernels of this scalar type exist for (k_qp.hip)
     const int ok64[] = {0, -1, 32, 36, 40, 44, 48, 52, 56, 60, 64, 128, 256, 512};
-    const int ok32[] = {0, -1, 32, 64, 72, 80, 88, 96, 104, 112, 120, 128, 256, 512};
+    const int ok32[] = {0, -1, 32, 36, 40, 44, 48, 52, 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 256, 512};
     bool found = false;
     if (dtype == WBC_F64) { for (int v : ok64) found = found || o.qp_tile == v; }
     else { for (int v : ok32) found = found || o.qp_tile == v; }
@@ -625,13 +625,13 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   //  16 384; 31.2 / 24.6 / 30.3 at 24 576; 32.4 / 31.9 / 29.9 at 28 672; 35.9 / 34.7 / 30.4 at 32 768.  fp32 -- whose tile kernel holds 180
   //  registers, two workgroups per CU, where the one-wave kernel runs four wavefronts per SIMD -- trot batch: 17.0 / 20.8 / 20.5 at 16 384,
   //  19.6 / 31.2 / 20.5 at 24 576, 22.1 / 33.4 / 22.0 at 28 672, 24.3 / 35.7 / 22.7 at 32 768; standing batch 31.3 / 44.1 / 37.2 at 24 576)
-  // ONE ROUND OF RESIDENT WORKGROUPS: the tile kernel keeps three workgroups on a CU in fp64 (159 registers; 768 on the device), two in fp32
-  // (181; 512), and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
+  // ONE ROUND OF RESIDENT WORKGROUPS: the tile kernel keeps three workgroups on a CU (146 registers in fp64, 159 in fp32; 768 on the device),
+  // and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
   // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
   // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
   if (tile == 0) {
     if (std::is_same<T, float>::value) {
-      if (N >= 30720 && N <= 65536) { tile = (int)(((N + 511) / 512 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }
+      if (N >= 30720 && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
       else if (N > 65536) {                    // (beyond: the leaner fp32 body, FOUR workgroups per CU -- k_qp.hip: one round is 1 024 tiles)
         tile = (int)(((N + 1023) / 1024 + 7) / 8 * 8);
         tile = tile > 128 ? 64 : tile;         // (more than one round of 128-state tiles: many rounds of 64-state ones)
