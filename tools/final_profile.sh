@@ -17,6 +17,7 @@ WBC_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
 bash tools/r03_tiles.sh > "$O/tile_sweep.log" 2>&1
 bash tools/r03_tiles3.sh >> "$O/tile_sweep.log" 2>&1
 bash tools/r03_tiles4.sh >> "$O/tile_sweep.log" 2>&1
+bash tools/r03_tiles6.sh >> "$O/tile_sweep.log" 2>&1
 bash tools/r03_midrange.sh > "$O/midrange.log" 2>&1
 python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/bench.err"
 python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
