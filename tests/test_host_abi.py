@@ -208,3 +208,21 @@ def test_abi_version_is_the_same_everywhere(hip_lib):
     doc = int(re.search(r"int wbc_abi_version\(void\); /\* (\d+) \*/", hdr).group(1))
     entry = int(re.search(r"wbc_abi_version\(\) == (\d+)", open(os.path.join(ROOT, "__graft_entry__.py")).read()).group(1))
     assert hip_lib.wbc_abi_version() == doc == entry
+
+
+def test_dense_qp_argument_checks_need_no_gpu(hip_lib):
+    """wbc_qp_dense_batch validates sizes and pointers before any HIP call (no device in this container): bad dtype, sizes outside
+    1 <= n <= 36, 0 <= meq <= m <= 64, null pointers, negative iteration limit -> WBC_E_INVALID; an empty batch is a no-op."""
+    import ctypes as C
+    f = hip_lib.wbc_qp_dense_batch
+    f.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_double] + [C.c_void_p] * 5
+    p = C.c_void_p(16)   # any non-null address: never dereferenced on these paths
+    ok_args = lambda **kw: [kw.get("dtype", 0), kw.get("N", 4), kw.get("n", 12), kw.get("m", 24), kw.get("meq", 0), kw.get("H", p), p, kw.get("C", p), p,
+                            kw.get("max_iter", 100), kw.get("tol", 1e-9), p, None, kw.get("status", p), None, None]
+    INVALID = 1
+    for bad in (dict(dtype=2), dict(n=0), dict(n=37), dict(m=65), dict(m=-1), dict(meq=25), dict(meq=-1), dict(H=None), dict(C=None),
+                dict(status=None), dict(max_iter=-1), dict(tol=-1.0)):
+        assert f(*ok_args(**bad)) == INVALID, bad
+        assert hip_lib.wbc_last_error()
+    assert f(*ok_args(N=0)) == 0
+    assert f(*ok_args(N=0, m=0, C=None)) == 0      # no rows: C and d may be null
