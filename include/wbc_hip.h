@@ -103,11 +103,11 @@ enum wbc_timing_mode { WBC_TIMING_DISPATCH = 0, /* the dispatch's own start/stop
 typedef struct wbc_solver_options {
   size_t struct_size;     /* sizeof(wbc_solver_options) of the caller's build (set by wbc_solver_options_default) */
   long long fused_max;    /* ticks of at most this many states run as ONE launch of wavefront roles; -1 = auto
-                             (4096 for fp64 observer-on ticks, 8192 otherwise), 0 = always the two-kernel tick */
-  int rollout_persistent; /* 1 (default): rollouts of at most fused_max states = one launch per rollout; 0: per-tick launches */
+                             (8192; rollouts: 4096), 0 = always the two-kernel tick */
+  int rollout_persistent; /* 1 (default): rollouts of at most fused_max (auto: 4096) states = one launch per rollout; 0: per-tick launches */
   int rollout_spw;        /* states per workgroup of the rollout kernel: 0 = auto (4 up to 1024 states, else 16), 4, 16 */
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
-                             kernel instead of inside the sweep; -1 = auto (fp32: from 40960 states on, fp64: from 20480),
+                             kernel instead of inside the sweep; -1 = auto (fp32: from 33792 states on, fp64: from 20480),
                              -2 = never */
   int one_zerocopy;       /* (default 3) single-robot host-pointer calls: 0 = staging copies + hipStreamSynchronize; 1 = the kernel reads / writes the
                              pinned image directly (mapped host memory); 2 = as 1, and completion is a ticket the stream writes into the

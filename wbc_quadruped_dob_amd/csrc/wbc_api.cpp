@@ -63,8 +63,10 @@ struct wbc_solver {
   int* d_todo = nullptr;    // 4 + max_batch ints: states the per-lane QP kernel hands to the dense active-set kernel (count, workgroups done, count of the last tick, pad; indices)
   QpJidx jmap;
   // resolved options
-  size_t fused_max = 4096;        // observer-on fp64 ticks of at most this many states run as ONE kernel (fused_tick.hip.hpp)
-  size_t fused_max_noobs = 8192;  // observer-off (and all fp32) ticks: the fused kernel still wins with two rounds of workgroups
+  size_t fused_max = 4096;        // rollouts of at most this many states run as ONE persistent launch (rollout_kernel)
+  size_t fused_max_noobs = 8192;  // ticks of at most this many states run as ONE kernel (fused_tick.hip.hpp): it still wins with two rounds of workgroups --
+                                  // since round 3 also with the observer on in fp64 (M steps/s, two-kernel -> fused: 5 120 states 175 -> 233, 6 144: 220 -> 287,
+                                  // 8 192: 258 -> 331; the 4 096 limit there dated from the 20 us fused tick of round 2)
                                   // (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on)
   size_t obs_split_min = (size_t)-1;
   hipStream_t aux = nullptr;
@@ -568,7 +570,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   qa.wdes = nullptr;
   a.ws_geom = mats ? 0 : 1;
   const DevParams<T> dp = to_dev_params<T>(s->params);
-  if ((mats || !out->pf) && N <= ((ob && s->dtype == WBC_F64) ? s->fused_max : s->fused_max_noobs)) {   // fp32: half the LDS, 8 192 also with the observer on (29.7 vs 36.9 us)
+  if ((mats || !out->pf) && N <= s->fused_max_noobs) {
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
     TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap));
