@@ -122,8 +122,8 @@ typedef struct wbc_solver_options {
   int obs_split_serial;   /* that observer kernel runs 1 (default) = on the caller's stream before the sweep, 0 = beside it on a
                              second stream (measured slower: the two compete for the same SIMDs) */
   int qp_lane;            /* two-kernel ticks solve the QPs one state per LANE first (semismooth Newton on the residual wrench)
-                             and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches of more than
-                             49152 states, fp32 from 262144), 1 = always, -1 = never.  States solved per lane report status 0 and
+                             and send what that does not finish to the dense active-set kernel: 0 = auto (fp64 batches from
+                             106496 states on, fp32 from 212992), 1 = always, -1 = never.  States solved per lane report status 0 and
                              iters = Newton iterations (<= 5); the others the dense kernel's status / iteration count.
                              wbc_params.qp_tol and max_iter govern the DENSE kernel only: the per-lane kernel accepts a state when
                              the residual of its optimality equation is below 1e-11 (fp32: 2e-5) x (1 + |target wrench|) or a full

@@ -590,7 +590,11 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   // observer-on data (trot masks: a fifth of the states end in the hand-over list) 462 -> 456 at 65 536, 467 -> 430 at
   // 49 152.  Hence the default: fp64 from 49 152 states on (+18 % on the 4-contact data, -8 % on the trot data there, even
   // from 65 536 on), fp32 from 262 144.
-  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)49153 : (size_t)262144));   // (fp64: 49 152 states are still one round of 64-state tiles: 38.9 us against 32 + 14 for the per-lane pair)
+  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)106496 : (size_t)212992));
+  // (end of round 3, tiles with the predictor hand-over and the scalar weights against the per-lane pair, M steps/s.  fp64 standing batch: a tie from
+  //  53 248 to 98 304 states (605 / 605, 608 / 605, 606 / 604, 621 / 625, 638 / 639), then the pair: 636 / 690 at 114 688, 644 / 730 at 131 072; fp64 trot
+  //  batch: tiles 531 / 483 at 53 248, 533 / 463 at 57 344, 537 / 503 at 65 536, 554 / 520 at 81 920, 546 / 534 at 98 304, pair 527 / 554 at 114 688.
+  //  fp32 trot batch: tiles 1 043 / 919 at 98 304, 992 / 909 at 131 072, 934 / 911 at 196 608, pair 907 / 951 at 229 376)
   // front halves that do not change the target wrench leave it to the QP kernels to read the caller's w_des (QpArgs::wdes)
   const bool front_writes_b = ob && !(mats && N >= s->obs_split_min);   // the all-in-one observer forms: b = w_des - rhat_base
   qa.wdes = front_writes_b ? nullptr : (const T*)in->w_des;   // (those front halves run their SW_NOB / RS_NOB variants)
