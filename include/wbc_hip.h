@@ -134,12 +134,36 @@ typedef struct wbc_solver_options {
                              blocks, identity and skew-diagonal entries): 37 % of what the dynamics sweep stores.  1: a call that gets the
                              SAME M and Jc buffers and the same N as the previous call on this solver does not rewrite them -- the caller
                              promises not to touch M / Jc between ticks (any other pointer or N: written in full again).  0 (default):
-                             every call writes every word */
+                             every call writes every word.  The buffers are identified by ADDRESS: freeing and reallocating them (or a
+                             caching allocator handing the same address out again) counts as touching them -- call
+                             wbc_solver_invalidate_structural then */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
                          const wbc_solver_options* opt /* NULL = defaults */, wbc_solver** out);
 int wbc_solver_device(const wbc_solver* s); /* HIP device index, -1 for NULL */
+/* keep_structural: the next call writes M / Jc in full again whatever buffers it gets */
+int wbc_solver_invalidate_structural(wbc_solver* s);
+
+/* Which kernels a tick of N states runs with these options (no device needed): the measured switches of DESIGN.md 4.7 as data, so
+ * that a caller -- and the parity tests, which straddle every switch -- never restate them.  All fields are informational. */
+typedef struct wbc_tick_plan {
+  size_t struct_size; /* in: sizeof of the caller's build (0 = this build's); out: bytes written */
+  int fused;          /* 1: the whole tick is ONE fused_tick launch (wavefront roles); everything below is 0 then */
+  int front;          /* two-kernel ticks, front half: 0 = dyn_sweep (observer inside when on), 1 = rnea_step (caller passes no M/h/Jc),
+                         2 = observer kernel + observer-free dyn_sweep */
+  int qp;             /* 0 = qp_group16 (one-wavefront workgroups), 1 = qp_tile (tiles dealt by predicted work), 2 = qp_lane + qp_list */
+  int qp_tile;        /* states per tile when qp == 1 */
+  int qp_body;        /* 0 = wrench-space dual active set in fp64 arithmetic, 1 = 12 x 12 orthogonal-factor body in fp32 (fp32 tiles beyond 65 536 states) */
+  int sweep_pack2;    /* fp32 dyn_sweep with two states per lane */
+  int sweep_block;    /* threads per workgroup of the dyn_sweep launch (64 / 256); 0 when no dyn_sweep runs */
+} wbc_tick_plan;
+int wbc_plan_tick(int dtype, int observer_order, const wbc_solver_options* opt /* NULL = defaults */, size_t N, int with_mats, int with_pf,
+                  wbc_tick_plan* plan);
+int wbc_solver_plan_tick(const wbc_solver* s, size_t N, int with_mats, int with_pf, wbc_tick_plan* plan);
+/* the batch sizes N at which the plan differs from that of N - 1 (fp32: N - 2; odd batches never pack), ascending; *n = how many
+ * (at most 16), the first min(*n, cap) are written to out */
+int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_solver_options* opt, int with_mats, size_t* out, int cap, int* n);
 /* diagnostics (synchronises the device): states of the last two-kernel tick that the per-lane QP kernel handed to the dense one */
 int wbc_solver_qp_handover(wbc_solver* s, int* count);
 void wbc_solver_destroy(wbc_solver* s);
@@ -343,7 +367,7 @@ int wbc_qp_dense_batch(int dtype, size_t N, int n, int m, int meq, const void* H
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void); /* 5 */
+int wbc_abi_version(void); /* 6 */
 
 #ifdef __cplusplus
 }

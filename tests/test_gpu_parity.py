@@ -8,7 +8,7 @@ PARITY UNPINNED against the reference itself (source absent) -- see DESIGN.md.
 import numpy as np
 import pytest
 
-from tests.util import relerr, to_dev, to_host, unpack_M
+from tests.util import elementwise_excess, relerr, to_dev, to_host, unpack_M
 from wbc_quadruped_dob_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -96,6 +96,7 @@ def test_step_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n):
     np.testing.assert_array_equal(got["status"], ref["status"])
     assert relerr(got["tau"], ref["tau"]) < TOL64
     assert relerr(got["f"], ref["f"]) < TOL64
+    assert elementwise_excess(got["tau"], ref["tau"]) <= 1.0 and elementwise_excess(got["f"], ref["f"]) <= 1.0   # 1e-6 of EVERY entry
     # and what fp64 really achieves
     assert relerr(got["tau"], ref["tau"]) < TIGHT64
     assert relerr(got["f"], ref["f"]) < TIGHT64
@@ -107,18 +108,29 @@ def test_step_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n):
         assert relerr(got[k], d[k]) < TIGHT64, k
 
 
-# The defaults switch kernels with the batch size (wbc_api.cpp): fused tick up to 4 096 / 8 192 states, the dense QP dealt in
-# tiles from 12 288, the split observer from 20 480 (fp64) / 40 960 (fp32), the per-lane QP path from 49 152 (fp64).  One batch
-# either side of every switch, DEFAULT options, against the oracle.
-@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 0, 2, 8192), ("f64", 0, 2, 8200), ("f64", 1, 3, 4100), ("f64", 0, 2, 12300),
-                                             ("f64", 1, 3, 20470), ("f64", 1, 3, 20490), ("f64", 0, 2, 49100), ("f64", 0, 4, 49200),
-                                             ("f64", 2, 3, 49200), ("f32", 1, 4, 40950), ("f32", 1, 4, 40970), ("f32", 0, 2, 8200)])
-def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
-    torch = torch_cuda
+# The defaults switch kernels with the batch size.  The switches are DATA of the library (wbc_dispatch_thresholds / wbc_plan_tick,
+# include/wbc_hip.h -- step_impl launches what the same planner says), so this list cannot go stale when a threshold moves: one
+# batch either side of every switch, DEFAULT options, against the oracle, for the four (scalar type, observer) pairs the
+# BASELINE configs use.
+def _dispatch_cases():
+    import wbc_quadruped_dob_amd as W
+    import os
+    if not os.path.exists(W.LIB_PATH):
+        W.build_library()
+    cases = []
+    for dtype, obs, cfg in (("f64", 0, 2), ("f64", 1, 3), ("f32", 1, 4), ("f32", 0, 2)):
+        for t in W.dispatch_thresholds(dtype, obs):
+            # fp32: the packed sweep needs an even batch, so both sides are even (like with like)
+            lo, hi = (t - 1, t) if dtype == "f64" else ((t - 2, t) if t % 2 == 0 else (t - 1, t + 1))
+            cases.append(pytest.param(dtype, obs, cfg, lo, hi, id="%s-obs%d-%d|%d" % (dtype, obs, lo, hi)))
+    return cases
+
+
+def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_rank=17):
     nd = _np_dtype(dtype)
     c = lambda a: np.ascontiguousarray(a, nd)
     solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
-    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=17)
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=seed_rank)
     integ = r = None
     if obs:
         integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] - 0.02
@@ -134,6 +146,9 @@ def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, ora
         ok = ref["status"] == 0
         assert ok.mean() > 0.999
         tol = TIGHT64
+        # north_star's "within 1e-6 rel", element by element (small torques are held to it too)
+        assert elementwise_excess(got["tau"][ok], ref["tau"][ok]) <= 1.0
+        assert elementwise_excess(got["f"][ok], ref["f"][ok]) <= 1.0
     else:
         ok = (got["status"] == 0) & (ref["status"] == 0)
         assert ok.mean() > 0.995
@@ -142,9 +157,58 @@ def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, ora
     if obs:
         assert relerr(got["integ"], ig_ref) < (TIGHT64 if dtype == "f64" else 1e-4)
         assert relerr(got["r"], r_ref) < (TIGHT64 if dtype == "f64" else 2e-3)
-    d = oracle.dynamics(c(B["q"]), c(B["v"]), nthreads=8)
+    sub = slice(None) if n <= 70000 else slice(0, n, 8)     # (the dynamics outputs are 3.5 kB per state: a strided subset beyond 70 000 states)
+    d = oracle.dynamics(c(B["q"][sub]), c(B["v"][sub]), nthreads=8)
     for k in ("M", "h", "Jc", "pf"):
-        assert relerr(got[k], d[k]) < (TIGHT64 if dtype == "f64" else 1e-4), k
+        assert relerr(got[k][sub], d[k]) < (TIGHT64 if dtype == "f64" else 1e-4), k
+    return solver
+
+
+@pytest.mark.parametrize("dtype,obs,cfg,lo,hi", _dispatch_cases())
+def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, lo, hi):
+    import wbc_quadruped_dob_amd as W
+    p_lo, p_hi = W.plan_tick(lo, dtype, obs), W.plan_tick(hi, dtype, obs)
+    assert p_lo != p_hi, "no switch between %d and %d: %r" % (lo, hi, p_lo)       # the planner really changes kernels here
+    for n, plan in ((lo, p_lo), (hi, p_hi)):
+        solver = _step_default_vs_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n)
+        assert solver.plan_tick(n) == plan                                           # ... and the solver launches what the planner says
+        del solver
+        torch_cuda.cuda.empty_cache()
+
+
+def test_full_size_fp64_vs_oracle(torch_cuda, gpu_model, oracle):
+    """BASELINE.json's largest batch (262 144 states) on configs[1]'s inputs, fp64, DEFAULT options, against the oracle state by
+    state: status equal, tau and f within the element-wise 1e-6 gate and within 1e-9 of the largest entry."""
+    _step_default_vs_oracle(torch_cuda, gpu_model, oracle, "f64", 0, 2, 262144, seed_rank=0)
+
+
+def test_full_size_fp32_vs_both_oracles(torch_cuda, gpu_model, oracle):
+    """configs[3] at its full size (262 144 states, tilted normals, disturbances, observer on, fp32), DEFAULT options, against the
+    fp32 run of the oracle (stated fp32 tolerance 1e-3 of the largest entry) and against the fp64 oracle (1e-4: the HIP path
+    solves the QP in fp64 arithmetic); the fraction of states whose QP status differs from either oracle is asserted."""
+    torch = torch_cuda
+    n = 262144
+    solver, P = _solver(gpu_model, dtype="f32", obs=1, max_batch=n)
+    B = synth.make_batch(4, n, gpu_model.total_mass)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    r = np.zeros((n, 18))
+    ig32, r32 = f32(integ), f32(r)
+    ref32 = oracle.step(P, f32(B["q"]), f32(B["v"]), f32(B["w_des"]), f32(B["vdot_des"]), f32(B["normals"]), f32(B["mu"]), B["mask"],
+                        f32(B["tau_prev"]), f32(B["f_prev"]), ig32, r32, nthreads=8)
+    P64 = synth.default_params(observer_order=1)
+    ig64, r64 = integ.copy(), r.copy()
+    ref64 = oracle.step(P64, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"],
+                        ig64, r64, nthreads=8)
+    got = _run_step(torch, solver, B, "f32", integ, r)
+    flip32 = float(np.mean(got["status"] != ref32["status"]))
+    flip64 = float(np.mean(got["status"] != ref64["status"]))
+    assert flip32 < 1e-3 and flip64 < 1e-3, (flip32, flip64)
+    ok = (got["status"] == 0) & (ref32["status"] == 0) & (ref64["status"] == 0)
+    assert ok.mean() > 0.999
+    assert relerr(got["tau"][ok], ref32["tau"][ok]) < 1e-3 and relerr(got["f"][ok], ref32["f"][ok]) < 1e-3
+    assert relerr(got["tau"][ok], ref64["tau"][ok]) < 1e-4 and relerr(got["f"][ok], ref64["f"][ok]) < 1e-4
+    assert relerr(got["r"], r64) < 2e-3
 
 
 def test_step_vs_golden(torch_cuda, gpu_model, golden):

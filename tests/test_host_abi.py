@@ -226,3 +226,17 @@ def test_dense_qp_argument_checks_need_no_gpu(hip_lib):
         assert hip_lib.wbc_last_error()
     assert f(*ok_args(N=0)) == 0
     assert f(*ok_args(N=0, m=0, C=None)) == 0      # no rows: C and d may be null
+
+
+def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
+    """The round-3 defaults as the planner reports them; a deliberate change of a default changes this list."""
+    import wbc_quadruped_dob_amd as W
+    assert W.dispatch_thresholds("f64", 0) == [8193, 14336, 65536, 106496]
+    assert W.dispatch_thresholds("f64", 1) == [8193, 14336, 20480, 65536, 106496]
+    assert W.dispatch_thresholds("f32", 1) == [8193, 30720, 32768, 33792, 65537, 131072, 212992]
+    assert W.plan_tick(262144, "f64", 0)["qp"] == 2 and W.plan_tick(262144, "f32", 1) == dict(
+        fused=0, front=2, qp=2, qp_tile=0, qp_body=0, sweep_pack2=1, sweep_block=256)
+    # options move the switches, and the list follows
+    assert W.dispatch_thresholds("f64", 0, options={"qp_lane": -1, "qp_tile": -1, "fused_max": 0}) == [65536]
+
+

@@ -17,6 +17,18 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
 
 
+def elementwise_excess(a, b, rtol=1e-6, atol_frac=1e-9):
+    """The element-wise gate of BASELINE.json's "torques within 1e-6 rel": every entry must satisfy
+        |a_i - b_i| <= rtol * |b_i| + atol_frac * max|b|
+    (relerr() above divides by the LARGEST entry of the whole array, which says nothing about small torques).  Returns the largest
+    ratio |a_i - b_i| / bound_i: <= 1 passes."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.size == 0:
+        return 0.0
+    bound = rtol * np.abs(b) + atol_frac * float(np.max(np.abs(b)))
+    return float(np.max(np.abs(a - b) / np.maximum(bound, np.finfo(np.float64).tiny)))
+
+
 def to_dev(x, torch, dtype):
     """row-per-state numpy [N, c] -> component-major device tensor [c, N]"""
     t = torch.from_numpy(np.ascontiguousarray(np.asarray(x).T))

@@ -135,6 +135,35 @@ class _BatchOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("tau", "f", "status", "iters", "M", "h", "Jc", "pf")]
 
 
+class TickPlan(C.Structure):
+    """wbc_tick_plan (include/wbc_hip.h): which kernels a tick of N states runs."""
+    _fields_ = [("struct_size", C.c_size_t), ("fused", C.c_int), ("front", C.c_int), ("qp", C.c_int), ("qp_tile", C.c_int),
+                ("qp_body", C.c_int), ("sweep_pack2", C.c_int), ("sweep_block", C.c_int)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "struct_size"}
+
+
+def plan_tick(N, dtype="f64", observer_order=0, options=None, want_mats=True, want_pf=True):
+    """wbc_plan_tick: the kernels a tick of N states runs with these options (dict of wbc_tick_plan's fields); needs no device."""
+    pl = TickPlan()
+    pl.struct_size = C.sizeof(TickPlan)
+    o = SolverOptions.make({} if options is None else options)
+    _check(lib().wbc_plan_tick(F64 if dtype == "f64" else F32, int(observer_order), C.byref(o), int(N), int(want_mats), int(want_pf), C.byref(pl)),
+           "wbc_plan_tick")
+    return pl.as_dict()
+
+
+def dispatch_thresholds(dtype="f64", observer_order=0, options=None, want_mats=True):
+    """wbc_dispatch_thresholds: the batch sizes at which the tick's kernels change, ascending; needs no device."""
+    out = (C.c_size_t * 16)()
+    n = C.c_int(0)
+    o = SolverOptions.make({} if options is None else options)
+    _check(lib().wbc_dispatch_thresholds(F64 if dtype == "f64" else F32, int(observer_order), C.byref(o), int(want_mats), out, 16, C.byref(n)),
+           "wbc_dispatch_thresholds")
+    return [int(out[i]) for i in range(n.value)]
+
+
 class _ObsState(C.Structure):
     _fields_ = [("integ", C.c_void_p), ("r", C.c_void_p)]
 
@@ -194,6 +223,10 @@ def lib():
         L.wbc_reference_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4
         L.wbc_compute_reference.argtypes = [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 3
         L.wbc_rollout_tracking_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 8
+        L.wbc_plan_tick.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.wbc_solver_plan_tick.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.wbc_dispatch_thresholds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.wbc_solver_invalidate_structural.argtypes = [C.c_void_p]
         L.wbc_qp_dense_batch.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_double] + [C.c_void_p] * 5
         _lib = L
     return _lib
@@ -331,6 +364,10 @@ class Solver:
             if k not in out:
                 out[k] = torch.empty(N, dtype=torch.int32, device=self.device)
         if want_mats:
+            if "M" not in out or "Jc" not in out:
+                # keep_structural identifies "the same buffers" by address, and the caching allocator hands a just-freed address out
+                # again: buffers allocated HERE are always written in full (only a caller that passes out= keeps the constants)
+                lib().wbc_solver_invalidate_structural(self._h)
             for k in ("M", "h", "Jc", "pf"):
                 if k not in out:
                     out[k] = self.empty(rows[k], N)
@@ -358,6 +395,17 @@ class Solver:
             if rc:
                 _check(rc, "wbc_step_batch")
         return tick, out
+
+    def plan_tick(self, N, want_mats=True, want_pf=True):
+        """wbc_solver_plan_tick: which kernels a tick of N states runs on THIS solver (dict of wbc_tick_plan's fields)."""
+        pl = TickPlan()
+        pl.struct_size = C.sizeof(TickPlan)
+        _check(lib().wbc_solver_plan_tick(self._h, int(N), int(want_mats), int(want_pf), C.byref(pl)), "wbc_solver_plan_tick")
+        return pl.as_dict()
+
+    def invalidate_structural(self):
+        """keep_structural: the next tick writes M / Jc in full again (their buffers were freed, reallocated or overwritten)."""
+        _check(lib().wbc_solver_invalidate_structural(self._h), "wbc_solver_invalidate_structural")
 
     def integrate(self, q, v, M, h, Jc, tau, f, tau_ext=None):
         """Forward dynamics with the planned GRFs + semi-implicit Euler; q, v advance IN PLACE (one dt)."""

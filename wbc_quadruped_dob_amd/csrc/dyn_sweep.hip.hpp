@@ -293,6 +293,8 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   // lane's values at the same addresses.  Guarding every store with `if (live)` made each of the ~100 stores its own exec region
   // (s_and_saveexec / s_cbranch_execz / s_or: ~45 cycles each for a lone wavefront, tools/issue_probe.hip).  Only the observer state,
   // which is read-modified-written, keeps the guard (STVG): an all-dead wavefront could read it after the live one wrote it.
+  // (The workspace words that DEPEND on that state -- b = w_des - rhat, tau_partial - rhat -- are stored unguarded too; that is only
+  // sound while an observer variant's workgroup is ONE wavefront: static_assert in dyn_sweep_kernel.)
   const unsigned s32 = (unsigned)(live ? s_raw : N - W);
   const unsigned legN = (unsigned)leg * N32;
 #define CS(i) cst[(i) * 4 + leg]
@@ -862,6 +864,10 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 template <class T, int MODE, int BLOCK, int W = 1>
 __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void dyn_sweep_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                         SweepArgs<T> a) {
+  // The observer variants store the QP target wrench and tau_partial (which depend on the observer state they loaded) from dead
+  // lanes unguarded: bit-identical duplicates ONLY while no all-dead wavefront can re-read {integ, r} after the live wavefront
+  // of the same state updated them, i.e. while a workgroup is one wavefront.
+  static_assert(!((MODE & SW_OBS) && BLOCK > 64), "observer variants of the sweep are launched as 64-thread workgroups only");
   if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
   dyn_sweep_body<T, MODE, BLOCK, W>(model, prm, a);
 }

@@ -18,6 +18,4 @@
 
 namespace wbc {
 using Scalar = WBC_SCALAR;
-// enough work for two full rounds of 8 waves per CU: 256-thread workgroups share one constant table
-constexpr size_t BIG_GRID_THREADS = (size_t)256 * 8 * 64 * 2;
 }  // namespace wbc

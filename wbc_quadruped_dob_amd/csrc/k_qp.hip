@@ -6,9 +6,6 @@
 
 namespace wbc {
 
-#ifndef WBC_F32_DENSE_TILE_MIN
-#define WBC_F32_DENSE_TILE_MIN 65537
-#endif
 template <int TILE>
 static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
   using T = Scalar;

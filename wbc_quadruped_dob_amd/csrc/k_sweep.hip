@@ -22,9 +22,6 @@ static hipError_t sweep_launch(const LaunchCtx& L, const DevModel<Scalar>* model
 // fp32, even N: two states per lane as packed pairs (whole 128-byte lines per 16-lane row, v_pk_* arithmetic, half the
 // wavefronts).  Below PACK2_MIN_STATES the batch does not fill the SIMDs with one state per lane either, and the shorter
 // dependent chain per state of the unpacked form wins.
-#ifndef WBC_PACK2_MIN_STATES
-#define WBC_PACK2_MIN_STATES 32768
-#endif
 template <int MODE>
 static hipError_t sweep_mode(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {
   if constexpr (std::is_same<Scalar, float>::value) {

@@ -9,6 +9,20 @@
 
 namespace wbc {
 
+// Batch sizes at which a launcher changes kernel variant.  They live here so that the host side's tick planner (wbc_plan_tick,
+// wbc_api.cpp) reports exactly what the launchers do.
+// 256-thread workgroups (one constant table for four wavefronts) from two full rounds of 8 waves per CU on
+constexpr size_t BIG_GRID_THREADS = (size_t)256 * 8 * 64 * 2;
+// fp32 sweep, even N: two states per lane as packed pairs.  Below this the batch does not fill the SIMDs with one state per lane
+// either, and the shorter dependent chain per state of the unpacked form wins
+#ifndef WBC_PACK2_MIN_STATES
+#define WBC_PACK2_MIN_STATES 32768
+#endif
+// fp32 tiles of 64 ... 128 states from this batch size on run the leaner dense fp32 body (four workgroups per CU)
+#ifndef WBC_F32_DENSE_TILE_MIN
+#define WBC_F32_DENSE_TILE_MIN 65537
+#endif
+
 // stream of the launch + (optionally) the events that receive the dispatch's own start / stop timestamps
 struct LaunchCtx {
   hipStream_t st = nullptr;

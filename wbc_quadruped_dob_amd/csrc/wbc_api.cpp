@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,14 @@
 #include "model.hpp"
 
 using namespace wbc;
+
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+}
 
 static thread_local std::string g_err;
 int wbc::fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -50,6 +59,9 @@ constexpr size_t TIMING_MAX_SPANS = 4096;   // bounded ring: samples beyond it a
 constexpr int ONE_SCRATCH = 200;        // first scalar of the helpers' scratch region of the single-robot image (88 scalars)
 constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints (the tick uses the first 161)
 
+// thresholds between kernel variants after the options are applied (resolve_options)
+struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, tile_min, lane_min; };
+
 struct wbc_solver {
   int dtype = WBC_F64;
   int device = 0;
@@ -62,13 +74,7 @@ struct wbc_solver {
   int in_rollout = 0;       // inside the per-tick loop of wbc_rollout_batch, past its first tick
   int* d_todo = nullptr;    // 4 + max_batch ints: states the per-lane QP kernel hands to the dense active-set kernel (count, workgroups done, count of the last tick, pad; indices)
   QpJidx jmap;
-  // resolved options
-  size_t fused_max = 4096;        // rollouts of at most this many states run as ONE persistent launch (rollout_kernel)
-  size_t fused_max_noobs = 8192;  // ticks of at most this many states run as ONE kernel (fused_tick.hip.hpp): it still wins with two rounds of workgroups --
-                                  // since round 3 also with the observer on in fp64 (M steps/s, two-kernel -> fused: 5 120 states 175 -> 233, 6 144: 220 -> 287,
-                                  // 8 192: 258 -> 331; the 4 096 limit there dated from the 20 us fused tick of round 2)
-                                  // (measured: 34.3 vs 37.3 us at 5 120, 44.7 vs 45.6 us at 8 192, loses from 12 288 on)
-  size_t obs_split_min = (size_t)-1;
+  Resolved rz{};            // resolved thresholds (resolve_options)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void* d_ref = nullptr;     // DevRefParams<T>, set by wbc_solver_set_ref_params
@@ -290,6 +296,155 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->keep_structural = 0;
 }
 
+// ------------------------------------------------------------------------------------------ which kernels run a tick
+// The measured switches between kernel variants, in ONE place: step_impl launches what plan_tick says, wbc_plan_tick /
+// wbc_dispatch_thresholds report it (tests/test_gpu_parity.py straddles every switch with it, so a moved threshold moves the test).
+static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
+  Resolved r;
+  // rollouts of at most fused_max states run as ONE persistent launch (rollout_kernel); ticks of at most fused_max_noobs states run as
+  // ONE kernel (fused_tick.hip.hpp): it still wins with two rounds of workgroups -- since round 3 also with the observer on in fp64
+  // (M steps/s, two-kernel -> fused: 5 120 states 175 -> 233, 6 144: 220 -> 287, 8 192: 258 -> 331) -- and loses from 12 288 on
+  r.fused_max = 4096; r.fused_max_noobs = 8192;
+  if (o.fused_max >= 0) r.fused_max = r.fused_max_noobs = (size_t)o.fused_max;
+  // observer as its own kernel before the sweep (the all-in-one observer sweep runs one wavefront per SIMD).  Measured on
+  // MI355X, front half of the tick, all-in-one -> observer kernel + observer-free sweep (us): fp64 464 -> 112 + 279 at
+  // 262 144 states, 111 -> 34 + 57 at 65 536, but 48 -> 25 + 33 at 32 768; fp32 298 -> 57 + 168 at 262 144, 45 -> 17 + 27 at
+  // 65 536 (a tie per tick), 26 -> 13 + 16 at 32 768.  At the final kernels (observer-free sweep without the w_des forwarding,
+  // both observer forms with their inputs requested up front) per tick, all-in-one -> split (M steps/s): fp64 437 -> 472 at
+  // 65 536, 428 -> 446 at 49 152, 405 -> 439 at 40 960, 451 -> 460 at 32 768, 360 -> 398 at 24 576, 308 -> 341 at 20 480, but
+  // 330 -> 289 at 16 384; fp32 855 -> 934 at 98 304, 784 -> 798 at 65 536, 681 -> 717 at 49 152, 594 -> 629 at 40 960, but
+  // 625 -> 587 at 32 768.  Round 3 (M steps/s): fp32 570 -> 593 at 34 816, 599 -> 614 at 36 864, 612 -> 638 at 38 912 (past 32 768 states the
+  // all-in-one fp32 sweep needs a second round of wavefronts: 23.7 -> 37 us).  Default: fp64 from 20 480 states on, fp32 from 33 792.
+  r.obs_split_min = (size_t)-1;
+  if (o.obs_split_min >= 0) r.obs_split_min = (size_t)o.obs_split_min;
+  else if (o.obs_split_min == -1) r.obs_split_min = dtype == WBC_F32 ? 33792 : 20480;
+  // tiles dealt by predicted work (auto): fp64 from 14 336 states, fp32 from 30 720; per-lane QP pair (auto): fp64 from 106 496, fp32 from 212 992
+  r.tile_min = dtype == WBC_F32 ? 30720 : 14336;
+  r.lane_min = dtype == WBC_F32 ? 212992 : 106496;
+  return r;
+}
+
+struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block; bool obs_split, lane; };
+static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf) {
+  TickPlan p{};
+  const bool ob = observer_order > 0, f32 = dtype == WBC_F32;
+  if ((mats || !pf) && N <= r.fused_max_noobs) {
+    // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
+    // workspace through LDS (fused_tick.hip.hpp)
+    p.fused = 1;
+    return p;
+  }
+  // Large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench, 64 QPs
+  // per wavefront, no cross-lane traffic); the few per cent it does not finish go through a device-side list to the dense
+  // active-set kernel.  No host read: the list length stays on the device, the second launch is grid-stride over it.
+  // End of round 3, tiles with the predictor hand-over and the scalar weights against the per-lane pair, M steps/s.  fp64 standing batch: a tie from
+  // 53 248 to 98 304 states (605 / 605, 608 / 605, 606 / 604, 621 / 625, 638 / 639), then the pair: 636 / 690 at 114 688, 644 / 730 at 131 072; fp64 trot
+  // batch: tiles 531 / 483 at 53 248, 533 / 463 at 57 344, 537 / 503 at 65 536, 554 / 520 at 81 920, 546 / 534 at 98 304, pair 527 / 554 at 114 688.
+  // fp32 trot batch: tiles 1 043 / 919 at 98 304, 992 / 909 at 131 072, 934 / 911 at 196 608, pair 907 / 951 at 229 376.
+  // Hence the default: fp64 from 106 496 states on, fp32 from 212 992 (history of the threshold: DESIGN.md 4.3a).
+  p.lane = o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.lane_min);
+  if (!mats) p.front = 1;                                   // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
+  else if (ob && N >= r.obs_split_min) { p.front = 2; p.obs_split = true; }   // observer kernel + observer-free sweep
+  else p.front = 0;
+  if (p.front != 1) {   // what the dyn_sweep launcher picks (k_sweep.hip)
+    const bool obs_variant = p.front == 0 && ob;
+    p.pack2 = f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && (o.f32_pack2 > 0 || N >= (size_t)WBC_PACK2_MIN_STATES);
+    const size_t threads = ((N + (p.pack2 ? 2 : 1) - 1) / (p.pack2 ? 2 : 1)) * 4;
+    p.sweep_block = (!obs_variant && threads >= wbc::BIG_GRID_THREADS) ? 256 : 64;
+  }
+  // two-kernel ticks deal tiles of states to the wavefronts by predicted work (qp_tile_kernel).  Measured on MI355X, fp64,
+  // QP kernel alone, one-wavefront workgroups -> tiles: 34.7 -> 32.7 us at 12 288 states (tiles of 32), 62.4 -> 48.3 at
+  // 32 768, 109.6 -> 93.1 at 65 536, 408 -> 350 at 262 144 (tiles of 64; 128 and 256 lose to the workgroup lifetime);
+  // below 12 288 states the tiles do not fill the device
+  // (round 3, structured QP body, QP stage in us.  fp64 standing batch: one-wave 19.0 / tiles-of-32 19.6 at 12 288; 22.2 / 20.0 / 64: 23.9 at
+  //  16 384; 31.2 / 24.6 / 30.3 at 24 576; 32.4 / 31.9 / 29.9 at 28 672; 35.9 / 34.7 / 30.4 at 32 768.  fp32 -- whose tile kernel holds 180
+  //  registers, two workgroups per CU, where the one-wave kernel runs four wavefronts per SIMD -- trot batch: 17.0 / 20.8 / 20.5 at 16 384,
+  //  19.6 / 31.2 / 20.5 at 24 576, 22.1 / 33.4 / 22.0 at 28 672, 24.3 / 35.7 / 22.7 at 32 768; standing batch 31.3 / 44.1 / 37.2 at 24 576)
+  // ONE ROUND OF RESIDENT WORKGROUPS: the tile kernel keeps three workgroups on a CU (146 registers in fp64, 159 in fp32; 768 on the device),
+  // and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
+  // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
+  // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
+  int tile = o.qp_tile;
+  if (tile == 0) {
+    if (f32) {
+      if (N >= r.tile_min && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
+      else if (N > 65536) {                    // (beyond: the leaner fp32 body, FOUR workgroups per CU -- k_qp.hip: one round is 1 024 tiles)
+        tile = (int)(((N + 1023) / 1024 + 7) / 8 * 8);
+        tile = tile > 128 ? 64 : tile;         // (more than one round of 128-state tiles: many rounds of 64-state ones)
+      }
+    } else if (N >= r.tile_min) {
+      tile = (int)(((N + 767) / 768 + 3) / 4 * 4);
+      tile = tile < 32 ? 32 : (tile > 64 ? 64 : tile);
+    }
+  }
+  if (tile < 0) tile = 0;
+  if (p.lane) { p.qp = 2; p.tile = 0; }
+  else { p.qp = tile > 0 ? 1 : 0; p.tile = tile; }
+  p.qp_body = (p.qp == 1 && f32 && tile >= 64 && tile <= 128 && N >= (size_t)WBC_F32_DENSE_TILE_MIN) ? 1 : 0;
+  return p;
+}
+
+static int options_from_caller(const wbc_solver_options* opt, wbc_solver_options& o) {
+  wbc_solver_options_default(&o);
+  if (opt) {
+    if (opt->struct_size == 0 || opt->struct_size > sizeof(o)) return fail(WBC_E_INVALID, "wbc_solver_options.struct_size is not set (call wbc_solver_options_default first)");
+    std::memcpy(&o, opt, opt->struct_size);   // a caller built against an older, shorter struct keeps the newer defaults
+    o.struct_size = sizeof(o);
+  }
+  return WBC_OK;
+}
+
+static void plan_to_public(const TickPlan& p, wbc_tick_plan* out) {
+  wbc_tick_plan t;
+  std::memset(&t, 0, sizeof(t));
+  t.struct_size = sizeof(t);
+  t.fused = p.fused; t.front = p.front; t.qp = p.qp; t.qp_tile = p.tile; t.qp_body = p.qp_body; t.sweep_pack2 = p.pack2; t.sweep_block = p.sweep_block;
+  const size_t n = out->struct_size && out->struct_size < sizeof(t) ? out->struct_size : sizeof(t);
+  std::memcpy(out, &t, n);
+  out->struct_size = n;
+}
+
+extern "C" int wbc_plan_tick(int dtype, int observer_order, const wbc_solver_options* opt, size_t N, int with_mats, int with_pf,
+                             wbc_tick_plan* plan) {
+  if (!plan || (dtype != WBC_F64 && dtype != WBC_F32) || observer_order < 0 || observer_order > 2) return fail(WBC_E_INVALID, "bad argument");
+  wbc_solver_options o;
+  const int rc = options_from_caller(opt, o);
+  if (rc) return rc;
+  plan_to_public(plan_tick(dtype, observer_order, o, resolve_options(dtype, o), N, with_mats != 0, with_pf != 0), plan);
+  return WBC_OK;
+}
+
+// the batch sizes N at which plan(N) differs from plan(N - 1), ascending (the one-round tile SIZE is not a switch of kernel family
+// and is left out: it steps every 3 072 / 6 144 / 8 192 states)
+extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_solver_options* opt, int with_mats, size_t* out, int cap, int* n) {
+  if (!n || (cap > 0 && !out) || (dtype != WBC_F64 && dtype != WBC_F32) || observer_order < 0 || observer_order > 2) return fail(WBC_E_INVALID, "bad argument");
+  wbc_solver_options o;
+  const int rc = options_from_caller(opt, o);
+  if (rc) return rc;
+  const Resolved r = resolve_options(dtype, o);
+  // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
+  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+                         wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537};
+  size_t keep[16]; int k = 0;
+  for (size_t c : cand) {
+    if (c < 2 || c == (size_t)-1 || c > ((size_t)1 << 21)) continue;
+    // an odd N never packs: compare like with like (both even) for the fp32 sweep, plain neighbours otherwise
+    auto same = [&](size_t a, size_t b) {
+      const TickPlan x = plan_tick(dtype, observer_order, o, r, a, with_mats != 0, true), y = plan_tick(dtype, observer_order, o, r, b, with_mats != 0, true);
+      return x.fused == y.fused && x.front == y.front && x.qp == y.qp && x.qp_body == y.qp_body && x.pack2 == y.pack2 && x.sweep_block == y.sweep_block;
+    };
+    const bool changes = (c % 2 == 0) ? !same(c - 2, c) : !same(c - 1, c + 1);
+    if (!changes) continue;
+    bool dup = false;
+    for (int i = 0; i < k; ++i) dup = dup || keep[i] == c;
+    if (!dup && k < 16) keep[k++] = c;
+  }
+  for (int i = 0; i < k; ++i) for (int j = i + 1; j < k; ++j) if (keep[j] < keep[i]) { const size_t t = keep[i]; keep[i] = keep[j]; keep[j] = t; }
+  *n = k;
+  for (int i = 0; i < k && i < cap; ++i) out[i] = keep[i];
+  return WBC_OK;
+}
+
 extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
                                     const wbc_solver_options* opt, wbc_solver** out) {
   if (!m || !out || max_batch == 0 || (dtype != WBC_F64 && dtype != WBC_F32)) return fail(WBC_E_INVALID, "bad argument");
@@ -299,12 +454,8 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   int rc = check_params(p);
   if (rc) return rc;
   wbc_solver_options o;
-  wbc_solver_options_default(&o);
-  if (opt) {
-    if (opt->struct_size == 0 || opt->struct_size > sizeof(o)) return fail(WBC_E_INVALID, "wbc_solver_options.struct_size is not set (call wbc_solver_options_default first)");
-    std::memcpy(&o, opt, opt->struct_size);   // a caller built against an older, shorter struct keeps the newer defaults
-    o.struct_size = sizeof(o);
-  }
+  rc = options_from_caller(opt, o);
+  if (rc) return rc;
   if (o.rollout_spw != 0 && o.rollout_spw != 4 && o.rollout_spw != 16) return fail(WBC_E_INVALID, "rollout_spw must be 0 (auto), 4 or 16");
   {   // the tile sizes the kernels of this scalar type exist for (k_qp.hip)
     const int ok64[] = {0, -1, 32, 36, 40, 44, 48, 52, 56, 60, 64, 128, 256, 512};
@@ -333,18 +484,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   wbc_solver* s = new (std::nothrow) wbc_solver;
   if (!s) return fail(WBC_E_INVALID, "out of memory");
   s->dtype = dtype; s->device = device; s->max_batch = max_batch; s->params = *p; s->opt = o;
-  if (o.fused_max >= 0) s->fused_max = s->fused_max_noobs = (size_t)o.fused_max;
-  // observer as its own kernel before the sweep (the all-in-one observer sweep runs one wavefront per SIMD).  Measured on
-  // MI355X, front half of the tick, all-in-one -> observer kernel + observer-free sweep (us): fp64 464 -> 112 + 279 at
-  // 262 144 states, 111 -> 34 + 57 at 65 536, but 48 -> 25 + 33 at 32 768; fp32 298 -> 57 + 168 at 262 144, 45 -> 17 + 27 at
-  // 65 536 (a tie per tick), 26 -> 13 + 16 at 32 768.  At the final kernels (observer-free sweep without the w_des forwarding,
-  // both observer forms with their inputs requested up front) per tick, all-in-one -> split (M steps/s): fp64 437 -> 472 at
-  // 65 536, 428 -> 446 at 49 152, 405 -> 439 at 40 960, 451 -> 460 at 32 768, 360 -> 398 at 24 576, 308 -> 341 at 20 480, but
-  // 330 -> 289 at 16 384; fp32 855 -> 934 at 98 304, 784 -> 798 at 65 536, 681 -> 717 at 49 152, 594 -> 629 at 40 960, but
-  // 625 -> 587 at 32 768.  Round 3 (M steps/s): fp32 570 -> 593 at 34 816, 599 -> 614 at 36 864, 612 -> 638 at 38 912 (past 32 768 states the
-  // all-in-one fp32 sweep needs a second round of wavefronts: 23.7 -> 37 us).  Default: fp64 from 20 480 states on, fp32 from 33 792.
-  if (o.obs_split_min >= 0) s->obs_split_min = (size_t)o.obs_split_min;
-  else if (o.obs_split_min == -1) s->obs_split_min = dtype == WBC_F32 ? 33792 : 20480;
+  s->rz = resolve_options(dtype, o);
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
@@ -371,6 +511,8 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (e == hipSuccess) e = hipMalloc(&s->d_one, s->one_bytes);
   if (e == hipSuccess) e = hipHostMalloc(&s->h_one, s->one_bytes, hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(&s->h_one_dev, s->h_one, 0);
+  // (the completion ticket lives in this image: a recycled pinned block must not look like ticket 1 of a solver whose first tick is still running)
+  if (e == hipSuccess) { std::memset(s->h_one, 0, s->one_bytes); e = hipMemset(s->d_one, 0, s->one_bytes); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
@@ -413,6 +555,19 @@ extern "C" int wbc_solver_set_params(wbc_solver* s, const wbc_params* p) {
 }
 
 extern "C" int wbc_solver_device(const wbc_solver* s) { return s ? s->device : -1; }
+
+extern "C" int wbc_solver_plan_tick(const wbc_solver* s, size_t N, int with_mats, int with_pf, wbc_tick_plan* plan) {
+  if (!s || !plan) return fail(WBC_E_INVALID, "null argument");
+  plan_to_public(plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, with_mats != 0, with_pf != 0), plan);
+  return WBC_OK;
+}
+
+// keep_structural: forget which M / Jc buffers hold their structural constants (the caller freed, reallocated or overwrote them)
+extern "C" int wbc_solver_invalidate_structural(wbc_solver* s) {
+  if (!s) return fail(WBC_E_INVALID, "null solver");
+  s->kept_M = nullptr; s->kept_Jc = nullptr; s->kept_N = 0;
+  return WBC_OK;
+}
 
 // diagnostics: how many states of the LAST two-kernel tick the per-lane QP kernel handed to the dense kernel (synchronises)
 extern "C" int wbc_solver_qp_handover(wbc_solver* s, int* count) {
@@ -511,15 +666,18 @@ extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KIN
 
 template <class T> static const DevModel<T>* dev_model(const wbc_solver* s) { return (const DevModel<T>*)s->d_model; }
 
-// keep_structural: 1 when this call may skip the structural zeros / ones of M and Jc (same buffers and N as the call that
-// last wrote them); records the buffers otherwise
-static int structural_kept(wbc_solver* s, const void* M, const void* Jc, size_t N) {
-  if (!M) return 0;
-  // (in_rollout: ticks 1 .. horizon-1 of ONE wbc_rollout_batch call write the buffers tick 0 of the same call wrote)
-  if ((s->opt.keep_structural || s->in_rollout) && M == s->kept_M && Jc == s->kept_Jc && N == s->kept_N) return 1;
-  s->kept_M = M; s->kept_Jc = Jc; s->kept_N = N;
-  return 0;
-}
+// keep_structural: `skip` = this call may leave the structural zeros / ones of M and Jc alone (same buffers and N as the call that
+// last WROTE them).  The buffers are recorded only once the launch that writes them has been enqueued (written()); a call that
+// fails before that forgets them, so the next call writes every word again.
+struct KeepScope {
+  wbc_solver* s; const void* M; const void* Jc; size_t N; int skip = 0; bool done = false;
+  KeepScope(wbc_solver* s_, const void* M_, const void* Jc_, size_t N_) : s(s_), M(M_), Jc(Jc_), N(N_) {
+    // (in_rollout: ticks 1 .. horizon-1 of ONE wbc_rollout_batch call write the buffers tick 0 of the same call wrote)
+    if (M) skip = ((s->opt.keep_structural || s->in_rollout) && M == s->kept_M && Jc == s->kept_Jc && N == s->kept_N) ? 1 : 0;
+  }
+  void written() { if (M) { s->kept_M = M; s->kept_Jc = Jc; s->kept_N = N; } done = true; }
+  ~KeepScope() { if (M && !done) s->kept_M = nullptr; }
+};
 
 template <class T>
 static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, void* M, void* h, void* Jc, void* pf,
@@ -529,9 +687,11 @@ static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, 
   a.N = N; a.q = (const T*)q; a.v = (const T*)v;
   a.M = (T*)M; a.h = (T*)h; a.Jc = (T*)Jc; a.pf = (T*)pf; a.p = (T*)p; a.beta = (T*)beta;
   const int mode = (M ? SW_MATS : 0) | ((p || beta) ? SW_OBS : 0);
-  a.skip_consts = structural_kept(s, M, Jc, N);
+  KeepScope keep(s, M, Jc, N);
+  a.skip_consts = keep.skip;
   timing_tick(s);
   TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, mode, dev_model<T>(s), to_dev_params<T>(s->params), a));
+  keep.written();
   return WBC_OK;
 }
 
@@ -560,7 +720,8 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   a.obs_integ = obs ? (T*)obs->integ : nullptr; a.obs_r = obs ? (T*)obs->r : nullptr;
   a.ws = (T*)s->d_ws;
   const bool mats = out->M != nullptr, ob = s->params.observer_order > 0;
-  a.skip_consts = structural_kept(s, out->M, out->Jc, N);
+  KeepScope keep(s, out->M, out->Jc, N);
+  a.skip_consts = keep.skip;
   timing_tick(s);
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
@@ -570,44 +731,23 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   qa.wdes = nullptr;
   a.ws_geom = mats ? 0 : 1;
   const DevParams<T> dp = to_dev_params<T>(s->params);
-  if ((mats || !out->pf) && N <= s->fused_max_noobs) {
-    // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
-    // workspace through LDS (fused_tick.hip.hpp)
+  const TickPlan pl = plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, mats, out->pf != nullptr);   // (what runs, and why: plan_tick)
+  if (pl.fused) {
     TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap));
+    keep.written();
     return WBC_OK;
   }
-  // Large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench, 64 QPs
-  // per wavefront, no cross-lane traffic); the few per cent it does not finish go through a device-side list to the dense
-  // active-set kernel.  No host read: the list length stays on the device, the second launch is grid-stride over it.
-  // Measured on MI355X, QP stage, dense kernel alone -> per-lane + list (us), fp64 configs[1] data: 356 -> 101 + 45 at
-  // 262 144 states, 175 -> 54 + 34 at 131 072, 133 -> 50 + 33 at 98 304, 91 -> 36 + 32 at 65 536, 78 -> 32 + 26 at 49 152
-  // (32 768: 48 -> 31 + 25: a wavefront of the per-lane kernel takes ~32 us whatever the batch, and the list kernel at least
-  // the ~20 us of its longest QP); fp64 observer-on data (easier QPs): 223 -> 97 + 34 at 262 144, 102 -> 51 + 23 at 131 072,
-  // 76 -> 47 + 24 at 98 304, but 51 -> 35 + 21 at 65 536 and 43 -> 32 + 20 at 49 152; fp32 (configs[3]): 144 -> 84 + 34 at
-  // 262 144 but 101 -> 78 + 24 at 196 608 and 68 -> 49 + 23 at 131 072 (the per-lane kernel issues the same number of
-  // instructions in either precision, the dense kernel's fp32 instructions are cheaper).  Per tick at the final code
-  // (M steps/s, dense -> per-lane): fp64 configs[1] data 441 -> 526 at 65 536, 431 -> 507 at 49 152, 439 -> 393 at 32 768;
-  // observer-on data (trot masks: a fifth of the states end in the hand-over list) 462 -> 456 at 65 536, 467 -> 430 at
-  // 49 152.  Hence the default: fp64 from 49 152 states on (+18 % on the 4-contact data, -8 % on the trot data there, even
-  // from 65 536 on), fp32 from 262 144.
-  const bool lane = s->opt.qp_lane > 0 || (s->opt.qp_lane == 0 && N >= (s->dtype == WBC_F64 ? (size_t)106496 : (size_t)212992));
-  // (end of round 3, tiles with the predictor hand-over and the scalar weights against the per-lane pair, M steps/s.  fp64 standing batch: a tie from
-  //  53 248 to 98 304 states (605 / 605, 608 / 605, 606 / 604, 621 / 625, 638 / 639), then the pair: 636 / 690 at 114 688, 644 / 730 at 131 072; fp64 trot
-  //  batch: tiles 531 / 483 at 53 248, 533 / 463 at 57 344, 537 / 503 at 65 536, 554 / 520 at 81 920, 546 / 534 at 98 304, pair 527 / 554 at 114 688.
-  //  fp32 trot batch: tiles 1 043 / 919 at 98 304, 992 / 909 at 131 072, 934 / 911 at 196 608, pair 907 / 951 at 229 376)
   // front halves that do not change the target wrench leave it to the QP kernels to read the caller's w_des (QpArgs::wdes)
-  const bool front_writes_b = ob && !(mats && N >= s->obs_split_min);   // the all-in-one observer forms: b = w_des - rhat_base
+  const bool front_writes_b = ob && !pl.obs_split;   // the all-in-one observer forms: b = w_des - rhat_base
   qa.wdes = front_writes_b ? nullptr : (const T*)in->w_des;   // (those front halves run their SW_NOB / RS_NOB variants)
-  a.qp_todo = lane ? s->d_todo : nullptr;   // the front-half kernel empties the hand-over list (one thread; a kernel of its own took 4.7 us per tick)
-  bool obs_split = false;
-  if (!mats) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
+  a.qp_todo = pl.lane ? s->d_todo : nullptr;   // the front-half kernel empties the hand-over list (one thread; a kernel of its own took 4.7 us per tick)
+  if (pl.front == 1) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
     const int mode = RS_STEP | (ob ? RS_OBS : RS_NOB) | (out->pf ? RS_PF : 0);
     TIMED_LAUNCH(2, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
-  } else if (ob && N >= s->obs_split_min) {
+  } else if (pl.front == 2) {
     // large observer-on batch: the observer update runs as its own light kernel in front of (option: beside, on the second
     // stream) a dyn_sweep WITHOUT the observer passes (252 instead of 370 VGPRs: two waves per SIMD, shared tables), which writes
     // M, h, Jc; rhat travels through 18 extra workspace words and the QP kernel completes b and tau_partial with it
-    obs_split = true;
     if (s->opt.obs_split_serial) {   // same stream, one after the other
       TIMED_LAUNCH(2, st, "observer", k_observer<T>(L, dev_model<T>(s), dp, a));
       TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | SW_NOB, dev_model<T>(s), dp, a));
@@ -622,38 +762,13 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   } else {
     TIMED_LAUNCH(0, st, "dyn_sweep", k_dyn_sweep<T>(L, SW_MATS | SW_STEP | (ob ? SW_OBS : SW_NOB), dev_model<T>(s), dp, a));
   }
-  // two-kernel ticks deal tiles of states to the wavefronts by predicted work (qp_tile_kernel).  Measured on MI355X, fp64,
-  // QP kernel alone, one-wavefront workgroups -> tiles: 34.7 -> 32.7 us at 12 288 states (tiles of 32), 62.4 -> 48.3 at
-  // 32 768, 109.6 -> 93.1 at 65 536, 408 -> 350 at 262 144 (tiles of 64; 128 and 256 lose to the workgroup lifetime);
-  // below 12 288 states the tiles do not fill the device
-  int tile = s->opt.qp_tile;
-  // (round 3, structured QP body, QP stage in us.  fp64 standing batch: one-wave 19.0 / tiles-of-32 19.6 at 12 288; 22.2 / 20.0 / 64: 23.9 at
-  //  16 384; 31.2 / 24.6 / 30.3 at 24 576; 32.4 / 31.9 / 29.9 at 28 672; 35.9 / 34.7 / 30.4 at 32 768.  fp32 -- whose tile kernel holds 180
-  //  registers, two workgroups per CU, where the one-wave kernel runs four wavefronts per SIMD -- trot batch: 17.0 / 20.8 / 20.5 at 16 384,
-  //  19.6 / 31.2 / 20.5 at 24 576, 22.1 / 33.4 / 22.0 at 28 672, 24.3 / 35.7 / 22.7 at 32 768; standing batch 31.3 / 44.1 / 37.2 at 24 576)
-  // ONE ROUND OF RESIDENT WORKGROUPS: the tile kernel keeps three workgroups on a CU (146 registers in fp64, 159 in fp32; 768 on the device),
-  // and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
-  // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
-  // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
-  if (tile == 0) {
-    if (std::is_same<T, float>::value) {
-      if (N >= 30720 && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
-      else if (N > 65536) {                    // (beyond: the leaner fp32 body, FOUR workgroups per CU -- k_qp.hip: one round is 1 024 tiles)
-        tile = (int)(((N + 1023) / 1024 + 7) / 8 * 8);
-        tile = tile > 128 ? 64 : tile;         // (more than one round of 128-state tiles: many rounds of 64-state ones)
-      }
-    } else if (N >= 14336) {
-      tile = (int)(((N + 767) / 768 + 3) / 4 * 4);
-      tile = tile < 32 ? 32 : (tile > 64 ? 64 : tile);
-    }
-  }
-  if (tile < 0) tile = 0;
-  if (lane) {
-    TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, obs_split, dp, qa, s->jmap, s->d_todo));
-    TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, 0, dp, qa, s->jmap, s->d_todo));
+  keep.written();
+  if (pl.lane) {
+    TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, pl.obs_split, dp, qa, s->jmap, s->d_todo));
+    TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, 0, dp, qa, s->jmap, s->d_todo));
     return WBC_OK;
   }
-  TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, obs_split, tile, dp, qa, s->jmap));
+  TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, pl.tile, dp, qa, s->jmap));
   return WBC_OK;
 }
 
@@ -746,7 +861,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   return WBC_OK;
 }
 
-static bool rollout_as_one_launch(const wbc_solver* s, size_t N) { return N <= s->fused_max && s->opt.rollout_persistent; }
+static bool rollout_as_one_launch(const wbc_solver* s, size_t N) { return N <= s->rz.fused_max && s->opt.rollout_persistent; }
 
 extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                                  const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, void* stream) {
@@ -921,15 +1036,21 @@ static int one_tick_on_image(wbc_solver* s) {
   if (rc) return rc;
   if (!zc) HIP_TRY(hipMemcpyAsync(hb, d, s->one_bytes, hipMemcpyDeviceToHost, nullptr));
   if (zcm >= 2 && s->one_flag_ok) {
-    const unsigned ticket = ++s->one_seq;
+    unsigned ticket = ++s->one_seq;
+    if (ticket == 0) ticket = ++s->one_seq;                       // (0 is the "not yet" value below)
+    __atomic_store_n((unsigned*)(hints + 3), 0u, __ATOMIC_RELEASE);   // before the launch: a match can only come from THIS tick's write
     hipError_t e = zcm == 2 ? hipStreamWriteValue32(nullptr, dints + 3, ticket, 0) : k_flag(nullptr, (unsigned*)(dints + 3), ticket);
     if (e == hipSuccess) {
       // stream order puts the ticket behind the tick's kernels, whose writes to the (fine-grained) image are released at
       // their end: ticket visible => outputs visible.  Bounded spin, then the runtime's wait (a stalled device must not hang us).
       const unsigned* flag = (const unsigned*)(hints + 3);
-      for (long spin = 0; spin < 4000000; ++spin) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) return WBC_OK;
-        __builtin_ia32_pause();
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);   // a healthy tick takes ~15 us
+      for (;;) {
+        for (int spin = 0; spin < 256; ++spin) {
+          if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ticket) return WBC_OK;
+          cpu_relax();
+        }
+        if (std::chrono::steady_clock::now() > t_end) break;
       }
     } else {
       (void)hipGetLastError();
@@ -1099,4 +1220,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 5; }  // 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
+extern "C" int wbc_abi_version(void) { return 6; }  // 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_solver_options.rollout_warm); 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
