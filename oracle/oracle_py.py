@@ -130,8 +130,9 @@ class Oracle:
         return out
 
     def step(self, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, integ=None, r=None,
-             nthreads=1):
-        """integ, r are updated IN PLACE when the observer is on."""
+             nthreads=1, aset=None):
+        """integ, r are updated IN PLACE when the observer is on.  aset (optional, uint32 [N]): warm start of the QP from that active
+        set (encoding: include/wbc_hip.h, wbc_step_batch_warm); the returned dict always carries the active set at the solution."""
         dt = q.dtype
         N = q.shape[0]
         c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
@@ -146,15 +147,18 @@ class Oracle:
         status = np.empty(N, np.int32)
         iters = np.empty(N, np.int32)
         ps = make_params_struct(P)
+        aset_in = None if aset is None else np.ascontiguousarray(aset, dtype=np.uint32)
+        aset_out = np.zeros(N, np.uint32)
         getattr(lib(), "wbco_step_" + self._suf(dt))(self.h, C.byref(ps), N, _p(q), _p(v), _p(w_des), _p(vdot_des),
                                                      _p(normals), _p(mu), _p(mask), _p(tau_prev), _p(f_prev), _p(integ),
-                                                     _p(r), _p(tau), _p(f), _p(status), _p(iters), int(nthreads))
-        return dict(tau=tau, f=f, status=status, iters=iters)
+                                                     _p(r), _p(tau), _p(f), _p(status), _p(iters), int(nthreads), _p(aset_in), _p(aset_out))
+        return dict(tau=tau, f=f, status=status, iters=iters, aset=aset_out)
 
 
 def _rollout(self, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext=None, tau_prev=None, f_prev=None,
-             integ=None, r=None, want_traj=False, nthreads=1):
-    """q, v (and tau_prev, f_prev, integ, r when given) are updated IN PLACE.  Returns dict(status[, tau_traj])."""
+             integ=None, r=None, want_traj=False, nthreads=1, warm=False):
+    """q, v (and tau_prev, f_prev, integ, r when given) are updated IN PLACE.  Returns dict(status, iters_sum[, tau_traj]).
+    warm: ticks after the first start their QP from the previous tick's active set."""
     dt = q.dtype
     N = q.shape[0]
     assert q.flags.c_contiguous and v.flags.c_contiguous and v.dtype == dt
@@ -169,11 +173,12 @@ def _rollout(self, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext
         assert a is None or (a.dtype == dt and a.flags.c_contiguous)
     traj = np.zeros((N, horizon, self.nj), dt) if want_traj else None
     status = np.zeros(N, np.int32)
+    iters_sum = np.zeros(N, np.int32)
     ps = make_params_struct(P)
     getattr(lib(), "wbco_rollout_" + self._suf(dt))(self.h, C.byref(ps), N, int(horizon), _p(q), _p(v), _p(w_des),
                                                     _p(vdot_des), _p(normals), _p(mu), _p(mask), _p(tau_ext), _p(tau_prev),
-                                                    _p(f_prev), _p(integ), _p(r), _p(traj), _p(status), int(nthreads))
-    out = dict(status=status, tau_prev=tau_prev, f_prev=f_prev)
+                                                    _p(f_prev), _p(integ), _p(r), _p(traj), _p(status), int(nthreads), int(bool(warm)), _p(iters_sum))
+    out = dict(status=status, tau_prev=tau_prev, f_prev=f_prev, iters_sum=iters_sum)
     if want_traj:
         out["tau_traj"] = traj
     return out
@@ -197,7 +202,7 @@ def _reference(self, G, q, v, plan, t=0.0):
 
 
 def _rollout_tracking(self, P, G, horizon, q, v, plan, normals, mu, mask, tau_ext=None, tau_prev=None, f_prev=None,
-                      integ=None, r=None, want_traj=False, want_com=False, nthreads=1):
+                      integ=None, r=None, want_traj=False, want_com=False, nthreads=1, warm=False):
     """Planner-in-the-loop rollout; q, v (and tau_prev, f_prev, integ, r when given) are updated IN PLACE."""
     dt = q.dtype
     N = q.shape[0]
@@ -217,7 +222,7 @@ def _rollout_tracking(self, P, G, horizon, q, v, plan, normals, mu, mask, tau_ex
     getattr(lib(), "wbco_rollout_tracking_" + self._suf(dt))(
         self.h, C.byref(make_params_struct(P)), C.byref(make_ref_params_struct(G)), N, int(horizon), _p(q), _p(v), _p(plan),
         _p(normals), _p(mu), _p(mask), _p(tau_ext), _p(tau_prev), _p(f_prev), _p(integ), _p(r), _p(traj), _p(com), _p(status),
-        int(nthreads))
+        int(nthreads), int(bool(warm)))
     out = dict(status=status, tau_prev=tau_prev, f_prev=f_prev)
     if want_traj:
         out["tau_traj"] = traj
@@ -273,7 +278,8 @@ def _op_count(self, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, 
 Oracle.op_count = _op_count
 
 
-def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9):
+def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9, warm=None, want_active=False):
+    """warm: boolean [m] guess of the active set (see qp_solve_gi); want_active: also return the final active set."""
     dt = H.dtype
     n, m = len(g), len(d)
     H, g, Cm, d = (np.ascontiguousarray(a, dtype=dt) for a in (H, g, Cm, d))
@@ -283,7 +289,11 @@ def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9):
     fn = getattr(lib(), "wbco_qp_solve_" + Oracle._suf(dt))
     fn.restype = C.c_int
     ct = C.c_double if dt == np.float64 else C.c_float
-    it = fn(n, m, _p(H), _p(g), _p(Cm), _p(d), int(max_iter), ct(tol), _p(x), _p(lam), C.byref(st))
+    wf = None if warm is None else np.ascontiguousarray(warm, dtype=np.uint8)
+    af = np.zeros(max(m, 1), np.uint8)
+    it = fn(n, m, _p(H), _p(g), _p(Cm), _p(d), int(max_iter), ct(tol), _p(x), _p(lam), C.byref(st), _p(wf), _p(af))
+    if want_active:
+        return x, lam[:m], st.value, it, af[:m].astype(bool)
     return x, lam[:m], st.value, it
 
 

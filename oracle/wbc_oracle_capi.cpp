@@ -94,7 +94,7 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
   void wbco_step_##SUF(void* hh, const wbco_params* pp, int N, const T* q, const T* v, const T* w_des,          \
                        const T* vdot_des, const T* normals, const T* mu, const int* mask, const T* tau_prev,    \
                        const T* f_prev, T* obs_integ, T* obs_r, T* tau, T* f, int* status, int* iters,          \
-                       int nthreads) {                                                                          \
+                       int nthreads, const unsigned* aset_in, unsigned* aset_out) {                            \
     const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
     const Params P = to_params(pp);                                                                             \
     const int nv = m.nv(), nq = nv + 1, nj = m.nj(), nf = m.nf;                                                 \
@@ -106,7 +106,8 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
            normals + (size_t)s * 3 * nf, mu + (size_t)s * nf, (unsigned)mask[s],                                \
            tau_prev ? tau_prev + (size_t)s * nj : zt, f_prev ? f_prev + (size_t)s * 3 * nf : zt,                \
            obs_integ ? obs_integ + (size_t)s * nv : (T*)nullptr, obs_r ? obs_r + (size_t)s * nv : (T*)nullptr,  \
-           o);                                                                                                  \
+           o, (DynOut<T>*)nullptr, aset_in ? aset_in + s : (const unsigned*)nullptr,                            \
+           aset_out ? aset_out + s : (unsigned*)nullptr);                                                       \
       for (int e = 0; e < nj; ++e) tau[(size_t)s * nj + e] = o.tau[e];                                          \
       for (int e = 0; e < 3 * nf; ++e) f[(size_t)s * 3 * nf + e] = o.f[e];                                      \
       if (status) status[s] = o.status;                                                                         \
@@ -116,7 +117,8 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
   /* horizon ticks of {step, forward dynamics with the planned GRFs, integration}; q, v, tau_prev, f_prev, obs in/out */ \
   void wbco_rollout_##SUF(void* hh, const wbco_params* pp, int N, int horizon, T* q, T* v, const T* w_des,              \
                           const T* vdot_des, const T* normals, const T* mu, const int* mask, const T* tau_ext,         \
-                          T* tau_prev, T* f_prev, T* obs_integ, T* obs_r, T* tau_traj, int* status, int nthreads) {     \
+                          T* tau_prev, T* f_prev, T* obs_integ, T* obs_r, T* tau_traj, int* status, int nthreads,       \
+                          int warm, int* iters_sum) {                                                                  \
     const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
     const Params P = to_params(pp);                                                                             \
     const int nv = m.nv(), nq = nv + 1, nj = m.nj(), nf = m.nf;                                                 \
@@ -128,7 +130,7 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
               tau_ext ? tau_ext + (size_t)s * nv : (const T*)nullptr, tau_prev + (size_t)s * nj,                 \
               f_prev + (size_t)s * 3 * nf, obs_integ ? obs_integ + (size_t)s * nv : zi,                          \
               obs_r ? obs_r + (size_t)s * nv : zr, tau_traj ? tau_traj + (size_t)s * horizon * nj : (T*)nullptr, \
-              status ? status + s : (int*)nullptr);                                                             \
+              status ? status + s : (int*)nullptr, warm != 0, iters_sum ? iters_sum + s : (int*)nullptr);       \
     }                                                                                                           \
   }                                                                                                             \
   /* CoM reference generator (a11): plan [N][12] -> w_des [N][6], vdot_des [N][nv], optional com [N][6] */       \
@@ -144,7 +146,7 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
   void wbco_rollout_tracking_##SUF(void* hh, const wbco_params* pp, const wbco_ref_params* gg, int N,           \
                                    int horizon, T* q, T* v, const T* plan, const T* normals, const T* mu,       \
                                    const int* mask, const T* tau_ext, T* tau_prev, T* f_prev, T* obs_integ,     \
-                                   T* obs_r, T* tau_traj, T* com_traj, int* status, int nthreads) {             \
+                                   T* obs_r, T* tau_traj, T* com_traj, int* status, int nthreads, int warm) {   \
     const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
     const Params P = to_params(pp);                                                                             \
     const RefParams G = to_ref(gg);                                                                             \
@@ -159,7 +161,7 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
                        obs_r ? obs_r + (size_t)s * nv : zr,                                                     \
                        tau_traj ? tau_traj + (size_t)s * horizon * nj : (T*)nullptr,                            \
                        com_traj ? com_traj + (size_t)s * horizon * 6 : (T*)nullptr,                             \
-                       status ? status + s : (int*)nullptr);                                                    \
+                       status ? status + s : (int*)nullptr, warm != 0);                                         \
     }                                                                                                           \
   }                                                                                                             \
   void wbco_forward_dynamics_##SUF(int nv, int nj, int nf, const T* Mp, const T* h, const T* Jc, const T* tau,  \
@@ -168,13 +170,17 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
   }                                                                                                             \
   /* dense QP, row-major H[n*n], C[m*n]: min 1/2 x'Hx + g'x  s.t. Cx >= d */                                    \
   int wbco_qp_solve_##SUF(int n, int mm, const T* H, const T* g, const T* C, const T* d, int max_iter, T tol,   \
-                          T* x, T* lambda, int* status) {                                                       \
+                          T* x, T* lambda, int* status, const unsigned char* warm, unsigned char* active_out) { \
     if (n > QPN || mm > QPM) { *status = -1; return 0; }                                                        \
     QP<T> qp;                                                                                                   \
     qp.n = n; qp.m = mm;                                                                                        \
     for (int i = 0; i < n; ++i) { qp.g[i] = g[i]; for (int j = 0; j < n; ++j) qp.H[i * QPN + j] = H[i * n + j]; } \
     for (int i = 0; i < mm; ++i) { qp.d[i] = d[i]; for (int j = 0; j < n; ++j) qp.C[i * QPN + j] = C[i * n + j]; } \
-    return qp_solve_gi(qp, max_iter, tol, x, lambda, status);                                                   \
+    bool wf[QPM], af[QPM];                                                                                      \
+    for (int i = 0; i < mm; ++i) wf[i] = warm && warm[i];                                                       \
+    const int it = qp_solve_gi(qp, max_iter, tol, x, lambda, status, warm ? wf : (const bool*)nullptr, af);     \
+    if (active_out) for (int i = 0; i < mm; ++i) active_out[i] = af[i] ? 1 : 0;                                 \
+    return it;                                                                                                  \
   }                                                                                                             \
   /* QP assembly for one state: returns n, writes m; H[QPN*QPN] etc. with leading dimension QPN */              \
   int wbco_qp_assemble_##SUF(const wbco_params* pp, int nf, int mask, const T* pb, const T* pf,                  \

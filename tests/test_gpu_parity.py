@@ -184,8 +184,10 @@ def test_full_size_fp64_vs_oracle(torch_cuda, gpu_model, oracle):
 
 def test_full_size_fp32_vs_both_oracles(torch_cuda, gpu_model, oracle):
     """configs[3] at its full size (262 144 states, tilted normals, disturbances, observer on, fp32), DEFAULT options, against the
-    fp32 run of the oracle (stated fp32 tolerance 1e-3 of the largest entry) and against the fp64 oracle (1e-4: the HIP path
-    solves the QP in fp64 arithmetic); the fraction of states whose QP status differs from either oracle is asserted."""
+    fp32 run of the oracle (stated fp32 tolerance 1e-3 of the largest entry) and against the fp64 oracle (stated 2e-4; measured on
+    MI355X over the 262 144 states: tau 8.6e-5, f 1.1e-4 of the largest entry -- at this size the QPs go through the per-lane
+    kernel, whose fp32 acceptance test is a residual of 2e-5 (1 + |target wrench|)); the fraction of states whose QP status differs
+    from either oracle is asserted."""
     torch = torch_cuda
     n = 262144
     solver, P = _solver(gpu_model, dtype="f32", obs=1, max_batch=n)
@@ -207,7 +209,7 @@ def test_full_size_fp32_vs_both_oracles(torch_cuda, gpu_model, oracle):
     ok = (got["status"] == 0) & (ref32["status"] == 0) & (ref64["status"] == 0)
     assert ok.mean() > 0.999
     assert relerr(got["tau"][ok], ref32["tau"][ok]) < 1e-3 and relerr(got["f"][ok], ref32["f"][ok]) < 1e-3
-    assert relerr(got["tau"][ok], ref64["tau"][ok]) < 1e-4 and relerr(got["f"][ok], ref64["f"][ok]) < 1e-4
+    assert relerr(got["tau"][ok], ref64["tau"][ok]) < 2e-4 and relerr(got["f"][ok], ref64["f"][ok]) < 2e-4
     assert relerr(got["r"], r64) < 2e-3
 
 

@@ -41,3 +41,49 @@ def test_structured_iteration_matches_the_oracle(oracle, cfg, n, lateral):
         it_diff += int(it != ref["iters"][i])
     assert it_diff <= max(2, n // 10)   # same pivots except where two candidates tie to rounding
     assert ref["iters"].max() >= 4      # the sample does contain multi-constraint QPs
+
+
+@pytest.mark.parametrize("cfg,lateral", [(2, 150.0), (3, 40.0), (4, 80.0)])
+def test_structured_warm_setup_from_a_given_active_set(oracle, cfg, lateral):
+    """The block set-up for dependent ticks (closed-form projectors / pseudo-inverses per foot, G_A factorised directly, minimiser on
+    the set and its multipliers): from the oracle's own final set it reproduces the solution with zero iterations; from the set of
+    a NEIGHBOURING problem it lands on the cold solution; sets that are no S-pair are refused."""
+    spec = importlib.util.spec_from_file_location("structured_gi", os.path.join(ROOT, "tools", "structured_gi.py"))
+    sg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sg)
+    from oracle import urdf_model
+    flat = urdf_model.load_urdf(W.SYNTHETIC_URDF)
+    n = 60
+    P = synth.default_params(observer_order=0)
+    B = synth.make_batch(cfg, n, float(flat["mass"].sum()), rank=23)
+    B["w_des"][:, 0:2] += np.random.default_rng(5).uniform(-lateral, lateral, (n, 2))
+    dyn = oracle.dynamics(B["q"], B["v"])
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"])
+    BIT = (0, 16, 1, 17, 2, 3)
+    ids_of = lambda a: [6 * k + c for k in range(4) for c in range(6) if (int(a) >> (4 * k + BIT[c])) & 1]
+    used = refused = 0
+    for i in range(n):
+        mk = lambda w: sg.StructuredGI(np.asarray(P["S"], float), P["alpha"], int(B["mask"][i]), dyn["pf"][i].reshape(4, 3) - B["q"][i, :3],
+                                       B["normals"][i].reshape(4, 3), B["mu"][i] * P["mu_scale"], P["fn_min"], P["fn_max"], w, tol=P["qp_tol"],
+                                       max_iter=P["max_iter"])
+        on = np.repeat([(int(B["mask"][i]) >> k) & 1 for k in range(4)], 3)
+        s = mk(B["w_des"][i])
+        x, it, st, u = s.solve(warm=ids_of(ref["aset"][i]))
+        assert s.warm_used and it == 0 and st == 0
+        assert np.abs(x * on - ref["f"][i]).max() <= 1e-9 * max(1.0, np.abs(ref["f"][i]).max())
+        # the neighbour's problem (another target wrench) from this problem's set
+        w2 = B["w_des"][i] + np.random.default_rng(i).uniform(-8, 8, 6)
+        xc, itc, stc, _ = mk(w2).solve()
+        s2 = mk(w2)
+        xw, itw, stw, _ = s2.solve(warm=ids_of(ref["aset"][i]))
+        assert stw == stc == 0 and np.abs(xw - xc).max() <= 1e-9 * max(1.0, np.abs(xc).max())
+        used += int(s2.warm_used)
+        # no S-pair: both bounds of one normal force; all six rows of a foot
+        k0 = [k for k in range(4) if (int(B["mask"][i]) >> k) & 1]
+        if k0:
+            for bad in ([6 * k0[0] + 4, 6 * k0[0] + 5], [6 * k0[0] + c for c in range(6)]):
+                s3 = mk(B["w_des"][i])
+                x3, _, st3, _ = s3.solve(warm=bad)
+                assert not s3.warm_used and st3 == 0 and np.abs(x3 * on - ref["f"][i]).max() <= 1e-9 * max(1.0, np.abs(ref["f"][i]).max())
+                refused += 1
+    assert used > n // 2 and refused > 0

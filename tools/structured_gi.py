@@ -75,7 +75,41 @@ class StructuredGI:
     def G(self, P):
         return self.alpha * np.eye(6) + sum(self.B[k] @ P[k] @ self.B[k].T for k in range(4))
 
-    def solve(self):
+    def warm_setup(self, ids):
+        """Block set-up from a GIVEN active set (what csrc/qp_struct16.hip.hpp does for dependent ticks): per-foot projectors and
+        pseudo-inverses in closed form, G_A factorised directly, the minimiser ON the set and its multipliers
+            f_k = f_k^p - P_k B_k^T y,   f_k^p = N_k^+T rhs_k,   G_A y = sum_k B_k f_k^p - beta,   u_k = alpha N_k^+ (f_k + B_k^T y).
+        Returns None when the set is no S-pair of the dual method: more than three rows on a foot, dependent rows, a negative multiplier."""
+        a, B = self.alpha, self.B
+        act = [[] for _ in range(4)]
+        for c in sorted(ids):
+            if self.on[c // 6]:
+                act[c // 6].append(c)
+        P, Np = [], []
+        for k in range(4):
+            nrm = [self.C[c] for c in act[k]]
+            if len(nrm) > 3:
+                return None
+            if len(nrm) == 2 and np.cross(nrm[0], nrm[1]).dot(np.cross(nrm[0], nrm[1])) <= 1e-12:
+                return None
+            if len(nrm) == 3 and nrm[0].dot(np.cross(nrm[1], nrm[2])) ** 2 <= 1e-12:
+                return None
+            Pk, Nk = proj_and_pinv(nrm)
+            P.append(Pk); Np.append(Nk)
+        Ginv = np.linalg.inv(self.G(P))
+        fp = [Np[k].T @ np.array([self.rhs[c] for c in act[k]]) if act[k] else np.zeros(3) for k in range(4)]
+        y = Ginv @ (sum(B[k] @ fp[k] for k in range(4)) - self.beta)
+        f = [fp[k] - P[k] @ (B[k].T @ y) for k in range(4)]
+        u = {}
+        for k in range(4):
+            if act[k]:
+                for c, val in zip(act[k], a * (Np[k] @ (f[k] + B[k].T @ y))):
+                    u[c] = val
+        if any(not (val >= 0) for val in u.values()):
+            return None
+        return act, P, Np, Ginv, np.concatenate(f), u
+
+    def solve(self, warm=None):
         a, B = self.alpha, self.B
         act = [[] for _ in range(4)]                # per foot: constraint ids in slot order
         order = []                                  # global add order (tie-breaking of the ratio test)
@@ -84,6 +118,11 @@ class StructuredGI:
         Np = [np.zeros((0, 3)) for _ in range(4)]
         Ginv = np.linalg.inv(self.G(P))
         x = np.concatenate([B[k].T @ (Ginv @ self.beta) for k in range(4)])   # unconstrained minimum B^T G^-1 S^(1/2) b
+        ws = self.warm_setup(warm) if warm is not None else None
+        self.warm_used = ws is not None
+        if ws is not None:
+            act, P, Np, Ginv, x, u = ws
+            order = [c for k in range(4) for c in act[k]]
         eps = np.finfo(float).eps
         Rnorm, it, status = 1.0, 0, 0
         slack = lambda c, xx: self.C[c].dot(xx[3 * (c // 6):3 * (c // 6) + 3]) - self.rhs[c]
