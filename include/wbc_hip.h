@@ -137,6 +137,9 @@ typedef struct wbc_solver_options {
                              every call writes every word.  The buffers are identified by ADDRESS: freeing and reallocating them (or a
                              caching allocator handing the same address out again) counts as touching them -- call
                              wbc_solver_invalidate_structural then */
+  int rollout_warm;       /* (default 1) wbc_rollout_batch / wbc_rollout_tracking_batch: every tick after the first starts its GRF QPs from the
+                             active set of the previous tick (see wbc_step_batch_warm).  The QP is strictly convex, so the results do not
+                             depend on it -- the time per tick does.  0: every tick solves from the unconstrained minimum */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -158,9 +161,10 @@ typedef struct wbc_tick_plan {
   int sweep_pack2;    /* fp32 dyn_sweep with two states per lane */
   int sweep_block;    /* threads per workgroup of the dyn_sweep launch (64 / 256); 0 when no dyn_sweep runs */
 } wbc_tick_plan;
+/* warm != 0: the plan of wbc_step_batch_warm */
 int wbc_plan_tick(int dtype, int observer_order, const wbc_solver_options* opt /* NULL = defaults */, size_t N, int with_mats, int with_pf,
-                  wbc_tick_plan* plan);
-int wbc_solver_plan_tick(const wbc_solver* s, size_t N, int with_mats, int with_pf, wbc_tick_plan* plan);
+                  int warm, wbc_tick_plan* plan);
+int wbc_solver_plan_tick(const wbc_solver* s, size_t N, int with_mats, int with_pf, int warm, wbc_tick_plan* plan);
 /* the batch sizes N at which the plan differs from that of N - 1 (fp32: N - 2; odd batches never pack), ascending; *n = how many
  * (at most 16), the first min(*n, cap) are written to out */
 int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_solver_options* opt, int with_mats, size_t* out, int cap, int* n);
@@ -213,6 +217,20 @@ int wbc_dynamics_batch(wbc_solver* s, size_t N, const void* q, const void* v, vo
  * Stands for the controller's per-tick compute-torques entry point (name [UNVERIFIED]). */
 int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
                    const wbc_observer_state* obs, void* stream);
+
+/* One tick of a DEPENDENT sequence -- the reference controller runs in a loop on one robot (/root/reference/README.md:58-62), and
+ * consecutive ticks share most of the active set of their GRF QP.  active_in [N] int32 (may be NULL = start cold) is the active set
+ * each state's dual active-set iteration starts from: normally what the previous tick wrote to active_out [N] (may be NULL; in
+ * place allowed).  Encoding, per state: for foot k with unit normal n, tangents t1, t2 and mu~ = mu * mu_scale
+ *     bit 4k + j,      j = 0 .. 3:  the rows  (mu~ n - t1) . f >= 0,  (mu~ n - t2) . f >= 0,  n . f >= fn_min,  -n . f >= -fn_max
+ *     bit 16 + 4k + j, j = 0 .. 1:  the rows  (mu~ n + t1) . f >= 0,  (mu~ n + t2) . f >= 0
+ * Bits of swing feet are ignored.  The set is a HINT: the solver builds the minimiser on it in one block step and continues the
+ * iteration from there when it is an S-pair of the dual method (independent rows, non-negative multipliers), otherwise it starts
+ * cold -- the QP is strictly convex, so tau, f and status never depend on the hint, only `iters` (= iterations after the block step)
+ * and the time do.  Same buffers, checks and stream semantics as wbc_step_batch; batches beyond the fused-tick size solve the QPs with
+ * the one-wavefront kernel (wbc_plan_tick with warm = 1). */
+int wbc_step_batch_warm(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out, const wbc_observer_state* obs,
+                        const int* active_in, int* active_out, void* stream);
 
 /* SURVEY.md 8(f)-1 -- the step Gazebo performs in the reference loop (/root/reference/README.md:58), as the simplest
  * model that closes the loop for rollouts: forward dynamics with the planned GRFs applied,

@@ -1,0 +1,210 @@
+"""GPU: warm start of the GRF QP for dependent ticks (wbc_step_batch_warm, wbc_solver_options.rollout_warm; the block set-up of
+csrc/qp_struct16.hip.hpp) against the oracle and against the cold start of the same problem.
+
+The QP is strictly convex: a warm start may change `iters`, never tau, f or status.  PARITY UNPINNED against the reference itself
+(source absent) -- see DESIGN.md."""
+import numpy as np
+import pytest
+
+from tests.util import elementwise_excess, relerr, to_dev, to_host
+from tests.test_gpu_parity import _gpu_rollout, _np_dtype, _solver, TIGHT64
+from wbc_quadruped_dob_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+def _dev_inputs(torch, B, dtype):
+    td = torch.float64 if dtype == "f64" else torch.float32
+    ins = [to_dev(B[k], torch, td) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")]
+    mask = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
+    return ins, mask, td
+
+
+def _second_tick(B, seed):
+    """the same robots one control period later: joints, base height and the commanded wrench moved a little"""
+    rng = np.random.default_rng(seed)
+    n = B["q"].shape[0]
+    B2 = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in B.items()}
+    B2["q"][:, 7:] += rng.uniform(-0.01, 0.01, (n, 12))
+    B2["q"][:, 2] += rng.uniform(-0.002, 0.002, n)
+    B2["w_des"] += rng.uniform(-2.0, 2.0, (n, 6))
+    return B2
+
+
+@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 0, 2, 1000), ("f64", 1, 3, 4096), ("f64", 0, 2, 9001), ("f64", 2, 4, 24000), ("f64", 1, 3, 70001),
+                                             ("f32", 1, 4, 3000), ("f32", 0, 2, 40000)])
+def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
+    """Two consecutive ticks.  Tick 1 through wbc_step_batch_warm without a set (cold) reports the active sets; tick 2 starts from
+    them.  Fused tick (<= 8 192 states) and two-kernel ticks with the one-wavefront warm kernel; observer off / on / split."""
+    torch = torch_cuda
+    nd = _np_dtype(dtype)
+    c = lambda a: np.ascontiguousarray(a, nd)
+    solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=29)
+    B["w_des"][:, 0:2] += np.random.default_rng(1).uniform(-60, 60, (n, 2))       # friction rows become active
+    integ = r = None
+    if obs:
+        integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+        r = np.zeros((n, 18))
+    P0 = synth.default_params(observer_order=obs, dtype=dtype)
+    # ---- tick 1: oracle and GPU (cold, reports the sets)
+    ig_o, r_o = (None, None) if not obs else (c(integ).copy(), c(r).copy())
+    ref1 = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], c(B["tau_prev"]),
+                       c(B["f_prev"]), ig_o, r_o, nthreads=8)
+    ins, mask, td = _dev_inputs(torch, B, dtype)
+    ig = None if not obs else to_dev(integ, torch, td)
+    rr = None if not obs else to_dev(r, torch, td)
+    tp, fp = to_dev(B["tau_prev"], torch, td), to_dev(B["f_prev"], torch, td)
+    o1 = solver.step(*ins, mask, tp, fp, ig, rr, want_mats=True, warm=True)
+    torch.cuda.synchronize()
+    act1 = o1["active"].cpu().numpy().astype(np.uint32)
+    st1 = o1["status"].cpu().numpy()
+    tol = TIGHT64 if dtype == "f64" else 2e-3
+    ok1 = (st1 == 0) & (ref1["status"] == 0)
+    assert ok1.mean() > (0.999 if dtype == "f64" else 0.995)
+    assert relerr(to_host(o1["tau"])[ok1], ref1["tau"][ok1]) < tol
+    # the reported set is the oracle's wherever the vertex is regular (a stance foot without force sits at the apex of its pyramid,
+    # where any three of its five rows name the same point)
+    fn = np.einsum("nka,nka->nk", ref1["f"].reshape(n, 4, 3).astype(np.float64), B["normals"].reshape(n, 4, 3))
+    stance = ((B["mask"][:, None] >> np.arange(4)[None, :]) & 1) == 1
+    regular = np.all(~stance | (fn > 1e-3), axis=1) & ok1
+    assert regular.mean() > 0.3
+    if dtype == "f64":
+        assert np.array_equal(act1[regular], ref1["aset"][regular])
+    else:
+        assert np.mean(act1[regular] == ref1["aset"][regular]) > 0.99
+    # ---- tick 2 on the moved states: oracle cold, GPU cold, GPU warm
+    B2 = _second_tick(B, 3)
+    ig_o2, r_o2 = (None, None) if not obs else (ig_o.copy(), r_o.copy())
+    ref2 = oracle.step(P0, c(B2["q"]), c(B2["v"]), c(B2["w_des"]), c(B2["vdot_des"]), c(B2["normals"]), c(B2["mu"]), B2["mask"], ref1["tau"],
+                       ref1["f"], ig_o2, r_o2, nthreads=8)
+    ins2, mask2, _ = _dev_inputs(torch, B2, dtype)
+    tp2, fp2 = o1["tau"].clone(), o1["f"].clone()
+    res = {}
+    for tag in ("cold", "warm"):
+        ig2 = None if not obs else ig.clone()
+        rr2 = None if not obs else rr.clone()
+        o2 = solver.step(*ins2, mask2, tp2, fp2, ig2, rr2, want_mats=True, warm=(tag == "warm"),
+                         active_in=(o1["active"].clone() if tag == "warm" else None))
+        torch.cuda.synchronize()
+        res[tag] = {k: (to_host(v) if v.dim() == 2 else v.cpu().numpy()) for k, v in o2.items()}
+        if obs:
+            res[tag]["r"] = to_host(rr2)
+    np.testing.assert_array_equal(res["warm"]["status"], res["cold"]["status"])
+    ok = (res["warm"]["status"] == 0) & (ref2["status"] == 0)
+    assert ok.mean() > (0.999 if dtype == "f64" else 0.995)
+    for k in ("tau", "f"):
+        assert relerr(res["warm"][k][ok], res["cold"][k][ok]) < (TIGHT64 if dtype == "f64" else 1e-4), k      # warm == cold
+        assert relerr(res["warm"][k][ok], ref2[k][ok]) < tol, k                                               # == oracle
+    if dtype == "f64":
+        np.testing.assert_array_equal(res["warm"]["status"], ref2["status"])
+        assert elementwise_excess(res["warm"]["tau"][ok], ref2["tau"][ok]) <= 1.0
+    if obs:
+        assert relerr(res["warm"]["r"], r_o2) < (TIGHT64 if dtype == "f64" else 2e-3)
+    for k in ("M", "h", "Jc", "pf"):
+        assert np.array_equal(res["warm"][k], res["cold"][k]), k
+    # what the warm start is for: most states need no iteration at all, and far fewer in total
+    it_w, it_c = res["warm"]["iters"].astype(np.int64), res["cold"]["iters"].astype(np.int64)
+    assert it_w.sum() < 0.3 * it_c.sum(), (it_w.sum(), it_c.sum())
+    assert np.mean(it_w[ok] == 0) > 0.8
+
+
+@pytest.mark.parametrize("n", [512, 12000])
+def test_a_wrong_or_impossible_carried_set_still_gives_the_cold_result(torch_cuda, gpu_model, oracle, n):
+    """The carried set is a hint.  Random bits, every bit, both bounds of a normal force, four faces of one pyramid, rows of swing
+    feet, the set of ANOTHER state: tau, f, status equal the cold start (and the oracle) whatever comes in."""
+    torch = torch_cuda
+    solver, P = _solver(gpu_model, obs=0, max_batch=n)
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=41)       # trot masks: swing feet present
+    B["w_des"][:, 0:2] += np.random.default_rng(2).uniform(-80, 80, (n, 2))
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
+    ins, mask, td = _dev_inputs(torch, B, "f64")
+    cold = solver.step(*ins, mask, warm=True)
+    torch.cuda.synchronize()
+    tau_c, f_c, st_c = to_host(cold["tau"]), to_host(cold["f"]), cold["status"].cpu().numpy()
+    np.testing.assert_array_equal(st_c, ref["status"])
+    rng = np.random.default_rng(9)
+    true = cold["active"].cpu().numpy()
+    guesses = {
+        "random": rng.integers(0, 2 ** 31, n).astype(np.int32),
+        "all": np.full(n, -1, np.int32),
+        "both_bounds": np.full(n, 0x0C | (0x0C << 4), np.int32),
+        "whole_pyramid": np.full(n, 0x3 | (0x3 << 16), np.int32),
+        "neighbour": np.roll(true, 1),
+        "true_plus_noise": (true | (rng.integers(0, 2 ** 31, n) & rng.integers(0, 2 ** 31, n) & 0x00FFFFFF)).astype(np.int32),
+    }
+    for tag, g in guesses.items():
+        got = solver.step(*ins, mask, active_in=torch.from_numpy(np.ascontiguousarray(g, np.int32)).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(got["status"].cpu().numpy(), st_c, err_msg=tag)
+        assert relerr(to_host(got["tau"]), tau_c) < TIGHT64 and relerr(to_host(got["f"]), f_c) < TIGHT64, tag
+        assert relerr(to_host(got["tau"]), ref["tau"]) < TIGHT64, tag
+    # the true set of the same problem: zero iterations everywhere
+    got = solver.step(*ins, mask, active_in=cold["active"].clone())
+    torch.cuda.synchronize()
+    assert np.all(got["iters"].cpu().numpy()[st_c == 0] == 0)
+    assert np.array_equal(got["active"].cpu().numpy(), true)
+
+
+@pytest.mark.parametrize("cfg,obs,n,H,opt", [(2, 0, 1024, 20, {}), (3, 1, 1000, 20, {}), (3, 1, 777, 12, {"rollout_spw": 16}),
+                                            (4, 2, 5000, 8, {}), (3, 1, 600, 10, {"rollout_persistent": 0})])
+def test_rollouts_warm_equal_cold_and_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H, opt):
+    """wbc_rollout_batch with rollout_warm = 1 (default: ticks after the first start from the previous tick's active set, carried in
+    registers by the persistent kernel / through a device buffer by the per-tick launches) against rollout_warm = 0 and the oracle."""
+    torch = torch_cuda
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=19)
+    B["w_des"][:, 0:2] += np.random.default_rng(4).uniform(-70, 70, (n, 2))
+    tau_ext = np.zeros((n, 18))
+    tau_ext[:, 0:3] = B["push"] if cfg > 2 else 10.0
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
+    res = {}
+    for warm in (0, 1):
+        solver, P = _solver(gpu_model, obs=obs, max_batch=n, options=dict(opt, rollout_warm=warm))
+        res[warm] = _gpu_rollout(torch, solver, P, H, B, tau_ext, None if integ is None else integ.copy(), np.zeros((n, 18)) if obs else None)
+    q, v = B["q"].copy(), B["v"].copy()
+    ig_ref = None if integ is None else integ.copy()
+    r_ref = np.zeros((n, 18)) if obs else None
+    ref = oracle.rollout(P, H, q, v, B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], tau_ext=tau_ext, integ=ig_ref, r=r_ref,
+                         want_traj=True, nthreads=8, warm=True)
+    assert np.all(res[0]["status"] == 0) and np.all(res[1]["status"] == 0) and np.all(ref["status"] == 0)
+    assert relerr(res[1]["q"], res[0]["q"]) < 1e-9 and relerr(res[1]["v"], res[0]["v"]) < 1e-9
+    assert relerr(res[1]["tau_traj"], res[0]["tau_traj"]) < 1e-8
+    assert relerr(res[1]["q"], q) < 1e-8 and relerr(res[1]["v"], v) < 1e-8
+    assert relerr(res[1]["tau_traj"], ref["tau_traj"]) < 1e-7
+    assert relerr(res[1]["tau_traj"][:, 0], ref["tau_traj"][:, 0]) < TIGHT64
+
+
+def test_warm_tick_is_graph_capturable_and_carries_its_sets(torch_cuda, gpu_model, oracle):
+    """A closed loop of warm ticks in a hipGraph: the set buffer is updated in place, so replaying the captured tick IS the loop."""
+    torch = torch_cuda
+    n = 2048
+    solver, P = _solver(gpu_model, obs=0, max_batch=n)
+    B = synth.make_batch(2, n, gpu_model.total_mass, rank=8)
+    B["w_des"][:, 0:2] += np.random.default_rng(5).uniform(-60, 60, (n, 2))
+    ins, mask, td = _dev_inputs(torch, B, "f64")
+    act = torch.zeros(n, dtype=torch.int32, device="cuda")
+    out = {"active": act}
+    o = solver.step(*ins, mask, out=out, active_in=act)       # eager: cold (empty sets), leaves the sets in `act`
+    torch.cuda.synchronize()
+    it0 = o["iters"].cpu().numpy().copy()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        solver.step(*ins, mask, out=o, active_in=act)         # warm-up on the side stream
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            solver.step(*ins, mask, out=o, active_in=act)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], nthreads=8)
+    np.testing.assert_array_equal(o["status"].cpu().numpy(), ref["status"])
+    assert relerr(to_host(o["tau"]), ref["tau"]) < TIGHT64
+    assert it0.sum() > 0 and np.all(o["iters"].cpu().numpy() == 0)

@@ -97,10 +97,10 @@ class SolverOptions(C.Structure):
     the environment; Solver(options=None) builds them from the defaults overridden by the WBC_* variables below -- a
     convenience of THIS binding for the A/B scripts under tools/ and bench.py."""
     _fields_ = [("struct_size", C.c_size_t), ("fused_max", C.c_longlong), ("rollout_persistent", C.c_int),
-                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int), ("f32_pack2", C.c_int), ("keep_structural", C.c_int)]
+                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int), ("f32_pack2", C.c_int), ("keep_structural", C.c_int), ("rollout_warm", C.c_int)]
     ENV = {"WBC_FUSED_MAX": ("fused_max", int), "WBC_ROLLOUT_PERSISTENT": ("rollout_persistent", int),
            "WBC_ROLLOUT_SPW": ("rollout_spw", int), "WBC_OBS_SPLIT_MIN": ("obs_split_min", int),
-           "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int), "WBC_QP_LANE": ("qp_lane", int), "WBC_F32_PACK2": ("f32_pack2", int), "WBC_KEEP_STRUCTURAL": ("keep_structural", int),
+           "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int), "WBC_QP_LANE": ("qp_lane", int), "WBC_F32_PACK2": ("f32_pack2", int), "WBC_KEEP_STRUCTURAL": ("keep_structural", int), "WBC_ROLLOUT_WARM": ("rollout_warm", int),
            "WBC_TIMING": ("timing_mode", lambda v: 1 if v == "pair" else 0)}
 
     @staticmethod
@@ -144,12 +144,12 @@ class TickPlan(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "struct_size"}
 
 
-def plan_tick(N, dtype="f64", observer_order=0, options=None, want_mats=True, want_pf=True):
+def plan_tick(N, dtype="f64", observer_order=0, options=None, want_mats=True, want_pf=True, warm=False):
     """wbc_plan_tick: the kernels a tick of N states runs with these options (dict of wbc_tick_plan's fields); needs no device."""
     pl = TickPlan()
     pl.struct_size = C.sizeof(TickPlan)
     o = SolverOptions.make({} if options is None else options)
-    _check(lib().wbc_plan_tick(F64 if dtype == "f64" else F32, int(observer_order), C.byref(o), int(N), int(want_mats), int(want_pf), C.byref(pl)),
+    _check(lib().wbc_plan_tick(F64 if dtype == "f64" else F32, int(observer_order), C.byref(o), int(N), int(want_mats), int(want_pf), int(warm), C.byref(pl)),
            "wbc_plan_tick")
     return pl.as_dict()
 
@@ -223,8 +223,9 @@ def lib():
         L.wbc_reference_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 4
         L.wbc_compute_reference.argtypes = [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 3
         L.wbc_rollout_tracking_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 8
-        L.wbc_plan_tick.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
-        L.wbc_solver_plan_tick.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.wbc_plan_tick.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.wbc_solver_plan_tick.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.wbc_step_batch_warm.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
         L.wbc_dispatch_thresholds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.wbc_solver_invalidate_structural.argtypes = [C.c_void_p]
         L.wbc_qp_dense_batch.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_double] + [C.c_void_p] * 5
@@ -350,8 +351,10 @@ class Solver:
         return out
 
     def step(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None, obs_r=None,
-             out=None, want_mats=False, _prepared=False):
-        """One control tick.  Observer state tensors are updated in place.  Returns dict(tau, f, status, iters[, M, h, Jc, pf])."""
+             out=None, want_mats=False, _prepared=False, active_in=None, warm=False):
+        """One control tick.  Observer state tensors are updated in place.  Returns dict(tau, f, status, iters[, M, h, Jc, pf]).
+        warm=True (or active_in given): wbc_step_batch_warm -- the QPs start from the int32 [N] tensor active_in (None: cold) and the
+        final active sets are returned as out["active"] (pass out={"active": active_in} to update a set in place)."""
         torch = self.torch
         m = self.model
         N = q.shape[1]
@@ -378,17 +381,38 @@ class Solver:
         bo = _BatchOut(g("tau"), g("f"), self._ptr(out["status"], 1, N, torch.int32),
                        self._ptr(out["iters"], 1, N, torch.int32), g("M"), g("h"), g("Jc"), g("pf"))
         ob = _ObsState(self._ptr(obs_integ, m.nv, N), self._ptr(obs_r, m.nv, N))
+        warm = warm or active_in is not None
+        if warm and "active" not in out:
+            out["active"] = torch.zeros(N, dtype=torch.int32, device=self.device)
         if _prepared:   # prepare_step(): hand back the validated argument structs instead of launching
-            return out, (N, bi, bo, ob, (q, v, w_des, vdot_des, normals, mu, mask, tau_prev, f_prev, obs_integ, obs_r))
-        _check(lib().wbc_step_batch(self._h, N, C.byref(bi), C.byref(bo), C.byref(ob), self._stream()), "wbc_step_batch")
+            return out, (N, bi, bo, ob, (q, v, w_des, vdot_des, normals, mu, mask, tau_prev, f_prev, obs_integ, obs_r, active_in), warm)
+        if warm:
+            _check(lib().wbc_step_batch_warm(self._h, N, C.byref(bi), C.byref(bo), C.byref(ob), self._ptr(active_in, 1, N, torch.int32),
+                                             self._ptr(out["active"], 1, N, torch.int32), self._stream()), "wbc_step_batch_warm")
+        else:
+            _check(lib().wbc_step_batch(self._h, N, C.byref(bi), C.byref(bo), C.byref(ob), self._stream()), "wbc_step_batch")
         return out
 
     def prepare_step(self, *args, **kw):
         """Same arguments as step(); validates them and builds the C argument structs ONCE.  Returns (tick, out):
         tick() launches one control tick on the current stream with nothing but the C call in it (a control loop or a
         benchmark that reuses its buffers: ~3 us of host time per tick instead of ~15), out is step()'s dict."""
-        out, (N, bi, bo, ob, keep) = self.step(*args, _prepared=True, **kw)
-        fn, h, rbi, rbo, rob, stream_of = lib().wbc_step_batch, self._h, C.byref(bi), C.byref(bo), C.byref(ob), self._stream
+        out, (N, bi, bo, ob, keep, warm) = self.step(*args, _prepared=True, **kw)
+        h, rbi, rbo, rob, stream_of = self._h, C.byref(bi), C.byref(bo), C.byref(ob), self._stream
+        if warm:   # (a prepared warm tick carries its sets from call to call in out["active"]; the first call starts from active_in, or cold)
+            import torch
+            fnw = lib().wbc_step_batch_warm
+            a_in = keep[-1]
+            p_out = self._ptr(out["active"], 1, N, torch.int32)
+            state = {"first": self._ptr(a_in, 1, N, torch.int32) if a_in is not None else None, "n": 0}
+
+            def tick(_keep=(keep, bi, bo, ob, out)):
+                rc = fnw(h, N, rbi, rbo, rob, state["first"] if state["n"] == 0 else p_out, p_out, stream_of())
+                state["n"] += 1
+                if rc:
+                    _check(rc, "wbc_step_batch_warm")
+            return tick, out
+        fn = lib().wbc_step_batch
 
         def tick(_keep=(keep, bi, bo, ob, out)):   # the tensors and structs stay alive as long as the closure does
             rc = fn(h, N, rbi, rbo, rob, stream_of())
@@ -396,11 +420,11 @@ class Solver:
                 _check(rc, "wbc_step_batch")
         return tick, out
 
-    def plan_tick(self, N, want_mats=True, want_pf=True):
+    def plan_tick(self, N, want_mats=True, want_pf=True, warm=False):
         """wbc_solver_plan_tick: which kernels a tick of N states runs on THIS solver (dict of wbc_tick_plan's fields)."""
         pl = TickPlan()
         pl.struct_size = C.sizeof(TickPlan)
-        _check(lib().wbc_solver_plan_tick(self._h, int(N), int(want_mats), int(want_pf), C.byref(pl)), "wbc_solver_plan_tick")
+        _check(lib().wbc_solver_plan_tick(self._h, int(N), int(want_mats), int(want_pf), int(warm), C.byref(pl)), "wbc_solver_plan_tick")
         return pl.as_dict()
 
     def invalidate_structural(self):

@@ -78,6 +78,8 @@ template <class T> struct QpArgs {
   const T* Jc;   // non-null: foot lever arms and own-leg Jacobian blocks come from the Jacobian the sweep wrote, not from ws
   const T* wdes; // non-null: the target wrench b is read from the caller's w_des (the front half forwarded nothing to WS_B)
   T* tau; T* f; int* status; int* iters;
+  const int* aset_in;  // warm-start kernels: the active set each state's iteration starts from (null: cold); encoding: include/wbc_hip.h
+  int* aset_out;       // non-null: receives the active set at the solution (structured QP kernels)
 };
 
 struct QpJidx { int j[12]; };  // caller's joint index of leg-major joint 3l+k

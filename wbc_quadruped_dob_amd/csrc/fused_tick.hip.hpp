@@ -66,7 +66,8 @@ constexpr int FUSED_OBS_WAVES = 2;
 // (fp64 only: the fp32 tick fits two six-wavefront workgroups on a CU -- 147 VGPRs, 49 kB LDS -- and a seventh wavefront would end that)
 template <class T, bool OBSERVER, bool MATS> constexpr bool fused_split_h() { return WBC_FUSED_SPLIT_H && !OBSERVER && MATS && sizeof(T) == 8; }
 template <class T, bool OBSERVER, bool MATS> constexpr int fused_threads() { return OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : (fused_split_h<T, OBSERVER, MATS>() ? 448 : 384); }
-template <class T, bool OBSERVER, bool MATS>
+// WARM: the QP of every state starts from the active set in qa.aset_in (wbc_step_batch_warm: dependent ticks of a closed loop)
+template <class T, bool OBSERVER, bool MATS, bool WARM = false>
 __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
@@ -130,11 +131,11 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused
     if constexpr (MATS) {
       const int* const zs = zidx_s;
       const unsigned tq = threadIdx.x;
-      qp_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy, QpWho{0, false},
-                                         [=] __device__() { if (!a.skip_consts) structural_consts_quarter<T>(model, a, zs, tq); });
+      auto idle = [=] __device__() { if (!a.skip_consts) structural_consts_quarter<T>(model, a, zs, tq); };
+      qp_body<T, true, OBSERVER, 16, false, 4, decltype(idle), false, WARM ? 1 : 0>(prm, qa, jmap, wsl, &sy, QpWho{0, false}, idle);
     } else
 #endif
-    qp_body<T, true, OBSERVER>(prm, qa, jmap, wsl, &sy);
+    qp_body<T, true, OBSERVER, 16, false, 4, QpNoIdle, false, WARM ? 1 : 0>(prm, qa, jmap, wsl, &sy);
   }
 }
 
@@ -159,7 +160,10 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused
 // raises a third flag; the rnea role issues its state loads, then waits for that flag before it reads the references.
 // SPW: states per workgroup (16, or 4 for rollouts of at most 1 024 states: every CU gets a workgroup and a tick waits for
 // the slowest of 4 QPs instead of 16 -- only QP wavefront 0 works then, the producer lanes of the other slots idle along).
-template <class T, bool OBSERVER, bool TRACK, int SPW = 16>
+// WARM: every tick after the first starts its QPs from the previous tick's active set, carried in a register of the QP wavefronts
+// (wbc_solver_options.rollout_warm; the QP body of these instantiations is the block set-up of qp_struct16.hip.hpp for EVERY tick --
+// tick 0 from the empty set, or from qa.aset_in when the caller continues an earlier rollout).
+template <class T, bool OBSERVER, bool TRACK, int SPW = 16, bool WARM = false>
 __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,
                                                                          int horizon, const DevRefParams<T>* __restrict__ G, RefArgs<T> ra) {
@@ -175,6 +179,13 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
   T* const traj0 = ia.tau_traj;
   T* const com0 = ra.com;
+  int aset_carry = 0;   // (QP wavefronts, WARM) the active set of my row's state, from tick to tick
+  if constexpr (WARM) {
+    if (qa.aset_in && wave * 4 < SPW) {
+      const size_t sq = (size_t)blockIdx.x * SPW + ((threadIdx.x & 255) >> 4);
+      aset_carry = (sq < a.N && (int)((threadIdx.x & 255) >> 4) < SPW) ? qa.aset_in[sq] : 0;
+    }
+  }
   for (int t = 0; t < horizon; ++t) {
     // The batch size is laundered through an empty asm once per tick: every per-lane address in the role bodies derives
     // from it, so none of that (tick-invariant) address arithmetic is hoisted out of the horizon loop -- hoisted, it
@@ -262,6 +273,10 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #else
       const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
+      if constexpr (WARM) {
+        qat.aset_out = (t == horizon - 1) ? qa.aset_out : nullptr;   // the set goes out once, behind the last tick
+        if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_carry);
+      } else
       if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
     }
     __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator

@@ -6,10 +6,17 @@ namespace wbc {
 
 template <>
 hipError_t k_fused_tick<Scalar>(const LaunchCtx& L, bool observer, bool mats, const DevModel<Scalar>* model, const DevParams<Scalar>& prm,
-                                const SweepArgs<Scalar>& a, const QpArgs<Scalar>& qa, const QpJidx& jmap) {
+                                const SweepArgs<Scalar>& a, const QpArgs<Scalar>& qa, const QpJidx& jmap, bool warm) {
   using T = Scalar;
   const dim3 grid((unsigned)((a.N + 15) / 16));
   constexpr unsigned obs_threads = 384 + 64 * FUSED_OBS_WAVES;
+  if (warm) {
+    if (observer && mats) WBC_KLAUNCH(L, (fused_tick_kernel<T, true, true, true>), grid, dim3(obs_threads), model, prm, a, qa, jmap);
+    else if (observer) WBC_KLAUNCH(L, (fused_tick_kernel<T, true, false, true>), grid, dim3(obs_threads), model, prm, a, qa, jmap);
+    else if (mats) WBC_KLAUNCH(L, (fused_tick_kernel<T, false, true, true>), grid, dim3((unsigned)fused_threads<T, false, true>()), model, prm, a, qa, jmap);
+    else WBC_KLAUNCH(L, (fused_tick_kernel<T, false, false, true>), grid, dim3(384), model, prm, a, qa, jmap);
+    return hipGetLastError();
+  }
   if (observer && mats) WBC_KLAUNCH(L, (fused_tick_kernel<T, true, true>), grid, dim3(obs_threads), model, prm, a, qa, jmap);
   else if (observer) WBC_KLAUNCH(L, (fused_tick_kernel<T, true, false>), grid, dim3(obs_threads), model, prm, a, qa, jmap);
   else if (mats) WBC_KLAUNCH(L, (fused_tick_kernel<T, false, true>), grid, dim3((unsigned)fused_threads<T, false, true>()), model, prm, a, qa, jmap);

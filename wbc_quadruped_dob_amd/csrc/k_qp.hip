@@ -23,8 +23,15 @@ static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar
 }
 
 template <>
-hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* list) {
+hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* list, bool warm) {
   using T = Scalar;
+  if (warm) {   // dependent ticks: every state starts from its previous active set, so the rows of a wavefront do about equal work -- no dealing by predicted work
+    if (list || tile > 0) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((a.N + 3) / 4));
+    if (rhat) WBC_KLAUNCH(L, (qp_group16_kernel<T, true, true>), grid, dim3(64), prm, a, jmap);
+    else WBC_KLAUNCH(L, (qp_group16_kernel<T, false, true>), grid, dim3(64), prm, a, jmap);
+    return hipGetLastError();
+  }
   if (list) {   // the hand-over list of the per-lane kernel: one wavefront per four listed states, grid-stride
     const dim3 grid((unsigned)((a.N + 31) / 32));
     if (rhat) WBC_KLAUNCH(L, (qp_list_kernel<T, true>), grid, dim3(64), prm, a, jmap, list);

@@ -10,12 +10,13 @@ namespace wbc {
 #endif
 #define WBC_ROLLOUT_ARGS const LaunchCtx& L, bool observer, int spw, const DevModel<Scalar>* model, const DevParams<Scalar>& prm,            \
                          const SweepArgs<Scalar>& a, const QpArgs<Scalar>& qa, const QpJidx& jmap, const IntegrateArgs<Scalar>& ia, int horizon, \
-                         const DevRefParams<Scalar>* G, const RefArgs<Scalar>& ra
+                         const DevRefParams<Scalar>* G, const RefArgs<Scalar>& ra, bool warm
 hipError_t rollout_plain(WBC_ROLLOUT_ARGS);
 hipError_t rollout_track(WBC_ROLLOUT_ARGS);
 
 #define WBC_ROLLOUT(OB_, SPW_) \
-  WBC_KLAUNCH(L, (rollout_kernel<T, OB_, (WBC_ROLLOUT_TRACK != 0), SPW_>), grid, dim3(OB_ ? 512 : 448), model, prm, a, qa, jmap, ia, horizon, G, ra)
+  do { if (warm) WBC_KLAUNCH(L, (rollout_kernel<T, OB_, (WBC_ROLLOUT_TRACK != 0), SPW_, true>), grid, dim3(OB_ ? 512 : 448), model, prm, a, qa, jmap, ia, horizon, G, ra); \
+       else WBC_KLAUNCH(L, (rollout_kernel<T, OB_, (WBC_ROLLOUT_TRACK != 0), SPW_, false>), grid, dim3(OB_ ? 512 : 448), model, prm, a, qa, jmap, ia, horizon, G, ra); } while (0)
 
 #if WBC_ROLLOUT_TRACK
 hipError_t rollout_track(WBC_ROLLOUT_ARGS) {
@@ -33,9 +34,9 @@ hipError_t rollout_plain(WBC_ROLLOUT_ARGS) {
 template <>
 hipError_t k_rollout<Scalar>(const LaunchCtx& L, bool observer, bool track, int spw, const DevModel<Scalar>* model, const DevParams<Scalar>& prm,
                              const SweepArgs<Scalar>& a, const QpArgs<Scalar>& qa, const QpJidx& jmap, const IntegrateArgs<Scalar>& ia, int horizon,
-                             const DevRefParams<Scalar>* G, const RefArgs<Scalar>& ra) {
-  return track ? rollout_track(L, observer, spw, model, prm, a, qa, jmap, ia, horizon, G, ra)
-               : rollout_plain(L, observer, spw, model, prm, a, qa, jmap, ia, horizon, G, ra);
+                             const DevRefParams<Scalar>* G, const RefArgs<Scalar>& ra, bool warm) {
+  return track ? rollout_track(L, observer, spw, model, prm, a, qa, jmap, ia, horizon, G, ra, warm)
+               : rollout_plain(L, observer, spw, model, prm, a, qa, jmap, ia, horizon, G, ra, warm);
 }
 #endif
 

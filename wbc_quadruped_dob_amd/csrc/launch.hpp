@@ -41,19 +41,20 @@ template <class T> hipError_t k_observer(const LaunchCtx& L, const DevModel<T>* 
 // tile = 64 | 128 | 256 | 512: qp_tile_kernel, workgroups of four wavefronts deal a tile of that many states by predicted work
 // list (optional): solve the states list[4 .. 4 + list[0]) instead of the whole batch (qp_list_kernel; the count is reset by the
 // NEXT tick's front-half kernel, SweepArgs::qp_todo -- not here)
+// warm (tile = 0, no list): qp_group16_kernel<.., WARM>, every state starts from its active set in a.aset_in
 template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, int tile, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap,
-                                  int* list = nullptr);
+                                  int* list = nullptr, bool warm = false);
 // qp_lane_kernel<T, RHAT>: the GRF QP one state per LANE (semismooth Newton on the 6-dimensional residual wrench); states it
 // does not finish are appended to todo (todo[0] = count, todo[4 ...] = indices) for k_qp(..., list = todo); the count must be
 // zero when this kernel starts: the front-half kernel of the tick empties it (SweepArgs::qp_todo)
 template <class T> hipError_t k_qp_lane(const LaunchCtx& L, bool rhat, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int* todo);
 // fused_tick_kernel<T, OBSERVER, MATS>: the whole tick of a small batch as one launch
 template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bool mats, const DevModel<T>* model, const DevParams<T>& prm,
-                                          const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);
+                                          const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap, bool warm = false);
 // rollout_kernel<T, OBSERVER, TRACK, SPW>: `horizon` dependent ticks incl. forward dynamics (and the planner) as one launch
 template <class T> hipError_t k_rollout(const LaunchCtx& L, bool observer, bool track, int spw, const DevModel<T>* model, const DevParams<T>& prm,
                                        const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap, const IntegrateArgs<T>& ia, int horizon,
-                                       const DevRefParams<T>* G, const RefArgs<T>& ra);
+                                       const DevRefParams<T>* G, const RefArgs<T>& ra, bool warm = false);
 // qp_general_kernel<T>: dense QPs of run-time size (n <= 36 variables, m <= 64 rows, the first meq of them equalities), one per wavefront
 template <class T> hipError_t k_qp_general(const LaunchCtx& L, const QpGeneralArgs<T>& a);
 // one thread: *ptr = value, system scope (the completion ticket of the flag-polled single-robot tick)

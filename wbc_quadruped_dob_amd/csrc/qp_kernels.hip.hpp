@@ -7,9 +7,10 @@
 namespace wbc {
 
 // RHAT: rhat comes from the separate observer kernel through the HBM workspace (large observer-on batches)
-template <class T, bool RHAT = false>
+// WARM: every state's iteration starts from the active set in a.aset_in (wbc_step_batch_warm: dependent ticks)
+template <class T, bool RHAT = false, bool WARM = false>
 __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
-  qp_body<T, false, RHAT>(prm, a, jmap, nullptr);
+  qp_body<T, false, RHAT, 16, false, 1, QpNoIdle, false, WARM ? 1 : 0>(prm, a, jmap, nullptr);
 }
 
 // ======================================================================================================================

@@ -44,11 +44,24 @@ template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 16]; T D[4][4 * 3]
 // PRE (tiles only): G^-1 and the unconstrained minimum x0 of this state were computed by the tile's predictor, one state per lane, and wait
 // in LDS (who.pre: 36 + 12 doubles) -- the factorisation, the unit solves and the x0 solve below (~350 of the ~750 set-up instructions a
 // wavefront spends per four states) are skipped.
-template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false>
+// WARM (dependent ticks: rollouts, closed loops): the iteration starts from a GIVEN active set instead of from the unconstrained minimum.
+//   1: the set of each state comes from a.aset_in (null: cold), 2: from *carry, a register the caller keeps across the ticks of a
+//   persistent rollout; the final set always goes back to *carry (2) and to a.aset_out (when given, every instantiation).
+// Encoding (include/wbc_hip.h): bit l16 = constraint A of lane l16 (lane 4k + j: mu~ n - t1, mu~ n - t2, n, -n of foot k), bit 16 + l16 =
+// constraint B of lane l16 (j < 2: mu~ n + t1, mu~ n + t2) -- what the per-lane flags actA / actB are, read off two ballots.
+// The block set-up (derivation and numpy restatement: tools/structured_gi.py, warm_setup): per foot the <= 3 given normals give P_k and
+// N_k^+ in closed form (cross products, ONE reciprocal); every lane assembles G_A = alpha I + sum_k B_k P_k B_k^T (21 entries) from the
+// four P_k in LDS, factors it (general 6 x 6 Cholesky) and solves for its row of G_A^-1; the minimiser ON the set and its multipliers are
+//     f_k = f_k^p - P_k B_k^T y,   f_k^p = N_k^+T rhs_k,   G_A y = sum_k B_k f_k^p - S^(1/2) b,   u_k = alpha N_k^+ (f_k + B_k^T y).
+// A set with more than three rows on a foot, dependent rows or a negative multiplier is no S-pair of the dual method: that row of the
+// wavefront repeats the set-up with the empty set (= the cold start; the loop below runs at most twice).  The QP is strictly convex, so
+// the start changes the iteration count, never the solution.
+template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0>
 WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, const QpJidx& jmap, const TS* wsl, const QpSync* sync = nullptr,
-                              const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
+                              const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
   using T = double;
   static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
+  static_assert(!(WARM != 0 && (PRE || TILED)), "warm starts run in the one-wavefront and fused kernels");
   __shared__ S16Lds<T> lds_all[WPB];
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
@@ -87,6 +100,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   const bool geom_jc = !WSLDS && a.Jc != nullptr;
   const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
   const T mu_f = GLD(a.mu, f);
+  int aset = 0;
+  if constexpr (WARM == 1) { if (a.aset_in) aset = a.aset_in[s32]; }
+  if constexpr (WARM == 2) aset = *carry;
   WBC_QSTAMP(1);
   idle();
   if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
@@ -109,7 +125,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   if constexpr (WSLDS) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(ralpha));
   const int gi = l16 < 6 ? l16 : (l16 < 12 ? l16 - 6 : l16 - 12);
   T Gr[6];
-  if constexpr (PRE) {
+  if constexpr (WARM != 0) {
+    sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = 0; });   // (set by the block set-up below)
+  } else if constexpr (PRE) {
     sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = who.pre[6 * gi + j]; });
   } else {
   T a01, a02, a10, a12, a20, a21, b10, b20, b21;
@@ -203,6 +221,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   T Pr0 = c3 == 0 ? (T)1 : (T)0, Pr1 = c3 == 1 ? (T)1 : (T)0, Pr2 = c3 == 2 ? (T)1 : (T)0;
   T Np0 = 0, Np1 = 0, Np2 = 0, u_s = 0;
   int id_s = -1, qk = 0;
+  T* const prow = Pl + 16 * f + 4 * c3;   // my row of foot f's P in the LDS table (the spare lane owns a dummy row: no predicate on the write)
   {
     T* c = Cl + 3 * (2 * l16);
     c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
@@ -215,6 +234,166 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   }
   // ------------------------------------------------------------------ unconstrained minimum x0 = B^T G^-1 S^(1/2) b   (b = w_des - rhat_base)
   T x_me = 0;
+  bool actA = false, actB = false;
+  if constexpr (WARM != 0) {
+    // -------------------------------------------------------------- block set-up from the given active set (see the comment above the template)
+    {   // swing feet hold no rows; bits that name no constraint are dropped
+      int ok_bits = 0;
+      sfor<0, 4>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; ok_bits |= ((mask >> k) & 1) ? ((0xF << (4 * k)) | (0x3 << (16 + 4 * k))) : 0; });
+      aset &= ok_bits;
+    }
+    const T ec0 = c3 == 0 ? (T)1 : (T)0, ec1 = c3 == 1 ? (T)1 : (T)0, ec2 = c3 == 2 ? (T)1 : (T)0;
+    T bb[6] = {0, 0, 0, 0, 0, 0};
+    bool have_b = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      // (a) the slots of my foot: candidates in the order A0 A1 A2 A3 B0 B1
+      const int a4 = (aset >> (4 * f)) & 0xF, b2 = (aset >> (16 + 4 * f)) & 0x3;
+      int m6 = a4 | (b2 << 4);
+      int q = __builtin_popcount((unsigned)m6);
+      bool bad = q > 3 || (a4 & 0xC) == 0xC;          // more than three rows, or both bounds of the normal force
+      m6 = bad ? 0 : m6;
+      q = bad ? 0 : q;
+      const int m6b = m6 & (m6 - 1), m6c = m6b & (m6b - 1);
+      const int p0 = m6 ? __builtin_ctz((unsigned)m6) : 0, p1 = m6b ? __builtin_ctz((unsigned)m6b) : 0, p2 = m6c ? __builtin_ctz((unsigned)m6c) : 0;
+      const int i0 = p0 < 4 ? 2 * (4 * f + p0) : 2 * (4 * f + p0 - 4) + 1;
+      const int i1 = p1 < 4 ? 2 * (4 * f + p1) : 2 * (4 * f + p1 - 4) + 1;
+      const int i2 = p2 < 4 ? 2 * (4 * f + p2) : 2 * (4 * f + p2 - 4) + 1;
+      const T n00 = Cl[3 * i0], n01 = Cl[3 * i0 + 1], n02 = Cl[3 * i0 + 2];
+      const T n10 = Cl[3 * i1], n11 = Cl[3 * i1 + 1], n12 = Cl[3 * i1 + 2];
+      const T n20 = Cl[3 * i2], n21 = Cl[3 * i2 + 1], n22 = Cl[3 * i2 + 2];
+      // (b) P_k and N_k^+ in closed form
+      const T nn0 = n00 * n00 + n01 * n01 + n02 * n02;
+      const T wx = n01 * n12 - n02 * n11, wy = n02 * n10 - n00 * n12, wz = n00 * n11 - n01 * n10;   // n0 x n1
+      const T ww = wx * wx + wy * wy + wz * wz;
+      const T cx = n11 * n22 - n12 * n21, cy = n12 * n20 - n10 * n22, cz = n10 * n21 - n11 * n20;   // n1 x n2
+      const T det = n00 * cx + n01 * cy + n02 * cz;
+      bad = bad || (q == 2 && !(ww > (T)1e-12)) || (q == 3 && !(det * det > (T)1e-12));
+      const T inv = rcp_nr(q == 1 ? nn0 : (q == 2 ? ww : (q == 3 ? det : (T)1)));
+      const T n0c = c3 == 0 ? n00 : (c3 == 1 ? n01 : n02), wc = c3 == 0 ? wx : (c3 == 1 ? wy : wz);
+      const T g1 = n0c * inv, g2 = wc * inv;
+      Pr0 = q == 0 ? ec0 : (q == 1 ? ec0 - g1 * n00 : (q == 2 ? g2 * wx : (T)0));
+      Pr1 = q == 0 ? ec1 : (q == 1 ? ec1 - g1 * n01 : (q == 2 ? g2 * wy : (T)0));
+      Pr2 = q == 0 ? ec2 : (q == 1 ? ec2 - g1 * n02 : (q == 2 ? g2 * wz : (T)0));
+      {
+        // slot 0: n0 | n1 x w | n1 x n2;   slot 1: w x n0 | n2 x n0;   slot 2: w      (q = 1 | 2 | 3), all times inv
+        const T ax = n11 * wz - n12 * wy, ay = n12 * wx - n10 * wz, az = n10 * wy - n11 * wx;       // n1 x w
+        const T bx = wy * n02 - wz * n01, by_ = wz * n00 - wx * n02, bz = wx * n01 - wy * n00;      // w x n0
+        const T ex = n21 * n02 - n22 * n01, ey = n22 * n00 - n20 * n02, ez = n20 * n01 - n21 * n00; // n2 x n0
+        const T r0x = q == 1 ? n00 : (q == 2 ? ax : cx), r0y = q == 1 ? n01 : (q == 2 ? ay : cy), r0z = q == 1 ? n02 : (q == 2 ? az : cz);
+        const T r1x = q == 2 ? bx : ex, r1y = q == 2 ? by_ : ey, r1z = q == 2 ? bz : ez;
+        const T k_ = (isvar && c3 < q) ? inv : (T)0;
+        Np0 = k_ * (c3 == 0 ? r0x : (c3 == 1 ? r1x : wx));
+        Np1 = k_ * (c3 == 0 ? r0y : (c3 == 1 ? r1y : wy));
+        Np2 = k_ * (c3 == 0 ? r0z : (c3 == 1 ? r1z : wz));
+      }
+      qk = q;
+      const bool slot_on = isvar && c3 < q;
+      const int p_me = c3 == 0 ? p0 : (c3 == 1 ? p1 : p2);
+      id_s = slot_on ? (c3 == 0 ? i0 : (c3 == 1 ? i1 : i2)) : -1;
+      const T rs = slot_on ? (p_me == 2 ? (T)prm.fn_min : (p_me == 3 ? -(T)prm.fn_max : (T)0)) : (T)0;
+      // (c) the four P_k through LDS
+      prow[0] = Pr0; prow[1] = Pr1; prow[2] = Pr2;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      // (d) G_A = alpha I + S^(1/2) [sum P, sum X^T; sum X, sum Y] S^(1/2),  X = [d]x P,  Y = [d]x P [d]x^T   (lower triangle, 21 entries)
+      T Gm[6][6];
+      {
+        T Sp[6] = {0, 0, 0, 0, 0, 0}, Sx[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Sy[6] = {0, 0, 0, 0, 0, 0};
+#pragma clang loop unroll(disable)
+        for (int k = 0; k < 4; ++k) {   // (rolled: one foot's P and lever arm live at a time)
+          const T of = ((mask >> k) & 1) ? (T)1 : (T)0;
+          const T* pk = Pl + 16 * k;
+          const T pxx = of * pk[0], pxy = of * pk[1], pxz = of * pk[2], pyy = of * pk[5], pyz = of * pk[6], pzz = of * pk[10];
+          const T dx = Dl[3 * k], dy = Dl[3 * k + 1], dz = Dl[3 * k + 2];
+          const T x00 = dy * pxz - dz * pxy, x01 = dy * pyz - dz * pyy, x02 = dy * pzz - dz * pyz;
+          const T x10 = dz * pxx - dx * pxz, x11 = dz * pxy - dx * pyz, x12 = dz * pxz - dx * pzz;
+          const T x20 = dx * pxy - dy * pxx, x21 = dx * pyy - dy * pxy, x22 = dx * pyz - dy * pxz;
+          Sp[0] += pxx; Sp[1] += pxy; Sp[2] += pxz; Sp[3] += pyy; Sp[4] += pyz; Sp[5] += pzz;
+          Sx[0] += x00; Sx[1] += x01; Sx[2] += x02; Sx[3] += x10; Sx[4] += x11; Sx[5] += x12; Sx[6] += x20; Sx[7] += x21; Sx[8] += x22;
+          Sy[0] += dy * x02 - dz * x01; Sy[1] += dz * x00 - dx * x02; Sy[2] += dx * x01 - dy * x00;      // Y row 0 = d x X_0
+          Sy[3] += dz * x10 - dx * x12; Sy[4] += dx * x11 - dy * x10; Sy[5] += dx * x21 - dy * x20;      // Y11, Y12, Y22
+        }
+        Gm[0][0] = alpha_l + (s0 * s0) * Sp[0]; Gm[1][0] = (s1 * s0) * Sp[1]; Gm[1][1] = alpha_l + (s1 * s1) * Sp[3];
+        Gm[2][0] = (s2 * s0) * Sp[2]; Gm[2][1] = (s2 * s1) * Sp[4]; Gm[2][2] = alpha_l + (s2 * s2) * Sp[5];
+        Gm[3][0] = (s3 * s0) * Sx[0]; Gm[3][1] = (s3 * s1) * Sx[1]; Gm[3][2] = (s3 * s2) * Sx[2];
+        Gm[4][0] = (s4 * s0) * Sx[3]; Gm[4][1] = (s4 * s1) * Sx[4]; Gm[4][2] = (s4 * s2) * Sx[5];
+        Gm[5][0] = (s5 * s0) * Sx[6]; Gm[5][1] = (s5 * s1) * Sx[7]; Gm[5][2] = (s5 * s2) * Sx[8];
+        Gm[3][3] = alpha_l + (s3 * s3) * Sy[0]; Gm[4][3] = (s4 * s3) * Sy[1]; Gm[5][3] = (s5 * s3) * Sy[2];
+        Gm[4][4] = alpha_l + (s4 * s4) * Sy[3]; Gm[5][4] = (s5 * s4) * Sy[4]; Gm[5][5] = alpha_l + (s5 * s5) * Sy[5];
+      }
+      // (e) G_A = L L^T (in place, il = 1 / diagonal)  (f) my row gi of G_A^-1: L w = e_gi, L^T g = w
+      {
+        T il[6];
+        sfor<0, 6>([&](auto jc) __attribute__((always_inline)) {
+          constexpr int j = decltype(jc)::value;
+          T dj = Gm[j][j];
+          sfor<0, j>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; dj -= Gm[j][k] * Gm[j][k]; });
+          il[j] = rsqrt_nr(dj);
+          sfor<j + 1, 6>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            T sij = Gm[i][j];
+            sfor<0, j>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; sij -= Gm[i][k] * Gm[j][k]; });
+            Gm[i][j] = sij * il[j];
+          });
+        });
+        T w[6];
+        sfor<0, 6>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          T si = gi == i ? (T)1 : (T)0;
+          sfor<0, i>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; si -= Gm[i][k] * w[k]; });
+          w[i] = si * il[i];
+        });
+        sfor_down<0, 6>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          T si = w[i];
+          sfor<i + 1, 6>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; si -= Gm[k][i] * Gr[k]; });
+          Gr[i] = si * il[i];
+        });
+      }
+      // (g) the target wrench (first pass only: the producers may still be at it), f_k^p and the right-hand side
+      if (!have_b) {
+        have_b = true;
+        WBC_QSTAMP(3);
+        if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
+        if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
+        WBC_QSTAMP(4);
+        const T b_ld = (l16 < 6) ? BLD(l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
+        bb[0] = s0 * dppx<0x150 + 0>(b_ld); bb[1] = s1 * dppx<0x150 + 1>(b_ld); bb[2] = s2 * dppx<0x150 + 2>(b_ld);
+        bb[3] = s3 * dppx<0x150 + 3>(b_ld); bb[4] = s4 * dppx<0x150 + 4>(b_ld); bb[5] = s5 * dppx<0x150 + 5>(b_ld);
+      }
+      const T cp0 = Np0 * rs, cp1 = Np1 * rs, cp2 = Np2 * rs;
+      const T fp0 = (dppx<0x00>(cp0) + dppx<0x55>(cp0)) + dppx<0xAA>(cp0), fp1 = (dppx<0x00>(cp1) + dppx<0x55>(cp1)) + dppx<0xAA>(cp1),
+              fp2 = (dppx<0x00>(cp2) + dppx<0x55>(cp2)) + dppx<0xAA>(cp2);
+      T rr[6];
+      {   // sum over the four feet of B_k f_k^p: my foot's share, then the quads added up (row_ror 4, 8); nothing to add when no box row is active
+        T t6[6] = {onf * (s0 * fp0), onf * (s1 * fp1), onf * (s2 * fp2), s3 * (dqy * fp2 - dqz * fp1), s4 * (dqz * fp0 - dqx * fp2), s5 * (dqx * fp1 - dqy * fp0)};
+        sfor<0, 6>([&](auto jc) __attribute__((always_inline)) {
+          constexpr int j = decltype(jc)::value;
+          T t = t6[j];
+          t += dppx<0x124>(t);
+          t += dppx<0x128>(t);
+          rr[j] = t - bb[j];
+        });
+      }
+      // (h) y = G_A^-1 rr,  f_k = f_k^p - P_k B_k^T y   (i) u = alpha N^+ (f_k + B_k^T y)
+      T yi;
+      ginv_mul(rr, yi);
+      T w0, w1, w2;
+      bt_y(w0, w1, w2);
+      x_me = (c3 == 0 ? fp0 : (c3 == 1 ? fp1 : fp2)) - (Pr0 * w0 + Pr1 * w1 + Pr2 * w2);
+      x_me = isvar ? x_me : (T)0;
+      const T fx = dppx<0x00>(x_me), fy = dppx<0x55>(x_me), fz = dppx<0xAA>(x_me);
+      u_s = slot_on ? alpha_l * (Np0 * (fx + w0) + Np1 * (fy + w1) + Np2 * (fz + w2)) : (T)0;
+      // (j) an S-pair?  otherwise this row starts over from the empty set
+      const unsigned long long fb = __ballot(bad || (slot_on && !(u_s >= 0)));
+      const bool row_fail = (unsigned)((fb >> rowbase) & 0xFFFFull) != 0u;
+      aset = row_fail ? 0 : aset;
+      if (fb == 0ull) break;
+    }
+    actA = ((aset >> l16) & 1) != 0;
+    actB = hasB && ((aset >> (16 + l16)) & 1) != 0;
+  } else
   {
     WBC_QSTAMP(3);
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
@@ -244,7 +423,6 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   // (almost always) -- and per-row decisions are committed by selects at the end.
   int ip = -1, status = 0, iter = 0;
   bool done = !live;
-  bool actA = false, actB = false;
   T sip = 0, Rn2 = 1, u_c = 0;   // Rn2 = max(1, largest z . n+ of an added constraint) = Rnorm^2 of the dense method (its new R diagonal is |d2|)
   const T ntol = -prm.qp_tol;
 
@@ -280,8 +458,6 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
       Np0 = r0x * k0 + r1x * k1; Np1 = r0y * k0 + r1y * k1; Np2 = r0z * k0 + r1z * k1;
     }
   };
-  T* const prow = Pl + 16 * f + 4 * c3;   // my row of foot f's P in the LDS table (the spare lane owns a dummy row: no predicate on the write)
-
 #ifdef WBC_QP_STAMP
   const long long st_t1 = __builtin_readcyclecounter();
   long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -292,7 +468,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #endif
   {  // first candidate, at x0
     T val; int id;
-    const bool found = most_violated(dppx<0x00>(x_me), dppx<0x55>(x_me), dppx<0xAA>(x_me), false, false, val, id);
+    const bool found = most_violated(dppx<0x00>(x_me), dppx<0x55>(x_me), dppx<0xAA>(x_me), actA, actB, val, id);
     ip = (!done && found) ? id : -1;
     sip = val;
     done = done || !found;
@@ -465,6 +641,12 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   WBC_QSTAMP3(10);
   if constexpr (WSLDS) { if (sync) qp_wait(sync->fin, sync->need_fin); }
   WBC_QSTAMP(6);
+  {   // the active set at the solution: the per-lane flags, read off two ballots (row-uniform)
+    const unsigned long long ba = __ballot(actA), bbm = __ballot(actB);
+    const int aset_fin = (int)(((unsigned)(ba >> rowbase) & 0xFFFFu) | (((unsigned)(bbm >> rowbase) & 0xFFFFu) << 16));
+    if constexpr (WARM == 2) *carry = aset_fin;
+    if (a.aset_out && live && l16 == 0) a.aset_out[s32] = aset_fin;
+  }
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;
     int jm = 0;
@@ -513,10 +695,11 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #ifndef WBC_QP_STRUCT
 #define WBC_QP_STRUCT 2
 #endif
-template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false>
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0>
 WBC_DEV void qp_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
-                     const QpWho who = QpWho{0, false}, Idle idle = Idle()) {
-  if constexpr (WBC_QP_STRUCT != 0 && (WBC_QP_STRUCT > 1 || std::is_same<T, double>::value)) qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle, PRE>(prm, a, jmap, wsl, sync, who, idle);
+                     const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
+  if constexpr (WARM != 0 || (WBC_QP_STRUCT != 0 && (WBC_QP_STRUCT > 1 || std::is_same<T, double>::value)))
+    qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle, PRE, WARM>(prm, a, jmap, wsl, sync, who, idle, carry);
   else qp_group16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
 }
 

@@ -73,6 +73,7 @@ struct wbc_solver {
   void* d_ws = nullptr;     // WS_LDS_WORDS * max_batch * sizeof(T): the 66 step words + 18 words of rhat (separate observer kernel)
   int in_rollout = 0;       // inside the per-tick loop of wbc_rollout_batch, past its first tick
   int* d_todo = nullptr;    // 4 + max_batch ints: states the per-lane QP kernel hands to the dense active-set kernel (count, workgroups done, count of the last tick, pad; indices)
+  int* d_aset = nullptr;    // max_batch ints: the active sets that wbc_rollout_batch's per-tick launches carry from tick to tick (rollout_warm)
   QpJidx jmap;
   Resolved rz{};            // resolved thresholds (resolve_options)
   hipStream_t aux = nullptr;
@@ -294,6 +295,7 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->qp_lane = 0;
   o->f32_pack2 = 0;
   o->keep_structural = 0;
+  o->rollout_warm = 1;
 }
 
 // ------------------------------------------------------------------------------------------ which kernels run a tick
@@ -325,7 +327,7 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
 }
 
 struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block; bool obs_split, lane; };
-static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf) {
+static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf, bool warm = false) {
   TickPlan p{};
   const bool ob = observer_order > 0, f32 = dtype == WBC_F32;
   if ((mats || !pf) && N <= r.fused_max_noobs) {
@@ -342,7 +344,9 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // batch: tiles 531 / 483 at 53 248, 533 / 463 at 57 344, 537 / 503 at 65 536, 554 / 520 at 81 920, 546 / 534 at 98 304, pair 527 / 554 at 114 688.
   // fp32 trot batch: tiles 1 043 / 919 at 98 304, 992 / 909 at 131 072, 934 / 911 at 196 608, pair 907 / 951 at 229 376.
   // Hence the default: fp64 from 106 496 states on, fp32 from 212 992 (history of the threshold: DESIGN.md 4.3a).
-  p.lane = o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.lane_min);
+  // wbc_step_batch_warm (dependent ticks): every state starts from its previous active set, so the rows of a wavefront do about equal
+  // work and most take zero or one iteration -- the one-wavefront kernel with the block set-up, no dealing by predicted work, no per-lane pair
+  p.lane = !warm && (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.lane_min));
   if (!mats) p.front = 1;                                   // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
   else if (ob && N >= r.obs_split_min) { p.front = 2; p.obs_split = true; }   // observer kernel + observer-free sweep
   else p.front = 0;
@@ -364,7 +368,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
   // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
   // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
-  int tile = o.qp_tile;
+  int tile = warm ? -1 : o.qp_tile;
   if (tile == 0) {
     if (f32) {
       if (N >= r.tile_min && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
@@ -404,13 +408,13 @@ static void plan_to_public(const TickPlan& p, wbc_tick_plan* out) {
   out->struct_size = n;
 }
 
-extern "C" int wbc_plan_tick(int dtype, int observer_order, const wbc_solver_options* opt, size_t N, int with_mats, int with_pf,
+extern "C" int wbc_plan_tick(int dtype, int observer_order, const wbc_solver_options* opt, size_t N, int with_mats, int with_pf, int warm,
                              wbc_tick_plan* plan) {
   if (!plan || (dtype != WBC_F64 && dtype != WBC_F32) || observer_order < 0 || observer_order > 2) return fail(WBC_E_INVALID, "bad argument");
   wbc_solver_options o;
   const int rc = options_from_caller(opt, o);
   if (rc) return rc;
-  plan_to_public(plan_tick(dtype, observer_order, o, resolve_options(dtype, o), N, with_mats != 0, with_pf != 0), plan);
+  plan_to_public(plan_tick(dtype, observer_order, o, resolve_options(dtype, o), N, with_mats != 0, with_pf != 0, warm != 0), plan);
   return WBC_OK;
 }
 
@@ -469,6 +473,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (o.f32_pack2 < -1 || o.f32_pack2 > 1) return fail(WBC_E_INVALID, "f32_pack2 must be -1, 0 or 1");
   if (o.keep_structural != 0 && o.keep_structural != 1) return fail(WBC_E_INVALID, "keep_structural must be 0 or 1");
   if (o.one_zerocopy < 0 || o.one_zerocopy > 3) return fail(WBC_E_INVALID, "one_zerocopy must be 0 ... 3");
+  if (o.rollout_warm != 0 && o.rollout_warm != 1) return fail(WBC_E_INVALID, "rollout_warm must be 0 or 1");
   int leg_body[4][3];
   std::string err;
   rc = quadruped_topology(m->fm, leg_body, err);
@@ -504,6 +509,8 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (e == hipSuccess) e = hipMalloc(&s->d_ws, (size_t)WS_LDS_WORDS * max_batch * ts);
   if (e == hipSuccess) e = hipMalloc((void**)&s->d_todo, (max_batch + 4) * sizeof(int));
   if (e == hipSuccess) e = hipMemset(s->d_todo, 0, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_aset, max_batch * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(s->d_aset, 0, max_batch * sizeof(int));
   // N = 1 image: q19 v18 w6 a18 n12 mu4 tp12 fp12 integ18 r18 tau12 f12 (scalars; 161 of ONE_TICK_SCALARS), a scratch region for
   // the start-up / planner helpers (wbc_observer_init, wbc_compute_reference: they must not touch what a caller keeps in the
   // image between ticks, wbc_one_map), then the ints mask | status | iters | completion ticket
@@ -536,6 +543,7 @@ extern "C" void wbc_solver_destroy(wbc_solver* s) {
   if (s->d_model) (void)hipFree(s->d_model);
   if (s->d_ws) (void)hipFree(s->d_ws);
   if (s->d_todo) (void)hipFree(s->d_todo);
+  if (s->d_aset) (void)hipFree(s->d_aset);
   if (s->d_one) (void)hipFree(s->d_one);
   if (s->h_one) (void)hipHostFree(s->h_one);
   if (s->d_ref) (void)hipFree(s->d_ref);
@@ -556,9 +564,9 @@ extern "C" int wbc_solver_set_params(wbc_solver* s, const wbc_params* p) {
 
 extern "C" int wbc_solver_device(const wbc_solver* s) { return s ? s->device : -1; }
 
-extern "C" int wbc_solver_plan_tick(const wbc_solver* s, size_t N, int with_mats, int with_pf, wbc_tick_plan* plan) {
+extern "C" int wbc_solver_plan_tick(const wbc_solver* s, size_t N, int with_mats, int with_pf, int warm, wbc_tick_plan* plan) {
   if (!s || !plan) return fail(WBC_E_INVALID, "null argument");
-  plan_to_public(plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, with_mats != 0, with_pf != 0), plan);
+  plan_to_public(plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, with_mats != 0, with_pf != 0, warm != 0), plan);
   return WBC_OK;
 }
 
@@ -710,7 +718,7 @@ extern "C" int wbc_dynamics_batch(wbc_solver* s, size_t N, const void* q, const 
 
 template <class T>
 static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
-                     const wbc_observer_state* obs, hipStream_t st) {
+                     const wbc_observer_state* obs, hipStream_t st, bool warm_api = false, const int* aset_in = nullptr, int* aset_out = nullptr) {
   SweepArgs<T> a;
   std::memset(&a, 0, sizeof(a));
   a.N = N; a.q = (const T*)in->q; a.v = (const T*)in->v;
@@ -726,14 +734,16 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
+  qa.aset_in = aset_in; qa.aset_out = aset_out;
   // two-kernel tick with M/h/Jc outputs: the QP takes its geometry from Jc and the sweep skips those workspace words
   qa.Jc = mats ? (const T*)out->Jc : nullptr;
   qa.wdes = nullptr;
   a.ws_geom = mats ? 0 : 1;
   const DevParams<T> dp = to_dev_params<T>(s->params);
-  const TickPlan pl = plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, mats, out->pf != nullptr);   // (what runs, and why: plan_tick)
+  const TickPlan pl = plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, mats, out->pf != nullptr, warm_api);   // (what runs, and why: plan_tick)
+  const bool warm = warm_api && aset_in != nullptr;   // (no set to start from: the cold kernels, which still report the final set)
   if (pl.fused) {
-    TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap));
+    TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap, warm));
     keep.written();
     return WBC_OK;
   }
@@ -768,7 +778,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, 0, dp, qa, s->jmap, s->d_todo));
     return WBC_OK;
   }
-  TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, pl.tile, dp, qa, s->jmap));
+  TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, pl.tile, dp, qa, s->jmap, nullptr, warm));
   return WBC_OK;
 }
 
@@ -799,6 +809,18 @@ extern "C" int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, c
   ON_DEVICE(s);
   hipStream_t st = (hipStream_t)stream;
   return s->dtype == WBC_F64 ? step_impl<double>(s, N, in, out, obs, st) : step_impl<float>(s, N, in, out, obs, st);
+}
+
+// One tick of a DEPENDENT sequence (a closed loop, a rollout driven by the caller): the GRF QP of every state starts from active_in
+extern "C" int wbc_step_batch_warm(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out,
+                                   const wbc_observer_state* obs, const int* active_in, int* active_out, void* stream) {
+  const int rc0 = check_step_args(s, N, in, out, obs, false);
+  if (rc0) return rc0;
+  if (N == 0) return WBC_OK;
+  ON_DEVICE(s);
+  hipStream_t st = (hipStream_t)stream;
+  return s->dtype == WBC_F64 ? step_impl<double>(s, N, in, out, obs, st, true, active_in, active_out)
+                             : step_impl<float>(s, N, in, out, obs, st, true, active_in, active_out);
 }
 
 template <class T>
@@ -843,6 +865,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   QpArgs<T> qa;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters; qa.Jc = nullptr; qa.wdes = nullptr;
+  qa.aset_in = nullptr; qa.aset_out = nullptr;   // (every tick of the launch but the first starts from the previous tick's set, kept in registers)
   a.ws_geom = 1;
   IntegrateArgs<T> ia;
   ia.N = N; ia.q = (T*)in->q; ia.v = (T*)in->v; ia.M = (const T*)out->M; ia.h = (const T*)out->h; ia.Jc = (const T*)out->Jc;
@@ -856,7 +879,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   ra.w_des = (T*)in->w_des; ra.vdot_des = (T*)in->vdot_des; ra.com = (T*)com_traj;
   LaunchCtx L; L.st = st;
   hipError_t e = k_rollout<T>(L, s->params.observer_order > 0, plan != nullptr, spw, dev_model<T>(s), to_dev_params<T>(s->params), a, qa,
-                              s->jmap, ia, horizon, (const DevRefParams<T>*)s->d_ref, ra);
+                              s->jmap, ia, horizon, (const DevRefParams<T>*)s->d_ref, ra, s->opt.rollout_warm != 0);
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
   return WBC_OK;
 }
@@ -890,7 +913,9 @@ extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc
   s->kept_M = nullptr;   // tick 0 writes M, Jc in full whatever an earlier call left there
   for (int t = 0; t < horizon; ++t) {
     s->in_rollout = t > 0;
-    int rc = wbc_step_batch(s, N, &tick, out, obs, stream);
+    // rollout_warm: tick t > 0 starts its QPs from the active sets tick t - 1 left in d_aset
+    int rc = s->opt.rollout_warm ? wbc_step_batch_warm(s, N, &tick, out, obs, t > 0 ? s->d_aset : nullptr, s->d_aset, stream)
+                                 : wbc_step_batch(s, N, &tick, out, obs, stream);
     s->in_rollout = 0;
     if (rc) return rc;
     void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
@@ -991,7 +1016,8 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
     if (rc) return rc;
     if (t == 0) s->kept_M = nullptr;
     s->in_rollout = t > 0;
-    rc = wbc_step_batch(s, N, &tick, out, obs, stream);
+    rc = s->opt.rollout_warm ? wbc_step_batch_warm(s, N, &tick, out, obs, t > 0 ? s->d_aset : nullptr, s->d_aset, stream)
+                             : wbc_step_batch(s, N, &tick, out, obs, stream);
     s->in_rollout = 0;
     if (rc) return rc;
     void* traj = tau_traj ? (void*)((char*)tau_traj + (size_t)t * nj * N * ts) : nullptr;
