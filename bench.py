@@ -465,7 +465,17 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
                 r5["one_rollout"]()
             torch.cuda.synchronize()
             k5, bl, el = long_blocks_of(r5["one_rollout"], max(3, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 3, 1e-7)))), dist, torch, np)
+            rf5 = rollout_roofline(r5["solver"], r5, torch, np, n5, args.horizon, "f64", reps=10)
+            cpu5 = None
+            if rank == 0:
+                try:   # the timed CPU leg only on a one-rank job (the contract's "rank 0 at N = 1"); the operation count always
+                    cpu5 = (cpu_baseline_rollout(r5["B"], r5["P"], n5, args.horizon, r5["tau_ext_np"]) if (world == 1 and not args.no_cpu)
+                            else {"flops_per_tick": rollout_flops_only(r5, args.horizon)})
+                except Exception as e:
+                    cpu5 = None
             res.setdefault("scale_config5", {})[name] = {
+                "roofline": rollout_measurement_objects(rf5, cpu5, None, n5, args.horizon, "f64", world) if cpu5 else None,
+                "cpu_baseline": cpu5 if (cpu5 and "value" in cpu5) else None,
                 "workload": "configs[4]: horizon=%d x %d rollouts per GPU x %d GPUs, trot masks, observer on, pushes, fp64, rank-local for all ticks"
                             % (args.horizon, n5, world),
                 "value": k5 * args.horizon * n5 * world / el, "unit": "control-steps/s", "ms_per_rollout": el / k5 * 1e3,
@@ -576,7 +586,54 @@ def rollout_setup(args, W, synth, torch, np, model, dtype, n, H, rank, local_ran
         else:
             solver.rollout(H, inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, out, integ,
                            rr, tau_ext)
-    return {"one_rollout": one_rollout, "out": out, "solver": solver, "keep": (inp, q0, v0, mask, tau_ext, integ0, integ, rr, plan)}
+    return {"one_rollout": one_rollout, "out": out, "solver": solver, "B": B, "P": P, "tau_ext_np": text,
+            "keep": (inp, q0, v0, mask, tau_ext, integ0, integ, rr, plan)}
+
+
+# Algorithmic words per state and tick of a rollout: read q 19 + v 18 + w_des 6 + vdot_des 18 + normals 12 + mu 4 + mask 1 +
+# tau_ext 18 + observer state 36 + previous tau, f 24 = 156; written q, v 37 + tau, f 24 + observer state 36 + M, h, Jc without their 162
+# structural words 243 = 340 (tick 0 also writes the structural words: + 162 / horizon)
+ROLLOUT_WORDS_PER_TICK = 156 + 340
+
+
+def rollout_roofline(solver, r5, torch, np, n, H, dtype, reps=20):
+    """HIP start / stop events of the rollout dispatches themselves (wbc_solver_enable_timing: on the launch stream) over `reps` rollouts:
+    average launch duration of the persistent rollout_kernel, or the per-tick kernels' sum for batches beyond one launch."""
+    solver.enable_timing(1)
+    for _ in range(reps):
+        r5["one_rollout"]()
+    torch.cuda.synchronize()
+    tm = solver.collect_timing()
+    solver.enable_timing(0)
+    if tm.get("rollout_launches", 0):
+        return {"kernel": "rollout_kernel", "avg_launch_us": tm["rollout_ms"] * 1e3 / tm["rollout_launches"], "launches_timed": tm["rollout_launches"],
+                "ticks_per_launch": H}
+    per_rollout = sum(tm[k + "_ms"] for k in ("dyn", "qp", "rnea", "fused", "qp_lane")) * 1e3 / reps
+    return {"kernel": "per-tick launches (front half, QP; the integrate kernel is not instrumented)", "avg_launch_us": per_rollout,
+            "launches_timed": sum(tm[k + "_launches"] for k in ("dyn", "qp", "rnea", "fused", "qp_lane")), "ticks_per_launch": H}
+
+
+def rollout_measurement_objects(rf, cpu, value, n, H, dtype, world):
+    """`roofline` (whole path against the fp64 vector-FMA peak: the rollout is arithmetic / latency-bound) and the bytes the
+    rollout moves against HBM, from this run's event timing (rf) and the oracle's instrumented operation count (cpu)."""
+    ts = 8 if dtype == "f64" else 4
+    fl = cpu["flops_per_tick"] if cpu else None
+    launch_s = rf["avg_launch_us"] * 1e-6
+    steps_in_launch = n * H
+    tf = fl * steps_in_launch / launch_s / 1e12 if fl else None
+    peak = VALU_F64_PEAK_TFLOPS * (1.0 if dtype == "f64" else 2.0)
+    gbs = ROLLOUT_WORDS_PER_TICK * ts * steps_in_launch / launch_s / 1e9
+    return {"kernel": rf["kernel"], "bound": "valu_f64" if dtype == "f64" else "valu_f32", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+            "frac": (tf / peak) if tf else None, "traffic": None,
+            "flops_per_tick": fl, "avg_launch_us": rf["avg_launch_us"], "us_per_tick": rf["avg_launch_us"] / H, "launches_timed": rf["launches_timed"],
+            "note": "ALGORITHMIC flops = the oracle's instrumented operation count per tick (control step with warm-started QP + forward dynamics + "
+                    "integrator) x rollouts x ticks of one launch / that launch's average duration (HIP start / stop events of the dispatch on the "
+                    "launch stream); peak = fp64 vector FMA, 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz.  The rollout is a chain of dependent ticks "
+                    "on one workgroup per 4 robots: latency-bound, see DESIGN.md 4.6a",
+            "bytes": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                      "algorithmic_words_per_state_and_tick": ROLLOUT_WORDS_PER_TICK,
+                      "note": "the state a rollout actually moves per tick (inputs, q / v / tau / f / observer state written back, M, h, Jc without "
+                              "their structural words) -- far from binding"}}
 
 
 def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
@@ -596,9 +653,22 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
     blocks = timed_blocks(one_rollout, args.steps, dist, torch)
     elapsed = float(np.median(blocks))
     ok = float((out["status"].cpu().numpy() == 0).mean())
+    iters_last = float(out["iters"].double().mean().item())
+    rf = rollout_roofline(r5["solver"], r5, torch, np, n, H, dtype)
     if rank == 0:
+        value = args.steps * H * n * world / elapsed
+        cpu = None
+        if not args.no_cpu and world == 1 and dtype == "f64" and not args.tracking:
+            cpu = cpu_baseline_rollout(r5["B"], r5["P"], n, H, r5["tau_ext_np"])
+        flops_src = cpu
+        if flops_src is None:   # (N > 1, fp32 or the planner in the loop: the operation count alone, no timed CPU leg)
+            try:
+                flops_src = {"flops_per_tick": rollout_flops_only(r5, H)}
+            except Exception:
+                flops_src = None
+        warm_on = os.environ.get("WBC_ROLLOUT_WARM", "1") != "0"
         print_line({
-            "metric": "WBC control-steps/sec (batched DogBot)", "value": args.steps * H * n * world / elapsed,
+            "metric": "WBC control-steps/sec (batched DogBot)", "value": value,
             "unit": "control-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
@@ -606,15 +676,29 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
                                    "one step = one rollout (%d dependent ticks incl. %sforward dynamics + integrator)"
                                    % (H, n, dtype, H, "CoM planner/reference generator + " if args.tracking else ""),
                        "batch_per_gpu": n, "horizon": H, "parallelism": "batch-sharded x%d, rank-local for all ticks" % world,
+                       "qp_warm_start": ("ticks after the first start their QPs from the previous tick's active set (wbc_solver_options.rollout_warm = 1; "
+                                         "results do not depend on it)" if warm_on else "off (rollout_warm = 0): every tick solves from the unconstrained minimum"),
                        "launches": ("one persistent rollout_kernel launch per rollout" if (n <= 4096 and os.environ.get("WBC_ROLLOUT_PERSISTENT", "1") != "0")
                                     else "per tick: %sdyn_sweep/fused tick, qp, integrate" % ("reference, " if args.tracking else ""))},
-            "us_per_tick": elapsed / args.steps / H * 1e6, "qp": {"status_ok_frac_last_tick": ok},
+            "us_per_tick": elapsed / args.steps / H * 1e6, "qp": {"status_ok_frac_last_tick": ok, "iters_mean_last_tick": iters_last},
             "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_min": min(blocks) * 1e3,
                        "block_ms_median": elapsed * 1e3, "block_ms_max": max(blocks) * 1e3},
             "rccl_ranks": world if dist is not None else None,
-            "roofline": None, "cpu_baseline": None})
+            "roofline": rollout_measurement_objects(rf, flops_src, value, n, H, dtype, world), "cpu_baseline": cpu})
     if dist is not None:
         dist.destroy_process_group()
+
+
+def rollout_flops_only(r5, H):
+    import numpy as np
+    import wbc_quadruped_dob_amd as W
+    from oracle import oracle_py, urdf_model
+    orc = oracle_py.Oracle(urdf_model.load_urdf(W.SYNTHETIC_URDF))
+    B, P, te = r5["B"], r5["P"], r5["tau_ext_np"]
+    m = min(B["q"].shape[0], 32)
+    integ0 = orc.dynamics(B["q"][:m], B["v"][:m])["p"]
+    return float(np.mean([orc.op_count_rollout(P, H, B["q"][i], B["v"][i], B["w_des"][i], B["vdot_des"][i], B["normals"][i], B["mu"][i],
+                                               int(B["mask"][i]), te[i], integ0[i], warm=True)["flops_per_tick"] for i in range(m)]))
 
 
 def qp_dense_general(W, torch, dtype):
@@ -890,38 +974,66 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
             "steps_per_s": K * n / el, "ms_per_step": el / K * 1e3}
 
 
+def host_cpu_info():
+    """What the host gives this process: logical CPUs, the affinity mask, the cgroup CPU quota, the OpenMP binding in force."""
+    info = {"nproc": os.cpu_count()}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        info["affinity"] = info["nproc"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            info["cgroup_cpu_quota_source"] = path
+            break
+        except Exception:
+            continue
+    info["cgroup_cpu_quota_cores"] = quota
+    info["usable_cores"] = int(min(info["affinity"], quota)) if quota else info["affinity"]
+    info["OMP_PROC_BIND"] = os.environ.get("OMP_PROC_BIND")
+    info["OMP_PLACES"] = os.environ.get("OMP_PLACES")
+    return info
+
+
+def _thread_counts(usable):
+    return sorted({t for t in (2, 4, 8, 16, 32, 64, 128, usable) if 1 < t <= usable})
+
+
 def cpu_baseline(B, P, dtype, n):
-    """The build's CPU restatement (oracle, kind "port") timed on this box's host cores: bounded sample."""
+    """The build's CPU restatement (oracle, kind "port") timed on this box's host cores: bounded sample.  Every thread count runs
+    `reps` passes over the batch inside ONE OpenMP region (static schedule, per-thread scratch on the thread's stack), so thread
+    start-up and the fork / join of a region per 4 096-state call -- what made round 3's 32 threads 35 % efficient and its 256
+    threads collapse -- are outside the clock; thread counts beyond the cgroup quota / affinity mask are not tried."""
     import numpy as np
     import wbc_quadruped_dob_amd as W
+    os.environ.setdefault("OMP_PROC_BIND", "close")     # (read when the oracle's libgomp loads, below)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")
     from oracle import oracle_py, urdf_model
     orc = oracle_py.Oracle(urdf_model.load_urdf(W.SYNTHETIC_URDF))
     nd = np.float64 if dtype == "f64" else np.float32
     c = lambda a: np.ascontiguousarray(a, dtype=nd)
     args = [c(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")] + [B["mask"], c(B["tau_prev"]), c(B["f_prev"])]
-    try:
-        navail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        navail = os.cpu_count() or 1
+    host = host_cpu_info()
+    usable = max(1, host["usable_cores"])
 
     def run(threads, budget):
-        integ = np.zeros((n, 18), nd)
-        r = np.zeros((n, 18), nd)
-        orc.step(P, *args, integ, r, nthreads=threads)  # warm
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < budget:
-            orc.step(P, *args, integ, r, nthreads=threads)
-            reps += 1
-        return reps * n / (time.perf_counter() - t0), reps
+        sec = orc.step_timed(P, *args, reps=1, nthreads=threads)           # warm: threads exist, pages touched
+        reps = max(2, int(budget / max(sec, 1e-6)))
+        sec = orc.step_timed(P, *args, reps=reps, nthreads=threads)
+        return reps * n / sec, reps
 
-    one, r1 = run(1, 5.0)
+    one, r1 = run(1, 4.0)
     best, bt, br = one, 1, r1
     tried = {1: one}
-    for t in sorted({min(navail, c) for c in (8, 32, 64, navail)}):
-        if t <= 1:
-            continue
-        val, reps = run(t, 4.0)
+    for t in _thread_counts(usable):
+        val, reps = run(t, 2.5)
         tried[t] = val
         if val > best:
             best, bt, br = val, t, reps
@@ -942,10 +1054,65 @@ def cpu_baseline(B, P, dtype, n):
         extras["flops_note"] = ("instrumented count (add+mul+div+sqrt+trig, FMA = 2) of the oracle's scalar type over the first "
                                 "%d states; dense restatement, upper bound for a structure-exploiting kernel" % ns_)
     return {"value": best, "unit": "control-steps/s", "cores": bt, "kind": "port", **extras,
-            "sample": "the same %d-state batch repeated %d times on %d OpenMP thread(s); ~5 s single-thread + ~4 s per "
-                      "thread count tried %s (host reports %d usable cores); g++ -O2 -march=native build of oracle/"
-                      % (n, br, bt, sorted(tried), navail),
-            "single_thread_value": one, "by_threads": {str(k): v for k, v in sorted(tried.items())}}
+            "parallel_efficiency": best / (one * bt),
+            "sample": "the same %d-state batch, %d passes inside one OpenMP region on %d thread(s) (static schedule, per-thread scratch); ~4 s "
+                      "single-thread + ~2.5 s per thread count tried %s; host: %d logical CPUs, %d in the affinity mask, cgroup quota %s cores; "
+                      "OMP_PROC_BIND=%s OMP_PLACES=%s; g++ -O2 -march=native build of oracle/"
+                      % (n, br, bt, sorted(tried), host["nproc"], host["affinity"],
+                         ("%.1f" % host["cgroup_cpu_quota_cores"]) if host["cgroup_cpu_quota_cores"] else "none",
+                         os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
+            "host": host, "single_thread_value": one, "by_threads": {str(k): v for k, v in sorted(tried.items())}}
+
+
+def cpu_baseline_rollout(B, P, n, H, tau_ext):
+    """configs[4] on the host cores: the oracle's rollout() (horizon H dependent ticks incl. forward dynamics + integrator, QPs warm-started
+    from the previous tick like the HIP path's) over the same n rollouts, OpenMP over rollouts; bounded sample, best thread count."""
+    import numpy as np
+    import wbc_quadruped_dob_amd as W
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    from oracle import oracle_py, urdf_model
+    orc = oracle_py.Oracle(urdf_model.load_urdf(W.SYNTHETIC_URDF))
+    host = host_cpu_info()
+    usable = max(1, host["usable_cores"])
+    integ0 = orc.dynamics(B["q"], B["v"], nthreads=min(8, usable))["p"]
+
+    def run(threads, budget):
+        t_used, reps = 0.0, 0
+        while t_used < budget:
+            q, v = B["q"].copy(), B["v"].copy()
+            integ, r = integ0.copy(), np.zeros((n, 18))
+            t0 = time.perf_counter()
+            orc.rollout(P, H, q, v, B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], tau_ext=tau_ext, integ=integ, r=r,
+                        nthreads=threads, warm=True)
+            t_used += time.perf_counter() - t0
+            reps += 1
+        return reps * n * H / t_used, reps
+
+    run(min(8, usable), 0.2)
+    one, _ = run(1, 3.0)
+    best, bt, br = one, 1, 0
+    tried = {1: one}
+    for t in _thread_counts(usable):
+        val, reps = run(t, 2.0)
+        tried[t] = val
+        if val > best:
+            best, bt, br = val, t, reps
+    oc = [orc.op_count_rollout(P, H, B["q"][i], B["v"][i], B["w_des"][i], B["vdot_des"][i], B["normals"][i], B["mu"][i], int(B["mask"][i]),
+                               tau_ext[i], integ0[i], warm=w) for w in (True, False) for i in range(min(n, 64))]
+    k = len(oc) // 2
+    return {"value": best, "unit": "control-steps/s", "cores": bt, "kind": "port", "parallel_efficiency": best / (one * bt),
+            "flops_per_tick": float(np.mean([o["flops_per_tick"] for o in oc[:k]])),
+            "flops_per_tick_cold_qp": float(np.mean([o["flops_per_tick"] for o in oc[k:]])),
+            "qp_iters_per_tick": float(np.mean([o["iters_sum"] for o in oc[:k]])) / H,
+            "qp_iters_per_tick_cold": float(np.mean([o["iters_sum"] for o in oc[k:]])) / H,
+            "sample": "the oracle's rollout() over the same %d rollouts x %d ticks (QPs warm-started from the previous tick's active set), OpenMP over "
+                      "rollouts, %d repetitions on %d thread(s); ~3 s single-thread + ~2 s per thread count tried %s; host: %d logical CPUs, %d in the "
+                      "affinity mask, cgroup quota %s cores" % (n, H, br, bt, sorted(tried), host["nproc"], host["affinity"],
+                                                                ("%.1f" % host["cgroup_cpu_quota_cores"]) if host["cgroup_cpu_quota_cores"] else "none"),
+            "host": host, "single_thread_value": one, "by_threads": {str(k_): v for k_, v in sorted(tried.items())},
+            "flops_note": "instrumented count (add+mul+div+sqrt+trig, FMA = 2) of the oracle's rollout over the first %d rollouts, per tick: control step "
+                          "+ dense 18 x 18 forward dynamics + integrator; dense restatement, upper bound for a structure-exploiting kernel" % k}
 
 
 if __name__ == "__main__":

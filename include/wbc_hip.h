@@ -313,11 +313,11 @@ int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const
  * 4096 event pairs once; samples beyond it are dropped until wbc_solver_collect_timing drains the ring, so a tick never
  * allocates.  While timing is on, the instrumented dispatches are not hipGraph-capturable. ---- */
 int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 every kernel launch; k > 1: every k-th tick */
-#define WBC_TIMING_KINDS 5
+#define WBC_TIMING_KINDS 6   /* ABI 6 (was 5): callers pass arrays of this many entries */
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed
  * 0 = dyn_sweep kernel, 1 = QP kernel, 2 = rnea_step kernel (no-M/h/Jc ticks) / stand-alone observer kernel,
  * 3 = fused tick kernel (sweep + QP of small batches in one launch), 4 = per-lane QP kernel (then 1 = the dense kernel's
- * pass over the states the per-lane kernel handed over); resets the accumulators. */
+ * pass over the states the per-lane kernel handed over), 5 = persistent rollout kernel (one launch = a whole horizon); resets the accumulators. */
 int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KINDS], int launches[WBC_TIMING_KINDS]);
 
 /* ---- multi-device: ONE host process, one solver per GPU of the node.  The reference is a single C++

@@ -131,4 +131,35 @@ int wbco_op_count(int nb, const int* parent, const double* Rt, const double* rt,
   return iters;
 }
 
+// Operation count of a whole ROLLOUT of one state (configs[4]: `horizon` dependent ticks of {control step, forward dynamics,
+// integration}; warm != 0: QPs after the first tick start from the previous tick's active set, as the HIP path's rollouts do).
+// counts[6] = {add, mul, div, sqrt, trig, cmp} summed over the horizon; returns the sum of the QP iteration counts.
+int wbco_op_count_rollout(int nb, const int* parent, const double* Rt, const double* rt, const double* axis, const double* mass,
+                          const double* com, const double* Ic, int nf, const int* foot_body, const double* foot_off,
+                          const double* gravity, const wbco_params_oc* pp, int horizon, int warm, const double* q, const double* v,
+                          const double* w_des, const double* vdot_des, const double* normals, const double* mu, int mask,
+                          const double* tau_ext, const double* obs_integ, long long* counts) {
+  if (nb < 1 || nb > MAXB || nf < 0 || nf > MAXF) return -1;
+  static Model<Cnt> m;
+  model_from_flat(m, nb, parent, Rt, rt, axis, mass, com, Ic, nf, foot_body, foot_off, gravity);
+  Params P;
+  for (int i = 0; i < 6; ++i) P.S[i] = pp->S[i];
+  P.alpha = pp->alpha; P.fn_min = pp->fn_min; P.fn_max = pp->fn_max; P.mu_scale = pp->mu_scale; P.dt = pp->dt;
+  P.observer_order = pp->observer_order; P.max_iter = pp->max_iter; P.qp_tol = pp->qp_tol;
+  for (int i = 0; i < MAXV; ++i) { P.K1[i] = pp->K1[i]; P.K2[i] = pp->K2[i]; }
+  const int nv = m.nv(), nq = nv + 1;
+  Cnt cq[MAXV + 1], cv[MAXV], cw[6], cvd[MAXV], cn[3 * MAXF], cmu[MAXF], cte[MAXV], ctp[MAXV], cfp[3 * MAXF], ci[MAXV], cr[MAXV];
+  for (int i = 0; i < nq; ++i) cq[i] = q[i];
+  for (int i = 0; i < nv; ++i) { cv[i] = v[i]; cvd[i] = vdot_des[i]; cte[i] = tau_ext ? tau_ext[i] : 0.0; ci[i] = obs_integ ? obs_integ[i] : 0.0; cr[i] = 0.0; ctp[i] = 0.0; }
+  for (int i = 0; i < 6; ++i) cw[i] = w_des[i];
+  for (int i = 0; i < 3 * nf; ++i) { cn[i] = normals[i]; cfp[i] = 0.0; }
+  for (int i = 0; i < nf; ++i) cmu[i] = mu[i];
+  int st = 0, its = 0;
+  g_c = Counters{};
+  rollout(m, P, horizon, cq, cv, cw, cvd, cn, cmu, (unsigned)mask, tau_ext ? cte : (const Cnt*)nullptr, ctp, cfp, ci, cr, (Cnt*)nullptr, &st,
+          warm != 0, &its);
+  counts[0] = g_c.add; counts[1] = g_c.mul; counts[2] = g_c.div; counts[3] = g_c.sqrt_; counts[4] = g_c.trig; counts[5] = g_c.cmp;
+  return its;
+}
+
 }  // extern "C"

@@ -278,6 +278,44 @@ def _op_count(self, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, 
 Oracle.op_count = _op_count
 
 
+def _op_count_rollout(self, P, horizon, q, v, w_des, vdot_des, normals, mu, mask, tau_ext=None, integ=None, warm=True):
+    """Instrumented operation count of ONE oracle rollout of ONE state (1-D float64 inputs): dict(flops, flops_per_tick, iters_sum, counts)."""
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    k = self._keep
+    counts = np.zeros(len(OP_KINDS), np.int64)
+    ps = make_params_struct(P)
+    fn = lib().wbco_op_count_rollout
+    fn.restype = C.c_int
+    it = fn(self.nb, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]), _p(k[6]), self.nf, _p(k[7]), _p(k[8]), _p(k[9]), C.byref(ps),
+            int(horizon), int(bool(warm)), _p(c(q)), _p(c(v)), _p(c(w_des)), _p(c(vdot_des)), _p(c(normals)), _p(c(mu)), int(mask), _p(c(tau_ext)),
+            _p(c(integ)), _p(counts))
+    assert it >= 0
+    fl = int(counts[:5].sum())
+    return dict(counts={kd: int(counts[j]) for j, kd in enumerate(OP_KINDS)}, flops=fl, flops_per_tick=fl / horizon, iters_sum=it)
+
+
+Oracle.op_count_rollout = _op_count_rollout
+
+
+def _step_timed(self, P, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, reps=1, nthreads=1):
+    """`reps` passes of step() over the batch inside ONE OpenMP region (observer state zero, per-thread scratch): returns the wall
+    seconds between the region's two barriers -- thread start-up and per-call fork/join are outside."""
+    dt = q.dtype
+    N = q.shape[0]
+    c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+    q, v, w_des, vdot_des, normals, mu, tau_prev, f_prev = map(c, (q, v, w_des, vdot_des, normals, mu, tau_prev, f_prev))
+    mask = np.ascontiguousarray(mask, dtype=np.int32)
+    tau, f, status = np.empty((N, self.nj), dt), np.empty((N, 3 * self.nf), dt), np.empty(N, np.int32)
+    sec = C.c_double(0.0)
+    getattr(lib(), "wbco_step_timed_" + self._suf(dt))(self.h, C.byref(make_params_struct(P)), N, _p(q), _p(v), _p(w_des), _p(vdot_des),
+                                                       _p(normals), _p(mu), _p(mask), _p(tau_prev), _p(f_prev), _p(tau), _p(f), _p(status),
+                                                       int(reps), int(nthreads), C.byref(sec))
+    return sec.value
+
+
+Oracle.step_timed = _step_timed
+
+
 def qp_solve(H, g, Cm, d, max_iter=100, tol=1e-9, warm=None, want_active=False):
     """warm: boolean [m] guess of the active set (see qp_solve_gi); want_active: also return the final active set."""
     dt = H.dtype

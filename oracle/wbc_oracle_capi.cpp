@@ -5,6 +5,7 @@
 #include "wbc_oracle.hpp"
 #include "qp_general.hpp"
 #include <chrono>
+#include <omp.h>
 #include <new>
 
 using namespace wbco;
@@ -113,6 +114,37 @@ void wbco_model_destroy(void* h) { delete (OracleHandle*)h; }
       if (status) status[s] = o.status;                                                                         \
       if (iters) iters[s] = o.iters;                                                                            \
     }                                                                                                           \
+  }                                                                                                             \
+  /* the cpu_baseline leg of bench.py: `reps` passes of wbco_step over the batch inside ONE parallel region (thread start-up and   \
+     the fork/join of a region per 4 096-state call are not what is being measured); static schedule, every thread keeps its       \
+     scratch on its own stack; *seconds = wall time between two barriers of that region */                                        \
+  void wbco_step_timed_##SUF(void* hh, const wbco_params* pp, int N, const T* q, const T* v, const T* w_des,    \
+                             const T* vdot_des, const T* normals, const T* mu, const int* mask, const T* tau_prev, \
+                             const T* f_prev, T* tau, T* f, int* status, int reps, int nthreads, double* seconds) { \
+    const Model<T>& m = ((OracleHandle*)hh)->MODEL;                                                             \
+    const Params P = to_params(pp);                                                                             \
+    const int nv = m.nv(), nq = nv + 1, nj = m.nj(), nf = m.nf;                                                 \
+    double t0 = 0, t1 = 0;                                                                                      \
+    _Pragma("omp parallel num_threads(nthreads)") {                                                             \
+      _Pragma("omp barrier")                                                                                    \
+      _Pragma("omp master") t0 = omp_get_wtime();                                                               \
+      for (int rep = 0; rep < reps; ++rep) {                                                                    \
+        _Pragma("omp for schedule(static) nowait") for (int s = 0; s < N; ++s) {                               \
+          StepOut<T> o;                                                                                         \
+          T zt[MAXV], ig[MAXV], rr[MAXV];                                                                       \
+          for (int i = 0; i < MAXV; ++i) zt[i] = ig[i] = rr[i] = 0;                                             \
+          step(m, P, q + (size_t)s * nq, v + (size_t)s * nv, w_des + (size_t)s * 6, vdot_des + (size_t)s * nv,  \
+               normals + (size_t)s * 3 * nf, mu + (size_t)s * nf, (unsigned)mask[s],                            \
+               tau_prev ? tau_prev + (size_t)s * nj : zt, f_prev ? f_prev + (size_t)s * 3 * nf : zt, ig, rr, o); \
+          for (int e = 0; e < nj; ++e) tau[(size_t)s * nj + e] = o.tau[e];                                      \
+          for (int e = 0; e < 3 * nf; ++e) f[(size_t)s * 3 * nf + e] = o.f[e];                                  \
+          status[s] = o.status;                                                                                 \
+        }                                                                                                       \
+      }                                                                                                         \
+      _Pragma("omp barrier")                                                                                    \
+      _Pragma("omp master") t1 = omp_get_wtime();                                                               \
+    }                                                                                                           \
+    *seconds = t1 - t0;                                                                                         \
   }                                                                                                             \
   /* horizon ticks of {step, forward dynamics with the planned GRFs, integration}; q, v, tau_prev, f_prev, obs in/out */ \
   void wbco_rollout_##SUF(void* hh, const wbco_params* pp, int N, int horizon, T* q, T* v, const T* w_des,              \

@@ -89,3 +89,25 @@ def test_scale_legs_of_the_multi_gpu_line_on_one_rank():
         assert "error" not in c5[k], c5[k]
         assert "configs[4]" in c5[k]["workload"] and abs(c5[k]["value"] - 20 * n / (c5[k]["ms_per_rollout"] * 1e-3)) <= 1e-6 * c5[k]["value"]
         assert 5.0 < c5[k]["us_per_tick"] < 200.0
+        r = c5[k]["roofline"]
+        assert r and r["bound"] == "valu_f64" and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+        assert r["launches_timed"] >= 5 and r["us_per_tick"] <= c5[k]["us_per_tick"] * 1.02 and r["bytes"]["achieved"] > 0
+
+
+def test_config5_line_carries_roofline_and_cpu_baseline():
+    """`bench.py --config 5` (BASELINE.json configs[4]: horizon-20 rollouts of 1 024 robots): both measurement objects, priced on the
+    rollout launch's own start / stop events and the oracle's instrumented operation count; the CPU leg is the oracle's rollout()."""
+    d = one_line([sys.executable, "bench.py", "--config", "5", "--steps", "5", "--warmup", "2"])
+    for k in KEYS:
+        assert k in d, k
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["batch_per_gpu"] == 1024 and d["config"]["horizon"] == 20
+    assert abs(d["value"] - 20 * 1024 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "valu_f64" and r["unit"] == "TFLOP/s" and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches_timed"] >= 10 and r["avg_launch_us"] * 1e-3 <= d["ms_per_step"] * 1.02       # the launch fits inside a step
+    assert abs(r["achieved"] - r["flops_per_tick"] * 20 * 1024 / (r["avg_launch_us"] * 1e-6) / 1e12) <= 1e-6 * r["achieved"]
+    assert r["bytes"]["bound"] == "hbm" and r["bytes"]["achieved"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["flops_per_tick"] > 1e4
+    assert c["qp_iters_per_tick"] < c["qp_iters_per_tick_cold"]
+    assert d["qp"]["status_ok_frac_last_tick"] == 1.0

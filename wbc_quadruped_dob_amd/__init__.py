@@ -574,10 +574,10 @@ class Solver:
         _check(lib().wbc_solver_enable_timing(self._h, int(on)), "wbc_solver_enable_timing")
 
     def collect_timing(self):
-        ms = (C.c_double * 5)()
-        cnt = (C.c_int * 5)()
+        ms = (C.c_double * 6)()
+        cnt = (C.c_int * 6)()
         _check(lib().wbc_solver_collect_timing(self._h, ms, cnt), "wbc_solver_collect_timing")
-        names = ("dyn", "qp", "rnea", "fused", "qp_lane")  # fused = one-kernel tick of small batches; dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
+        names = ("dyn", "qp", "rnea", "fused", "qp_lane", "rollout")  # fused = one-kernel tick of small batches; dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
         out = {}
         for i, n in enumerate(names):
             out[n + "_ms"] = ms[i]

@@ -660,7 +660,7 @@ extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KIN
   return WBC_OK;
 }
 
-// one instrumented launch: kind = index into the timing arrays (0 dyn_sweep, 1 QP (dense active set), 2 rnea_step / observer, 3 fused tick, 4 QP one state per lane)
+// one instrumented launch: kind = index into the timing arrays (0 dyn_sweep, 1 QP (dense active set), 2 rnea_step / observer, 3 fused tick, 4 QP one state per lane, 5 persistent rollout)
 #define TIMED_LAUNCH(kind_, stream_, what_, call_)                                                          \
   do {                                                                                                      \
     SpanScope sc_(s, kind_, stream_);                                                                       \
@@ -877,10 +877,9 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   std::memset(&ra, 0, sizeof(ra));
   ra.N = N; ra.q = (const T*)in->q; ra.v = (const T*)in->v; ra.plan = (const T*)plan; ra.t = (T)0;
   ra.w_des = (T*)in->w_des; ra.vdot_des = (T*)in->vdot_des; ra.com = (T*)com_traj;
-  LaunchCtx L; L.st = st;
-  hipError_t e = k_rollout<T>(L, s->params.observer_order > 0, plan != nullptr, spw, dev_model<T>(s), to_dev_params<T>(s->params), a, qa,
-                              s->jmap, ia, horizon, (const DevRefParams<T>*)s->d_ref, ra, s->opt.rollout_warm != 0);
-  if (e != hipSuccess) return fail(WBC_E_HIP, std::string("rollout launch: ") + hipGetErrorString(e));
+  timing_tick(s);
+  TIMED_LAUNCH(5, st, "rollout", k_rollout<T>(L, s->params.observer_order > 0, plan != nullptr, spw, dev_model<T>(s), to_dev_params<T>(s->params), a, qa,
+                                              s->jmap, ia, horizon, (const DevRefParams<T>*)s->d_ref, ra, s->opt.rollout_warm != 0));
   return WBC_OK;
 }
 
