@@ -179,12 +179,15 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
   T* const traj0 = ia.tau_traj;
   T* const com0 = ra.com;
-  int aset_carry = 0;   // (QP wavefronts, WARM) the active set of my row's state, from tick to tick
+  // (WARM) the active set of each of the workgroup's states, from tick to tick: one LDS word per state, read and written by the state's own
+  // QP row only (a register of the QP wavefronts would be live through every role's code of this 256-register kernel)
+  __shared__ int aset_sh[16];
   if constexpr (WARM) {
-    if (qa.aset_in && wave * 4 < SPW) {
-      const size_t sq = (size_t)blockIdx.x * SPW + ((threadIdx.x & 255) >> 4);
-      aset_carry = (sq < a.N && (int)((threadIdx.x & 255) >> 4) < SPW) ? qa.aset_in[sq] : 0;
+    if (threadIdx.x < 16) {
+      const size_t sq = (size_t)blockIdx.x * SPW + threadIdx.x;
+      aset_sh[threadIdx.x] = (qa.aset_in && sq < a.N && (int)threadIdx.x < SPW) ? qa.aset_in[sq] : 0;
     }
+    __syncthreads();
   }
   for (int t = 0; t < horizon; ++t) {
     // The batch size is laundered through an empty asm once per tick: every per-lane address in the role bodies derives
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #endif
       if constexpr (WARM) {
         qat.aset_out = (t == horizon - 1) ? qa.aset_out : nullptr;   // the set goes out once, behind the last tick
-        if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_carry);
+        if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_sh[(threadIdx.x & 255) >> 4]);
       } else
       if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
     }

@@ -45,8 +45,8 @@ template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 16]; T D[4][4 * 3]
 // in LDS (who.pre: 36 + 12 doubles) -- the factorisation, the unit solves and the x0 solve below (~350 of the ~750 set-up instructions a
 // wavefront spends per four states) are skipped.
 // WARM (dependent ticks: rollouts, closed loops): the iteration starts from a GIVEN active set instead of from the unconstrained minimum.
-//   1: the set of each state comes from a.aset_in (null: cold), 2: from *carry, a register the caller keeps across the ticks of a
-//   persistent rollout; the final set always goes back to *carry (2) and to a.aset_out (when given, every instantiation).
+//   1: the set of each state comes from a.aset_in (null: cold), 2: from *carry, an LDS word per state that the persistent rollout kernel keeps
+//   across its ticks; the final set always goes back to *carry (2) and to a.aset_out (when given, every instantiation).
 // Encoding (include/wbc_hip.h): bit l16 = constraint A of lane l16 (lane 4k + j: mu~ n - t1, mu~ n - t2, n, -n of foot k), bit 16 + l16 =
 // constraint B of lane l16 (j < 2: mu~ n + t1, mu~ n + t2) -- what the per-lane flags actA / actB are, read off two ballots.
 // The block set-up (derivation and numpy restatement: tools/structured_gi.py, warm_setup): per foot the <= 3 given normals give P_k and
@@ -243,9 +243,8 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
       aset &= ok_bits;
     }
     const T ec0 = c3 == 0 ? (T)1 : (T)0, ec1 = c3 == 1 ? (T)1 : (T)0, ec2 = c3 == 2 ? (T)1 : (T)0;
-    T bb[6] = {0, 0, 0, 0, 0, 0};
-    bool have_b = false;
-    for (int pass = 0; pass < 2; ++pass) {
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < 2; ++pass) {   // (rolled: the second pass is the rare cold fall-back, not a second copy of the set-up in the instruction stream)
       // (a) the slots of my foot: candidates in the order A0 A1 A2 A3 B0 B1
       const int a4 = (aset >> (4 * f)) & 0xF, b2 = (aset >> (16 + 4 * f)) & 0x3;
       int m6 = a4 | (b2 << 4);
@@ -351,13 +350,16 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
           Gr[i] = si * il[i];
         });
       }
-      // (g) the target wrench (first pass only: the producers may still be at it), f_k^p and the right-hand side
-      if (!have_b) {
-        have_b = true;
+      // (g) the target wrench (the producers may still be at it: waited for HERE, behind the factorisation, and read again in the rare
+      // second pass rather than kept in twelve registers across the set-up), f_k^p and the right-hand side
+      if (pass == 0) {
         WBC_QSTAMP(3);
         if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
         if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
         WBC_QSTAMP(4);
+      }
+      T bb[6];
+      {
         const T b_ld = (l16 < 6) ? BLD(l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
         bb[0] = s0 * dppx<0x150 + 0>(b_ld); bb[1] = s1 * dppx<0x150 + 1>(b_ld); bb[2] = s2 * dppx<0x150 + 2>(b_ld);
         bb[3] = s3 * dppx<0x150 + 3>(b_ld); bb[4] = s4 * dppx<0x150 + 4>(b_ld); bb[5] = s5 * dppx<0x150 + 5>(b_ld);
@@ -644,7 +646,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   {   // the active set at the solution: the per-lane flags, read off two ballots (row-uniform)
     const unsigned long long ba = __ballot(actA), bbm = __ballot(actB);
     const int aset_fin = (int)(((unsigned)(ba >> rowbase) & 0xFFFFu) | (((unsigned)(bbm >> rowbase) & 0xFFFFu) << 16));
-    if constexpr (WARM == 2) *carry = aset_fin;
+    if constexpr (WARM == 2) { if (l16 == 0) *carry = aset_fin; }   // (LDS: read back by this row in the next tick -- program order of one wavefront)
     if (a.aset_out && live && l16 == 0) a.aset_out[s32] = aset_fin;
   }
   if (live) {

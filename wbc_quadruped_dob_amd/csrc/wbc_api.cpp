@@ -910,10 +910,13 @@ extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc
   const size_t nj = 12;
   ON_DEVICE(s);
   s->kept_M = nullptr;   // tick 0 writes M, Jc in full whatever an earlier call left there
+  // rollout_warm with per-tick launches: only where the tick is the fused launch.  Beyond it the tiles dealt by predicted work (cold) beat
+  // the one-wavefront warm kernel (32 768 rollouts, MI355X: 85.1 vs 88.8 us per tick)
+  const bool warm_ticks = s->opt.rollout_warm && plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, true, out->pf != nullptr, true).fused;
   for (int t = 0; t < horizon; ++t) {
     s->in_rollout = t > 0;
-    // rollout_warm: tick t > 0 starts its QPs from the active sets tick t - 1 left in d_aset
-    int rc = s->opt.rollout_warm ? wbc_step_batch_warm(s, N, &tick, out, obs, t > 0 ? s->d_aset : nullptr, s->d_aset, stream)
+    // tick t > 0 starts its QPs from the active sets tick t - 1 left in d_aset
+    int rc = warm_ticks ? wbc_step_batch_warm(s, N, &tick, out, obs, t > 0 ? s->d_aset : nullptr, s->d_aset, stream)
                                  : wbc_step_batch(s, N, &tick, out, obs, stream);
     s->in_rollout = 0;
     if (rc) return rc;
@@ -1008,6 +1011,7 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const size_t nj = 12;
   ON_DEVICE(s);
+  const bool warm_ticks = s->opt.rollout_warm && plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, true, out->pf != nullptr, true).fused;
   for (int t = 0; t < horizon; ++t) {
     void* com = com_traj ? (void*)((char*)com_traj + (size_t)t * 6 * N * ts) : nullptr;
     int rc = wbc_reference_batch(s, N, in->q, in->v, plan, (double)t * s->params.dt, (void*)in->w_des, (void*)in->vdot_des, com,
@@ -1015,7 +1019,7 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
     if (rc) return rc;
     if (t == 0) s->kept_M = nullptr;
     s->in_rollout = t > 0;
-    rc = s->opt.rollout_warm ? wbc_step_batch_warm(s, N, &tick, out, obs, t > 0 ? s->d_aset : nullptr, s->d_aset, stream)
+    rc = warm_ticks ? wbc_step_batch_warm(s, N, &tick, out, obs, t > 0 ? s->d_aset : nullptr, s->d_aset, stream)
                              : wbc_step_batch(s, N, &tick, out, obs, stream);
     s->in_rollout = 0;
     if (rc) return rc;
