@@ -233,11 +233,25 @@ def main():
     gather_res = None
     if dist is not None and not os.environ.get("WBC_BENCH_NO_GATHER"):
         try:
-            from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather
-            el_g, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, args.steps, torch.cuda.synchronize)
+            from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather, timed_steps_with_overlapped_gather
+            nbytes = 12 * n * (8 if dtype == "f64" else 4)
+            el_s, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, args.steps, torch.cuda.synchronize)
+            # double-buffered tau: a second prepared tick over the same inputs and outputs except for its own tau buffer; the gather of
+            # tick k runs on a side stream beside tick k + 1 (sharding.timed_steps_with_overlapped_gather)
+            out_b = dict(out)
+            out_b["tau"] = torch.empty_like(out["tau"])
+            tick_b, out_b2 = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
+                                                 inp["tau_prev"], inp["f_prev"], integ, rr, out=out_b, want_mats=want_mats)
+
+            def step_b():
+                tick_b()
+                return out_b2
+            el_g, _ = timed_steps_with_overlapped_gather((step, step_b), lambda o: o["tau"], dist, args.steps, torch.cuda.synchronize)
             gather_res = {"value": args.steps * n * world / el_g, "ms_per_step": el_g / args.steps * 1e3,
-                          "collective": "all_gather_into_tensor(tau) after every step, RCCL, %d B per rank per step"
-                                        % (12 * n * (8 if dtype == "f64" else 4))}
+                          "collective": "all_gather_into_tensor(tau) of every step, RCCL, %d B per rank per step; tau double-buffered, the gather of "
+                                        "tick k on a side stream beside tick k + 1" % nbytes,
+                          "serial": {"value": args.steps * n * world / el_s, "ms_per_step": el_s / args.steps * 1e3,
+                                     "collective": "the same gather on the tick's stream, behind every tick (round 3's form)"}}
         except Exception as e:  # never lose the main line to the optional leg
             gather_res = {"error": repr(e)[:200]}
 
@@ -414,7 +428,7 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
     and configs[4] (horizon-20 rollouts, 1 024 per GPU and 1 024 in total = 128 per GPU) measured by the driver's own N > 1
     command: per leg steps/s over all ranks in blocks of >= 5 ms, the same with an all-gather of tau after every tick
     (configs[3]), and the RCCL rank count.  Every rank keeps its slice for all ticks: no data-path collective."""
-    from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather
+    from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather, timed_steps_with_overlapped_gather
     res = {}
     td = torch.float32
     n3 = 32768
@@ -441,16 +455,27 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
             step()
         torch.cuda.synchronize()
         k3, bl, el = long_blocks_of(step, max(20, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 20, 1e-7)))), dist, torch, np)
-        el_g, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, k3, torch.cuda.synchronize)
+        el_s, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, k3, torch.cuda.synchronize)
+        out_b = dict(out)
+        out_b["tau"] = torch.empty_like(out["tau"])
+        tick_b, out_b2 = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
+                                             inp["tau_prev"], inp["f_prev"], integ, rr, out=out_b, want_mats=True)
+
+        def step_b():
+            tick_b()
+            return out_b2
+        el_g, _ = timed_steps_with_overlapped_gather((step, step_b), lambda o: o["tau"], dist, k3, torch.cuda.synchronize)
         ok = float((out["status"] == 0).double().mean().item())
         res["scale_config3"] = {
             "workload": "configs[3]: batch=%d fp32 = %d states per GPU x %d, tilted terrain normals + disturbances, observer on, M/h/Jc written"
                         % (n3 * world, n3, world),
             "value": k3 * n3 * world / el, "unit": "control-steps/s", "ms_per_step": el / k3 * 1e3, "steps_per_block": k3, "blocks": len(bl),
             "with_tau_allgather": {"value": k3 * n3 * world / el_g, "ms_per_step": el_g / k3 * 1e3,
-                                   "collective": "all_gather_into_tensor(tau) after every step, RCCL, %d B per rank per step" % (12 * n3 * 4)},
+                                   "collective": "all_gather_into_tensor(tau) of every step, RCCL, %d B per rank per step; tau double-buffered, the gather "
+                                                 "of tick k on a side stream beside tick k + 1" % (12 * n3 * 4),
+                                   "serial": {"value": k3 * n3 * world / el_s, "ms_per_step": el_s / k3 * 1e3}},
             "rccl_ranks": world, "dtype": "f32", "status_ok_frac_rank0": ok}
-        del solver, tick, out, inp, integ, rr
+        del solver, tick, out, inp, integ, rr, tick_b, out_b, out_b2
         torch.cuda.empty_cache()
     except Exception as e:   # never lose the headline to an extra leg
         res["scale_config3"] = {"error": repr(e)[:300]}
@@ -517,18 +542,26 @@ def multi_capi_bench(args, W, synth, torch, np):
             integ.append(sv.dynamics(ins["q"][i], ins["v"][i], want=("p",))["p"].clone())
         obs_state = (integ, [torch.zeros_like(x) for x in integ])
     tick, outs = ms.prepare_step(n_total, ins, obs_state, want_mats=not args.no_mats)
+    tick_b, outs_b = ms.prepare_step(n_total, ins, obs_state, want_mats=not args.no_mats)   # second tau buffer for the overlapped gather
     tau_all = ms.allgather_tau(n_total, outs)
+    tau_all_b = ms.allgather_tau(n_total, outs_b)
     ms.synchronize()
 
-    def run(with_gather):
+    def run(mode):
         times, total = [], 0.0
         while total < 0.05 or not times:
             ms.synchronize()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
-                tick()
-                if with_gather:
-                    ms.allgather_tau(n_total, outs, tau_all)
+            for k in range(args.steps):
+                if mode == 2:      # wbc_multi_allgather_tau_async: gather of tick k beside tick k + 1, tau double-buffered
+                    b = k & 1
+                    ms.gather_wait(b)
+                    (tick_b if b else tick)()
+                    ms.allgather_tau_async(n_total, outs_b if b else outs, tau_all_b if b else tau_all, b)
+                else:
+                    tick()
+                    if mode == 1:
+                        ms.allgather_tau(n_total, outs, tau_all)
             ms.synchronize()
             times.append(time.perf_counter() - t0)
             total += times[-1]
@@ -536,9 +569,10 @@ def multi_capi_bench(args, W, synth, torch, np):
 
     for _ in range(args.warmup):
         tick()
-    blocks = run(False)
-    gblocks = run(True)
-    el, gel = float(np.median(blocks)), float(np.median(gblocks))
+    blocks = run(0)
+    sblocks = run(1)
+    gblocks = run(2)
+    el, gel, sel = float(np.median(blocks)), float(np.median(gblocks)), float(np.median(sblocks))
     ok = float(np.mean([(o["status"] == 0).double().mean().item() for o in outs]))
     print_line({
         "metric": "WBC control-steps/sec (batched DogBot)", "value": args.steps * n_total / el, "unit": "control-steps/s",
@@ -551,7 +585,10 @@ def multi_capi_bench(args, W, synth, torch, np):
         "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_median": el * 1e3, "block_ms_min": min(blocks) * 1e3,
                    "block_ms_max": max(blocks) * 1e3},
         "with_tau_allgather": {"value": args.steps * n_total / gel, "ms_per_step": gel / args.steps * 1e3,
-                               "collective": ("RCCL ncclAllGather (ncclCommInitAll, one group call)" if distinct else "peer copies (shards share a device)")},
+                               "collective": ("RCCL ncclAllGather (ncclCommInitAll, one group call)" if distinct else "peer copies (shards share a device)")
+                                             + "; wbc_multi_allgather_tau_async: on the gather streams beside the next tick, tau double-buffered",
+                               "serial": {"value": args.steps * n_total / sel, "ms_per_step": sel / args.steps * 1e3,
+                                          "collective": "wbc_multi_allgather_tau on the shard streams behind every tick"}},
         "rccl_ranks": ms.rccl_ranks, "qp": {"status_ok_frac": ok}, "roofline": None, "cpu_baseline": None})
 
 

@@ -357,7 +357,14 @@ int wbc_multi_rollout_batch(wbc_multi* mm, size_t n_total, int horizon, const wb
  * tau_all[k] on devices[k] receives wbc_multi_size blocks of nj * count_0 scalars, block j = shard j's tau exactly as
  * shard j laid it out ([nj][count_j], packed; the tail of a shorter shard's block is padding). */
 int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all);
-int wbc_multi_synchronize(wbc_multi* mm);                   /* waits for every shard stream */
+/* The same gather OFF the tick's critical path: it is enqueued on per-shard gather streams behind the tick that is on the shard streams
+ * now and runs BESIDE the next tick.  The caller double-buffers tau (two tau buffers per shard, ticks alternate between them) and names
+ * the slot (0 / 1) of the buffer being gathered; wbc_multi_gather_wait(slot) makes every shard stream wait -- on the device, the host
+ * returns at once -- for that slot's last gather: call it before the tick that overwrites that slot's tau.  Per tick k, slot b = k & 1:
+ *     wbc_multi_gather_wait(mm, b);  wbc_multi_step_batch(... out[b] ...);  wbc_multi_allgather_tau_async(mm, n, tau_b, tau_all_b, b);  */
+int wbc_multi_allgather_tau_async(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, int slot);
+int wbc_multi_gather_wait(wbc_multi* mm, int slot);
+int wbc_multi_synchronize(wbc_multi* mm);                   /* waits for every shard stream (and gather stream) */
 /* Host-resident batch (a C++ caller that holds host arrays, e.g. the ROS side): in / out / obs hold HOST pointers to
  * component-major arrays [ncomp][n_total] of the solver's scalar type; slices are scattered to the devices with pitched
  * copies, stepped, and tau, f, status, iters (and the observer state, when obs is given) gathered back.  out->M, h, Jc,

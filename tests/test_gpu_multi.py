@@ -107,7 +107,7 @@ def test_abi_smoke_cpp_program_runs(torch_cuda, consumer):
     assert "wbc_qp_dense_batch: status=0 x=(0.800000 0.200000)" in run.stdout      # the general dense QP from plain C++
 
 
-@pytest.mark.parametrize("obs,gather", [(0, "peer"), (1, "peer"), (1, "rccl")])
+@pytest.mark.parametrize("obs,gather", [(0, "peer"), (1, "peer"), (1, "rccl"), (0, "rccl")])
 def test_python_multisolver_equals_single_solver(torch_cuda, gpu_model, obs, gather):
     """The binding over wbc_multi_*: shards on the visible devices (device 0 repeated for the peer-copy variant on a 1-GPU
     box) against ONE solver over the whole batch -- bit-identical tau, f, status and observer state; the gathered torques
@@ -156,6 +156,34 @@ def test_python_multisolver_equals_single_solver(torch_cuda, gpu_model, obs, gat
             blk = ta[j, :12 * cnt].reshape(12, cnt).to("cuda:0")
             assert torch.equal(blk, ref["tau"][:, st:st + cnt]), (d, j)
         assert ta.shape == (ms.n, 12 * c0)
+    if obs:
+        return
+    # the overlapped form (wbc_multi_allgather_tau_async / wbc_multi_gather_wait): tau double-buffered, two ticks over DIFFERENT commanded
+    # wrenches alternate, the gather of tick k runs on the gather streams beside tick k + 1; after 7 ticks slot 0 holds the even ticks'
+    # torques and slot 1 the odd ticks' -- a gather that read a buffer too late (overwritten) or too early (tick unfinished) shows
+    ins_b = dict(ins)
+    ins_b["w_des"] = [w * 1.07 for w in ins["w_des"]]
+    ref_b = single.step(full["q"], full["v"], full["w_des"] * 1.07, full["vdot_des"], full["normals"], full["mu"], mask, full["tau_prev"], full["f_prev"])
+    torch.cuda.synchronize()
+    tick_b, outs_b = ms.prepare_step(n, ins_b, None)
+    alls = [ms.allgather_tau(n, outs), ms.allgather_tau(n, outs_b)]
+    for t in alls:
+        for x in t:
+            x.zero_()
+    ms.sync_torch_streams()
+    ms.synchronize()
+    for k in range(7):
+        b = k & 1
+        ms.gather_wait(b)
+        (tick_b if b else tick)()
+        ms.allgather_tau_async(n, outs_b if b else outs, alls[b], b)
+    ms.synchronize()
+    for b, rf in ((0, ref), (1, ref_b)):
+        for d, ta in enumerate(alls[b]):
+            for j in range(ms.n):
+                st, cnt = W.shard_range(n, ms.n, j)
+                assert torch.equal(ta[j, :12 * cnt].reshape(12, cnt).to("cuda:0"), rf["tau"][:, st:st + cnt]), (b, d, j)
+    assert not torch.equal(ref["tau"], ref_b["tau"])
 
 
 def test_rccl_gather_over_more_than_one_device_or_says_it_did_not_run(torch_cuda, gpu_model):

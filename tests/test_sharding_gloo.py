@@ -68,6 +68,22 @@ def _worker(rank, world, port, n_total, q):
         secs, gathered = timed_steps_with_gather(lambda: sb.step(eq), lambda o: o["tau"], dist, k_steps)
         assert secs > 0 and tuple(gathered.shape) == (world, 12, 500)
         assert torch.equal(gathered[rank], sb.step(eq)["tau"])
+        # the double-buffered form (gather of tick k beside tick k + 1): two ticks that write DIFFERENT tau buffers, the second over
+        # other states, so that a gather that read the wrong buffer -- or a buffer overwritten too early -- shows
+        from wbc_quadruped_dob_amd.sharding import timed_steps_with_overlapped_gather
+        eq2 = dict(eq)
+        eq2["w_des"] = eq["w_des"] * 1.05
+        keep = {}
+
+        def mk(inputs, tag):
+            def f():
+                keep[tag] = sb.step(inputs)
+                return keep[tag]
+            return f
+        secs2, (g0, g1) = timed_steps_with_overlapped_gather((mk(eq, "a"), mk(eq2, "b")), lambda o: o["tau"], dist, 5)
+        assert secs2 > 0 and tuple(g0.shape) == tuple(g1.shape) == (world, 12, 500)
+        assert torch.equal(g0[rank], sb.step(eq)["tau"]) and torch.equal(g1[rank], sb.step(eq2)["tau"])   # ticks 4 (even) and 3 (odd)
+        assert not torch.equal(g0[rank], g1[rank])
         if rank == 0:
             ref = orc.step(P, *[B[k] for k in keys], B["mask"])
             q.put((float(np.abs(tau_all.numpy().T - ref["tau"]).max()), stats, int((ref["status"] == 0).sum()),

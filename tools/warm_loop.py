@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""A closed loop of DEPENDENT ticks through wbc_step_batch_warm (tools/warm_loop.py [N ...]): the same batch ticked K times while the
+states drift a little between ticks (joint angles and the commanded wrench), cold start (wbc_step_batch) against warm start from the
+previous tick's active set.  Prints us per tick and mean QP iterations for both."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import wbc_quadruped_dob_amd as W
+from wbc_quadruped_dob_amd import synth
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [1024, 4096, 8192, 32768]
+    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    for cfg, obs, dtype in ((2, 0, "f64"), (3, 1, "f64"), (4, 1, "f32")):
+        td = torch.float64 if dtype == "f64" else torch.float32
+        for n in sizes:
+            P = synth.default_params(observer_order=obs, dtype=dtype)
+            B = synth.make_batch(cfg, n, model.total_mass, rank=1)
+            B["w_des"][:, 0:2] += np.random.default_rng(1).uniform(-40, 40, (n, 2))
+            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
+            res = {}
+            for warm in (False, True):
+                solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n)
+                inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+                mask = torch.from_numpy(B["mask"]).cuda()
+                integ = rr = None
+                if obs:
+                    integ = solver.dynamics(inp["q"], inp["v"], want=("p",))["p"].clone()
+                    rr = torch.zeros_like(integ)
+                dq = 1e-3 * torch.randn((12, n), dtype=td, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+                dw = 0.2 * torch.randn((6, n), dtype=td, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+                tick, out = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                                                inp["f_prev"], integ, rr, want_mats=True, warm=warm)
+
+                def loop(k):
+                    for i in range(k):
+                        inp["q"][7:] += dq if i % 2 == 0 else -dq          # the robots move between ticks
+                        inp["w_des"] += dw if i % 2 == 0 else -dw
+                        tick()
+                loop(20)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                K = 200
+                loop(K)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                # the drift alone (two elementwise kernels per tick)
+                t0 = time.perf_counter()
+                for i in range(K):
+                    inp["q"][7:] += dq if i % 2 == 0 else -dq
+                    inp["w_des"] += dw if i % 2 == 0 else -dw
+                torch.cuda.synchronize()
+                el0 = time.perf_counter() - t0
+                solver.enable_timing(1)
+                loop(20)
+                torch.cuda.synchronize()
+                tm = solver.collect_timing()
+                kern = {k[:-3]: round(v * 1e3 / max(1, tm[k[:-3] + "_launches"]), 1) for k, v in tm.items() if k.endswith("_ms") and v > 0}
+                solver.enable_timing(0)
+                res[warm] = ((el - el0) / K * 1e6, float(out["iters"].double().mean()), float((out["status"] == 0).double().mean()), kern)
+            print("cfg%d %s obs%d n=%6d: cold %7.2f us/tick (iters %.2f)   warm %7.2f us/tick (iters %.2f)   ok %.4f / %.4f   plan %s  kernels cold %s warm %s" % (
+                cfg, dtype, obs, n, res[False][0], res[False][1], res[True][0], res[True][1], res[False][2], res[True][2],
+                "fused" if W.plan_tick(n, dtype, obs, warm=True)["fused"] else "two-kernel", res[False][3], res[True][3]))
+
+
+if __name__ == "__main__":
+    main()

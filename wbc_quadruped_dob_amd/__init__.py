@@ -212,6 +212,8 @@ def lib():
         L.wbc_multi_rollout_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wbc_multi_allgather_tau.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.wbc_multi_synchronize.argtypes = [C.c_void_p]
+        L.wbc_multi_allgather_tau_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.wbc_multi_gather_wait.argtypes = [C.c_void_p, C.c_int]
         L.wbc_multi_step_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wbc_dynamics_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
         L.wbc_step_batch.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
@@ -728,6 +730,17 @@ class MultiSolver:
         allp = (C.c_void_p * self.n)(*[t.data_ptr() for t in tau_all])
         _check(lib().wbc_multi_allgather_tau(self._h, n_total, loc, allp), "wbc_multi_allgather_tau")
         return tau_all
+
+    def allgather_tau_async(self, n_total, outs, tau_all, slot):
+        """wbc_multi_allgather_tau_async: the gather of `outs` (slot 0 / 1 of a double-buffered tau) on the gather streams, beside the next tick"""
+        loc = (C.c_void_p * self.n)(*[o["tau"].data_ptr() for o in outs])
+        allp = (C.c_void_p * self.n)(*[t.data_ptr() for t in tau_all])
+        _check(lib().wbc_multi_allgather_tau_async(self._h, n_total, loc, allp, int(slot)), "wbc_multi_allgather_tau_async")
+        return tau_all
+
+    def gather_wait(self, slot):
+        """the shard streams wait (on the device) for the last gather of `slot`: before the tick that overwrites that slot's tau"""
+        _check(lib().wbc_multi_gather_wait(self._h, int(slot)), "wbc_multi_gather_wait")
 
     def step_host(self, q, v, w_des, vdot_des, normals, mu, mask, tau_prev=None, f_prev=None, obs_integ=None, obs_r=None):
         """Host-resident batch (numpy, component-major [ncomp, n_total] in the solver's dtype): scatter, tick, gather.

@@ -61,6 +61,9 @@ struct Shard {
   wbc_solver* solver = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev = nullptr;        // "my part of the gather / tick is enqueued"
+  hipStream_t gstream = nullptr;  // overlapped gathers (wbc_multi_allgather_tau_async): the collective runs here, beside the next tick
+  hipEvent_t ev_tick = nullptr;   // "the tick whose tau is to be gathered is enqueued" (recorded on `stream`, waited for by `gstream`)
+  hipEvent_t ev_slot[2] = {nullptr, nullptr};   // "the gather of buffer slot b is enqueued" (recorded on `gstream`)
   ncclComm_t comm = nullptr;
   void* d_send = nullptr;         // gather staging [nj * cmax] (ragged shards only)
   // host-batch convenience: device image of one shard (allocated on first wbc_multi_step_host)
@@ -105,7 +108,11 @@ extern "C" void wbc_multi_destroy(wbc_multi* mm) {
     if (s.comm && mm->rccl.CommDestroy) (void)mm->rccl.CommDestroy(s.comm);
     if (s.d_send) (void)hipFree(s.d_send);
     if (s.d_host_img) (void)hipFree(s.d_host_img);
+    if (s.gstream) (void)hipStreamSynchronize(s.gstream);
     if (s.ev) (void)hipEventDestroy(s.ev);
+    if (s.ev_tick) (void)hipEventDestroy(s.ev_tick);
+    for (hipEvent_t e : s.ev_slot) if (e) (void)hipEventDestroy(e);
+    if (s.gstream) (void)hipStreamDestroy(s.gstream);
     if (s.stream) (void)hipStreamDestroy(s.stream);
     if (s.solver) wbc_solver_destroy(s.solver);
   }
@@ -143,6 +150,11 @@ extern "C" int wbc_multi_create(const wbc_model* m, const wbc_params* p, int dty
     hipError_t e = hipSetDevice(s.device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+    if (e == hipSuccess && gather_backend != WBC_GATHER_NONE) {
+      e = hipStreamCreateWithFlags(&s.gstream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_tick, hipEventDisableTiming);
+      for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&s.ev_slot[b], hipEventDisableTiming);
+    }
     if (e == hipSuccess && gather_backend != WBC_GATHER_NONE) e = hipMalloc(&s.d_send, (size_t)mm->nj * cmax * mm->ts());
     if (e != hipSuccess) { wbc_multi_destroy(mm); return fail(WBC_E_HIP, std::string("shard setup: ") + hipGetErrorString(e)); }
   }
@@ -235,7 +247,9 @@ extern "C" int wbc_multi_rollout_batch(wbc_multi* mm, size_t n_total, int horizo
   return WBC_OK;
 }
 
-extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all) {
+// the gather on the shard streams (side = false: behind the tick) or on the shards' gather streams (side = true: beside the next tick)
+static int gather_impl(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, bool side) {
+#define GSTREAM(sh_) (side ? (sh_).gstream : (sh_).stream)
   if (!mm || !tau_local || !tau_all) return fail(WBC_E_INVALID, "null argument");
   if (mm->backend == WBC_GATHER_NONE) return fail(WBC_E_INVALID, "this wbc_multi was created without a gather backend");
   if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
@@ -256,14 +270,14 @@ extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void
       if (cnt != cmax) {   // ragged: the collective needs equal counts, so the short shards send from a padded staging copy
         Shard& s = mm->sh[(size_t)k];
         HIP_TRY(hipSetDevice(s.device));
-        if (cnt) HIP_TRY(hipMemcpyAsync(s.d_send, tau_local[k], (size_t)mm->nj * cnt * ts, hipMemcpyDeviceToDevice, s.stream));
+        if (cnt) HIP_TRY(hipMemcpyAsync(s.d_send, tau_local[k], (size_t)mm->nj * cnt * ts, hipMemcpyDeviceToDevice, GSTREAM(s)));
         send[(size_t)k] = s.d_send;
       }
     }
     ncclResult_t r = mm->rccl.GroupStart();
     for (int k = 0; k < n && r == ncclSuccess; ++k) {
       Shard& s = mm->sh[(size_t)k];
-      r = mm->rccl.AllGather(send[(size_t)k], tau_all[k], blk, mm->dtype == WBC_F64 ? ncclFloat64 : ncclFloat32, s.comm, s.stream);
+      r = mm->rccl.AllGather(send[(size_t)k], tau_all[k], blk, mm->dtype == WBC_F64 ? ncclFloat64 : ncclFloat32, s.comm, GSTREAM(s));
     }
     const ncclResult_t r2 = mm->rccl.GroupEnd();
     if (r == ncclSuccess) r = r2;
@@ -280,15 +294,59 @@ extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void
     const size_t bytes = (size_t)mm->nj * cnt * ts;
     for (int d = 0; d < n && bytes; ++d) {
       char* dst = (char*)tau_all[d] + (size_t)j * blk * ts;
-      if (mm->sh[(size_t)d].device == src.device) HIP_TRY(hipMemcpyAsync(dst, tau_local[j], bytes, hipMemcpyDeviceToDevice, src.stream));
-      else HIP_TRY(hipMemcpyPeerAsync(dst, mm->sh[(size_t)d].device, tau_local[j], src.device, bytes, src.stream));
+      if (mm->sh[(size_t)d].device == src.device) HIP_TRY(hipMemcpyAsync(dst, tau_local[j], bytes, hipMemcpyDeviceToDevice, GSTREAM(src)));
+      else HIP_TRY(hipMemcpyPeerAsync(dst, mm->sh[(size_t)d].device, tau_local[j], src.device, bytes, GSTREAM(src)));
     }
-    HIP_TRY(hipEventRecord(src.ev, src.stream));
+    HIP_TRY(hipEventRecord(src.ev, GSTREAM(src)));
   }
   for (int d = 0; d < n; ++d) {
     HIP_TRY(hipSetDevice(mm->sh[(size_t)d].device));
     for (int j = 0; j < n; ++j)
-      if (j != d) HIP_TRY(hipStreamWaitEvent(mm->sh[(size_t)d].stream, mm->sh[(size_t)j].ev, 0));
+      if (j != d) HIP_TRY(hipStreamWaitEvent(GSTREAM(mm->sh[(size_t)d]), mm->sh[(size_t)j].ev, 0));
+  }
+  return WBC_OK;
+#undef GSTREAM
+}
+
+extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all) {
+  return gather_impl(mm, n_total, tau_local, tau_all, false);
+}
+
+// The gather OFF the tick's path: enqueued on the shards' gather streams behind the tick that is on the shard streams now, so that it
+// runs beside the NEXT tick.  The caller double-buffers tau (two wbc_batch_out.tau per shard, alternating) and names the buffer's
+// slot; before the tick that overwrites a slot's tau it calls wbc_multi_gather_wait(slot).
+extern "C" int wbc_multi_allgather_tau_async(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, int slot) {
+  if (!mm) return fail(WBC_E_INVALID, "null argument");
+  if (slot < 0 || slot > 1) return fail(WBC_E_INVALID, "slot must be 0 or 1");
+  if (mm->backend == WBC_GATHER_NONE) return fail(WBC_E_INVALID, "this wbc_multi was created without a gather backend");
+  {
+    DeviceScope keep;
+    for (Shard& s : mm->sh) {   // every gather stream waits for ITS shard's tick (peer copies read only the source shard's tau)
+      HIP_TRY(hipSetDevice(s.device));
+      HIP_TRY(hipEventRecord(s.ev_tick, s.stream));
+      HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0));
+    }
+  }
+  const int rc = gather_impl(mm, n_total, tau_local, tau_all, true);
+  if (rc) return rc;
+  DeviceScope keep;
+  for (Shard& s : mm->sh) {
+    HIP_TRY(hipSetDevice(s.device));
+    HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream));
+  }
+  return WBC_OK;
+}
+
+// every shard stream waits (on the device, not on the host) for the last gather of `slot`: call it before the tick that overwrites
+// that slot's tau, and before reading that slot's tau_all on a shard stream
+extern "C" int wbc_multi_gather_wait(wbc_multi* mm, int slot) {
+  if (!mm) return fail(WBC_E_INVALID, "null argument");
+  if (slot < 0 || slot > 1) return fail(WBC_E_INVALID, "slot must be 0 or 1");
+  if (mm->backend == WBC_GATHER_NONE) return WBC_OK;
+  DeviceScope keep;
+  for (Shard& s : mm->sh) {
+    HIP_TRY(hipSetDevice(s.device));
+    HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_slot[slot], 0));
   }
   return WBC_OK;
 }
@@ -299,6 +357,7 @@ extern "C" int wbc_multi_synchronize(wbc_multi* mm) {
   for (Shard& s : mm->sh) {
     HIP_TRY(hipSetDevice(s.device));
     HIP_TRY(hipStreamSynchronize(s.stream));
+    if (s.gstream) HIP_TRY(hipStreamSynchronize(s.gstream));
   }
   return WBC_OK;
 }

@@ -108,3 +108,56 @@ def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None):
     el = torch.tensor([dt], dtype=torch.float64, device=tau.device)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     return float(el.item()), gathered
+
+
+def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lambda: None):
+    """The consumer-side all-gather OFF the tick's critical path: tau is double-buffered -- step_fns = (even, odd), two ticks over the
+    same inputs that write their torques into DIFFERENT buffers -- and the gather of tick k runs on a side stream while tick k + 1
+    computes; tick k + 2, which overwrites tick k's buffer, waits (stream-ordered, not on the host) for that gather only.
+    Order of operations per tick k, buffer b = k & 1:   wait(gather k-2)  ->  tick k writes tau_b  ->  gather k of tau_b into all_b (async).
+    Returns (max-over-ranks seconds, [all_0, all_1]): all_b[r] = rank r's tau of the last tick that used buffer b.
+    CPU tensors (the gloo tests) take the same path without streams: async_op works, wait() blocks the host."""
+    import time
+    import torch
+    world = dist.get_world_size()
+    taus = [get_tau(f()) for f in step_fns]
+    assert taus[0].data_ptr() != taus[1].data_ptr(), "the two ticks must write their torques into different buffers"
+    cuda = taus[0].is_cuda
+    flat = [torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in taus]
+    gathered = [fl.view((world,) + tuple(t.shape)) for fl, t in zip(flat, taus)]
+    side = torch.cuda.Stream(device=taus[0].device) if cuda else None
+    evs = [torch.cuda.Event() for _ in range(2)] if cuda else None
+    works = [None, None]
+
+    def gather(b, tau):
+        if cuda:
+            evs[b].record()                          # tau_b is complete on the compute stream ...
+            side.wait_event(evs[b])                  # ... before the side stream reads it
+            with torch.cuda.stream(side):
+                works[b] = dist.all_gather_into_tensor(flat[b], tau, async_op=True)
+        else:
+            works[b] = dist.all_gather_into_tensor(flat[b], tau, async_op=True)
+
+    for b in (0, 1):                                 # warm the communicator and both paths
+        gather(b, taus[b].contiguous())
+    for b in (0, 1):
+        works[b].wait()
+    sync()
+    dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        b = k & 1
+        if works[b] is not None:
+            works[b].wait()                          # (GPU: the CURRENT stream waits for gather k - 2; the host does not)
+        tau = get_tau(step_fns[b]())
+        gather(b, tau if tau.is_contiguous() else tau.contiguous())
+    for b in (0, 1):
+        if works[b] is not None:
+            works[b].wait()
+    sync()
+    dt = time.perf_counter() - t0
+    dist.barrier()
+    el = torch.tensor([dt], dtype=torch.float64, device=taus[0].device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item()), gathered
