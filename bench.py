@@ -233,25 +233,19 @@ def main():
     gather_res = None
     if dist is not None and not os.environ.get("WBC_BENCH_NO_GATHER"):
         try:
-            from wbc_quadruped_dob_amd.sharding import timed_steps_with_gather, timed_steps_with_overlapped_gather
             nbytes = 12 * n * (8 if dtype == "f64" else 4)
-            el_s, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, args.steps, torch.cuda.synchronize)
-            # double-buffered tau: a second prepared tick over the same inputs and outputs except for its own tau buffer; the gather of
-            # tick k runs on a side stream beside tick k + 1 (sharding.timed_steps_with_overlapped_gather)
-            out_b = dict(out)
-            out_b["tau"] = torch.empty_like(out["tau"])
-            tick_b, out_b2 = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
-                                                 inp["tau_prev"], inp["f_prev"], integ, rr, out=out_b, want_mats=want_mats)
 
-            def step_b():
-                tick_b()
-                return out_b2
-            el_g, _ = timed_steps_with_overlapped_gather((step, step_b), lambda o: o["tau"], dist, args.steps, torch.cuda.synchronize)
-            gather_res = {"value": args.steps * n * world / el_g, "ms_per_step": el_g / args.steps * 1e3,
-                          "collective": "all_gather_into_tensor(tau) of every step, RCCL, %d B per rank per step; tau double-buffered, the gather of "
-                                        "tick k on a side stream beside tick k + 1" % nbytes,
-                          "serial": {"value": args.steps * n * world / el_s, "ms_per_step": el_s / args.steps * 1e3,
-                                     "collective": "the same gather on the tick's stream, behind every tick (round 3's form)"}}
+            def make_tick(tau_view):   # the same tick, its torques written straight into this rank's block of a gather buffer
+                o = dict(out)
+                o["tau"] = tau_view
+                tk, o2 = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
+                                             inp["tau_prev"], inp["f_prev"], integ, rr, out=o, want_mats=want_mats)
+
+                def st():
+                    tk()
+                    return o2
+                return st
+            gather_res = gather_leg(make_tick, dist, args.steps, n, world, rank, nbytes, td, torch)
         except Exception as e:  # never lose the main line to the optional leg
             gather_res = {"error": repr(e)[:200]}
 
@@ -399,6 +393,58 @@ def main():
         dist.destroy_process_group()
 
 
+def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch):
+    """SURVEY.md 8e "steps/s with and without the all-gather": the consumer-side collective of every tick.  The ticks write their
+    torques straight into this rank's block of the gather buffer (in-place all-gather: no second copy of the local block), two
+    buffers alternate.  `value` = K ticks + K gathers captured ONCE as a hipGraph and replayed (what the device needs; a tick of
+    4 096 states is shorter than the Python call of one collective) -- the better of "gather behind the tick on its stream" and
+    "gather on a side stream beside the next tick"; the same graph without the collectives and the eager (host-issued) forms are
+    reported beside it."""
+    from wbc_quadruped_dob_amd.sharding import (agree_on_steps, gather_buffers, graph_steps_with_gather, timed_steps_with_gather,
+                                                timed_steps_with_overlapped_gather)
+    get = lambda o: o["tau"]
+    flats, views = gather_buffers(world, rank, 12, n, td, "cuda")
+    step_fns = tuple(make_tick(v) for v in views)
+    el_serial, _ = timed_steps_with_gather(step_fns[0], get, dist, steps, torch.cuda.synchronize, flat=flats[0])
+    res = {"collective": "all_gather_into_tensor(tau) of every step, RCCL, %d B per rank per step, in place (the tick writes tau into its block of "
+                         "the gather buffer); two buffers alternate" % nbytes,
+           "eager_serial": {"value": steps * n * world / el_serial, "ms_per_step": el_serial / steps * 1e3,
+                            "note": "host-issued, the gather on the tick's stream behind every tick"}}
+    try:
+        el_o, _ = timed_steps_with_overlapped_gather(step_fns, get, dist, steps, torch.cuda.synchronize, flats=flats)
+        res["eager_overlapped"] = {"value": steps * n * world / el_o, "ms_per_step": el_o / steps * 1e3,
+                                   "note": "host-issued, side stream beside the next tick: bound by the Python cost of the collective calls"}
+    except Exception as e:
+        res["eager_overlapped"] = {"error": repr(e)[:200]}
+    # The hipGraph forms are OPT-IN (WBC_BENCH_GRAPH_GATHER=1): capturing RCCL collectives beside the process group's watchdog thread
+    # stalled one run in three on this stack for the 10 minutes of the group's time-out (and aborted it in the default capture mode) --
+    # not something the driver's scaling command should risk.  profiles/r04*_bench_scale_legs_1rank_graph.json is such an opt-in run.
+    graph_forms = (("graph_ticks_only", False, False), ("graph_serial", False, True), ("graph_overlapped", True, True)) \
+        if os.environ.get("WBC_BENCH_GRAPH_GATHER") == "1" else ()
+    # graphs long enough (>= 5 ms) that the replay's own launch cost is < 1 % of what it times
+    kg = max(steps, int(5e-3 / max(el_serial / steps, 1e-6)) + 1)
+    kg = agree_on_steps(kg, dist, "cuda") if graph_forms else kg
+    for key, ov, ga in graph_forms:
+        try:
+            el, _ = graph_steps_with_gather(step_fns, get, dist, kg, replays=5, overlapped=ov, gather=ga, flats=flats)
+            res[key] = {"value": kg * n * world / el, "ms_per_step": el / kg * 1e3,
+                        "note": "%d ticks%s captured once as a hipGraph, replayed 5 times" % (kg, " + %d gathers" % kg if ga else " (no gather: the baseline)")}
+        except Exception as e:
+            res[key] = {"error": repr(e)[:300]}
+    cands = [k for k in ("graph_serial", "graph_overlapped") if "value" in res.get(k, {})]
+    if cands:
+        bk = max(cands, key=lambda k: res[k]["value"])
+        res["value"], res["ms_per_step"], res["value_is"] = res[bk]["value"], res[bk]["ms_per_step"], bk
+        if "value" in res.get("graph_ticks_only", {}):
+            res["frac_of_graph_ticks_only"] = res["value"] / res["graph_ticks_only"]["value"]
+    else:
+        ek = max([k for k in ("eager_serial", "eager_overlapped") if "value" in res.get(k, {})], key=lambda k: res[k]["value"])
+        res["value"], res["ms_per_step"], res["value_is"] = res[ek]["value"], res[ek]["ms_per_step"], ek
+        res["note"] = ("host-issued ticks and collectives: at this tick length the Python call of a collective costs more than the tick; the device-side "
+                       "cost (the same sequence captured as a hipGraph) is measured with WBC_BENCH_GRAPH_GATHER=1")
+    return res
+
+
 def device_probe(torch):
     """What this device's memory system delivers on a plain copy (the pool's devices differ by up to 12 % on the HBM-bound
     tick at identical clocks): 1 GiB device-to-device copy, read + write bytes over the median of 10 copies."""
@@ -455,27 +501,25 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
             step()
         torch.cuda.synchronize()
         k3, bl, el = long_blocks_of(step, max(20, int(np.ceil(5e-3 / max((time.perf_counter() - t0) / 20, 1e-7)))), dist, torch, np)
-        el_s, _ = timed_steps_with_gather(step, lambda o: o["tau"], dist, k3, torch.cuda.synchronize)
-        out_b = dict(out)
-        out_b["tau"] = torch.empty_like(out["tau"])
-        tick_b, out_b2 = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
-                                             inp["tau_prev"], inp["f_prev"], integ, rr, out=out_b, want_mats=True)
+        def make_tick(tau_view):
+            o = dict(out)
+            o["tau"] = tau_view
+            tk, o2 = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask,
+                                         inp["tau_prev"], inp["f_prev"], integ, rr, out=o, want_mats=True)
 
-        def step_b():
-            tick_b()
-            return out_b2
-        el_g, _ = timed_steps_with_overlapped_gather((step, step_b), lambda o: o["tau"], dist, k3, torch.cuda.synchronize)
+            def st():
+                tk()
+                return o2
+            return st
+        g3 = gather_leg(make_tick, dist, k3, n3, world, rank, 12 * n3 * 4, td, torch)
         ok = float((out["status"] == 0).double().mean().item())
         res["scale_config3"] = {
             "workload": "configs[3]: batch=%d fp32 = %d states per GPU x %d, tilted terrain normals + disturbances, observer on, M/h/Jc written"
                         % (n3 * world, n3, world),
             "value": k3 * n3 * world / el, "unit": "control-steps/s", "ms_per_step": el / k3 * 1e3, "steps_per_block": k3, "blocks": len(bl),
-            "with_tau_allgather": {"value": k3 * n3 * world / el_g, "ms_per_step": el_g / k3 * 1e3,
-                                   "collective": "all_gather_into_tensor(tau) of every step, RCCL, %d B per rank per step; tau double-buffered, the gather "
-                                                 "of tick k on a side stream beside tick k + 1" % (12 * n3 * 4),
-                                   "serial": {"value": k3 * n3 * world / el_s, "ms_per_step": el_s / k3 * 1e3}},
+            "with_tau_allgather": g3,
             "rccl_ranks": world, "dtype": "f32", "status_ok_frac_rank0": ok}
-        del solver, tick, out, inp, integ, rr, tick_b, out_b, out_b2
+        del solver, tick, out, inp, integ, rr, make_tick
         torch.cuda.empty_cache()
     except Exception as e:   # never lose the headline to an extra leg
         res["scale_config3"] = {"error": repr(e)[:300]}

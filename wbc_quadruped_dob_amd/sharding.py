@@ -82,7 +82,17 @@ def agree_on_steps(k, dist, device=None):
     return int(t.item())
 
 
-def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None):
+def gather_buffers(world, rank, rows, n, dtype, device, count=2):
+    """Buffers for the IN-PLACE all-gather: `count` flat [world * rows, n] tensors and, for each, the view of this rank's block.  A tick
+    that writes its torques straight into that view (Solver.step(out={"tau": view})) makes the collective in place: the local block
+    is not copied again, and a one-rank communicator has nothing left to do."""
+    import torch
+    flats = [torch.zeros((world * rows, n), dtype=dtype, device=device) for _ in range(count)]
+    views = [f.view(world, rows, n)[rank] for f in flats]
+    return flats, views
+
+
+def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None, flat=None):
     """SURVEY.md 8e "report steps/s with and without the all-gather": runs `steps` ticks where every tick is followed by
     an all-gather of this rank's tau ([nj, n_local], equal n_local on every rank) into a preallocated
     [world, nj, n_local] buffer.  Returns (max-over-ranks seconds, gathered buffer).  bench.py calls it on the GPU box
@@ -91,8 +101,10 @@ def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None):
     import torch
     world = dist.get_world_size()
     tau = get_tau(step_fn())
-    # output = the ranks' blocks concatenated along dim 0 (the one layout both RCCL and gloo accept)
-    flat = torch.empty((world * tau.shape[0],) + tuple(tau.shape[1:]), dtype=tau.dtype, device=tau.device)
+    # output = the ranks' blocks concatenated along dim 0 (the one layout both RCCL and gloo accept); `flat` given: the caller's buffer
+    # (in place when tau is this rank's block of it, gather_buffers)
+    if flat is None:
+        flat = torch.empty((world * tau.shape[0],) + tuple(tau.shape[1:]), dtype=tau.dtype, device=tau.device)
     gathered = flat.view((world,) + tuple(tau.shape))
     dist.all_gather_into_tensor(flat, tau.contiguous())   # warm the communicator
     sync()
@@ -110,7 +122,7 @@ def timed_steps_with_gather(step_fn, get_tau, dist, steps, sync=lambda: None):
     return float(el.item()), gathered
 
 
-def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lambda: None):
+def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lambda: None, flats=None):
     """The consumer-side all-gather OFF the tick's critical path: tau is double-buffered -- step_fns = (even, odd), two ticks over the
     same inputs that write their torques into DIFFERENT buffers -- and the gather of tick k runs on a side stream while tick k + 1
     computes; tick k + 2, which overwrites tick k's buffer, waits (stream-ordered, not on the host) for that gather only.
@@ -123,7 +135,7 @@ def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lamb
     taus = [get_tau(f()) for f in step_fns]
     assert taus[0].data_ptr() != taus[1].data_ptr(), "the two ticks must write their torques into different buffers"
     cuda = taus[0].is_cuda
-    flat = [torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in taus]
+    flat = flats if flats is not None else [torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in taus]
     gathered = [fl.view((world,) + tuple(t.shape)) for fl, t in zip(flat, taus)]
     side = torch.cuda.Stream(device=taus[0].device) if cuda else None
     evs = [torch.cuda.Event() for _ in range(2)] if cuda else None
@@ -157,6 +169,67 @@ def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lamb
             works[b].wait()
     sync()
     dt = time.perf_counter() - t0
+    dist.barrier()
+    el = torch.tensor([dt], dtype=torch.float64, device=taus[0].device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item()), gathered
+
+
+def graph_steps_with_gather(step_fns, get_tau, dist, steps, replays=20, overlapped=True, gather=True, flats=None):
+    """The same double-buffered tick + gather sequence as timed_steps_with_overlapped_gather (overlapped = False: the gather on the tick's
+    own stream behind every tick), CAPTURED ONCE as a hipGraph of `steps` ticks and replayed: the host issues one graph launch per
+    `steps` ticks, so what is timed is what the DEVICE needs for K ticks with their K gathers -- at 4 096 states a tick lasts 14 us,
+    less than the Python call of one torch.distributed collective.  gather = False: the same graph without the collectives (the
+    baseline the other two are compared with).  GPU tensors only.  Returns (max-over-ranks seconds per replay,
+    [all_0, all_1]); raises when the stack refuses to capture the collective (the caller falls back to the eager forms)."""
+    import time
+    import torch
+    world = dist.get_world_size()
+    taus = [get_tau(f()) for f in step_fns]
+    assert taus[0].is_cuda and taus[0].data_ptr() != taus[1].data_ptr()
+    flat = flats if flats is not None else [torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in taus]
+    gathered = [fl.view((world,) + tuple(t.shape)) for fl, t in zip(flat, taus)]
+    for b in (0, 1):
+        dist.all_gather_into_tensor(flat[b], taus[b])          # communicator and buffers warm before the capture
+    torch.cuda.synchronize()
+    main = torch.cuda.Stream(device=taus[0].device)
+    side = torch.cuda.Stream(device=taus[0].device)
+    main.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(main):
+        # (thread_local: the process group's watchdog thread polls events of earlier collectives while this thread captures; in the
+        #  default "global" mode that foreign call invalidates the capture and the watchdog aborts the process)
+        with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
+            works = [None, None]
+            for k in range(steps):
+                b = k & 1
+                if works[b] is not None:
+                    works[b].wait()                              # tick k overwrites tau_b: behind gather k - 2
+                tau = get_tau(step_fns[b]())
+                if not gather:
+                    continue
+                if overlapped:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        works[b] = dist.all_gather_into_tensor(flat[b], tau, async_op=True)
+                else:
+                    dist.all_gather_into_tensor(flat[b], tau)
+            for b in (0, 1):
+                if works[b] is not None:
+                    works[b].wait()
+            main.wait_stream(side)                               # the side stream joins before the capture ends
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / replays
     dist.barrier()
     el = torch.tensor([dt], dtype=torch.float64, device=taus[0].device)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
