@@ -14,11 +14,8 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver_flags_steps20.
 WBC_KEEP_STRUCTURAL=1 python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144_keep_structural.json" 2>> "$O/bench.err"
 WBC_KEEP_STRUCTURAL=1 python bench.py --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n4096_keep_structural.json" 2>> "$O/bench.err"
 WBC_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-latency --large-batch 0 > "$O/bench_scale_legs_1rank.json" 2>> "$O/bench.err"
-bash tools/r03_tiles.sh > "$O/tile_sweep.log" 2>&1
-bash tools/r03_tiles3.sh >> "$O/tile_sweep.log" 2>&1
-bash tools/r03_tiles4.sh >> "$O/tile_sweep.log" 2>&1
-bash tools/r03_tiles6.sh >> "$O/tile_sweep.log" 2>&1
-bash tools/r03_midrange.sh > "$O/midrange.log" 2>&1
+bash tools/ab_sweep.sh "2 3" "49152 65536 98304 114688" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f64.log" 2>&1
+bash tools/ab_sweep.sh "4" "98304 163840 229376" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f32.log" 2>&1
 python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/bench.err"
 python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
 python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
