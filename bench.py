@@ -354,7 +354,7 @@ def main():
         if not args.no_latency and world == 1:
             res["qp_latency"] = qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs)
         if not args.no_latency and world == 1:
-            res["qp_dense_general"] = qp_dense_general(W, torch, dtype)
+            res["qp_dense_general"] = qp_dense_general(W, torch, dtype, with_cpu=not args.no_cpu)
         if fused and world == 1:
             res["roofline_dyn_sweep_alone"] = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
         if args.large_batch and world == 1:
@@ -782,7 +782,7 @@ def rollout_flops_only(r5, H):
                                                int(B["mask"][i]), te[i], integ0[i], warm=True)["flops_per_tick"] for i in range(m)]))
 
 
-def qp_dense_general(W, torch, dtype):
+def qp_dense_general(W, torch, dtype, with_cpu=False):
     """The general dense QP kernel (wbc_qp_dense_batch: run-time sizes, one QP per wavefront, factors in LDS) on random strictly
     convex problems generated on the device: the size of the controller's own GRF QP, the size of a whole-body QP over CoM / joint accelerations
     and contact forces with torque bounds (30 variables, 58 rows, 18 of them equalities), the largest size it takes, and ONE such problem per
@@ -813,11 +813,50 @@ def qp_dense_general(W, torch, dtype):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        out["n%d_m%d_meq%d%s" % (n, m, meq, "" if N > 1 else "_single")] = {"batch": N, "launch_us": us, "qps_per_s": N / us * 1e6, "iters_mean": float(o["iters"].double().mean()),
-                                            "status_ok_frac": float((o["status"] == 0).double().mean())}
+        key = "n%d_m%d_meq%d%s" % (n, m, meq, "" if N > 1 else "_single")
+        it_mean = float(o["iters"].double().mean())
+        # work of one Goldfarb-Idnani iteration at these sizes: d = J^T n+ (2 n^2), z = J2 d2 (<= 2 n^2), r = R^-1 d1 (<= n^2), the slacks of
+        # the m rows (2 m n), the Givens update of J (<= 6 n^2): ~ 11 n^2 + 2 m n flops
+        fl_it = 11.0 * n * n + 2.0 * m * n
+        out[key] = {"batch": N, "launch_us": us, "qps_per_s": N / us * 1e6, "iters_mean": it_mean,
+                    "status_ok_frac": float((o["status"] == 0).double().mean()),
+                    "us_per_iteration_of_a_wavefront": us / max(it_mean, 1e-9) if N == 1 else None,
+                    "roofline": {"bound": "valu_%s" % dtype, "achieved": fl_it * it_mean * N / (us * 1e-6) / 1e12, "peak": VALU_F64_PEAK_TFLOPS * (1 if dtype == "f64" else 2),
+                                 "unit": "TFLOP/s", "flops_per_iteration_estimate": fl_it,
+                                 "note": "O(n^2) work per iteration spread over 64 lanes with an LDS round trip between its steps: latency-bound, one wavefront per QP"}}
+        out[key]["roofline"]["frac"] = out[key]["roofline"]["achieved"] / out[key]["roofline"]["peak"]
+        if with_cpu and dtype == "f64":   # the same problems through the oracle's general solver on the host cores (the cpu_baseline of THIS kernel)
+            try:
+                from oracle import oracle_py
+                Hn, gn, Cn, dn = (t.double().cpu().numpy() for t in (H, g, Cm, d))
+                t0 = time.perf_counter()
+                xr, _, sr, itr = oracle_py.qp_general(Hn, gn, Cn, dn, meq=meq, max_iter=400, tol=tol) if N > 1 else oracle_py.qp_general(Hn[0], gn[0], Cn[0], dn[0], meq=meq, max_iter=400, tol=tol)
+                dtc = time.perf_counter() - t0
+                if N > 1:
+                    t0 = time.perf_counter()
+                    oracle_py.qp_general(Hn, gn, Cn, dn, meq=meq, max_iter=400, tol=tol)
+                    dtc = time.perf_counter() - t0
+                    agree = float(np_abs_max(o["x"].double().cpu().numpy() - xr) / max(1.0, np_abs_max(xr)))
+                else:
+                    reps_c = 200
+                    t0 = time.perf_counter()
+                    for _ in range(reps_c):
+                        oracle_py.qp_general(Hn[0], gn[0], Cn[0], dn[0], meq=meq, max_iter=400, tol=tol)
+                    dtc = (time.perf_counter() - t0) / reps_c
+                    agree = float(np_abs_max(o["x"].double().cpu().numpy()[0] - xr) / max(1.0, np_abs_max(xr)))
+                out[key]["cpu_oracle"] = {"us": dtc * 1e6, "qps_per_s": N / dtc, "threads": 8 if N > 1 else 1, "kind": "port",
+                                          "max_rel_difference_of_x": agree,
+                                          "note": "oracle/qp_general.hpp on the same problems (OpenMP over problems, 8 threads%s)" % ("" if N > 1 else "; one problem: one thread, incl. the ctypes call")}
+            except Exception as e:
+                out[key]["cpu_oracle"] = {"error": repr(e)[:200]}
     out["note"] = ("random feasible problems (H = A A^T / n + I, a third of the rows active at the optimum), same-stream back-to-back launches; the "
                    "controller's own 12-variable GRF QP goes through the structured kernels instead (kernels.qp_us)")
     return out
+
+
+def np_abs_max(a):
+    import numpy as np
+    return float(np.abs(a).max()) if a.size else 0.0
 
 
 def qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs):

@@ -495,8 +495,8 @@ def test_permuted_joint_and_foot_order(torch_cuda, tmp_path):
             assert relerr(got["integ"], ig_ref) < TIGHT64 and relerr(got["r"], r_ref) < TIGHT64
 
 
-def _gpu_rollout(torch, solver, P, H, B, tau_ext, integ, r, want_traj=True):
-    td = torch.float64
+def _gpu_rollout(torch, solver, P, H, B, tau_ext, integ, r, want_traj=True, dtype="f64"):
+    td = torch.float64 if dtype == "f64" else torch.float32
     n = B["q"].shape[0]
     dv = lambda a: to_dev(a, torch, td)
     q, v = dv(B["q"]), dv(B["v"])

@@ -181,6 +181,30 @@ def test_rollouts_warm_equal_cold_and_oracle(torch_cuda, gpu_model, oracle, cfg,
     assert relerr(res[1]["tau_traj"][:, 0], ref["tau_traj"][:, 0]) < TIGHT64
 
 
+@pytest.mark.parametrize("n,H,opt", [(1024, 20, {}), (300, 9, {"rollout_spw": 16}), (5000, 6, {})])
+def test_fp32_rollouts_warm_equal_cold(torch_cuda, gpu_model, oracle, n, H, opt):
+    """The fp32 instantiations of the warm rollout kernels (the QP itself runs in fp64 arithmetic on fp32 arrays): warm = cold to fp32
+    rounding over the horizon, every status 0, and close to the fp64 oracle's rollout."""
+    torch = torch_cuda
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=23)
+    B["w_des"][:, 0:2] += np.random.default_rng(8).uniform(-60, 60, (n, 2))
+    tau_ext = np.zeros((n, 18))
+    tau_ext[:, 0:3] = B["push"]
+    integ = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    res = {}
+    for warm in (0, 1):
+        solver, P = _solver(gpu_model, dtype="f32", obs=1, max_batch=n, options=dict(opt, rollout_warm=warm))
+        res[warm] = _gpu_rollout(torch, solver, P, H, B, tau_ext, integ.copy(), np.zeros((n, 18)), dtype="f32")
+    assert np.all(res[0]["status"] == 0) and np.all(res[1]["status"] == 0)
+    assert relerr(res[1]["q"], res[0]["q"]) < 1e-5 and relerr(res[1]["v"], res[0]["v"]) < 1e-4
+    assert relerr(res[1]["tau_traj"], res[0]["tau_traj"]) < 2e-3
+    P64 = synth.default_params(observer_order=1)
+    q, v = B["q"].copy(), B["v"].copy()
+    oracle.rollout(P64, H, q, v, B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], tau_ext=tau_ext, integ=integ.copy(), r=np.zeros((n, 18)),
+                   nthreads=8, warm=True)
+    assert relerr(res[1]["q"], q) < 1e-4 and relerr(res[1]["v"], v) < 2e-3
+
+
 def test_warm_tick_is_graph_capturable_and_carries_its_sets(torch_cuda, gpu_model, oracle):
     """A closed loop of warm ticks in a hipGraph: the set buffer is updated in place, so replaying the captured tick IS the loop."""
     torch = torch_cuda
