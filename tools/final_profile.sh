@@ -13,7 +13,14 @@ python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver_flags_steps20.json" 2>> "$O/bench.err"
 WBC_KEEP_STRUCTURAL=1 python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144_keep_structural.json" 2>> "$O/bench.err"
 WBC_KEEP_STRUCTURAL=1 python bench.py --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n4096_keep_structural.json" 2>> "$O/bench.err"
-WBC_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-latency --large-batch 0 > "$O/bench_scale_legs_1rank.json" 2>> "$O/bench.err"
+WBC_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 5 --no-latency --large-batch 0 > "$O/bench_scale_legs_1rank.json" 2>> "$O/bench.err"
+# the same legs with the hipGraph forms of the gather (opt-in: RCCL capture beside the watchdog thread can stall; bounded by a timeout)
+WBC_BENCH_GRAPH_GATHER=1 WBC_BENCH_FORCE_DIST=1 timeout 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29545 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-latency --large-batch 0 > "$O/bench_scale_legs_1rank_graph.json" 2>> "$O/bench.err"
+# configs[4] rollouts without the warm start (A/B of wbc_solver_options.rollout_warm)
+WBC_ROLLOUT_WARM=0 python bench.py --config 5 --steps 100 --warmup 10 --no-cpu > "$O/bench_cfg5_h20_n1024_cold.json" 2>> "$O/bench.err"
+WBC_ROLLOUT_WARM=0 python bench.py --config 5 --tracking --steps 100 --warmup 10 --no-cpu > "$O/bench_cfg5_tracking_h20_n1024_cold.json" 2>> "$O/bench.err"
+python tools/warm_loop.py 1024 4096 8192 > "$O/warm_loop.log" 2>> "$O/bench.err"
+python tools/warm_timing.py > "$O/warm_timing.log" 2>> "$O/bench.err"
 bash tools/ab_sweep.sh "2 3" "49152 65536 98304 114688" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f64.log" 2>&1
 bash tools/ab_sweep.sh "4" "98304 163840 229376" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f32.log" 2>&1
 python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/bench.err"
@@ -42,6 +49,7 @@ if [ -f wbc_quadruped_dob_amd/lib_qstamp/libwbc_hip.so ]; then
 fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- python3 "$R/bench.py" --config 5 --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_qp_general -- python3 "$R/tools/qp_general_profile.py" > "$O/qp_general.json" 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5trk -- python3 "$R/bench.py" --config 5 --tracking --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
