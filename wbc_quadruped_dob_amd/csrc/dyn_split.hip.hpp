@@ -135,8 +135,13 @@ WBC_DEV void structural_consts_quarter(const DevModel<T>* __restrict__ model, co
   }
 }
 
+// `hand` (persistent rollout, round 4): the entries of M and Jc the integrator's factorisation needs ALSO go to an LDS image
+// hand[word][64] (lane = 16 leg + state slot) -- leg block of M (6: upper triangle (k, j)), base-leg block (18: 6 + 3 r + k), own-leg
+// Jacobian block (9: 24 + 3 m + k), lever arm (3: 33..35), base block as (m, R h, R I R^T) (10: 36..45) -- so that the integrator
+// wavefront neither waits for this role's global stores to drain nor reloads them through L2.
+constexpr int MJ_HAND_WORDS = 46;
 template <class T, int BLOCK, int EXT, int SPW = 16, bool ZEROS = true>
-WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext) {
+WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext, T* hand = nullptr) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   static_assert(SPW == 16 || EXT != 0, "fewer states per workgroup only for roles");
   WBC_LAUNDERED_TID(tx);
@@ -233,6 +238,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
       int i = 6 + jx[k], jj = 6 + jx[j];
       if (i > jj) { const int t = i; i = jj; jj = t; }
       STV(a.M, i * 18 - i * (i - 1) / 2 + (jj - i), mkj);
+      if (hand) hand[(k * 3 - k * (k - 1) / 2 + (j - k)) * 64 + (int)(tx & 63)] = mkj;
     }
     jc[k] = cross(ax, dft);
     dft = r + mul(E, dft);
@@ -269,7 +275,14 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
     STLX(a.Jc, 0 * 18 + 6, 54, x, jw.x);  // overwrites a zero written above (same lane, program order)
     STLX(a.Jc, 1 * 18 + 6, 54, x, jw.y);
     STLX(a.Jc, 2 * 18 + 6, 54, x, jw.z);
+    if (hand) {
+      T* hl = hand + (int)(tx & 63);
+      hl[(6 + 0 + k) * 64] = Mf.x; hl[(6 + 3 + k) * 64] = Mf.y; hl[(6 + 6 + k) * 64] = Mf.z;
+      hl[(6 + 9 + k) * 64] = Mn.x; hl[(6 + 12 + k) * 64] = Mn.y; hl[(6 + 15 + k) * 64] = Mn.z;
+      hl[(24 + 0 + k) * 64] = jw.x; hl[(24 + 3 + k) * 64] = jw.y; hl[(24 + 6 + k) * 64] = jw.z;
+    }
   }
+  if (hand) { T* hl = hand + (int)(tx & 63); hl[33 * 64] = dw.x; hl[34 * 64] = dw.y; hl[35 * 64] = dw.z; }
   STL(a.Jc, 0 * 18 + 4, 54, dw.z);  STL(a.Jc, 0 * 18 + 5, 54, -dw.y);
   STL(a.Jc, 1 * 18 + 3, 54, -dw.z); STL(a.Jc, 1 * 18 + 5, 54, dw.x);
   STL(a.Jc, 2 * 18 + 3, 54, dw.y);  STL(a.Jc, 2 * 18 + 4, 54, -dw.x);
@@ -293,6 +306,11 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
     ST4(M, midx18(0, 5), -hw.y, midx18(1, 3), -hw.z, midx18(1, 5), hw.x, midx18(2, 3), hw.y);
     ST4(M, midx18(2, 4), -hw.x, midx18(3, 3), Iw.xx, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz);
     if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
+    if (hand) {
+      T* hl = hand + (int)(tx & 63);
+      hl[36 * 64] = tm; hl[37 * 64] = hw.x; hl[38 * 64] = hw.y; hl[39 * 64] = hw.z;
+      hl[40 * 64] = Iw.xx; hl[41 * 64] = Iw.xy; hl[42 * 64] = Iw.xz; hl[43 * 64] = Iw.yy; hl[44 * 64] = Iw.yz; hl[45 * 64] = Iw.zz;
+    }
   }
 }
 

@@ -182,6 +182,10 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   // (WARM) the active set of each of the workgroup's states, from tick to tick: one LDS word per state, read and written by the state's own
   // QP row only (a register of the QP wavefronts would be live through every role's code of this 256-register kernel)
   __shared__ int aset_sh[16];
+  // what the integrator's factorisation needs of M and Jc, handed over by the mass_jac role in LDS (dyn_split.hip.hpp): with the QP warm-started
+  // the tick's barrier waits for that factorisation, not for the QP, and its operands should neither wait for the role's stores to drain
+  // nor come back through L2
+  __shared__ T mj_hand[MJ_HAND_WORDS * 64];
   if constexpr (WARM) {
     if (threadIdx.x < 16) {
       const size_t sq = (size_t)blockIdx.x * SPW + threadIdx.x;
@@ -229,15 +233,15 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       }
       // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has published them
       // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
-      while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
 #ifdef WBC_FUSED_STAMP
       RSTAMP(9);   // factorisation can start (M, Jc published; the observer's joint rows are done)
-      integrate_body<T, SPW>(model, iat, [=] __device__() { __syncthreads(); RSTAMP(7); });
+      integrate_body<T, SPW>(model, iat, [=] __device__() { __syncthreads(); RSTAMP(7); }, mj_hand);
       RSTAMP(8);
 #else
-      integrate_body<T, SPW>(model, iat, [] __device__() { __syncthreads(); });   // <- barrier A inside
+      integrate_body<T, SPW>(model, iat, [] __device__() { __syncthreads(); }, mj_hand);   // <- barrier A inside
 #endif
       __syncthreads();                                                       // barrier B: q, v of the next tick
       continue;
@@ -258,8 +262,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wave == 5) {
-      mass_jac_body<T, 64, 1, SPW>(model, at, cst, zidx_s);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // M, Jc are in L2 (waits for my stores) ...
+      mass_jac_body<T, 64, 1, SPW>(model, at, cst, zidx_s, mj_hand);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the hand-over image is in LDS (the M / Jc stores to HBM drain on their own: nothing in this kernel reads them) ...
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&mready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {

@@ -20,8 +20,11 @@ namespace wbc {
 // `between()` runs after it (nothing in the stand-alone kernel; the tick barrier in the rollout kernel, where phase 1
 // overlaps the QP).  Phase 2 needs tau, f, h, q, v: right-hand sides, the two triangular solves, the state update.
 struct IntegrateNoWait { WBC_DEV void operator()() const {} };
+// `hand` (persistent rollout): M's leg / base-leg / base blocks, the own-leg Jacobian block and the lever arm come from the LDS image
+// the mass_jac role left (dyn_split.hip.hpp, MJ_HAND_WORDS) instead of from the M / Jc buffers through L2 -- same numbers, so the
+// results are bit-identical; what changes is when phase 1 can start and how long its operands take to arrive.
 template <class T, int SPW = 16, class Between = IntegrateNoWait>
-WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between()) {
+WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between(), const T* hand = nullptr) {
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   unsigned tx = threadIdx.x;
@@ -43,12 +46,15 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 
   // ================================================================== phase 1: M, Jc only
   // foot position relative to the base origin from the base-angular block of my foot's Jacobian rows, -[d]x
-  const V3<T> dl = mk<T>(LDL(a.Jc, 18 * 1 + 5, 54), LDL(a.Jc, 18 * 2 + 3, 54), LDL(a.Jc, 18 * 0 + 4, 54));
+  const T* hl = hand ? hand + (int)(tx & 63) : nullptr;
+  const V3<T> dl = hand ? mk<T>(hl[33 * 64], hl[34 * 64], hl[35 * 64])
+                        : mk<T>(LDL(a.Jc, 18 * 1 + 5, 54), LDL(a.Jc, 18 * 2 + 3, 54), LDL(a.Jc, 18 * 0 + 4, 54));
   T jcl[3][3];   // own-leg Jacobian block: jcl[m][k] = d pf_m / d q_(leg, k)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const unsigned jo = (unsigned)(6 + jx[k]) * N32;   // column of joint (leg, k) in rows 3*leg + m of Jc
-    jcl[0][k] = LDLX(a.Jc, 0, 54, jo); jcl[1][k] = LDLX(a.Jc, 18, 54, jo); jcl[2][k] = LDLX(a.Jc, 36, 54, jo);
+    if (hand) { jcl[0][k] = hl[(24 + k) * 64]; jcl[1][k] = hl[(27 + k) * 64]; jcl[2][k] = hl[(30 + k) * 64]; }
+    else { jcl[0][k] = LDLX(a.Jc, 0, 54, jo); jcl[1][k] = LDLX(a.Jc, 18, 54, jo); jcl[2][k] = LDLX(a.Jc, 36, 54, jo); }
   }
   // leg block (symmetric 3x3) and base-leg block (6x3) of M
   auto mi = [](int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return i * 18 - i * (i - 1) / 2 + (j - i); };
@@ -56,11 +62,29 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
   for (int k1 = 0; k1 < 3; ++k1)
 #pragma unroll
-    for (int k2 = k1; k2 < 3; ++k2) { Ml[k1][k2] = LDV(a.M, mi(6 + jx[k1], 6 + jx[k2])); Ml[k2][k1] = Ml[k1][k2]; }
+    for (int k2 = k1; k2 < 3; ++k2) {
+      Ml[k1][k2] = hand ? hl[(k1 * 3 - k1 * (k1 - 1) / 2 + (k2 - k1)) * 64] : LDV(a.M, mi(6 + jx[k1], 6 + jx[k2]));
+      Ml[k2][k1] = Ml[k1][k2];
+    }
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) Mb[r][k] = LDV(a.M, midx18(r, r) + (6 + jx[k] - r));
+    for (int k = 0; k < 3; ++k) Mb[r][k] = hand ? hl[(6 + 3 * r + k) * 64] : LDV(a.M, midx18(r, r) + (6 + jx[k] - r));
+  // base block of M (upper triangle): from the buffer, or rebuilt from (m, R h, R I R^T) of the hand-over image
+  T Mbb[6][6];
+  if (hand) {
+    const T tm = hl[36 * 64], hx = hl[37 * 64], hy = hl[38 * 64], hz = hl[39 * 64];
+    const T Z = (T)0;
+    Mbb[0][0] = tm; Mbb[0][1] = Z; Mbb[0][2] = Z; Mbb[0][3] = Z; Mbb[0][4] = hz; Mbb[0][5] = -hy;
+    Mbb[1][1] = tm; Mbb[1][2] = Z; Mbb[1][3] = -hz; Mbb[1][4] = Z; Mbb[1][5] = hx;
+    Mbb[2][2] = tm; Mbb[2][3] = hy; Mbb[2][4] = -hx; Mbb[2][5] = Z;
+    Mbb[3][3] = hl[40 * 64]; Mbb[3][4] = hl[41 * 64]; Mbb[3][5] = hl[42 * 64]; Mbb[4][4] = hl[43 * 64]; Mbb[4][5] = hl[44 * 64]; Mbb[5][5] = hl[45 * 64];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c) Mbb[r][c] = LDU(a.M, midx18(r, c));
+  }
   // A = Ml^-1 by cofactors (SPD 3x3)
   T A[3][3];
   {
@@ -84,7 +108,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
     for (int c = r; c < 6; ++c) {
       const T sc = Wr[0] * Mb[c][0] + Wr[1] * Mb[c][1] + Wr[2] * Mb[c][2];
-      S[r][c] = LDU(a.M, midx18(r, c)) - xrow_sum(sc);
+      S[r][c] = Mbb[r][c] - xrow_sum(sc);
     }
   }
   // Cholesky of S (L[j][j] holds 1 / L_jj), in registers
