@@ -87,6 +87,14 @@ def test_cpp_consumer_matches_oracle_and_shards_match_single(torch_cuda, gpu_mod
     assert relerr(one["tau"], ref["tau"]) < 1e-9 and relerr(one["f"], ref["f"]) < 1e-9
     if obs:
         assert relerr(one["integ"], ig_ref) < 1e-9 and relerr(one["r"], r_ref) < 1e-9
+    # wbc_step_batch_warm from plain C++: a cold tick on a scratch copy reports the active sets, the dumped tick starts from them in place
+    # (the consumer itself fails when any state of the warm tick needed an iteration)
+    warm = _consume(consumer, tmp_path, "warm", B, P, integ, r)
+    assert warm["gather_mismatches"] == 0 and np.all(warm["iters"] == 0)
+    assert np.array_equal(warm["status"], ref["status"])
+    assert relerr(warm["tau"], ref["tau"]) < 1e-9 and relerr(warm["f"], ref["f"]) < 1e-9
+    if obs:
+        assert relerr(warm["r"], r_ref) < 1e-9
     ndev = torch_cuda.cuda.device_count()
     for mode in ("multi:3", "multi:%d" % max(2, ndev), "rccl", "host:2", "host:5"):
         got = _consume(consumer, tmp_path, mode, B, P, integ, r)

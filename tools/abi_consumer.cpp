@@ -3,6 +3,8 @@
 // with raw hipMalloc'ed buffers, and dumps the results for the test to compare with the oracle.
 //   abi_consumer <urdf> <in.bin> <out.bin> <mode>
 //     single        wbc_solver_create_ex + wbc_step_batch on device 0
+//     warm          wbc_step_batch_warm twice: a cold tick on a scratch copy of the batch reports the active sets, the tick that is
+//                   dumped starts from them (same inputs: zero iterations everywhere, the same tau / f); prints wbc_plan_tick's answer
 //     multi:<k>     wbc_multi_* with k shards dealt round-robin over the visible devices, peer-copy gather of tau,
 //                   checked on every device against the shards' own tau
 //     rccl          wbc_multi_* with one shard per visible device and the RCCL gather (ncclCommInitAll + ncclAllGather)
@@ -103,7 +105,7 @@ static void fill_structs(const Host& h, const DevSlice& d, wbc_batch_in& in, wbc
 }
 
 int main(int argc, char** argv) {
-  if (argc < 5) { std::puts("usage: abi_consumer <urdf> <in.bin> <out.bin> single|multi:<k>|rccl|host:<k>"); return 1; }
+  if (argc < 5) { std::puts("usage: abi_consumer <urdf> <in.bin> <out.bin> single|warm|multi:<k>|rccl|host:<k>"); return 1; }
   Host h;
   if (!read_in(argv[2], h)) { std::puts("cannot read the input file"); return 2; }
   const std::string mode = argv[4];
@@ -127,6 +129,31 @@ int main(int argc, char** argv) {
     CK(wbc_step_batch(s, N, &in, &out, h.obs ? &os : nullptr, st));
     HK(hipStreamSynchronize(st));
     if (download(h, 0, d)) return 11;
+    wbc_solver_destroy(s);
+  } else if (mode == "warm") {
+    wbc_solver* s = nullptr;
+    CK(wbc_solver_create(m, &h.prm, WBC_F64, 0, N, &s));
+    wbc_tick_plan plan;
+    plan.struct_size = sizeof(plan);
+    CK(wbc_solver_plan_tick(s, N, 0, 0, 1, &plan));
+    DevSlice d1, d2;
+    if (upload(h, 0, N, 0, d1) || upload(h, 0, N, 0, d2)) return 11;
+    int* active = nullptr;
+    HK(hipMalloc(&active, N * sizeof(int)));
+    HK(hipMemset(active, 0xFF, N * sizeof(int)));   // garbage: the first tick is told to start cold (active_in = NULL) and overwrites it
+    wbc_batch_in in; wbc_batch_out out; wbc_observer_state os;
+    hipStream_t st;
+    HK(hipStreamCreate(&st));
+    fill_structs(h, d1, in, out, os);
+    CK(wbc_step_batch_warm(s, N, &in, &out, h.obs ? &os : nullptr, nullptr, active, st));
+    fill_structs(h, d2, in, out, os);
+    CK(wbc_step_batch_warm(s, N, &in, &out, h.obs ? &os : nullptr, active, active, st));     // in place
+    HK(hipStreamSynchronize(st));
+    if (download(h, 0, d2)) return 11;
+    long long it_sum = 0;
+    for (size_t i = 0; i < N; ++i) it_sum += h.iters[i];
+    std::printf("warm: plan fused=%d qp=%d, iterations of the warm tick (sum over %zu states) = %lld\n", plan.fused, plan.qp, N, it_sum);
+    if (it_sum != 0) ++mismatches;    // the true set of the same problem: no iteration anywhere
     wbc_solver_destroy(s);
   } else if (mode.rfind("host:", 0) == 0) {
     const int k = std::atoi(mode.c_str() + 5);
