@@ -177,6 +177,17 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
+  // Workgroups of 4 states (SPW = 4) use QP wavefront 0 only; wavefronts 1..3 idle through the kernel and can take the two roles the
+  // integrator wavefront runs in front of its factorisation: the observer's joint rows (WBC_RO_JOINT_WAVE) and the planner (WBC_RO_PLAN_WAVE).
+  // -1 = the integrator wavefront keeps the role (always so with 16 states per workgroup).  Measured placements: DESIGN.md 8.0a.
+#ifndef WBC_RO_JOINT_WAVE
+#define WBC_RO_JOINT_WAVE -1
+#endif
+#ifndef WBC_RO_PLAN_WAVE
+#define WBC_RO_PLAN_WAVE 3    // planner on QP wavefront 3: 17.7 -> 16.4 us per tick at 1 024 tracked rollouts (wavefront 1: 16.65); the joint rows anywhere else
+#endif                        // than on the integrator wavefront LOSE (wavefront 1: 15.1, 2: 13.9, 3: 13.55 against 13.3 us per tick)
+  constexpr int JOINT_WAVE = (OBSERVER && FUSED_OBS_WAVES == 2 && SPW == 4) ? WBC_RO_JOINT_WAVE : -1;
+  constexpr int PLAN_WAVE = (TRACK && SPW == 4) ? WBC_RO_PLAN_WAVE : -1;
   T* const traj0 = ia.tau_traj;
   T* const com0 = ra.com;
   // (WARM) the active set of each of the workgroup's states, from tick to tick: one LDS word per state, read and written by the state's own
@@ -214,8 +225,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #else
 #define RSTAMP(slot) do {} while (0)
 #endif
-    if (wave == WINT) {
-      if constexpr (TRACK) {   // planner role first: this tick's references
+    auto planner_role = [&]() __attribute__((always_inline)) {   // this tick's references
+      if constexpr (TRACK) {
         RefArgs<T> rt = ra;
         rt.N = (size_t)n_tick;
         rt.t = (T)t * prm.dt + ra.t;
@@ -224,13 +235,19 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
       }
+    };
+    auto joint_rows_role = [&]() __attribute__((always_inline)) {
       if constexpr (OBSERVER && FUSED_OBS_WAVES == 2) {
-        // idle until M, Jc exist: this wavefront takes the JOINT rows of the observer update (rhat_joint, which the QP
-        // needs only in its torque map); wave 6 is left with the base rows, whose rhat_base the QP's b waits for
+        // the JOINT rows of the observer update (rhat_joint, which the QP needs only in its torque map); wave 6 is left with the base rows,
+        // whose rhat_base the QP's b waits for
         observer_body<T, 64, 1, 2, SPW>(model, prm, at, cst, wsl);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+    };
+    if (wave == WINT) {
+      if constexpr (PLAN_WAVE < 0) planner_role();       // planner role first
+      if constexpr (JOINT_WAVE < 0) joint_rows_role();   // idle until M, Jc exist: this wavefront takes the joint rows
       // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has published them
       // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
       while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
@@ -280,6 +297,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #else
       const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
+      if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }
+      if constexpr (JOINT_WAVE >= 0) { if (wave == JOINT_WAVE) joint_rows_role(); }
       if constexpr (WARM) {
         qat.aset_out = (t == horizon - 1) ? qa.aset_out : nullptr;   // the set goes out once, behind the last tick
         if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_sh[(threadIdx.x & 255) >> 4]);
