@@ -186,6 +186,10 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #ifndef WBC_RO_PLAN_WAVE
 #define WBC_RO_PLAN_WAVE 3    // planner on QP wavefront 3: 17.7 -> 16.4 us per tick at 1 024 tracked rollouts (wavefront 1: 16.65); the joint rows anywhere else
 #endif                        // than on the integrator wavefront LOSE (wavefront 1: 15.1, 2: 13.9, 3: 13.55 against 13.3 us per tick)
+#ifndef WBC_RO_INT_WAVE
+#define WBC_RO_INT_WAVE -1
+#endif
+  constexpr int INT_WAVE = (SPW == 4) ? WBC_RO_INT_WAVE : -1;   // the integrator itself on an idle QP wavefront (the aux wavefront keeps the roles not moved)
   constexpr int JOINT_WAVE = (OBSERVER && FUSED_OBS_WAVES == 2 && SPW == 4) ? WBC_RO_JOINT_WAVE : -1;
   constexpr int PLAN_WAVE = (TRACK && SPW == 4) ? WBC_RO_PLAN_WAVE : -1;
   T* const traj0 = ia.tau_traj;
@@ -245,23 +249,26 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     };
-    if (wave == WINT) {
-      if constexpr (PLAN_WAVE < 0) planner_role();       // planner role first
-      if constexpr (JOINT_WAVE < 0) joint_rows_role();   // idle until M, Jc exist: this wavefront takes the joint rows
-      // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has published them
+    auto integrator_role = [&]() __attribute__((always_inline)) {
+      // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has handed them over
       // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
       while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
 #ifdef WBC_FUSED_STAMP
-      RSTAMP(9);   // factorisation can start (M, Jc published; the observer's joint rows are done)
+      RSTAMP(9);   // factorisation can start (M, Jc handed over; the roles in front of it on this wavefront are done)
       integrate_body<T, SPW>(model, iat, [=] __device__() { __syncthreads(); RSTAMP(7); }, mj_hand);
       RSTAMP(8);
 #else
       integrate_body<T, SPW>(model, iat, [] __device__() { __syncthreads(); }, mj_hand);   // <- barrier A inside
 #endif
       __syncthreads();                                                       // barrier B: q, v of the next tick
-      continue;
+    };
+    if (wave == WINT) {
+      if constexpr (PLAN_WAVE < 0) planner_role();       // planner role first
+      if constexpr (JOINT_WAVE < 0) joint_rows_role();   // idle until M, Jc exist: this wavefront takes the joint rows
+      if constexpr (INT_WAVE < 0) { integrator_role(); continue; }
+      else { __syncthreads(); __syncthreads(); continue; }
     }
     if (wave == 4) {
       int* const rflag = &rready;
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #endif
       if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }
       if constexpr (JOINT_WAVE >= 0) { if (wave == JOINT_WAVE) joint_rows_role(); }
+      if constexpr (INT_WAVE >= 0) { if (wave == INT_WAVE) { integrator_role(); continue; } }
       if constexpr (WARM) {
         qat.aset_out = (t == horizon - 1) ? qa.aset_out : nullptr;   // the set goes out once, behind the last tick
         if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_sh[(threadIdx.x & 255) >> 4]);
