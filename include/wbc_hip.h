@@ -160,14 +160,19 @@ typedef struct wbc_tick_plan {
   int qp_body;        /* 0 = wrench-space dual active set in fp64 arithmetic, 1 = 12 x 12 orthogonal-factor body in fp32 (fp32 tiles beyond 65 536 states) */
   int sweep_pack2;    /* fp32 dyn_sweep with two states per lane */
   int sweep_block;    /* threads per workgroup of the dyn_sweep launch (64 / 256); 0 when no dyn_sweep runs */
+  int qp_warm;        /* wbc_step_batch_warm: 1 = the QP kernels START from the carried active sets, 0 = they only report them (the sizes at which
+                         the cold tiles are the faster kernels) */
 } wbc_tick_plan;
 /* warm != 0: the plan of wbc_step_batch_warm */
 int wbc_plan_tick(int dtype, int observer_order, const wbc_solver_options* opt /* NULL = defaults */, size_t N, int with_mats, int with_pf,
                   int warm, wbc_tick_plan* plan);
 int wbc_solver_plan_tick(const wbc_solver* s, size_t N, int with_mats, int with_pf, int warm, wbc_tick_plan* plan);
 /* the batch sizes N at which the plan differs from that of N - 1 (fp32: N - 2; odd batches never pack), ascending; *n = how many
- * (at most 16), the first min(*n, cap) are written to out */
-int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_solver_options* opt, int with_mats, size_t* out, int cap, int* n);
+ * (at most 16), the first min(*n, cap) are written to out.  flags: WBC_PLAN_WITH_MATS (the caller passes M / h / Jc buffers) |
+ * WBC_PLAN_WARM (the switches of wbc_step_batch_warm) */
+#define WBC_PLAN_WITH_MATS 1
+#define WBC_PLAN_WARM 2
+int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_solver_options* opt, int flags, size_t* out, int cap, int* n);
 /* diagnostics (synchronises the device): states of the last two-kernel tick that the per-lane QP kernel handed to the dense one */
 int wbc_solver_qp_handover(wbc_solver* s, int* count);
 void wbc_solver_destroy(wbc_solver* s);

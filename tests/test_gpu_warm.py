@@ -39,10 +39,11 @@ def _second_tick(B, seed):
 
 
 @pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 0, 2, 1000), ("f64", 1, 3, 4096), ("f64", 0, 2, 9001), ("f64", 2, 4, 24000), ("f64", 1, 3, 70001),
-                                             ("f32", 1, 4, 3000), ("f32", 0, 2, 40000)])
+                                             ("f64", 0, 2, 53248), ("f32", 1, 4, 3000), ("f32", 0, 2, 33000), ("f32", 0, 2, 40000), ("f32", 1, 3, 150001)])
 def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
     """Two consecutive ticks.  Tick 1 through wbc_step_batch_warm without a set (cold) reports the active sets; tick 2 starts from
-    them.  Fused tick (<= 8 192 states) and two-kernel ticks with the one-wavefront warm kernel; observer off / on / split."""
+    them.  Fused tick (<= 8 192 states), two-kernel ticks with the one-wavefront warm kernel, with the cold tiles (which only report the
+    sets) and with the warm per-lane pair; observer off / on / split."""
     torch = torch_cuda
     nd = _np_dtype(dtype)
     c = lambda a: np.ascontiguousarray(a, nd)
@@ -86,6 +87,8 @@ def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dt
     ref2 = oracle.step(P0, c(B2["q"]), c(B2["v"]), c(B2["w_des"]), c(B2["vdot_des"]), c(B2["normals"]), c(B2["mu"]), B2["mask"], ref1["tau"],
                        ref1["f"], ig_o2, r_o2, nthreads=8)
     ins2, mask2, _ = _dev_inputs(torch, B2, dtype)
+    fn2 = np.einsum("nka,nka->nk", ref2["f"].reshape(n, 4, 3).astype(np.float64), B2["normals"].reshape(n, 4, 3))
+    regular2 = np.all(~stance | (fn2 > 1e-3), axis=1)
     tp2, fp2 = o1["tau"].clone(), o1["f"].clone()
     res = {}
     for tag in ("cold", "warm"):
@@ -100,8 +103,11 @@ def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dt
     np.testing.assert_array_equal(res["warm"]["status"], res["cold"]["status"])
     ok = (res["warm"]["status"] == 0) & (ref2["status"] == 0)
     assert ok.mean() > (0.999 if dtype == "f64" else 0.995)
+    # (fp32: 1e-4 between two runs of the same solver; where the warm and the cold tick run DIFFERENT fp32 solvers -- per-lane Newton against
+    #  the 12 x 12 tiles beyond 65 536 states -- their rounding differs by more: measured 1.6e-4 at 150 001 states)
+    same_kernels = solver.plan_tick(n, warm=True)["qp"] == solver.plan_tick(n)["qp"]
     for k in ("tau", "f"):
-        assert relerr(res["warm"][k][ok], res["cold"][k][ok]) < (TIGHT64 if dtype == "f64" else 1e-4), k      # warm == cold
+        assert relerr(res["warm"][k][ok], res["cold"][k][ok]) < (TIGHT64 if dtype == "f64" else (1e-4 if same_kernels else 5e-4)), k      # warm == cold
         assert relerr(res["warm"][k][ok], ref2[k][ok]) < tol, k                                               # == oracle
     if dtype == "f64":
         np.testing.assert_array_equal(res["warm"]["status"], ref2["status"])
@@ -110,13 +116,21 @@ def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dt
         assert relerr(res["warm"]["r"], r_o2) < (TIGHT64 if dtype == "f64" else 2e-3)
     for k in ("M", "h", "Jc", "pf"):
         assert np.array_equal(res["warm"][k], res["cold"][k]), k
-    # what the warm start is for: most states need no iteration at all, and far fewer in total
+    # what the warm start is for: most states need no iteration at all, and far fewer in total (the planner says whether the QP kernels of
+    # this size start from the sets -- between the tile and the warm per-lane thresholds the cold tiles are the faster kernels and only report them)
+    plan = solver.plan_tick(n, warm=True)
     it_w, it_c = res["warm"]["iters"].astype(np.int64), res["cold"]["iters"].astype(np.int64)
-    assert it_w.sum() < 0.3 * it_c.sum(), (it_w.sum(), it_c.sum())
-    assert np.mean(it_w[ok] == 0) > 0.8
+    if not plan["qp_warm"]:
+        assert plan["qp"] == 1 and np.array_equal(it_w, it_c)
+    else:
+        assert np.mean(it_w[ok] == 0) > (0.8 if plan["qp"] != 2 else 0.6)   # (per-lane: a foot at the apex of its pyramid costs one Newton step)
+        if plan["qp"] != 2:      # (the per-lane pair counts Newton steps, and active-set iterations for the few states it hands over)
+            assert it_w.sum() < 0.3 * it_c.sum(), (it_w.sum(), it_c.sum())
+    if dtype == "f64":       # the carried set that goes out is the oracle's, whichever kernel produced it
+        assert np.array_equal(res["warm"]["active"].astype(np.uint32)[ok & regular2], ref2["aset"][ok & regular2])
 
 
-@pytest.mark.parametrize("n", [512, 12000])
+@pytest.mark.parametrize("n", [512, 12000, 60000])
 def test_a_wrong_or_impossible_carried_set_still_gives_the_cold_result(torch_cuda, gpu_model, oracle, n):
     """The carried set is a hint.  Random bits, every bit, both bounds of a normal force, four faces of one pyramid, rows of swing
     feet, the set of ANOTHER state: tau, f, status equal the cold start (and the oracle) whatever comes in."""
@@ -146,11 +160,20 @@ def test_a_wrong_or_impossible_carried_set_still_gives_the_cold_result(torch_cud
         np.testing.assert_array_equal(got["status"].cpu().numpy(), st_c, err_msg=tag)
         assert relerr(to_host(got["tau"]), tau_c) < TIGHT64 and relerr(to_host(got["f"]), f_c) < TIGHT64, tag
         assert relerr(to_host(got["tau"]), ref["tau"]) < TIGHT64, tag
-    # the true set of the same problem: zero iterations everywhere
+    # the true set of the same problem: zero iterations everywhere (per-lane pair: wherever the vertex is regular -- at the apex of a
+    # pyramid the projection names its own three rows, one more Newton step)
     got = solver.step(*ins, mask, active_in=cold["active"].clone())
     torch.cuda.synchronize()
-    assert np.all(got["iters"].cpu().numpy()[st_c == 0] == 0)
-    assert np.array_equal(got["active"].cpu().numpy(), true)
+    if solver.plan_tick(n, warm=True)["qp"] == 2:
+        fn = np.einsum("nka,nka->nk", ref["f"].reshape(n, 4, 3), B["normals"].reshape(n, 4, 3))
+        stance = ((B["mask"][:, None] >> np.arange(4)[None, :]) & 1) == 1
+        regular = np.all(~stance | (fn > 1e-3), axis=1) & (st_c == 0)
+        assert regular.mean() > 0.3
+        assert np.all(got["iters"].cpu().numpy()[regular] == 0)
+        assert np.array_equal(got["active"].cpu().numpy()[regular], true[regular])
+    else:
+        assert np.all(got["iters"].cpu().numpy()[st_c == 0] == 0)
+        assert np.array_equal(got["active"].cpu().numpy(), true)
 
 
 @pytest.mark.parametrize("cfg,obs,n,H,opt", [(2, 0, 1024, 20, {}), (3, 1, 1000, 20, {}), (3, 1, 777, 12, {"rollout_spw": 16}),

@@ -235,8 +235,13 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.dispatch_thresholds("f64", 1) == [8193, 14336, 20480, 65536, 106496]
     assert W.dispatch_thresholds("f32", 1) == [8193, 30720, 32768, 33792, 65537, 131072, 212992]
     assert W.plan_tick(262144, "f64", 0)["qp"] == 2 and W.plan_tick(262144, "f32", 1) == dict(
-        fused=0, front=2, qp=2, qp_tile=0, qp_body=0, sweep_pack2=1, sweep_block=256)
+        fused=0, front=2, qp=2, qp_tile=0, qp_body=0, sweep_pack2=1, sweep_block=256, qp_warm=0)
     # options move the switches, and the list follows
     assert W.dispatch_thresholds("f64", 0, options={"qp_lane": -1, "qp_tile": -1, "fused_max": 0}) == [65536]
+    # warm-started ticks (wbc_step_batch_warm): fused, warm one-wavefront kernel, cold tiles that only report the sets, warm per-lane pair
+    assert W.dispatch_thresholds("f64", 1, warm=True) == [8193, 14336, 20480, 53248, 65536]
+    assert W.dispatch_thresholds("f32", 1, warm=True) == [8193, 30720, 32768, 33792, 36864, 131072]
+    assert [W.plan_tick(n, "f64", 1, warm=True)["qp_warm"] for n in (4096, 9000, 20000, 60000)] == [1, 1, 0, 1]
+    assert [W.plan_tick(n, "f64", 1, warm=True)["qp"] for n in (9000, 20000, 60000)] == [0, 1, 2]
 
 

@@ -104,30 +104,32 @@ for c in range(cases):
             a1 = _run_step(torch, s, B, DT, *zz, want_mats=bool(c % 2))
             a2 = _run_step(torch, s, B, DT, a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
             res[tag] = (a1, a2)
-        if c % 2 == 0:   # wbc_step_batch_warm: tick 1 cold (reports its active sets), tick 2 from them -- against the cold tick 2 of the fused variant
-            s, P = solver_with({}, obs=obs, max_batch=n, dtype=DT)
-            td_ = torch.float64 if DT == "f64" else torch.float32
-            from tests.util import to_dev, to_host
-            dv = lambda k_: to_dev(B[k_], torch, td_)
-            ins_ = [dv(k_) for k_ in ("q", "v", "w_des", "vdot_des", "normals", "mu")]
-            mk_ = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
-            zz = tuple(None if t is None else to_dev(t.astype(np.float32 if DT == "f32" else np.float64), torch, td_) for t in z())
-            tp_, fp_ = dv("tau_prev"), dv("f_prev")
-            o1 = s.step(*ins_, mk_, tp_, fp_, zz[0], zz[1], want_mats=bool(c % 2), warm=True)
-            o2 = s.step(*ins_, mk_, tp_, fp_, zz[0], zz[1], want_mats=bool(c % 2), active_in=o1["active"].clone(), out={k_: v_ for k_, v_ in o1.items() if k_ != "active"})
-            torch.cuda.synchronize()
-            b2 = res["fused"][1]
-            st_w = o2["status"].cpu().numpy()
-            same = st_w == b2["status"]
-            if not same.all():
-                if DT == "f64" or same.mean() < 0.995:
-                    bad.append((c, "warm tick status", n, obs, cfg))
-                flips += int((~same).sum())
-            for k_ in ("tau", "f"):
-                e = relerr(to_host(o2[k_])[same], b2[k_][same]) if same.any() else 0.0
-                worst = max(worst, e)
-                if not e < (1e-9 if DT == "f64" else TOL):
-                    bad.append((c, "warm tick " + k_, n, obs, cfg, e))
+        if c % 2 == 0:   # wbc_step_batch_warm: tick 1 cold (reports its active sets), tick 2 from them -- against the cold tick 2 of the fused variant;
+        #   default plan (fused at these sizes) and the warm per-lane pair forced
+            for wtag, wopt in (("", {}), (" (per-lane)", {"qp_lane": 1, "fused_max": 0})):
+                s, P = solver_with(wopt, obs=obs, max_batch=n, dtype=DT)
+                td_ = torch.float64 if DT == "f64" else torch.float32
+                from tests.util import to_dev, to_host
+                dv = lambda k_: to_dev(B[k_], torch, td_)
+                ins_ = [dv(k_) for k_ in ("q", "v", "w_des", "vdot_des", "normals", "mu")]
+                mk_ = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
+                zz = tuple(None if t is None else to_dev(t.astype(np.float32 if DT == "f32" else np.float64), torch, td_) for t in z())
+                tp_, fp_ = dv("tau_prev"), dv("f_prev")
+                o1 = s.step(*ins_, mk_, tp_, fp_, zz[0], zz[1], want_mats=bool(c % 2), warm=True)
+                o2 = s.step(*ins_, mk_, tp_, fp_, zz[0], zz[1], want_mats=bool(c % 2), active_in=o1["active"].clone(), out={k_: v_ for k_, v_ in o1.items() if k_ != "active"})
+                torch.cuda.synchronize()
+                b2 = res["fused"][1]
+                st_w = o2["status"].cpu().numpy()
+                same = st_w == b2["status"]
+                if not same.all():
+                    if DT == "f64" or same.mean() < 0.995:
+                        bad.append((c, "warm tick status" + wtag, n, obs, cfg))
+                    flips += int((~same).sum())
+                for k_ in ("tau", "f"):
+                    e = relerr(to_host(o2[k_])[same], b2[k_][same]) if same.any() else 0.0
+                    worst = max(worst, e)
+                    if not e < (1e-9 if DT == "f64" else TOL):
+                        bad.append((c, "warm tick " + k_ + wtag, n, obs, cfg, e))
         if c % 5 == 0 and DT == "f64":   # the same launch again, several times: results must be bit-identical run to run
             s, P = solver_with({}, obs=obs, max_batch=n)
             first = _run_step(torch, s, B, "f64", *z(), want_mats=True)

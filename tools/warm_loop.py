@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """A closed loop of DEPENDENT ticks through wbc_step_batch_warm (tools/warm_loop.py [N ...]): the same batch ticked K times while the
 states drift a little between ticks (joint angles and the commanded wrench), cold start (wbc_step_batch) against warm start from the
-previous tick's active set.  Prints the wall time per tick of the whole loop (the two elementwise drift kernels included, and timed alone beside
+previous tick's active set (WARM_LOOP_LANE=1: the warm tick twice, forced through the one-wavefront kernel and through the per-lane kernel).  Prints the wall time per tick of the whole loop (the two elementwise drift kernels included, and timed alone beside
 it), the tick's kernels by their own dispatch events, and the mean QP iterations."""
+import os
 import sys
 import time
 
@@ -25,8 +26,11 @@ def main():
             B["w_des"][:, 0:2] += np.random.default_rng(1).uniform(-40, 40, (n, 2))
             dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
             res = {}
-            for warm in (False, True):
-                solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n)
+            variants = [(False, False, {}), (True, True, {})]
+            if os.environ.get("WARM_LOOP_LANE") == "1":
+                variants = [(False, False, {}), ("warm16", True, {"qp_lane": -1}), ("warmlane", True, {"qp_lane": 1})]
+            for tag, warm, opts in variants:
+                solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n, options=opts)
                 inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
                 mask = torch.from_numpy(B["mask"]).cuda()
                 integ = rr = None
@@ -66,7 +70,14 @@ def main():
                 tm = solver.collect_timing()
                 kern = {k[:-3]: round(v * 1e3 / max(1, tm[k[:-3] + "_launches"]), 1) for k, v in tm.items() if k.endswith("_ms") and v > 0}
                 solver.enable_timing(0)
-                res[warm] = (el / K * 1e6, el0 / K * 1e6, float(out["iters"].double().mean()), float((out["status"] == 0).double().mean()), kern)
+                if solver.plan_tick(n, warm=warm)["qp"] == 2:
+                    kern["handed_over"] = solver.qp_handover()
+                res[tag] = (el / K * 1e6, el0 / K * 1e6, float(out["iters"].double().mean()), float((out["status"] == 0).double().mean()), kern)
+            if len(variants) == 3:
+                print("cfg%d %s obs%d n=%6d wall us/tick: cold %6.2f  warm one-wavefront %6.2f  warm per-lane %6.2f | iters %.2f / %.2f / %.2f | kernels cold %s  warm16 %s  warmlane %s" % (
+                    cfg, dtype, obs, n, res[False][0], res["warm16"][0], res["warmlane"][0], res[False][2], res["warm16"][2], res["warmlane"][2],
+                    res[False][4], res["warm16"][4], res["warmlane"][4]), flush=True)
+                continue
             print("cfg%d %s obs%d n=%6d: wall per tick incl. the drift kernels (drift alone %.1f us): cold %6.2f us (iters %.2f)  warm %6.2f us (iters %.2f)  ok %.4f / %.4f  %s  "
                   "tick kernels by dispatch events: cold %s warm %s" % (
                       cfg, dtype, obs, n, res[False][1], res[False][0], res[False][2], res[True][0], res[True][2], res[False][3], res[True][3],

@@ -138,7 +138,7 @@ class _BatchOut(C.Structure):
 class TickPlan(C.Structure):
     """wbc_tick_plan (include/wbc_hip.h): which kernels a tick of N states runs."""
     _fields_ = [("struct_size", C.c_size_t), ("fused", C.c_int), ("front", C.c_int), ("qp", C.c_int), ("qp_tile", C.c_int),
-                ("qp_body", C.c_int), ("sweep_pack2", C.c_int), ("sweep_block", C.c_int)]
+                ("qp_body", C.c_int), ("sweep_pack2", C.c_int), ("sweep_block", C.c_int), ("qp_warm", C.c_int)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "struct_size"}
@@ -154,12 +154,12 @@ def plan_tick(N, dtype="f64", observer_order=0, options=None, want_mats=True, wa
     return pl.as_dict()
 
 
-def dispatch_thresholds(dtype="f64", observer_order=0, options=None, want_mats=True):
-    """wbc_dispatch_thresholds: the batch sizes at which the tick's kernels change, ascending; needs no device."""
+def dispatch_thresholds(dtype="f64", observer_order=0, options=None, want_mats=True, warm=False):
+    """wbc_dispatch_thresholds: the batch sizes at which the tick's kernels change (warm: those of a warm-started tick), ascending; needs no device."""
     out = (C.c_size_t * 16)()
     n = C.c_int(0)
     o = SolverOptions.make({} if options is None else options)
-    _check(lib().wbc_dispatch_thresholds(F64 if dtype == "f64" else F32, int(observer_order), C.byref(o), int(want_mats), out, 16, C.byref(n)),
+    _check(lib().wbc_dispatch_thresholds(F64 if dtype == "f64" else F32, int(observer_order), C.byref(o), (1 if want_mats else 0) | (2 if warm else 0), out, 16, C.byref(n)),
            "wbc_dispatch_thresholds")
     return [int(out[i]) for i in range(n.value)]
 

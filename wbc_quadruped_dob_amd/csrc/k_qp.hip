@@ -25,8 +25,8 @@ static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar
 template <>
 hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* list, bool warm) {
   using T = Scalar;
-  if (warm) {   // dependent ticks: every state starts from its previous active set, so the rows of a wavefront do about equal work -- no dealing by predicted work
-    if (list || tile > 0) return hipErrorInvalidValue;
+  if (warm && !list) {   // dependent ticks: every state starts from its previous active set, so the rows of a wavefront do about equal work -- no dealing by predicted work
+    if (tile > 0) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((a.N + 3) / 4));
     if (rhat) WBC_KLAUNCH(L, (qp_group16_kernel<T, true, true>), grid, dim3(64), prm, a, jmap);
     else WBC_KLAUNCH(L, (qp_group16_kernel<T, false, true>), grid, dim3(64), prm, a, jmap);
@@ -64,9 +64,14 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
 }
 
 template <>
-hipError_t k_qp_lane<Scalar>(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* todo) {
+hipError_t k_qp_lane<Scalar>(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* todo, bool warm) {
   using T = Scalar;
   const dim3 grid((unsigned)((a.N + QPL_WG - 1) / QPL_WG));   // one state per lane
+  if (warm) {
+    if (rhat) WBC_KLAUNCH(L, (qp_lane_kernel<T, true, true>), grid, dim3(QPL_WG), prm, a, jmap, todo);
+    else WBC_KLAUNCH(L, (qp_lane_kernel<T, false, true>), grid, dim3(QPL_WG), prm, a, jmap, todo);
+    return hipGetLastError();
+  }
   if (rhat) WBC_KLAUNCH(L, (qp_lane_kernel<T, true>), grid, dim3(QPL_WG), prm, a, jmap, todo);
   else WBC_KLAUNCH(L, (qp_lane_kernel<T, false>), grid, dim3(QPL_WG), prm, a, jmap, todo);
   return hipGetLastError();

@@ -47,7 +47,7 @@ template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, int tile, cons
 // qp_lane_kernel<T, RHAT>: the GRF QP one state per LANE (semismooth Newton on the 6-dimensional residual wrench); states it
 // does not finish are appended to todo (todo[0] = count, todo[4 ...] = indices) for k_qp(..., list = todo); the count must be
 // zero when this kernel starts: the front-half kernel of the tick empties it (SweepArgs::qp_todo)
-template <class T> hipError_t k_qp_lane(const LaunchCtx& L, bool rhat, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int* todo);
+template <class T> hipError_t k_qp_lane(const LaunchCtx& L, bool rhat, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int* todo, bool warm = false);
 // fused_tick_kernel<T, OBSERVER, MATS>: the whole tick of a small batch as one launch
 template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bool mats, const DevModel<T>* model, const DevParams<T>& prm,
                                           const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap, bool warm = false);

@@ -213,6 +213,7 @@ WBC_DEV void qp_predict_finish(const DevParams<T>& prm, const QpArgs<T>& a, cons
     }
     a.status[s32] = 0;
     if (a.iters) a.iters[s32] = 0;
+    if (a.aset_out) a.aset_out[s32] = 0;   // the unconstrained minimum: the empty active set
 #undef PST
   }
 #undef PLD_D
@@ -314,6 +315,8 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
 //   * letting the last workgroup of this kernel reset it (one agent-scope atomic per workgroup to count them, an agent-scope
 //     load of the length) serialises on that one address: 8192 workgroups took 330 us instead of 65 us (N = 262 144);
 //   * a one-thread kernel of its own: correct, 4.7 us per tick.
+// (behind the WARM per-lane kernel the list is solved cold as well: starting the listed states from their carried sets was measured --
+//  the hardest state sets the kernel's 11-15 us either way, and the block set-up makes every group longer: 13.2 -> 15.4 us at 32 768 states)
 template <class T, bool RHAT>
 __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_list_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ list) {
   const int n = min(list[0], (int)a.N);

@@ -279,9 +279,46 @@ WBC_DEV void qpl_newton(const QplLds<T>& L, unsigned tid, int mask, const T* sS,
   }
 }
 
+// The faces of the four projections <-> the public active-set word (include/wbc_hip.h, wbc_step_batch_warm): per foot k
+//   sa = +1 (a clipped at +mu c: (mu n - t1) . f = 0)  <->  bit 4k + 0        sa = -1 ((mu n + t1) . f = 0)  <->  bit 16 + 4k + 0
+//   sb = +1                                             <->  bit 4k + 1        sb = -1                         <->  bit 16 + 4k + 1
+//   sc = -1 (n . f = fn_min)                            <->  bit 4k + 2        sc = +1 (n . f = fn_max)        <->  bit 4k + 3
+WBC_DEV int qpl_codes_from_aset(int aset, int mask) {
+  int codes = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int A = (aset >> (4 * k)) & 0xF, B = (aset >> (16 + 4 * k)) & 0x3;
+    const int sa = (A & 1) ? 1 : ((B & 1) ? -1 : 0), sb = (A & 2) ? 1 : ((B & 2) ? -1 : 0), sc = (A & 8) ? 1 : ((A & 4) ? -1 : 0);
+    const int cd = (sa + 1) | ((sb + 1) << 2) | ((sc + 1) << 4);
+    codes |= (((mask >> k) & 1) ? cd : QPL_FREE) << (6 * k);
+  }
+  return codes;
+}
+WBC_DEV int qpl_aset_from_codes(int codes, int mask) {
+  int aset = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cd = (codes >> (6 * k)) & 63;
+    const int sa = (cd & 3) - 1, sb = ((cd >> 2) & 3) - 1, sc = (cd >> 4) - 1;
+    int A = (sa > 0 ? 1 : 0) | (sb > 0 ? 2 : 0) | (sc < 0 ? 4 : 0) | (sc > 0 ? 8 : 0);
+    int B = (sa < 0 ? 1 : 0) | (sb < 0 ? 2 : 0);
+    if (!((mask >> k) & 1)) { A = 0; B = 0; }
+    aset |= (A << (4 * k)) | (B << (16 + 4 * k));
+  }
+  return aset;
+}
+
 // todo[0] = number of states handed to the dense kernel (zeroed by the front-half kernel of the same tick: SweepArgs::qp_todo),
 // todo[2] = that number of the last tick (diagnostics), todo[4 ...] = their indices
-template <class T, bool RHAT>
+#ifndef QPL_WARM_MIN_NEWTON
+#define QPL_WARM_MIN_NEWTON 1
+#endif
+// WARM (wbc_step_batch_warm at large batches: dependent ticks): the Newton iteration starts from the faces of a.aset_in instead of from "all free".
+// Any face set is a valid starting iterate of the semismooth Newton method -- a wrong or stale guess costs iterations (or sends the state to the
+// hand-over list), never the solution -- and the right one is confirmed by ONE Newton step that leaves the faces unchanged; a wavefront then
+// goes on only while >= QPL_MORE_LANES of its lanes are unfinished (no minimum of three iterations: most lanes are done at once; a minimum
+// of two was measured: a third fewer states handed over, the kernel 2-3 us longer, the tick no faster).
+template <class T, bool RHAT, bool WARM = false>
 __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_WAVES)) void qp_lane_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ todo) {
   __shared__ QplLds<T> L;
   const unsigned tid = threadIdx.x;
@@ -341,13 +378,16 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
   const T alpha = prm.alpha, ralpha = prm.rsqrt_alpha * prm.rsqrt_alpha, fmin = prm.fn_min, fmax = prm.fn_max;
   const T tolF = (std::is_same<T, double>::value ? (T)1e-11 : (T)2e-5) * ((T)1 + bmax);
 
-  // start: all faces free (the unconstrained minimum)
+  // start: all faces free (the unconstrained minimum) -- or the faces the previous tick ended on (WARM)
   int code = QPL_FREE | (QPL_FREE << 6) | (QPL_FREE << 12) | (QPL_FREE << 18);
+  if constexpr (WARM) { if (a.aset_in) code = qpl_codes_from_aset(a.aset_in[s32], mask); }
   T e[6], F[6];
   qpl_newton(L, tid, mask, sS, alpha, fmin, fmax, beta, code, e);
+  const int code0 = code;
   qpl_eval<T, false>(L, tid, mask, sS, ralpha, fmin, fmax, beta, e, code, F);
   int iters = 0, prev_cnt = 64;
   bool conv = false;
+  constexpr int MIN_NEWTON = WARM ? QPL_WARM_MIN_NEWTON : QPL_MIN_NEWTON;
   auto fnorm = [](const T* v) __attribute__((always_inline)) -> T {
     T m = 0;
 #pragma unroll
@@ -357,6 +397,7 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
   auto nan6 = [](const T* v) __attribute__((always_inline)) -> bool {   // a NaN (or an Inf - Inf) among the components
     const T t = ((v[0] + v[1]) + (v[2] + v[3])) + (v[4] + v[5]);
     return !(t - t == (T)0); };
+  if constexpr (WARM) conv = code == code0 && !nan6(F);   // the Newton step from the given faces left them unchanged: it IS the solution
   // Live across an iteration: the current point e, F(e) and its faces (no forces: they are recomputed once from the final e).
 #pragma unroll 1
   for (int itn = 0; itn < QPL_MAX_NEWTON; ++itn) {
@@ -366,7 +407,7 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
     const int todo_cnt = __popcll(todo_lanes);
     // beyond the minimum: only while enough lanes are left AND the last iteration finished at least 40 % of those it started with
     // (stances with swing feet leave ~20 % of the lanes in a diverging face cycle that no further full step ends)
-    if (todo_cnt == 0 || (itn >= QPL_MIN_NEWTON && (todo_cnt < QPL_MORE_LANES || 5 * todo_cnt > 3 * prev_cnt))) break;
+    if (todo_cnt == 0 || (itn >= MIN_NEWTON && (todo_cnt < QPL_MORE_LANES || 5 * todo_cnt > 3 * prev_cnt))) break;
     prev_cnt = todo_cnt;
     iters += act ? 1 : 0;
     T eN[6], Ft[6];
@@ -409,6 +450,7 @@ __global__ __launch_bounds__(QPL_WG, (sizeof(T) == 4 ? QPL_F32_WAVES : QPL_F64_W
     }
     a.status[s32] = 0;
     if (a.iters) a.iters[s32] = iters;
+    if (a.aset_out) a.aset_out[s32] = qpl_aset_from_codes(code, mask);
   } else if (live) {
     const int slot = atomicAdd(&todo[0], 1);
     if (slot < (int)a.N) todo[4 + slot] = (int)s32;   // (always, while the count starts a tick at zero: the guard keeps a stale count from writing past the list)

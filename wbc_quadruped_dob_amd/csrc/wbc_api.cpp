@@ -60,7 +60,13 @@ constexpr int ONE_SCRATCH = 200;        // first scalar of the helpers' scratch 
 constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints (the tick uses the first 161)
 
 // thresholds between kernel variants after the options are applied (resolve_options)
-struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, tile_min, lane_min; };
+#ifndef WBC_WARM_LANE_MIN_F64
+#define WBC_WARM_LANE_MIN_F64 53248
+#endif
+#ifndef WBC_WARM_LANE_MIN_F32
+#define WBC_WARM_LANE_MIN_F32 36864
+#endif
+struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, tile_min, lane_min, warm_lane_min; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -323,10 +329,11 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // tiles dealt by predicted work (auto): fp64 from 14 336 states, fp32 from 30 720; per-lane QP pair (auto): fp64 from 106 496, fp32 from 212 992
   r.tile_min = dtype == WBC_F32 ? 30720 : 14336;
   r.lane_min = dtype == WBC_F32 ? 212992 : 106496;
+  r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   return r;
 }
 
-struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block; bool obs_split, lane; };
+struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block, qp_warm; bool obs_split, lane; };
 static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf, bool warm = false) {
   TickPlan p{};
   const bool ob = observer_order > 0, f32 = dtype == WBC_F32;
@@ -334,6 +341,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
     p.fused = 1;
+    p.qp_warm = warm;
     return p;
   }
   // Large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench, 64 QPs
@@ -344,9 +352,16 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // batch: tiles 531 / 483 at 53 248, 533 / 463 at 57 344, 537 / 503 at 65 536, 554 / 520 at 81 920, 546 / 534 at 98 304, pair 527 / 554 at 114 688.
   // fp32 trot batch: tiles 1 043 / 919 at 98 304, 992 / 909 at 131 072, 934 / 911 at 196 608, pair 907 / 951 at 229 376.
   // Hence the default: fp64 from 106 496 states on, fp32 from 212 992 (history of the threshold: DESIGN.md 4.3a).
-  // wbc_step_batch_warm (dependent ticks): every state starts from its previous active set, so the rows of a wavefront do about equal
-  // work and most take zero or one iteration -- the one-wavefront kernel with the block set-up, no dealing by predicted work, no per-lane pair
-  p.lane = !warm && (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.lane_min));
+  // wbc_step_batch_warm (dependent ticks), beyond the fused size.  Below tile_min the one-wavefront kernel with the block set-up
+  // (qp_struct16.hip.hpp); from warm_lane_min on the per-lane kernel started from the previous FACES (one Newton step confirms them;
+  // qp_lane.hip.hpp) with the hand-over list behind it; in between the COLD tiles, which only report the sets (qp_warm = 0): the warm
+  // one-wavefront kernel holds 232-252 registers and loses to them there, and the per-lane pair has a floor of two dependent launches (a
+  // wavefront of the lane kernel 14-19 us, then the hardest handed-over state's cold solve, 11-15 us).  Closed loops of drifting states on
+  // MI355X, tick in us, cold tiles / warm one-wavefront / warm per-lane: fp64 observer on 36 864: 82.6 / 91.0 / 89.7, 49 152: 102.4 / 110.5 /
+  // 104.8, 57 344: 124.2 / 133.3 / 121.4, 65 536: 135 / 148 / 129, 262 144: 474 / 533 / 414; fp64 observer off 32 768: 63.8 / 61.9 / 71.7,
+  // 49 152: 88.3 / 85.5 / 87.9, 65 536: 120 / 115 / 108, 98 304: 168 / 170 / 153; fp32 (QP stage alone) 36 864: 35.5 / 36.3 / 32.4,
+  // 57 344: 42.7 / 50.6 / 34.2, 98 304: 64.9 / 80.6 / 41.4, whole tick 262 144: 300 / 378 / 230.  wbc_solver_options.qp_lane = -1 / 1 forces either.
+  p.lane = warm ? (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.warm_lane_min)) : (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.lane_min));
   if (!mats) p.front = 1;                                   // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
   else if (ob && N >= r.obs_split_min) { p.front = 2; p.obs_split = true; }   // observer kernel + observer-free sweep
   else p.front = 0;
@@ -368,7 +383,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
   // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
   // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
-  int tile = warm ? -1 : o.qp_tile;
+  int tile = warm ? (o.qp_tile == 0 && !(f32 && N > 65536) ? 0 : -1) : o.qp_tile;   // (warm: the auto tiles only, and never the fp32 12 x 12 body, which reports no set)
   if (tile == 0) {
     if (f32) {
       if (N >= r.tile_min && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
@@ -384,6 +399,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   if (tile < 0) tile = 0;
   if (p.lane) { p.qp = 2; p.tile = 0; }
   else { p.qp = tile > 0 ? 1 : 0; p.tile = tile; }
+  p.qp_warm = warm && p.qp != 1;
   p.qp_body = (p.qp == 1 && f32 && tile >= 64 && tile <= 128 && N >= (size_t)WBC_F32_DENSE_TILE_MIN) ? 1 : 0;
   return p;
 }
@@ -403,6 +419,7 @@ static void plan_to_public(const TickPlan& p, wbc_tick_plan* out) {
   std::memset(&t, 0, sizeof(t));
   t.struct_size = sizeof(t);
   t.fused = p.fused; t.front = p.front; t.qp = p.qp; t.qp_tile = p.tile; t.qp_body = p.qp_body; t.sweep_pack2 = p.pack2; t.sweep_block = p.sweep_block;
+  t.qp_warm = p.qp_warm;
   const size_t n = out->struct_size && out->struct_size < sizeof(t) ? out->struct_size : sizeof(t);
   std::memcpy(out, &t, n);
   out->struct_size = n;
@@ -420,22 +437,24 @@ extern "C" int wbc_plan_tick(int dtype, int observer_order, const wbc_solver_opt
 
 // the batch sizes N at which plan(N) differs from plan(N - 1), ascending (the one-round tile SIZE is not a switch of kernel family
 // and is left out: it steps every 3 072 / 6 144 / 8 192 states)
-extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_solver_options* opt, int with_mats, size_t* out, int cap, int* n) {
+extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_solver_options* opt, int flags, size_t* out, int cap, int* n) {
+  const int with_mats = flags & WBC_PLAN_WITH_MATS;
+  const bool warm = (flags & WBC_PLAN_WARM) != 0;
   if (!n || (cap > 0 && !out) || (dtype != WBC_F64 && dtype != WBC_F32) || observer_order < 0 || observer_order > 2) return fail(WBC_E_INVALID, "bad argument");
   wbc_solver_options o;
   const int rc = options_from_caller(opt, o);
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_lane_min, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537};
   size_t keep[16]; int k = 0;
   for (size_t c : cand) {
     if (c < 2 || c == (size_t)-1 || c > ((size_t)1 << 21)) continue;
     // an odd N never packs: compare like with like (both even) for the fp32 sweep, plain neighbours otherwise
     auto same = [&](size_t a, size_t b) {
-      const TickPlan x = plan_tick(dtype, observer_order, o, r, a, with_mats != 0, true), y = plan_tick(dtype, observer_order, o, r, b, with_mats != 0, true);
-      return x.fused == y.fused && x.front == y.front && x.qp == y.qp && x.qp_body == y.qp_body && x.pack2 == y.pack2 && x.sweep_block == y.sweep_block;
+      const TickPlan x = plan_tick(dtype, observer_order, o, r, a, with_mats != 0, true, warm), y = plan_tick(dtype, observer_order, o, r, b, with_mats != 0, true, warm);
+      return x.fused == y.fused && x.front == y.front && x.qp == y.qp && x.qp_body == y.qp_body && x.pack2 == y.pack2 && x.sweep_block == y.sweep_block && x.qp_warm == y.qp_warm;
     };
     const bool changes = (c % 2 == 0) ? !same(c - 2, c) : !same(c - 1, c + 1);
     if (!changes) continue;
@@ -741,7 +760,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   a.ws_geom = mats ? 0 : 1;
   const DevParams<T> dp = to_dev_params<T>(s->params);
   const TickPlan pl = plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, mats, out->pf != nullptr, warm_api);   // (what runs, and why: plan_tick)
-  const bool warm = warm_api && aset_in != nullptr;   // (no set to start from: the cold kernels, which still report the final set)
+  const bool warm = warm_api && aset_in != nullptr && pl.qp_warm;   // (no set to start from, or a size where the cold tiles win: the cold kernels, which still report the final set)
   if (pl.fused) {
     TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap, warm));
     keep.written();
@@ -774,8 +793,8 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   }
   keep.written();
   if (pl.lane) {
-    TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, pl.obs_split, dp, qa, s->jmap, s->d_todo));
-    TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, 0, dp, qa, s->jmap, s->d_todo));
+    TIMED_LAUNCH(4, st, "qp_lane", k_qp_lane<T>(L, pl.obs_split, dp, qa, s->jmap, s->d_todo, warm));
+    TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, 0, dp, qa, s->jmap, s->d_todo, warm));
     return WBC_OK;
   }
   TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, pl.tile, dp, qa, s->jmap, nullptr, warm));
