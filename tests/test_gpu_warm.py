@@ -255,3 +255,53 @@ def test_warm_tick_is_graph_capturable_and_carries_its_sets(torch_cuda, gpu_mode
     np.testing.assert_array_equal(o["status"].cpu().numpy(), ref["status"])
     assert relerr(to_host(o["tau"]), ref["tau"]) < TIGHT64
     assert it0.sum() > 0 and np.all(o["iters"].cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 1, 3, 6000), ("f64", 1, 3, 24000), ("f64", 0, 2, 60000), ("f32", 1, 4, 45000)])
+def test_closed_loop_of_warm_ticks_follows_the_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
+    """Six dependent ticks of a drifting batch with ONE carried set buffer (active_in = active_out), tau / f fed back as tau_prev / f_prev and the
+    observer state advancing in place -- fused tick, reporting tiles and the warm per-lane pair (whose handed-over states get their sets from the
+    list kernel): every tick equals the oracle's cold tick on the same inputs, and the carried sets stay the oracle's on regular vertices."""
+    torch = torch_cuda
+    nd = _np_dtype(dtype)
+    c = lambda a: np.ascontiguousarray(a, nd)
+    solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
+    P0 = synth.default_params(observer_order=obs, dtype=dtype)
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=17)
+    B["w_des"][:, 0:2] += np.random.default_rng(6).uniform(-50, 50, (n, 2))
+    ig_o = r_o = ig = rr = None
+    td = torch.float64 if dtype == "f64" else torch.float32
+    if obs:
+        ig_o = c(oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]); r_o = c(np.zeros((n, 18)))
+        ig, rr = to_dev(ig_o, torch, td), to_dev(r_o, torch, td)
+    tp_o, fp_o = c(B["tau_prev"]), c(B["f_prev"])
+    tp, fp = to_dev(tp_o, torch, td), to_dev(fp_o, torch, td)
+    act = torch.zeros(n, dtype=torch.int32, device="cuda")
+    tol = TIGHT64 if dtype == "f64" else 2e-3
+    zero_iter = []
+    for k in range(6):
+        if k:
+            B = _second_tick(B, 100 + k)
+        ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], tp_o, fp_o, ig_o, r_o, nthreads=8)
+        ins, mask, _ = _dev_inputs(torch, B, dtype)
+        o = solver.step(*ins, mask, tp, fp, ig, rr, want_mats=True, active_in=act, out={"active": act})
+        torch.cuda.synchronize()
+        st = o["status"].cpu().numpy()
+        if dtype == "f64":
+            np.testing.assert_array_equal(st, ref["status"], err_msg="tick %d" % k)
+        ok = (st == 0) & (ref["status"] == 0)
+        assert ok.mean() > (0.999 if dtype == "f64" else 0.995), k
+        for key in ("tau", "f"):
+            assert relerr(to_host(o[key])[ok], ref[key][ok]) < tol, (k, key)
+        if obs:
+            assert relerr(to_host(rr), r_o) < tol, k
+        fn = np.einsum("nka,nka->nk", ref["f"].reshape(n, 4, 3).astype(np.float64), B["normals"].reshape(n, 4, 3))
+        stance = ((B["mask"][:, None] >> np.arange(4)[None, :]) & 1) == 1
+        regular = np.all(~stance | (fn > 1e-3), axis=1) & ok
+        same_set = act.cpu().numpy().astype(np.uint32)[regular] == ref["aset"][regular]
+        assert same_set.mean() > (0.9999 if dtype == "f64" else 0.99), (k, same_set.mean())
+        zero_iter.append(float(np.mean(o["iters"].cpu().numpy()[ok] == 0)))
+        tp, fp = o["tau"].clone(), o["f"].clone()                  # the loop: this tick's outputs are the next tick's tau_prev / f_prev
+        tp_o, fp_o = ref["tau"], ref["f"]
+    if solver.plan_tick(n, warm=True)["qp_warm"]:
+        assert min(zero_iter[1:]) > 0.5, zero_iter                 # the carried sets do their job from the second tick on
