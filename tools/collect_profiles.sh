@@ -17,7 +17,7 @@ for f in bench_scale_legs_1rank_graph bench_cfg5_h20_n1024_cold bench_cfg5_track
   [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
 done
 [ -f "$O/stats_qp_general_kernel_stats.csv" ] && cp "$O/stats_qp_general_kernel_stats.csv" "$P/${T}_kernel_stats_qp_general.csv"
-for f in issue_probe tile_sweep midrange midrange_f64 midrange_f32 warm_loop warm_timing; do [ -f "$O/$f.log" ] && cp "$O/$f.log" "$P/${T}_$f.log"; done
+for f in issue_probe tile_sweep midrange midrange_f64 midrange_f32 warm_loop warm_loop_large warm_timing soak; do [ -f "$O/$f.log" ] && cp "$O/$f.log" "$P/${T}_$f.log"; done
 [ -f "$O/stats_cfg4_n262144_kernel_stats.csv" ] && cp "$O/stats_cfg4_n262144_kernel_stats.csv" "$P/${T}_kernel_stats_cfg4_f32_n262144.csv"
 [ -f "$O/stats_dyn_f32_kernel_stats.csv" ] && cp "$O/stats_dyn_f32_kernel_stats.csv" "$P/${T}_kernel_stats_dyn_alone_f32_n262144.csv"
 [ -f "$O/stats_dyn_f32_n32768_kernel_stats.csv" ] && cp "$O/stats_dyn_f32_n32768_kernel_stats.csv" "$P/${T}_kernel_stats_dyn_alone_f32_n32768.csv"

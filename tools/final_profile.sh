@@ -20,6 +20,9 @@ WBC_BENCH_GRAPH_GATHER=1 WBC_BENCH_FORCE_DIST=1 timeout 240 python -m torch.dist
 WBC_ROLLOUT_WARM=0 python bench.py --config 5 --steps 100 --warmup 10 --no-cpu > "$O/bench_cfg5_h20_n1024_cold.json" 2>> "$O/bench.err"
 WBC_ROLLOUT_WARM=0 python bench.py --config 5 --tracking --steps 100 --warmup 10 --no-cpu > "$O/bench_cfg5_tracking_h20_n1024_cold.json" 2>> "$O/bench.err"
 python tools/warm_loop.py 1024 4096 8192 > "$O/warm_loop.log" 2>> "$O/bench.err"
+# large closed loops: cold tick / warm one-wavefront kernel / warm per-lane pair (the planner's warm thresholds come from this table)
+WARM_LOOP_LANE=1 timeout 900 python tools/warm_loop.py 16384 32768 49152 65536 131072 262144 > "$O/warm_loop_large.log" 2>> "$O/bench.err"
+timeout 600 python tools/soak.py 1000 51 f64 2>&1 | tail -1 > "$O/soak.log"; timeout 600 python tools/soak.py 400 52 f32 2>&1 | tail -1 >> "$O/soak.log"
 python tools/warm_timing.py > "$O/warm_timing.log" 2>> "$O/bench.err"
 bash tools/ab_sweep.sh "2 3" "49152 65536 98304 114688" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f64.log" 2>&1
 bash tools/ab_sweep.sh "4" "98304 163840 229376" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f32.log" 2>&1
