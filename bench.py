@@ -137,6 +137,8 @@ def main():
                          "took 2 %% off `value`; a prime, so that with short blocks the samples fall on every position of a block)")
     ap.add_argument("--large-batch", type=int, default=262144, help="extra roofline characterisation batch (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-state latency leg (p50 over 1000 ticks)")
+    ap.add_argument("--closed-loop", action="store_true",
+                    help="extra leg: dependent ticks of a DRIFTING batch, cold start against wbc_step_batch_warm (reported beside `value`)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without torchrun: ONE process drives N devices through the C-ABI's wbc_multi_* path")
     args = ap.parse_args()
@@ -365,6 +367,8 @@ def main():
             # four of five devices probed, 208-213 us on the fifth): which kind this run drew, by the sweep's own time
             res["device"]["pool_class"] = "fast" if lb_["avg_launch_us"] <= 196.0 else "slow"
             res["device"]["pool_class_basis"] = "dyn_sweep<double, 11> at 262 144 states: %.1f us (<= 196 us = fast)" % lb_["avg_launch_us"]
+        if args.closed_loop and world == 1:
+            res["closed_loop"] = closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, local_rank, want_mats)
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
             fl = res["cpu_baseline"].get("flops_per_step")
@@ -391,6 +395,66 @@ def main():
         print_line(res)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, device, want_mats, ticks=200):
+    """Dependent ticks: the joint angles and the commanded wrench of every state move between ticks (two elementwise kernels), so the tick's
+    inputs are never those of the previous tick.  The same loop twice -- wbc_step_batch (cold start) and wbc_step_batch_warm (every QP starts
+    from the active set the previous tick ended on, carried in one int32 buffer).  `value` of the main line stays the cold tick on standing
+    inputs; this leg says what a control loop over the same batch gets."""
+    import time
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    dq = 1e-3 * torch.randn((12, n), dtype=td, device="cuda", generator=gen)
+    dw = 0.2 * torch.randn((6, n), dtype=td, device="cuda", generator=gen)
+    dqn, dwn = -dq, -dw
+    res = {}
+    for tag, warm in (("cold", False), ("warm", True)):
+        solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=device, max_batch=n)
+        inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+        mask = torch.from_numpy(B["mask"]).cuda()
+        integ = rr = None
+        if obs:
+            integ = solver.dynamics(inp["q"], inp["v"], want=("p",))["p"].clone()
+            rr = torch.zeros_like(integ)
+        tick, out = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"],
+                                        inp["f_prev"], integ, rr, want_mats=want_mats, warm=warm)
+        qj = inp["q"][7:]
+
+        def loop(k, with_tick=True):
+            for i in range(k):
+                qj.add_(dq if i % 2 == 0 else dqn)
+                inp["w_des"].add_(dw if i % 2 == 0 else dwn)
+                if with_tick:
+                    tick()
+        loop(20)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            loop(ticks)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        t0 = time.perf_counter()
+        loop(ticks, with_tick=False)
+        torch.cuda.synchronize()
+        drift = time.perf_counter() - t0
+        solver.enable_timing(7)
+        loop(210)
+        torch.cuda.synchronize()
+        tm = solver.collect_timing()
+        solver.enable_timing(0)
+        kern = {k[:-3] + "_us": v * 1e3 / max(1, tm[k[:-3] + "_launches"]) for k, v in tm.items() if k.endswith("_ms") and v > 0}
+        res[tag] = {"us_per_tick": best / ticks * 1e6, "value": n * ticks / best, "drift_kernels_alone_us_per_tick": drift / ticks * 1e6,
+                    "tick_kernels_us": kern, "kernels_sum_us": sum(kern.values()), "qp_iters_mean": float(out["iters"].double().mean()),
+                    "status_ok_frac": float((out["status"] == 0).double().mean()), "plan": solver.plan_tick(n, want_mats=want_mats, warm=warm)}
+    res["speedup_wall"] = res["cold"]["us_per_tick"] / res["warm"]["us_per_tick"]
+    res["unit"] = "control-steps/s"
+    res["note"] = ("best of 3 blocks of %d dependent ticks, wall time incl. the two drift kernels per tick (timed alone beside it); tick_kernels_us: the "
+                   "tick's own kernels by their dispatch events, every 7th tick; plan.qp_warm = 0: at this size the cold tiles are the faster QP kernels "
+                   "and the warm tick only carries the sets (DESIGN.md 4.2b)" % ticks)
+    return res
 
 
 def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch):

@@ -355,6 +355,10 @@ int wbc_multi_set_params(wbc_multi* mm, const wbc_params* p);
  * count.  Enqueues every shard on its stream and returns without synchronising. */
 int wbc_multi_step_batch(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out,
                          const wbc_observer_state* obs);
+/* wbc_step_batch_warm per shard (a sharded closed loop): active[k] = shard k's carried active sets, int32 [count_k] on devices[k],
+ * read as the start of this tick's QPs and rewritten in place with the sets they end on (all zero = cold) */
+int wbc_multi_step_batch_warm(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out,
+                              const wbc_observer_state* obs, int* const* active);
 /* wbc_rollout_batch per shard (BASELINE.json configs[4]: rank-local for all ticks); tau_ext[k] may be NULL (as may tau_ext) */
 int wbc_multi_rollout_batch(wbc_multi* mm, size_t n_total, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                             const wbc_observer_state* obs, const void* const* tau_ext);

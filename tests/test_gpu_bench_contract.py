@@ -111,3 +111,19 @@ def test_config5_line_carries_roofline_and_cpu_baseline():
     assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["flops_per_tick"] > 1e4
     assert c["qp_iters_per_tick"] < c["qp_iters_per_tick_cold"]
     assert d["qp"]["status_ok_frac_last_tick"] == 1.0
+
+
+def test_closed_loop_leg_reports_cold_and_warm_ticks_of_a_drifting_batch():
+    """--closed-loop adds the dependent-tick leg BESIDE `value` (which stays the cold tick on standing inputs): same batch, inputs rewritten
+    every tick, wbc_step_batch against wbc_step_batch_warm; both loops solve every QP, the warm one in fewer iterations."""
+    d = one_line([sys.executable, "bench.py", "--steps", "50", "--warmup", "5", "--large-batch", "0", "--no-latency", "--no-cpu", "--closed-loop"])
+    check_common(d, 50, 5)
+    cl = d["closed_loop"]
+    for tag in ("cold", "warm"):
+        leg = cl[tag]
+        assert leg["status_ok_frac"] > 0.999 and leg["us_per_tick"] > leg["drift_kernels_alone_us_per_tick"] * 0.5
+        assert abs(leg["value"] - 4096 / (leg["us_per_tick"] * 1e-6)) <= 1e-6 * leg["value"]
+        assert leg["plan"]["fused"] == 1 and "fused_us" in leg["tick_kernels_us"]
+    assert cl["warm"]["plan"]["qp_warm"] == 1 and cl["cold"]["plan"]["qp_warm"] == 0
+    assert cl["warm"]["qp_iters_mean"] < 0.3 * cl["cold"]["qp_iters_mean"]
+    assert cl["warm"]["tick_kernels_us"]["fused_us"] < cl["cold"]["tick_kernels_us"]["fused_us"]

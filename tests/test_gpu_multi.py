@@ -115,6 +115,64 @@ def test_abi_smoke_cpp_program_runs(torch_cuda, consumer):
     assert "wbc_qp_dense_batch: status=0 x=(0.800000 0.200000)" in run.stdout      # the general dense QP from plain C++
 
 
+@pytest.mark.parametrize("obs,n", [(1, 9001), (0, 100000), (0, 180000)])
+def test_sharded_closed_loop_of_warm_ticks(torch_cuda, gpu_model, obs, n):
+    """wbc_multi_step_batch_warm: every shard carries its own active sets.  Four dependent ticks of a drifting batch on three shards
+    (3 000 states per shard: fused warm ticks; 33 333: cold tiles that only report the sets; 60 000: the warm per-lane pair) against ONE
+    solver's cold ticks over the whole batch."""
+    import wbc_quadruped_dob_amd as W
+    torch = torch_cuda
+    ndev = torch.cuda.device_count()
+    devices = [k % ndev for k in range(3)]
+    P = synth.default_params(observer_order=obs)
+    prm = W.Params.from_dict(P)
+    B = synth.make_batch(3, n, gpu_model.total_mass, rank=31)
+    B["w_des"][:, 0:2] += np.random.default_rng(4).uniform(-50, 50, (n, 2))
+    td = torch.float64
+    full = {k: to_dev(B[k], torch, td) for k in ROWS}
+    mask = torch.from_numpy(B["mask"]).cuda()
+    single = W.Solver(gpu_model, prm, device=0, max_batch=n, options={})
+    ig = rr = None
+    if obs:
+        ig = single.dynamics(full["q"], full["v"], want=("p",))["p"].clone()
+        rr = torch.zeros_like(ig)
+    ms = W.MultiSolver(gpu_model, prm, devices=devices, max_batch_total=n, gather="none", options={})
+    ins = {k: ms.scatter(full[k], ROWS[k], n) for k in ROWS}
+    ins["mask"] = ms.scatter(mask, 1, n)
+    obs_state = (ms.scatter(ig, 18, n), ms.scatter(rr, 18, n)) if obs else None
+    tick, outs = ms.prepare_step(n, ins, obs_state, warm=True)
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    zero_iter = []
+    for k in range(4):
+        if k:   # the robots and the commands move; the same drift goes to the single solver's inputs and to the shards'
+            dq = 5e-3 * torch.randn((12, n), dtype=td, device="cuda", generator=gen)
+            dw = 1.0 * torch.randn((6, n), dtype=td, device="cuda", generator=gen)
+            full["q"][7:] += dq
+            full["w_des"] += dw
+            torch.cuda.synchronize()
+            for j in range(ms.n):
+                st, cnt = W.shard_range(n, ms.n, j)
+                ins["q"][j].copy_(full["q"][:, st:st + cnt])
+                ins["w_des"][j].copy_(full["w_des"][:, st:st + cnt])
+            ms.sync_torch_streams()
+        ref = single.step(full["q"], full["v"], full["w_des"], full["vdot_des"], full["normals"], full["mu"], mask, full["tau_prev"], full["f_prev"], ig, rr)
+        torch.cuda.synchronize()
+        tick()
+        ms.synchronize()
+        got = {key: torch.cat([o[key].to("cuda:0") for o in outs], dim=-1) for key in ("tau", "f", "status", "iters")}
+        assert torch.equal(got["status"], ref["status"]), k
+        ok = (ref["status"] == 0)
+        for key in ("tau", "f"):
+            a, b = got[key][:, ok], ref[key][:, ok]
+            assert float((a - b).abs().max() / b.abs().max()) < 1e-9, (k, key)
+        if obs:
+            assert float((torch.cat([x.to("cuda:0") for x in obs_state[1]], dim=-1) - rr).abs().max()) < 1e-9 * max(1.0, float(rr.abs().max()))
+        zero_iter.append(float((got["iters"][ok] == 0).double().mean()))
+    assert all(int(o["active"].abs().max()) > 0 for o in outs)
+    if W.plan_tick(W.shard_range(n, ms.n, 0)[1], "f64", obs, warm=True)["qp_warm"]:
+        assert min(zero_iter[1:]) > 0.5, zero_iter
+
+
 @pytest.mark.parametrize("obs,gather", [(0, "peer"), (1, "peer"), (1, "rccl"), (0, "rccl")])
 def test_python_multisolver_equals_single_solver(torch_cuda, gpu_model, obs, gather):
     """The binding over wbc_multi_*: shards on the visible devices (device 0 repeated for the peer-copy variant on a 1-GPU

@@ -61,7 +61,7 @@ def test_structured_warm_setup_from_a_given_active_set(oracle, cfg, lateral):
     ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"])
     BIT = (0, 16, 1, 17, 2, 3)
     ids_of = lambda a: [6 * k + c for k in range(4) for c in range(6) if (int(a) >> (4 * k + BIT[c])) & 1]
-    used = refused = 0
+    used = refused = stale = stale_used = stale_it = cold_it = 0
     for i in range(n):
         mk = lambda w: sg.StructuredGI(np.asarray(P["S"], float), P["alpha"], int(B["mask"][i]), dyn["pf"][i].reshape(4, 3) - B["q"][i, :3],
                                        B["normals"][i].reshape(4, 3), B["mu"][i] * P["mu_scale"], P["fn_min"], P["fn_max"], w, tol=P["qp_tol"],
@@ -78,6 +78,20 @@ def test_structured_warm_setup_from_a_given_active_set(oracle, cfg, lateral):
         xw, itw, stw, _ = s2.solve(warm=ids_of(ref["aset"][i]))
         assert stw == stc == 0 and np.abs(xw - xc).max() <= 1e-9 * max(1.0, np.abs(xc).max())
         used += int(s2.warm_used)
+        # a STALE set: the true rows plus one the state is not on.  Rows whose multiplier comes out negative are dropped and the set-up
+        # repeated on the smaller set -- an S-pair next to the solution, where a cold restart pays one iteration per active row
+        true_ids = ids_of(ref["aset"][i])
+        extra = [6 * k + c for k in range(4) if (int(B["mask"][i]) >> k) & 1 for c in (0, 1, 2, 3, 4)
+                 if 6 * k + c not in true_ids and sum(1 for t in true_ids if t // 6 == k) < 3 and not (c == 4 and 6 * k + 5 in true_ids)
+                 and not (c % 2 == 0 and c < 4 and 6 * k + c + 1 in true_ids) and not (c % 2 == 1 and c < 4 and 6 * k + c - 1 in true_ids)]
+        if extra:
+            s4 = mk(B["w_des"][i])
+            x4, it4, st4, _ = s4.solve(warm=true_ids + [extra[i % len(extra)]])
+            assert st4 == 0 and np.abs(x4 * on - ref["f"][i]).max() <= 1e-9 * max(1.0, np.abs(ref["f"][i]).max())
+            stale += 1
+            stale_used += int(s4.warm_used)
+            stale_it += it4
+            cold_it += int(ref["iters"][i])
         # no S-pair: both bounds of one normal force; all six rows of a foot
         k0 = [k for k in range(4) if (int(B["mask"][i]) >> k) & 1]
         if k0:
@@ -87,3 +101,4 @@ def test_structured_warm_setup_from_a_given_active_set(oracle, cfg, lateral):
                 assert not s3.warm_used and st3 == 0 and np.abs(x3 * on - ref["f"][i]).max() <= 1e-9 * max(1.0, np.abs(ref["f"][i]).max())
                 refused += 1
     assert used > n // 2 and refused > 0
+    assert stale > n // 2 and stale_used >= 0.75 * stale and stale_it < 0.6 * cold_it, (stale, stale_used, stale_it, cold_it)

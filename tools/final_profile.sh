@@ -22,6 +22,10 @@ WBC_ROLLOUT_WARM=0 python bench.py --config 5 --tracking --steps 100 --warmup 10
 python tools/warm_loop.py 1024 4096 8192 > "$O/warm_loop.log" 2>> "$O/bench.err"
 # large closed loops: cold tick / warm one-wavefront kernel / warm per-lane pair (the planner's warm thresholds come from this table)
 WARM_LOOP_LANE=1 timeout 900 python tools/warm_loop.py 16384 32768 49152 65536 131072 262144 > "$O/warm_loop_large.log" 2>> "$O/bench.err"
+# the closed-loop leg of the bench line (cold against warm ticks of a drifting batch), small and large batches
+for spec in "2 4096" "3 8192" "3 65536" "3 262144" "4 262144"; do set -- $spec
+  python bench.py --config $1 --batch $2 --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --closed-loop > "$O/bench_closed_loop_cfg$1_n$2.json" 2>> "$O/bench.err"
+done
 timeout 600 python tools/soak.py 1000 51 f64 2>&1 | tail -1 > "$O/soak.log"; timeout 600 python tools/soak.py 400 52 f32 2>&1 | tail -1 >> "$O/soak.log"
 python tools/warm_timing.py > "$O/warm_timing.log" 2>> "$O/bench.err"
 bash tools/ab_sweep.sh "2 3" "49152 65536 98304 114688" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f64.log" 2>&1

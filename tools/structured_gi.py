@@ -79,7 +79,8 @@ class StructuredGI:
         """Block set-up from a GIVEN active set (what csrc/qp_struct16.hip.hpp does for dependent ticks): per-foot projectors and
         pseudo-inverses in closed form, G_A factorised directly, the minimiser ON the set and its multipliers
             f_k = f_k^p - P_k B_k^T y,   f_k^p = N_k^+T rhs_k,   G_A y = sum_k B_k f_k^p - beta,   u_k = alpha N_k^+ (f_k + B_k^T y).
-        Returns None when the set is no S-pair of the dual method: more than three rows on a foot, dependent rows, a negative multiplier."""
+        Returns None when the set is no S-pair of the dual method (more than three rows on a foot, dependent rows), and the list of rows
+        with a negative multiplier when there are any (the caller retries once without them)."""
         a, B = self.alpha, self.B
         act = [[] for _ in range(4)]
         for c in sorted(ids):
@@ -105,8 +106,9 @@ class StructuredGI:
             if act[k]:
                 for c, val in zip(act[k], a * (Np[k] @ (f[k] + B[k].T @ y))):
                     u[c] = val
-        if any(not (val >= 0) for val in u.values()):
-            return None
+        neg = [c for c, val in u.items() if not (val >= 0)]
+        if neg:
+            return neg
         return act, P, Np, Ginv, np.concatenate(f), u
 
     def solve(self, warm=None):
@@ -119,6 +121,9 @@ class StructuredGI:
         Ginv = np.linalg.inv(self.G(P))
         x = np.concatenate([B[k].T @ (Ginv @ self.beta) for k in range(4)])   # unconstrained minimum B^T G^-1 S^(1/2) b
         ws = self.warm_setup(warm) if warm is not None else None
+        if isinstance(ws, list):      # rows with negative multipliers (constraints the state has just left): once more without them, else cold
+            ws = self.warm_setup([c for c in warm if c not in ws])
+            ws = None if isinstance(ws, list) else ws
         self.warm_used = ws is not None
         if ws is not None:
             act, P, Np, Ginv, x, u = ws

@@ -209,6 +209,7 @@ def lib():
         L.wbc_multi_rccl_ranks.argtypes = [C.c_void_p]
         L.wbc_multi_set_params.argtypes = [C.c_void_p, C.c_void_p]
         L.wbc_multi_step_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wbc_multi_step_batch_warm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wbc_multi_rollout_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wbc_multi_allgather_tau.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.wbc_multi_synchronize.argtypes = [C.c_void_p]
@@ -681,10 +682,11 @@ class MultiSolver:
             outs.append(x.to(dtype) if dtype is not None else x)
         return outs
 
-    def prepare_step(self, n_total, ins, obs=None, want_mats=False):
+    def prepare_step(self, n_total, ins, obs=None, want_mats=False, warm=False):
         """ins: dict name -> list of per-shard tensors (q, v, w_des, vdot_des, normals, mu, mask[, tau_prev, f_prev]);
         obs: (list integ, list r) or None.  Returns (tick, outs): tick() enqueues one control tick on every shard
-        (wbc_multi_step_batch), outs is a list of per-shard output dicts."""
+        (wbc_multi_step_batch), outs is a list of per-shard output dicts.  warm: wbc_multi_step_batch_warm -- every shard carries
+        its active sets in outs[k]["active"] (int32 [count_k], zero = cold) from tick to tick."""
         torch, m = self.torch, self.model
         BI, BO, OS = (_BatchIn * self.n)(), (_BatchOut * self.n)(), (_ObsState * self.n)()
         outs, keep = [], []
@@ -706,17 +708,21 @@ class MultiSolver:
             BO[k] = _BatchOut(p(o["tau"]), p(o["f"]), p(o["status"]), p(o["iters"]), p(o.get("M")), p(o.get("h")), p(o.get("Jc")), p(o.get("pf")))
             if obs is not None:
                 OS[k] = _ObsState(p(obs[0][k]), p(obs[1][k]))
+            if warm:
+                o["active"] = torch.zeros(max(cnt, 1), dtype=torch.int32, device=d)[:cnt]
             outs.append(o)
-        keep = (ins, obs, outs, BI, BO, OS)
+        ACT = (C.c_void_p * self.n)(*[o["active"].data_ptr() if warm else None for o in outs])
+        keep = (ins, obs, outs, BI, BO, OS, ACT)
         fn, h, has_obs = lib().wbc_multi_step_batch, self._h, obs is not None
+        fn_warm = lib().wbc_multi_step_batch_warm
         # The shard streams are library-created non-blocking streams: nothing orders them behind the torch streams that
         # produced these buffers (scatter()'s copies, the zero-fills above, a caller's observer state).  One-off cost.
         self.sync_torch_streams()
 
         def tick(_keep=keep):
-            rc = fn(h, n_total, BI, BO, OS if has_obs else None)
+            rc = fn_warm(h, n_total, BI, BO, OS if has_obs else None, ACT) if warm else fn(h, n_total, BI, BO, OS if has_obs else None)
             if rc:
-                _check(rc, "wbc_multi_step_batch")
+                _check(rc, "wbc_multi_step_batch_warm" if warm else "wbc_multi_step_batch")
         return tick, outs
 
     def allgather_tau(self, n_total, outs, tau_all=None):

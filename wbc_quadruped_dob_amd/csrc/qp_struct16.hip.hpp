@@ -244,7 +244,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     }
     const T ec0 = c3 == 0 ? (T)1 : (T)0, ec1 = c3 == 1 ? (T)1 : (T)0, ec2 = c3 == 2 ? (T)1 : (T)0;
 #pragma clang loop unroll(disable)
-    for (int pass = 0; pass < 2; ++pass) {   // (rolled: the second pass is the rare cold fall-back, not a second copy of the set-up in the instruction stream)
+    for (int pass = 0; pass < 3; ++pass) {   // (rolled: the later passes are the rare fall-backs, not more copies of the set-up in the instruction stream)
       // (a) the slots of my foot: candidates in the order A0 A1 A2 A3 B0 B1
       const int a4 = (aset >> (4 * f)) & 0xF, b2 = (aset >> (16 + 4 * f)) & 0x3;
       int m6 = a4 | (b2 << 4);
@@ -387,11 +387,17 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
       x_me = isvar ? x_me : (T)0;
       const T fx = dppx<0x00>(x_me), fy = dppx<0x55>(x_me), fz = dppx<0xAA>(x_me);
       u_s = slot_on ? alpha_l * (Np0 * (fx + w0) + Np1 * (fy + w1) + Np2 * (fz + w2)) : (T)0;
-      // (j) an S-pair?  otherwise this row starts over from the empty set
-      const unsigned long long fb = __ballot(bad || (slot_on && !(u_s >= 0)));
-      const bool row_fail = (unsigned)((fb >> rowbase) & 0xFFFFull) != 0u;
-      aset = row_fail ? 0 : aset;
-      if (fb == 0ull) break;
+      // (j) an S-pair?  A set that is structurally impossible starts over from the empty set.  Rows with NEGATIVE multipliers -- constraints
+      // the state has just left, the common way a carried set goes stale -- are dropped and the set-up repeated on the smaller set (its
+      // minimiser has a lower objective and, nearly always, multipliers >= 0: an S-pair one or no iteration from the solution, where the cold
+      // start pays one iteration per active row); a second failure starts cold, and the empty set cannot fail.
+      const bool neg = slot_on && !(u_s >= 0);
+      const unsigned long long fbad = __ballot(bad), fneg = __ballot(neg);
+      const bool row_bad = (unsigned)((fbad >> rowbase) & 0xFFFFull) != 0u, row_neg = (unsigned)((fneg >> rowbase) & 0xFFFFull) != 0u;
+      int drop = neg ? (1 << (p_me < 4 ? 4 * f + p_me : 16 + 4 * f + (p_me - 4))) : 0;
+      drop |= dppx<0x121>(drop); drop |= dppx<0x122>(drop); drop |= dppx<0x124>(drop); drop |= dppx<0x128>(drop);   // OR over the 16 lanes of my row (row_ror 1, 2, 4, 8)
+      aset = (row_bad || (row_neg && pass > 0)) ? 0 : (aset & ~drop);
+      if ((fbad | fneg) == 0ull) break;
     }
     actA = ((aset >> l16) & 1) != 0;
     actB = hasB && ((aset >> (16 + l16)) & 1) != 0;

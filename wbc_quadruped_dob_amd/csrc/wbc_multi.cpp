@@ -225,6 +225,29 @@ extern "C" int wbc_multi_step_batch(wbc_multi* mm, size_t n_total, const wbc_bat
   return WBC_OK;
 }
 
+// wbc_step_batch_warm per shard: active[k] = shard k's carried active sets (int32 [count_k] on devices[k]), read and rewritten in place
+extern "C" int wbc_multi_step_batch_warm(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out,
+                                         const wbc_observer_state* obs, int* const* active) {
+  if (!mm || !in || !out || !active) return fail(WBC_E_INVALID, "null argument");
+  if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
+  const int n = (int)mm->sh.size();
+  for (int k = 0; k < n; ++k) {   // validate all shards first (see wbc_multi_step_batch)
+    size_t st, cnt;
+    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
+    int rc = wbc::check_step_args(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, false);
+    if (rc) return rc;
+    if (cnt && !active[k]) return fail(WBC_E_INVALID, "null active-set buffer");
+  }
+  for (int k = 0; k < n; ++k) {
+    size_t st, cnt;
+    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
+    int rc = wbc_step_batch_warm(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, active[k], active[k],
+                                 mm->sh[(size_t)k].stream);
+    if (rc) return rc;
+  }
+  return WBC_OK;
+}
+
 extern "C" int wbc_multi_rollout_batch(wbc_multi* mm, size_t n_total, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                                        const wbc_observer_state* obs, const void* const* tau_ext) {
   if (!mm || !in || !out) return fail(WBC_E_INVALID, "null argument");
