@@ -38,7 +38,7 @@ def _second_tick(B, seed):
     return B2
 
 
-@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 0, 2, 1000), ("f64", 1, 3, 4096), ("f64", 0, 2, 9001), ("f64", 2, 4, 24000), ("f64", 1, 3, 70001),
+@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 0, 2, 1000), ("f64", 1, 3, 4096), ("f64", 0, 2, 9001), ("f64", 2, 4, 24000), ("f64", 2, 4, 30000), ("f64", 1, 3, 70001),
                                              ("f64", 0, 2, 53248), ("f32", 1, 4, 3000), ("f32", 0, 2, 33000), ("f32", 0, 2, 40000), ("f32", 1, 3, 150001)])
 def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
     """Two consecutive ticks.  Tick 1 through wbc_step_batch_warm without a set (cold) reports the active sets; tick 2 starts from
@@ -177,7 +177,8 @@ def test_a_wrong_or_impossible_carried_set_still_gives_the_cold_result(torch_cud
 
 
 @pytest.mark.parametrize("cfg,obs,n,H,opt", [(2, 0, 1024, 20, {}), (3, 1, 1000, 20, {}), (3, 1, 777, 12, {"rollout_spw": 16}),
-                                            (4, 2, 5000, 8, {}), (3, 1, 600, 10, {"rollout_persistent": 0})])
+                                            (4, 2, 5000, 8, {}), (3, 1, 600, 10, {"rollout_persistent": 0}),
+                                            (3, 1, 12000, 5, {}), (2, 0, 56000, 4, {})])   # (per-tick launches: warm one-wavefront kernel; warm per-lane pair)
 def test_rollouts_warm_equal_cold_and_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H, opt):
     """wbc_rollout_batch with rollout_warm = 1 (default: ticks after the first start from the previous tick's active set, carried in
     registers by the persistent kernel / through a device buffer by the per-tick launches) against rollout_warm = 0 and the oracle."""
@@ -257,7 +258,7 @@ def test_warm_tick_is_graph_capturable_and_carries_its_sets(torch_cuda, gpu_mode
     assert it0.sum() > 0 and np.all(o["iters"].cpu().numpy() == 0)
 
 
-@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 1, 3, 6000), ("f64", 1, 3, 24000), ("f64", 0, 2, 60000), ("f32", 1, 4, 45000)])
+@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 1, 3, 6000), ("f64", 1, 3, 20000), ("f64", 1, 3, 30000), ("f64", 0, 2, 60000), ("f32", 1, 4, 45000)])
 def test_closed_loop_of_warm_ticks_follows_the_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
     """Six dependent ticks of a drifting batch with ONE carried set buffer (active_in = active_out), tau / f fed back as tau_prev / f_prev and the
     observer state advancing in place -- fused tick, reporting tiles and the warm per-lane pair (whose handed-over states get their sets from the

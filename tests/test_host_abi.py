@@ -239,9 +239,9 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     # options move the switches, and the list follows
     assert W.dispatch_thresholds("f64", 0, options={"qp_lane": -1, "qp_tile": -1, "fused_max": 0}) == [65536]
     # warm-started ticks (wbc_step_batch_warm): fused, warm one-wavefront kernel, cold tiles that only report the sets, warm per-lane pair
-    assert W.dispatch_thresholds("f64", 1, warm=True) == [8193, 14336, 20480, 53248, 65536]
+    assert W.dispatch_thresholds("f64", 1, warm=True) == [8193, 20480, 24576, 53248, 65536]
     assert W.dispatch_thresholds("f32", 1, warm=True) == [8193, 30720, 32768, 33792, 36864, 131072]
-    assert [W.plan_tick(n, "f64", 1, warm=True)["qp_warm"] for n in (4096, 9000, 20000, 60000)] == [1, 1, 0, 1]
-    assert [W.plan_tick(n, "f64", 1, warm=True)["qp"] for n in (9000, 20000, 60000)] == [0, 1, 2]
+    assert [W.plan_tick(n, "f64", 1, warm=True)["qp_warm"] for n in (4096, 9000, 20000, 30000, 60000)] == [1, 1, 1, 0, 1]
+    assert [W.plan_tick(n, "f64", 1, warm=True)["qp"] for n in (9000, 20000, 30000, 60000)] == [0, 0, 1, 2]
 
 

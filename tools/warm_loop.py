@@ -28,7 +28,8 @@ def main():
             res = {}
             variants = [(False, False, {}), (True, True, {})]
             if os.environ.get("WARM_LOOP_LANE") == "1":
-                variants = [(False, False, {}), ("warm16", True, {"qp_lane": -1}), ("warmlane", True, {"qp_lane": 1})]
+                variants = [(False, False, {}), ("warm16", True, {"qp_lane": -1}), ("warmlane", True, {"qp_lane": 1}),
+                            ("warm16f", True, {"qp_lane": -1, "qp_tile": -1})]     # (the last: the warm one-wavefront kernel at every size)
             for tag, warm, opts in variants:
                 solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n, options=opts)
                 inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
@@ -76,10 +77,10 @@ def main():
                 if solver.plan_tick(n, warm=warm)["qp"] == 2:
                     kern["handed_over"] = solver.qp_handover()
                 res[tag] = (el / K * 1e6, el0 / K * 1e6, float(out["iters"].double().mean()), float((out["status"] == 0).double().mean()), kern)
-            if len(variants) == 3:
-                print("cfg%d %s obs%d n=%6d wall us/tick: cold %6.2f  warm, per-lane pair off %6.2f  warm per-lane %6.2f | iters %.2f / %.2f / %.2f | kernels cold %s  warm16 %s  warmlane %s" % (
-                    cfg, dtype, obs, n, res[False][0], res["warm16"][0], res["warmlane"][0], res[False][2], res["warm16"][2], res["warmlane"][2],
-                    res[False][4], res["warm16"][4], res["warmlane"][4]), flush=True)
+            if len(variants) == 4:
+                print("cfg%d %s obs%d n=%6d wall us/tick: cold %6.2f  warm, per-lane pair off %6.2f  warm per-lane %6.2f  warm one-wavefront kernel forced %6.2f | iters %.2f / %.2f / %.2f / %.2f | kernels cold %s  warm16 %s  warmlane %s  warm16f %s" % (
+                    cfg, dtype, obs, n, res[False][0], res["warm16"][0], res["warmlane"][0], res["warm16f"][0], res[False][2], res["warm16"][2], res["warmlane"][2], res["warm16f"][2],
+                    res[False][4], res["warm16"][4], res["warmlane"][4], res["warm16f"][4]), flush=True)
                 continue
             print("cfg%d %s obs%d n=%6d: wall per tick incl. the drift kernels (drift alone %.1f us): cold %6.2f us (iters %.2f)  warm %6.2f us (iters %.2f)  ok %.4f / %.4f  %s  "
                   "tick kernels by dispatch events: cold %s warm %s" % (

@@ -66,7 +66,7 @@ constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints 
 #ifndef WBC_WARM_LANE_MIN_F32
 #define WBC_WARM_LANE_MIN_F32 36864
 #endif
-struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, tile_min, lane_min, warm_lane_min; };
+struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, tile_min, lane_min, warm_tile_min, warm_lane_min; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -329,6 +329,7 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // tiles dealt by predicted work (auto): fp64 from 14 336 states, fp32 from 30 720; per-lane QP pair (auto): fp64 from 106 496, fp32 from 212 992
   r.tile_min = dtype == WBC_F32 ? 30720 : 14336;
   r.lane_min = dtype == WBC_F32 ? 212992 : 106496;
+  r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   return r;
 }
@@ -352,8 +353,8 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // batch: tiles 531 / 483 at 53 248, 533 / 463 at 57 344, 537 / 503 at 65 536, 554 / 520 at 81 920, 546 / 534 at 98 304, pair 527 / 554 at 114 688.
   // fp32 trot batch: tiles 1 043 / 919 at 98 304, 992 / 909 at 131 072, 934 / 911 at 196 608, pair 907 / 951 at 229 376.
   // Hence the default: fp64 from 106 496 states on, fp32 from 212 992 (history of the threshold: DESIGN.md 4.3a).
-  // wbc_step_batch_warm (dependent ticks), beyond the fused size.  Below tile_min the one-wavefront kernel with the block set-up
-  // (qp_struct16.hip.hpp); from warm_lane_min on the per-lane kernel started from the previous FACES (one Newton step confirms them;
+  // wbc_step_batch_warm (dependent ticks), beyond the fused size.  Below warm_tile_min (fp64 24 576 states, fp32 the cold tile_min) the
+  // one-wavefront kernel with the block set-up (qp_struct16.hip.hpp); from warm_lane_min on the per-lane kernel started from the previous FACES (one Newton step confirms them;
   // qp_lane.hip.hpp) with the hand-over list behind it; in between the COLD tiles, which only report the sets (qp_warm = 0): the warm
   // one-wavefront kernel holds 232-252 registers and loses to them there, and the per-lane pair has a floor of two dependent launches (a
   // wavefront of the lane kernel 14-19 us, then the hardest handed-over state's cold solve, 11-15 us).  Closed loops of drifting states on
@@ -361,6 +362,11 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // 104.8, 57 344: 124.2 / 133.3 / 121.4, 65 536: 135 / 148 / 129, 262 144: 474 / 533 / 414; fp64 observer off 32 768: 63.8 / 61.9 / 71.7,
   // 49 152: 88.3 / 85.5 / 87.9, 65 536: 120 / 115 / 108, 98 304: 168 / 170 / 153; fp32 (QP stage alone) 36 864: 35.5 / 36.3 / 32.4,
   // 57 344: 42.7 / 50.6 / 34.2, 98 304: 64.9 / 80.6 / 41.4, whole tick 262 144: 300 / 378 / 230.  wbc_solver_options.qp_lane = -1 / 1 forces either.
+  // Since the set-up drops rows with negative multipliers instead of restarting cold, the warm one-wavefront kernel against the cold tiles
+  // (tick in us, cold / warm one-wavefront): fp64 observer off 16 384: 45.4 / 42.2, 24 576: 52.9 / 49.4, 32 768: 61.8 / 58.0, 49 152: 82.6 / 78.7;
+  // fp64 observer on (a trot batch whose cold solves need 0.9 iterations) 16 384: 46.8 / 45.6, 24 576: 61.8 / 62.2, 32 768: 71.3 / 76.4,
+  // 49 152: 98.2 / 105.0; fp32 16 384: 45.2 / 43.4, 24 576: 53.0 / 52.6, 32 768: 58.0 / 57.8, 49 152: 78.5 / 82.3 -- it depends on how hard
+  // the batch's cold solves are; the default takes it up to 24 576 fp64 states, where it wins or ties on both.
   p.lane = warm ? (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.warm_lane_min)) : (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.lane_min));
   if (!mats) p.front = 1;                                   // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
   else if (ob && N >= r.obs_split_min) { p.front = 2; p.obs_split = true; }   // observer kernel + observer-free sweep
@@ -383,7 +389,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // and a launch with a few workgroups more than that runs a second, nearly empty round -- QP stage at 36 864 fp64 states: tiles of
   // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
   // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
-  int tile = warm ? (o.qp_tile == 0 && !(f32 && N > 65536) ? 0 : -1) : o.qp_tile;   // (warm: the auto tiles only, and never the fp32 12 x 12 body, which reports no set)
+  int tile = warm ? (o.qp_tile == 0 && N >= r.warm_tile_min && !(f32 && N > 65536) ? 0 : -1) : o.qp_tile;   // (warm: the auto tiles only, and never the fp32 12 x 12 body, which reports no set)
   if (tile == 0) {
     if (f32) {
       if (N >= r.tile_min && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
@@ -446,7 +452,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_lane_min, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537};
   size_t keep[16]; int k = 0;
   for (size_t c : cand) {
@@ -929,9 +935,9 @@ extern "C" int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc
   const size_t nj = 12;
   ON_DEVICE(s);
   s->kept_M = nullptr;   // tick 0 writes M, Jc in full whatever an earlier call left there
-  // rollout_warm with per-tick launches: only where the tick is the fused launch.  Beyond it the tiles dealt by predicted work (cold) beat
-  // the one-wavefront warm kernel (32 768 rollouts, MI355X: 85.1 vs 88.8 us per tick)
-  const bool warm_ticks = s->opt.rollout_warm && plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, true, out->pf != nullptr, true).fused;
+  // rollout_warm with per-tick launches: where the planner's warm tick really starts from the sets (fused launch, warm one-wavefront kernel,
+  // warm per-lane pair); in between the cold tiles are the faster kernels (plan_tick)
+  const bool warm_ticks = s->opt.rollout_warm && plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, true, out->pf != nullptr, true).qp_warm;
   for (int t = 0; t < horizon; ++t) {
     s->in_rollout = t > 0;
     // tick t > 0 starts its QPs from the active sets tick t - 1 left in d_aset
@@ -1030,7 +1036,7 @@ extern "C" int wbc_rollout_tracking_batch(wbc_solver* s, size_t N, int horizon, 
   const size_t ts = s->dtype == WBC_F64 ? 8 : 4;
   const size_t nj = 12;
   ON_DEVICE(s);
-  const bool warm_ticks = s->opt.rollout_warm && plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, true, out->pf != nullptr, true).fused;
+  const bool warm_ticks = s->opt.rollout_warm && plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, true, out->pf != nullptr, true).qp_warm;
   for (int t = 0; t < horizon; ++t) {
     void* com = com_traj ? (void*)((char*)com_traj + (size_t)t * 6 * N * ts) : nullptr;
     int rc = wbc_reference_batch(s, N, in->q, in->v, plan, (double)t * s->params.dt, (void*)in->w_des, (void*)in->vdot_des, com,
