@@ -138,7 +138,8 @@ def main():
     ap.add_argument("--large-batch", type=int, default=262144, help="extra roofline characterisation batch (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-state latency leg (p50 over 1000 ticks)")
     ap.add_argument("--closed-loop", action="store_true",
-                    help="extra leg: dependent ticks of a DRIFTING batch, cold start against wbc_step_batch_warm (reported beside `value`)")
+                    help="extra leg: dependent ticks of a DRIFTING batch, cold start against wbc_step_batch_warm, reported beside `value` (opt-in: its "
+                         "cold ticks launch the same kernel symbols as the timed region and would mix into a rocprofv3 --stats summary of the command)")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without torchrun: ONE process drives N devices through the C-ABI's wbc_multi_* path")
     args = ap.parse_args()
@@ -368,7 +369,10 @@ def main():
             res["device"]["pool_class"] = "fast" if lb_["avg_launch_us"] <= 196.0 else "slow"
             res["device"]["pool_class_basis"] = "dyn_sweep<double, 11> at 262 144 states: %.1f us (<= 196 us = fast)" % lb_["avg_launch_us"]
         if args.closed_loop and world == 1:
-            res["closed_loop"] = closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, local_rank, want_mats)
+            try:
+                res["closed_loop"] = closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, local_rank, want_mats)
+            except Exception as e:  # never lose the main line to the optional leg
+                res["closed_loop"] = {"error": repr(e)[:200]}
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
             fl = res["cpu_baseline"].get("flops_per_step")
