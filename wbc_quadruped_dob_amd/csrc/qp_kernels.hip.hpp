@@ -315,9 +315,9 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
 //   * letting the last workgroup of this kernel reset it (one agent-scope atomic per workgroup to count them, an agent-scope
 //     load of the length) serialises on that one address: 8192 workgroups took 330 us instead of 65 us (N = 262 144);
 //   * a one-thread kernel of its own: correct, 4.7 us per tick.
-// (behind the WARM per-lane kernel the list is solved cold as well: starting the listed states from their carried sets was measured --
-//  the hardest state sets the kernel's 11-15 us either way, and the block set-up makes every group longer: 13.2 -> 15.4 us at 32 768 states)
-template <class T, bool RHAT>
+// WARM (behind the WARM per-lane kernel): the listed states start from their carried active sets too -- the states the Newton iteration gives
+// up on are mostly the same from tick to tick, and their sets are the ones this kernel reported the tick before
+template <class T, bool RHAT, bool WARM = false>
 __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_list_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int* __restrict__ list) {
   const int n = min(list[0], (int)a.N);
   const int ngroups = (n + 3) >> 2;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_list_kernel(DevParams<T> 
   for (int g = (int)blockIdx.x; g < ngroups; g += (int)gridDim.x) {
     const int i = 4 * g + row;
     const bool live = i < n;
-    qp_body<T, false, RHAT, 16, true, 1>(prm, a, jmap, nullptr, nullptr, QpWho{live ? (size_t)list[4 + i] : (size_t)0, live});
+    qp_body<T, false, RHAT, 16, true, 1, QpNoIdle, false, WARM ? 1 : 0>(prm, a, jmap, nullptr, nullptr, QpWho{live ? (size_t)list[4 + i] : (size_t)0, live});
   }
 }
 

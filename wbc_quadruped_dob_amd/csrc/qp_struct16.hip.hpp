@@ -61,7 +61,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
                               const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
   using T = double;
   static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
-  static_assert(!(WARM != 0 && (PRE || TILED)), "warm starts run in the one-wavefront and fused kernels");
+  static_assert(!(WARM != 0 && PRE), "warm starts set their blocks up themselves");
   __shared__ S16Lds<T> lds_all[WPB];
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
