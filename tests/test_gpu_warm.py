@@ -285,9 +285,14 @@ def test_closed_loop_of_warm_ticks_follows_the_oracle(torch_cuda, gpu_model, ora
     act = torch.zeros(n, dtype=torch.int32, device="cuda")
     tol = TIGHT64 if dtype == "f64" else 2e-3
     zero_iter = []
+    masks0 = B["mask"].copy()
     for k in range(6):
         if k:
             B = _second_tick(B, 100 + k)
+            # the gait goes on: every third tick the contact pattern of every robot changes (feet lift and land), so carried rows of feet
+            # that are now in the air must be ignored and feet that have just landed start without rows
+            if k % 3 == 0:
+                B["mask"] = np.roll(masks0, 7 * k).astype(masks0.dtype)
         ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], tp_o, fp_o, ig_o, r_o, nthreads=8)
         ins, mask, _ = _dev_inputs(torch, B, dtype)
         o = solver.step(*ins, mask, tp, fp, ig, rr, want_mats=True, active_in=act, out={"active": act})
@@ -310,4 +315,5 @@ def test_closed_loop_of_warm_ticks_follows_the_oracle(torch_cuda, gpu_model, ora
         tp, fp = o["tau"].clone(), o["f"].clone()                  # the loop: this tick's outputs are the next tick's tau_prev / f_prev
         tp_o, fp_o = ref["tau"], ref["f"]
     if solver.plan_tick(n, warm=True)["qp_warm"]:
-        assert min(zero_iter[1:]) > 0.5, zero_iter                 # the carried sets do their job from the second tick on
+        keep = [z for k, z in enumerate(zero_iter) if k and k % 3]
+        assert min(keep) > 0.5, zero_iter                          # the carried sets do their job on every tick that keeps its contact pattern
