@@ -1274,4 +1274,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 6; }  // 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_solver_options.rollout_warm); 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
+extern "C" int wbc_abi_version(void) { return 6; }  // 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_multi_step_batch_warm, wbc_solver_options.rollout_warm, wbc_tick_plan.qp_warm, WBC_PLAN_* flags), wbc_multi_allgather_tau_async / wbc_multi_gather_wait; 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
