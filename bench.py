@@ -186,7 +186,7 @@ def main():
     obs = 0 if args.config == 2 else 1
     td = torch.float64 if dtype == "f64" else torch.float32
     n = args.batch
-    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    model = load_model(W, torch, dist, rank, local_rank)
     P = synth.default_params(observer_order=obs, dtype=dtype)
     solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=local_rank, max_batch=n)
     B = synth.make_batch(args.config, n, model.total_mass, rank=rank)
@@ -399,6 +399,16 @@ def main():
         print_line(res)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def load_model(W, torch, dist, rank, local_rank):
+    """The robot model of this rank.  N > 1: rank 0 reads the description, the flat arrays (< 4 kB) are broadcast once and
+    every other rank builds its model from them (wbc_model_from_flat)."""
+    if dist is None:
+        return W.Model.from_urdf(W.SYNTHETIC_URDF)
+    from wbc_quadruped_dob_amd.sharding import broadcast_model
+    flat = W.Model.from_urdf(W.SYNTHETIC_URDF).flat() if rank == 0 else None
+    return W.Model.from_flat(broadcast_model(flat, dist, device=torch.device("cuda", local_rank)))
 
 
 def closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, device, want_mats, ticks=200):
@@ -792,7 +802,7 @@ def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
     dtype = args.dtype or "f64"
     n = args.batch if args.batch != 4096 else 1024
     H = args.horizon
-    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    model = load_model(W, torch, dist, rank, local_rank)
     r5 = rollout_setup(args, W, synth, torch, np, model, dtype, n, H, rank, local_rank, args.tracking)
     one_rollout, out = r5["one_rollout"], r5["out"]
 

@@ -125,3 +125,52 @@ def test_eight_rank_gloo_ragged_matches_single_process():
     assert err == 0.0
     assert cnt0 == 501
     assert stats["ok"] == ok == n_total and stats["iters_sum"] == isum and stats["iters_max"] == imax
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import wbc_quadruped_dob_amd as W
+        from wbc_quadruped_dob_amd.sharding import broadcast_model
+        # only rank 0 opens the URDF; the others receive the flat arrays and build their model from them
+        mine = W.Model.from_urdf(W.SYNTHETIC_URDF).flat() if rank == 0 else None
+        got = broadcast_model(mine, dist)
+        model = W.Model.from_flat(got)
+        back = model.flat()
+        ref = W.Model.from_urdf(W.SYNTHETIC_URDF).flat()      # (the check only: what this rank would have parsed itself)
+        same = all(np.array_equal(np.asarray(back[k]), np.asarray(ref[k])) for k in
+                   ("parent", "Rt", "rt", "axis", "mass", "com", "Ic", "foot_body", "foot_off", "gravity"))
+        dims = (model.nb, model.nq, model.nv, model.nj, model.nf)
+        t = torch.tensor([1 if same else 0], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            q.put((int(t.item()), dims, abs(model.total_mass - float(ref["mass"].sum()))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_model_constants_are_broadcast_once():
+    """rank 0 reads the robot description, every other rank builds its model from the broadcast flat arrays (one float64
+    vector of < 4 kB) -- bit-identical to parsing the file itself."""
+    from wbc_quadruped_dob_amd.sharding import pack_model, unpack_model, model_vector_len
+    import wbc_quadruped_dob_amd as W
+    flat = W.Model.from_urdf(W.SYNTHETIC_URDF).flat()
+    vec = pack_model(flat)
+    assert len(vec) == model_vector_len(int(flat["nb"]), len(flat["foot_body"])) and vec.nbytes < 4096
+    again = unpack_model(vec)
+    assert all(np.array_equal(np.asarray(again[k]), np.asarray(flat[k])) for k in again if k != "nb")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    same, dims, dm = q.get(timeout=100)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert same == 1 and dims == (13, 19, 18, 12, 4) and dm < 1e-12

@@ -70,6 +70,52 @@ class ShardedBatch:
                     iters_max=int(mx[0]))
 
 
+_FLAT_F64 = ("Rt", "rt", "axis", "mass", "com", "Ic", "foot_off", "gravity")
+
+
+def pack_model(flat):
+    """The flat robot model (Model.flat(): < 4 kB) as ONE float64 vector: [nb, nf, parent(nb), foot_body(nf), Rt, rt, axis, mass, com, Ic,
+    foot_off, gravity] -- the integers are exact in float64."""
+    nb, nf = int(flat["nb"]), len(flat["foot_body"])
+    parts = [np.array([nb, nf], np.float64), np.asarray(flat["parent"], np.float64), np.asarray(flat["foot_body"], np.float64)]
+    parts += [np.asarray(flat[k], np.float64).ravel() for k in _FLAT_F64]
+    return np.concatenate(parts)
+
+
+def unpack_model(vec):
+    vec = np.asarray(vec, np.float64)
+    nb, nf = int(vec[0]), int(vec[1])
+    shapes = dict(Rt=(nb, 9), rt=(nb, 3), axis=(nb, 3), mass=(nb,), com=(nb, 3), Ic=(nb, 6), foot_off=(nf, 3), gravity=(3,))
+    o = dict(nb=nb, parent=vec[2:2 + nb].astype(np.int32), foot_body=vec[2 + nb:2 + nb + nf].astype(np.int32))
+    at = 2 + nb + nf
+    for k in _FLAT_F64:
+        n = int(np.prod(shapes[k]))
+        o[k] = vec[at:at + n].reshape(shapes[k]).copy()
+        at += n
+    assert at == len(vec)
+    return o
+
+
+def model_vector_len(nb, nf):
+    return 2 + nb + nf + nb * (9 + 3 + 3 + 1 + 3 + 6) + nf * 3 + 3
+
+
+def broadcast_model(flat, dist, device=None, src=0):
+    """the model constants are read ONCE (rank `src` parses the URDF) and broadcast; the other ranks build their model from
+    the received flat arrays (Model.from_flat / wbc_model_from_flat) instead of each opening the file.  flat: Model.flat() on rank src,
+    ignored elsewhere.  Returns the flat dict on every rank (bit-identical: one float64 vector, two collectives -- its length, then it)."""
+    import torch
+    if dist is None:
+        return flat
+    mine = dist.get_rank() == src
+    vec = pack_model(flat) if mine else None
+    n = torch.tensor([len(vec) if mine else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    buf = torch.from_numpy(vec).to(device) if mine else torch.empty(int(n.item()), dtype=torch.float64, device=device)
+    dist.broadcast(buf, src=src)
+    return unpack_model(buf.cpu().numpy())
+
+
 def agree_on_steps(k, dist, device=None):
     """Every rank derives its block length from its OWN clock; legs that follow each step with a collective (the all-gather below)
     must run the same number of steps on every rank or they hang.  Returns the maximum of `k` over the ranks (k itself without a
