@@ -154,7 +154,7 @@ typedef struct wbc_tick_plan {
   size_t struct_size; /* in: sizeof of the caller's build (0 = this build's); out: bytes written */
   int fused;          /* 1: the whole tick is ONE fused_tick launch (wavefront roles); everything below is 0 then */
   int front;          /* two-kernel ticks, front half: 0 = dyn_sweep (observer inside when on), 1 = rnea_step (caller passes no M/h/Jc),
-                         2 = observer kernel + observer-free dyn_sweep */
+                         2 = observer kernel + observer-free dyn_sweep, 3 = observer kernel + observer-free rnea_step (no M/h/Jc) */
   int qp;             /* 0 = qp_group16 (one-wavefront workgroups), 1 = qp_tile (tiles dealt by predicted work), 2 = qp_lane + qp_list */
   int qp_tile;        /* states per tile when qp == 1 */
   int qp_body;        /* 0 = wrench-space dual active set in fp64 arithmetic, 1 = 12 x 12 orthogonal-factor body in fp32 (fp32 tiles beyond 65 536 states) */

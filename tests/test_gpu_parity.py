@@ -112,21 +112,21 @@ def test_step_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n):
 # include/wbc_hip.h -- step_impl launches what the same planner says), so this list cannot go stale when a threshold moves: one
 # batch either side of every switch, DEFAULT options, against the oracle, for the four (scalar type, observer) pairs the
 # BASELINE configs use.
-def _dispatch_cases():
+def _dispatch_cases(want_mats=True):
     import wbc_quadruped_dob_amd as W
     import os
     if not os.path.exists(W.LIB_PATH):
         W.build_library()
     cases = []
     for dtype, obs, cfg in (("f64", 0, 2), ("f64", 1, 3), ("f32", 1, 4), ("f32", 0, 2)):
-        for t in W.dispatch_thresholds(dtype, obs):
+        for t in W.dispatch_thresholds(dtype, obs, want_mats=want_mats):
             # fp32: the packed sweep needs an even batch, so both sides are even (like with like)
             lo, hi = (t - 1, t) if dtype == "f64" else ((t - 2, t) if t % 2 == 0 else (t - 1, t + 1))
             cases.append(pytest.param(dtype, obs, cfg, lo, hi, id="%s-obs%d-%d|%d" % (dtype, obs, lo, hi)))
     return cases
 
 
-def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_rank=17):
+def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_rank=17, want_mats=True):
     nd = _np_dtype(dtype)
     c = lambda a: np.ascontiguousarray(a, nd)
     solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
@@ -140,7 +140,7 @@ def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_r
     r_ref = None if r is None else c(r).copy()
     ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], c(B["tau_prev"]),
                       c(B["f_prev"]), ig_ref, r_ref, nthreads=8)
-    got = _run_step(torch, solver, B, dtype, None if integ is None else c(integ).copy(), None if r is None else c(r).copy(), want_mats=True)
+    got = _run_step(torch, solver, B, dtype, None if integ is None else c(integ).copy(), None if r is None else c(r).copy(), want_mats=want_mats)
     if dtype == "f64":
         np.testing.assert_array_equal(got["status"], ref["status"])
         ok = ref["status"] == 0
@@ -157,6 +157,8 @@ def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_r
     if obs:
         assert relerr(got["integ"], ig_ref) < (TIGHT64 if dtype == "f64" else 1e-4)
         assert relerr(got["r"], r_ref) < (TIGHT64 if dtype == "f64" else 2e-3)
+    if not want_mats:
+        return solver
     sub = slice(None) if n <= 70000 else slice(0, n, 8)     # (the dynamics outputs are 3.5 kB per state: a strided subset beyond 70 000 states)
     d = oracle.dynamics(c(B["q"][sub]), c(B["v"][sub]), nthreads=8)
     for k in ("M", "h", "Jc", "pf"):
@@ -172,6 +174,20 @@ def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, ora
     for n, plan in ((lo, p_lo), (hi, p_hi)):
         solver = _step_default_vs_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n)
         assert solver.plan_tick(n) == plan                                           # ... and the solver launches what the planner says
+        del solver
+        torch_cuda.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype,obs,cfg,lo,hi", _dispatch_cases(want_mats=False))
+def test_default_dispatch_without_matrix_outputs_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, lo, hi):
+    """The same for ticks whose caller passes no M / h / Jc buffers (tau, f only: what a controller needs): rnea_step front half, from
+    16 384 fp64 / 32 768 fp32 observer-on states the observer kernel + the observer-free rnea_step."""
+    import wbc_quadruped_dob_amd as W
+    p_lo, p_hi = W.plan_tick(lo, dtype, obs, want_mats=False), W.plan_tick(hi, dtype, obs, want_mats=False)
+    assert p_lo != p_hi, "no switch between %d and %d: %r" % (lo, hi, p_lo)
+    for n, plan in ((lo, p_lo), (hi, p_hi)):
+        solver = _step_default_vs_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n, want_mats=False)
+        assert solver.plan_tick(n, want_mats=False) == plan
         del solver
         torch_cuda.cuda.empty_cache()
 
@@ -697,7 +713,10 @@ def test_rnea_step_kernel_ticks_without_matrix_outputs(torch_cuda, gpu_model, or
                       ig, rr, out=out, want_mats=False)
     torch.cuda.synchronize()
     tm = solver.collect_timing()
-    assert tm["rnea_launches"] == 1 and tm["qp_launches"] == 1 and tm["fused_launches"] == 0 and tm["dyn_launches"] == 0
+    # (large observer-on batches: observer kernel [timed with the rnea kind] + observer-free rnea_step [timed with the front-half kind])
+    split = solver.plan_tick(n, want_mats=False, want_pf=pf)["front"] == 3
+    assert split == (obs > 0 and n >= 16384)
+    assert tm["rnea_launches"] == 1 and tm["qp_launches"] == 1 and tm["fused_launches"] == 0 and tm["dyn_launches"] == (1 if split else 0)
     assert np.array_equal(got["status"].cpu().numpy(), ref["status"])
     assert relerr(to_host(got["tau"]), ref["tau"]) < TIGHT64 and relerr(to_host(got["f"]), ref["f"]) < TIGHT64
     if pf:

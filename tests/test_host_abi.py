@@ -238,6 +238,11 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
         fused=0, front=2, qp=2, qp_tile=0, qp_body=0, sweep_pack2=1, sweep_block=256, qp_warm=0)
     # options move the switches, and the list follows
     assert W.dispatch_thresholds("f64", 0, options={"qp_lane": -1, "qp_tile": -1, "fused_max": 0}) == [65536]
+    # ticks whose caller passes no M / h / Jc buffers: rnea_step front half; observer kernel + observer-free rnea_step from 16 384 fp64 / 32 768 fp32 states
+    assert W.dispatch_thresholds("f64", 1, want_mats=False) == [14336, 16384, 106496]
+    assert W.dispatch_thresholds("f32", 1, want_mats=False) == [30720, 32768, 65537, 212992]
+    assert [W.plan_tick(n, "f64", 1, want_mats=False)["front"] for n in (9000, 16383, 16384, 262144)] == [1, 1, 3, 3]
+    assert W.plan_tick(262144, "f64", 0, want_mats=False)["front"] == 1
     # warm-started ticks (wbc_step_batch_warm): fused, warm one-wavefront kernel, cold tiles that only report the sets, warm per-lane pair
     assert W.dispatch_thresholds("f64", 1, warm=True) == [8193, 20480, 24576, 53248, 65536]
     assert W.dispatch_thresholds("f32", 1, warm=True) == [8193, 30720, 32768, 33792, 36864, 131072]

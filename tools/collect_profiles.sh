@@ -16,6 +16,7 @@ done
 for f in bench_scale_legs_1rank_graph bench_cfg5_h20_n1024_cold bench_cfg5_tracking_h20_n1024_cold qp_general; do
   [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
 done
+for f in "$O"/bench_cfg?_n262144_nomats.json; do [ -s "$f" ] && cp "$f" "$P/${T}_$(basename "$f")"; done
 for f in "$O"/bench_closed_loop_*.json; do [ -s "$f" ] && cp "$f" "$P/${T}_$(basename "$f")"; done
 [ -f "$O/stats_qp_general_kernel_stats.csv" ] && cp "$O/stats_qp_general_kernel_stats.csv" "$P/${T}_kernel_stats_qp_general.csv"
 for f in issue_probe tile_sweep midrange midrange_f64 midrange_f32 warm_loop warm_loop_large warm_timing soak; do [ -f "$O/$f.log" ] && cp "$O/$f.log" "$P/${T}_$f.log"; done

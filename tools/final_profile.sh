@@ -35,6 +35,8 @@ python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large
 python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
 python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144.json" 2>> "$O/bench.err"
 python bench.py --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --no-mats > "$O/bench_cfg2_n4096_nomats.json" 2>> "$O/bench.err"
+# tau, f only (no M / h / Jc buffers) at the large batch: what a controller that needs only the torques gets
+for c in 2 3 4; do python bench.py --config $c --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 --no-mats > "$O/bench_cfg${c}_n262144_nomats.json" 2>> "$O/bench.err"; done
 python bench.py --config 5 --steps 100 --warmup 10 > "$O/bench_cfg5_h20_n1024.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 100 --warmup 10 --batch 128 > "$O/bench_cfg5_h20_n128.json" 2>> "$O/bench.err"
 python bench.py --config 5 --tracking --steps 100 --warmup 10 > "$O/bench_cfg5_tracking_h20_n1024.json" 2>> "$O/bench.err"

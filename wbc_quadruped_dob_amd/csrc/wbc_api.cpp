@@ -60,13 +60,19 @@ constexpr int ONE_SCRATCH = 200;        // first scalar of the helpers' scratch 
 constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints (the tick uses the first 161)
 
 // thresholds between kernel variants after the options are applied (resolve_options)
+#ifndef WBC_OBS_SPLIT_MIN_NOMATS_F64
+#define WBC_OBS_SPLIT_MIN_NOMATS_F64 16384
+#endif
+#ifndef WBC_OBS_SPLIT_MIN_NOMATS_F32
+#define WBC_OBS_SPLIT_MIN_NOMATS_F32 32768
+#endif
 #ifndef WBC_WARM_LANE_MIN_F64
 #define WBC_WARM_LANE_MIN_F64 53248
 #endif
 #ifndef WBC_WARM_LANE_MIN_F32
 #define WBC_WARM_LANE_MIN_F32 36864
 #endif
-struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, tile_min, lane_min, warm_tile_min, warm_lane_min; };
+struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -326,6 +332,13 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   r.obs_split_min = (size_t)-1;
   if (o.obs_split_min >= 0) r.obs_split_min = (size_t)o.obs_split_min;
   else if (o.obs_split_min == -1) r.obs_split_min = dtype == WBC_F32 ? 33792 : 20480;
+  // ticks without M / h / Jc outputs: the all-in-one observer form of rnea_step against observer kernel + observer-free rnea_step.  Measured
+  // (tools/ab_sweep.sh with AB_EXTRA=--no-mats, M steps/s, all-in-one -> split): fp64 trot batch 12 288: 460 -> 409, 16 384: 393 -> 449, 24 576: 528 -> 581,
+  // 32 768: 542 -> 648, 65 536: 580 -> 792, 131 072: 649 -> 940, 262 144: 606 -> 967 (rnea_step with the observer inside 332 us; observer kernel 100 +
+  // observer-free rnea_step 68); fp32 24 576: 688 -> 637, 32 768: 720 -> 759, 65 536: 966 -> 1 163, 131 072: 1 160 -> 1 441, 262 144: 1 149 -> 1 539.
+  // (The two kernels on two streams lose to one after the other at every size, as with the sweep.)
+  r.obs_split_min_nomats = o.obs_split_min >= 0 ? (size_t)o.obs_split_min
+                           : (o.obs_split_min == -1 ? (size_t)(dtype == WBC_F32 ? WBC_OBS_SPLIT_MIN_NOMATS_F32 : WBC_OBS_SPLIT_MIN_NOMATS_F64) : (size_t)-1);
   // tiles dealt by predicted work (auto): fp64 from 14 336 states, fp32 from 30 720; per-lane QP pair (auto): fp64 from 106 496, fp32 from 212 992
   r.tile_min = dtype == WBC_F32 ? 30720 : 14336;
   r.lane_min = dtype == WBC_F32 ? 212992 : 106496;
@@ -368,10 +381,13 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // 49 152: 98.2 / 105.0; fp32 16 384: 45.2 / 43.4, 24 576: 53.0 / 52.6, 32 768: 58.0 / 57.8, 49 152: 78.5 / 82.3 -- it depends on how hard
   // the batch's cold solves are; the default takes it up to 24 576 fp64 states, where it wins or ties on both.
   p.lane = warm ? (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.warm_lane_min)) : (o.qp_lane > 0 || (o.qp_lane == 0 && N >= r.lane_min));
-  if (!mats) p.front = 1;                                   // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
+  if (!mats) {   // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the front half -- large observer-on batches: observer kernel + observer-free rnea_step
+    p.obs_split = ob && N >= r.obs_split_min_nomats;
+    p.front = p.obs_split ? 3 : 1;
+  }
   else if (ob && N >= r.obs_split_min) { p.front = 2; p.obs_split = true; }   // observer kernel + observer-free sweep
   else p.front = 0;
-  if (p.front != 1) {   // what the dyn_sweep launcher picks (k_sweep.hip)
+  if (p.front != 1 && p.front != 3) {   // what the dyn_sweep launcher picks (k_sweep.hip)
     const bool obs_variant = p.front == 0 && ob;
     p.pack2 = f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && (o.f32_pack2 > 0 || N >= (size_t)WBC_PACK2_MIN_STATES);
     const size_t threads = ((N + (p.pack2 ? 2 : 1) - 1) / (p.pack2 ? 2 : 1)) * 4;
@@ -452,7 +468,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537};
   size_t keep[16]; int k = 0;
   for (size_t c : cand) {
@@ -776,7 +792,20 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   const bool front_writes_b = ob && !pl.obs_split;   // the all-in-one observer forms: b = w_des - rhat_base
   qa.wdes = front_writes_b ? nullptr : (const T*)in->w_des;   // (those front halves run their SW_NOB / RS_NOB variants)
   a.qp_todo = pl.lane ? s->d_todo : nullptr;   // the front-half kernel empties the hand-over list (one thread; a kernel of its own took 4.7 us per tick)
-  if (pl.front == 1) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
+  if (pl.front == 3) {   // no M, h, Jc wanted, large observer-on batch: observer kernel beside the observer-free rnea_step (as front == 2 below)
+    const int mode = RS_STEP | RS_NOB | (out->pf ? RS_PF : 0);
+    if (s->opt.obs_split_serial) {
+      TIMED_LAUNCH(2, st, "observer", k_observer<T>(L, dev_model<T>(s), dp, a));
+      TIMED_LAUNCH(0, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
+    } else {
+      HIP_TRY(hipEventRecord(s->ev_fork, st));
+      HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_fork, 0));
+      TIMED_LAUNCH(2, s->aux, "observer", k_observer<T>(L, dev_model<T>(s), dp, a));
+      HIP_TRY(hipEventRecord(s->ev_join, s->aux));
+      TIMED_LAUNCH(0, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
+      HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));   // the QP needs rhat
+    }
+  } else if (pl.front == 1) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
     const int mode = RS_STEP | (ob ? RS_OBS : RS_NOB) | (out->pf ? RS_PF : 0);
     TIMED_LAUNCH(2, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
   } else if (pl.front == 2) {
