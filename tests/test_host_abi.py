@@ -173,6 +173,22 @@ def test_multi_create_argument_errors(hip_lib):
     assert W.lib().wbc_multi_create(good._h, C.byref(prm), 0, dup, 0, 64, 0, None, C.byref(h)) == 1
     assert W.lib().wbc_multi_create(good._h, C.byref(prm), 0, dup, 2, 64, 9, None, C.byref(h)) == 1
     assert W.lib().wbc_multi_size(None) == 0 and W.lib().wbc_multi_rccl_ranks(None) == 0
+    # the tick entry points refuse null handles / null argument arrays before they touch a device
+    L = W.lib()
+    assert L.wbc_multi_step_batch(None, 8, None, None, None) == 1
+    assert L.wbc_multi_step_batch_warm(None, 8, None, None, None, None) == 1
+    L.wbc_step_batch_warm.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.wbc_step_batch_warm(None, 8, None, None, None, None, None, None) == 1
+    plan = W.TickPlan()
+    plan.struct_size = C.sizeof(W.TickPlan)
+    assert L.wbc_plan_tick(7, 0, None, 4096, 1, 1, 0, C.byref(plan)) == 1            # no such scalar type
+    assert L.wbc_plan_tick(W.F64, 3, None, 4096, 1, 1, 0, C.byref(plan)) == 1        # no such observer order
+    assert L.wbc_plan_tick(W.F64, 1, None, 4096, 1, 1, 1, C.byref(plan)) == 0 and plan.fused == 1 and plan.qp_warm == 1
+    # an older caller's smaller wbc_tick_plan: only its bytes are written
+    plan2 = W.TickPlan()
+    plan2.struct_size = C.sizeof(W.TickPlan) - C.sizeof(C.c_int)
+    plan2.qp_warm = 77
+    assert L.wbc_plan_tick(W.F64, 1, None, 4096, 1, 1, 1, C.byref(plan2)) == 0 and plan2.fused == 1 and plan2.qp_warm == 77
 
 
 def test_ros_section_compiles_against_stubs(hip_lib, tmp_path):
