@@ -1158,10 +1158,43 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
         del s2
     except Exception as e:
         kept = {"error": repr(e)[:200]}
+    # the same ticks for a caller that passes no M / h / Jc buffers (tau, f only -- what a controller consumes): rnea_step front half, no CRBA,
+    # no matrix stores; observer-on batches run the observer kernel + the observer-free rnea_step
+    tf_only = None
+    try:
+        s3 = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=n)
+        integ3 = None if integ is None else integ.clone()
+        rr3 = None if rr is None else torch.zeros_like(rr)
+        o3 = s3.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"], inp["f_prev"], integ3, rr3,
+                     want_mats=False)
+        for _ in range(20):
+            s3.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"], inp["f_prev"], integ3, rr3,
+                    out=o3, want_mats=False)
+        torch.cuda.synchronize()
+        s3.enable_timing(1)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            s3.step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"], inp["f_prev"], integ3, rr3,
+                    out=o3, want_mats=False)
+        torch.cuda.synchronize()
+        el3 = time.perf_counter() - t0
+        tm3 = s3.collect_timing()
+        s3.enable_timing(0)
+        us = lambda k: (tm3[k + "_ms"] * 1e3 / tm3[k + "_launches"]) if tm3.get(k + "_launches", 0) else None
+        plan3 = s3.plan_tick(n, want_mats=False, want_pf=False)
+        tf_only = {"steps_per_s": K * n / el3, "ms_per_step": el3 / K * 1e3, "plan": plan3,
+                   "rnea_step_us": us("dyn") if plan3["front"] == 3 else us("rnea"), "observer_us": us("rnea") if plan3["front"] == 3 else None,
+                   "qp_us": us("qp"), "qp_lane_us": us("qp_lane"), "status_ok_frac": float((o3["status"] == 0).double().mean()),
+                   "whole_path_GBps": (102 + (96 if obs else 0)) * ts * K * n / el3 / 1e9,
+                   "note": "out.M = out.h = out.Jc = NULL: SURVEY.md 8(d)'s whole-path bytes (inputs + tau, f [+ observer state]) are all this tick moves "
+                           "besides its 66-word workspace; plan.front = 3: observer kernel + observer-free rnea_step"}
+        del s3
+    except Exception as e:
+        tf_only = {"error": repr(e)[:200]}
     alone = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
     alone["traffic"] = pmc_traffic("dyn_sweep_kernel<%s, 1," % ("double" if dtype == "f64" else "float"), n, dtype)
     return {"batch": n, "kernel": dyn_kernel_name(split), "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "dynamics_stage_alone": alone, "keep_structural": kept,
+            "dynamics_stage_alone": alone, "keep_structural": kept, "tau_f_only": tf_only,
             "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(tick_sweep_symbol(dtype, obs, n), n, dtype),
             "algorithmic_words_per_state": dyn_words(split), "avg_launch_us": dyn_s * 1e6,
             "rnea_step_us": tm["rnea_ms"] * 1e3 / max(1, tm["rnea_launches"]), "qp_us": qp_s * 1e6,
