@@ -114,8 +114,10 @@ def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dt
         assert elementwise_excess(res["warm"]["tau"][ok], ref2["tau"][ok]) <= 1.0
     if obs:
         assert relerr(res["warm"]["r"], r_o2) < (TIGHT64 if dtype == "f64" else 2e-3)
-    for k in ("M", "h", "Jc", "pf"):
+    for k in ("M", "Jc", "pf"):
         assert np.array_equal(res["warm"][k], res["cold"][k]), k
+    # (h: the warm fused tick without observer computes the bias forces in a recursion of their own, on a seventh wavefront -- same numbers to rounding)
+    assert relerr(res["warm"]["h"], res["cold"]["h"]) < 1e-13
     # what the warm start is for: most states need no iteration at all, and far fewer in total (the planner says whether the QP kernels of
     # this size start from the sets -- between the tile and the warm per-lane thresholds the cold tiles are the faster kernels and only report them)
     plan = solver.plan_tick(n, warm=True)
@@ -263,7 +265,7 @@ def test_warm_tick_is_graph_capturable_and_carries_its_sets(torch_cuda, gpu_mode
         assert it0.sum() > 0 and np.all(it == 0)
 
 
-@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 1, 3, 6000), ("f64", 1, 3, 20000), ("f64", 1, 3, 30000), ("f64", 0, 2, 60000), ("f32", 1, 4, 45000)])
+@pytest.mark.parametrize("dtype,obs,cfg,n", [("f64", 1, 3, 6000), ("f64", 0, 2, 5000), ("f64", 1, 3, 20000), ("f64", 1, 3, 30000), ("f64", 0, 2, 60000), ("f32", 1, 4, 45000)])
 def test_closed_loop_of_warm_ticks_follows_the_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
     """Six dependent ticks of a drifting batch with ONE carried set buffer (active_in = active_out), tau / f fed back as tau_prev / f_prev and the
     observer state advancing in place -- fused tick, reporting tiles and the warm per-lane pair (whose handed-over states get their sets from the

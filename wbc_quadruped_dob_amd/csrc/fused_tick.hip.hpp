@@ -64,11 +64,17 @@ constexpr int FUSED_OBS_WAVES = 2;
 #define WBC_FUSED_SPLIT_H 0
 #endif
 // (fp64 only: the fp32 tick fits two six-wavefront workgroups on a CU -- 147 VGPRs, 49 kB LDS -- and a seventh wavefront would end that)
-template <class T, bool OBSERVER, bool MATS> constexpr bool fused_split_h() { return WBC_FUSED_SPLIT_H && !OBSERVER && MATS && sizeof(T) == 8; }
-template <class T, bool OBSERVER, bool MATS> constexpr int fused_threads() { return OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : (fused_split_h<T, OBSERVER, MATS>() ? 448 : 384); }
+// WARM ticks are another matter: the block set-up ends the QP at about +5.5 us, so the tick ends with the rnea role and its torque map, and taking
+// the bias-force chain off that role shows: tick kernel 12.0 -> 11.0 us at 1 024 states, 13.2 -> 12.6 at 4 096, 22.2 -> 21.3 at 8 192 in a closed
+// loop of drifting states (13.5 -> 13.2 on the bench's own batch; tools/r04_splith.sh).  On by default for the warm instantiation.
+#ifndef WBC_FUSED_SPLIT_H_WARM
+#define WBC_FUSED_SPLIT_H_WARM 1
+#endif
+template <class T, bool OBSERVER, bool MATS, bool WARM = false> constexpr bool fused_split_h() { return (WBC_FUSED_SPLIT_H || (WBC_FUSED_SPLIT_H_WARM && WARM)) && !OBSERVER && MATS && sizeof(T) == 8; }
+template <class T, bool OBSERVER, bool MATS, bool WARM = false> constexpr int fused_threads() { return OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : (fused_split_h<T, OBSERVER, MATS, WARM>() ? 448 : 384); }
 // WARM: the QP of every state starts from the active set in qa.aset_in (wbc_step_batch_warm: dependent ticks of a closed loop)
 template <class T, bool OBSERVER, bool MATS, bool WARM = false>
-__global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+__global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void fused_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                             SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
@@ -88,7 +94,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused
   // barrier from inside their bodies (EXT = 2), so table staging and state loads share a memory round trip.
   if (wave == 4) {
     int* const gflag = &gready;
-    rnea_step_body<T, ((MATS && !fused_split_h<T, OBSERVER, MATS>()) ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [=] __device__() {
+    rnea_step_body<T, ((MATS && !fused_split_h<T, OBSERVER, MATS, WARM>()) ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [=] __device__() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       FSTAMP(7);
@@ -100,8 +106,8 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS>()), 1) void fused
     if constexpr (MATS) mass_jac_body<T, 64, 2, 16, !WBC_FUSED_ZEROS_BY_QP>(model, a, cst, zidx_s);
     else __syncthreads();
     FSTAMP(9);
-  } else if (fused_split_h<T, OBSERVER, MATS>() && wave == 6) {
-    if constexpr (fused_split_h<T, OBSERVER, MATS>()) rnea_step_body<T, RS_H, 64, 2>(model, prm, a, cst, wsl);   // bias forces h -> HBM only
+  } else if (fused_split_h<T, OBSERVER, MATS, WARM>() && wave == 6) {
+    if constexpr (fused_split_h<T, OBSERVER, MATS, WARM>()) rnea_step_body<T, RS_H, 64, 2>(model, prm, a, cst, wsl);   // bias forces h -> HBM only
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
       if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 2, 1>(model, prm, a, cst, wsl);   // base rows

@@ -13,7 +13,7 @@ hipError_t k_fused_tick<Scalar>(const LaunchCtx& L, bool observer, bool mats, co
   if (warm) {
     if (observer && mats) WBC_KLAUNCH(L, (fused_tick_kernel<T, true, true, true>), grid, dim3(obs_threads), model, prm, a, qa, jmap);
     else if (observer) WBC_KLAUNCH(L, (fused_tick_kernel<T, true, false, true>), grid, dim3(obs_threads), model, prm, a, qa, jmap);
-    else if (mats) WBC_KLAUNCH(L, (fused_tick_kernel<T, false, true, true>), grid, dim3((unsigned)fused_threads<T, false, true>()), model, prm, a, qa, jmap);
+    else if (mats) WBC_KLAUNCH(L, (fused_tick_kernel<T, false, true, true>), grid, dim3((unsigned)fused_threads<T, false, true, true>()), model, prm, a, qa, jmap);
     else WBC_KLAUNCH(L, (fused_tick_kernel<T, false, false, true>), grid, dim3(384), model, prm, a, qa, jmap);
     return hipGetLastError();
   }
