@@ -1,7 +1,8 @@
 #!/bin/bash
+# the N > 1 legs on one rank with the hipGraph forms of the gather, and the single-process two-shard line (tools/gather_check.sh [pytest -k expression])
 set -u
 export TMPDIR=/tmp
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r04_gather"; rm -rf "$O"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/gather_check"; rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 python -m pytest tests/test_gpu_multi.py tests/test_gpu_bench_contract.py -q -x -k "${1:-multisolver or scale_legs}" > "$O/pytest.log" 2>&1; tail -3 "$O/pytest.log"
 WBC_BENCH_GRAPH_GATHER=1 WBC_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-latency --large-batch 0 > "$O/bench_scale_legs_1rank.json" 2>> "$O/bench.err"

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4 quick check: warm tests, rollouts, the headline tick, a closed loop of warm ticks (tools/r04_quick.sh [pytest -k expression])
+# quick check: warm tests, rollouts, the headline tick, a closed loop of warm ticks (tools/quick_check.sh [pytest -k expression])
 set -u
 export TMPDIR=/tmp
-R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r04_quick"; rm -rf "$O"; mkdir -p "$O"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/quick_check"; rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 python -m pytest tests/test_gpu_warm.py tests/test_gpu_parity.py -q -x -k "${1:-warm or rollout}" > "$O/pytest.log" 2>&1; tail -3 "$O/pytest.log"
 pick='import sys,json; d=json.loads(sys.stdin.read()); r=d.get("roofline") or {}; print("%-34s %8.1f M steps/s  %7.2f us/tick  launch %s us" % (sys.argv[1], d["value"]/1e6, d["us_per_tick"], r.get("avg_launch_us")))'

@@ -66,7 +66,7 @@ constexpr int FUSED_OBS_WAVES = 2;
 // (fp64 only: the fp32 tick fits two six-wavefront workgroups on a CU -- 147 VGPRs, 49 kB LDS -- and a seventh wavefront would end that)
 // WARM ticks are another matter: the block set-up ends the QP at about +5.5 us, so the tick ends with the rnea role and its torque map, and taking
 // the bias-force chain off that role shows: tick kernel 12.0 -> 11.0 us at 1 024 states, 13.2 -> 12.6 at 4 096, 22.2 -> 21.3 at 8 192 in a closed
-// loop of drifting states (13.5 -> 13.2 on the bench's own batch; tools/r04_splith.sh).  On by default for the warm instantiation.
+// loop of drifting states (13.5 -> 13.2 on the bench's own batch; tools/ab_libs.sh with --closed-loop).  On by default for the warm instantiation.
 #ifndef WBC_FUSED_SPLIT_H_WARM
 #define WBC_FUSED_SPLIT_H_WARM 1
 #endif
