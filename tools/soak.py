@@ -89,6 +89,28 @@ for c in range(cases):
                 worst = max(worst, e)
                 if not e < 1e-9:
                     bad.append((c, "lane " + k, n, obs, cfg, e))
+        # wbc_step_batch_warm at this size: tick 1 cold (reports the sets), tick 2 from them -- the planner's choice, the warm per-lane pair and the warm
+        # one-wavefront kernel forced -- against the cold second tick of the one-wave kernel
+        from tests.util import to_dev, to_host
+        for wtag, wopt in (("warm default", {}), ("warm per-lane", {"qp_lane": 1}), ("warm one-wave", {"qp_lane": -1, "qp_tile": -1})):
+            s, P = solver_with(wopt, obs=obs, max_batch=n, dtype=DT)
+            dv = lambda k_: to_dev(B[k_], torch, torch.float64)
+            ins_ = [dv(k_) for k_ in ("q", "v", "w_des", "vdot_des", "normals", "mu")]
+            mk_ = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
+            zw = tuple(None if t is None else to_dev(t, torch, torch.float64) for t in z())
+            tp_, fp_ = dv("tau_prev"), dv("f_prev")
+            o1 = s.step(*ins_, mk_, tp_, fp_, zw[0], zw[1], want_mats=bool(c % 2), warm=True)
+            o2 = s.step(*ins_, mk_, tp_, fp_, zw[0], zw[1], want_mats=bool(c % 2), active_in=o1["active"].clone(), out={k_: v_ for k_, v_ in o1.items() if k_ != "active"})
+            torch.cuda.synchronize()
+            b2 = res["plain"][1]
+            if not np.array_equal(o2["status"].cpu().numpy(), b2["status"]):
+                bad.append((c, wtag + " status", n, obs, cfg))
+            for k_ in ("tau", "f"):
+                e = relerr(to_host(o2[k_]), b2[k_])
+                worst = max(worst, e)
+                if not e < 1e-9:
+                    bad.append((c, wtag + " " + k_, n, obs, cfg, e))
+            del s
         if c % 2:
             ig, r = z()
             ref = orc.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"], ig, r, nthreads=8)
