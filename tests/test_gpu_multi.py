@@ -83,7 +83,13 @@ def test_cpp_consumer_matches_oracle_and_shards_match_single(torch_cuda, gpu_mod
     ref = oracle.step(P, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"],
                       ig_ref if obs else None, r_ref if obs else None, nthreads=8)
     assert np.array_equal(one["status"], ref["status"])
-    assert np.mean(one["iters"] != ref["iters"]) <= 5e-3   # a rounding-level difference may flip a degenerate pivot choice
+    if obs == 0 or n > 8192:
+        assert np.mean(one["iters"] != ref["iters"]) <= 5e-3   # a rounding-level difference may flip a degenerate pivot choice
+    else:
+        # fused tick with the observer on: the QP starts on b~ = w_des - r_prev and moves its solution to b when rhat arrives (qp_struct16.hip.hpp,
+        # SPEC) -- another pivot sequence to the same solution; with an observer state as arbitrary as this one some wavefronts solve twice
+        d = one["iters"].astype(np.int64) - ref["iters"].astype(np.int64)
+        assert d.min() >= -3 and d.max() <= 2 * int(P["max_iter"]) and d.mean() < 2.0, (d.min(), d.max(), d.mean())
     assert relerr(one["tau"], ref["tau"]) < 1e-9 and relerr(one["f"], ref["f"]) < 1e-9
     if obs:
         assert relerr(one["integ"], ig_ref) < 1e-9 and relerr(one["r"], r_ref) < 1e-9

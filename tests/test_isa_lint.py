@@ -49,7 +49,9 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
         hits = {k: v for k, v in res.items() if re.search(pat, k)}
         assert hits, pat
         for k, v in hits.items():
-            assert v["scratch"] == 0, (k, v)
+            # no spill traffic: no private segment at all, or one that no instruction of the kernel touches (hipcc leaves a 36-byte frame object behind in
+            # one fused instantiation: SGPR spills it then served from VGPR lanes)
+            assert v["scratch"] == 0 or (v["scratch"] <= 64 and v["scratch_insts"] == 0), (k, v)
             assert v["vgpr"] + v["agpr"] <= regs, (k, v)
 
 

@@ -47,14 +47,20 @@ def compile_asm(out="/tmp/asm/wbc_lint.s", extra=()):
 
 
 def resources(path):
-    """{kernel symbol: dict(vgpr, agpr, scratch, lds)} from the .amdhsa_kernel blocks of `path`."""
+    """{kernel symbol: dict(vgpr, agpr, scratch, lds, scratch_insts)} from the .amdhsa_kernel blocks of `path`; scratch_insts = scratch / stack
+    instructions in the kernel's body (a kernel can carry a private segment that nothing touches: a frame object the backend created for SGPR
+    spills and then served from VGPR lanes)."""
     txt = open(path).read()
     out = {}
+    insts = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\s*\.end_amdhsa_kernel", txt, flags=re.S | re.M):
+        insts[m.group(1)] = len(re.findall(r"^\s*(scratch_(load|store)|buffer_(load|store)\S*\s[^\n]*\boffen\b)", m.group(2), flags=re.M))
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, flags=re.S):
         b = m.group(2)
         g = lambda k: int(re.search(k + r"\s+(\d+)", b).group(1))
         nv, acc = g("amdhsa_next_free_vgpr"), g("amdhsa_accum_offset")
-        out[m.group(1)] = dict(vgpr=min(nv, acc), agpr=max(0, nv - acc), scratch=g("amdhsa_private_segment_fixed_size"), lds=g("amdhsa_group_segment_fixed_size"))
+        out[m.group(1)] = dict(vgpr=min(nv, acc), agpr=max(0, nv - acc), scratch=g("amdhsa_private_segment_fixed_size"), lds=g("amdhsa_group_segment_fixed_size"),
+                               scratch_insts=insts.get(m.group(1), -1))
     return out
 
 

@@ -64,6 +64,7 @@ class StructuredGI:
         sS = np.sqrt(S)
         self.B = [np.vstack([np.eye(3), skew(d[k])]) * sS[:, None] * self.on[k] for k in range(4)]   # 6 x 3 each
         self.beta = sS * b
+        self._S = np.asarray(S, float)
         self.C, self.rhs = [], []      # constraint k*6+c: normal (3), rhs; C f_k >= rhs
         for k in range(4):
             t1, t2, nn = contact_frame(normals[k])
@@ -111,7 +112,12 @@ class StructuredGI:
             return neg
         return act, P, Np, Ginv, np.concatenate(f), u
 
-    def solve(self, warm=None):
+    def solve(self, warm=None, move_to=None):
+        """move_to (a target wrench b): the speculative start of the fused observer-on tick (csrc/qp_struct16.hip.hpp, SPEC) -- the iteration runs on
+        the wrench this object was built with (b~), then the minimiser on the active set it has reached is moved to b:
+            d = S^(1/2) (b - b~),  dy = -G_A^-1 d,  df_k = -P_k B_k^T dy,  du_k = alpha N_k^+ (df_k + B_k^T dy),
+        and the iteration goes on from there; a negative multiplier after the move starts the solve over from the empty set with b.
+        self.moved = True when the moved point was an S-pair."""
         a, B = self.alpha, self.B
         act = [[] for _ in range(4)]                # per foot: constraint ids in slot order
         order = []                                  # global add order (tie-breaking of the ratio test)
@@ -160,7 +166,26 @@ class StructuredGI:
                 if s < smin:
                     smin, ip = s, c
             if ip < 0:
-                break
+                if move_to is None:
+                    break
+                beta_new = np.sqrt(self._S) * np.asarray(move_to, float)
+                d = beta_new - self.beta
+                self.beta, move_to = beta_new, None
+                dy = -Ginv @ d
+                df = [-P[k] @ (B[k].T @ dy) for k in range(4)]
+                for k in range(4):
+                    if act[k]:
+                        for c, val in zip(act[k], a * (Np[k] @ (df[k] + B[k].T @ dy))):
+                            u[c] += val
+                x = x + np.concatenate(df)
+                self.moved = all(val >= 0 for val in u.values())
+                if not self.moved:      # no S-pair for b: from the empty set, with b
+                    act = [[] for _ in range(4)]; order = []; u = {}
+                    P = [np.eye(3) for _ in range(4)]; Np = [np.zeros((0, 3)) for _ in range(4)]
+                    Ginv = np.linalg.inv(self.G(P))
+                    x = np.concatenate([B[k].T @ (Ginv @ self.beta) for k in range(4)])
+                    Rnorm = 1.0
+                continue
             sip, up, kp = smin, 0.0, ip // 6
             nplus = self.C[ip]
             while True:

@@ -36,100 +36,12 @@
 namespace wbc {
 
 // per wave: four QPs x {32 constraint normals, P of the four feet (xx xy xz yy yz zz), lever arms of the four feet, scratch what}
-template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 16]; T D[4][4 * 3]; T W[4][4]; };   // P: row c of foot k at 16 k + 4 c (row 3: the spare lane's dummy)
+template <class T> struct S16Lds { T C[4][32 * 3]; T P[4][4 * 16]; T D[4][4 * 3]; T W[4][4]; T R[4][6]; };   // P: row c of foot k at 16 k + 4 c (row 3: the spare lane's dummy); R: SPEC's r_prev (base rows)
 
-// TS = the solver's scalar type (what the batch arrays and the LDS workspace hold); the arithmetic is ALWAYS double: the inverse
-// is kept by rank-one updates (cond(G_A) ~ 1e4-1e5 is too much for fp32), and on gfx950 a dependent v_fma_f64 costs a lone
-// wavefront what a dependent v_fma_f32 costs (13.5 vs 13.1 cycles, tools/issue_probe.hip) -- the QP is latency-, not byte-bound.
-// PRE (tiles only): G^-1 and the unconstrained minimum x0 of this state were computed by the tile's predictor, one state per lane, and wait
-// in LDS (who.pre: 36 + 12 doubles) -- the factorisation, the unit solves and the x0 solve below (~350 of the ~750 set-up instructions a
-// wavefront spends per four states) are skipped.
-// WARM (dependent ticks: rollouts, closed loops): the iteration starts from a GIVEN active set instead of from the unconstrained minimum.
-//   1: the set of each state comes from a.aset_in (null: cold), 2: from *carry, an LDS word per state that the persistent rollout kernel keeps
-//   across its ticks; the final set always goes back to *carry (2) and to a.aset_out (when given, every instantiation).
-// Encoding (include/wbc_hip.h): bit l16 = constraint A of lane l16 (lane 4k + j: mu~ n - t1, mu~ n - t2, n, -n of foot k), bit 16 + l16 =
-// constraint B of lane l16 (j < 2: mu~ n + t1, mu~ n + t2) -- what the per-lane flags actA / actB are, read off two ballots.
-// The block set-up (derivation and numpy restatement: tools/structured_gi.py, warm_setup): per foot the <= 3 given normals give P_k and
-// N_k^+ in closed form (cross products, ONE reciprocal); every lane assembles G_A = alpha I + sum_k B_k P_k B_k^T (21 entries) from the
-// four P_k in LDS, factors it (general 6 x 6 Cholesky) and solves for its row of G_A^-1; the minimiser ON the set and its multipliers are
-//     f_k = f_k^p - P_k B_k^T y,   f_k^p = N_k^+T rhs_k,   G_A y = sum_k B_k f_k^p - S^(1/2) b,   u_k = alpha N_k^+ (f_k + B_k^T y).
-// A set with more than three rows on a foot, dependent rows or a negative multiplier is no S-pair of the dual method: that row of the
-// wavefront repeats the set-up with the empty set (= the cold start; the loop below runs at most twice).  The QP is strictly convex, so
-// the start changes the iteration count, never the solution.
-template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0>
-WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, const QpJidx& jmap, const TS* wsl, const QpSync* sync = nullptr,
-                              const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
-  using T = double;
-  static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
-  static_assert(!(WARM != 0 && PRE), "warm starts set their blocks up themselves");
-  __shared__ S16Lds<T> lds_all[WPB];
-  unsigned tx = threadIdx.x;
-  asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
-  const int lane = tx & 63;
-  const int l16 = lane & 15;
-  const int rowbase = lane & 48;
-  const int grp = lane >> 4;
-  const int f = l16 >> 2, c3 = l16 & 3;
-  const bool isvar = c3 < 3;
-  const int v = 3 * f + (isvar ? c3 : 0);
-  S16Lds<T>& L = lds_all[tx >> 6];
-  T* Cl = L.C[grp];
-  T* Pl = L.P[grp];
-  T* Dl = L.D[grp];
-  T* Wl = L.W[grp];
-  const size_t N = a.N;
-  const unsigned N32 = (unsigned)N;
-  size_t wg = blockIdx.x;
-  if (WPB == 1 && (gridDim.x & 31) == 0) wg = (wg & ~(size_t)31) + ((wg & 7) << 2) + ((wg >> 3) & 3);   // XCD-aware (qp_group16.hip.hpp)
-  static_assert(SPW == 16 || WSLDS, "fewer states per workgroup only inside the fused kernels");
-  const size_t qp_raw = TILED ? who.state : WSLDS ? (size_t)blockIdx.x * SPW + (tx >> 4) : (wg * blockDim.x + tx) >> 4;
-  bool live = TILED ? who.live : (qp_raw < N && (SPW == 16 || (int)(tx >> 4) < SPW));
-  unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
-  const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
-#define GLD(ptr, comp) ((T)(*(const TS*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS)))))
-#define WSLD(comp) (WSLDS ? (T)wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
-#define BLD(c) (WSLDS ? (T)wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
-#define GST(ptr, comp, val) (*(TS*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS))) = (TS)(val))
-
-#ifdef WBC_QP_STAMP
-  const long long st_t0 = __builtin_readcyclecounter();
-#endif
-  // ------------------------------------------------------------------ inputs
-  int mask = a.mask[s32] & 0xF;
-  bool on = (mask >> f) & 1;
-  const bool geom_jc = !WSLDS && a.Jc != nullptr;
-  const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
-  const T mu_f = GLD(a.mu, f);
-  int aset = 0;
-  if constexpr (WARM == 1) { if (a.aset_in) aset = a.aset_in[s32]; }
-  if constexpr (WARM == 2) aset = *carry;
-  WBC_QSTAMP(1);
-  idle();
-  if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
-  WBC_QSTAMP(2);
-  T d_me = 0;
-  if (geom_jc) {
-    const int comp = c3 == 0 ? (3 * f + 1) * 18 + 5 : (c3 == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4);
-    if (isvar) d_me = GLD(a.Jc, comp);
-  } else if (isvar) d_me = WSLD(WS_D + v);
-
-  // ------------------------------------------------------------------ G = alpha I + B B^T and its factor (as in qp_group16_body)
-  const T onf = on ? (T)1 : (T)0;
-  const T dqx = onf * dppx<0x00>(d_me), dqy = onf * dppx<0x55>(d_me), dqz = onf * dppx<0xAA>(d_me);   // my foot's lever arm, zero for a swing foot
-  // (kernel-uniform weights pass through an empty asm so that products of two of them are not hoisted out of the tile / horizon loop and held
-  //  in registers for the whole kernel.  Tiles launder the raw values as SCALARS, before any conversion: sixteen vector registers less)
-  TS r0 = prm.sS[0], r1 = prm.sS[1], r2 = prm.sS[2], r3 = prm.sS[3], r4 = prm.sS[4], r5 = prm.sS[5], ra = prm.alpha, rq = prm.rsqrt_alpha;
-  if constexpr (TILED) asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3), "+s"(r4), "+s"(r5), "+s"(ra), "+s"(rq));
-  T s0 = r0, s1 = r1, s2 = r2, s3 = r3, s4 = r4, s5 = r5;
-  T alpha_l = ra, ralpha = (T)rq * (T)rq;
-  if constexpr (WSLDS) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(ralpha));
-  const int gi = l16 < 6 ? l16 : (l16 < 12 ? l16 - 6 : l16 - 12);
-  T Gr[6];
-  if constexpr (WARM != 0) {
-    sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = 0; });   // (set by the block set-up below)
-  } else if constexpr (PRE) {
-    sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = who.pre[6 * gi + j]; });
-  } else {
+// row gi of (alpha I + B B^T)^-1 -- the inverse of the EMPTY active set -- from the lever arms of the stance feet (cold start; SPEC: also where a
+// wavefront starts over).  A function of explicit arguments, not a capturing lambda: called from two places, a closure object would sit on the stack.
+template <class T>
+WBC_DEV void s16_cold_inverse_row(int mask, T d_me, T alpha_l, T s0, T s1, T s2, T s3, T s4, T s5, int gi, T (&Gr)[6]) {
   T a01, a02, a10, a12, a20, a21, b10, b20, b21;
   T il[6];
   {
@@ -181,6 +93,113 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     Gr[0] = (w[0] - a10 * Gr[4] - a20 * Gr[5]) * il[0];
   }
   }
+
+// TS = the solver's scalar type (what the batch arrays and the LDS workspace hold); the arithmetic is ALWAYS double: the inverse
+// is kept by rank-one updates (cond(G_A) ~ 1e4-1e5 is too much for fp32), and on gfx950 a dependent v_fma_f64 costs a lone
+// wavefront what a dependent v_fma_f32 costs (13.5 vs 13.1 cycles, tools/issue_probe.hip) -- the QP is latency-, not byte-bound.
+// PRE (tiles only): G^-1 and the unconstrained minimum x0 of this state were computed by the tile's predictor, one state per lane, and wait
+// in LDS (who.pre: 36 + 12 doubles) -- the factorisation, the unit solves and the x0 solve below (~350 of the ~750 set-up instructions a
+// wavefront spends per four states) are skipped.
+// WARM (dependent ticks: rollouts, closed loops): the iteration starts from a GIVEN active set instead of from the unconstrained minimum.
+//   1: the set of each state comes from a.aset_in (null: cold), 2: from *carry, an LDS word per state that the persistent rollout kernel keeps
+//   across its ticks; the final set always goes back to *carry (2) and to a.aset_out (when given, every instantiation).
+// Encoding (include/wbc_hip.h): bit l16 = constraint A of lane l16 (lane 4k + j: mu~ n - t1, mu~ n - t2, n, -n of foot k), bit 16 + l16 =
+// constraint B of lane l16 (j < 2: mu~ n + t1, mu~ n + t2) -- what the per-lane flags actA / actB are, read off two ballots.
+// The block set-up (derivation and numpy restatement: tools/structured_gi.py, warm_setup): per foot the <= 3 given normals give P_k and
+// N_k^+ in closed form (cross products, ONE reciprocal); every lane assembles G_A = alpha I + sum_k B_k P_k B_k^T (21 entries) from the
+// four P_k in LDS, factors it (general 6 x 6 Cholesky) and solves for its row of G_A^-1; the minimiser ON the set and its multipliers are
+//     f_k = f_k^p - P_k B_k^T y,   f_k^p = N_k^+T rhs_k,   G_A y = sum_k B_k f_k^p - S^(1/2) b,   u_k = alpha N_k^+ (f_k + B_k^T y).
+// A set with more than three rows on a foot, dependent rows or a negative multiplier is no S-pair of the dual method: that row of the
+// wavefront repeats the set-up with the empty set (= the cold start; the loop below runs at most twice).  The QP is strictly convex, so
+// the start changes the iteration count, never the solution.
+template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0>
+WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, const QpJidx& jmap, const TS* wsl, const QpSync* sync = nullptr,
+                              const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
+  using T = double;
+  static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
+  // SPEC (fused / rollout kernels with the observer on, cold start): the target wrench b = w_des - rhat_base is the last input to arrive -- the observer
+  // role's base rows end at about +6.2 us, the QP's factor is done at +3.6.  The iteration therefore STARTS on b~ = w_des - r_prev (the observer state as
+  // the tick finds it: an input, one filter step away from rhat) and, when rhat is there, moves the solution to b on the active set it has reached: with
+  // beta -> beta + d the minimiser on a fixed set moves by  dy = -G_A^-1 d,  df_k = -P_k B_k^T dy,  du_k = alpha N_k^+ (df_k + B_k^T dy)  -- one product with
+  // the inverse the loop maintains.  Multipliers still >= 0: an S-pair for b, the loop goes on from it (usually it has nothing left to do).  A negative
+  // multiplier (a row that the last filter step releases): that row of the wavefront starts over from the empty set with b itself.  The QP is
+  // strictly convex, so f, tau, status do not depend on b~ at all -- a torn or already updated read of r_prev only makes the guess better or worse.
+#ifndef WBC_QP_SPEC
+#define WBC_QP_SPEC 1
+#endif
+  constexpr bool SPEC = WBC_QP_SPEC != 0 && WSLDS && RHAT && WARM == 0 && !PRE && !TILED;
+  static_assert(!(WARM != 0 && PRE), "warm starts set their blocks up themselves");
+  __shared__ S16Lds<T> lds_all[WPB];
+  unsigned tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
+  const int lane = tx & 63;
+  const int l16 = lane & 15;
+  const int rowbase = lane & 48;
+  const int grp = lane >> 4;
+  const int f = l16 >> 2, c3 = l16 & 3;
+  const bool isvar = c3 < 3;
+  const int v = 3 * f + (isvar ? c3 : 0);
+  S16Lds<T>& L = lds_all[tx >> 6];
+  T* Cl = L.C[grp];
+  T* Pl = L.P[grp];
+  T* Dl = L.D[grp];
+  T* Wl = L.W[grp];
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)N;
+  size_t wg = blockIdx.x;
+  if (WPB == 1 && (gridDim.x & 31) == 0) wg = (wg & ~(size_t)31) + ((wg & 7) << 2) + ((wg >> 3) & 3);   // XCD-aware (qp_group16.hip.hpp)
+  static_assert(SPW == 16 || WSLDS, "fewer states per workgroup only inside the fused kernels");
+  const size_t qp_raw = TILED ? who.state : WSLDS ? (size_t)blockIdx.x * SPW + (tx >> 4) : (wg * blockDim.x + tx) >> 4;
+  bool live = TILED ? who.live : (qp_raw < N && (SPW == 16 || (int)(tx >> 4) < SPW));
+  unsigned s32 = (unsigned)(live ? qp_raw : N - 1);
+  const T INF = Lim<T>::inf, EPS = Lim<T>::eps;
+#define GLD(ptr, comp) ((T)(*(const TS*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS)))))
+#define WSLD(comp) (WSLDS ? (T)wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
+#define BLD(c) (WSLDS ? (T)wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
+#define GST(ptr, comp, val) (*(TS*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS))) = (TS)(val))
+
+#ifdef WBC_QP_STAMP
+  const long long st_t0 = __builtin_readcyclecounter();
+#endif
+  // ------------------------------------------------------------------ inputs
+  int mask = a.mask[s32] & 0xF;
+  bool on = (mask >> f) & 1;
+  const bool geom_jc = !WSLDS && a.Jc != nullptr;
+  const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
+  const T mu_f = GLD(a.mu, f);
+  T rprev_in = 0;
+  if constexpr (SPEC) { if (a.rprev && l16 < 6) rprev_in = GLD(a.rprev, l16); }   // (parked in LDS once b~ is formed: read back behind the iteration)
+  int aset = 0;
+  if constexpr (WARM == 1) { if (a.aset_in) aset = a.aset_in[s32]; }
+  if constexpr (WARM == 2) aset = *carry;
+  WBC_QSTAMP(1);
+  idle();
+  if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
+  WBC_QSTAMP(2);
+  T d_me = 0;
+  if (geom_jc) {
+    const int comp = c3 == 0 ? (3 * f + 1) * 18 + 5 : (c3 == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4);
+    if (isvar) d_me = GLD(a.Jc, comp);
+  } else if (isvar) d_me = WSLD(WS_D + v);
+
+  // ------------------------------------------------------------------ G = alpha I + B B^T and its factor (as in qp_group16_body)
+  const T onf = on ? (T)1 : (T)0;
+  const T dqx = onf * dppx<0x00>(d_me), dqy = onf * dppx<0x55>(d_me), dqz = onf * dppx<0xAA>(d_me);   // my foot's lever arm, zero for a swing foot
+  // (kernel-uniform weights pass through an empty asm so that products of two of them are not hoisted out of the tile / horizon loop and held
+  //  in registers for the whole kernel.  Tiles launder the raw values as SCALARS, before any conversion: sixteen vector registers less)
+  TS r0 = prm.sS[0], r1 = prm.sS[1], r2 = prm.sS[2], r3 = prm.sS[3], r4 = prm.sS[4], r5 = prm.sS[5], ra = prm.alpha, rq = prm.rsqrt_alpha;
+  if constexpr (TILED) asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3), "+s"(r4), "+s"(r5), "+s"(ra), "+s"(rq));
+  T s0 = r0, s1 = r1, s2 = r2, s3 = r3, s4 = r4, s5 = r5;
+  T alpha_l = ra, ralpha = (T)rq * (T)rq;
+  if constexpr (WSLDS) asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(alpha_l), "+v"(ralpha));
+  const int gi = l16 < 6 ? l16 : (l16 < 12 ? l16 - 6 : l16 - 12);
+  T Gr[6];
+  if constexpr (WARM != 0) {
+    sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = 0; });   // (set by the block set-up below)
+  } else if constexpr (PRE) {
+    sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = who.pre[6 * gi + j]; });
+  }
+  if constexpr (WARM == 0 && !PRE) s16_cold_inverse_row<T>(mask, d_me, alpha_l, s0, s1, s2, s3, s4, s5, gi, Gr);
   // y = G_A^-1 b for a row-uniform b: my component from my row, then six broadcasts from the static lanes 0..5
   T y[6];
   auto ginv_mul = [&](const T* bb, T& yi) __attribute__((always_inline)) {
@@ -405,12 +424,13 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   {
     WBC_QSTAMP(3);
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
-    if constexpr (WSLDS && RHAT) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
+    if constexpr (WSLDS && RHAT && !SPEC) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
     WBC_QSTAMP(4);
     if constexpr (PRE) {
       x_me = isvar ? who.pre[36 + v] : (T)0;
     } else {
-    const T b_ld = (l16 < 6) ? BLD(l16) - (RHAT ? WSLD(WS_RHAT + l16) : (T)0) : (T)0;
+    const T b_ld = (l16 < 6) ? BLD(l16) - (SPEC ? rprev_in : (RHAT ? WSLD(WS_RHAT + l16) : (T)0)) : (T)0;   // (SPEC: b~, see the top)
+    if constexpr (SPEC) { if (l16 < 6) L.R[grp][l16] = rprev_in; }
     T bb[6];
     bb[0] = s0 * dppx<0x150 + 0>(b_ld); bb[1] = s1 * dppx<0x150 + 1>(b_ld); bb[2] = s2 * dppx<0x150 + 2>(b_ld);
     bb[3] = s3 * dppx<0x150 + 3>(b_ld); bb[4] = s4 * dppx<0x150 + 4>(b_ld); bb[5] = s5 * dppx<0x150 + 5>(b_ld);
@@ -434,6 +454,10 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   T sip = 0, Rn2 = 1, u_c = 0;   // Rn2 = max(1, largest z . n+ of an added constraint) = Rnorm^2 of the dense method (its new R diagonal is |d2|)
   const T ntol = -prm.qp_tol;
 
+#pragma clang loop unroll(disable)
+  for (int ph = 0; ph < (SPEC ? 2 : 1); ++ph) {   // (SPEC: the iteration on b~, then -- from the point moved to b -- whatever is left of it; rolled: one copy of the loop)
+  // (the two helpers below are defined INSIDE the phase loop: defined in front of it, the closure of one of them stayed behind as a dead 36-byte
+  //  stack object in one fused instantiation -- no scratch instruction, but a private segment to set up)
   // most violated inactive constraint of the row at the point whose foot components are (xq0, xq1, xq2) in my quad
   auto most_violated = [&](T xq0, T xq1, T xq2, bool aA, bool aB, T& val, int& id) __attribute__((always_inline)) -> bool {
     const T sA = cAx * xq0 + cAy * xq1 + cAz * xq2 - rA;
@@ -643,6 +667,59 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     }
     SEG(5);
   }
+  if constexpr (SPEC) {
+    if (ph == 0) {
+      // ---- rhat is needed now: move the minimiser on the active set reached with b~ to b = b~ - (rhat - r_prev)
+      if (sync) qp_wait(sync->rhat, sync->need_rhat);
+      const T db_ld = (l16 < 6) ? L.R[grp][l16] - WSLD(WS_RHAT + l16) : (T)0;   // (my own LDS word: program order of one lane)
+      T rr[6];
+      rr[0] = -(s0 * dppx<0x150 + 0>(db_ld)); rr[1] = -(s1 * dppx<0x150 + 1>(db_ld)); rr[2] = -(s2 * dppx<0x150 + 2>(db_ld));
+      rr[3] = -(s3 * dppx<0x150 + 3>(db_ld)); rr[4] = -(s4 * dppx<0x150 + 4>(db_ld)); rr[5] = -(s5 * dppx<0x150 + 5>(db_ld));
+      T yi;
+      ginv_mul(rr, yi);                       // dy = -G_A^-1 d
+      T w0, w1, w2;
+      bt_y(w0, w1, w2);                       // B_k^T dy of my foot
+      const T dx = isvar ? -(Pr0 * w0 + Pr1 * w1 + Pr2 * w2) : (T)0;     // df_k = -P_k B_k^T dy, my component
+      x_me += dx;
+      const T dfx = dppx<0x00>(dx), dfy = dppx<0x55>(dx), dfz = dppx<0xAA>(dx);
+      const bool slot_now = isvar && c3 < qk;
+      u_s += slot_now ? alpha_l * (Np0 * (dfx + w0) + Np1 * (dfy + w1) + Np2 * (dfz + w2)) : (T)0;
+      // ---- still an S-pair?  A row with a negative multiplier starts over from the empty set, with b itself.  Per ROW: what a state computes
+      // must not depend on the three states that happen to share its wavefront (shards of a batch group the states differently, and their
+      // results are compared bit for bit with the unsharded run)
+      const unsigned long long fneg = __ballot(live && status == 0 && slot_now && !(u_s >= 0));
+      if (fneg != 0ull) {   // (wave-uniform branch, rare; inside it every change is selected per row)
+        const bool row_over = (unsigned)((fneg >> rowbase) & 0xFFFFull) != 0u;
+        T GrK[6];
+        sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; GrK[j] = Gr[j]; });
+        s16_cold_inverse_row<T>(mask, d_me, alpha_l, s0, s1, s2, s3, s4, s5, gi, Gr);
+        sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Gr[j] = row_over ? Gr[j] : GrK[j]; });
+        Pr0 = row_over ? (c3 == 0 ? (T)1 : (T)0) : Pr0; Pr1 = row_over ? (c3 == 1 ? (T)1 : (T)0) : Pr1; Pr2 = row_over ? (c3 == 2 ? (T)1 : (T)0) : Pr2;
+        Np0 = row_over ? (T)0 : Np0; Np1 = row_over ? (T)0 : Np1; Np2 = row_over ? (T)0 : Np2;
+        u_s = row_over ? (T)0 : u_s;
+        id_s = row_over ? -1 : id_s;
+        qk = row_over ? 0 : qk;
+        actA = row_over ? false : actA; actB = row_over ? false : actB;
+        Rn2 = row_over ? (T)1 : Rn2;
+        prow[0] = Pr0; prow[1] = Pr1; prow[2] = Pr2;      // (every lane rewrites its row of the LDS table: unchanged for the rows that go on)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const T bt_ld = (l16 < 6) ? BLD(l16) - WSLD(WS_RHAT + l16) : (T)0;
+        T bb[6];
+        bb[0] = s0 * dppx<0x150 + 0>(bt_ld); bb[1] = s1 * dppx<0x150 + 1>(bt_ld); bb[2] = s2 * dppx<0x150 + 2>(bt_ld);
+        bb[3] = s3 * dppx<0x150 + 3>(bt_ld); bb[4] = s4 * dppx<0x150 + 4>(bt_ld); bb[5] = s5 * dppx<0x150 + 5>(bt_ld);
+        T y2;
+        ginv_mul(bb, y2);                     // (rows that go on compute a product they do not use)
+        T v0, v1, v2;
+        bt_y(v0, v1, v2);
+        const T x0_me = c3 == 0 ? v0 : (c3 == 1 ? v1 : v2);
+        x_me = row_over ? x0_me : x_me;
+      }
+      done = !live || status != 0;            // every row looks for violated rows again at its new point
+    }
+  }
+  }   // ph
 
   // ------------------------------------------------------------------ outputs: f, tau (a9), status
   WBC_QSTAMP(5);
