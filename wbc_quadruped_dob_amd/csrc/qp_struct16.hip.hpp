@@ -454,6 +454,14 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   T sip = 0, Rn2 = 1, u_c = 0;   // Rn2 = max(1, largest z . n+ of an added constraint) = Rnorm^2 of the dense method (its new R diagonal is |d2|)
   const T ntol = -prm.qp_tol;
 
+#ifdef WBC_QP_STAMP
+  const long long st_t1 = __builtin_readcyclecounter();
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_last = st_t1;
+#define SEG(i) do { const long long now_ = __builtin_readcyclecounter(); seg[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define SEG(i) do {} while (0)
+#endif
 #pragma clang loop unroll(disable)
   for (int ph = 0; ph < (SPEC ? 2 : 1); ++ph) {   // (SPEC: the iteration on b~, then -- from the point moved to b -- whatever is left of it; rolled: one copy of the loop)
   // (the two helpers below are defined INSIDE the phase loop: defined in front of it, the closure of one of them stayed behind as a dead 36-byte
@@ -490,14 +498,6 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
       Np0 = r0x * k0 + r1x * k1; Np1 = r0y * k0 + r1y * k1; Np2 = r0z * k0 + r1z * k1;
     }
   };
-#ifdef WBC_QP_STAMP
-  const long long st_t1 = __builtin_readcyclecounter();
-  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long st_last = st_t1;
-#define SEG(i) do { const long long now_ = __builtin_readcyclecounter(); seg[i] += now_ - st_last; st_last = now_; } while (0)
-#else
-#define SEG(i) do {} while (0)
-#endif
   {  // first candidate, at x0
     T val; int id;
     const bool found = most_violated(dppx<0x00>(x_me), dppx<0x55>(x_me), dppx<0xAA>(x_me), actA, actB, val, id);
