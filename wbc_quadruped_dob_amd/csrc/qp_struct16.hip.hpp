@@ -119,7 +119,8 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
   // SPEC (fused / rollout kernels with the observer on, cold start): the target wrench b = w_des - rhat_base is the last input to arrive -- the observer
   // role's base rows end at about +6.2 us, the QP's factor is done at +3.6.  The iteration therefore STARTS on b~ = w_des - r_prev (the observer state as
-  // the tick finds it: an input, one filter step away from rhat) and, when rhat is there, moves the solution to b on the active set it has reached: with
+  // the tick finds it: an input, one filter step away from rhat; QpArgs::rprev, null = opt out) and, when rhat is there, moves the solution to b on the
+// active set it has reached: with
   // beta -> beta + d the minimiser on a fixed set moves by  dy = -G_A^-1 d,  df_k = -P_k B_k^T dy,  du_k = alpha N_k^+ (df_k + B_k^T dy)  -- one product with
   // the inverse the loop maintains.  Multipliers still >= 0: an S-pair for b, the loop goes on from it (usually it has nothing left to do).  A negative
   // multiplier (a row that the last filter step releases): that row of the wavefront starts over from the empty set with b itself.  The QP is
@@ -425,6 +426,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     WBC_QSTAMP(3);
     if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_b); }
     if constexpr (WSLDS && RHAT && !SPEC) { if (sync) qp_wait(sync->rhat, sync->need_rhat); }
+    if constexpr (SPEC) {   // (a.rprev == null: the caller opts out -- wait for rhat and start on b itself; the move below is then by zero)
+      if (!a.rprev) { if (sync) qp_wait(sync->rhat, sync->need_rhat); rprev_in = (l16 < 6) ? WSLD(WS_RHAT + l16) : (T)0; }
+    }
     WBC_QSTAMP(4);
     if constexpr (PRE) {
       x_me = isvar ? who.pre[36 + v] : (T)0;
