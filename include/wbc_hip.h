@@ -194,7 +194,8 @@ typedef struct wbc_batch_out {
   void* tau;
   void* f;
   int* status;
-  int* iters; /* may be NULL */
+  int* iters; /* may be NULL.  The solver's own count per state -- dual active-set trips (one-launch ticks with the observer on: of both phases of the
+               * speculative start), Newton steps where the per-lane kernel solved the state; informational, never part of the parity contract */
   void* M;    /* optional dynamics outputs: all NULL or M, h, Jc all non-NULL */
   void* h;
   void* Jc;
