@@ -81,7 +81,7 @@ template <class T> struct QpArgs {
   const int* aset_in;  // warm-start kernels: the active set each state's iteration starts from (null: cold); encoding: include/wbc_hip.h
   int* aset_out;       // non-null: receives the active set at the solution (structured QP kernels)
   const T* rprev;      // fused observer-on ticks: the observer state r as the tick finds it ([18][N], base rows used) -- the QP starts on b~ = w_des - r_prev
-                       // while the observer role is still computing r (qp_struct16.hip.hpp, SPEC); null: b~ = w_des
+                       // while the observer role is still computing r (qp_struct16.hip.hpp, SPEC); null: opt out -- the QP waits for rhat as before
 };
 
 struct QpJidx { int j[12]; };  // caller's joint index of leg-major joint 3l+k
