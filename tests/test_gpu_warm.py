@@ -42,7 +42,7 @@ def _second_tick(B, seed):
                                              ("f64", 0, 2, 53248), ("f32", 1, 4, 3000), ("f32", 0, 2, 33000), ("f32", 0, 2, 40000), ("f32", 1, 3, 150001)])
 def test_warm_tick_equals_cold_tick_and_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n):
     """Two consecutive ticks.  Tick 1 through wbc_step_batch_warm without a set (cold) reports the active sets; tick 2 starts from
-    them.  Fused tick (<= 8 192 states), two-kernel ticks with the one-wavefront warm kernel, with the cold tiles (which only report the
+    them.  Fused tick (<= 11 264 states, observer on 12 288), two-kernel ticks with the one-wavefront warm kernel, with the cold tiles (which only report the
     sets) and with the warm per-lane pair; observer off / on / split."""
     torch = torch_cuda
     nd = _np_dtype(dtype)

@@ -34,7 +34,7 @@ bad, worst, worst_big, t0 = [], 0.0, 0.0, time.time()
 for c in range(cases):
     obs = int(rng.integers(0, 3))
     cfg = int(rng.choice([2, 3, 4]))
-    n = int(rng.choice([1, 7, 16, 17, 100, 1000, 2048, 4096, 5000, 8192][: (10 if obs == 0 else 8)]))
+    n = int(rng.choice([1, 7, 16, 17, 100, 1000, 2048, 4096, 5000, 8192, 11000, 12288][: (11 if obs == 0 else 12)]))   # (the one-launch tick: up to 11 264 states, observer on 12 288)
     if rng.random() < 0.3:
         n = int(rng.integers(1, 4097))
     big = c % 7 == 3   # a larger batch: the tiled QP kernel (dealt by predicted work; the predictor hands G^-1 / x0 to the solver or finishes the state) and the per-lane kernel against the one-wave kernel

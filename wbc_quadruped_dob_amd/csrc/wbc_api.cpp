@@ -72,7 +72,7 @@ constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints 
 #ifndef WBC_WARM_LANE_MIN_F32
 #define WBC_WARM_LANE_MIN_F32 36864
 #endif
-struct Resolved { size_t fused_max, fused_max_noobs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min; };
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -315,11 +315,15 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
 // wbc_dispatch_thresholds report it (tests/test_gpu_parity.py straddles every switch with it, so a moved threshold moves the test).
 static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   Resolved r;
-  // rollouts of at most fused_max states run as ONE persistent launch (rollout_kernel); ticks of at most fused_max_noobs states run as
+  // rollouts of at most fused_max states run as ONE persistent launch (rollout_kernel); ticks of at most fused_max_noobs / fused_max_obs states run as
   // ONE kernel (fused_tick.hip.hpp): it still wins with two rounds of workgroups -- since round 3 also with the observer on in fp64
   // (M steps/s, two-kernel -> fused: 5 120 states 175 -> 233, 6 144: 220 -> 287, 8 192: 258 -> 331) -- and loses from 12 288 on
-  r.fused_max = 4096; r.fused_max_noobs = 8192;
-  if (o.fused_max >= 0) r.fused_max = r.fused_max_noobs = (size_t)o.fused_max;
+  // End of round 4 (the observer-on tick's QP no longer waits for rhat, warm ticks end with the dynamics roles): the one-launch tick still wins with THREE
+  // rounds of workgroups.  M steps/s, two-kernel -> fused: fp64 observer on 9 216: 291 -> 318, 10 240: 317 -> 351, 12 288: 347 -> 377, but 13 312: 384 -> 353;
+  // fp32 observer on 9 216: 281 -> 344, 12 288: 380 -> 406, 13 312: 360 -> 376, 14 336: 385 -> 347; fp64 observer off 9 216: 295 -> 301, 11 264: 309 -> 328,
+  // 12 288: 348 -> 342 (warm ticks in a closed loop, kernels in us: observer off 10 240: 30.9 -> 27.6, 12 288: 32.7 -> 30.2; on 10 240: 34.8 -> 32.7).
+  r.fused_max = 4096; r.fused_max_noobs = 11264; r.fused_max_obs = 12288;
+  if (o.fused_max >= 0) r.fused_max = r.fused_max_noobs = r.fused_max_obs = (size_t)o.fused_max;
   // observer as its own kernel before the sweep (the all-in-one observer sweep runs one wavefront per SIMD).  Measured on
   // MI355X, front half of the tick, all-in-one -> observer kernel + observer-free sweep (us): fp64 464 -> 112 + 279 at
   // 262 144 states, 111 -> 34 + 57 at 65 536, but 48 -> 25 + 33 at 32 768; fp32 298 -> 57 + 168 at 262 144, 45 -> 17 + 27 at
@@ -351,7 +355,7 @@ struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block, qp_wa
 static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf, bool warm = false) {
   TickPlan p{};
   const bool ob = observer_order > 0, f32 = dtype == WBC_F32;
-  if ((mats || !pf) && N <= r.fused_max_noobs) {
+  if ((mats || !pf) && N <= (ob ? r.fused_max_obs : r.fused_max_noobs)) {
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
     p.fused = 1;
@@ -468,7 +472,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.fused_max_noobs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537};
   size_t keep[16]; int k = 0;
   for (size_t c : cand) {
