@@ -103,7 +103,7 @@ enum wbc_timing_mode { WBC_TIMING_DISPATCH = 0, /* the dispatch's own start/stop
 typedef struct wbc_solver_options {
   size_t struct_size;     /* sizeof(wbc_solver_options) of the caller's build (set by wbc_solver_options_default) */
   long long fused_max;    /* ticks of at most this many states run as ONE launch of wavefront roles; -1 = auto
-                             (8192; rollouts: 4096), 0 = always the two-kernel tick */
+                             (11264, observer on 12288; rollouts: 4096 -- wbc_plan_tick / wbc_dispatch_thresholds report it), 0 = always the two-kernel tick */
   int rollout_persistent; /* 1 (default): rollouts of at most fused_max (auto: 4096) states = one launch per rollout; 0: per-tick launches */
   int rollout_spw;        /* states per workgroup of the rollout kernel: 0 = auto (4 up to 1024 states, else 16), 4, 16 */
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
