@@ -70,7 +70,13 @@ constexpr int FUSED_OBS_WAVES = 2;
 #ifndef WBC_FUSED_SPLIT_H_WARM
 #define WBC_FUSED_SPLIT_H_WARM 1
 #endif
-template <class T, bool OBSERVER, bool MATS, bool WARM = false> constexpr bool fused_split_h() { return (WBC_FUSED_SPLIT_H || (WBC_FUSED_SPLIT_H_WARM && WARM)) && !OBSERVER && MATS && sizeof(T) == 8; }
+#ifndef WBC_FUSED_SPLIT_H_WARM_F32   // (the fp32 WARM instantiation holds 254 registers: one workgroup per CU whatever the wavefront count -- measured: tick
+                                     //  kernel 12.4 -> 12.1 us at 4 096 drifting states, 21.3 -> 20.4 at 8 192: too little to carry another instantiation)
+#define WBC_FUSED_SPLIT_H_WARM_F32 0
+#endif
+template <class T, bool OBSERVER, bool MATS, bool WARM = false> constexpr bool fused_split_h() {
+  return !OBSERVER && MATS && ((WBC_FUSED_SPLIT_H && sizeof(T) == 8) || (WBC_FUSED_SPLIT_H_WARM && WARM && (sizeof(T) == 8 || WBC_FUSED_SPLIT_H_WARM_F32)));
+}
 template <class T, bool OBSERVER, bool MATS, bool WARM = false> constexpr int fused_threads() { return OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : (fused_split_h<T, OBSERVER, MATS, WARM>() ? 448 : 384); }
 // WARM: the QP of every state starts from the active set in qa.aset_in (wbc_step_batch_warm: dependent ticks of a closed loop)
 template <class T, bool OBSERVER, bool MATS, bool WARM = false>
