@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--closed-loop", action="store_true",
                     help="extra leg: dependent ticks of a DRIFTING batch, cold start against wbc_step_batch_warm, reported beside `value` (opt-in: its "
                          "cold ticks launch the same kernel symbols as the timed region and would mix into a rocprofv3 --stats summary of the command)")
+    ap.add_argument("--closed-loop-only", action="store_true",
+                    help="(internal) print ONLY the closed-loop leg of this config / batch -- the bench's own batch and the same batch with +-40 N "
+                         "lateral commands -- as one JSON line: what the default run starts as a CHILD process")
+    ap.add_argument("--no-closed-loop", action="store_true", help="default run: do not start the closed-loop child")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 without torchrun: ONE process drives N devices through the C-ABI's wbc_multi_* path")
     args = ap.parse_args()
@@ -175,6 +179,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.single_process:
         return multi_capi_bench(args, W, synth, torch, np)
+    if args.closed_loop_only:
+        return closed_loop_only(args, W, synth, torch, np)
     if world != args.gpus:
         sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
         sys.exit(2)
@@ -373,6 +379,12 @@ def main():
                 res["closed_loop"] = closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, local_rank, want_mats)
             except Exception as e:  # never lose the main line to the optional leg
                 res["closed_loop"] = {"error": repr(e)[:200]}
+        elif world == 1 and not args.no_closed_loop and not args.no_latency:
+            # The full line carries the closed loop of its own batch (`value` is the cold tick on STANDING inputs, the friendliest case
+            # of its kernel -- the same batch ticked as a control loop, and with harder commands, belongs beside it).  It runs in a CHILD process
+            # started without the profiler's preload: its cold ticks launch the same kernel symbols as the timed region and would otherwise mix
+            # into a rocprofv3 --stats summary of this command.
+            res["closed_loop"] = closed_loop_child(args)
         if not args.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(B, P, dtype, n)
             fl = res["cpu_baseline"].get("flops_per_step")
@@ -409,6 +421,42 @@ def load_model(W, torch, dist, rank, local_rank):
     from wbc_quadruped_dob_amd.sharding import broadcast_model
     flat = W.Model.from_urdf(W.SYNTHETIC_URDF).flat() if rank == 0 else None
     return W.Model.from_flat(broadcast_model(flat, dist, device=torch.device("cuda", local_rank)))
+
+
+def closed_loop_child(args):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not (k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE") or k.startswith("ROCP") or k.startswith("ROCPROF"))}
+    cmd = [sys.executable, os.path.abspath(__file__), "--closed-loop-only", "--config", str(args.config), "--batch", str(args.batch)]
+    if args.dtype:
+        cmd += ["--dtype", args.dtype]
+    if args.no_mats:
+        cmd += ["--no-mats"]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": "child exited %d: %s" % (p.returncode, p.stderr[-200:])}
+        return json.loads(lines[-1])
+    except Exception as e:  # never lose the main line to this leg
+        return {"error": repr(e)[:200]}
+
+
+def closed_loop_only(args, W, synth, torch, np):
+    dtype = args.dtype or ("f32" if args.config == 4 else "f64")
+    obs = 0 if args.config == 2 else 1
+    td = torch.float64 if dtype == "f64" else torch.float32
+    n = args.batch
+    model = W.Model.from_urdf(W.SYNTHETIC_URDF)
+    P = synth.default_params(observer_order=obs, dtype=dtype)
+    B = synth.make_batch(args.config, n, model.total_mass, rank=0)
+    res = closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, 0, not args.no_mats)
+    Bh = {k: v.copy() for k, v in B.items()}
+    Bh["w_des"][:, 0:2] += np.random.default_rng(1).uniform(-40, 40, (n, 2))   # (tools/warm_loop.py's batch: the same mean iteration count, harder worst cases)
+    hard = closed_loop_leg(W, torch, np, model, P, Bh, dtype, td, obs, n, 0, not args.no_mats)
+    res["hard_commands"] = {k: hard[k] for k in ("cold", "warm", "speedup_wall")}
+    res["hard_commands"]["note"] = "the same loop with +-40 N lateral commands added to w_des: the tick lasts as long as its hardest QP"
+    res["process"] = "child of the bench run (no profiler preload)"
+    print_line(res)
 
 
 def closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, device, want_mats, ticks=200):
@@ -667,34 +715,64 @@ def multi_capi_bench(args, W, synth, torch, np):
     tick_b, outs_b = ms.prepare_step(n_total, ins, obs_state, want_mats=not args.no_mats)   # second tau buffer for the overlapped gather
     tau_all = ms.allgather_tau(n_total, outs)
     tau_all_b = ms.allgather_tau(n_total, outs_b)
+    tick_gather = ms.prepare_tick_gather(n_total, [tick.capi, tick_b.capi], [tau_all, tau_all_b])
     ms.synchronize()
 
-    def run(mode):
-        times, total = [], 0.0
+    def run(mode, ms=ms, tick=tick, tick_gather=tick_gather):
+        times, total, host = [], 0.0, []
         while total < 0.05 or not times:
             ms.synchronize()
+            ms.host_stats(reset=True)
             t0 = time.perf_counter()
             for k in range(args.steps):
-                if mode == 2:      # wbc_multi_allgather_tau_async: gather of tick k beside tick k + 1, tau double-buffered
-                    b = k & 1
-                    ms.gather_wait(b)
-                    (tick_b if b else tick)()
-                    ms.allgather_tau_async(n_total, outs_b if b else outs, tau_all_b if b else tau_all, b)
+                if mode == 2:      # wbc_multi_tick_gather: gather_wait + tick + the gather of tick k beside tick k + 1, tau double-buffered, ONE call
+                    tick_gather(k & 1)
                 else:
                     tick()
                     if mode == 1:
                         ms.allgather_tau(n_total, outs, tau_all)
+            t1 = time.perf_counter()
             ms.synchronize()
             times.append(time.perf_counter() - t0)
             total += times[-1]
-        return times
+            calls, sec = ms.host_stats()
+            host.append((sec / args.steps * 1e6, (t1 - t0) / args.steps * 1e6))   # inside the C entry points / the whole Python loop, per tick
+        return times, host
 
     for _ in range(args.warmup):
         tick()
-    blocks = run(0)
-    sblocks = run(1)
-    gblocks = run(2)
+    blocks, host0 = run(0)
+    sblocks, host1 = run(1)
+    gblocks, host2 = run(2)
     el, gel, sel = float(np.median(blocks)), float(np.median(gblocks)), float(np.median(sblocks))
+    med = lambda hs, i: float(np.median([h[i] for h in hs]))
+    host_issue = {"issue_threads": ms.issue_threads,
+                  "tick_call_us": med(host0, 0), "tick_loop_us": med(host0, 1),
+                  "tick_gather_call_us": med(host2, 0), "tick_gather_loop_us": med(host2, 1),
+                  "note": "host time per tick: *_call_us inside the C entry points (wbc_multi_host_stats), *_loop_us the Python loop around them; the device "
+                          "needs ms_per_step -- the path is host-bound when the call time exceeds it"}
+    # the same ticks with the issue threads forced on / off (wbc_solver_options.multi_threads = 1 / -1; auto = threads when the shards sit on more than
+    # one device), same gather backend: what the caller pays per tick either way
+    for tag, mt in (("threads", 1), ("serial", -1)):
+        try:
+            ms_v = W.MultiSolver(model, W.Params.from_dict(P, dtype), dtype=dtype, devices=devices, max_batch_total=n_total,
+                                 gather="rccl" if distinct else "peer", options={"multi_threads": mt})
+            tick_v, outs_v = ms_v.prepare_step(n_total, ins, obs_state, want_mats=not args.no_mats)
+            tick_vb, outs_vb = ms_v.prepare_step(n_total, ins, obs_state, want_mats=not args.no_mats)
+            alls_v = [ms_v.allgather_tau(n_total, outs_v), ms_v.allgather_tau(n_total, outs_vb)]
+            tg_v = ms_v.prepare_tick_gather(n_total, [tick_v.capi, tick_vb.capi], alls_v)
+            ms_v.synchronize()
+            for _ in range(args.warmup):
+                tick_v()
+            bl_v, host_v = run(0, ms=ms_v, tick=tick_v, tick_gather=None)
+            bl_g, host_g = run(2, ms=ms_v, tick=tick_v, tick_gather=tg_v)
+            host_issue[tag] = {"issue_threads": ms_v.issue_threads, "empty_ticket_us": ms_v.probe_issue(), "tick_call_us": med(host_v, 0), "tick_loop_us": med(host_v, 1),
+                               "value": args.steps * n_total / float(np.median(bl_v)),
+                               "tick_gather_call_us": med(host_g, 0), "tick_gather_loop_us": med(host_g, 1),
+                               "with_tau_allgather_value": args.steps * n_total / float(np.median(bl_g))}
+            del ms_v, tick_v, tick_vb, tg_v
+        except Exception as e:
+            host_issue[tag] = {"error": repr(e)[:200]}
     ok = float(np.mean([(o["status"] == 0).double().mean().item() for o in outs]))
     print_line({
         "metric": "WBC control-steps/sec (batched DogBot)", "value": args.steps * n_total / el, "unit": "control-steps/s",
@@ -708,9 +786,10 @@ def multi_capi_bench(args, W, synth, torch, np):
                    "block_ms_max": max(blocks) * 1e3},
         "with_tau_allgather": {"value": args.steps * n_total / gel, "ms_per_step": gel / args.steps * 1e3,
                                "collective": ("RCCL ncclAllGather (ncclCommInitAll, one group call)" if distinct else "peer copies (shards share a device)")
-                                             + "; wbc_multi_allgather_tau_async: on the gather streams beside the next tick, tau double-buffered",
+                                             + "; wbc_multi_tick_gather: the gather on the gather streams beside the next tick, tau double-buffered, one call per tick",
                                "serial": {"value": args.steps * n_total / sel, "ms_per_step": sel / args.steps * 1e3,
                                           "collective": "wbc_multi_allgather_tau on the shard streams behind every tick"}},
+        "host_issue": host_issue,
         "rccl_ranks": ms.rccl_ranks, "qp": {"status_ok_frac": ok}, "roofline": None, "cpu_baseline": None})
 
 

@@ -140,6 +140,16 @@ typedef struct wbc_solver_options {
   int rollout_warm;       /* (default 1) wbc_rollout_batch / wbc_rollout_tracking_batch: every tick after the first starts its GRF QPs from the
                              active set of the previous tick (see wbc_step_batch_warm).  The QP is strictly convex, so the results do not
                              depend on it -- the time per tick does.  0: every tick solves from the unconstrained minimum */
+  int multi_threads;      /* (ABI 7; read by wbc_multi_create only) one persistent ISSUE THREAD per shard, bound to the shard's device: an entry point
+                             validates every shard on the caller's thread, posts one ticket, the threads enqueue their shards in parallel and the call
+                             returns when all have -- eight devices are no longer fed one launch after the other from one thread.  0 = auto (threads when
+                             the shards sit on more than one device), 1 = always, -1 = never (the serial issue of ABI <= 6) */
+  int multi_spin_us;      /* (default 200) an idle issue thread polls for its next ticket this long before it parks on a condition variable: a tick loop
+                             never pays a wake-up, a 1 kHz control loop does not burn a core per shard */
+  int obs_colaunch;       /* (ABI 7) observer-on two-kernel ticks with M/h/Jc outputs: the observer update and the observer-free sweep as the TWO ROLES OF
+                             ONE LAUNCH (wbc_tick_plan.front = 4) while both roles' wavefronts are resident together -- fp32 batches of 12290 ... 32768
+                             states (even; both roles with two states per lane), BASELINE's configs[3] shard.  0 = auto, 1 = whenever the tick is
+                             a two-kernel tick with the observer on, -1 = never */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -154,7 +164,8 @@ typedef struct wbc_tick_plan {
   size_t struct_size; /* in: sizeof of the caller's build (0 = this build's); out: bytes written */
   int fused;          /* 1: the whole tick is ONE fused_tick launch (wavefront roles); everything below is 0 then */
   int front;          /* two-kernel ticks, front half: 0 = dyn_sweep (observer inside when on), 1 = rnea_step (caller passes no M/h/Jc),
-                         2 = observer kernel + observer-free dyn_sweep, 3 = observer kernel + observer-free rnea_step (no M/h/Jc) */
+                         2 = observer kernel + observer-free dyn_sweep, 3 = observer kernel + observer-free rnea_step (no M/h/Jc),
+                         4 = observer update and observer-free dyn_sweep as the two roles of ONE launch (sweep_obs_kernel) */
   int qp;             /* 0 = qp_group16 (one-wavefront workgroups), 1 = qp_tile (tiles dealt by predicted work), 2 = qp_lane + qp_list */
   int qp_tile;        /* states per tile when qp == 1 */
   int qp_body;        /* 0 = wrench-space dual active set in fp64 arithmetic, 1 = 12 x 12 orthogonal-factor body in fp32 (fp32 tiles beyond 65 536 states) */
@@ -233,8 +244,8 @@ int wbc_step_batch(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_ba
  * Bits of swing feet are ignored.  The set is a HINT: the solver builds the minimiser on it in one block step and continues the
  * iteration from there when it is an S-pair of the dual method (independent rows, non-negative multipliers), otherwise it starts
  * cold -- the QP is strictly convex, so tau, f and status never depend on the hint, only `iters` (= iterations after the block step)
- * and the time do.  Same buffers, checks and stream semantics as wbc_step_batch; batches beyond the fused-tick size solve the QPs with
- * the one-wavefront kernel (wbc_plan_tick with warm = 1). */
+ * and the time do.  Same buffers, checks and stream semantics as wbc_step_batch.  Which kernels run: wbc_plan_tick with warm = 1 -- a call with
+ * active_in = NULL runs (and is planned as) the cold tick, which still reports the sets. */
 int wbc_step_batch_warm(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_batch_out* out, const wbc_observer_state* obs,
                         const int* active_in, int* active_out, void* stream);
 
@@ -319,12 +330,14 @@ int wbc_compute_reference(wbc_solver* s, const double* q, const double* v, const
  * 4096 event pairs once; samples beyond it are dropped until wbc_solver_collect_timing drains the ring, so a tick never
  * allocates.  While timing is on, the instrumented dispatches are not hipGraph-capturable. ---- */
 int wbc_solver_enable_timing(wbc_solver* s, int on); /* 0 off; 1 every kernel launch; k > 1: every k-th tick */
-#define WBC_TIMING_KINDS 6   /* ABI 6 (was 5): callers pass arrays of this many entries */
+#define WBC_TIMING_KINDS 6   /* kinds this build knows */
 /* synchronises the recorded events; returns summed milliseconds and launch counts since the last reset, indexed
  * 0 = dyn_sweep kernel, 1 = QP kernel, 2 = rnea_step kernel (no-M/h/Jc ticks) / stand-alone observer kernel,
  * 3 = fused tick kernel (sweep + QP of small batches in one launch), 4 = per-lane QP kernel (then 1 = the dense kernel's
  * pass over the states the per-lane kernel handed over), 5 = persistent rollout kernel (one launch = a whole horizon); resets the accumulators. */
-int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KINDS], int launches[WBC_TIMING_KINDS]);
+int wbc_solver_collect_timing_n(wbc_solver* s, double* ms, int* launches, int cap /* entries of ms / launches: at most cap are written */);
+/* the unsized call of ABI <= 6: writes FIVE entries (kinds 0 .. 4), what every version of it has written; use the sized call */
+int wbc_solver_collect_timing(wbc_solver* s, double* ms, int* launches);
 
 /* ---- multi-device: ONE host process, one solver per GPU of the node.  The reference is a single C++
  * process (/root/reference/README.md:58-60); this is how that process shards a batch over the node without Python.
@@ -374,7 +387,16 @@ int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* ta
  *     wbc_multi_gather_wait(mm, b);  wbc_multi_step_batch(... out[b] ...);  wbc_multi_allgather_tau_async(mm, n, tau_b, tau_all_b, b);  */
 int wbc_multi_allgather_tau_async(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, int slot);
 int wbc_multi_gather_wait(wbc_multi* mm, int slot);
+/* One call per tick of that double-buffered loop: wbc_multi_gather_wait(slot), the tick (wbc_multi_step_batch, or _warm when active is given)
+ * writing out[k].tau -- the slot's buffer -- and wbc_multi_allgather_tau_async of out[k].tau into tau_all[k]: two tickets to the issue threads. */
+int wbc_multi_tick_gather(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out, const wbc_observer_state* obs,
+                          int* const* active /* may be NULL */, void* const* tau_all, int slot);
 int wbc_multi_synchronize(wbc_multi* mm);                   /* waits for every shard stream (and gather stream) */
+int wbc_multi_issue_threads(const wbc_multi* mm);           /* number of issue threads (0: the shards are issued on the caller's thread) */
+/* host time the caller has spent INSIDE the tick / rollout / gather entry points since the last reset: what feeding the devices costs */
+int wbc_multi_host_stats(wbc_multi* mm, unsigned long long* calls, double* seconds, int reset);
+/* diagnostics: the time of `iters` EMPTY tickets through the issue threads (what a round trip costs apart from the HIP calls inside it) */
+int wbc_multi_probe_issue(wbc_multi* mm, int iters, double* seconds);
 /* Host-resident batch (a C++ caller that holds host arrays, e.g. the ROS side): in / out / obs hold HOST pointers to
  * component-major arrays [ncomp][n_total] of the solver's scalar type; slices are scattered to the devices with pitched
  * copies, stepped, and tau, f, status, iters (and the observer state, when obs is given) gathered back.  out->M, h, Jc,
@@ -402,7 +424,7 @@ int wbc_qp_dense_batch(int dtype, size_t N, int n, int m, int meq, const void* H
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void); /* 6 */
+int wbc_abi_version(void); /* 7 */
 
 #ifdef __cplusplus
 }

@@ -150,9 +150,12 @@ def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_r
         assert elementwise_excess(got["tau"][ok], ref["tau"][ok]) <= 1.0
         assert elementwise_excess(got["f"][ok], ref["f"][ok]) <= 1.0
     else:
+        # fp32 against the fp32 oracle: measured 1.4e-4 of the largest entry and no status flip over 800 soak cases (profiles/r04i_soak_long.log);
+        # the gates sit at 5e-4 and one flip in a thousand (round 4: 2e-3 and five in a thousand)
+        assert (got["status"] != ref["status"]).mean() <= 1e-3
         ok = (got["status"] == 0) & (ref["status"] == 0)
         assert ok.mean() > 0.995
-        tol = 2e-3
+        tol = 5e-4
     assert relerr(got["tau"][ok], ref["tau"][ok]) < tol and relerr(got["f"][ok], ref["f"][ok]) < tol
     if obs:
         assert relerr(got["integ"], ig_ref) < (TIGHT64 if dtype == "f64" else 1e-4)

@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("WBC_LIB") or os.path.join(_HERE, "lib", "libwbc_hip.s
 SYNTHETIC_URDF = os.path.join(_HERE, "assets", "synthetic_quadruped.urdf")
 WBC_MAXV = 32
 F64, F32 = 0, 1
+ABI_VERSION = 7   # include/wbc_hip.h: wbc_abi_version()
 
 _lib = None
 
@@ -97,10 +98,12 @@ class SolverOptions(C.Structure):
     the environment; Solver(options=None) builds them from the defaults overridden by the WBC_* variables below -- a
     convenience of THIS binding for the A/B scripts under tools/ and bench.py."""
     _fields_ = [("struct_size", C.c_size_t), ("fused_max", C.c_longlong), ("rollout_persistent", C.c_int),
-                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int), ("f32_pack2", C.c_int), ("keep_structural", C.c_int), ("rollout_warm", C.c_int)]
+                ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int), ("f32_pack2", C.c_int), ("keep_structural", C.c_int), ("rollout_warm", C.c_int),
+                ("multi_threads", C.c_int), ("multi_spin_us", C.c_int), ("obs_colaunch", C.c_int)]
     ENV = {"WBC_FUSED_MAX": ("fused_max", int), "WBC_ROLLOUT_PERSISTENT": ("rollout_persistent", int),
            "WBC_ROLLOUT_SPW": ("rollout_spw", int), "WBC_OBS_SPLIT_MIN": ("obs_split_min", int),
            "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int), "WBC_QP_LANE": ("qp_lane", int), "WBC_F32_PACK2": ("f32_pack2", int), "WBC_KEEP_STRUCTURAL": ("keep_structural", int), "WBC_ROLLOUT_WARM": ("rollout_warm", int),
+           "WBC_MULTI_THREADS": ("multi_threads", int), "WBC_MULTI_SPIN_US": ("multi_spin_us", int), "WBC_OBS_COLAUNCH": ("obs_colaunch", int),
            "WBC_TIMING": ("timing_mode", lambda v: 1 if v == "pair" else 0)}
 
     @staticmethod
@@ -232,6 +235,15 @@ def lib():
         L.wbc_dispatch_thresholds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.wbc_solver_invalidate_structural.argtypes = [C.c_void_p]
         L.wbc_qp_dense_batch.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_double] + [C.c_void_p] * 5
+        # this binding's struct layouts and array sizes are those of ONE header version: refuse any other library
+        if L.wbc_abi_version() != ABI_VERSION:
+            raise RuntimeError("%s is ABI %d, this binding is written against ABI %d: rebuild the library (python -c 'import __graft_entry__ as g; g.build()')"
+                               % (LIB_PATH, L.wbc_abi_version(), ABI_VERSION))
+        L.wbc_solver_collect_timing_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.wbc_multi_tick_gather.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.wbc_multi_issue_threads.argtypes = [C.c_void_p]
+        L.wbc_multi_host_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.wbc_multi_probe_issue.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -579,7 +591,7 @@ class Solver:
     def collect_timing(self):
         ms = (C.c_double * 6)()
         cnt = (C.c_int * 6)()
-        _check(lib().wbc_solver_collect_timing(self._h, ms, cnt), "wbc_solver_collect_timing")
+        _check(lib().wbc_solver_collect_timing_n(self._h, ms, cnt, 6), "wbc_solver_collect_timing_n")
         names = ("dyn", "qp", "rnea", "fused", "qp_lane", "rollout")  # fused = one-kernel tick of small batches; dyn = fused sweep (mass_jac kernel with WBC_SWEEP=split); rnea = rnea_step front half
         out = {}
         for i, n in enumerate(names):
@@ -723,6 +735,7 @@ class MultiSolver:
             rc = fn_warm(h, n_total, BI, BO, OS if has_obs else None, ACT) if warm else fn(h, n_total, BI, BO, OS if has_obs else None)
             if rc:
                 _check(rc, "wbc_multi_step_batch_warm" if warm else "wbc_multi_step_batch")
+        tick.capi = (BI, BO, OS, ACT, has_obs)   # (for prepare_tick_gather)
         return tick, outs
 
     def allgather_tau(self, n_total, outs, tau_all=None):
@@ -743,6 +756,38 @@ class MultiSolver:
         allp = (C.c_void_p * self.n)(*[t.data_ptr() for t in tau_all])
         _check(lib().wbc_multi_allgather_tau_async(self._h, n_total, loc, allp, int(slot)), "wbc_multi_allgather_tau_async")
         return tau_all
+
+    def prepare_tick_gather(self, n_total, ticks, tau_alls, warm=False):
+        """wbc_multi_tick_gather as a closure: ticks = [(BI, BO, OS, ACT) per slot] as kept by prepare_step (its _keep tuple), tau_alls = per slot the
+        per-device gather buffers.  Returns run(slot): gather_wait(slot) + tick into the slot's tau + overlapped gather of the slot, ONE call."""
+        fn, h = lib().wbc_multi_tick_gather, self._h
+        slots = []
+        for (BI, BO, OS, ACT, has_obs), tau_all in zip(ticks, tau_alls):
+            allp = (C.c_void_p * self.n)(*[t.data_ptr() for t in tau_all])
+            slots.append((BI, BO, OS if has_obs else None, ACT if warm else None, allp))
+
+        def run(slot, _keep=(ticks, tau_alls, slots)):
+            BI, BO, OS, ACT, allp = slots[slot]
+            rc = fn(h, n_total, BI, BO, OS, ACT, allp, slot)
+            if rc:
+                _check(rc, "wbc_multi_tick_gather")
+        return run
+
+    @property
+    def issue_threads(self):
+        return lib().wbc_multi_issue_threads(self._h)
+
+    def host_stats(self, reset=True):
+        """(calls, seconds) the caller has spent inside the tick / rollout / gather entry points since the last reset"""
+        calls, sec = C.c_ulonglong(), C.c_double()
+        _check(lib().wbc_multi_host_stats(self._h, C.byref(calls), C.byref(sec), 1 if reset else 0), "wbc_multi_host_stats")
+        return calls.value, sec.value
+
+    def probe_issue(self, iters=2000):
+        """microseconds per EMPTY ticket through the issue threads (serial issue: per empty loop over the shards)"""
+        sec = C.c_double()
+        _check(lib().wbc_multi_probe_issue(self._h, int(iters), C.byref(sec)), "wbc_multi_probe_issue")
+        return sec.value / iters * 1e6
 
     def gather_wait(self, slot):
         """the shard streams wait (on the device) for the last gather of `slot`: before the tick that overwrites that slot's tau"""

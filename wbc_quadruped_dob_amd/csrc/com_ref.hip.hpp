@@ -47,10 +47,10 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
 #pragma unroll
   for (int c = 0; c < PLAN_WORDS; ++c) pl[c] = RLDU(a.plan, c);
   int jx[3];
+  jidx_of_leg(model, a.jpack, leg, jx);
   T ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    jx[k] = model->jidx[leg][k];
     ql[k] = RLDV(a.q, 7 + jx[k]);
     vl[k] = RLDV(a.v, 6 + jx[k]);
   }

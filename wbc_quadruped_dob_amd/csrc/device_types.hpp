@@ -13,6 +13,12 @@
 #define WBC_OUT_GUARD
 #endif
 
+// 1 (round 5): joint indices come from the packed kernel argument jpack, 0: from DevModel::jidx loads / the QpJidx select chain (rounds 1-4);
+// see jidx_of_leg (dyn_sweep.hip.hpp)
+#ifndef WBC_JIDX_ARGS
+#define WBC_JIDX_ARGS 1
+#endif
+
 namespace wbc {
 
 // ---- per-leg model constants, as read by the dynamics-sweep kernel -------------------------
@@ -70,6 +76,11 @@ template <class T> struct SweepArgs {
   int ws_geom;   // 1: also write d and the own-leg Jacobian blocks to the workspace; 0: the QP reads them from Jc (M/h/Jc ticks)
   int* qp_todo;  // non-null: the hand-over list of the per-lane QP kernel that follows; this kernel empties it (qp_lane.hip.hpp)
   int skip_consts;  // 1: the structural zeros / ones of M and Jc are already in the caller's buffers (wbc_solver_options.keep_structural): not rewritten
+  int skip_mats;    // (persistent rollout, set by the kernel) 1: nobody will read the M / Jc / pf of THIS tick from memory -- the integrator takes them from
+                    // the mass_jac role's LDS image -- so they are not stored (every tick of a launch but the last)
+  unsigned long long jpack;   // the caller's joint index of leg l joint k in nibble 3 l + k (pack_jidx): the bodies take it from these two
+                              // SGPRs instead of loading DevModel::jidx -- a per-lane global load in FRONT of the joint-state loads, i.e. one
+                              // more dependent trip through L2 at the head of every role of every tick (round 5)
 };
 
 template <class T> struct QpArgs {
@@ -82,9 +93,15 @@ template <class T> struct QpArgs {
   int* aset_out;       // non-null: receives the active set at the solution (structured QP kernels)
   const T* rprev;      // fused observer-on ticks: the observer state r as the tick finds it ([18][N], base rows used) -- the QP starts on b~ = w_des - r_prev
                        // while the observer role is still computing r (qp_struct16.hip.hpp, SPEC); null: opt out -- the QP waits for rhat as before
+  unsigned long long jpack;   // QpJidx as nibbles (pack_jidx): what the structured / dense QP bodies index the torque map with
 };
 
 struct QpJidx { int j[12]; };  // caller's joint index of leg-major joint 3l+k
+inline unsigned long long pack_jidx(const int* j12) {   // nibble 3 l + k = joint index (0 .. 11) of leg l joint k
+  unsigned long long p = 0;
+  for (int i = 0; i < 12; ++i) p |= (unsigned long long)(j12[i] & 15) << (4 * i);
+  return p;
+}
 
 // forward dynamics + integrator (integrate.hip.hpp)
 template <class T> struct IntegrateArgs {
@@ -95,6 +112,7 @@ template <class T> struct IntegrateArgs {
   const T* tau_ext;                 // [nv][N] or null
   T* tau_traj;                      // [nj][N] slice for this tick, or null
   T dt;
+  unsigned long long jpack;         // see SweepArgs::jpack
 };
 
 // CoM reference generator (com_ref.hip.hpp)
@@ -111,6 +129,7 @@ template <class T> struct RefArgs {
   T t;
   T* w_des; T* vdot_des;
   T* com;   // [6][N] or null
+  unsigned long long jpack;   // see SweepArgs::jpack
 };
 
 // MODE bits of dyn_sweep_kernel (dyn_sweep.hip.hpp)

@@ -90,7 +90,9 @@ WBC_DEV void structural_consts_quarter(const DevModel<T>* __restrict__ model, co
   const bool live = s_raw < N;
   const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
   const T Z = (T)0;
-  const int j0 = model->jidx[leg][0], j1 = model->jidx[leg][1], j2 = model->jidx[leg][2];
+  int jq[3];
+  jidx_of_leg(model, a.jpack, leg, jq);
+  const int j0 = jq[0], j1 = jq[1], j2 = jq[2];
   if ((N & 1) == 0) {
     // 16 bytes per lane: neighbouring lanes pair up, the even one takes the even-numbered constants, the odd one the odd-numbered
     // ones, each for both states (as in dyn_sweep_kernel): half the store instructions
@@ -139,9 +141,15 @@ WBC_DEV void structural_consts_quarter(const DevModel<T>* __restrict__ model, co
 // hand[word][64] (lane = 16 leg + state slot) -- leg block of M (6: upper triangle (k, j)), base-leg block (18: 6 + 3 r + k), own-leg
 // Jacobian block (9: 24 + 3 m + k), lever arm (3: 33..35), base block as (m, R h, R I R^T) (10: 36..45) -- so that the integrator
 // wavefront neither waits for this role's global stores to drain nor reloads them through L2.
+// Round 5: with `hand` the image is COMPLETE (it holds every data-dependent word this role produces), so the role computes into the image only,
+// calls after_hand() -- the caller raises the integrator's flag there -- and issues the ~50 global store instructions of M, Jc, pf AFTERWARDS, from
+// the image; a tick whose M / Jc nobody will read (a.skip_mats: every tick of a persistent rollout but the last) does not issue them at all.  A wave
+// store instruction costs ~90 cycles to issue whatever its width (tools/issue_probe.hip): they were ~2 us of the mass_jac -> factorisation chain.
 constexpr int MJ_HAND_WORDS = 46;
-template <class T, int BLOCK, int EXT, int SPW = 16, bool ZEROS = true>
-WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext, T* hand = nullptr) {
+struct MjNoHook { WBC_DEV void operator()() const {} };
+template <class T, int BLOCK, int EXT, int SPW = 16, bool ZEROS = true, class AfterHand = MjNoHook>
+WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext, T* hand = nullptr,
+                           AfterHand after_hand = AfterHand()) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   static_assert(SPW == 16 || EXT != 0, "fewer states per workgroup only for roles");
   WBC_LAUNDERED_TID(tx);
@@ -155,14 +163,16 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   const T* cst = EXT ? cst_ext : cst_own;
   const int* zidx_s = EXT ? zidx_ext : zidx_own;
   WBC_ADDR_MACROS
+  const bool direct = hand == nullptr;   // (a literal at every call site: folded)
 
   T qq[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) qq[c] = LDU(a.q, 3 + c);
   int jx[3];
   unsigned jxN[3];
+  jidx_of_leg(model, a.jpack, leg, jx);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { jx[k] = model->jidx[leg][k]; jxN[k] = (unsigned)jx[k] * N32; }
+  for (int k = 0; k < 3; ++k) jxN[k] = (unsigned)jx[k] * N32;
   T ql[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) ql[k] = LDX(a.q, 7, jxN[k]);
@@ -193,6 +203,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   // joint transforms: E of joints 0 and 1 wait in LDS ([word][lane]) until the return sweep reaches them
   __shared__ T park[18][BLOCK];
   const int ln = EXT ? (int)(tx & 63) : (int)tx;
+  T* const hl = hand ? hand + (int)(tx & 63) : nullptr;
   M3<T> E2;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -235,10 +246,11 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
 #pragma unroll
     for (int j = k; j < 3; ++j) {
       const T mkj = dot(ax, Fp[j].n);
-      int i = 6 + jx[k], jj = 6 + jx[j];
-      if (i > jj) { const int t = i; i = jj; jj = t; }
-      STV(a.M, i * 18 - i * (i - 1) / 2 + (jj - i), mkj);
-      if (hand) hand[(k * 3 - k * (k - 1) / 2 + (j - k)) * 64 + (int)(tx & 63)] = mkj;
+      if (direct) {
+        int i = 6 + jx[k], jj = 6 + jx[j];
+        if (i > jj) { const int t = i; i = jj; jj = t; }
+        STV(a.M, i * 18 - i * (i - 1) / 2 + (jj - i), mkj);
+      } else hl[(k * 3 - k * (k - 1) / 2 + (j - k)) * 64] = mkj;
     }
     jc[k] = cross(ax, dft);
     dft = r + mul(E, dft);
@@ -264,33 +276,34 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const V3<T> Mf = mul(R, Fp[k].f), Mn = mul(R, Fp[k].n);
-    const unsigned x = jxN[k];
-    STLX(a.M, 6, 0, x, Mf.x);
-    STLX(a.M, midx18(1, 1) + 5, 0, x, Mf.y);
-    STLX(a.M, midx18(2, 2) + 4, 0, x, Mf.z);
-    STLX(a.M, midx18(3, 3) + 3, 0, x, Mn.x);
-    STLX(a.M, midx18(4, 4) + 2, 0, x, Mn.y);
-    STLX(a.M, midx18(5, 5) + 1, 0, x, Mn.z);
     const V3<T> jw = mul(R, jc[k]);
-    STLX(a.Jc, 0 * 18 + 6, 54, x, jw.x);  // overwrites a zero written above (same lane, program order)
-    STLX(a.Jc, 1 * 18 + 6, 54, x, jw.y);
-    STLX(a.Jc, 2 * 18 + 6, 54, x, jw.z);
-    if (hand) {
-      T* hl = hand + (int)(tx & 63);
+    if (direct) {
+      const unsigned x = jxN[k];
+      STLX(a.M, 6, 0, x, Mf.x);
+      STLX(a.M, midx18(1, 1) + 5, 0, x, Mf.y);
+      STLX(a.M, midx18(2, 2) + 4, 0, x, Mf.z);
+      STLX(a.M, midx18(3, 3) + 3, 0, x, Mn.x);
+      STLX(a.M, midx18(4, 4) + 2, 0, x, Mn.y);
+      STLX(a.M, midx18(5, 5) + 1, 0, x, Mn.z);
+      STLX(a.Jc, 0 * 18 + 6, 54, x, jw.x);  // overwrites a zero written above (same lane, program order)
+      STLX(a.Jc, 1 * 18 + 6, 54, x, jw.y);
+      STLX(a.Jc, 2 * 18 + 6, 54, x, jw.z);
+    } else {
       hl[(6 + 0 + k) * 64] = Mf.x; hl[(6 + 3 + k) * 64] = Mf.y; hl[(6 + 6 + k) * 64] = Mf.z;
       hl[(6 + 9 + k) * 64] = Mn.x; hl[(6 + 12 + k) * 64] = Mn.y; hl[(6 + 15 + k) * 64] = Mn.z;
       hl[(24 + 0 + k) * 64] = jw.x; hl[(24 + 3 + k) * 64] = jw.y; hl[(24 + 6 + k) * 64] = jw.z;
     }
   }
-  if (hand) { T* hl = hand + (int)(tx & 63); hl[33 * 64] = dw.x; hl[34 * 64] = dw.y; hl[35 * 64] = dw.z; }
-  STL(a.Jc, 0 * 18 + 4, 54, dw.z);  STL(a.Jc, 0 * 18 + 5, 54, -dw.y);
-  STL(a.Jc, 1 * 18 + 3, 54, -dw.z); STL(a.Jc, 1 * 18 + 5, 54, dw.x);
-  STL(a.Jc, 2 * 18 + 3, 54, dw.y);  STL(a.Jc, 2 * 18 + 4, 54, -dw.x);
-  if (a.pf) {
-    STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
-    STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
-    STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
-  }
+  if (direct) {
+    STL(a.Jc, 0 * 18 + 4, 54, dw.z);  STL(a.Jc, 0 * 18 + 5, 54, -dw.y);
+    STL(a.Jc, 1 * 18 + 3, 54, -dw.z); STL(a.Jc, 1 * 18 + 5, 54, dw.x);
+    STL(a.Jc, 2 * 18 + 3, 54, dw.y);  STL(a.Jc, 2 * 18 + 4, 54, -dw.x);
+    if (a.pf) {
+      STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
+      STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
+      STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
+    }
+  } else { hl[33 * 64] = dw.x; hl[34 * 64] = dw.y; hl[35 * 64] = dw.z; }
   {
     const T bm = model->base_m;
     const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
@@ -301,15 +314,54 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
     tI.yy = xrow_sum(cI.yy) + model->base_Io[3]; tI.yz = xrow_sum(cI.yz) + model->base_Io[4]; tI.zz = xrow_sum(cI.zz) + model->base_Io[5];
     const V3<T> hw = mul(R, th);
     const S3<T> Iw = congr(R, tI);
-    T* M = a.M;
-    ST4(M, midx18(0, 0), tm, midx18(1, 1), tm, midx18(2, 2), tm, midx18(0, 4), hw.z);
-    ST4(M, midx18(0, 5), -hw.y, midx18(1, 3), -hw.z, midx18(1, 5), hw.x, midx18(2, 3), hw.y);
-    ST4(M, midx18(2, 4), -hw.x, midx18(3, 3), Iw.xx, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz);
-    if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
-    if (hand) {
-      T* hl = hand + (int)(tx & 63);
+    if (direct) {
+      T* M = a.M;
+      ST4(M, midx18(0, 0), tm, midx18(1, 1), tm, midx18(2, 2), tm, midx18(0, 4), hw.z);
+      ST4(M, midx18(0, 5), -hw.y, midx18(1, 3), -hw.z, midx18(1, 5), hw.x, midx18(2, 3), hw.y);
+      ST4(M, midx18(2, 4), -hw.x, midx18(3, 3), Iw.xx, midx18(3, 4), Iw.xy, midx18(3, 5), Iw.xz);
+      if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, Iw.yy, Iw.yz, Iw.zz, Iw.zz));
+    } else {
       hl[36 * 64] = tm; hl[37 * 64] = hw.x; hl[38 * 64] = hw.y; hl[39 * 64] = hw.z;
       hl[40 * 64] = Iw.xx; hl[41 * 64] = Iw.xy; hl[42 * 64] = Iw.xz; hl[43 * 64] = Iw.yy; hl[44 * 64] = Iw.yz; hl[45 * 64] = Iw.zz;
+    }
+  }
+  if (!direct) {
+    after_hand();   // the image is complete: the integrator may start
+    if (!a.skip_mats) {   // M, Jc, pf for the caller, from the image (my own LDS words: program order of one lane)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int j = k; j < 3; ++j) {
+          int i = 6 + jx[k], jj = 6 + jx[j];
+          if (i > jj) { const int t = i; i = jj; jj = t; }
+          STV(a.M, i * 18 - i * (i - 1) / 2 + (jj - i), hl[(k * 3 - k * (k - 1) / 2 + (j - k)) * 64]);
+        }
+        const unsigned x = jxN[k];
+        STLX(a.M, 6, 0, x, hl[(6 + 0 + k) * 64]);
+        STLX(a.M, midx18(1, 1) + 5, 0, x, hl[(6 + 3 + k) * 64]);
+        STLX(a.M, midx18(2, 2) + 4, 0, x, hl[(6 + 6 + k) * 64]);
+        STLX(a.M, midx18(3, 3) + 3, 0, x, hl[(6 + 9 + k) * 64]);
+        STLX(a.M, midx18(4, 4) + 2, 0, x, hl[(6 + 12 + k) * 64]);
+        STLX(a.M, midx18(5, 5) + 1, 0, x, hl[(6 + 15 + k) * 64]);
+        STLX(a.Jc, 0 * 18 + 6, 54, x, hl[(24 + 0 + k) * 64]);
+        STLX(a.Jc, 1 * 18 + 6, 54, x, hl[(24 + 3 + k) * 64]);
+        STLX(a.Jc, 2 * 18 + 6, 54, x, hl[(24 + 6 + k) * 64]);
+      }
+      const T dx = hl[33 * 64], dy = hl[34 * 64], dz = hl[35 * 64];
+      STL(a.Jc, 0 * 18 + 4, 54, dz);  STL(a.Jc, 0 * 18 + 5, 54, -dy);
+      STL(a.Jc, 1 * 18 + 3, 54, -dz); STL(a.Jc, 1 * 18 + 5, 54, dx);
+      STL(a.Jc, 2 * 18 + 3, 54, dy);  STL(a.Jc, 2 * 18 + 4, 54, -dx);
+      if (a.pf) {
+        STL(a.pf, 0, 3, LDU(a.q, 0) + dx);
+        STL(a.pf, 1, 3, LDU(a.q, 1) + dy);
+        STL(a.pf, 2, 3, LDU(a.q, 2) + dz);
+      }
+      const T tm = hl[36 * 64], hwx = hl[37 * 64], hwy = hl[38 * 64], hwz = hl[39 * 64];
+      T* M = a.M;
+      ST4(M, midx18(0, 0), tm, midx18(1, 1), tm, midx18(2, 2), tm, midx18(0, 4), hwz);
+      ST4(M, midx18(0, 5), -hwy, midx18(1, 3), -hwz, midx18(1, 5), hwx, midx18(2, 3), hwy);
+      ST4(M, midx18(2, 4), -hwx, midx18(3, 3), hl[40 * 64], midx18(3, 4), hl[41 * 64], midx18(3, 5), hl[42 * 64]);
+      if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, hl[43 * 64], hl[44 * 64], hl[45 * 64], hl[45 * 64]));
     }
   }
 }
@@ -365,8 +417,9 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   }
   int jx[3];
   unsigned jxN[3];
+  jidx_of_leg(model, a.jpack, leg, jx);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { jx[k] = model->jidx[leg][k]; jxN[k] = (unsigned)jx[k] * N32; }
+  for (int k = 0; k < 3; ++k) jxN[k] = (unsigned)jx[k] * N32;
   T ql[3], vl[3], al[3] = {0, 0, 0}, ad[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 3; ++k) { ql[k] = LDX(a.q, 7, jxN[k]); vl[k] = LDX(a.v, 6, jxN[k]); }
@@ -578,7 +631,16 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     }
     {
       const T hk = dot(ax, fk.n);  // bias torque (TWO) or merged M vdot_des + h (one chain)
-      if (WH) STLX(a.h, 6, 0, jxN[k], hk);
+      if (WH) {
+#if WBC_JIDX_ARGS   // the column offset again, from a laundered copy of the packed map: three VGPRs less across both sweeps than keeping jxN alive
+        unsigned long long jp = a.jpack;
+        asm volatile("" : "+s"(jp));
+        const unsigned jxN_k = (((unsigned)(jp >> (12 * leg)) >> (4 * k)) & 15u) * N32;
+        STLX(a.h, 6, 0, jxN_k, hk);
+#else
+        STLX(a.h, 6, 0, jxN[k], hk);
+#endif
+      }
       if (STEP) taup[k] = hk + (TWO ? dot(ax, fak.n) : (T)0);
     }
     if (OBS) {

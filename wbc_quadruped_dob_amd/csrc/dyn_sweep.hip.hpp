@@ -145,6 +145,20 @@ template <class T, int K> WBC_DEV void xrow_sum_k(T (&x)[K]) {
 
 template <class T> WBC_DEV T sel4(int leg, T a, T b, T c, T d) { return leg == 0 ? a : (leg == 1 ? b : (leg == 2 ? c : d)); }
 
+// The caller's joint indices of a lane's leg.  1 (default, round 5): from the kernel argument jpack (nibble 3 leg + k; SweepArgs / IntegrateArgs /
+// RefArgs) -- one 64-bit shift and three bit-field extracts.  0: the per-lane load of DevModel::jidx of rounds 1-4, which sat IN FRONT of the
+// joint-state loads of every body: two dependent trips through L2 at the head of every role of the fused tick and of every tick of a rollout.
+// (the macro lives in device_types.hpp: the QP bodies use it too)
+template <class Model> WBC_DEV void jidx_of_leg(const Model* __restrict__ model, unsigned long long jpack, int leg, int (&jx)[3]) {
+#if WBC_JIDX_ARGS
+  const unsigned t = (unsigned)(jpack >> (12 * leg));
+  jx[0] = (int)(t & 15u); jx[1] = (int)((t >> 4) & 15u); jx[2] = (int)((t >> 8) & 15u);
+#else
+#pragma unroll
+  for (int k = 0; k < 3; ++k) jx[k] = model->jidx[leg][k];
+#endif
+}
+
 // fp64 sin/cos, straight-line (no branches, so the three joints of a leg interleave in the pipeline): two-term
 // Cody-Waite reduction by pi/2 with FMA, then the classic degree-13 / degree-14 minimax kernels on |r| <= pi/4
 // (coefficients of the well-known fdlibm kernels; < 1 ulp there).  Valid for |x| up to ~1e5 rad -- joint angles.
@@ -233,6 +247,11 @@ WBC_DEV void sincos_t(Pk2f x, Pk2f* sp, Pk2f* cp) {
   *sp = Pk2f(so); *cp = Pk2f(co);
 }
 WBC_DEV Pk2f rsqrt_t(Pk2f x) { wbc_f2v r; r.x = 1.0f / sqrtf(x.v.x); r.y = 1.0f / sqrtf(x.v.y); return Pk2f(r); }
+// a value passed through an empty asm: the compiler can neither move its computation across this point nor rematerialise it later
+WBC_DEV void pin(double& x) { asm volatile("" : "+v"(x)); }
+WBC_DEV void pin(float& x) { asm volatile("" : "+v"(x)); }
+WBC_DEV void pin(Pk2f& x) { asm volatile("" : "+v"(x.v)); }
+template <class X> WBC_DEV void pin(V3<X>& v) { pin(v.x); pin(v.y); pin(v.z); }
 
 // MODE bits
 
@@ -252,8 +271,16 @@ WBC_DEV Pk2f rsqrt_t(Pk2f x) { wbc_f2v r; r.x = 1.0f / sqrtf(x.v.x); r.y = 1.0f 
 // every 16-lane row still moves whole 128-byte lines (16 lanes x 8 B) and the arithmetic is v_pk_fma_f32 / v_pk_mul_f32 /
 // v_pk_add_f32 -- a wavefront then carries 32 states and the batch needs half the wavefronts.  With one fp32 state per lane a
 // row moved half a line per instruction and the kernel took as long as the fp64 one (round 2: 24.1 vs 24.7 us at 32 768 states).
+// The workgroup's LDS (declared by the KERNEL and handed to the body, so that a kernel that runs this body as one of two roles can overlay
+// it with the other role's: sweep_obs_kernel below).  Layout: see the comment in dyn_sweep_body.
+template <class T, int MODE, int BLOCK, int W> struct SweepLds {
+  using V = typename LaneT<T, W>::type;
+  static constexpr bool OBS = (MODE & SW_OBS) != 0;
+  T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; V park[2 * 8 + 6 + (OBS ? 2 : 0) + 9][BLOCK];
+};
+// blk: the index of this workgroup among the workgroups that run this body (blockIdx.x in the stand-alone kernel)
 template <class T, int MODE, int BLOCK, int W = 1>
-WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
+WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, SweepLds<T, MODE, BLOCK, W>& lds, const unsigned blk) {
   using V = typename LaneT<T, W>::type;   // what a lane computes with: T, or a packed pair of T
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0, FWD_B = (MODE & SW_NOB) == 0;
   // ONE LDS object with the constant table first: ds_read / ds_write reach base + 16-bit offset, and the compiler places
@@ -268,8 +295,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr int PB = 6;                    // parked words of the base body's own wrench
   constexpr int PE2 = OBS ? 2 : 0;         // observer: sin, cos of joint 2 too (the momentum pass walks the leg again)
   constexpr int PX = 9;                    // vdot_des base rows 6, base position 3
-  struct Lds { T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; V park[2 * PW + PB + PE2 + PX][BLOCK]; };
-  __shared__ Lds lds;
+  static_assert(sizeof(lds.park) == sizeof(V) * (2 * PW + PB + PE2 + PX) * BLOCK, "SweepLds::park is sized for this layout");
   T (&cst)[CST_WORDS] = lds.cst;
   int (&zidx_s)[64] = lds.zidx_s;
   T (&kgain)[OBS ? 36 : 2] = lds.kgain;
@@ -287,7 +313,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   const unsigned N32 = (unsigned)N;
   // lane = 16*leg + (state within the wave): each 16-lane row owns one leg of 16 consecutive states
   const int leg = (int)((threadIdx.x & 63) >> 4);
-  const size_t s_raw = (((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15)) * W;   // first state of this lane
+  const size_t s_raw = (((size_t)blk * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15)) * W;   // first state of this lane
   const bool live = s_raw < N;                            // (W = 2: N is even, so both states of a lane are in range together)
   // Dead lanes (beyond the batch) recompute the last state(s) and STORE what they computed: bit-identical duplicates of the live
   // lane's values at the same addresses.  Guarding every store with `if (live)` made each of the ~100 stores its own exec region
@@ -324,8 +350,9 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   for (int c = 0; c < 6; ++c) vb[c] = LDU(a.v, c);
   int jx[3];
   unsigned jxN[3];
+  jidx_of_leg(model, a.jpack, leg, jx);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { jx[k] = model->jidx[leg][k]; jxN[k] = (unsigned)jx[k] * N32; }
+  for (int k = 0; k < 3; ++k) jxN[k] = (unsigned)jx[k] * N32;
   V ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -869,7 +896,8 @@ __global__ __launch_bounds__(BLOCK, (MODE & SW_OBS) ? 1 : WBC_SWEEP_WAVES) void 
   // of the same state updated them, i.e. while a workgroup is one wavefront.
   static_assert(!((MODE & SW_OBS) && BLOCK > 64), "observer variants of the sweep are launched as 64-thread workgroups only");
   if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
-  dyn_sweep_body<T, MODE, BLOCK, W>(model, prm, a);
+  __shared__ SweepLds<T, MODE, BLOCK, W> lds;
+  dyn_sweep_body<T, MODE, BLOCK, W>(model, prm, a, lds, blockIdx.x);
 }
 
 }  // namespace wbc

@@ -63,6 +63,10 @@ constexpr int FUSED_OBS_WAVES = 2;
 #ifndef WBC_FUSED_SPLIT_H
 #define WBC_FUSED_SPLIT_H 0
 #endif
+// 1 (default, round 5): the observer role stores r only after the QP wavefronts have read r_prev (QpSync::rp_ack); 0: the unordered read of round 4 (A/B)
+#ifndef WBC_SPEC_ORDER
+#define WBC_SPEC_ORDER 1
+#endif
 // (fp64 only: the fp32 tick fits two six-wavefront workgroups on a CU -- 147 VGPRs, 49 kB LDS -- and a seventh wavefront would end that)
 // WARM ticks are another matter: the block set-up ends the QP at about +5.5 us, so the tick ends with the rnea role and its torque map, and taking
 // the bias-force chain off that role shows: tick kernel 12.0 -> 11.0 us at 1 024 states, 13.2 -> 12.6 at 4 096, 22.2 -> 21.3 at 8 192 in a closed
@@ -86,6 +90,8 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready, gready, oready;   // rnea role done / its lever arms are out / observer role done
+  __shared__ int rpack;                   // QP wavefronts that have read r_prev (speculative start): the observer role stores r behind all four
+  constexpr bool SPEC_ORDER = OBSERVER && !WARM && WBC_QP_SPEC != 0 && WBC_SPEC_ORDER != 0;
   const int wave = (int)(threadIdx.x >> 6);
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the pf output carries the role timestamps (slot, workgroup) instead of foot positions
   double* const stamp = (double*)a.pf;
@@ -116,7 +122,11 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
     if constexpr (fused_split_h<T, OBSERVER, MATS, WARM>()) rnea_step_body<T, RS_H, 64, 2>(model, prm, a, cst, wsl);   // bias forces h -> HBM only
   } else if (OBSERVER && wave == 6) {
     if constexpr (OBSERVER) {
-      if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 2, 1>(model, prm, a, cst, wsl);   // base rows
+      int* const ack = &rpack;
+      auto wait_ack = [ack] __device__() {   // (see QpSync::rp_ack; the QP wavefronts count at about +2.6 us, this role gets here at about +6)
+        if constexpr (SPEC_ORDER) { while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1); }
+      };
+      if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 2, 1, 16, decltype(wait_ack)>(model, prm, a, cst, wsl, wait_ack);   // base rows
       else WBC_OBS_ROLE(2, a);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -131,14 +141,15 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   } else {
     for (int i = threadIdx.x; i < CST_WORDS; i += 256) cst[i] = model->cst[i];
     if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-    if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; }
+    if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; rpack = 0; }
     __syncthreads();
     constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint-row wavefront)
 #ifdef WBC_FUSED_STAMP
-    const QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN, stamp, stampN};
+    QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN, stamp, stampN};
 #else
-    const QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN};   // the QP waits for each piece where it first needs it
+    QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN};   // the QP waits for each piece where it first needs it
 #endif
+    if constexpr (SPEC_ORDER) sy.rp_ack = &rpack;
 #if WBC_FUSED_ZEROS_BY_QP
     if constexpr (MATS) {
       const int* const zs = zidx_s;
@@ -183,9 +194,12 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready, gready, oready, mready, rready;
+  __shared__ int rpack;   // (QpSync::rp_ack: QP wavefronts that have read r_prev in this tick, counted over the ticks)
+  constexpr bool SPEC_ORDER = OBSERVER && !WARM && WBC_QP_SPEC != 0 && WBC_SPEC_ORDER != 0;
+  constexpr int QP_WAVES = SPW / 4;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; }
+  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; rpack = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
@@ -201,6 +215,13 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #ifndef WBC_RO_INT_WAVE
 #define WBC_RO_INT_WAVE -1
 #endif
+  // (round 5) 4-state workgroups: the bias-force recursion -- whose only consumers are the caller's h buffer and the integrator behind the tick's barrier --
+  // leaves the rnea role for idle QP wavefront WBC_RO_H_WAVE; the rnea role is left with the ONE merged recursion RNEA(q, v, vdot_des) that the torque map
+  // waits for (the tick's second chain once the mass_jac role publishes early).  -1: one wavefront runs both recursions (rounds 1-4)
+#ifndef WBC_RO_H_WAVE
+#define WBC_RO_H_WAVE 2
+#endif
+  constexpr int H_WAVE = (SPW == 4) ? WBC_RO_H_WAVE : -1;
   constexpr int INT_WAVE = (SPW == 4) ? WBC_RO_INT_WAVE : -1;   // the integrator itself on an idle QP wavefront (the aux wavefront keeps the roles not moved)
   constexpr int JOINT_WAVE = (OBSERVER && FUSED_OBS_WAVES == 2 && SPW == 4) ? WBC_RO_JOINT_WAVE : -1;
   constexpr int PLAN_WAVE = (TRACK && SPW == 4) ? WBC_RO_PLAN_WAVE : -1;
@@ -230,6 +251,10 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     QpArgs<T> qat = qa;
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
+#ifndef WBC_RO_SKIP_MATS
+#define WBC_RO_SKIP_MATS 1   // 0: every tick stores its M / Jc / pf (A/B)
+#endif
+    at.skip_mats = (WBC_RO_SKIP_MATS && t < horizon - 1) ? 1 : 0;   // M, Jc, pf of the LAST tick are what the caller finds in its buffers (as with per-tick launches)
     if (t > 0) at.skip_consts = 1;   // the structural zeros / ones of M, Jc were written by tick 0 of THIS launch into the same buffers (the mass_jac role's
                                      // ~55 store instructions per tick sit in front of the integrator's factorisation: wbc_api.cpp, rollout_persistent)
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the last tick's role timestamps go out through the pf output
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       int* const rflag = &rready;
       const int rneed = t + 1;
       int* const gflag = &gready;
-      rnea_step_body<T, RS_STEP | RS_H, 64, 1, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
+      rnea_step_body<T, (H_WAVE >= 0 ? RS_STEP : (RS_STEP | RS_H)), 64, 1, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -298,13 +323,23 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wave == 5) {
-      mass_jac_body<T, 64, 1, SPW>(model, at, cst, zidx_s, mj_hand);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the hand-over image is in LDS (the M / Jc stores to HBM drain on their own: nothing in this kernel reads them) ...
-      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&mready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
+      int* const mflag = &mready;
+      auto publish = [mflag] __device__() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the hand-over image is in LDS ...
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(mflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
+      };
+      // (the M / Jc / pf stores to HBM come BEHIND the flag, from the image, and only in the launch's last tick: nothing in this kernel reads them)
+      mass_jac_body<T, 64, 1, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {
-        if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1, SPW>(model, prm, at, cst, wsl);   // base rows
-        else observer_body<T, 64, 1, 0, SPW>(model, prm, at, cst, wsl);
+        int* const ack = &rpack;
+        const int ack_need = QP_WAVES * (t + 1);
+        const bool ack_on = qa.rprev != nullptr;   // (null: the QP waits for rhat and reads nothing this role writes)
+        auto wait_ack = [ack, ack_need, ack_on] __device__() {
+          if constexpr (SPEC_ORDER) { if (ack_on) { while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ack_need) __builtin_amdgcn_s_sleep(1); } }
+        };
+        if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
+        else observer_body<T, 64, 1, 0, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         RSTAMP(10);
@@ -312,10 +347,12 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     } else {
       constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint rows, run by the integrator wavefront)
 #ifdef WBC_FUSED_STAMP
-      const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1), rstamp, rstampN};
+      QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1), rstamp, rstampN};
 #else
-      const QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
+      QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
+      if constexpr (SPEC_ORDER) { if (qa.rprev) sy.rp_ack = &rpack; }
+      if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, 1, SPW>(model, prm, at, cst, wsl); }   // bias forces h -> HBM (visible behind barrier A)
       if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }
       if constexpr (JOINT_WAVE >= 0) { if (wave == JOINT_WAVE) joint_rows_role(); }
       if constexpr (INT_WAVE >= 0) { if (wave == INT_WAVE) { integrator_role(); continue; } }

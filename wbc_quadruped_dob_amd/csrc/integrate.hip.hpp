@@ -41,8 +41,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #define LDLX(ptr, c0, stride, xN) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))))
 #define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   int jx[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) jx[k] = model->jidx[leg][k];
+  jidx_of_leg(model, a.jpack, leg, jx);
 
   // ================================================================== phase 1: M, Jc only
   // foot position relative to the base origin from the base-angular block of my foot's Jacobian rows, -[d]x

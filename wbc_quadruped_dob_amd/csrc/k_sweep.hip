@@ -2,6 +2,7 @@
 #include "k_common.hip.hpp"
 #include <type_traits>
 #include "dyn_sweep.hip.hpp"
+#include "observer.hip.hpp"
 
 namespace wbc {
 
@@ -41,6 +42,23 @@ hipError_t k_dyn_sweep<Scalar>(const LaunchCtx& L, int mode, const DevModel<Scal
     case SW_MATS | SW_STEP | SW_OBS: return sweep_mode<SW_MATS | SW_STEP | SW_OBS>(L, model, prm, a);
     default: return hipErrorInvalidValue;
   }
+}
+
+// sweep_obs_kernel: the observer update + the observer-free sweep as the two roles of one launch (observer.hip.hpp).  fp32, even N: both roles
+// with two states per lane (unless f32_pack2 = -1) -- the form exists for batches whose 2 x N / 16 (packed: N / 32) wavefronts fit one round.
+template <>
+hipError_t k_sweep_obs<Scalar>(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {
+  using T = Scalar;
+  if constexpr (std::is_same<Scalar, float>::value) {
+    if ((a.N & 1) == 0 && L.f32_pack2 >= 0) {
+      const unsigned nsw = (unsigned)((a.N / 2 + 15) / 16);
+      WBC_KLAUNCH(L, (sweep_obs_kernel<T, 2>), dim3(2 * nsw), dim3(64), model, prm, a, nsw);
+      return hipGetLastError();
+    }
+  }
+  const unsigned nsw = (unsigned)((a.N + 15) / 16);
+  WBC_KLAUNCH(L, (sweep_obs_kernel<T, 1>), dim3(2 * nsw), dim3(64), model, prm, a, nsw);
+  return hipGetLastError();
 }
 
 }  // namespace wbc

@@ -36,6 +36,8 @@ template <class T> hipError_t k_dyn_sweep(const LaunchCtx& L, int mode, const De
 template <class T> hipError_t k_rnea_step(const LaunchCtx& L, int mode, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
 // observer_kernel<T>: the momentum-observer update as its own kernel (large observer-on batches, second stream)
 template <class T> hipError_t k_observer(const LaunchCtx& L, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
+// sweep_obs_kernel<T, W>: k_observer and the observer-free k_dyn_sweep(SW_MATS | SW_STEP | SW_NOB) as the two roles of ONE launch (mid-size observer-on batches)
+template <class T> hipError_t k_sweep_obs(const LaunchCtx& L, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
 // GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran).
 // tile = 0: qp_group16_kernel, one wavefront per workgroup, four consecutive states per wavefront;
 // tile = 64 | 128 | 256 | 512: qp_tile_kernel, workgroups of four wavefronts deal a tile of that many states by predicted work
@@ -59,6 +61,8 @@ template <class T> hipError_t k_rollout(const LaunchCtx& L, bool observer, bool 
 template <class T> hipError_t k_qp_general(const LaunchCtx& L, const QpGeneralArgs<T>& a);
 // one thread: *ptr = value, system scope (the completion ticket of the flag-polled single-robot tick)
 hipError_t k_flag(hipStream_t st, unsigned* ptr, unsigned value);
+// the peer gather of wbc_multi_*: ONE launch copies `bytes` bytes at src to each of the nd <= 64 destinations (this device's or peer-mapped memory)
+hipError_t k_gather_push(hipStream_t st, const void* src, void* const* dst, int nd, size_t bytes);
 template <class T> hipError_t k_integrate(const LaunchCtx& L, const DevModel<T>* model, const IntegrateArgs<T>& a);
 template <class T> hipError_t k_reference(const LaunchCtx& L, const DevModel<T>* model, const DevRefParams<T>* G, const RefArgs<T>& a);
 

@@ -28,8 +28,12 @@ namespace wbc {
 // PART (roles only): 0 = the whole update; 1 = base rows only (momentum / gravity sums over the legs, rhat_base: what the QP's
 // target wrench b waits for); 2 = joint rows only (rhat_joint, needed in the torque map).  Two wavefronts running parts 1
 // and 2 side by side share the sweeps' arithmetic but each drops the other's projections and update.
-template <class T, int BLOCK, int EXT, int PART = 0, int SPW = 16>
-WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext, T* wsl) {
+// `before_store()` (roles) runs right before the base rows of {integ, r} are stored: the fused kernels wait there until the QP wavefronts
+// have read r_prev (QpSync::rp_ack) -- normally long past by then.
+struct ObsNoWait { WBC_DEV void operator()() const {} };
+template <class T, int BLOCK, int EXT, int PART = 0, int SPW = 16, class BeforeStore = ObsNoWait>
+WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext, T* wsl,
+                           BeforeStore before_store = BeforeStore()) {
   static_assert(EXT == 0 || BLOCK == 64, "one wavefront");
   static_assert(PART == 0 || EXT != 0, "split parts exist only as roles");
   constexpr bool BASE = PART != 2, JOINTS = PART != 1;
@@ -58,10 +62,13 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 #pragma unroll
   for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
   int jx[3];
+  // (the role keeps the table load: its joint-state loads are not on the tick's critical path -- the QP starts on r_prev -- and with the indices in
+  // hand two cycles after entry the fp64 observer-on fused tick, which sits at 255 registers, spills a value)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) jx[k] = model->jidx[leg][k];
   T ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    jx[k] = model->jidx[leg][k];
     ql[k] = OLDV(a.q, 7 + jx[k]);
     vl[k] = OLDV(a.v, 6 + jx[k]);
   }
@@ -186,6 +193,7 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
       }
       // every lane's loads of the replicated rows feed its own store values: all loads of a row have returned in every lane
       // of the wave before any lane stores to it
+      before_store();
       OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
       if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
       OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
@@ -224,40 +232,46 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 
 // ======================================================================================================================
 // The stand-alone kernel: the same recursion with the forward sweep's per-joint state parked in LDS (see the file header).
+// Round 5: written against the lane value type V of the sweep (dyn_sweep.hip.hpp) -- T itself, or with W = 2 a packed pair of fp32 states per lane
+// (whole 128-byte lines per 16-lane row, v_pk_* arithmetic, half the wavefronts) -- and with its LDS handed in by the kernel, so that it can run
+// as one of the two roles of sweep_obs_kernel (below).
 // ======================================================================================================================
-template <class T, int BLOCK>
-WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a) {
-  constexpr int PKW = 11;   // parked words per joint: sin, cos, body angular / linear velocity, gravity direction
-  // one LDS object, constant table first (see dyn_sweep.hip.hpp)
-  struct Lds { T cst[CST_WORDS]; T kgain[36]; T park[3 * PKW][BLOCK]; };
-  __shared__ Lds lds;
+constexpr int OBS_PKW = 11;   // parked words per joint: sin, cos, body angular / linear velocity, gravity direction
+template <class T, int BLOCK, int W> struct ObsLds {   // one LDS object, constant table first (see dyn_sweep.hip.hpp)
+  using V = typename LaneT<T, W>::type;
+  T cst[CST_WORDS]; T kgain[36]; V park[3 * OBS_PKW][BLOCK];
+};
+template <class T, int BLOCK, int W = 1>
+WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, ObsLds<T, BLOCK, W>& lds, const unsigned blk) {
+  using V = typename LaneT<T, W>::type;
+  constexpr int PKW = OBS_PKW;
   T (&cst)[CST_WORDS] = lds.cst;
   T (&kgain)[36] = lds.kgain;
-  T (&park)[3 * PKW][BLOCK] = lds.park;
+  V (&park)[3 * PKW][BLOCK] = lds.park;
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   const int leg = (int)((tx & 63) >> 4);
-  const size_t s_raw = ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);
+  const size_t s_raw = (((size_t)blk * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15)) * W;   // first state of this lane (W = 2: N is even)
   const bool live = s_raw < N;
-  const unsigned s32 = (unsigned)(live ? s_raw : N - 1);
+  const unsigned s32 = (unsigned)(live ? s_raw : N - W);
 #define OCS(i) cst[(i) * 4 + leg]
-#define OLDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
-#define OLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
-#define OSTV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
-#define OST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) OSTV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
+#define OLDU(ptr, comp) (*(const V*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
+#define OLDV(ptr, comp) (*(const V*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
+#define OSTV(ptr, comp, val) do { if (live) *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define OST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) OSTV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
   // state loads first, table staging while they are in flight
-  T qq[4], vb[6];
+  V qq[4], vb[6];
 #pragma unroll
   for (int c = 0; c < 4; ++c) qq[c] = OLDU(a.q, 3 + c);
 #pragma unroll
   for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
   int jx[3];
-  T ql[3], vl[3];
+  jidx_of_leg(model, a.jpack, leg, jx);
+  V ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    jx[k] = model->jidx[leg][k];
     ql[k] = OLDV(a.q, 7 + jx[k]);
     vl[k] = OLDV(a.v, 6 + jx[k]);
   }
@@ -277,56 +291,56 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   }
   __syncthreads();
 
-  T qx, qy, qz, qw;
+  V qx, qy, qz, qw;
   {
-    const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    const V n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
   // base rotation, base body inertia, base velocity / gravity in base coordinates: formed twice -- here for the forward sweep
   // and again after the return sweep, from the (laundered) quaternion and a second read of v -- so that 34 values do not live
   // through both sweeps
-  auto base_state = [&](const T* vbx, M3<T>& R, T& bm, V3<T>& bh, S3<T>& bI, V3<T>& om0, V3<T>& v0, V3<T>& gneg) __attribute__((always_inline)) {
-    const T x = qx, y = qy, z = qz, w = qw;
+  auto base_state = [&](const V* vbx, M3<V>& R, V& bm, V3<V>& bh, S3<V>& bI, V3<V>& om0, V3<V>& v0, V3<V>& gneg) __attribute__((always_inline)) {
+    const V x = qx, y = qy, z = qz, w = qw;
     R.a[0] = 1 - 2 * (y * y + z * z); R.a[1] = 2 * (x * y - z * w);     R.a[2] = 2 * (x * z + y * w);
     R.a[3] = 2 * (x * y + z * w);     R.a[4] = 1 - 2 * (x * x + z * z); R.a[5] = 2 * (y * z - x * w);
     R.a[6] = 2 * (x * z - y * w);     R.a[7] = 2 * (y * z + x * w);     R.a[8] = 1 - 2 * (x * x + y * y);
     bm = model->base_m;
-    bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
+    bh = mk<V>(model->base_h[0], model->base_h[1], model->base_h[2]);
     bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
     bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
-    om0 = tmul(R, mk<T>(vbx[3], vbx[4], vbx[5]));
-    v0 = tmul(R, mk<T>(vbx[0], vbx[1], vbx[2]));
-    gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));   // R^T (-g)
+    om0 = tmul(R, mk<V>(vbx[3], vbx[4], vbx[5]));
+    v0 = tmul(R, mk<V>(vbx[0], vbx[1], vbx[2]));
+    gneg = tmul(R, mk<V>(-model->grav[0], -model->grav[1], -model->grav[2]));   // R^T (-g)
   };
-  M3<T> R;
-  T bm;
-  V3<T> bh, om0, v0, gneg;
-  S3<T> bI;
+  M3<V> R;
+  V bm;
+  V3<V> bh, om0, v0, gneg;
+  S3<V> bI;
   base_state(vb, R, bm, bh, bI, om0, v0, gneg);
 
   // ---- forward sweep down the leg: joint rotations, body velocities, weights.  What the return sweep needs is PARKED in LDS
   // ([word][lane], conflict-free): sin / cos of the joint angle (E is rebuilt from them: 18 FMAs on constants that are read from
   // LDS anyway) and the body's velocity and gravity direction -- 11 words per joint instead of 54 live values through both sweeps.
-  auto joint_E = [&](int k, T sn, T cs, M3<T>& Ek) __attribute__((always_inline)) {
+  auto joint_E = [&](int k, V sn, V cs, M3<V>& Ek) __attribute__((always_inline)) {
     const int o = JOINT_WORDS * k;
 #pragma unroll
     for (int e = 0; e < 9; ++e) Ek.a[e] = OCS(o + e) + cs * OCS(o + 9 + e) + sn * OCS(o + 18 + e);
   };
   {
-    V3<T> omp = om0, vp = v0, gp = gneg;
+    V3<V> omp = om0, vp = v0, gp = gneg;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int o = JOINT_WORDS * k;
-      T sn, cs;
+      V sn, cs;
       sincos_t(ql[k], &sn, &cs);
-      M3<T> Ek;
+      M3<V> Ek;
       joint_E(k, sn, cs, Ek);
-      const V3<T> r = mk<T>(OCS(o + 27), OCS(o + 28), OCS(o + 29));
-      const V3<T> ax = mk<T>(OCS(o + 30), OCS(o + 31), OCS(o + 32));
-      const V3<T> omk = tmul(Ek, omp) + ax * vl[k];
-      const V3<T> vvk = tmul(Ek, vp + cross(omp, r));
-      const V3<T> gk = tmul(Ek, gp);
-      T* pk = &park[PKW * k][tx];
+      const V3<V> r = mk<V>(OCS(o + 27), OCS(o + 28), OCS(o + 29));
+      const V3<V> ax = mk<V>(OCS(o + 30), OCS(o + 31), OCS(o + 32));
+      const V3<V> omk = tmul(Ek, omp) + ax * vl[k];
+      const V3<V> vvk = tmul(Ek, vp + cross(omp, r));
+      const V3<V> gk = tmul(Ek, gp);
+      V* pk = &park[PKW * k][tx];
       pk[0] = sn; pk[BLOCK] = cs;
       pk[BLOCK * 2] = omk.x; pk[BLOCK * 3] = omk.y; pk[BLOCK * 4] = omk.z;
       pk[BLOCK * 5] = vvk.x; pk[BLOCK * 6] = vvk.y; pk[BLOCK * 7] = vvk.z;
@@ -342,10 +356,10 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   // The inputs of the update -- previous forces and torques, the observer state -- are requested HERE, so that they arrive
   // during the return sweep: loaded where they are used, after it, each exposed a memory latency (two wavefronts per SIMD).
   const bool obs_on = prm.observer_order > 0;
-  V3<T> fp = mk<T>(0, 0, 0);
-  T in_r[3] = {0, 0, 0}, in_ig[3] = {0, 0, 0}, in_tp[3] = {0, 0, 0}, in_rb[6] = {0, 0, 0, 0, 0, 0}, in_igb[6] = {0, 0, 0, 0, 0, 0};
+  V3<V> fp = mk<V>(0, 0, 0);
+  V in_r[3] = {0, 0, 0}, in_ig[3] = {0, 0, 0}, in_tp[3] = {0, 0, 0}, in_rb[6] = {0, 0, 0, 0, 0, 0}, in_igb[6] = {0, 0, 0, 0, 0, 0};
   if (obs_on) {
-    fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
+    fp = mk<V>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
 #pragma unroll
     for (int k = 0; k < 3; ++k) { in_r[k] = OLDV(a.obs_r, 6 + jx[k]); in_ig[k] = OLDV(a.obs_integ, 6 + jx[k]); in_tp[k] = OLDV(a.tau_prev, jx[k]); }
 #pragma unroll
@@ -354,26 +368,26 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
 #pragma unroll
   for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);   // the base velocity again, for base_state after the sweep
   // ---- return sweep: subtree momentum / weight, their projections on the joint axes, foot geometry
-  T p_leg[3], beta_l[3];
-  V3<T> dft = mk<T>(OCS(129), OCS(130), OCS(131));
-  V3<T> jc[3];
-  SF<T> macc, gacc;
+  V p_leg[3], beta_l[3];
+  V3<V> dft = mk<V>(OCS(129), OCS(130), OCS(131));
+  V3<V> jc[3];
+  SF<V> macc, gacc;
 #pragma unroll
   for (int k = 2; k >= 0; --k) {
     const int o = JOINT_WORDS * k;
-    const V3<T> r = mk<T>(OCS(o + 27), OCS(o + 28), OCS(o + 29));
-    const V3<T> ax = mk<T>(OCS(o + 30), OCS(o + 31), OCS(o + 32));
-    const T m = OCS(o + 33);
-    const V3<T> h = mk<T>(OCS(o + 34), OCS(o + 35), OCS(o + 36));
-    S3<T> Io;
+    const V3<V> r = mk<V>(OCS(o + 27), OCS(o + 28), OCS(o + 29));
+    const V3<V> ax = mk<V>(OCS(o + 30), OCS(o + 31), OCS(o + 32));
+    const V m = OCS(o + 33);
+    const V3<V> h = mk<V>(OCS(o + 34), OCS(o + 35), OCS(o + 36));
+    S3<V> Io;
     Io.xx = OCS(o + 37); Io.xy = OCS(o + 38); Io.xz = OCS(o + 39); Io.yy = OCS(o + 40); Io.yz = OCS(o + 41); Io.zz = OCS(o + 42);
-    const T* pk = &park[PKW * k][tx];
-    M3<T> Ek;
+    const V* pk = &park[PKW * k][tx];
+    M3<V> Ek;
     joint_E(k, pk[0], pk[BLOCK], Ek);
-    const V3<T> omk = mk<T>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]);
-    const V3<T> vvk = mk<T>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]);
-    const V3<T> glk = mk<T>(pk[BLOCK * 8], pk[BLOCK * 9], pk[BLOCK * 10]);
-    SF<T> mk_ = inertia_mul(m, h, Io, omk, vvk), gk;
+    const V3<V> omk = mk<V>(pk[BLOCK * 2], pk[BLOCK * 3], pk[BLOCK * 4]);
+    const V3<V> vvk = mk<V>(pk[BLOCK * 5], pk[BLOCK * 6], pk[BLOCK * 7]);
+    const V3<V> glk = mk<V>(pk[BLOCK * 8], pk[BLOCK * 9], pk[BLOCK * 10]);
+    SF<V> mk_ = inertia_mul(m, h, Io, omk, vvk), gk;
     gk.n = cross(h, glk);
     gk.f = glk * m;
     if (k < 2) { mk_.n = mk_.n + macc.n; mk_.f = mk_.f + macc.f; gk.n = gk.n + gacc.n; gk.f = gk.f + gacc.f; }
@@ -389,17 +403,16 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
     // arithmetic into that guarded region and leaves the LDS reads of all three iterations (~160 doubles: table words and
     // parked values) in a row in front of it.  Passing the carried values through an empty asm statement pins each
     // iteration's arithmetic where it is written.
-    asm volatile("" : "+v"(macc.n.x), "+v"(macc.n.y), "+v"(macc.n.z), "+v"(macc.f.x), "+v"(macc.f.y), "+v"(macc.f.z));
-    asm volatile("" : "+v"(gacc.n.x), "+v"(gacc.n.y), "+v"(gacc.n.z), "+v"(gacc.f.x), "+v"(gacc.f.y), "+v"(gacc.f.z));
-    asm volatile("" : "+v"(dft.x), "+v"(dft.y), "+v"(dft.z), "+v"(p_leg[k]), "+v"(beta_l[k]));
+    pin(macc.n); pin(macc.f); pin(gacc.n); pin(gacc.f);
+    pin(dft); pin(p_leg[k]); pin(beta_l[k]);
 #pragma unroll
-    for (int j = k; j < 3; ++j) asm volatile("" : "+v"(jc[j].x), "+v"(jc[j].y), "+v"(jc[j].z));
+    for (int j = k; j < 3; ++j) pin(jc[j]);
     __builtin_amdgcn_sched_barrier(0);
   }
   // base quantities again (see base_state)
-  asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
+  pin(qx); pin(qy); pin(qz); pin(qw);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(vb[c]));
+  for (int c = 0; c < 6; ++c) pin(vb[c]);
   base_state(vb, R, bm, bh, bI, om0, v0, gneg);
 
   // ---- observer update (order 1 or 2) and rhat for the QP kernel (18 words at WS_RHAT of the step workspace), in two phases:
@@ -407,21 +420,21 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   const T dt = prm.dt;
   const bool o1 = prm.observer_order == 1;
   // (pins: the loads above stay where they are issued)
-  asm volatile("" : "+v"(fp.x), "+v"(fp.y), "+v"(fp.z));
+  pin(fp);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(in_r[k]), "+v"(in_ig[k]), "+v"(in_tp[k]));
+  for (int k = 0; k < 3; ++k) { pin(in_r[k]); pin(in_ig[k]); pin(in_tp[k]); }
 #pragma unroll
-  for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(in_rb[c]), "+v"(in_igb[c]));
+  for (int c = 0; c < 6; ++c) { pin(in_rb[c]); pin(in_igb[c]); }
   {
-    T rl[3] = {0, 0, 0};
+    V rl[3] = {0, 0, 0};
     if (obs_on) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int c = 6 + jx[k];
-        const T r0 = in_r[k];
-        const T u = in_tp[k] + dot(mul(R, jc[k]), fp);
-        const T ig = in_ig[k] + dt * (u + beta_l[k] + r0);
-        const T e = p_leg[k] - ig;
+        const V r0 = in_r[k];
+        const V u = in_tp[k] + dot(mul(R, jc[k]), fp);
+        const V ig = in_ig[k] + dt * (u + beta_l[k] + r0);
+        const V e = p_leg[k] - ig;
         const T k1 = kgain[c], k2 = kgain[18 + c];
         rl[k] = o1 ? k1 * e : r0 + dt * k2 * (k1 * e - r0);
         OSTV(a.obs_integ, c, ig);
@@ -435,30 +448,30 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   __builtin_amdgcn_sched_barrier(0);
   {
     // the four legs + the base body itself
-    T p_b[6], beta_b[6];
+    V p_b[6], beta_b[6];
     {
-      const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
-      T xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
-      xrow_sum_k<T, 12>(xb);
-      const V3<T> m0n = mk<T>(xb[0], xb[1], xb[2]) + Iv0.n, m0f = mk<T>(xb[3], xb[4], xb[5]) + Iv0.f;
-      const V3<T> g0n = mk<T>(xb[6], xb[7], xb[8]) + cross(bh, gneg), g0f = mk<T>(xb[9], xb[10], xb[11]) + gneg * bm;
-      const V3<T> Pl = mul(R, m0f), Pa = mul(R, m0n);
-      const V3<T> gl = mul(R, g0f), ga = mul(R, g0n);
-      const V3<T> cx = cross(mk<T>(vb[0], vb[1], vb[2]), Pl);
+      const SF<V> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
+      V xb[12] = {macc.n.x, macc.n.y, macc.n.z, macc.f.x, macc.f.y, macc.f.z, gacc.n.x, gacc.n.y, gacc.n.z, gacc.f.x, gacc.f.y, gacc.f.z};
+      xrow_sum_k<V, 12>(xb);
+      const V3<V> m0n = mk<V>(xb[0], xb[1], xb[2]) + Iv0.n, m0f = mk<V>(xb[3], xb[4], xb[5]) + Iv0.f;
+      const V3<V> g0n = mk<V>(xb[6], xb[7], xb[8]) + cross(bh, gneg), g0f = mk<V>(xb[9], xb[10], xb[11]) + gneg * bm;
+      const V3<V> Pl = mul(R, m0f), Pa = mul(R, m0n);
+      const V3<V> gl = mul(R, g0f), ga = mul(R, g0n);
+      const V3<V> cx = cross(mk<V>(vb[0], vb[1], vb[2]), Pl);
       p_b[0] = Pl.x; p_b[1] = Pl.y; p_b[2] = Pl.z; p_b[3] = Pa.x; p_b[4] = Pa.y; p_b[5] = Pa.z;
       beta_b[0] = -gl.x; beta_b[1] = -gl.y; beta_b[2] = -gl.z;
       beta_b[3] = -cx.x - ga.x; beta_b[4] = -cx.y - ga.y; beta_b[5] = -cx.z - ga.z;
     }
-    T rb[6] = {0, 0, 0, 0, 0, 0};
+    V rb[6] = {0, 0, 0, 0, 0, 0};
     if (obs_on) {
-      const V3<T> dxf = cross(mul(R, dft), fp);
-      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
-      xrow_sum_k<T, 6>(ub);
+      const V3<V> dxf = cross(mul(R, dft), fp);
+      V ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+      xrow_sum_k<V, 6>(ub);
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        const T r0 = in_rb[c];
-        const T ig = in_igb[c] + dt * (ub[c] + beta_b[c] + r0);
-        const T e = p_b[c] - ig;
+        const V r0 = in_rb[c];
+        const V ig = in_igb[c] + dt * (ub[c] + beta_b[c] + r0);
+        const V e = p_b[c] - ig;
         rb[c] = o1 ? kgain[c] * e : r0 + dt * kgain[18 + c] * (kgain[c] * e - r0);
         p_b[c] = ig;
       }
@@ -468,7 +481,7 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
       OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
       if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
     }
-    OSTV(a.ws, sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
+    OSTV(a.ws, sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<V>(leg, rb[0], rb[1], rb[2], rb[3]));
     if (leg < 2) OSTV(a.ws, WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
   }
 #undef OST4
@@ -481,9 +494,34 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
 #ifndef WBC_OBS_WAVES
 #define WBC_OBS_WAVES 2
 #endif
-template <class T, int BLOCK>
+template <class T, int BLOCK, int W = 1>
 __global__ __launch_bounds__(BLOCK, WBC_OBS_WAVES) void observer_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a) {
-  observer_park_body<T, BLOCK>(model, prm, a);
+  __shared__ ObsLds<T, BLOCK, W> lds;
+  observer_park_body<T, BLOCK, W>(model, prm, a, lds, blockIdx.x);
+}
+
+// ======================================================================================================================
+// sweep_obs_kernel (round 5): the observer update and the observer-free dynamics sweep as the TWO ROLES OF ONE LAUNCH -- the first
+// `nsweep` workgroups run dyn_sweep_body<SW_MATS | SW_STEP | SW_NOB>, the rest observer_park_body, on the same states.
+// Why: BASELINE.json's configs[3] puts 32 768 fp32 states on each GPU.  At that size the all-in-one observer sweep is ONE packed
+// wavefront per SIMD (430 registers) running a 23 us dependent chain -- 0.31 of HBM on the stage's 443 words, against north_star's 0.40 --
+// and its two halves as two kernels one after the other (the large-batch form) each pay their own latency-bound round.  As roles of one
+// launch both halves are resident together -- 1 024 + 1 024 packed wavefronts = two per SIMD at <= 256 registers -- and the launch lasts
+// about as long as the longer of the two chains.  Only worth it while BOTH fit one round of resident wavefronts (the host picks: plan_tick).
+// One-wavefront workgroups, LDS overlaid (a workgroup runs one role).
+// ======================================================================================================================
+template <class T, int W>
+__global__ __launch_bounds__(64, 2) void sweep_obs_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a, unsigned nsweep) {
+  constexpr int MODE = SW_MATS | SW_STEP | SW_NOB;
+  union Lds {
+    SweepLds<T, MODE, 64, W> sw;
+    ObsLds<T, 64, W> ob;
+    __device__ Lds() {}
+  };
+  __shared__ Lds lds;
+  if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
+  if (blockIdx.x < nsweep) dyn_sweep_body<T, MODE, 64, W>(model, prm, a, lds.sw, blockIdx.x);
+  else observer_park_body<T, 64, W>(model, prm, a, lds.ob, blockIdx.x - nsweep);
 }
 
 }  // namespace wbc

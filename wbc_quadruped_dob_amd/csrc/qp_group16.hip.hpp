@@ -160,6 +160,10 @@ struct QpSync {
 #ifdef WBC_FUSED_STAMP   // diagnostic build (tools/fused_stamp.py): 100 MHz timestamps of the roles, one column per workgroup
   double* stamp; unsigned stampN;
 #endif
+  // (round 5) the speculative start reads the observer state r_prev that the observer role of the SAME launch rewrites in place: every QP wavefront
+  // counts here once its read has returned, and the observer role stores r only behind that count (fused_tick.hip.hpp) -- the read is ordered in
+  // front of the write, so that iters and the last bits of tau do not depend on timing
+  int* rp_ack = nullptr;
 };
 #ifdef WBC_FUSED_STAMP
 #define WBC_FSTAMP(ptr, N_, slot) do { if ((threadIdx.x & 63) == 0) (ptr)[(size_t)(slot) * (N_) + (size_t)blockIdx.x * 16] = (double)wall_clock64(); } while (0)
@@ -668,7 +672,11 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     int jm = 0;   // caller's index of my joint (leg f, joint c3)
+#if WBC_JIDX_ARGS   // (nibble v of the packed joint map, a kernel argument in two SGPRs: the select chain over jmap held twelve)
+    jm = (int)((unsigned)(a.jpack >> (4 * (v & 15))) & 15u);
+#else
     sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
+#endif
     if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
       if (geom_jc) {

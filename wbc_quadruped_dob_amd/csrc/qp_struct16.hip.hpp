@@ -434,7 +434,13 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
       x_me = isvar ? who.pre[36 + v] : (T)0;
     } else {
     const T b_ld = (l16 < 6) ? BLD(l16) - (SPEC ? rprev_in : (RHAT ? WSLD(WS_RHAT + l16) : (T)0)) : (T)0;   // (SPEC: b~, see the top)
-    if constexpr (SPEC) { if (l16 < 6) L.R[grp][l16] = rprev_in; }
+    if constexpr (SPEC) {
+      if (l16 < 6) L.R[grp][l16] = rprev_in;
+      if (sync && sync->rp_ack) {   // r_prev is in my registers: the observer role may overwrite it now (QpSync::rp_ack)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(sync->rp_ack, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
     T bb[6];
     bb[0] = s0 * dppx<0x150 + 0>(b_ld); bb[1] = s1 * dppx<0x150 + 1>(b_ld); bb[2] = s2 * dppx<0x150 + 2>(b_ld);
     bb[3] = s3 * dppx<0x150 + 3>(b_ld); bb[4] = s4 * dppx<0x150 + 4>(b_ld); bb[5] = s5 * dppx<0x150 + 5>(b_ld);
@@ -454,6 +460,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   // search for the NEXT candidate at its end point, which is speculative: it is used when the step turns out to be full
   // (almost always) -- and per-row decisions are committed by selects at the end.
   int ip = -1, status = 0, iter = 0;
+  int iter0 = 0;   // (SPEC) trips of the phase on b~: the second phase has the whole of max_iter (it used to get what phase 0 left)
   bool done = !live;
   T sip = 0, Rn2 = 1, u_c = 0;   // Rn2 = max(1, largest z . n+ of an added constraint) = Rnorm^2 of the dense method (its new R diagonal is |d2|)
   const T ntol = -prm.qp_tol;
@@ -512,7 +519,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   while (__ballot(!done && ip >= 0) != 0ull) {   // (every trip counts against max_iter in every row that is still working)
     bool go = !done && ip >= 0;
     iter += go ? 1 : 0;
-    const bool over = go && iter > prm.max_iter;
+    const bool over = go && iter - iter0 > prm.max_iter;
     status = over ? 1 : status;
     done = done || over;
     go = go && !over;
@@ -691,9 +698,14 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
       // ---- still an S-pair?  A row with a negative multiplier starts over from the empty set, with b itself.  Per ROW: what a state computes
       // must not depend on the three states that happen to share its wavefront (shards of a batch group the states differently, and their
       // results are compared bit for bit with the unsharded run)
-      const unsigned long long fneg = __ballot(live && status == 0 && slot_now && !(u_s >= 0));
+      // (round 5, ADVICE r4: a row whose iteration on b~ ENDED with a status -- iteration limit, "infeasible" -- starts over as well, with a fresh
+      // iteration budget: what the solver reports for b must not be a verdict about b~)
+      const unsigned long long fneg = __ballot(live && (status != 0 || (slot_now && !(u_s >= 0))));
       if (fneg != 0ull) {   // (wave-uniform branch, rare; inside it every change is selected per row)
         const bool row_over = (unsigned)((fneg >> rowbase) & 0xFFFFull) != 0u;
+        status = row_over ? 0 : status;
+        iter = row_over ? 0 : iter;
+        u_c = row_over ? (T)0 : u_c;      // (a row stopped by the iteration limit may sit between a partial step and its full step)
         T GrK[6];
         sfor<0, 6>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; GrK[j] = Gr[j]; });
         s16_cold_inverse_row<T>(mask, d_me, alpha_l, s0, s1, s2, s3, s4, s5, gi, Gr);
@@ -720,6 +732,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
         const T x0_me = c3 == 0 ? v0 : (c3 == 1 ? v1 : v2);
         x_me = row_over ? x0_me : x_me;
       }
+      iter0 = iter;                           // (a row that started over: both zero)
       done = !live || status != 0;            // every row looks for violated rows again at its new point
     }
   }
@@ -739,7 +752,11 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;
     int jm = 0;
+#if WBC_JIDX_ARGS   // (nibble v of the packed joint map, a kernel argument in two SGPRs: the select chain over jmap held twelve)
+    jm = (int)((unsigned)(a.jpack >> (4 * (v & 15))) & 15u);
+#else
     sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
+#endif
     if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
       if (geom_jc) {

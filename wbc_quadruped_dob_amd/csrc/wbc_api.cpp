@@ -72,7 +72,13 @@ constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints 
 #ifndef WBC_WARM_LANE_MIN_F32
 #define WBC_WARM_LANE_MIN_F32 36864
 #endif
-struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min; };
+#ifndef WBC_COLAUNCH_MIN_F32
+#define WBC_COLAUNCH_MIN_F32 12289
+#endif
+#ifndef WBC_COLAUNCH_MAX_F32
+#define WBC_COLAUNCH_MAX_F32 32768
+#endif
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -87,6 +93,7 @@ struct wbc_solver {
   int* d_todo = nullptr;    // 4 + max_batch ints: states the per-lane QP kernel hands to the dense active-set kernel (count, workgroups done, count of the last tick, pad; indices)
   int* d_aset = nullptr;    // max_batch ints: the active sets that wbc_rollout_batch's per-tick launches carry from tick to tick (rollout_warm)
   QpJidx jmap;
+  unsigned long long jpack = 0;   // jmap as nibbles (pack_jidx): the dynamics bodies' joint indices, a kernel argument
   Resolved rz{};            // resolved thresholds (resolve_options)
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -308,6 +315,9 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->f32_pack2 = 0;
   o->keep_structural = 0;
   o->rollout_warm = 1;
+  o->multi_threads = 0;
+  o->multi_spin_us = 200;
+  o->obs_colaunch = 0;
 }
 
 // ------------------------------------------------------------------------------------------ which kernels run a tick
@@ -348,6 +358,12 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   r.lane_min = dtype == WBC_F32 ? 212992 : 106496;
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
+  // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
+  // together -- fp32 with two states per lane: 2 x N / 32 <= 2 048 wavefronts, i.e. up to 32 768 states, BASELINE's configs[3] shard.  fp64 (228 registers,
+  // 21 kB of LDS per one-wavefront workgroup: seven per CU) would fit 14 336 states, 2 048 beyond the one-launch tick: not enabled by default.
+  r.colaunch_min = (size_t)-1; r.colaunch_max = 0;
+  if (o.obs_colaunch > 0) { r.colaunch_min = 0; r.colaunch_max = (size_t)-1; }
+  else if (o.obs_colaunch == 0 && dtype == WBC_F32) { r.colaunch_min = WBC_COLAUNCH_MIN_F32; r.colaunch_max = WBC_COLAUNCH_MAX_F32; }
   return r;
 }
 
@@ -389,13 +405,14 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
     p.obs_split = ob && N >= r.obs_split_min_nomats;
     p.front = p.obs_split ? 3 : 1;
   }
+  else if (ob && N >= r.colaunch_min && N <= r.colaunch_max && (!f32 || o.obs_colaunch > 0 || ((N & 1) == 0 && o.f32_pack2 >= 0))) { p.front = 4; p.obs_split = true; }   // ... as the two roles of one launch
   else if (ob && N >= r.obs_split_min) { p.front = 2; p.obs_split = true; }   // observer kernel + observer-free sweep
   else p.front = 0;
   if (p.front != 1 && p.front != 3) {   // what the dyn_sweep launcher picks (k_sweep.hip)
     const bool obs_variant = p.front == 0 && ob;
-    p.pack2 = f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && (o.f32_pack2 > 0 || N >= (size_t)WBC_PACK2_MIN_STATES);
+    p.pack2 = f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && (o.f32_pack2 > 0 || N >= (size_t)WBC_PACK2_MIN_STATES || p.front == 4);   // (the two-role launch packs every even fp32 batch)
     const size_t threads = ((N + (p.pack2 ? 2 : 1) - 1) / (p.pack2 ? 2 : 1)) * 4;
-    p.sweep_block = (!obs_variant && threads >= wbc::BIG_GRID_THREADS) ? 256 : 64;
+    p.sweep_block = (!obs_variant && p.front != 4 && threads >= wbc::BIG_GRID_THREADS) ? 256 : 64;
   }
   // two-kernel ticks deal tiles of states to the wavefronts by predicted work (qp_tile_kernel).  Measured on MI355X, fp64,
   // QP kernel alone, one-wavefront workgroups -> tiles: 34.7 -> 32.7 us at 12 288 states (tiles of 32), 62.4 -> 48.3 at
@@ -473,7 +490,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
   const size_t cand[] = {r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
-                         wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537};
+                         wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
   size_t keep[16]; int k = 0;
   for (size_t c : cand) {
     if (c < 2 || c == (size_t)-1 || c > ((size_t)1 << 21)) continue;
@@ -519,6 +536,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (o.keep_structural != 0 && o.keep_structural != 1) return fail(WBC_E_INVALID, "keep_structural must be 0 or 1");
   if (o.one_zerocopy < 0 || o.one_zerocopy > 3) return fail(WBC_E_INVALID, "one_zerocopy must be 0 ... 3");
   if (o.rollout_warm != 0 && o.rollout_warm != 1) return fail(WBC_E_INVALID, "rollout_warm must be 0 or 1");
+  if (o.obs_colaunch < -1 || o.obs_colaunch > 1) return fail(WBC_E_INVALID, "obs_colaunch must be -1, 0 or 1");
   int leg_body[4][3];
   std::string err;
   rc = quadruped_topology(m->fm, leg_body, err);
@@ -537,6 +555,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   s->rz = resolve_options(dtype, o);
   std::memcpy(s->leg_body, leg_body, sizeof(leg_body));
   for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) s->jmap.j[3 * l + k] = leg_body[l][k] - 1;
+  s->jpack = pack_jidx(s->jmap.j);
   const size_t ts = dtype == WBC_F64 ? 8 : 4;
   DeviceGuard guard(device);
   hipError_t e = guard.err;
@@ -689,21 +708,25 @@ extern "C" int wbc_solver_enable_timing(wbc_solver* s, int on) {
   return WBC_OK;
 }
 
-extern "C" int wbc_solver_collect_timing(wbc_solver* s, double ms[WBC_TIMING_KINDS], int launches[WBC_TIMING_KINDS]) {
-  if (!s || !ms || !launches) return fail(WBC_E_INVALID, "null argument");
-  for (int k = 0; k < WBC_TIMING_KINDS; ++k) { ms[k] = 0; launches[k] = 0; }
+// cap = entries of the caller's arrays: kinds beyond it are dropped, never written (the unsized call wrote as many entries as THIS
+// build knows, whatever the caller was built against)
+extern "C" int wbc_solver_collect_timing_n(wbc_solver* s, double* ms, int* launches, int cap) {
+  if (!s || !ms || !launches || cap < 0) return fail(WBC_E_INVALID, "bad argument");
+  const int n = cap < WBC_TIMING_KINDS ? cap : WBC_TIMING_KINDS;
+  for (int k = 0; k < n; ++k) { ms[k] = 0; launches[k] = 0; }
   ON_DEVICE(s);
   for (auto& sp : s->spans) {
     HIP_TRY(hipEventSynchronize(sp.b));
     float t = 0;
     HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
-    ms[sp.kind] += t;
-    launches[sp.kind]++;
+    if (sp.kind < n) { ms[sp.kind] += t; launches[sp.kind]++; }
   }
   s->spans.clear();
   s->dropped = 0;
   return WBC_OK;
 }
+// the unsized call of ABI <= 6 writes the FIVE entries every version of it has had (kind 5, the persistent rollout kernel, needs the sized call)
+extern "C" int wbc_solver_collect_timing(wbc_solver* s, double* ms, int* launches) { return wbc_solver_collect_timing_n(s, ms, launches, 5); }
 
 // one instrumented launch: kind = index into the timing arrays (0 dyn_sweep, 1 QP (dense active set), 2 rnea_step / observer, 3 fused tick, 4 QP one state per lane, 5 persistent rollout)
 #define TIMED_LAUNCH(kind_, stream_, what_, call_)                                                          \
@@ -737,6 +760,7 @@ static int dynamics_impl(wbc_solver* s, size_t N, const void* q, const void* v, 
                          void* p, void* beta, hipStream_t st) {
   SweepArgs<T> a;
   std::memset(&a, 0, sizeof(a));
+  a.jpack = s->jpack;
   a.N = N; a.q = (const T*)q; a.v = (const T*)v;
   a.M = (T*)M; a.h = (T*)h; a.Jc = (T*)Jc; a.pf = (T*)pf; a.p = (T*)p; a.beta = (T*)beta;
   const int mode = (M ? SW_MATS : 0) | ((p || beta) ? SW_OBS : 0);
@@ -766,6 +790,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
                      const wbc_observer_state* obs, hipStream_t st, bool warm_api = false, const int* aset_in = nullptr, int* aset_out = nullptr) {
   SweepArgs<T> a;
   std::memset(&a, 0, sizeof(a));
+  a.jpack = s->jpack;
   a.N = N; a.q = (const T*)in->q; a.v = (const T*)in->v;
   a.M = (T*)out->M; a.h = (T*)out->h; a.Jc = (T*)out->Jc; a.pf = (T*)out->pf;
   a.w_des = (const T*)in->w_des; a.vdot_des = (const T*)in->vdot_des;
@@ -777,6 +802,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   a.skip_consts = keep.skip;
   timing_tick(s);
   QpArgs<T> qa;
+  qa.jpack = s->jpack;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters;
   qa.aset_in = aset_in; qa.aset_out = aset_out;
@@ -786,8 +812,15 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   qa.wdes = nullptr;
   a.ws_geom = mats ? 0 : 1;
   const DevParams<T> dp = to_dev_params<T>(s->params);
-  const TickPlan pl = plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, mats, out->pf != nullptr, warm_api);   // (what runs, and why: plan_tick)
-  const bool warm = warm_api && aset_in != nullptr && pl.qp_warm;   // (no set to start from, or a size where the cold tiles win: the cold kernels, which still report the final set)
+  // (what runs, and why: plan_tick.  A warm call WITHOUT a set to start from -- tick 0 of a per-tick-launch rollout, the first tick of a closed loop --
+  //  is planned as the cold tick it is: between the warm and the cold per-lane thresholds the cold tiles are the faster kernels; they still report the set)
+  //  -- unless the cold plan's QP kernel is the fp32 12 x 12 body, which reports no set: then the warm plan's kernels run, started from the empty set.)
+  TickPlan pl = plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, mats, out->pf != nullptr, warm_api);
+  if (warm_api && aset_in == nullptr) {
+    const TickPlan pc = plan_tick(s->dtype, s->params.observer_order, s->opt, s->rz, N, mats, out->pf != nullptr, false);
+    if (pc.qp_body == 0) pl = pc;
+  }
+  const bool warm = warm_api && aset_in != nullptr && pl.qp_warm;
   if (pl.fused) {
     TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap, warm));
     keep.written();
@@ -813,6 +846,8 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   } else if (pl.front == 1) {  // no M, h, Jc wanted: the CRBA-free rnea_step kernel is the whole front half
     const int mode = RS_STEP | (ob ? RS_OBS : RS_NOB) | (out->pf ? RS_PF : 0);
     TIMED_LAUNCH(2, st, "rnea_step", k_rnea_step<T>(L, mode, dev_model<T>(s), dp, a));
+  } else if (pl.front == 4) {   // mid-size observer-on batch: the observer update and the observer-free sweep as the two roles of one launch
+    TIMED_LAUNCH(0, st, "sweep_obs", k_sweep_obs<T>(L, dev_model<T>(s), dp, a));
   } else if (pl.front == 2) {
     // large observer-on batch: the observer update runs as its own light kernel in front of (option: beside, on the second
     // stream) a dyn_sweep WITHOUT the observer passes (252 instead of 370 VGPRs: two waves per SIMD, shared tables), which writes
@@ -889,6 +924,7 @@ static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void*
   a.N = N; a.q = (T*)q; a.v = (T*)v; a.M = (const T*)M; a.h = (const T*)h; a.Jc = (const T*)Jc;
   a.tau = (const T*)tau; a.f = (const T*)f; a.tau_ext = (const T*)tau_ext; a.tau_traj = (T*)tau_traj;
   a.dt = (T)s->params.dt;
+  a.jpack = s->jpack;
   LaunchCtx L; L.st = st;
   hipError_t e = k_integrate<T>(L, dev_model<T>(s), a);
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("integrate launch: ") + hipGetErrorString(e));
@@ -913,6 +949,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
                               const void* plan = nullptr, void* com_traj = nullptr) {
   SweepArgs<T> a;
   std::memset(&a, 0, sizeof(a));
+  a.jpack = s->jpack;
   a.N = N; a.q = (const T*)in->q; a.v = (const T*)in->v;
   a.M = (T*)out->M; a.h = (T*)out->h; a.Jc = (T*)out->Jc; a.pf = (T*)out->pf;
   a.w_des = (const T*)in->w_des; a.vdot_des = (const T*)in->vdot_des;
@@ -922,6 +959,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   a.skip_consts = 0;   // (tick 0 writes M / Jc in full; the later ticks of the launch leave their structural zeros / ones alone: rollout_kernel)
   s->kept_M = nullptr;
   QpArgs<T> qa;
+  qa.jpack = s->jpack;
   qa.N = N; qa.ws = (const T*)s->d_ws; qa.normals = (const T*)in->normals; qa.mu = (const T*)in->mu; qa.mask = in->mask;
   qa.tau = (T*)out->tau; qa.f = (T*)out->f; qa.status = out->status; qa.iters = out->iters; qa.Jc = nullptr; qa.wdes = nullptr;
   qa.aset_in = nullptr; qa.aset_out = nullptr;   // (every tick of the launch but the first starts from the previous tick's set, kept in registers)
@@ -932,10 +970,12 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   ia.N = N; ia.q = (T*)in->q; ia.v = (T*)in->v; ia.M = (const T*)out->M; ia.h = (const T*)out->h; ia.Jc = (const T*)out->Jc;
   ia.tau = (const T*)out->tau; ia.f = (const T*)out->f; ia.tau_ext = (const T*)tau_ext; ia.tau_traj = (T*)tau_traj;
   ia.dt = (T)s->params.dt;
+  ia.jpack = s->jpack;
   // states per workgroup: 4 while that still fits one workgroup per CU (a tick then waits for the slowest of 4 QPs, not 16)
   const int spw = (s->opt.rollout_spw == 4 || (s->opt.rollout_spw == 0 && N <= 1024)) ? 4 : 16;
   RefArgs<T> ra;
   std::memset(&ra, 0, sizeof(ra));
+  ra.jpack = s->jpack;
   ra.N = N; ra.q = (const T*)in->q; ra.v = (const T*)in->v; ra.plan = (const T*)plan; ra.t = (T)0;
   ra.w_des = (T*)in->w_des; ra.vdot_des = (T*)in->vdot_des; ra.com = (T*)com_traj;
   timing_tick(s);
@@ -1028,6 +1068,7 @@ static int reference_impl(wbc_solver* s, size_t N, const void* q, const void* v,
   RefArgs<T> a;
   a.N = N; a.q = (const T*)q; a.v = (const T*)v; a.plan = (const T*)plan; a.t = (T)t;
   a.w_des = (T*)w_des; a.vdot_des = (T*)vdot_des; a.com = (T*)com;
+  a.jpack = s->jpack;
   LaunchCtx L; L.st = st;
   hipError_t e = k_reference<T>(L, dev_model<T>(s), (const DevRefParams<T>*)s->d_ref, a);
   if (e != hipSuccess) return fail(WBC_E_HIP, std::string("reference launch: ") + hipGetErrorString(e));
@@ -1310,4 +1351,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 6; }  // 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_multi_step_batch_warm, wbc_solver_options.rollout_warm, wbc_tick_plan.qp_warm, WBC_PLAN_* flags), wbc_multi_allgather_tau_async / wbc_multi_gather_wait; 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
+extern "C" int wbc_abi_version(void) { return 7; }  // 7: wbc_solver_collect_timing_n (the unsized call writes 5 entries again), wbc_solver_options.multi_threads / multi_spin_us, wbc_multi_tick_gather / wbc_multi_issue_threads / wbc_multi_host_stats; 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_multi_step_batch_warm, wbc_solver_options.rollout_warm, wbc_tick_plan.qp_warm, WBC_PLAN_* flags), wbc_multi_allgather_tau_async / wbc_multi_gather_wait; 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)

@@ -4,23 +4,38 @@
 //
 // The batch splits into contiguous slices (wbc_shard_range), shard k lives on devices[k] with its own stream; there is
 // no data-path collective.  The one optional collective is consumer-side: every device receives all torques, either as
-// an RCCL ncclAllGather (communicators from ncclCommInitAll, one group call over all devices; xGMI is point-to-point,
-// so for 12 words/state this is latency- not bandwidth-bound) or as peer copies on the shard streams.  RCCL is loaded
-// with dlopen only when that backend is asked for, so single-GPU users of the library do not depend on it.
+// an RCCL ncclAllGather (communicators from ncclCommInitAll; xGMI is point-to-point, so for 12 words/state this is
+// latency- not bandwidth-bound) or as ONE push kernel per shard that writes the shard's block into every device's buffer
+// through peer mappings.  RCCL is loaded with dlopen only when that backend is asked for, so single-GPU users of the
+// library do not depend on it.
 //
-// Built on the public C-ABI only (wbc_solver_create_ex, wbc_step_batch, ...): pure host code.
+// Round 5: the shards are ISSUED IN PARALLEL.  A 4 096-state tick is 13 us of GPU time; issued one shard after the other
+// from one host thread (rounds 2-4) eight devices are fed at one launch per ~3 us, i.e. the path was host-bound by
+// construction.  Every shard now has a persistent issue thread bound to its device (IssuePool below): an entry point
+// validates all shards on the caller's thread, posts ONE ticket, every thread enqueues its shard's part, the caller returns
+// when all have.  wbc_solver_options.multi_threads = -1 keeps the serial issue (and a single shard never starts a thread).
+//
+// Built on the public C-ABI (wbc_solver_create_ex, wbc_step_batch, ...) plus one launcher of launch.hpp (the push kernel).
 #include "../../include/wbc_hip.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstddef>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_internal.hpp"
+#include "launch.hpp"
 
 using wbc::fail;
 
@@ -31,6 +46,14 @@ using wbc::fail;
   } while (0)
 
 namespace {
+
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+}
 
 struct Rccl {   // the few RCCL entry points the gather needs, resolved at run time
   void* handle = nullptr;
@@ -60,12 +83,13 @@ struct Shard {
   int device = 0;
   wbc_solver* solver = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev = nullptr;        // "my part of the gather / tick is enqueued"
+  hipEvent_t ev = nullptr;        // "my part of the serial gather is enqueued" (wbc_multi_allgather_tau)
   hipStream_t gstream = nullptr;  // overlapped gathers (wbc_multi_allgather_tau_async): the collective runs here, beside the next tick
-  hipEvent_t ev_tick = nullptr;   // "the tick whose tau is to be gathered is enqueued" (recorded on `stream`, waited for by `gstream`)
+  hipEvent_t ev_tick = nullptr;   // "everything enqueued on `stream` so far" -- recorded where an overlapped / peer gather is about to order itself behind the ticks
   hipEvent_t ev_slot[2] = {nullptr, nullptr};   // "the gather of buffer slot b is enqueued" (recorded on `gstream`)
   ncclComm_t comm = nullptr;
-  void* d_send = nullptr;         // gather staging [nj * cmax] (ragged shards only)
+  void* d_send = nullptr;         // gather staging [nj * cmax] of ragged shards: the gathers on the shard stream ...
+  void* d_send_slot[2] = {nullptr, nullptr};   // ... and the overlapped gathers, one per slot (the two forms no longer share one buffer)
   // host-batch convenience: device image of one shard (allocated on first wbc_multi_step_host)
   void* d_host_img = nullptr;
   size_t host_img_cap = 0;        // states
@@ -77,6 +101,89 @@ struct DeviceScope {
   ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// ---- persistent issue threads: one per shard, bound to the shard's device.  A job is a reference to a callable on the poster's
+// stack: the poster does not return before every thread has run it, so nothing is copied or allocated per tick.
+struct JobRef { int (*call)(void*, int) = nullptr; void* ctx = nullptr; };
+
+class IssuePool {
+ public:
+  struct alignas(64) Worker {
+    std::thread th;
+    std::atomic<unsigned> seq{0};    // tickets posted
+    std::atomic<unsigned> done{0};   // tickets completed
+    std::atomic<int> parked{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    int rc = 0;
+    std::string err;
+  };
+  IssuePool(const std::vector<int>& devices, int spin_us) : spin_ns_((long long)spin_us * 1000), w_(devices.size()) {
+    for (size_t k = 0; k < devices.size(); ++k) w_[k].reset(new Worker);
+    for (size_t k = 0; k < devices.size(); ++k) w_[k]->th = std::thread([this, k, dev = devices[k]] { loop((int)k, dev); });
+  }
+  ~IssuePool() {
+    quit_.store(true, std::memory_order_seq_cst);
+    for (auto& w : w_) { post_one(*w); }
+    for (auto& w : w_) if (w->th.joinable()) w->th.join();
+  }
+  // runs job(k) on the thread of every shard k and returns the first non-zero status (its message becomes wbc_last_error())
+  int run(const JobRef& j) {
+    job_ = j;
+    for (auto& w : w_) post_one(*w);
+    int rc = 0;
+    for (auto& w : w_) {
+      const unsigned want = w->seq.load(std::memory_order_relaxed);
+      while (w->done.load(std::memory_order_acquire) != want) cpu_relax();
+      if (w->rc && !rc) rc = fail(w->rc, w->err);
+    }
+    return rc;
+  }
+  size_t size() const { return w_.size(); }
+
+ private:
+  void post_one(Worker& w) {
+    w.seq.fetch_add(1, std::memory_order_seq_cst);
+    if (w.parked.load(std::memory_order_seq_cst)) {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.cv.notify_one();
+    }
+  }
+  void loop(int k, int dev) {
+    (void)hipSetDevice(dev);   // every call this thread makes runs on the shard's device: no device switch per tick
+    Worker& w = *w_[(size_t)k];
+    unsigned last = 0;
+    for (;;) {
+      // wait for a ticket: spin while the caller is in a tick loop (a tick is ~13 us), park on the condition variable once it has
+      // been quiet for spin_ns_ (a 1 kHz control loop then pays a wake-up per tick instead of a core per shard)
+      if (w.seq.load(std::memory_order_acquire) == last) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+          bool got = false;
+          for (int i = 0; i < 64 && !got; ++i) { got = w.seq.load(std::memory_order_acquire) != last; if (!got) cpu_relax(); }
+          if (got) break;
+          if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns_) {
+            std::unique_lock<std::mutex> lk(w.mu);
+            w.parked.store(1, std::memory_order_seq_cst);
+            w.cv.wait(lk, [&] { return w.seq.load(std::memory_order_seq_cst) != last; });
+            w.parked.store(0, std::memory_order_seq_cst);
+            break;
+          }
+        }
+      }
+      ++last;
+      if (quit_.load(std::memory_order_seq_cst)) { w.done.store(last, std::memory_order_release); return; }
+      const int rc = job_.call(job_.ctx, k);
+      w.rc = rc;
+      if (rc) w.err = wbc_last_error();
+      w.done.store(last, std::memory_order_release);
+    }
+  }
+  JobRef job_;
+  std::atomic<bool> quit_{false};
+  long long spin_ns_;
+  std::vector<std::unique_ptr<Worker>> w_;
+};
+
 }  // namespace
 
 struct wbc_multi {
@@ -86,9 +193,42 @@ struct wbc_multi {
   int backend = WBC_GATHER_NONE;
   int rccl_ranks = 0;
   int observer_order = 0;
+  bool push_ok = false;           // peer backend: every device can write every other device's memory (the push kernel); else peer copies
   Rccl rccl;
   std::vector<Shard> sh;
+  std::unique_ptr<IssuePool> pool;   // null: the shards are issued one after the other on the caller's thread
+  // host time spent inside the tick entry points (wbc_multi_host_stats): what feeding n devices costs the caller
+  unsigned long long stat_calls = 0, stat_ns = 0;
   size_t ts() const { return dtype == WBC_F64 ? 8 : 4; }
+};
+
+// f(k) for every shard k: on the shards' issue threads (in parallel) or, without them, one after the other here
+template <class F> static int for_shards(wbc_multi* mm, F&& f) {
+  if (!mm->pool) {
+    DeviceScope keep;
+    for (int k = 0; k < (int)mm->sh.size(); ++k) {
+      hipError_t e = hipSetDevice(mm->sh[(size_t)k].device);
+      if (e != hipSuccess) return fail(WBC_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+      const int rc = f(k);
+      if (rc) return rc;
+    }
+    return WBC_OK;
+  }
+  using Fn = typename std::remove_reference<F>::type;
+  JobRef j;
+  j.call = [](void* c, int k) -> int { return (*(Fn*)c)(k); };
+  j.ctx = (void*)&f;
+  return mm->pool->run(j);
+}
+
+struct HostTimer {   // accumulates the caller-visible time of one entry point
+  wbc_multi* mm;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit HostTimer(wbc_multi* m) : mm(m) {}
+  ~HostTimer() {
+    mm->stat_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    ++mm->stat_calls;
+  }
 };
 
 extern "C" int wbc_shard_range(size_t n_total, int n_shards, int shard, size_t* start, size_t* count) {
@@ -101,14 +241,16 @@ extern "C" int wbc_shard_range(size_t n_total, int n_shards, int shard, size_t* 
 
 extern "C" void wbc_multi_destroy(wbc_multi* mm) {
   if (!mm) return;
+  mm->pool.reset();   // the issue threads first: nothing is enqueued behind this point
   DeviceScope keep;
   for (Shard& s : mm->sh) {
     (void)hipSetDevice(s.device);
     if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.gstream) (void)hipStreamSynchronize(s.gstream);
     if (s.comm && mm->rccl.CommDestroy) (void)mm->rccl.CommDestroy(s.comm);
     if (s.d_send) (void)hipFree(s.d_send);
+    for (void* p : s.d_send_slot) if (p) (void)hipFree(p);
     if (s.d_host_img) (void)hipFree(s.d_host_img);
-    if (s.gstream) (void)hipStreamSynchronize(s.gstream);
     if (s.ev) (void)hipEventDestroy(s.ev);
     if (s.ev_tick) (void)hipEventDestroy(s.ev_tick);
     for (hipEvent_t e : s.ev_slot) if (e) (void)hipEventDestroy(e);
@@ -132,6 +274,11 @@ extern "C" int wbc_multi_create(const wbc_model* m, const wbc_params* p, int dty
       for (int j = 0; j < i; ++j)
         if (devices[i] == devices[j])
           return fail(WBC_E_INVALID, "RCCL needs distinct devices (one rank per GPU); use WBC_GATHER_PEER_COPY for shards that share a device");
+  // issue threads: the fields live at the END of wbc_solver_options, so a caller built against an older struct gets the defaults
+  int multi_threads = 0, multi_spin_us = 200;
+  if (opt && opt->struct_size >= offsetof(wbc_solver_options, multi_spin_us) + sizeof(int)) { multi_threads = opt->multi_threads; multi_spin_us = opt->multi_spin_us; }
+  if (multi_threads < -1 || multi_threads > 1) return fail(WBC_E_INVALID, "multi_threads must be -1 (serial issue), 0 (auto) or 1 (always)");
+  if (multi_spin_us < 0 || multi_spin_us > 1000000) return fail(WBC_E_INVALID, "multi_spin_us must be 0 ... 1000000");
   wbc_multi* mm = new (std::nothrow) wbc_multi;
   if (!mm) return fail(WBC_E_INVALID, "out of memory");
   mm->dtype = dtype; mm->max_total = max_batch_total; mm->backend = gather_backend; mm->observer_order = p->observer_order;
@@ -155,16 +302,26 @@ extern "C" int wbc_multi_create(const wbc_model* m, const wbc_params* p, int dty
       if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_tick, hipEventDisableTiming);
       for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&s.ev_slot[b], hipEventDisableTiming);
     }
-    if (e == hipSuccess && gather_backend != WBC_GATHER_NONE) e = hipMalloc(&s.d_send, (size_t)mm->nj * cmax * mm->ts());
+    if (e == hipSuccess && gather_backend == WBC_GATHER_RCCL) {   // (the staging copies exist for the collective's equal counts only)
+      e = hipMalloc(&s.d_send, (size_t)mm->nj * cmax * mm->ts());
+      for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipMalloc(&s.d_send_slot[b], (size_t)mm->nj * cmax * mm->ts());
+    }
     if (e != hipSuccess) { wbc_multi_destroy(mm); return fail(WBC_E_HIP, std::string("shard setup: ") + hipGetErrorString(e)); }
   }
   if (gather_backend == WBC_GATHER_PEER_COPY) {
+    mm->push_ok = true;
     for (int i = 0; i < n_devices; ++i)
       for (int j = 0; j < n_devices; ++j) {
         if (devices[i] == devices[j]) continue;
         int can = 0;
         (void)hipDeviceCanAccessPeer(&can, devices[i], devices[j]);
-        if (can) { (void)hipSetDevice(devices[i]); hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0); (void)e; (void)hipGetLastError(); }  // (already enabled is fine; without it the copies stage through the host)
+        if (can) {
+          (void)hipSetDevice(devices[i]);
+          const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+          (void)hipGetLastError();
+        }
+        if (!can) mm->push_ok = false;   // (without the mapping the copies stage through the host: hipMemcpyPeerAsync below)
       }
   }
   if (gather_backend == WBC_GATHER_RCCL) {
@@ -177,12 +334,23 @@ extern "C" int wbc_multi_create(const wbc_model* m, const wbc_params* p, int dty
     int cnt = 0;
     if (mm->rccl.CommCount(comms[0], &cnt) == ncclSuccess) mm->rccl_ranks = cnt;
   }
+  int distinct = 0;
+  for (int i = 0; i < n_devices; ++i) { bool seen = false; for (int j = 0; j < i; ++j) seen = seen || devices[j] == devices[i]; distinct += seen ? 0 : 1; }
+  // auto: threads when the shards sit on more than one DEVICE.  Shards that share a device share its queue lock in the runtime: measured on one MI355X
+  // (bench.py --single-process, profiles/r05a_*), 8 shards 30 -> 17 us per tick call, but 2 shards 7.2 -> 10.6 us -- the ticket round trip costs more than
+  // two launches that the runtime serialises anyway
+  if (multi_threads == 1 || (multi_threads == 0 && distinct > 1)) {
+    std::vector<int> devs(devices, devices + n_devices);
+    mm->pool.reset(new (std::nothrow) IssuePool(devs, multi_spin_us));
+    if (!mm->pool) { wbc_multi_destroy(mm); return fail(WBC_E_INVALID, "out of memory"); }
+  }
   *out = mm;
   return WBC_OK;
 }
 
 extern "C" int wbc_multi_size(const wbc_multi* mm) { return mm ? (int)mm->sh.size() : 0; }
 extern "C" int wbc_multi_rccl_ranks(const wbc_multi* mm) { return mm ? mm->rccl_ranks : 0; }
+extern "C" int wbc_multi_issue_threads(const wbc_multi* mm) { return (mm && mm->pool) ? (int)mm->pool->size() : 0; }
 extern "C" wbc_solver* wbc_multi_solver(wbc_multi* mm, int shard) {
   if (!mm || shard < 0 || shard >= (int)mm->sh.size()) return nullptr;
   return mm->sh[(size_t)shard].solver;
@@ -196,6 +364,26 @@ extern "C" int wbc_multi_device(const wbc_multi* mm, int shard) {
   return mm->sh[(size_t)shard].device;
 }
 
+extern "C" int wbc_multi_host_stats(wbc_multi* mm, unsigned long long* calls, double* seconds, int reset) {
+  if (!mm) return fail(WBC_E_INVALID, "null argument");
+  if (calls) *calls = mm->stat_calls;
+  if (seconds) *seconds = (double)mm->stat_ns * 1e-9;
+  if (reset) { mm->stat_calls = 0; mm->stat_ns = 0; }
+  return WBC_OK;
+}
+
+// diagnostics: `iters` empty tickets through the issue threads -- what one for_shards round trip costs the caller apart from the HIP calls inside it
+extern "C" int wbc_multi_probe_issue(wbc_multi* mm, int iters, double* seconds) {
+  if (!mm || iters < 1 || !seconds) return fail(WBC_E_INVALID, "bad argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) {
+    const int rc = for_shards(mm, [](int) { return WBC_OK; });
+    if (rc) return rc;
+  }
+  *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return WBC_OK;
+}
+
 extern "C" int wbc_multi_set_params(wbc_multi* mm, const wbc_params* p) {
   if (!mm) return fail(WBC_E_INVALID, "null argument");
   int rc = wbc::check_params_public(p);   // checked once, then applied to every shard: the shards never disagree about the parameters
@@ -205,134 +393,221 @@ extern "C" int wbc_multi_set_params(wbc_multi* mm, const wbc_params* p) {
   return WBC_OK;
 }
 
+// every shard's arguments are checked before any shard is enqueued: a bad shard k must not leave shards 0..k-1 one tick ahead
+// (their observer state advanced) of the others
+static int check_all(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out, const wbc_observer_state* obs,
+                     bool rollout, int* const* active = nullptr, bool need_active = false) {
+  if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
+  const int n = (int)mm->sh.size();
+  for (int k = 0; k < n; ++k) {
+    size_t st, cnt;
+    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
+    const int rc = wbc::check_step_args(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, rollout);
+    if (rc) return rc;
+    if (need_active && cnt && !active[k]) return fail(WBC_E_INVALID, "null active-set buffer");
+  }
+  return WBC_OK;
+}
+
+// shard k's tick on its stream (+ the "tick enqueued" event the overlapped gathers wait for)
+static int tick_shard(wbc_multi* mm, int k, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out, const wbc_observer_state* obs,
+                      int* const* active, bool record) {
+  Shard& s = mm->sh[(size_t)k];
+  size_t st, cnt;
+  (void)wbc_shard_range(n_total, (int)mm->sh.size(), k, &st, &cnt);
+  const int rc = active ? wbc_step_batch_warm(s.solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, active[k], active[k], s.stream)
+                        : wbc_step_batch(s.solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, s.stream);
+  if (rc) return rc;
+  // (only where an overlapped gather follows in the same call: an event record is a release fence in the queue, and two of them per tick pair
+  //  on one device cost the ticks more than the launches -- measured, round 5)
+  if (record && s.ev_tick) HIP_TRY(hipEventRecord(s.ev_tick, s.stream));
+  return WBC_OK;
+}
+
 extern "C" int wbc_multi_step_batch(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out,
                                     const wbc_observer_state* obs) {
   if (!mm || !in || !out) return fail(WBC_E_INVALID, "null argument");
-  if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
-  const int n = (int)mm->sh.size();
-  for (int k = 0; k < n; ++k) {   // every shard's arguments are checked before any shard is enqueued: a bad shard k must not
-    size_t st, cnt;               // leave shards 0..k-1 one tick ahead (their observer state advanced) of the others
-    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-    int rc = wbc::check_step_args(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, false);
-    if (rc) return rc;
-  }
-  for (int k = 0; k < n; ++k) {   // enqueue every shard before looking at any: the devices run concurrently
-    size_t st, cnt;
-    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-    int rc = wbc_step_batch(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, mm->sh[(size_t)k].stream);
-    if (rc) return rc;
-  }
-  return WBC_OK;
+  HostTimer ht(mm);
+  const int rc = check_all(mm, n_total, in, out, obs, false);
+  if (rc) return rc;
+  return for_shards(mm, [&](int k) { return tick_shard(mm, k, n_total, in, out, obs, nullptr, false); });   // every shard is enqueued before any is looked at: the devices run concurrently
 }
 
 // wbc_step_batch_warm per shard: active[k] = shard k's carried active sets (int32 [count_k] on devices[k]), read and rewritten in place
 extern "C" int wbc_multi_step_batch_warm(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out,
                                          const wbc_observer_state* obs, int* const* active) {
   if (!mm || !in || !out || !active) return fail(WBC_E_INVALID, "null argument");
-  if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
-  const int n = (int)mm->sh.size();
-  for (int k = 0; k < n; ++k) {   // validate all shards first (see wbc_multi_step_batch)
-    size_t st, cnt;
-    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-    int rc = wbc::check_step_args(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, false);
-    if (rc) return rc;
-    if (cnt && !active[k]) return fail(WBC_E_INVALID, "null active-set buffer");
-  }
-  for (int k = 0; k < n; ++k) {
-    size_t st, cnt;
-    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-    int rc = wbc_step_batch_warm(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, active[k], active[k],
-                                 mm->sh[(size_t)k].stream);
-    if (rc) return rc;
-  }
-  return WBC_OK;
+  HostTimer ht(mm);
+  const int rc = check_all(mm, n_total, in, out, obs, false, active, true);
+  if (rc) return rc;
+  return for_shards(mm, [&](int k) { return tick_shard(mm, k, n_total, in, out, obs, active, false); });
 }
 
 extern "C" int wbc_multi_rollout_batch(wbc_multi* mm, size_t n_total, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                                        const wbc_observer_state* obs, const void* const* tau_ext) {
   if (!mm || !in || !out) return fail(WBC_E_INVALID, "null argument");
-  if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
-  const int n = (int)mm->sh.size();
   if (horizon < 1) return fail(WBC_E_INVALID, "horizon must be >= 1");
-  for (int k = 0; k < n; ++k) {   // validate all shards first (see wbc_multi_step_batch)
+  HostTimer ht(mm);
+  const int rc = check_all(mm, n_total, in, out, obs, true);
+  if (rc) return rc;
+  const int n = (int)mm->sh.size();
+  return for_shards(mm, [&](int k) -> int {   // rank-local for all ticks
+    Shard& s = mm->sh[(size_t)k];
     size_t st, cnt;
     (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-    int rc = wbc::check_step_args(mm->sh[(size_t)k].solver, cnt, &in[k], &out[k], obs ? &obs[k] : nullptr, true);
-    if (rc) return rc;
-  }
-  for (int k = 0; k < n; ++k) {   // rank-local for all ticks
-    size_t st, cnt;
-    (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-    int rc = wbc_rollout_batch(mm->sh[(size_t)k].solver, cnt, horizon, &in[k], &out[k], obs ? &obs[k] : nullptr,
-                               tau_ext ? tau_ext[k] : nullptr, nullptr, mm->sh[(size_t)k].stream);
-    if (rc) return rc;
-  }
-  return WBC_OK;
+    const int r = wbc_rollout_batch(s.solver, cnt, horizon, &in[k], &out[k], obs ? &obs[k] : nullptr, tau_ext ? tau_ext[k] : nullptr, nullptr, s.stream);
+    return r;
+  });
 }
 
-// the gather on the shard streams (side = false: behind the tick) or on the shards' gather streams (side = true: beside the next tick)
-static int gather_impl(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, bool side) {
-#define GSTREAM(sh_) (side ? (sh_).gstream : (sh_).stream)
+// ---- the gather.  Layout of tau_all[d] (on devices[d]): n blocks of nj * count_0 scalars, block j = shard j's [nj][count_j], packed.
+struct GatherGeom { size_t cmax, blk; };
+static int gather_geom(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, GatherGeom& g) {
   if (!mm || !tau_local || !tau_all) return fail(WBC_E_INVALID, "null argument");
   if (mm->backend == WBC_GATHER_NONE) return fail(WBC_E_INVALID, "this wbc_multi was created without a gather backend");
   if (n_total > mm->max_total) return fail(WBC_E_CAPACITY, "n_total exceeds max_batch_total");
   const int n = (int)mm->sh.size();
+  size_t st0;
+  (void)wbc_shard_range(n_total, n, 0, &st0, &g.cmax);
+  g.blk = (size_t)mm->nj * g.cmax;
+  for (int k = 0; k < n && g.cmax; ++k) if (!tau_local[k] || !tau_all[k]) return fail(WBC_E_INVALID, "null tau buffer");
+  return WBC_OK;
+}
+
+// shard j's part of a gather on stream `gs` (its shard stream, or its gather stream): RCCL = its rank's ncclAllGather; peer = push my block
+// into every device's buffer.  `grouped`: the caller brackets all shards' calls with ncclGroupStart / End (serial issue); the issue threads
+// call their rank's collective concurrently instead, the one-thread-per-device form of the library.
+static int gather_shard(wbc_multi* mm, int j, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all,
+                        hipStream_t gs, void* staging) {
+  const int n = (int)mm->sh.size();
   const size_t ts = mm->ts();
-  size_t st0, cmax;
-  (void)wbc_shard_range(n_total, n, 0, &st0, &cmax);
-  if (cmax == 0) return WBC_OK;
-  const size_t blk = (size_t)mm->nj * cmax;   // elements per block of tau_all: shard j's [nj][count_j], packed, then padding
-  DeviceScope keep;
+  Shard& src = mm->sh[(size_t)j];
+  size_t st, cnt;
+  (void)wbc_shard_range(n_total, n, j, &st, &cnt);
+  const size_t bytes = (size_t)mm->nj * cnt * ts;
   if (mm->backend == WBC_GATHER_RCCL) {
-    std::vector<const void*> send((size_t)n);
-    for (int k = 0; k < n; ++k) {
-      size_t st, cnt;
-      (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-      if (!tau_local[k] || !tau_all[k]) return fail(WBC_E_INVALID, "null tau buffer");
-      send[(size_t)k] = tau_local[k];
-      if (cnt != cmax) {   // ragged: the collective needs equal counts, so the short shards send from a padded staging copy
-        Shard& s = mm->sh[(size_t)k];
-        HIP_TRY(hipSetDevice(s.device));
-        if (cnt) HIP_TRY(hipMemcpyAsync(s.d_send, tau_local[k], (size_t)mm->nj * cnt * ts, hipMemcpyDeviceToDevice, GSTREAM(s)));
-        send[(size_t)k] = s.d_send;
-      }
+    const void* send = tau_local[j];
+    if (cnt != g.cmax) {   // ragged: the collective needs equal counts, so the short shards send from a padded staging copy
+      if (cnt) HIP_TRY(hipMemcpyAsync(staging, tau_local[j], bytes, hipMemcpyDeviceToDevice, gs));
+      send = staging;
     }
-    ncclResult_t r = mm->rccl.GroupStart();
-    for (int k = 0; k < n && r == ncclSuccess; ++k) {
-      Shard& s = mm->sh[(size_t)k];
-      r = mm->rccl.AllGather(send[(size_t)k], tau_all[k], blk, mm->dtype == WBC_F64 ? ncclFloat64 : ncclFloat32, s.comm, GSTREAM(s));
-    }
-    const ncclResult_t r2 = mm->rccl.GroupEnd();
-    if (r == ncclSuccess) r = r2;
+    const ncclResult_t r = mm->rccl.AllGather(send, tau_all[j], g.blk, mm->dtype == WBC_F64 ? ncclFloat64 : ncclFloat32, src.comm, gs);
     if (r != ncclSuccess) return fail(WBC_E_HIP, std::string("ncclAllGather: ") + mm->rccl.GetErrorString(r));
     return WBC_OK;
   }
-  // peer copies: shard j pushes its block to every device on ITS stream (behind its tick), then every stream waits for all pushes
-  for (int j = 0; j < n; ++j) {
-    size_t st, cnt;
-    (void)wbc_shard_range(n_total, n, j, &st, &cnt);
-    Shard& src = mm->sh[(size_t)j];
-    if (!tau_local[j] || !tau_all[j]) return fail(WBC_E_INVALID, "null tau buffer");
-    HIP_TRY(hipSetDevice(src.device));
-    const size_t bytes = (size_t)mm->nj * cnt * ts;
-    for (int d = 0; d < n && bytes; ++d) {
-      char* dst = (char*)tau_all[d] + (size_t)j * blk * ts;
-      if (mm->sh[(size_t)d].device == src.device) HIP_TRY(hipMemcpyAsync(dst, tau_local[j], bytes, hipMemcpyDeviceToDevice, GSTREAM(src)));
-      else HIP_TRY(hipMemcpyPeerAsync(dst, mm->sh[(size_t)d].device, tau_local[j], src.device, bytes, GSTREAM(src)));
+  if (!bytes) return WBC_OK;
+  if (mm->push_ok) {   // ONE launch writes my block to all n destinations (peer mappings over xGMI; 2 n^2 -> n runtime calls per gather against the copies)
+    void* dst[64];
+    int nd = 0;
+    for (int d = 0; d < n; ++d) {
+      void* p = (char*)tau_all[d] + (size_t)j * g.blk * ts;
+      if (p != tau_local[j]) dst[nd++] = p;   // (in-place gather: the tick wrote tau straight into its own block of its own device's buffer)
     }
-    HIP_TRY(hipEventRecord(src.ev, GSTREAM(src)));
+    if (nd) {
+      const hipError_t e = wbc::k_gather_push(gs, tau_local[j], dst, nd, bytes);
+      if (e != hipSuccess) return fail(WBC_E_HIP, std::string("gather push launch: ") + hipGetErrorString(e));
+    }
+    return WBC_OK;
   }
   for (int d = 0; d < n; ++d) {
-    HIP_TRY(hipSetDevice(mm->sh[(size_t)d].device));
-    for (int j = 0; j < n; ++j)
-      if (j != d) HIP_TRY(hipStreamWaitEvent(GSTREAM(mm->sh[(size_t)d]), mm->sh[(size_t)j].ev, 0));
+    char* dst = (char*)tau_all[d] + (size_t)j * g.blk * ts;
+    if ((const void*)dst == tau_local[j]) continue;
+    if (mm->sh[(size_t)d].device == src.device) HIP_TRY(hipMemcpyAsync(dst, tau_local[j], bytes, hipMemcpyDeviceToDevice, gs));
+    else HIP_TRY(hipMemcpyPeerAsync(dst, mm->sh[(size_t)d].device, tau_local[j], src.device, bytes, gs));
   }
   return WBC_OK;
-#undef GSTREAM
 }
 
+// "everything enqueued on the shard streams so far": what the gathers order themselves behind
+static int record_ticks(wbc_multi* mm) {
+  return for_shards(mm, [&](int k) -> int { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipEventRecord(s.ev_tick, s.stream)); return WBC_OK; });
+}
+
+// behind the tick, on the shard streams; on return every shard stream is ordered behind ALL blocks of its tau_all
 extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all) {
-  return gather_impl(mm, n_total, tau_local, tau_all, false);
+  GatherGeom g;
+  int rc = gather_geom(mm, n_total, tau_local, tau_all, g);
+  if (rc || g.cmax == 0) return rc;
+  HostTimer ht(mm);
+  const int n = (int)mm->sh.size();
+  if (mm->backend == WBC_GATHER_RCCL) {
+    if (mm->pool) return for_shards(mm, [&](int k) { Shard& s = mm->sh[(size_t)k]; return gather_shard(mm, k, n_total, g, tau_local, tau_all, s.stream, s.d_send); });
+    DeviceScope keep;
+    ncclResult_t r = mm->rccl.GroupStart();
+    if (r != ncclSuccess) return fail(WBC_E_HIP, std::string("ncclGroupStart: ") + mm->rccl.GetErrorString(r));
+    for (int k = 0; k < n && !rc; ++k) {
+      Shard& s = mm->sh[(size_t)k];
+      HIP_TRY(hipSetDevice(s.device));
+      rc = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.stream, s.d_send);
+    }
+    r = mm->rccl.GroupEnd();
+    if (!rc && r != ncclSuccess) rc = fail(WBC_E_HIP, std::string("ncclGroupEnd: ") + mm->rccl.GetErrorString(r));
+    return rc;
+  }
+  rc = record_ticks(mm);
+  if (rc) return rc;
+  // peer: (1) every shard stream waits for every OTHER shard's tick -- a push lands in buffers that the destination's own tick, or a consumer
+  // enqueued behind it, may still be reading -- then pushes its block and records; (2) every shard stream waits for all pushes
+  rc = for_shards(mm, [&](int k) -> int {
+    Shard& s = mm->sh[(size_t)k];
+    for (int d = 0; d < n; ++d)
+      if (d != k && mm->sh[(size_t)d].ev_tick) HIP_TRY(hipStreamWaitEvent(s.stream, mm->sh[(size_t)d].ev_tick, 0));
+    const int r = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.stream, nullptr);
+    if (r) return r;
+    HIP_TRY(hipEventRecord(s.ev, s.stream));
+    return WBC_OK;
+  });
+  if (rc) return rc;
+  return for_shards(mm, [&](int k) -> int {
+    for (int j = 0; j < n; ++j)
+      if (j != k) HIP_TRY(hipStreamWaitEvent(mm->sh[(size_t)k].stream, mm->sh[(size_t)j].ev, 0));
+    return WBC_OK;
+  });
+}
+
+// shard k's part of the overlapped gather of `slot`: on its GATHER stream, behind the ticks that are enqueued now, beside the next tick
+static int gather_async_shard(wbc_multi* mm, int k, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all, int slot) {
+  const int n = (int)mm->sh.size();
+  Shard& s = mm->sh[(size_t)k];
+  if (mm->backend == WBC_GATHER_RCCL) HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0));   // (the collective itself meets the other ranks)
+  else   // peer pushes write OTHER devices' buffers: behind every shard's tick and whatever read those buffers before it
+    for (int d = 0; d < n; ++d) HIP_TRY(hipStreamWaitEvent(s.gstream, mm->sh[(size_t)d].ev_tick, 0));
+  const int rc = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.gstream, s.d_send_slot[slot]);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream));
+  return WBC_OK;
+}
+
+// every shard stream waits (on the device, not on the host) for the last gather of `slot`
+static int gather_wait_shard(wbc_multi* mm, int k, int slot) {
+  Shard& s = mm->sh[(size_t)k];
+  if (mm->backend == WBC_GATHER_RCCL) { HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_slot[slot], 0)); return WBC_OK; }
+  // peer: my tau_all receives a block from every shard's gather stream, and my tau is read by my own
+  for (Shard& o : mm->sh) HIP_TRY(hipStreamWaitEvent(s.stream, o.ev_slot[slot], 0));
+  return WBC_OK;
+}
+
+// all shards' parts of the overlapped gather of `slot` (see wbc_multi_allgather_tau_async); the ev_tick events have been recorded
+static int gather_async_all(wbc_multi* mm, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all, int slot) {
+  if (mm->backend == WBC_GATHER_RCCL && !mm->pool) {   // serial issue: one group call over all ranks
+    DeviceScope keep;
+    const int n = (int)mm->sh.size();
+    int rc = WBC_OK;
+    for (int k = 0; k < n; ++k) { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0)); }
+    ncclResult_t r = mm->rccl.GroupStart();
+    if (r != ncclSuccess) return fail(WBC_E_HIP, std::string("ncclGroupStart: ") + mm->rccl.GetErrorString(r));
+    for (int k = 0; k < n && !rc; ++k) {
+      Shard& s = mm->sh[(size_t)k];
+      HIP_TRY(hipSetDevice(s.device));
+      rc = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.gstream, s.d_send_slot[slot]);
+    }
+    r = mm->rccl.GroupEnd();
+    if (!rc && r != ncclSuccess) rc = fail(WBC_E_HIP, std::string("ncclGroupEnd: ") + mm->rccl.GetErrorString(r));
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k) { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream)); }
+    return WBC_OK;
+  }
+  return for_shards(mm, [&](int k) { return gather_async_shard(mm, k, n_total, g, tau_local, tau_all, slot); });
 }
 
 // The gather OFF the tick's path: enqueued on the shards' gather streams behind the tick that is on the shard streams now, so that it
@@ -341,48 +616,55 @@ extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void
 extern "C" int wbc_multi_allgather_tau_async(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, int slot) {
   if (!mm) return fail(WBC_E_INVALID, "null argument");
   if (slot < 0 || slot > 1) return fail(WBC_E_INVALID, "slot must be 0 or 1");
-  if (mm->backend == WBC_GATHER_NONE) return fail(WBC_E_INVALID, "this wbc_multi was created without a gather backend");
-  {
-    DeviceScope keep;
-    for (Shard& s : mm->sh) {   // every gather stream waits for ITS shard's tick (peer copies read only the source shard's tau)
-      HIP_TRY(hipSetDevice(s.device));
-      HIP_TRY(hipEventRecord(s.ev_tick, s.stream));
-      HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0));
-    }
-  }
-  const int rc = gather_impl(mm, n_total, tau_local, tau_all, true);
-  if (rc) return rc;
-  DeviceScope keep;
-  for (Shard& s : mm->sh) {
-    HIP_TRY(hipSetDevice(s.device));
-    HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream));
-  }
-  return WBC_OK;
+  GatherGeom g;
+  const int rc = gather_geom(mm, n_total, tau_local, tau_all, g);
+  if (rc || g.cmax == 0) return rc;
+  HostTimer ht(mm);
+  const int rc2 = record_ticks(mm);
+  return rc2 ? rc2 : gather_async_all(mm, n_total, g, tau_local, tau_all, slot);
 }
 
-// every shard stream waits (on the device, not on the host) for the last gather of `slot`: call it before the tick that overwrites
-// that slot's tau, and before reading that slot's tau_all on a shard stream
 extern "C" int wbc_multi_gather_wait(wbc_multi* mm, int slot) {
   if (!mm) return fail(WBC_E_INVALID, "null argument");
   if (slot < 0 || slot > 1) return fail(WBC_E_INVALID, "slot must be 0 or 1");
   if (mm->backend == WBC_GATHER_NONE) return WBC_OK;
-  DeviceScope keep;
-  for (Shard& s : mm->sh) {
-    HIP_TRY(hipSetDevice(s.device));
-    HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_slot[slot], 0));
-  }
-  return WBC_OK;
+  HostTimer ht(mm);
+  return for_shards(mm, [&](int k) { return gather_wait_shard(mm, k, slot); });
+}
+
+// One call per tick of a double-buffered loop: gather_wait(slot) -> tick writing the slot's tau -> overlapped gather of the slot.  Two
+// tickets to the issue threads instead of three calls of the caller (the gather waits for EVERY shard's "tick enqueued" event, so all ticks
+// must have been enqueued -- one join between the two halves).
+extern "C" int wbc_multi_tick_gather(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out, const wbc_observer_state* obs,
+                                     int* const* active, void* const* tau_all, int slot) {
+  if (!mm || !in || !out || !tau_all) return fail(WBC_E_INVALID, "null argument");
+  if (slot < 0 || slot > 1) return fail(WBC_E_INVALID, "slot must be 0 or 1");
+  HostTimer ht(mm);
+  int rc = check_all(mm, n_total, in, out, obs, false, active, active != nullptr);
+  if (rc) return rc;
+  const int n = (int)mm->sh.size();
+  if (n > 64) return fail(WBC_E_INVALID, "too many shards");
+  const void* tau_local[64];
+  for (int k = 0; k < n; ++k) tau_local[k] = out[k].tau;
+  GatherGeom g;
+  rc = gather_geom(mm, n_total, tau_local, tau_all, g);
+  if (rc) return rc;
+  rc = for_shards(mm, [&](int k) -> int {
+    const int r = gather_wait_shard(mm, k, slot);
+    return r ? r : tick_shard(mm, k, n_total, in, out, obs, active, true);
+  });
+  if (rc || g.cmax == 0) return rc;
+  return gather_async_all(mm, n_total, g, tau_local, tau_all, slot);
 }
 
 extern "C" int wbc_multi_synchronize(wbc_multi* mm) {
   if (!mm) return fail(WBC_E_INVALID, "null argument");
-  DeviceScope keep;
-  for (Shard& s : mm->sh) {
-    HIP_TRY(hipSetDevice(s.device));
+  return for_shards(mm, [&](int k) -> int {
+    Shard& s = mm->sh[(size_t)k];
     HIP_TRY(hipStreamSynchronize(s.stream));
     if (s.gstream) HIP_TRY(hipStreamSynchronize(s.gstream));
-  }
-  return WBC_OK;
+    return WBC_OK;
+  });
 }
 
 // ---- host-resident batch: scatter -> tick -> gather.  Component-major host arrays [ncomp][n_total]; a shard's slice is
@@ -407,13 +689,11 @@ extern "C" int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batc
   if (ob && (!hin->tau_prev || !hin->f_prev)) return fail(WBC_E_INVALID, "observer state given without tau_prev / f_prev");
   const int n = (int)mm->sh.size();
   const size_t ts = mm->ts();
-  DeviceScope keep;
-  for (int k = 0; k < n; ++k) {
+  const int rc = for_shards(mm, [&](int k) -> int {
     size_t st, cnt;
     (void)wbc_shard_range(n_total, n, k, &st, &cnt);
-    if (cnt == 0) continue;
+    if (cnt == 0) return WBC_OK;
     Shard& s = mm->sh[(size_t)k];
-    HIP_TRY(hipSetDevice(s.device));
     if (s.host_img_cap < cnt) {
       if (s.d_host_img) { HIP_TRY(hipStreamSynchronize(s.stream)); HIP_TRY(hipFree(s.d_host_img)); s.d_host_img = nullptr; }
       size_t st0, cap;
@@ -444,8 +724,8 @@ extern "C" int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batc
     std::memset(&out, 0, sizeof(out));
     out.tau = dptr(HostImg::TAU); out.f = dptr(HostImg::F); out.status = dints + cap; out.iters = dints + 2 * cap;
     wbc_observer_state os{dptr(HostImg::IG), dptr(HostImg::R)};
-    int rc = wbc_step_batch(s.solver, cnt, &in, &out, &os, s.stream);
-    if (rc) return rc;
+    const int r = wbc_step_batch(s.solver, cnt, &in, &out, &os, s.stream);
+    if (r) return r;
     auto d2h = [&](void* dst, int off, int rows) -> hipError_t {
       return hipMemcpy2DAsync((char*)dst + st * ts, n_total * ts, dptr(off), cnt * ts, cnt * ts, (size_t)rows, hipMemcpyDeviceToHost, s.stream);
     };
@@ -453,6 +733,8 @@ extern "C" int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batc
     HIP_TRY(hipMemcpyAsync(hout->status + st, dints + cap, cnt * sizeof(int), hipMemcpyDeviceToHost, s.stream));
     if (hout->iters) HIP_TRY(hipMemcpyAsync(hout->iters + st, dints + 2 * cap, cnt * sizeof(int), hipMemcpyDeviceToHost, s.stream));
     if (ob) { HIP_TRY(d2h(hobs->integ, HostImg::IG, 18)); HIP_TRY(d2h(hobs->r, HostImg::R, 18)); }
-  }
+    return WBC_OK;
+  });
+  if (rc) return rc;
   return wbc_multi_synchronize(mm);
 }

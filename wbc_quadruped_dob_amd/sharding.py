@@ -188,7 +188,12 @@ def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lamb
     works = [None, None]
 
     def gather(b, tau):
+        #  the collective reads tau on the SIDE stream: a `.contiguous()` temporary made on the compute stream would be handed back to the
+        # caching allocator when this function returns and could be reused while the side stream still reads it -- tau must be the tick's own
+        # (contiguous, long-lived) output buffer, and the allocator is told which other stream uses it
+        assert tau.is_contiguous(), "the overlapped gather needs the tick's own contiguous tau buffer"
         if cuda:
+            tau.record_stream(side)
             evs[b].record()                          # tau_b is complete on the compute stream ...
             side.wait_event(evs[b])                  # ... before the side stream reads it
             with torch.cuda.stream(side):
@@ -197,7 +202,7 @@ def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lamb
             works[b] = dist.all_gather_into_tensor(flat[b], tau, async_op=True)
 
     for b in (0, 1):                                 # warm the communicator and both paths
-        gather(b, taus[b].contiguous())
+        gather(b, taus[b])
     for b in (0, 1):
         works[b].wait()
     sync()
@@ -209,7 +214,7 @@ def timed_steps_with_overlapped_gather(step_fns, get_tau, dist, steps, sync=lamb
         if works[b] is not None:
             works[b].wait()                          # (GPU: the CURRENT stream waits for gather k - 2; the host does not)
         tau = get_tau(step_fns[b]())
-        gather(b, tau if tau.is_contiguous() else tau.contiguous())
+        gather(b, tau)
     for b in (0, 1):
         if works[b] is not None:
             works[b].wait()
@@ -254,7 +259,9 @@ def graph_steps_with_gather(step_fns, get_tau, dist, steps, replays=20, overlapp
                 tau = get_tau(step_fns[b]())
                 if not gather:
                     continue
+                assert tau.is_contiguous()                       # (no temporaries across streams: see timed_steps_with_overlapped_gather)
                 if overlapped:
+                    tau.record_stream(side)
                     ev = torch.cuda.Event()
                     ev.record()
                     side.wait_event(ev)
