@@ -148,8 +148,8 @@ typedef struct wbc_solver_options {
                              never pays a wake-up, a 1 kHz control loop does not burn a core per shard */
   int obs_colaunch;       /* (ABI 7) observer-on two-kernel ticks with M/h/Jc outputs: the observer update and the observer-free sweep as the TWO ROLES OF
                              ONE LAUNCH (wbc_tick_plan.front = 4) while both roles' wavefronts are resident together -- fp32 batches of 12290 ... 32768
-                             states (even; both roles with two states per lane), BASELINE's configs[3] shard.  0 = auto, 1 = whenever the tick is
-                             a two-kernel tick with the observer on, -1 = never */
+                             states (even; both roles with two states per lane), BASELINE's configs[3] shard; fp64 batches of 12289 ... 14336.
+                             0 = auto, 1 = whenever the tick is a two-kernel tick with the observer on, -1 = never */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,

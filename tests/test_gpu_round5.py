@@ -154,8 +154,8 @@ def test_issue_threads_tick_gather_and_a_consumer_on_the_shard_streams(torch_cud
 @pytest.mark.parametrize("dtype,n", [("f64", 13000), ("f64", 4097), ("f32", 20001), ("f32", 32768), ("f32", 16384), ("f32", 7)])
 def test_two_role_front_half_equals_the_two_kernels(torch_cuda, gpu_model, oracle, dtype, n):
     """sweep_obs_kernel (wbc_tick_plan.front = 4: the observer update and the observer-free sweep as the two roles of one launch) against the same two
-    bodies as two kernels (front = 2), forced at sizes either side of what the planner would pick: fp64 and unpacked fp32 (odd N) bit for bit,
-    packed fp32 against the unpacked kernels to fp32 rounding -- and against the oracle."""
+    bodies as two kernels (front = 2), forced at sizes either side of what the planner would pick: fp64 bit for bit, fp32 (packed for even N, unpacked for odd)
+    against the unpacked kernels to fp32 rounding -- and against the oracle."""
     torch = torch_cuda
     td = torch.float64 if dtype == "f64" else torch.float32
     B = synth.make_batch(4, n, gpu_model.total_mass, rank=9)
@@ -172,9 +172,10 @@ def test_two_role_front_half_equals_the_two_kernels(torch_cuda, gpu_model, oracl
         torch.cuda.synchronize()
         res[tag] = {k: out[k].clone() for k in ("tau", "f", "status", "M", "h", "Jc", "pf")}
         res[tag]["integ"], res[tag]["r"] = ig, rr
-        packed = solver.plan_tick(n)["sweep_pack2"]
+        if tag == "roles":
+            packed = solver.plan_tick(n)["sweep_pack2"]
     a, b = res["roles"], res["kernels"]
-    exact = dtype == "f64" or n % 2 == 1
+    exact = dtype == "f64"   # (fp32: the compiler contracts a * b + c * d differently in the two kernels that instantiate the same body)
     for k in a:
         if exact or k == "status":
             if k == "status" and not exact:

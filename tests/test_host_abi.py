@@ -245,11 +245,15 @@ def test_dense_qp_argument_checks_need_no_gpu(hip_lib):
 
 
 def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
-    """The round-3 defaults as the planner reports them; a deliberate change of a default changes this list."""
+    """The defaults as the planner reports them; a deliberate change of a default changes this list.  Round 5: mid-size observer-on
+    ticks with matrix outputs run the observer update and the sweep as the two roles of one launch (front = 4): fp64 12 289 .. 14 336, fp32 .. 32 768."""
     import wbc_quadruped_dob_amd as W
     assert W.dispatch_thresholds("f64", 0) == [11265, 14336, 65536, 106496]
-    assert W.dispatch_thresholds("f64", 1) == [12289, 14336, 20480, 65536, 106496]
-    assert W.dispatch_thresholds("f32", 1) == [12289, 30720, 32768, 33792, 65537, 131072, 212992]
+    assert W.dispatch_thresholds("f64", 1) == [12289, 14336, 14337, 20480, 65536, 106496]
+    assert W.dispatch_thresholds("f32", 1) == [12289, 30720, 32769, 33792, 65537, 131072, 212992]
+    assert [W.plan_tick(n, "f64", 1)["front"] for n in (12288, 12289, 14336, 14337, 20480)] == [0, 4, 4, 0, 2]
+    assert [W.plan_tick(n, "f32", 1)["front"] for n in (12290, 12291, 32768, 32770, 33792)] == [4, 0, 4, 0, 2]
+    assert W.plan_tick(20000, "f32", 1)["sweep_pack2"] == 1 and W.plan_tick(20000, "f32", 1, options={"obs_colaunch": -1})["sweep_pack2"] == 0
     assert W.plan_tick(262144, "f64", 0)["qp"] == 2 and W.plan_tick(262144, "f32", 1) == dict(
         fused=0, front=2, qp=2, qp_tile=0, qp_body=0, sweep_pack2=1, sweep_block=256, qp_warm=0)
     # options move the switches, and the list follows
@@ -260,8 +264,8 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert [W.plan_tick(n, "f64", 1, want_mats=False)["front"] for n in (9000, 16383, 16384, 262144)] == [1, 1, 3, 3]
     assert W.plan_tick(262144, "f64", 0, want_mats=False)["front"] == 1
     # warm-started ticks (wbc_step_batch_warm): fused, warm one-wavefront kernel, cold tiles that only report the sets, warm per-lane pair
-    assert W.dispatch_thresholds("f64", 1, warm=True) == [12289, 20480, 24576, 53248, 65536]
-    assert W.dispatch_thresholds("f32", 1, warm=True) == [12289, 30720, 32768, 33792, 36864, 131072]
+    assert W.dispatch_thresholds("f64", 1, warm=True) == [12289, 14337, 20480, 24576, 53248, 65536]
+    assert W.dispatch_thresholds("f32", 1, warm=True) == [12289, 30720, 32769, 33792, 36864, 131072]
     assert [W.plan_tick(n, "f64", 1, warm=True)["qp_warm"] for n in (4096, 13000, 20000, 30000, 60000)] == [1, 1, 1, 0, 1]
     assert [W.plan_tick(n, "f64", 1, warm=True)["qp"] for n in (13000, 20000, 30000, 60000)] == [0, 0, 1, 2]
     assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((11264, 0), (11265, 0), (12288, 1), (12289, 1))] == [1, 0, 1, 0]

@@ -113,6 +113,9 @@ template <class T> struct IntegrateArgs {
   T* tau_traj;                      // [nj][N] slice for this tick, or null
   T dt;
   unsigned long long jpack;         // see SweepArgs::jpack
+#ifdef WBC_FUSED_STAMP   // diagnostic build (tools/rollout_stamp.py): the integrator's own phases, column 1 of its workgroup
+  double* istamp; unsigned istampN;
+#endif
 };
 
 // CoM reference generator (com_ref.hip.hpp)

@@ -51,10 +51,15 @@ namespace wbc {
 #define LDX(ptr, c0, xN) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((xN) + s32) * (unsigned)sizeof(T))))
 // (pure-output stores keep their `if (live)` guard here: without it the roles save ~1 % in the fused tick but the persistent rollout
 // kernel, which sits at 256 registers, spills -- 19.5 -> 24.0 us per tick, measured)
-#define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+// -DWBC_ROLE_UNGUARD=1 (A/B): pure-output stores of the ROLES (EXT != 0) without their guard -- a dead lane of a role duplicates a state of its own wavefront
+#ifndef WBC_ROLE_UNGUARD
+#define WBC_ROLE_UNGUARD 0
+#endif
+#define WBC_ROLE_LIVE ((WBC_ROLE_UNGUARD && EXT != 0) || live)
+#define STV(ptr, comp, val) do { if (WBC_ROLE_LIVE) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define STVG(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)   /* in/out state (observer): dead lanes of OTHER wavefronts would race with the live one */
-#define STL(ptr, c0, stride, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
-#define STLX(ptr, c0, stride, xN, val) do { if (live) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STL(ptr, c0, stride, val) do { if (WBC_ROLE_LIVE) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STLX(ptr, c0, stride, xN, val) do { if (WBC_ROLE_LIVE) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 #define ST4G(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STVG(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 #define MAKE_R(R_, qx, qy, qz, qw) do { const T x = qx, y = qy, z = qz, w = qw; \
@@ -384,7 +389,8 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
 struct NoWait { WBC_DEV void operator()() const {} };
 template <class T, int MODE, int BLOCK, int EXT, int SPW = 16, class BeforeRefs = NoWait, class AfterGeom = NoWait>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
-                            T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom()) {
+                            T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom(), T* hres = nullptr) {
+  // hres (persistent rollout): LDS image [..][16] whose rows 0 .. 17 ALSO receive h (the integrator reads it behind an LDS-only barrier)
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   WBC_LAUNDERED_TID(tx);
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0, FWD_B = (MODE & RS_NOB) == 0;
@@ -635,10 +641,13 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 #if WBC_JIDX_ARGS   // the column offset again, from a laundered copy of the packed map: three VGPRs less across both sweeps than keeping jxN alive
         unsigned long long jp = a.jpack;
         asm volatile("" : "+s"(jp));
-        const unsigned jxN_k = (((unsigned)(jp >> (12 * leg)) >> (4 * k)) & 15u) * N32;
+        const unsigned jx_k = ((unsigned)(jp >> (12 * leg)) >> (4 * k)) & 15u;
+        const unsigned jxN_k = jx_k * N32;
         STLX(a.h, 6, 0, jxN_k, hk);
+        if (hres) hres[(6 + (int)jx_k) * 16 + (int)(tx & 15)] = hk;
 #else
         STLX(a.h, 6, 0, jxN[k], hk);
+        if (hres) hres[(6 + jx[k]) * 16 + (int)(tx & 15)] = hk;
 #endif
       }
       if (STEP) taup[k] = hk + (TWO ? dot(ax, fak.n) : (T)0);
@@ -692,6 +701,10 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);
     ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
     if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
+    if (hres) {
+      hres[sel4<int>(leg, 0, 1, 2, 3) * 16 + (int)(tx & 15)] = sel4<T>(leg, hb_f.x, hb_f.y, hb_f.z, hb_n.x);
+      if (leg < 2) hres[(4 + leg) * 16 + (int)(tx & 15)] = leg == 0 ? hb_n.y : hb_n.z;
+    }
   }
   T p_b[6], beta_b[6], beta_l[3];
   if (OBS) {

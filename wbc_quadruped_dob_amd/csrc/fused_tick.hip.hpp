@@ -219,7 +219,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   // leaves the rnea role for idle QP wavefront WBC_RO_H_WAVE; the rnea role is left with the ONE merged recursion RNEA(q, v, vdot_des) that the torque map
   // waits for (the tick's second chain once the mass_jac role publishes early).  -1: one wavefront runs both recursions (rounds 1-4)
 #ifndef WBC_RO_H_WAVE
-#define WBC_RO_H_WAVE 2
+#define WBC_RO_H_WAVE -1   // measured (profiles/r05b_ab_rollout_*.log): wavefront 2: 12.26 -> 12.67 us per tick at 1 024 robots, wavefront 1: 12.83 -- not kept
 #endif
   constexpr int H_WAVE = (SPW == 4) ? WBC_RO_H_WAVE : -1;
   constexpr int INT_WAVE = (SPW == 4) ? WBC_RO_INT_WAVE : -1;   // the integrator itself on an idle QP wavefront (the aux wavefront keeps the roles not moved)
@@ -234,6 +234,43 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   // the tick's barrier waits for that factorisation, not for the QP, and its operands should neither wait for the role's stores to drain
   // nor come back through L2
   __shared__ T mj_hand[MJ_HAND_WORDS * 64];
+  // 1: the factorisation (phase 1 of the integrator) runs on the mass_jac wavefront, right behind its image; the integrator wavefront runs the observer's
+  // joint rows, waits at the tick barrier and does phase 2 with the factors from an LDS image.  In the stamp build the tick's barrier moves from +10.3 to
+  // +9.2 us (profiles/r05g_rollout_timeline_spw4.txt); WITHOUT stamps the tick gets slower -- 12.5 -> 13.1 us at 1 024 robots, fp32 10.6 -> 11.2
+  // (profiles/r05g_ab_rollout_*.log): measured, not kept.  0 (default): phase 1 on the integrator wavefront behind the joint rows
+#ifndef WBC_RO_SPLIT_INT
+#define WBC_RO_SPLIT_INT 0
+#endif
+#ifndef WBC_RO_INT_UNGUARD   // the integrator's state stores without their `if (live)` (integrate.hip.hpp, UNGUARD)
+#define WBC_RO_INT_UNGUARD 1
+#endif
+  // (round 5) this tick's tau, f (QP wavefronts) and h (rnea role) for the integrator ALSO in LDS, the tick's first barrier ordering LDS only (the global
+  // stores drain until barrier B) and phase 2 reading them there instead of through L2.  Measured (profiles/r05f_ab_rollout_reslds_*.log, us per tick at
+  // 1 024 robots, off -> on): fp32 10.57 -> 10.01, fp64 12.51 -> 12.80 (128 robots 12.30 -> 12.67, planner in the loop 15.15 -> 15.6) -- round 4 had seen the
+  // same sign for fp64.  1 (default): fp32 kernels only; 0: never; 2: both scalar types (A/B)
+#ifndef WBC_RO_RES_LDS
+#define WBC_RO_RES_LDS 1
+#endif
+  constexpr bool RES_LDS = WBC_RO_RES_LDS == 2 || (WBC_RO_RES_LDS == 1 && sizeof(T) == 4);
+  __shared__ T fact_sh[WBC_RO_SPLIT_INT ? INT_FACT_WORDS * 64 : 1];   // the integrator's phase 1 -> phase 2 hand-over (integrate.hip.hpp, PHASE)
+  __shared__ T res_sh[RES_LDS ? (RES_WORDS + 18) * 16 : 1];   // (+ 18 rows: the external torques of the workgroup's states, parked once)
+  T* const res_img = RES_LDS ? res_sh : nullptr;
+  if constexpr (RES_LDS) {
+    for (int i = threadIdx.x; i < 18 * 16; i += blockDim.x) {
+      const int comp = i >> 4, slot = i & 15;
+      size_t st = (size_t)blockIdx.x * SPW + (slot < SPW ? slot : 0);
+      st = st < a.N ? st : a.N - 1;
+      res_sh[(RES_WORDS + comp) * 16 + slot] = ia.tau_ext ? ia.tau_ext[(size_t)comp * a.N + st] : (T)0;
+    }
+    __syncthreads();
+  }
+  auto barrier_A = [] __device__() {
+    if constexpr (RES_LDS) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // my LDS writes (lgkmcnt only): the global stores keep draining
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    } else __syncthreads();
+  };
   if constexpr (WARM) {
     if (threadIdx.x < 16) {
       const size_t sq = (size_t)blockIdx.x * SPW + threadIdx.x;
@@ -261,7 +298,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     double* const rstamp = (t == horizon - 1) ? (double*)a.pf : nullptr;
     const unsigned rstampN = (unsigned)n_tick;
     at.pf = nullptr;
-#define RSTAMP(slot) do { if (rstamp) WBC_FSTAMP(rstamp, rstampN, slot); } while (0)
+#define RSTAMP(slot) do { if (rstamp) WBC_FSTAMP_S(rstamp, rstampN, slot, SPW); } while (0)
     if (wave == 0) RSTAMP(0);
 #else
 #define RSTAMP(slot) do {} while (0)
@@ -289,23 +326,38 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     auto integrator_role = [&]() __attribute__((always_inline)) {
       // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has handed them over
       // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
-      while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      if constexpr (!WBC_RO_SPLIT_INT) {
+        while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      }
       iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
+      constexpr int PH = WBC_RO_SPLIT_INT ? 2 : 0;
 #ifdef WBC_FUSED_STAMP
+      iat.istamp = rstamp; iat.istampN = rstampN;
       RSTAMP(9);   // factorisation can start (M, Jc handed over; the roles in front of it on this wavefront are done)
-      integrate_body<T, SPW>(model, iat, [=] __device__() { __syncthreads(); RSTAMP(7); }, mj_hand);
+      auto betw = [=] __device__() { RSTAMP(2); barrier_A(); RSTAMP(7); };   // (2, WBC_RO_STAMP_ALT: this wavefront is at the tick barrier)
+      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0)>(model, iat, betw, mj_hand, res_img, fact_sh);
       RSTAMP(8);
 #else
-      integrate_body<T, SPW>(model, iat, [] __device__() { __syncthreads(); }, mj_hand);   // <- barrier A inside
+      auto betw = [=] __device__() { barrier_A(); };
+      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0)>(model, iat, betw, mj_hand, res_img, fact_sh);   // <- barrier A inside
 #endif
       __syncthreads();                                                       // barrier B: q, v of the next tick
     };
+    // -DWBC_RO_KNOCK=<bits> (diagnostic, results are garbage): roles reduced to their flags / barriers, to read the tick's critical path off the time that is
+    // left -- 1: integrator, 2: observer joint rows, 4: mass_jac, 8: observer base rows (tools/ro_knock.sh)
+#ifndef WBC_RO_KNOCK
+#define WBC_RO_KNOCK 0
+#endif
     if (wave == WINT) {
       if constexpr (PLAN_WAVE < 0) planner_role();       // planner role first
-      if constexpr (JOINT_WAVE < 0) joint_rows_role();   // idle until M, Jc exist: this wavefront takes the joint rows
+      if constexpr (JOINT_WAVE < 0) {
+        if constexpr ((WBC_RO_KNOCK & 2) != 0) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        else joint_rows_role();   // idle until M, Jc exist: this wavefront takes the joint rows
+      }
+      if constexpr ((WBC_RO_KNOCK & 1) != 0) { barrier_A(); __syncthreads(); continue; }
       if constexpr (INT_WAVE < 0) { integrator_role(); continue; }
-      else { __syncthreads(); __syncthreads(); continue; }
+      else { barrier_A(); __syncthreads(); continue; }
     }
     if (wave == 4) {
       int* const rflag = &rready;
@@ -319,17 +371,26 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       }, [gflag] __device__() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      });
+      }, res_img ? res_img + RES_H * 16 : nullptr);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      RSTAMP(3);   // (WBC_RO_STAMP_ALT) rnea: done
     } else if (wave == 5) {
       int* const mflag = &mready;
-      auto publish = [mflag] __device__() {
+      T* const factp = fact_sh;
+      T* const handp = mj_hand;
+      const IntegrateArgs<T> ia1 = iat;
+      auto publish = [=] __device__() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the hand-over image is in LDS ...
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(mflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then tell the integrator
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(mflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
+        RSTAMP(1);   // (WBC_RO_STAMP_ALT) mass_jac: image published
+        // phase 1 of the integrator, on my own image (my own LDS words: program order of one lane); the factors are complete when this wavefront
+        // reaches the tick barrier, behind which the integrator wavefront reads them
+        if constexpr (WBC_RO_SPLIT_INT != 0) integrate_body<T, SPW, IntegrateNoWait, 1, (WBC_RO_INT_UNGUARD != 0)>(model, ia1, IntegrateNoWait(), handp, nullptr, factp);
       };
       // (the M / Jc / pf stores to HBM come BEHIND the flag, from the image, and only in the launch's last tick: nothing in this kernel reads them)
-      mass_jac_body<T, 64, 1, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
+      if constexpr ((WBC_RO_KNOCK & 4) != 0) publish();
+      else mass_jac_body<T, 64, 1, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
     } else if (OBSERVER && wave == 6) {
       if constexpr (OBSERVER) {
         int* const ack = &rpack;
@@ -338,7 +399,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         auto wait_ack = [ack, ack_need, ack_on] __device__() {
           if constexpr (SPEC_ORDER) { if (ack_on) { while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ack_need) __builtin_amdgcn_s_sleep(1); } }
         };
-        if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
+        if constexpr ((WBC_RO_KNOCK & 8) != 0) {}
+        else if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
         else observer_body<T, 64, 1, 0, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -352,7 +414,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1)};
 #endif
       if constexpr (SPEC_ORDER) { if (qa.rprev) sy.rp_ack = &rpack; }
-      if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, 1, SPW>(model, prm, at, cst, wsl); }   // bias forces h -> HBM (visible behind barrier A)
+      sy.res = res_img;
+      if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, 1, SPW>(model, prm, at, cst, wsl, NoWait(), NoWait(), res_img ? res_img + RES_H * 16 : nullptr); }   // bias forces h
       if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }
       if constexpr (JOINT_WAVE >= 0) { if (wave == JOINT_WAVE) joint_rows_role(); }
       if constexpr (INT_WAVE >= 0) { if (wave == INT_WAVE) { integrator_role(); continue; } }
@@ -362,8 +425,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       } else
       if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
     }
-    __syncthreads();   // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator
-    __syncthreads();   // barrier B: q, v of the next tick
+    barrier_A();       // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator (round 5: in LDS)
+    __syncthreads();   // barrier B: q, v of the next tick -- and this tick's tau, f, h in memory (the next tick's observer role reads tau, f as tau_prev, f_prev)
   }
 }
 

@@ -23,8 +23,26 @@ struct IntegrateNoWait { WBC_DEV void operator()() const {} };
 // `hand` (persistent rollout): M's leg / base-leg / base blocks, the own-leg Jacobian block and the lever arm come from the LDS image
 // the mass_jac role left (dyn_split.hip.hpp, MJ_HAND_WORDS) instead of from the M / Jc buffers through L2 -- same numbers, so the
 // results are bit-identical; what changes is when phase 1 can start and how long its operands take to arrive.
-template <class T, int SPW = 16, class Between = IntegrateNoWait>
-WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between(), const T* hand = nullptr) {
+// `res` (persistent rollout, round 5): this tick's tau (rows 0 .. 11), f (12 .. 23), h (24 .. 41) in an LDS image [42][16] written by the QP wavefronts and
+// the rnea role: phase 2 starts behind an LDS-only barrier instead of behind the acknowledgement of their global stores and a trip through L2.
+// PHASE (persistent rollout, round 5): 0 = both phases on this wavefront.  1 = phase 1 ONLY, run by the mass_jac wavefront itself right behind its
+// image (no flag, no second wavefront waiting for it), leaving the leg block's inverse (6 words) and the base factor (21) in the LDS image
+// fact[27][64]; 2 = phase 2 only, on the integrator wavefront: state loads, the tick barrier, then M's blocks from `hand` and the factors from `fact`.
+// The integrator wavefront used to run the observer's joint rows, THEN phase 1, and arrived last at the tick barrier (+10.3 us; profiles/r05f_*).
+constexpr int INT_FACT_WORDS = 27;
+// UNGUARD (persistent rollout): the state stores carry no `if (live)`.  Lanes beyond the batch or beyond the workgroup's states recompute a state of THEIR OWN
+// wavefront (the workgroup's first, or the batch's last, which the last workgroup owns), in lockstep with the lane that owns it: what they store is a
+// bit-identical duplicate at the same address, and every one of the 22 guards was an exec region of ~45 cycles in the one phase of a rollout tick during
+// which nothing else runs (knock-out analysis: profiles/r05h_ro_knock.log).  Not for the stand-alone kernel: there a dead lane may sit in another wavefront.
+// WBC_INT_SINV: 1 = phase 1 (which runs beside the QP: hidden) ends with the explicit inverse of the base Schur complement, and phase 2 multiplies by it --
+// 36 independent multiply-adds instead of two triangular solves of 54 dependent operations at 13 cycles each for a lone wavefront; 0 (default) = the solves.
+#ifndef WBC_INT_SINV
+#define WBC_INT_SINV 0   // measured (profiles/r05i_ab_rollout_phase2_*.log): 12.05 -> 12.22 us per tick in fp64, and the fp32 inverse loses the accuracy the
+#endif                 // fp32 rollout tests ask for (NaN on stiff states): not kept
+template <class T, int SPW = 16, class Between = IntegrateNoWait, int PHASE = 0, bool UNGUARD = false>
+WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between(), const T* hand = nullptr,
+                            const T* res = nullptr, T* fact = nullptr) {
+  static_assert(PHASE == 0 || PHASE == 1 || PHASE == 2, "phase");
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   unsigned tx = threadIdx.x;
@@ -39,25 +57,44 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define LDL(ptr, c0, stride) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))))
 #define LDLX(ptr, c0, stride, xN) (*(const T*)((const char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))))
-#define STV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STV(ptr, comp, val) do { if (UNGUARD || live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   int jx[3];
   jidx_of_leg(model, a.jpack, leg, jx);
+#ifdef WBC_FUSED_STAMP
+#define ISTAMP(slot) do { if (a.istamp && SPW < 16 && (tx & 63) == 0) a.istamp[(size_t)(slot) * a.istampN + (size_t)blockIdx.x * SPW + 1] = (double)wall_clock64(); } while (0)
+#else
+#define ISTAMP(slot) do {} while (0)
+#endif
+  ISTAMP(0);
 
   // ================================================================== phase 1: M, Jc only
-  // foot position relative to the base origin from the base-angular block of my foot's Jacobian rows, -[d]x
   const T* hl = hand ? hand + (int)(tx & 63) : nullptr;
-  const V3<T> dl = hand ? mk<T>(hl[33 * 64], hl[34 * 64], hl[35 * 64])
-                        : mk<T>(LDL(a.Jc, 18 * 1 + 5, 54), LDL(a.Jc, 18 * 2 + 3, 54), LDL(a.Jc, 18 * 0 + 4, 54));
+  T* const fl_ = fact ? fact + (int)(tx & 63) : nullptr;
+  V3<T> dl;
   T jcl[3][3];   // own-leg Jacobian block: jcl[m][k] = d pf_m / d q_(leg, k)
+  T Mb[6][3];    // base-leg block (6x3) of M
+  T A[3][3];     // inverse of the leg block
+  T L[6][6];     // Cholesky factor of the base Schur complement (L[j][j] holds 1 / L_jj)
+  auto load_blocks = [&]() __attribute__((always_inline)) {
+    // foot position relative to the base origin from the base-angular block of my foot's Jacobian rows, -[d]x
+    dl = hand ? mk<T>(hl[33 * 64], hl[34 * 64], hl[35 * 64])
+              : mk<T>(LDL(a.Jc, 18 * 1 + 5, 54), LDL(a.Jc, 18 * 2 + 3, 54), LDL(a.Jc, 18 * 0 + 4, 54));
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const unsigned jo = (unsigned)(6 + jx[k]) * N32;   // column of joint (leg, k) in rows 3*leg + m of Jc
-    if (hand) { jcl[0][k] = hl[(24 + k) * 64]; jcl[1][k] = hl[(27 + k) * 64]; jcl[2][k] = hl[(30 + k) * 64]; }
-    else { jcl[0][k] = LDLX(a.Jc, 0, 54, jo); jcl[1][k] = LDLX(a.Jc, 18, 54, jo); jcl[2][k] = LDLX(a.Jc, 36, 54, jo); }
-  }
-  // leg block (symmetric 3x3) and base-leg block (6x3) of M
+    for (int k = 0; k < 3; ++k) {
+      const unsigned jo = (unsigned)(6 + jx[k]) * N32;   // column of joint (leg, k) in rows 3*leg + m of Jc
+      if (hand) { jcl[0][k] = hl[(24 + k) * 64]; jcl[1][k] = hl[(27 + k) * 64]; jcl[2][k] = hl[(30 + k) * 64]; }
+      else { jcl[0][k] = LDLX(a.Jc, 0, 54, jo); jcl[1][k] = LDLX(a.Jc, 18, 54, jo); jcl[2][k] = LDLX(a.Jc, 36, 54, jo); }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Mb[r][k] = hand ? hl[(6 + 3 * r + k) * 64] : LDV(a.M, midx18(r, r) + (6 + jx[k] - r));
+  };
+  if constexpr (PHASE != 2) {
+  load_blocks();
+  // leg block (symmetric 3x3) of M
   auto mi = [](int i, int j) { if (i > j) { const int t = i; i = j; j = t; } return i * 18 - i * (i - 1) / 2 + (j - i); };
-  T Ml[3][3], Mb[6][3];
+  T Ml[3][3];
 #pragma unroll
   for (int k1 = 0; k1 < 3; ++k1)
 #pragma unroll
@@ -65,10 +102,6 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
       Ml[k1][k2] = hand ? hl[(k1 * 3 - k1 * (k1 - 1) / 2 + (k2 - k1)) * 64] : LDV(a.M, mi(6 + jx[k1], 6 + jx[k2]));
       Ml[k2][k1] = Ml[k1][k2];
     }
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) Mb[r][k] = hand ? hl[(6 + 3 * r + k) * 64] : LDV(a.M, midx18(r, r) + (6 + jx[k] - r));
   // base block of M (upper triangle): from the buffer, or rebuilt from (m, R h, R I R^T) of the hand-over image
   T Mbb[6][6];
   if (hand) {
@@ -84,8 +117,8 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
       for (int c = r; c < 6; ++c) Mbb[r][c] = LDU(a.M, midx18(r, c));
   }
+  ISTAMP(1);   // image read requested
   // A = Ml^-1 by cofactors (SPD 3x3)
-  T A[3][3];
   {
     const T c00 = Ml[1][1] * Ml[2][2] - Ml[1][2] * Ml[1][2];
     const T c01 = Ml[0][2] * Ml[1][2] - Ml[0][1] * Ml[2][2];
@@ -97,6 +130,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     A[0][0] = c00 * idet; A[0][1] = A[1][0] = c01 * idet; A[0][2] = A[2][0] = c02 * idet;
     A[1][1] = c11 * idet; A[1][2] = A[2][1] = c12 * idet; A[2][2] = c22 * idet;
   }
+  ISTAMP(2);   // leg block inverted
   // base Schur complement S = Mbb - sum_legs W Mb^T with W = Mb A (6x3), one row of W at a time
   T S[6][6];
 #pragma unroll
@@ -110,8 +144,8 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
       S[r][c] = Mbb[r][c] - xrow_sum(sc);
     }
   }
+  ISTAMP(3);   // Schur complement summed over the legs
   // Cholesky of S (L[j][j] holds 1 / L_jj), in registers
-  T L[6][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     T d = S[j][j];
@@ -128,6 +162,41 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     }
   }
 
+#if WBC_INT_SINV
+  {   // S^-1 = L^-T L^-1 into the lower triangle of L (L[i][i] holds 1 / L_ii on entry): first Li = L^-1 (lower), then the products
+    T Li[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      Li[j][j] = L[j][j];
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        T acc = (T)0;
+#pragma unroll
+        for (int k = j; k < i; ++k) acc -= L[i][k] * Li[k][j];
+        Li[i][j] = acc * L[i][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        T acc = (T)0;
+#pragma unroll
+        for (int k = i; k < 6; ++k) acc += Li[k][i] * Li[k][j];
+        L[i][j] = acc;   // (S^-1)_ij, i >= j
+      }
+  }
+#endif
+  if constexpr (PHASE == 1) {   // hand the factors to the integrator wavefront (which reads them behind the tick barrier) and return
+    fl_[0 * 64] = A[0][0]; fl_[1 * 64] = A[0][1]; fl_[2 * 64] = A[0][2]; fl_[3 * 64] = A[1][1]; fl_[4 * 64] = A[1][2]; fl_[5 * 64] = A[2][2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) fl_[(6 + i * (i + 1) / 2 + j) * 64] = L[i][j];
+    return;
+  }
+  }   // PHASE != 2
+  ISTAMP(4);   // Cholesky done
   // the state of this tick (q, v: inputs of the tick, untouched until the stores at the end) is requested BEFORE the tick barrier: the loads
   // complete while the wavefront waits there instead of after it
   T ql[3], vl[3];
@@ -140,17 +209,33 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
 
   between();
+  ISTAMP(5);   // barrier passed
+  // (the image is indexed by the slot of the state a lane COMPUTES: a lane beyond the workgroup's states duplicates state s32, and with UNGUARD it stores)
+  const T* rs = res ? res + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
+  if constexpr (PHASE == 2) {   // M's blocks from the mass_jac role's image, the factors from the image phase 1 left (both complete behind the barrier)
+    load_blocks();
+    A[0][0] = fl_[0 * 64]; A[0][1] = A[1][0] = fl_[1 * 64]; A[0][2] = A[2][0] = fl_[2 * 64]; A[1][1] = fl_[3 * 64]; A[1][2] = A[2][1] = fl_[4 * 64]; A[2][2] = fl_[5 * 64];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[i][j] = fl_[(6 + i * (i + 1) / 2 + j) * 64];
+  }
+  // the external torques: rows RES_WORDS .. RES_WORDS + 17 of the image hold them for the whole launch (parked once by the rollout kernel: fetched per
+  // tick in front of the barrier they cost 18 registers across it -- and scratch), or the caller's buffer
+  auto text = [&](int comp) __attribute__((always_inline)) -> T { return rs ? rs[(42 + comp) * 16] : (a.tau_ext ? LDV(a.tau_ext, comp) : (T)0); };
 
   // ================================================================== phase 2: tau, f, h, q, v
   // ---- my leg: rhs_l = tau_l + JcL^T f_l + tau_ext_l - h_l
-  const V3<T> fl = mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
+  const V3<T> fl = rs ? mk<T>(rs[(12 + 3 * leg + 0) * 16], rs[(12 + 3 * leg + 1) * 16], rs[(12 + 3 * leg + 2) * 16])
+                      : mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
   T rl[3], taul[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    taul[k] = LDV(a.tau, jx[k]);
-    rl[k] = taul[k] + jcl[0][k] * fl.x + jcl[1][k] * fl.y + jcl[2][k] * fl.z - LDV(a.h, 6 + jx[k]) +
-            (a.tau_ext ? LDV(a.tau_ext, 6 + jx[k]) : (T)0);
+    taul[k] = rs ? rs[jx[k] * 16] : LDV(a.tau, jx[k]);
+    const T hl_k = rs ? rs[(24 + 6 + jx[k]) * 16] : LDV(a.h, 6 + jx[k]);
+    rl[k] = taul[k] + jcl[0][k] * fl.x + jcl[1][k] * fl.y + jcl[2][k] * fl.z - hl_k + text(6 + jx[k]);
   }
+  ISTAMP(6);   // tau, f, h arrived: leg right-hand side
   // ---- base right-hand side rb = rhs_b - sum_legs W rl
   T rb[6];
   {
@@ -162,11 +247,21 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
       for (int k = 0; k < 3; ++k) Wr[k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
       const T part = own[r] - (Wr[0] * rl[0] + Wr[1] * rl[1] + Wr[2] * rl[2]);
-      rb[r] = xrow_sum(part) - LDU(a.h, r) + (a.tau_ext ? LDU(a.tau_ext, r) : (T)0);
+      rb[r] = xrow_sum(part) - (rs ? rs[(24 + r) * 16] : LDU(a.h, r)) + text(r);
     }
   }
-  // ---- the two triangular solves
+  ISTAMP(7);   // base right-hand side summed
+  // ---- base accelerations: S vb = rb
   T vb[6];
+#if WBC_INT_SINV
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    T acc = (T)0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += (k <= i ? L[i][k] : L[k][i]) * rb[k];
+    vb[i] = acc;
+  }
+#else
   {
     T y[6];
 #pragma unroll
@@ -184,6 +279,8 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
       vb[i] = sx * L[i][i];
     }
   }
+#endif
+  ISTAMP(8);   // solves done
   // ---- leg accelerations: vdl = A (rl - Mb^T vb)
   T tl[3], vdl[3];
 #pragma unroll
@@ -205,6 +302,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     STV(a.q, 7 + jx[k], ql[k] + dt * vn);
     if (a.tau_traj) STV(a.tau_traj, jx[k], taul[k]);
   }
+  ISTAMP(9);   // joint rows stored
   T vbn[6];
 #pragma unroll
   for (int c = 0; c < 6; ++c) vbn[c] = vb0[c] + dt * vb[c];
@@ -230,10 +328,13 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   }
   // the 13 base words are replicated over the four leg rows: every row stores its share.  All rows have read
   // q/v base rows above (their values feed these stores), so no lane can store before every lane has loaded.
+  ISTAMP(10);   // quaternion advanced
   STV(a.v, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, vbn[0], vbn[1], vbn[2], vbn[3]));
   if (leg < 2) STV(a.v, 4 + leg, leg == 0 ? vbn[4] : vbn[5]);
   STV(a.q, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, qn[0], qn[1], qn[2], qn[3]));
   if (leg < 3) STV(a.q, 4 + leg, sel4<T>(leg, qn[4], qn[5], qn[6], qn[6]));
+  ISTAMP(11);   // base rows stored
+#undef ISTAMP
 #undef STV
 #undef LDLX
 #undef LDL

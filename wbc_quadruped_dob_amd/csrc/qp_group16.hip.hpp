@@ -164,11 +164,24 @@ struct QpSync {
   // counts here once its read has returned, and the observer role stores r only behind that count (fused_tick.hip.hpp) -- the read is ordered in
   // front of the write, so that iters and the last bits of tau do not depend on timing
   int* rp_ack = nullptr;
+  // (round 5, persistent rollout) LDS image [42][16] of the solver's scalar type that ALSO receives this tick's results: tau (rows 0 .. 11, caller's joint
+  // order), f (12 .. 23), and -- from the rnea role -- h (24 .. 41).  The integrator takes them from there behind an LDS-only barrier, instead of waiting
+  // for the global stores to be acknowledged and reading them back through L2
+  void* res = nullptr;
 };
+constexpr int RES_TAU = 0, RES_F = 12, RES_H = 24, RES_WORDS = 42;
 #ifdef WBC_FUSED_STAMP
-#define WBC_FSTAMP(ptr, N_, slot) do { if ((threadIdx.x & 63) == 0) (ptr)[(size_t)(slot) * (N_) + (size_t)blockIdx.x * 16] = (double)wall_clock64(); } while (0)
-#define WBC_QSTAMP(slot) do { if (sync && sync->stamp && (tx >> 6) == 0) WBC_FSTAMP(sync->stamp, sync->stampN, slot); } while (0)
-#define WBC_QSTAMP3(slot) do { if (!RHAT && sync && sync->stamp && (tx >> 6) == 3) WBC_FSTAMP(sync->stamp, sync->stampN, slot); } while (0)
+// (one column per workgroup: column = first state of the workgroup, i.e. blockIdx.x * states-per-workgroup)
+#define WBC_FSTAMP_S(ptr, N_, slot, spw) do { if ((threadIdx.x & 63) == 0) (ptr)[(size_t)(slot) * (N_) + (size_t)blockIdx.x * (spw)] = (double)wall_clock64(); } while (0)
+#define WBC_FSTAMP(ptr, N_, slot) WBC_FSTAMP_S(ptr, N_, slot, 16)
+// -DWBC_RO_STAMP_ALT (tools/rollout_stamp.py): slots 1, 2, 3 belong to the mass_jac / integrator / rnea roles of the rollout kernel instead of to QP wavefront 0
+#ifdef WBC_RO_STAMP_ALT
+#define WBC_QSTAMP_OK(slot) ((slot) != 1 && (slot) != 2 && (slot) != 3)
+#else
+#define WBC_QSTAMP_OK(slot) true
+#endif
+#define WBC_QSTAMP(slot) do { if (WBC_QSTAMP_OK(slot) && sync && sync->stamp && (tx >> 6) == 0) WBC_FSTAMP_S(sync->stamp, sync->stampN, slot, SPW); } while (0)
+#define WBC_QSTAMP3(slot) do { if (!RHAT && sync && sync->stamp && (tx >> 6) == 3) WBC_FSTAMP_S(sync->stamp, sync->stampN, slot, SPW); } while (0)
 #else
 #define WBC_QSTAMP(slot) do {} while (0)
 #define WBC_QSTAMP3(slot) do {} while (0)
@@ -690,6 +703,13 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
       GST(a.f, v, on ? x_me : (T)0);
       const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
       GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+      if constexpr (WSLDS) {
+        if (sync && sync->res) {
+          T* rs = (T*)sync->res + (int)(tx >> 4);
+          rs[(RES_F + v) * 16] = on ? x_me : (T)0;
+          rs[(RES_TAU + jm) * 16] = taup - (jl0 * fx + jl1 * fy + jl2 * fz);
+        }
+      }
     }
     if (l16 == 0) {
       a.status[s32] = status;

@@ -770,6 +770,13 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
       GST(a.f, v, on ? x_me : (T)0);
       const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
       GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+      if constexpr (WSLDS) {
+        if (sync && sync->res) {   // (persistent rollout: the integrator reads this tick's tau, f from LDS -- QpSync::res)
+          TS* rs = (TS*)sync->res + (int)(tx >> 4);
+          rs[(RES_F + v) * 16] = (TS)(on ? x_me : (T)0);
+          rs[(RES_TAU + jm) * 16] = (TS)(taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+        }
+      }
     }
     if (l16 == 0) {
       a.status[s32] = status;

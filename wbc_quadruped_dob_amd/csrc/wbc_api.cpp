@@ -78,6 +78,12 @@ constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints 
 #ifndef WBC_COLAUNCH_MAX_F32
 #define WBC_COLAUNCH_MAX_F32 32768
 #endif
+#ifndef WBC_COLAUNCH_MIN_F64
+#define WBC_COLAUNCH_MIN_F64 12289
+#endif
+#ifndef WBC_COLAUNCH_MAX_F64
+#define WBC_COLAUNCH_MAX_F64 14336
+#endif
 struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max; };
 
 struct wbc_solver {
@@ -359,11 +365,14 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
-  // together -- fp32 with two states per lane: 2 x N / 32 <= 2 048 wavefronts, i.e. up to 32 768 states, BASELINE's configs[3] shard.  fp64 (228 registers,
-  // 21 kB of LDS per one-wavefront workgroup: seven per CU) would fit 14 336 states, 2 048 beyond the one-launch tick: not enabled by default.
+  // together -- fp32 with two states per lane: 2 x N / 32 <= 2 048 wavefronts, i.e. up to 32 768 states, BASELINE's configs[3] shard; fp64 (228 registers,
+  // 21 kB of LDS per one-wavefront workgroup: seven per CU, 1 792 on the device) up to 14 336 states.  Measured (profiles/r05b_ab_colaunch_*.log, M steps/s,
+  // all-in-one observer sweep -> two roles): fp32 12 290: 351 -> 393, 16 384: 445 -> 498, 20 480: 498 -> 551, 24 576: 586 -> 651, 28 672: 639 -> 679,
+  // 32 768: 732 -> 779 (the two bodies as two kernels one after the other: 315 / 411 / 467 / 536 / 594 / 630); fp64 12 800: 321 -> 352, 13 312: 385 -> 420,
+  // 14 336: 386 -> 448, but 16 384 (two rounds): 418 -> 405.
   r.colaunch_min = (size_t)-1; r.colaunch_max = 0;
   if (o.obs_colaunch > 0) { r.colaunch_min = 0; r.colaunch_max = (size_t)-1; }
-  else if (o.obs_colaunch == 0 && dtype == WBC_F32) { r.colaunch_min = WBC_COLAUNCH_MIN_F32; r.colaunch_max = WBC_COLAUNCH_MAX_F32; }
+  else if (o.obs_colaunch == 0) { r.colaunch_min = dtype == WBC_F32 ? WBC_COLAUNCH_MIN_F32 : WBC_COLAUNCH_MIN_F64; r.colaunch_max = dtype == WBC_F32 ? WBC_COLAUNCH_MAX_F32 : WBC_COLAUNCH_MAX_F64; }
   return r;
 }
 
@@ -921,6 +930,7 @@ template <class T>
 static int integrate_impl(wbc_solver* s, size_t N, void* q, void* v, const void* M, const void* h, const void* Jc,
                           const void* tau, const void* f, const void* tau_ext, void* tau_traj, hipStream_t st) {
   IntegrateArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
   a.N = N; a.q = (T*)q; a.v = (T*)v; a.M = (const T*)M; a.h = (const T*)h; a.Jc = (const T*)Jc;
   a.tau = (const T*)tau; a.f = (const T*)f; a.tau_ext = (const T*)tau_ext; a.tau_traj = (T*)tau_traj;
   a.dt = (T)s->params.dt;
@@ -967,6 +977,7 @@ static int rollout_persistent(wbc_solver* s, size_t N, int horizon, const wbc_ba
   qa.rprev = (s->params.observer_order > 0 && obs && !plan) ? (const T*)obs->r : nullptr;
   a.ws_geom = 1;
   IntegrateArgs<T> ia;
+  std::memset(&ia, 0, sizeof(ia));
   ia.N = N; ia.q = (T*)in->q; ia.v = (T*)in->v; ia.M = (const T*)out->M; ia.h = (const T*)out->h; ia.Jc = (const T*)out->Jc;
   ia.tau = (const T*)out->tau; ia.f = (const T*)out->f; ia.tau_ext = (const T*)tau_ext; ia.tau_traj = (T*)tau_traj;
   ia.dt = (T)s->params.dt;
