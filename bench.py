@@ -41,11 +41,22 @@ def dyn_kernel_name(split):
 
 
 def tick_sweep_symbol(dtype, obs, n):
-    """rocprofv3 name prefix of the sweep a two-kernel tick with M/h/Jc outputs launches (wbc_api.cpp): MODE 11 = MATS | STEP | NOB
-    (observer off, or the observer as its own kernel from obs_split_min states on), MODE 7 = MATS | STEP | OBS"""
-    split_min = 20480 if dtype == "f64" else 40960
-    mode = 7 if (obs and n < split_min) else 11
-    return "dyn_sweep_kernel<%s, %d," % ("double" if dtype == "f64" else "float", mode)
+    """rocprofv3 name prefix of the front-half kernel that writes M, h, Jc in a two-kernel tick -- asked of the library's own planner (wbc_plan_tick), not
+    restated: front 4 = sweep_obs_kernel (observer update + observer-free sweep as two roles of one launch), MODE 11 = MATS | STEP | NOB (observer off, or
+    the observer as its own kernel in front), MODE 7 = MATS | STEP | OBS (all-in-one observer sweep)"""
+    import wbc_quadruped_dob_amd as W
+    sc = "double" if dtype == "f64" else "float"
+    pl = W.plan_tick(n, dtype, obs)
+    if pl["front"] == 4:
+        return "sweep_obs_kernel<%s," % sc
+    return "dyn_sweep_kernel<%s, %d," % (sc, 7 if (obs and pl["front"] == 0) else 11)
+
+
+def tick_sweep_name(dtype, obs, n, split):
+    """the name the roofline object carries for that kernel"""
+    if split:
+        return "mass_jac_kernel"
+    return "sweep_obs_kernel (observer update + observer-free dynamics sweep as the two roles of one launch)" if tick_sweep_symbol(dtype, obs, n).startswith("sweep_obs") else "dyn_sweep_kernel"
 
 
 print_line = lambda obj: print(json.dumps(obj))   # replaced in main() once descriptor 1 has been pointed at stderr
@@ -72,7 +83,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min_blocks=3):
+def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min_blocks=7):
     """Times blocks of EXACTLY `steps` ticks, each bracketed by barrier + synchronize on both sides, until at least
     `min_total_s` has been measured AND at least `min_blocks` blocks exist; returns the per-block seconds (max over ranks).
     The ranks leave the opening barrier together and do not talk to each other inside a block (no data-path collective), so
@@ -100,7 +111,9 @@ def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         times.append(dt)
-        total += dt
+        # a stalled block (host hiccup: > 3 x the fastest block so far) is kept as a sample but does not count towards the measured total -- round 5: one
+        # 70 ms stall had ended a run after three blocks, whose median then sat 5 % off the twelve-block runs beside it (profiles/r05m_bench_cfg4_f32_n32768.json)
+        total += dt if dt <= 3.0 * min(times) else 0.0
     return times
 
 
@@ -259,7 +272,7 @@ def main():
             gather_res = {"error": repr(e)[:200]}
 
     # cost of an event pair with nothing between them, on the same stream (reported for reference: the per-kernel times
-    # are the dispatches' own start/stop events unless WBC_TIMING=pair)
+    # are the dispatches' own start/stop events unless WBC_TIMING=pair, see docs/DESIGN_R04.md section 6)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
     for e0, e1 in ev:
         step()
@@ -314,7 +327,7 @@ def main():
                                                              "on" if obs else "off", dtype),
                        "batch_per_gpu": n, "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "writes_M_h_Jc": want_mats},
-            "roofline": {"kernel": ("fused_tick_kernel" if fused else dyn_kernel_name(split)),
+            "roofline": {"kernel": ("fused_tick_kernel" if fused else tick_sweep_name(dtype, obs, n, split)),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": pmc_traffic(("fused_tick" if fused else tick_sweep_symbol(dtype, obs, n)), n, dtype),
@@ -370,7 +383,7 @@ def main():
             res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split)
         lb_ = res.get("roofline_large_batch")
         if lb_ and isinstance(res.get("device"), dict) and dtype == "f64" and not obs and args.large_batch == 262144:
-            # the pool's devices fall into two classes on the HBM-bound tick at identical clocks (sweep 182-187 us on
+            # the pool's devices fall into two classes on the HBM-bound tick at identical clocks (docs/DESIGN_R04.md 6.0: sweep 182-187 us on
             # four of five devices probed, 208-213 us on the fifth): which kind this run drew, by the sweep's own time
             res["device"]["pool_class"] = "fast" if lb_["avg_launch_us"] <= 196.0 else "slow"
             res["device"]["pool_class_basis"] = "dyn_sweep<double, 11> at 262 144 states: %.1f us (<= 196 us = fast)" % lb_["avg_launch_us"]
@@ -515,7 +528,7 @@ def closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, device, want_m
     res["unit"] = "control-steps/s"
     res["note"] = ("best of 3 blocks of %d dependent ticks, wall time incl. the two drift kernels per tick (timed alone beside it); tick_kernels_us: the "
                    "tick's own kernels by their dispatch events, every 7th tick; plan.qp_warm = 0: at this size the cold tiles are the faster QP kernels "
-                   "and the warm tick only carries the sets (DESIGN.md 4.2b)" % ticks)
+                   "and the warm tick only carries the sets (DESIGN.md 4.4)" % ticks)
     return res
 
 
@@ -573,7 +586,7 @@ def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch):
 
 def device_probe(torch):
     """What this device's memory system delivers on a plain copy (the pool's devices differ by up to 12 % on the HBM-bound
-    tick at identical clocks): 1 GiB device-to-device copy, read + write bytes over the median of 10 copies."""
+    tick at identical clocks, docs/DESIGN_R04.md 6.0): 1 GiB device-to-device copy, read + write bytes over the median of 10 copies."""
     n = 1 << 28
     try:
         a = torch.empty(n, dtype=torch.float32, device="cuda")
@@ -741,6 +754,7 @@ def multi_capi_bench(args, W, synth, torch, np):
 
     for _ in range(args.warmup):
         tick()
+    run(0)              # one untimed pass of blocks: the first measured mode otherwise carries clock / allocator warm-up (155 M against 294 M for the same ticks)
     blocks, host0 = run(0)
     sblocks, host1 = run(1)
     gblocks, host2 = run(2)
@@ -828,10 +842,11 @@ def rollout_setup(args, W, synth, torch, np, model, dtype, n, H, rank, local_ran
             "keep": (inp, q0, v0, mask, tau_ext, integ0, integ, rr, plan)}
 
 
-# Algorithmic words per state and tick of a rollout (DESIGN.md 4.6a): read q 19 + v 18 + w_des 6 + vdot_des 18 + normals 12 + mu 4 + mask 1 +
-# tau_ext 18 + observer state 36 + previous tau, f 24 = 156; written q, v 37 + tau, f 24 + observer state 36 + M, h, Jc without their 162
-# structural words 243 = 340 (tick 0 also writes the structural words: + 162 / horizon)
-ROLLOUT_WORDS_PER_TICK = 156 + 340
+# Algorithmic words per state and tick of a rollout (DESIGN.md 4.7): read q 19 + v 18 + w_des 6 + vdot_des 18 + normals 12 + mu 4 + mask 1 +
+# tau_ext 18 + observer state 36 + previous tau, f 24 = 156; written q, v 37 + tau, f 24 + observer state 36 + h 18 = 115.  Round 5: the persistent
+# kernel writes M and Jc (225 data words + 162 structural ones) ONCE per launch, in its last tick -- the integrator takes them from LDS -- which the
+# per-tick figure below leaves out (387 / horizon words per tick more)
+ROLLOUT_WORDS_PER_TICK = 156 + 115
 
 
 def rollout_roofline(solver, r5, torch, np, n, H, dtype, reps=20):
@@ -867,11 +882,11 @@ def rollout_measurement_objects(rf, cpu, value, n, H, dtype, world):
             "note": "ALGORITHMIC flops = the oracle's instrumented operation count per tick (control step with warm-started QP + forward dynamics + "
                     "integrator) x rollouts x ticks of one launch / that launch's average duration (HIP start / stop events of the dispatch on the "
                     "launch stream); peak = fp64 vector FMA, 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz.  The rollout is a chain of dependent ticks "
-                    "on one workgroup per 4 robots: latency-bound, see DESIGN.md 4.6a",
+                    "on one workgroup per 4 robots: latency-bound, see DESIGN.md 4.7",
             "bytes": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                       "algorithmic_words_per_state_and_tick": ROLLOUT_WORDS_PER_TICK,
-                      "note": "the state a rollout actually moves per tick (inputs, q / v / tau / f / observer state written back, M, h, Jc without "
-                              "their structural words) -- far from binding"}}
+                      "note": "the state a rollout actually moves per tick (inputs; q / v / tau / f / h / observer state written back; M, Jc once per "
+                              "launch, not counted) -- far from binding"}}
 
 
 def rollout_bench(args, W, synth, torch, np, dist, world, rank, local_rank):
@@ -1238,7 +1253,7 @@ def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split
     except Exception as e:
         kept = {"error": repr(e)[:200]}
     # the same ticks for a caller that passes no M / h / Jc buffers (tau, f only -- what a controller consumes): rnea_step front half, no CRBA,
-    # no matrix stores; observer-on batches run the observer kernel + the observer-free rnea_step (DESIGN.md 4.3b)
+    # no matrix stores; observer-on batches run the observer kernel + the observer-free rnea_step (DESIGN.md 4.2)
     tf_only = None
     try:
         s3 = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=n)

@@ -96,7 +96,7 @@ void wbc_params_default(wbc_params* p, int dtype);
 int wbc_solver_create(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
                       wbc_solver** out);
 
-/* Kernel-selection options.  The defaults are the measured winners (DESIGN.md 4.8); nothing in the library reads the
+/* Kernel-selection options.  The defaults are the measured winners (DESIGN.md section 5); nothing in the library reads the
  * environment, so a C++ host sees every switch here.  Call wbc_solver_options_default first, then change fields. */
 enum wbc_timing_mode { WBC_TIMING_DISPATCH = 0, /* the dispatch's own start/stop timestamps (what rocprofv3 reports) */
                        WBC_TIMING_EVENT_PAIR = 1 /* an event pair recorded around the launch (+2-3 us per span) */ };
@@ -158,7 +158,7 @@ int wbc_solver_device(const wbc_solver* s); /* HIP device index, -1 for NULL */
 /* keep_structural: the next call writes M / Jc in full again whatever buffers it gets */
 int wbc_solver_invalidate_structural(wbc_solver* s);
 
-/* Which kernels a tick of N states runs with these options (no device needed): the measured switches of DESIGN.md 4.7 as data, so
+/* Which kernels a tick of N states runs with these options (no device needed): the measured switches of DESIGN.md section 5 as data, so
  * that a caller -- and the parity tests, which straddle every switch -- never restate them.  All fields are informational. */
 typedef struct wbc_tick_plan {
   size_t struct_size; /* in: sizeof of the caller's build (0 = this build's); out: bytes written */
@@ -206,7 +206,7 @@ typedef struct wbc_batch_out {
   void* f;
   int* status;
   int* iters; /* may be NULL.  The solver's own count per state -- dual active-set trips (one-launch ticks with the observer on: of both phases of the
-               * speculative start, DESIGN.md 4.6), Newton steps where the per-lane kernel solved the state; informational, never part of the parity contract */
+               * speculative start, DESIGN.md 4.4), Newton steps where the per-lane kernel solved the state; informational, never part of the parity contract */
   void* M;    /* optional dynamics outputs: all NULL or M, h, Jc all non-NULL */
   void* h;
   void* Jc;
@@ -400,7 +400,7 @@ int wbc_multi_probe_issue(wbc_multi* mm, int iters, double* seconds);
 /* Host-resident batch (a C++ caller that holds host arrays, e.g. the ROS side): in / out / obs hold HOST pointers to
  * component-major arrays [ncomp][n_total] of the solver's scalar type; slices are scattered to the devices with pitched
  * copies, stepped, and tau, f, status, iters (and the observer state, when obs is given) gathered back.  out->M, h, Jc,
- * pf must be NULL.  Synchronises.  PCIe-bound by construction (DESIGN.md section 6). */
+ * pf must be NULL.  Synchronises.  PCIe-bound by construction. */
 int wbc_multi_step_host(wbc_multi* mm, size_t n_total, const wbc_batch_in* host_in, const wbc_batch_out* host_out,
                         const wbc_observer_state* host_obs);
 

@@ -271,3 +271,17 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((11264, 0), (11265, 0), (12288, 1), (12289, 1))] == [1, 0, 1, 0]
 
 
+
+
+def test_design_md_carries_the_current_dispatch_table(hip_lib):
+    """DESIGN.md section 5 is GENERATED from the planner (tools/gen_dispatch_table.py, refreshed by tools/update_design.py): a moved threshold that is
+    not carried into the document fails here.  Also: the document stays a design record -- at most 50 kB."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("update_design", os.path.join(ROOT, "tools", "update_design.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"<!-- BEGIN generated by tools/gen_dispatch_table.py -->.*?<!-- END generated -->", text, flags=re.S)
+    assert m, "DESIGN.md has lost its generated dispatch table"
+    assert m.group(0) == mod.generated(), "DESIGN.md section 5 is stale: run python tools/update_design.py"
+    assert len(text.encode()) <= 50 * 1024

@@ -26,7 +26,7 @@ WARM_LOOP_LANE=1 timeout 900 python tools/warm_loop.py 16384 32768 49152 65536 1
 for spec in "2 4096" "3 8192" "3 65536" "3 262144" "4 262144"; do set -- $spec
   python bench.py --config $1 --batch $2 --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --closed-loop > "$O/bench_closed_loop_cfg$1_n$2.json" 2>> "$O/bench.err"
 done
-timeout 600 python tools/soak.py 1000 51 f64 2>&1 | tail -1 > "$O/soak.log"; timeout 600 python tools/soak.py 400 52 f32 2>&1 | tail -1 >> "$O/soak.log"
+timeout 900 python tools/soak.py 1500 51 f64 2>&1 | tail -1 > "$O/soak.log"; timeout 900 python tools/soak.py 600 52 f32 2>&1 | tail -1 >> "$O/soak.log"
 python tools/warm_timing.py > "$O/warm_timing.log" 2>> "$O/bench.err"
 bash tools/ab_sweep.sh "2 3" "49152 65536 98304 114688" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f64.log" 2>&1
 bash tools/ab_sweep.sh "4" "98304 163840 229376" "-:default" "WBC_QP_LANE=1:lane" > "$O/midrange_f32.log" 2>&1
@@ -47,6 +47,16 @@ python bench.py --steps 50 --warmup 5 --batch 262144 --config 4 --no-cpu --no-la
 python bench.py --steps 100 --warmup 10 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n32768.json" 2>> "$O/bench.err"
 python bench.py --gpus 2 --steps 20 --warmup 5 > "$O/bench_gpus2_bare.json" 2> "$O/bench_gpus2_bare.err"; echo "exit $?" >> "$O/bench_gpus2_bare.err"
 python bench.py --gpus 2 --single-process --steps 100 --warmup 10 > "$O/bench_single_process_2shards.json" 2>> "$O/bench.err"
+# host time of the one-process path: 8 shards (on however many devices are visible), issue threads against serial issue (host_issue in the line)
+python bench.py --gpus 8 --single-process --batch 4096 --steps 200 --warmup 20 > "$O/bench_single_process_8shards_b4096.json" 2>> "$O/bench.err"
+python bench.py --gpus 8 --single-process --batch 512 --steps 200 --warmup 20 > "$O/bench_single_process_8shards_b512.json" 2>> "$O/bench.err"
+# the two-role front half against the all-in-one observer sweep and the two kernels (fp32 shard of configs[3]; fp64 beside the one-launch tick)
+bash tools/ab_sweep.sh "4" "16384 24576 32768" "WBC_OBS_COLAUNCH=-1:allinone" "-:tworoles" "WBC_OBS_COLAUNCH=-1,WBC_OBS_SPLIT_MIN=0:twokernels" > "$O/ab_colaunch_f32.log" 2>&1
+bash tools/ab_sweep.sh "3" "13312 14336" "WBC_OBS_COLAUNCH=-1:allinone" "-:tworoles" > "$O/ab_colaunch_f64.log" 2>&1
+# role timeline of the last tick of a persistent rollout (make -C wbc_quadruped_dob_amd/csrc -j8 LIBDIR=../lib_rstamp EXTRA="-DWBC_FUSED_STAMP -DWBC_RO_STAMP_ALT")
+if [ -f wbc_quadruped_dob_amd/lib_rstamp/libwbc_hip.so ]; then
+  WBC_LIB=$R/wbc_quadruped_dob_amd/lib_rstamp/libwbc_hip.so python tools/rollout_stamp.py 1024 4 > "$O/rollout_timeline.txt" 2>> "$O/bench.err"
+fi
 ./tools/mfma_probe.bin > "$O/mfma_probe.log" 2>&1
 bash tools/n_sweep.sh 2>/dev/null > "$O/n_sweep.csv"
 # role timeline of the fused tick (diagnostic build, made beforehand: make -C wbc_quadruped_dob_amd/csrc -j8 LIBDIR=../lib_fstamp EXTRA=-DWBC_FUSED_STAMP)

@@ -158,7 +158,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   static_assert(SPW == 16 || EXT != 0, "fewer states per workgroup only for roles");
   WBC_LAUNDERED_TID(tx);
-  __shared__ __attribute__((aligned(512))) T cst_own[EXT ? 1 : CST_WORDS];   // (aligned: first in LDS, see section 4.9 of DESIGN.md)
+  __shared__ __attribute__((aligned(512))) T cst_own[EXT ? 1 : CST_WORDS];   // (aligned: first in LDS, see section 4.9 of docs/DESIGN_R04.md)
   __shared__ int zidx_own[EXT ? 1 : 64];
   if constexpr (EXT == 0) {
     for (int i = tx; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
@@ -400,7 +400,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr bool TWO = STEP && WH;              // h and tau_partial both wanted: two force chains; else one (merged)
   constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
   constexpr bool EARLY = EXT != 0 && STEP;      // role inside the fused tick: publish the foot lever arms first
-  __shared__ __attribute__((aligned(512))) T cst_own[EXT ? 1 : CST_WORDS];   // (aligned: first in LDS, see section 4.9 of DESIGN.md)
+  __shared__ __attribute__((aligned(512))) T cst_own[EXT ? 1 : CST_WORDS];   // (aligned: first in LDS, see section 4.9 of docs/DESIGN_R04.md)
   if constexpr (EXT == 0) {
     for (int i = tx; i < CST_WORDS; i += blockDim.x) cst_own[i] = model->cst[i];
     __syncthreads();

@@ -13,7 +13,7 @@
 //
 // Algorithms (textbook; the reference's own dynamics library is in an absent submodule):
 // Featherstone RNEA / CRBA in link coordinates with (m, h, Io) rigid-body inertias, mixed
-// ("world-aligned at the base origin") generalized velocity -- DESIGN.md section 3.
+// ("world-aligned at the base origin") generalized velocity -- docs/DESIGN_R04.md section 3.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"

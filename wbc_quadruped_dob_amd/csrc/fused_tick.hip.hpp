@@ -93,6 +93,13 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   __shared__ int rpack;                   // QP wavefronts that have read r_prev (speculative start): the observer role stores r behind all four
   constexpr bool SPEC_ORDER = OBSERVER && !WARM && WBC_QP_SPEC != 0 && WBC_SPEC_ORDER != 0;
   const int wave = (int)(threadIdx.x >> 6);
+  // -DWBC_FUSED_PRIO=1: QP wavefronts at a higher issue priority than the producers they share a SIMD with (the kernel lasts as long as its slowest QP);
+  // 2: the rnea role (whose lever arms and tau_partial the QPs wait for) high instead
+#ifndef WBC_FUSED_PRIO
+#define WBC_FUSED_PRIO 0
+#endif
+  if constexpr (WBC_FUSED_PRIO == 1) { if (wave < 4) __builtin_amdgcn_s_setprio(3); }
+  if constexpr (WBC_FUSED_PRIO == 2) { if (wave == 4) __builtin_amdgcn_s_setprio(3); }
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the pf output carries the role timestamps (slot, workgroup) instead of foot positions
   double* const stamp = (double*)a.pf;
   const unsigned stampN = (unsigned)a.N;
@@ -202,10 +209,15 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
   if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; rpack = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
+  // -DWBC_RO_PRIO=1: the rnea role -- the chain a rollout tick waits for (tools/ro_knock.sh) -- at a higher issue priority than QP wavefront 0, its SIMD-mate
+#ifndef WBC_RO_PRIO
+#define WBC_RO_PRIO 0
+#endif
+  if constexpr (WBC_RO_PRIO != 0) { if (wave == 4) __builtin_amdgcn_s_setprio(3); }
   constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
   // Workgroups of 4 states (SPW = 4) use QP wavefront 0 only; wavefronts 1..3 idle through the kernel and can take the two roles the
   // integrator wavefront runs in front of its factorisation: the observer's joint rows (WBC_RO_JOINT_WAVE) and the planner (WBC_RO_PLAN_WAVE).
-  // -1 = the integrator wavefront keeps the role (always so with 16 states per workgroup).  Measured placements: DESIGN.md 8.0a.
+  // -1 = the integrator wavefront keeps the role (always so with 16 states per workgroup).  Measured placements: docs/DESIGN_R04.md 8.0a; round 5: DESIGN.md 4.7.
 #ifndef WBC_RO_JOINT_WAVE
 #define WBC_RO_JOINT_WAVE -1
 #endif

@@ -13,7 +13,7 @@
 // 170 VGPRs, no scratch, 112 us fp64 / 57 us fp32 -- default for fp64 observer-on batches from 65 536 states on
 // (fp32: 98 304); see wbc_api.cpp for the A/B.
 // Same lane mapping as the sweep (lane = 16*leg + state), same formulas as the observer role of the fused tick
-// (rnea_step_body<RS_OBS | RS_OBSW>): beta = C^T v - g from the momentum recursion, see DESIGN.md section 3.
+// (rnea_step_body<RS_OBS | RS_OBSW>): beta = C^T v - g from the momentum recursion, see docs/DESIGN_R04.md section 3.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
@@ -520,8 +520,14 @@ __global__ __launch_bounds__(64, 2) void sweep_obs_kernel(const DevModel<T>* __r
   };
   __shared__ Lds lds;
   if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
-  if (blockIdx.x < nsweep) dyn_sweep_body<T, MODE, 64, W>(model, prm, a, lds.sw, blockIdx.x);
-  else observer_park_body<T, 64, W>(model, prm, a, lds.ob, blockIdx.x - nsweep);
+  // -DWBC_SWEEP_OBS_PRIO=1: the sweep role (the longer chain: ~16 us alone against ~12) at a higher issue priority than the observer role it shares SIMDs with
+#ifndef WBC_SWEEP_OBS_PRIO
+#define WBC_SWEEP_OBS_PRIO 0
+#endif
+  if (blockIdx.x < nsweep) {
+    if constexpr (WBC_SWEEP_OBS_PRIO != 0) __builtin_amdgcn_s_setprio(3);
+    dyn_sweep_body<T, MODE, 64, W>(model, prm, a, lds.sw, blockIdx.x);
+  } else observer_park_body<T, 64, W>(model, prm, a, lds.ob, blockIdx.x - nsweep);
 }
 
 }  // namespace wbc

@@ -8,7 +8,7 @@
 // (.gitmodules:4-6).  A formulation with other variables (accelerations, slacks, joint-torque rows) does not fit those kernels at
 // all.  This one takes any (H, g, C, d) -- the survey's "parametric in nvar <= 36, ncon <= 48" (64 rows here: a constraint per lane), and the north_star's "one QP per
 // wavefront with active-set iterations held in LDS" literally.  It is the general path, not the fast one (the 12-variable GRF QP
-// through it: see DESIGN.md section 4.2b for the measured factor).
+// through it: see docs/DESIGN_R04.md section 4.3c for the measured factor).
 //
 // Method: Goldfarb-Idnani dual active set, as oracle/qp_general.hpp (same steps, same tests, same status codes, so iteration
 // counts agree) with the wavefront's 64 lanes as the vector unit:

@@ -2,7 +2,7 @@
 //
 // qp_group16.hip.hpp solves the QP with a dense dual active-set method whose 12x12 factor J is spread over a 16-lane row
 // (four QPs per wavefront; 12 of 16 lanes carry data, a third of the instructions are predication of four independent
-// rows): about 510 vector instructions per QP.  The structure that section 4.2 of DESIGN.md uses for the initial factor goes
+// rows): about 510 vector instructions per QP.  The structure that section 4.2 of docs/DESIGN_R04.md uses for the initial factor goes
 // further: with e = B f - beta (the residual wrench, 6 numbers) the problem
 //     min 1/2 alpha |f|^2 + 1/2 |B f - beta|^2   s.t.  f_k in K_k  (friction pyramid and normal-force box of stance foot k)
 // separates per foot once e is known,  f_k(e) = Proj_{K_k}(-B_k^T e / alpha)  (Euclidean projection of a 3-vector onto a

@@ -394,7 +394,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // 53 248 to 98 304 states (605 / 605, 608 / 605, 606 / 604, 621 / 625, 638 / 639), then the pair: 636 / 690 at 114 688, 644 / 730 at 131 072; fp64 trot
   // batch: tiles 531 / 483 at 53 248, 533 / 463 at 57 344, 537 / 503 at 65 536, 554 / 520 at 81 920, 546 / 534 at 98 304, pair 527 / 554 at 114 688.
   // fp32 trot batch: tiles 1 043 / 919 at 98 304, 992 / 909 at 131 072, 934 / 911 at 196 608, pair 907 / 951 at 229 376.
-  // Hence the default: fp64 from 106 496 states on, fp32 from 212 992 (history of the threshold: DESIGN.md 4.3a).
+  // Hence the default: fp64 from 106 496 states on, fp32 from 212 992 (history of the threshold: docs/DESIGN_R04.md 4.3a).
   // wbc_step_batch_warm (dependent ticks), beyond the fused size.  Below warm_tile_min (fp64 24 576 states, fp32 the cold tile_min) the
   // one-wavefront kernel with the block set-up (qp_struct16.hip.hpp); from warm_lane_min on the per-lane kernel started from the previous FACES (one Newton step confirms them;
   // qp_lane.hip.hpp) with the hand-over list behind it; in between the COLD tiles, which only report the sets (qp_warm = 0): the warm

@@ -650,8 +650,11 @@ extern "C" int wbc_multi_tick_gather(wbc_multi* mm, size_t n_total, const wbc_ba
   rc = gather_geom(mm, n_total, tau_local, tau_all, g);
   if (rc) return rc;
   rc = for_shards(mm, [&](int k) -> int {
-    const int r = gather_wait_shard(mm, k, slot);
-    return r ? r : tick_shard(mm, k, n_total, in, out, obs, active, true);
+    // the tick overwrites out[k].tau, which only shard k's OWN gather stream read (gather k - 2 of this slot): one wait, not one per shard --
+    // the pushes of gather k that land in tau_all[k] order themselves behind this tick through ev_tick
+    Shard& s = mm->sh[(size_t)k];
+    HIP_TRY(hipStreamWaitEvent(s.stream, s.ev_slot[slot], 0));
+    return tick_shard(mm, k, n_total, in, out, obs, active, true);
   });
   if (rc || g.cmax == 0) return rc;
   return gather_async_all(mm, n_total, g, tau_local, tau_all, slot);
