@@ -397,6 +397,9 @@ int wbc_multi_issue_threads(const wbc_multi* mm);           /* number of issue t
 int wbc_multi_host_stats(wbc_multi* mm, unsigned long long* calls, double* seconds, int reset);
 /* diagnostics: the time of `iters` EMPTY tickets through the issue threads (what a round trip costs apart from the HIP calls inside it) */
 int wbc_multi_probe_issue(wbc_multi* mm, int iters, double* seconds);
+/* self-test of the issue threads without a device (run by the CPU test-suite): every thread must run every ticket exactly once, in order, and a thread's
+ * error must reach the caller; spin_us = 0 forces the parked (condition variable) path, pause_us > 0 lets the threads park between tickets */
+int wbc_multi_selftest_issue(int threads, int tickets, int spin_us, int pause_us);
 /* Host-resident batch (a C++ caller that holds host arrays, e.g. the ROS side): in / out / obs hold HOST pointers to
  * component-major arrays [ncomp][n_total] of the solver's scalar type; slices are scattered to the devices with pitched
  * copies, stepped, and tau, f, status, iters (and the observer state, when obs is given) gathered back.  out->M, h, Jc,

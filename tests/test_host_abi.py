@@ -285,3 +285,12 @@ def test_design_md_carries_the_current_dispatch_table(hip_lib):
     assert m, "DESIGN.md has lost its generated dispatch table"
     assert m.group(0) == mod.generated(), "DESIGN.md section 5 is stale: run python tools/update_design.py"
     assert len(text.encode()) <= 50 * 1024
+
+
+@pytest.mark.parametrize("threads,tickets,spin_us,pause_us", [(8, 20000, 200, 0), (8, 400, 0, 0), (3, 300, 0, 150), (2, 300, 50, 120), (16, 2000, 20, 0)])
+def test_issue_threads_run_every_ticket_once(hip_lib, threads, tickets, spin_us, pause_us):
+    """wbc_multi_*'s per-shard issue threads (csrc/wbc_multi.cpp, IssuePool), without a device: every thread runs every ticket exactly once and in order, an
+    error of one thread reaches the caller with its message -- spinning (a tick loop), always parked (spin_us = 0) and parking between tickets (pause_us)."""
+    hip_lib.wbc_multi_selftest_issue.argtypes = [C.c_int] * 4
+    rc = hip_lib.wbc_multi_selftest_issue(threads, tickets, spin_us, pause_us)
+    assert rc == 0, hip_lib.wbc_last_error()

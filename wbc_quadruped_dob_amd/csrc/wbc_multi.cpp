@@ -372,6 +372,34 @@ extern "C" int wbc_multi_host_stats(wbc_multi* mm, unsigned long long* calls, do
   return WBC_OK;
 }
 
+// Self-test of the issue threads WITHOUT a device (the CPU test-suite runs it: tests/test_host_abi.py): `threads` threads, `tickets` tickets, every thread must
+// run every ticket exactly once and in order; spin_us = 0 makes every wait park on the condition variable (the path a tick loop never takes),
+// pause_us > 0 lets the threads park between tickets.  Returns WBC_OK, or WBC_E_INVALID with the first discrepancy in wbc_last_error().
+extern "C" int wbc_multi_selftest_issue(int threads, int tickets, int spin_us, int pause_us) {
+  if (threads < 1 || threads > 64 || tickets < 1 || spin_us < 0 || pause_us < 0) return fail(WBC_E_INVALID, "bad argument");
+  std::vector<int> devs((size_t)threads, 0);
+  IssuePool pool(devs, spin_us);
+  std::vector<long long> seen((size_t)threads, -1), bad((size_t)threads, 0);
+  for (int t = 0; t < tickets; ++t) {
+    auto job = [&](int k) -> int {
+      if (seen[(size_t)k] != t - 1) ++bad[(size_t)k];     // a ticket skipped, or run twice
+      seen[(size_t)k] = t;
+      return (t % 7 == 3 && k == threads - 1) ? fail(WBC_E_CAPACITY, "ticket " + std::to_string(t)) : WBC_OK;   // an error now and then: it must reach the caller
+    };
+    JobRef j;
+    j.call = [](void* c, int k) -> int { return (*(decltype(job)*)c)(k); };
+    j.ctx = (void*)&job;
+    const int rc = pool.run(j);
+    const int want = (t % 7 == 3) ? WBC_E_CAPACITY : WBC_OK;
+    if (rc != want) return fail(WBC_E_INVALID, "ticket " + std::to_string(t) + ": status " + std::to_string(rc) + " instead of " + std::to_string(want));
+    if (want && std::string(wbc_last_error()) != "ticket " + std::to_string(t)) return fail(WBC_E_INVALID, "the failing thread's message did not reach the caller");
+    if (pause_us) std::this_thread::sleep_for(std::chrono::microseconds(pause_us));
+  }
+  for (int k = 0; k < threads; ++k)
+    if (bad[(size_t)k] || seen[(size_t)k] != tickets - 1) return fail(WBC_E_INVALID, "thread " + std::to_string(k) + " missed or repeated a ticket");
+  return WBC_OK;
+}
+
 // diagnostics: `iters` empty tickets through the issue threads -- what one for_shards round trip costs the caller apart from the HIP calls inside it
 extern "C" int wbc_multi_probe_issue(wbc_multi* mm, int iters, double* seconds) {
   if (!mm || iters < 1 || !seconds) return fail(WBC_E_INVALID, "bad argument");
