@@ -586,7 +586,9 @@ def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, orac
 @pytest.mark.parametrize("obs,n", [(1, 777), (0, 130), (2, 1500)])
 def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, oracle, obs, n):
     """The persistent rollout kernel gives a workgroup 4 states (up to 1024 rollouts) or 16 (wbc_solver_options.rollout_spw): another
-    distribution of the same per-state arithmetic over the device -> bit-identical results."""
+    distribution of the same per-state arithmetic over the device.  Since round 5 the 4-state workgroups run the two force recursions of the
+    rnea role side by side in the lanes (RS_LANE2) and add their torques across lanes, where the 16-state ones add them inside one fused
+    multiply-add chain: the last bit of ~3 % of the torques differs per tick (tools/spw_diff.py), the active sets do not."""
     torch = torch_cuda
     B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=67)
     tau_ext = np.zeros((n, 18))
@@ -598,7 +600,10 @@ def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, orac
         res[spw] = _gpu_rollout(torch, solver, P, 9, B, tau_ext, None if integ is None else integ.copy(),
                                 np.zeros((n, 18)) if obs else None)
     for k in res["4"]:
-        assert np.array_equal(res["4"][k], res["16"][k]), k
+        if res["4"][k].dtype.kind in "iu":
+            assert np.array_equal(res["4"][k], res["16"][k]), k
+        else:
+            assert relerr(res["4"][k], res["16"][k]) < 1e-11, k
 
 
 def test_rollout_vs_golden(torch_cuda, gpu_model):

@@ -148,5 +148,8 @@ constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
 constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, without RS_STEP / RS_H): no force recursion, the
                             // momentum observer is updated and rhat (18 words) goes to the LDS image at WS_RHAT
 constexpr int RS_NOB = 32;  // (stand-alone kernel, observer off) w_des is not forwarded to the workspace: see SW_NOB
+constexpr int RS_LANE2 = 64; // (roles with 4 states per workgroup, RS_STEP | RS_H) the two force recursions SIDE BY SIDE in the lanes instead of one after the
+                             // other: slots 0 .. 3 of every leg row run RNEA(q, v, 0) (the bias forces h), slots 4 .. 7 RNEA(q, 0, vdot_des) without gravity
+                             // (M vdot_des) of the same states, as ONE instruction stream; tau_partial = their sum, across lanes (round 5)
 
 }  // namespace wbc

@@ -43,7 +43,7 @@ namespace wbc {
                            : ((size_t)blockIdx.x * (BLOCK / 64) + (tx >> 6)) * 16 + (tx & 15);           \
   const bool slot_ok = SPW == 16 || (int)(tx & 15) < SPW;                                                                  \
   const bool live = slot_ok && s_raw < N;                                                                                  \
-  const unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));                            \
+  unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));                                  \
   const unsigned legN = (unsigned)leg * N32;
 #define CS(i) cst[(i) * 4 + leg]
 #define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
@@ -397,7 +397,9 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr bool OBSW = (MODE & RS_OBSW) != 0;
   static_assert(!OBSW || (EXT != 0 && OBS && !STEP && !WH), "the observer role exists only inside the fused tick");
   constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
-  constexpr bool TWO = STEP && WH;              // h and tau_partial both wanted: two force chains; else one (merged)
+  constexpr bool LANE2 = (MODE & RS_LANE2) != 0;   // the two chains side by side in the lanes (device_types.hpp)
+  static_assert(!LANE2 || (EXT != 0 && SPW == 4 && STEP && WH && !OBS), "RS_LANE2: a role of 4-state workgroups that wants h and tau_partial");
+  constexpr bool TWO = STEP && WH && !LANE2;    // h and tau_partial both wanted: two force chains in every lane; else one (merged, or one per lane group)
   constexpr bool BASEROWS = WH || OBS;          // base rows of h / p / beta needed
   constexpr bool EARLY = EXT != 0 && STEP;      // role inside the fused tick: publish the foot lever arms first
   __shared__ __attribute__((aligned(512))) T cst_own[EXT ? 1 : CST_WORDS];   // (aligned: first in LDS, see section 4.9 of docs/DESIGN_R04.md)
@@ -407,6 +409,11 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   }
   const T* cst = EXT ? cst_ext : cst_own;
   WBC_ADDR_MACROS
+  // RS_LANE2: slots 4 .. 7 are the acceleration-only recursion of states 0 .. 3 (they stay !live: they store nothing to memory)
+  const bool chainB = LANE2 && (int)(tx & 15) >= SPW && (int)(tx & 15) < 2 * SPW;
+  if constexpr (LANE2) {
+    if (chainB) { const size_t sb = (size_t)blockIdx.x * SPW + (tx & 15) - SPW; s32 = (unsigned)(sb < N ? sb : N - 1); }
+  }
 #define WSTV(comp, val) do { if constexpr (EXT != 0) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else STV(a.ws, comp, val); } while (0)
 #define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 #define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
@@ -447,6 +454,15 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     }
   };
   if constexpr (!LATE_REFS) load_refs();
+  auto lane2_mask = [&]() __attribute__((always_inline)) {   // chain A keeps the velocities (and gravity, below), chain B the desired accelerations
+    if constexpr (LANE2) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { vb[c] = chainB ? (T)0 : vb[c]; ad[c] = chainB ? ad[c] : (T)0; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { vl[k] = chainB ? (T)0 : vl[k]; al[k] = chainB ? al[k] : (T)0; }
+    }
+  };
+  if constexpr (!LATE_REFS) lane2_mask();
   if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
   if constexpr (!EARLY) {   // (EARLY: w_des is stored after the lever arms, so that those do not wait for its load)
     if (STEP && !OBS && FWD_B) {
@@ -485,7 +501,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     WSTL(WS_D + 1, 3, dw0.y);
     WSTL(WS_D + 2, 3, dw0.z);
     after_geom();   // first call: lever arms are out
-    if constexpr (LATE_REFS) load_refs();
+    if constexpr (LATE_REFS) { load_refs(); lane2_mask(); }
     if (STEP && !OBS && FWD_B) {
       WST4(WS_B + 0, bw[0], WS_B + 1, bw[1], WS_B + 2, bw[2], WS_B + 3, bw[3]);
       if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? bw[4] : bw[5]);
@@ -511,7 +527,8 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     MAKE_R(R, qx, qy, qz, qw);
     const V3<T> om0 = tmul(R, mk<T>(vb[3], vb[4], vb[5]));
     const V3<T> v0 = tmul(R, mk<T>(vb[0], vb[1], vb[2]));
-    const V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));
+    V3<T> gneg = tmul(R, mk<T>(-model->grav[0], -model->grav[1], -model->grav[2]));
+    if constexpr (LANE2) { gneg.x = chainB ? (T)0 : gneg.x; gneg.y = chainB ? (T)0 : gneg.y; gneg.z = chainB ? (T)0 : gneg.z; }
     const V3<T> aL0 = gneg - cross(om0, v0);
     if (BASEROWS) {
       const SF<T> Iv0 = inertia_mul(bm, bh, bI, om0, v0);
@@ -785,6 +802,10 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
         for (int c = 0; c < 6; ++c) b[c] = LDU(a.w_des, c) - rb[c];
         WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
         if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
+      }
+      if constexpr (LANE2) {   // tau_partial = h (my chain, slot s) + M vdot_des (slot s + 4): row_ror:12 hands lane i the value of lane (i + 4) mod 16
+#pragma unroll
+        for (int k = 0; k < 3; ++k) taup[k] += dpp_mov<0x12C>(taup[k]);
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k) WSTL(WS_TAUP + k, 3, taup[k] - rl[k]);

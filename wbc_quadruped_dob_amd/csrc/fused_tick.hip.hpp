@@ -375,7 +375,12 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       int* const rflag = &rready;
       const int rneed = t + 1;
       int* const gflag = &gready;
-      rnea_step_body<T, (H_WAVE >= 0 ? RS_STEP : (RS_STEP | RS_H)), 64, 1, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
+      // (4-state workgroups: the bias and the acceleration recursion side by side in the lanes -- RS_LANE2, device_types.hpp; -DWBC_RO_LANE2=0: one after the other)
+#ifndef WBC_RO_LANE2
+#define WBC_RO_LANE2 1
+#endif
+      constexpr int RNEA_MODE = H_WAVE >= 0 ? RS_STEP : ((SPW == 4 && WBC_RO_LANE2) ? (RS_STEP | RS_H | RS_LANE2) : (RS_STEP | RS_H));
+      rnea_step_body<T, RNEA_MODE, 64, 1, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

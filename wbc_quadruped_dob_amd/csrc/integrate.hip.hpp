@@ -208,7 +208,34 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
   for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
 
+  // (so is the unit quaternion of the state: a square root and a division of ~0.2 us for a lone wavefront, which used to sit behind the barrier)
+  // Three shortenings of phase 2 (round 5), each 1 = fp32 only (default), 2 = both scalar types, 0 = off.  Measured at 1 024 rollouts
+  // (profiles/r05n_ab_rollout_phase2.log): fp32 10.08 -> 9.82 us per tick with all three; fp64 11.57 -> 11.75 / 11.68 / 11.88 as they are added -- the fp64
+  // rollout kernel sits at its 256 registers and each of them moves spill code INTO this phase (ISA: 11 scratch loads behind the barrier), so fp64 keeps
+  // the forms of rounds 1-4.
+#ifndef WBC_INT_ARL           // W rl = Mb (A rl) instead of forming W = Mb A again behind the barrier
+#define WBC_INT_ARL 1
+#endif
+#ifndef WBC_INT_QUAT_SERIES   // the quaternion increment from its power series (below)
+#define WBC_INT_QUAT_SERIES 1
+#endif
+#ifndef WBC_INT_QNORM_EARLY   // the state's unit quaternion (a square root and a division) in front of the barrier
+#define WBC_INT_QNORM_EARLY 1
+#endif
+  constexpr bool ARL = WBC_INT_ARL == 2 || (WBC_INT_ARL == 1 && sizeof(T) == 4);
+  constexpr bool QUAT_SERIES = WBC_INT_QUAT_SERIES == 2 || (WBC_INT_QUAT_SERIES == 1 && sizeof(T) == 4);
+  constexpr bool QNORM_EARLY = WBC_INT_QNORM_EARLY == 2 || (WBC_INT_QNORM_EARLY == 1 && sizeof(T) == 4);
+  T ux, uy, uz, uw;
+  if constexpr (QNORM_EARLY) {
+    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    ux = qb[3] * n; uy = qb[4] * n; uz = qb[5] * n; uw = qb[6] * n;
+  }
+
   between();
+  if constexpr (!QNORM_EARLY) {
+    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    ux = qb[3] * n; uy = qb[4] * n; uz = qb[5] * n; uw = qb[6] * n;
+  }
   ISTAMP(5);   // barrier passed
   // (the image is indexed by the slot of the state a lane COMPUTES: a lane beyond the workgroup's states duplicates state s32, and with UNGUARD it stores)
   const T* rs = res ? res + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
@@ -241,12 +268,19 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   {
     const V3<T> mo = cross(dl, fl);
     const T own[6] = {fl.x, fl.y, fl.z, mo.x, mo.y, mo.z};
+    T ul[3];   // W rl = Mb (A rl): 27 multiply-adds behind the barrier instead of the 72 of forming W = Mb A again
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ul[k] = A[k][0] * rl[0] + A[k][1] * rl[1] + A[k][2] * rl[2];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      T Wr[3];
+      T part;
+      if constexpr (ARL) part = own[r] - (Mb[r][0] * ul[0] + Mb[r][1] * ul[1] + Mb[r][2] * ul[2]);
+      else {
+        T Wr[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Wr[k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
-      const T part = own[r] - (Wr[0] * rl[0] + Wr[1] * rl[1] + Wr[2] * rl[2]);
+        for (int k = 0; k < 3; ++k) Wr[k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
+        part = own[r] - (Wr[0] * rl[0] + Wr[1] * rl[1] + Wr[2] * rl[2]);
+      }
       rb[r] = xrow_sum(part) - (rs ? rs[(24 + r) * 16] : LDU(a.h, r)) + text(r);
     }
   }
@@ -310,17 +344,34 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
   for (int c = 0; c < 3; ++c) qn[c] = qb[c] + dt * vbn[c];
   {
+    // q <- dq(omega dt) * q with dq = [sin(th/2) / th * w ; cos(th/2)], w = omega dt, th = |w|.  Both factors are even power series in th: with
+    // u = th^2 / 4 <= 1/16 (half a radian per step) seven terms carry them to below 1e-19 -- no square root, no division, no argument reduction, which
+    // together were ~1 us of the 3 us a rollout tick spends in this phase alone (profiles/r05g_rollout_timeline_spw4.txt).  Beyond that the closed form,
+    // selected per lane: what a state gets does not depend on its neighbours.
     const T wx = vbn[3] * dt, wy = vbn[4] * dt, wz = vbn[5] * dt;
     const T th2 = wx * wx + wy * wy + wz * wz;
-    const T th = th2 > (T)0 ? th2 * rsqrt_t(th2) : (T)0;
-    T sn, cs;
-    sincos_t(th * (T)0.5, &sn, &cs);
-    const bool small = th <= (T)1e-8;
-    const T sc = small ? (T)0.5 - th2 * (T)(1.0 / 48.0) : sn / (small ? (T)1 : th);
-    const T dw = small ? (T)1 - th2 * (T)0.125 : cs;
+    const T u = th2 * (T)0.25;
+    T sc = (T)(1.0 / 6227020800.0), dw = (T)(1.0 / 479001600.0);
+    sc = sc * u - (T)(1.0 / 39916800.0); dw = dw * u - (T)(1.0 / 3628800.0);
+    sc = sc * u + (T)(1.0 / 362880.0);   dw = dw * u + (T)(1.0 / 40320.0);
+    sc = sc * u - (T)(1.0 / 5040.0);     dw = dw * u - (T)(1.0 / 720.0);
+    sc = sc * u + (T)(1.0 / 120.0);      dw = dw * u + (T)(1.0 / 24.0);
+    sc = sc * u - (T)(1.0 / 6.0);        dw = dw * u - (T)0.5;
+    sc = sc * u + (T)1;                  dw = dw * u + (T)1;
+    sc = sc * (T)0.5;
+    const bool big = QUAT_SERIES ? !(u <= (T)0.0625) : true;
+    if (!QUAT_SERIES || __ballot(big) != 0) {   // the closed form (with its own two-term series next to th = 0, as in rounds 1-4)
+      const T th = th2 > (T)0 ? th2 * rsqrt_t(th2) : (T)0;
+      T sn, cs;
+      sincos_t(th * (T)0.5, &sn, &cs);
+      const bool small = th <= (T)1e-8;
+      const T sc_c = small ? (T)0.5 - th2 * (T)(1.0 / 48.0) : sn / (small ? (T)1 : th);
+      const T dw_c = small ? (T)1 - th2 * (T)0.125 : cs;
+      sc = big ? sc_c : sc;
+      dw = big ? dw_c : dw;
+    }
     const T dx = sc * wx, dy = sc * wy, dz = sc * wz;
-    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
-    const T x = qb[3] * n, y = qb[4] * n, z = qb[5] * n, w = qb[6] * n;
+    const T x = ux, y = uy, z = uz, w = uw;
     qn[3] = dw * x + dx * w + dy * z - dz * y;
     qn[4] = dw * y - dx * z + dy * w + dz * x;
     qn[5] = dw * z + dx * y - dy * x + dz * w;
