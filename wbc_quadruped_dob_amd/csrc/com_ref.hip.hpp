@@ -39,11 +39,13 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
 #define RLDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define RLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define RSTV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+  constexpr bool SIMG = EXT && SPW == 4 && WBC_RO_MERGE != 0;   // the state from the workgroup's LDS image (WBC_STATE_MACROS, dyn_split.hip.hpp)
+  const T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
   T qb[7], vb[6], pl[PLAN_WORDS];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) qb[c] = RLDU(a.q, c);
+  for (int c = 0; c < 7; ++c) qb[c] = SIMG ? si_[c * 16] : RLDU(a.q, c);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) vb[c] = RLDU(a.v, c);
+  for (int c = 0; c < 6; ++c) vb[c] = SIMG ? si_[(SIMG_V + c) * 16] : RLDU(a.v, c);
 #pragma unroll
   for (int c = 0; c < PLAN_WORDS; ++c) pl[c] = RLDU(a.plan, c);
   int jx[3];
@@ -51,8 +53,8 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
   T ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    ql[k] = RLDV(a.q, 7 + jx[k]);
-    vl[k] = RLDV(a.v, 6 + jx[k]);
+    ql[k] = SIMG ? si_[(7 + jx[k]) * 16] : RLDV(a.q, 7 + jx[k]);
+    vl[k] = SIMG ? si_[(SIMG_V + 6 + jx[k]) * 16] : RLDV(a.v, 6 + jx[k]);
   }
   T qx, qy, qz, qw;
   {

@@ -81,7 +81,15 @@ template <class T> struct SweepArgs {
   unsigned long long jpack;   // the caller's joint index of leg l joint k in nibble 3 l + k (pack_jidx): the bodies take it from these two
                               // SGPRs instead of loading DevModel::jidx -- a per-lane global load in FRONT of the joint-state loads, i.e. one
                               // more dependent trip through L2 at the head of every role of every tick (round 5)
+  const T* simg;              // (set by the persistent rollout kernel, never by the host) the workgroup's state image in LDS: see WBC_RO_MERGE
 };
+// The state image of a 4-state rollout workgroup (WBC_RO_MERGE, fused_tick.hip.hpp): q (rows 0 .. 18) and v (19 .. 36) of the workgroup's states,
+// [row][16 slots], in LDS for the whole launch.  The integrator writes the new state there (and to memory); the roles of the next tick read it from
+// there instead of waiting for those stores and a trip through L2 at the head of the tick.
+constexpr int SIMG_V = 19, SIMG_WORDS = 37;
+#ifndef WBC_RO_MERGE
+#define WBC_RO_MERGE 1
+#endif
 
 template <class T> struct QpArgs {
   size_t N;
@@ -113,6 +121,8 @@ template <class T> struct IntegrateArgs {
   T* tau_traj;                      // [nj][N] slice for this tick, or null
   T dt;
   unsigned long long jpack;         // see SweepArgs::jpack
+  T* simg;                          // see SweepArgs::simg (the integrator reads the state there and writes the new one to both)
+  int skip_state;                   // (set by the persistent rollout kernel) 1: the new q, v go to the LDS image only -- every tick of a launch but the last
 #ifdef WBC_FUSED_STAMP   // diagnostic build (tools/rollout_stamp.py): the integrator's own phases, column 1 of its workgroup
   double* istamp; unsigned istampN;
 #endif
@@ -133,6 +143,7 @@ template <class T> struct RefArgs {
   T* w_des; T* vdot_des;
   T* com;   // [6][N] or null
   unsigned long long jpack;   // see SweepArgs::jpack
+  const T* simg;              // see SweepArgs::simg
 };
 
 // MODE bits of dyn_sweep_kernel (dyn_sweep.hip.hpp)

@@ -45,6 +45,16 @@ namespace wbc {
   const bool live = slot_ok && s_raw < N;                                                                                  \
   unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));                                  \
   const unsigned legN = (unsigned)leg * N32;
+// the state (q, v): from memory, or -- roles of 4-state rollout workgroups, WBC_RO_MERGE -- from the workgroup's LDS image (device_types.hpp, SIMG_*),
+// indexed by the slot of the state the lane COMPUTES (dead lanes duplicate a state of their own workgroup).  Needs jx / jxN in scope for the joint rows.
+#define WBC_STATE_MACROS                                                                                                                          \
+  constexpr bool SIMG = EXT != 0 && SPW == 4 && WBC_RO_MERGE != 0;                                                                                \
+  const T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;                                               \
+  auto ldq = [&](int comp) __attribute__((always_inline)) -> T { if constexpr (SIMG) return si_[comp * 16]; else return LDU(a.q, comp); };         \
+  auto ldv = [&](int comp) __attribute__((always_inline)) -> T { if constexpr (SIMG) return si_[(SIMG_V + comp) * 16]; else return LDU(a.v, comp); }; \
+  (void)ldq; (void)ldv;
+#define LDQJ(k_) (SIMG ? si_[(7 + jx[k_]) * 16] : LDX(a.q, 7, jxN[k_]))
+#define LDVJ(k_) (SIMG ? si_[(SIMG_V + 6 + jx[k_]) * 16] : LDX(a.v, 6, jxN[k_]))
 #define CS(i) cst[(i) * 4 + leg]
 #define LDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define LDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
@@ -168,11 +178,12 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   const T* cst = EXT ? cst_ext : cst_own;
   const int* zidx_s = EXT ? zidx_ext : zidx_own;
   WBC_ADDR_MACROS
+  WBC_STATE_MACROS
   const bool direct = hand == nullptr;   // (a literal at every call site: folded)
 
   T qq[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) qq[c] = LDU(a.q, 3 + c);
+  for (int c = 0; c < 4; ++c) qq[c] = ldq(3 + c);
   int jx[3];
   unsigned jxN[3];
   jidx_of_leg(model, a.jpack, leg, jx);
@@ -180,7 +191,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   for (int k = 0; k < 3; ++k) jxN[k] = (unsigned)jx[k] * N32;
   T ql[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) ql[k] = LDX(a.q, 7, jxN[k]);
+  for (int k = 0; k < 3; ++k) ql[k] = LDQJ(k);
   if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
 
   // structural zeros / ones first: they drain while the sweeps compute (ZEROS = false: other wavefronts write them)
@@ -304,9 +315,9 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
     STL(a.Jc, 1 * 18 + 3, 54, -dw.z); STL(a.Jc, 1 * 18 + 5, 54, dw.x);
     STL(a.Jc, 2 * 18 + 3, 54, dw.y);  STL(a.Jc, 2 * 18 + 4, 54, -dw.x);
     if (a.pf) {
-      STL(a.pf, 0, 3, LDU(a.q, 0) + dw.x);
-      STL(a.pf, 1, 3, LDU(a.q, 1) + dw.y);
-      STL(a.pf, 2, 3, LDU(a.q, 2) + dw.z);
+      STL(a.pf, 0, 3, ldq(0) + dw.x);
+      STL(a.pf, 1, 3, ldq(1) + dw.y);
+      STL(a.pf, 2, 3, ldq(2) + dw.z);
     }
   } else { hl[33 * 64] = dw.x; hl[34 * 64] = dw.y; hl[35 * 64] = dw.z; }
   {
@@ -357,9 +368,9 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
       STL(a.Jc, 1 * 18 + 3, 54, -dz); STL(a.Jc, 1 * 18 + 5, 54, dx);
       STL(a.Jc, 2 * 18 + 3, 54, dy);  STL(a.Jc, 2 * 18 + 4, 54, -dx);
       if (a.pf) {
-        STL(a.pf, 0, 3, LDU(a.q, 0) + dx);
-        STL(a.pf, 1, 3, LDU(a.q, 1) + dy);
-        STL(a.pf, 2, 3, LDU(a.q, 2) + dz);
+        STL(a.pf, 0, 3, ldq(0) + dx);
+        STL(a.pf, 1, 3, ldq(1) + dy);
+        STL(a.pf, 2, 3, ldq(2) + dz);
       }
       const T tm = hl[36 * 64], hwx = hl[37 * 64], hwy = hl[38 * 64], hwz = hl[39 * 64];
       T* M = a.M;
@@ -418,15 +429,16 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 #define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
 #define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
 
+  WBC_STATE_MACROS
   T qq[4], vb[6];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) qq[c] = LDU(a.q, 3 + c);
+  for (int c = 0; c < 4; ++c) qq[c] = ldq(3 + c);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) vb[c] = LDU(a.v, c);
+  for (int c = 0; c < 6; ++c) vb[c] = ldv(c);
   T qpos[3] = {0, 0, 0};   // base position for pf: requested with the rest (loaded where it is used it exposed a memory latency)
   if (WPF && a.pf) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) qpos[c] = LDU(a.q, c);
+    for (int c = 0; c < 3; ++c) qpos[c] = ldq(c);
   }
   int jx[3];
   unsigned jxN[3];
@@ -435,7 +447,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   for (int k = 0; k < 3; ++k) jxN[k] = (unsigned)jx[k] * N32;
   T ql[3], vl[3], al[3] = {0, 0, 0}, ad[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { ql[k] = LDX(a.q, 7, jxN[k]); vl[k] = LDX(a.v, 6, jxN[k]); }
+  for (int k = 0; k < 3; ++k) { ql[k] = LDQJ(k); vl[k] = LDVJ(k); }
   // The references: requested with the state -- unless somebody has to be waited for first (before_refs is a real hook:
   // the planner role of the tracking rollout), in which case the lever arms, which need q only, go out before that wait.
   constexpr bool LATE_REFS = EARLY && !std::is_same<BeforeRefs, NoWait>::value;

@@ -193,20 +193,40 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
 // WARM: every tick after the first starts its QPs from the previous tick's active set, carried in a register of the QP wavefronts
 // (wbc_solver_options.rollout_warm; the QP body of these instantiations is the block set-up of qp_struct16.hip.hpp for EVERY tick --
 // tick 0 from the empty set, or from qa.aset_in when the caller continues an earlier rollout).
+// WBC_RO_MERGE_OBS (four-wavefront layout of the 4-state workgroups, see MERGE below): where the observer's rows run -- 1: one pass over both sets of rows on
+// wavefront 3; 2: base rows, then joint rows, on wavefront 3; 3: base rows on wavefront 3, joint rows on a FIFTH wavefront (which shares SIMD 0 with the QP's,
+// and takes the kernel back to 256 registers per wavefront)
+#ifndef WBC_RO_MERGE_OBS
+#define WBC_RO_MERGE_OBS 1
+#endif
+__host__ __device__ constexpr int rollout_threads(bool observer, int spw) {
+  return (spw == 4 && WBC_RO_MERGE != 0) ? ((observer && WBC_RO_MERGE_OBS == 3) ? 320 : 256) : (observer ? 512 : 448);
+}
 template <class T, bool OBSERVER, bool TRACK, int SPW = 16, bool WARM = false>
-__global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
+__global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
                                                                          SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap, IntegrateArgs<T> ia,
                                                                          int horizon, const DevRefParams<T>* __restrict__ G, RefArgs<T> ra) {
   __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready, gready, oready, mready, rready;
+  __shared__ int ready, gready, oready, mready, rready, fready;
   __shared__ int rpack;   // (QpSync::rp_ack: QP wavefronts that have read r_prev in this tick, counted over the ticks)
+  // MERGE (round 5, 4-state workgroups): FOUR wavefronts instead of eight -- one per SIMD, so each may use the SIMD's whole register file (512 with the
+  // accumulation registers: the 8-wavefront kernel sat at 256 and spilled into the tick's critical phases) -- and the tick's critical chain on ONE of them:
+  //   wavefront 0  [planner,] QP, then the integrator's phase 2 right behind the torque map: no barrier and no trip through memory between them
+  //   wavefront 1  rnea role        wavefront 2  mass_jac role, then the integrator's phase 1 on its own image        wavefront 3  observer: base rows, then joint rows
+  // One barrier per tick (the state of the next one) instead of two; q and v stay in an LDS image (device_types.hpp, SIMG_*) from tick to tick.
+  constexpr bool MERGE = SPW == 4 && WBC_RO_MERGE != 0;
+  // (MERGE) the observer wavefront runs the WHOLE update in one pass (PART 0: both sets of rows share the sweeps) instead of the base rows and then the joint
+  // rows as two passes (-DWBC_RO_MERGE_OBS=2: measured, the joint rows then arrive behind the rnea role and the fp64 tick waits for them -- 11.8 against
+  // 11.1 us per tick for the eight-wavefront layout; profiles/r05o_ab_rollout_merge.log)
+  constexpr bool OBS_ONE = MERGE && WBC_RO_MERGE_OBS == 1;
+  constexpr bool OBS_FIFTH = MERGE && OBSERVER && FUSED_OBS_WAVES == 2 && WBC_RO_MERGE_OBS == 3;
   constexpr bool SPEC_ORDER = OBSERVER && !WARM && WBC_QP_SPEC != 0 && WBC_SPEC_ORDER != 0;
   constexpr int QP_WAVES = SPW / 4;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; rpack = 0; }
+  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; fready = 0; rpack = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   // -DWBC_RO_PRIO=1: the rnea role -- the chain a rollout tick waits for (tools/ro_knock.sh) -- at a higher issue priority than QP wavefront 0, its SIMD-mate
@@ -214,7 +234,8 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #define WBC_RO_PRIO 0
 #endif
   if constexpr (WBC_RO_PRIO != 0) { if (wave == 4) __builtin_amdgcn_s_setprio(3); }
-  constexpr int WINT = OBSERVER ? 7 : 6;   // the integrator wavefront
+  constexpr int WINT = MERGE ? -1 : (OBSERVER ? 7 : 6);   // the integrator wavefront (MERGE: none -- phase 1 on the mass_jac wavefront, phase 2 on the QP's)
+  constexpr int W_RNEA = MERGE ? 1 : 4, W_MJ = MERGE ? 2 : 5, W_OBS = MERGE ? 3 : 6;
   // Workgroups of 4 states (SPW = 4) use QP wavefront 0 only; wavefronts 1..3 idle through the kernel and can take the two roles the
   // integrator wavefront runs in front of its factorisation: the observer's joint rows (WBC_RO_JOINT_WAVE) and the planner (WBC_RO_PLAN_WAVE).
   // -1 = the integrator wavefront keeps the role (always so with 16 states per workgroup).  Measured placements: docs/DESIGN_R04.md 8.0a; round 5: DESIGN.md 4.7.
@@ -233,10 +254,11 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #ifndef WBC_RO_H_WAVE
 #define WBC_RO_H_WAVE -1   // measured (profiles/r05b_ab_rollout_*.log): wavefront 2: 12.26 -> 12.67 us per tick at 1 024 robots, wavefront 1: 12.83 -- not kept
 #endif
-  constexpr int H_WAVE = (SPW == 4) ? WBC_RO_H_WAVE : -1;
-  constexpr int INT_WAVE = (SPW == 4) ? WBC_RO_INT_WAVE : -1;   // the integrator itself on an idle QP wavefront (the aux wavefront keeps the roles not moved)
-  constexpr int JOINT_WAVE = (OBSERVER && FUSED_OBS_WAVES == 2 && SPW == 4) ? WBC_RO_JOINT_WAVE : -1;
-  constexpr int PLAN_WAVE = (TRACK && SPW == 4) ? WBC_RO_PLAN_WAVE : -1;
+  constexpr int H_WAVE = (SPW == 4 && !MERGE) ? WBC_RO_H_WAVE : -1;
+  constexpr int INT_WAVE = (SPW == 4 && !MERGE) ? WBC_RO_INT_WAVE : -1;   // the integrator itself on an idle QP wavefront (the aux wavefront keeps the roles not moved)
+  constexpr int JOINT_WAVE = (OBSERVER && FUSED_OBS_WAVES == 2 && SPW == 4 && !MERGE) ? WBC_RO_JOINT_WAVE : -1;
+  constexpr int PLAN_WAVE = (TRACK && SPW == 4) ? (MERGE ? 0 : WBC_RO_PLAN_WAVE) : -1;   // (MERGE: in front of the QP, whose first input -- the lever arms -- the rnea role
+                                                                                         // publishes only after it has waited for these references)
   T* const traj0 = ia.tau_traj;
   T* const com0 = ra.com;
   // (WARM) the active set of each of the workgroup's states, from tick to tick: one LDS word per state, read and written by the state's own
@@ -263,8 +285,19 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
 #ifndef WBC_RO_RES_LDS
 #define WBC_RO_RES_LDS 1
 #endif
-  constexpr bool RES_LDS = WBC_RO_RES_LDS == 2 || (WBC_RO_RES_LDS == 1 && sizeof(T) == 4);
-  __shared__ T fact_sh[WBC_RO_SPLIT_INT ? INT_FACT_WORDS * 64 : 1];   // the integrator's phase 1 -> phase 2 hand-over (integrate.hip.hpp, PHASE)
+  constexpr bool RES_LDS = MERGE || WBC_RO_RES_LDS == 2 || (WBC_RO_RES_LDS == 1 && sizeof(T) == 4);
+  constexpr bool SPLIT_INT = MERGE || WBC_RO_SPLIT_INT != 0;
+  __shared__ T fact_sh[SPLIT_INT ? INT_FACT_WORDS * 64 : 1];   // the integrator's phase 1 -> phase 2 hand-over (integrate.hip.hpp, PHASE)
+  __shared__ T st_sh[MERGE ? SIMG_WORDS * 16 : 1];             // (MERGE) the workgroup's states
+  if constexpr (MERGE) {
+    for (int i = threadIdx.x; i < SIMG_WORDS * 16; i += blockDim.x) {
+      const int comp = i >> 4, slot = i & 15;
+      size_t st = (size_t)blockIdx.x * SPW + (slot < SPW ? slot : 0);
+      st = st < a.N ? st : a.N - 1;
+      st_sh[i] = comp < SIMG_V ? a.q[(size_t)comp * a.N + st] : a.v[(size_t)(comp - SIMG_V) * a.N + st];
+    }
+    if constexpr (!RES_LDS) __syncthreads();
+  }
   __shared__ T res_sh[RES_LDS ? (RES_WORDS + 18) * 16 : 1];   // (+ 18 rows: the external torques of the workgroup's states, parked once)
   T* const res_img = RES_LDS ? res_sh : nullptr;
   if constexpr (RES_LDS) {
@@ -300,6 +333,11 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     QpArgs<T> qat = qa;
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
+    at.simg = st_sh; iat.simg = st_sh;
+#ifndef WBC_RO_SKIP_STATE
+#define WBC_RO_SKIP_STATE 1   // 0: every tick stores its q, v (A/B)
+#endif
+    iat.skip_state = (MERGE && WBC_RO_SKIP_STATE && t < horizon - 1) ? 1 : 0;   // q, v of the LAST tick are what the caller finds (the roles read the LDS image)
 #ifndef WBC_RO_SKIP_MATS
 #define WBC_RO_SKIP_MATS 1   // 0: every tick stores its M / Jc / pf (A/B)
 #endif
@@ -319,6 +357,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       if constexpr (TRACK) {
         RefArgs<T> rt = ra;
         rt.N = (size_t)n_tick;
+        rt.simg = st_sh;
         rt.t = (T)t * prm.dt + ra.t;
         rt.com = com0 ? com0 + (size_t)t * 6 * (size_t)n_tick : nullptr;
         com_reference_body<T, true, SPW>(model, G, rt, cst);
@@ -338,21 +377,21 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
     auto integrator_role = [&]() __attribute__((always_inline)) {
       // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has handed them over
       // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
-      if constexpr (!WBC_RO_SPLIT_INT) {
+      if constexpr (!SPLIT_INT) {
         while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       }
       iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
-      constexpr int PH = WBC_RO_SPLIT_INT ? 2 : 0;
+      constexpr int PH = SPLIT_INT ? 2 : 0;
 #ifdef WBC_FUSED_STAMP
       iat.istamp = rstamp; iat.istampN = rstampN;
       RSTAMP(9);   // factorisation can start (M, Jc handed over; the roles in front of it on this wavefront are done)
       auto betw = [=] __device__() { RSTAMP(2); barrier_A(); RSTAMP(7); };   // (2, WBC_RO_STAMP_ALT: this wavefront is at the tick barrier)
-      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0)>(model, iat, betw, mj_hand, res_img, fact_sh);
+      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0), true, RES_LDS>(model, iat, betw, mj_hand, res_img, fact_sh);
       RSTAMP(8);
 #else
       auto betw = [=] __device__() { barrier_A(); };
-      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0)>(model, iat, betw, mj_hand, res_img, fact_sh);   // <- barrier A inside
+      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0), true, RES_LDS>(model, iat, betw, mj_hand, res_img, fact_sh);   // <- barrier A inside
 #endif
       __syncthreads();                                                       // barrier B: q, v of the next tick
     };
@@ -371,7 +410,7 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       if constexpr (INT_WAVE < 0) { integrator_role(); continue; }
       else { barrier_A(); __syncthreads(); continue; }
     }
-    if (wave == 4) {
+    if (wave == W_RNEA) {
       int* const rflag = &rready;
       const int rneed = t + 1;
       int* const gflag = &gready;
@@ -392,8 +431,9 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       RSTAMP(3);   // (WBC_RO_STAMP_ALT) rnea: done
-    } else if (wave == 5) {
+    } else if (wave == W_MJ) {
       int* const mflag = &mready;
+      int* const fflag = &fready;
       T* const factp = fact_sh;
       T* const handp = mj_hand;
       const IntegrateArgs<T> ia1 = iat;
@@ -403,12 +443,16 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         RSTAMP(1);   // (WBC_RO_STAMP_ALT) mass_jac: image published
         // phase 1 of the integrator, on my own image (my own LDS words: program order of one lane); the factors are complete when this wavefront
         // reaches the tick barrier, behind which the integrator wavefront reads them
-        if constexpr (WBC_RO_SPLIT_INT != 0) integrate_body<T, SPW, IntegrateNoWait, 1, (WBC_RO_INT_UNGUARD != 0)>(model, ia1, IntegrateNoWait(), handp, nullptr, factp);
+        if constexpr (SPLIT_INT) integrate_body<T, SPW, IntegrateNoWait, 1, (WBC_RO_INT_UNGUARD != 0), true, false>(model, ia1, IntegrateNoWait(), handp, nullptr, factp);
+        if constexpr (MERGE) {   // the factors are in LDS: wavefront 0 may start phase 2
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(fflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       };
       // (the M / Jc / pf stores to HBM come BEHIND the flag, from the image, and only in the launch's last tick: nothing in this kernel reads them)
       if constexpr ((WBC_RO_KNOCK & 4) != 0) publish();
       else mass_jac_body<T, 64, 1, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
-    } else if (OBSERVER && wave == 6) {
+    } else if (OBSERVER && wave == W_OBS) {
       if constexpr (OBSERVER) {
         int* const ack = &rpack;
         const int ack_need = QP_WAVES * (t + 1);
@@ -416,15 +460,29 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         auto wait_ack = [ack, ack_need, ack_on] __device__() {
           if constexpr (SPEC_ORDER) { if (ack_on) { while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ack_need) __builtin_amdgcn_s_sleep(1); } }
         };
+        if constexpr (OBS_ONE) {   // one pass over both sets of rows; rhat_base is handed to the QP as soon as it exists, the joint rows count as a finisher
+          int* const oflag = &oready;
+          int* const jflag = &ready;
+          auto rows_out = [oflag, jflag] __device__(int stage) {   // 0: rhat_base is in the image, 1: rhat_joint is
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(stage == 0 ? oflag : jflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          };
+          observer_body<T, 64, 1, 0, SPW, decltype(wait_ack), decltype(rows_out)>(model, prm, at, cst, wsl, wait_ack, rows_out);
+          RSTAMP(10);
+        } else {
         if constexpr ((WBC_RO_KNOCK & 8) != 0) {}
         else if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
         else observer_body<T, 64, 1, 0, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         RSTAMP(10);
+        }
+        if constexpr (MERGE && FUSED_OBS_WAVES == 2 && !OBS_ONE && !OBS_FIFTH) joint_rows_role();   // (-DWBC_RO_MERGE_OBS=2) ... then the joint rows, which the torque map needs ~3 us later
       }
+    } else if (OBS_FIFTH && wave == 4) {
+      joint_rows_role();
     } else {
-      constexpr int NFIN = (OBSERVER && FUSED_OBS_WAVES == 2) ? 2 : 1;   // rnea role (+ the observer's joint rows, run by the integrator wavefront)
+      constexpr int NFIN = (OBSERVER && (FUSED_OBS_WAVES == 2 || OBS_ONE)) ? 2 : 1;   // rnea role (+ the observer's joint rows, run by the integrator wavefront)
 #ifdef WBC_FUSED_STAMP
       QpSync sy{&gready, &oready, &ready, 2 * t + 1, 2 * t + 2, t + 1, NFIN * (t + 1), rstamp, rstampN};
 #else
@@ -441,7 +499,21 @@ __global__ __launch_bounds__(OBSERVER ? 512 : 448, 1) void rollout_kernel(const 
         if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_sh[(threadIdx.x & 255) >> 4]);
       } else
       if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
+      if constexpr (MERGE) {
+        if (wave == 0) {   // phase 2 of the integrator, on the wavefront that has just written tau and f to the LDS image (its own LDS traffic: program order)
+          while (__hip_atomic_load(&fready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);   // M's blocks and the factors
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+          iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
+#ifdef WBC_FUSED_STAMP
+          iat.istamp = rstamp; iat.istampN = rstampN;
+          RSTAMP(7);   // phase 2 starts (the factors are there)
+#endif
+          integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true>(model, iat, IntegrateNoWait(), mj_hand, res_img, fact_sh);
+          RSTAMP(8);
+        }
+      }
     }
+    if constexpr (MERGE) { __syncthreads(); continue; }   // the tick's only barrier: the new state (LDS image), tau, f (memory: the next tick's observer reads them)
     barrier_A();       // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator (round 5: in LDS)
     __syncthreads();   // barrier B: q, v of the next tick -- and this tick's tau, f, h in memory (the next tick's observer role reads tau, f as tau_prev, f_prev)
   }

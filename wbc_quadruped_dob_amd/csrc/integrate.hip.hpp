@@ -39,10 +39,15 @@ constexpr int INT_FACT_WORDS = 27;
 #ifndef WBC_INT_SINV
 #define WBC_INT_SINV 0   // measured (profiles/r05i_ab_rollout_phase2_*.log): 12.05 -> 12.22 us per tick in fp64, and the fp32 inverse loses the accuracy the
 #endif                 // fp32 rollout tests ask for (NaN on stiff states): not kept
-template <class T, int SPW = 16, class Between = IntegrateNoWait, int PHASE = 0, bool UNGUARD = false>
-WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between(), const T* hand = nullptr,
-                            const T* res = nullptr, T* fact = nullptr) {
+// HAND / RESI: `hand` / `res` are given (template parameters, not null tests: a pointer that may be an LDS image or null turns every load behind it into a
+// flat_load -- 39 of them in the round-4 rollout kernels, 30 in phase 2 -- where the image wants a ds_read).
+template <class T, int SPW = 16, class Between = IntegrateNoWait, int PHASE = 0, bool UNGUARD = false, bool HAND = false, bool RESI = false>
+WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between(), const T* hand_ = nullptr,
+                            const T* res_ = nullptr, T* fact = nullptr) {
   static_assert(PHASE == 0 || PHASE == 1 || PHASE == 2, "phase");
+  static_assert(PHASE == 0 || HAND, "the split phases hand M's blocks over in LDS");
+  const T* const hand = HAND ? hand_ : nullptr;
+  const T* const res = RESI ? res_ : nullptr;
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   unsigned tx = threadIdx.x;
@@ -68,8 +73,8 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   ISTAMP(0);
 
   // ================================================================== phase 1: M, Jc only
-  const T* hl = hand ? hand + (int)(tx & 63) : nullptr;
-  T* const fl_ = fact ? fact + (int)(tx & 63) : nullptr;
+  const T* hl = HAND ? hand + (int)(tx & 63) : nullptr;
+  T* const fl_ = PHASE != 0 ? fact + (int)(tx & 63) : nullptr;
   V3<T> dl;
   T jcl[3][3];   // own-leg Jacobian block: jcl[m][k] = d pf_m / d q_(leg, k)
   T Mb[6][3];    // base-leg block (6x3) of M
@@ -77,18 +82,18 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   T L[6][6];     // Cholesky factor of the base Schur complement (L[j][j] holds 1 / L_jj)
   auto load_blocks = [&]() __attribute__((always_inline)) {
     // foot position relative to the base origin from the base-angular block of my foot's Jacobian rows, -[d]x
-    dl = hand ? mk<T>(hl[33 * 64], hl[34 * 64], hl[35 * 64])
+    dl = HAND ? mk<T>(hl[33 * 64], hl[34 * 64], hl[35 * 64])
               : mk<T>(LDL(a.Jc, 18 * 1 + 5, 54), LDL(a.Jc, 18 * 2 + 3, 54), LDL(a.Jc, 18 * 0 + 4, 54));
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const unsigned jo = (unsigned)(6 + jx[k]) * N32;   // column of joint (leg, k) in rows 3*leg + m of Jc
-      if (hand) { jcl[0][k] = hl[(24 + k) * 64]; jcl[1][k] = hl[(27 + k) * 64]; jcl[2][k] = hl[(30 + k) * 64]; }
+      if constexpr (HAND) { jcl[0][k] = hl[(24 + k) * 64]; jcl[1][k] = hl[(27 + k) * 64]; jcl[2][k] = hl[(30 + k) * 64]; }
       else { jcl[0][k] = LDLX(a.Jc, 0, 54, jo); jcl[1][k] = LDLX(a.Jc, 18, 54, jo); jcl[2][k] = LDLX(a.Jc, 36, 54, jo); }
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Mb[r][k] = hand ? hl[(6 + 3 * r + k) * 64] : LDV(a.M, midx18(r, r) + (6 + jx[k] - r));
+      for (int k = 0; k < 3; ++k) Mb[r][k] = HAND ? hl[(6 + 3 * r + k) * 64] : LDV(a.M, midx18(r, r) + (6 + jx[k] - r));
   };
   if constexpr (PHASE != 2) {
   load_blocks();
@@ -99,12 +104,12 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   for (int k1 = 0; k1 < 3; ++k1)
 #pragma unroll
     for (int k2 = k1; k2 < 3; ++k2) {
-      Ml[k1][k2] = hand ? hl[(k1 * 3 - k1 * (k1 - 1) / 2 + (k2 - k1)) * 64] : LDV(a.M, mi(6 + jx[k1], 6 + jx[k2]));
+      Ml[k1][k2] = HAND ? hl[(k1 * 3 - k1 * (k1 - 1) / 2 + (k2 - k1)) * 64] : LDV(a.M, mi(6 + jx[k1], 6 + jx[k2]));
       Ml[k2][k1] = Ml[k1][k2];
     }
   // base block of M (upper triangle): from the buffer, or rebuilt from (m, R h, R I R^T) of the hand-over image
   T Mbb[6][6];
-  if (hand) {
+  if constexpr (HAND) {
     const T tm = hl[36 * 64], hx = hl[37 * 64], hy = hl[38 * 64], hz = hl[39 * 64];
     const T Z = (T)0;
     Mbb[0][0] = tm; Mbb[0][1] = Z; Mbb[0][2] = Z; Mbb[0][3] = Z; Mbb[0][4] = hz; Mbb[0][5] = -hy;
@@ -199,14 +204,19 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   ISTAMP(4);   // Cholesky done
   // the state of this tick (q, v: inputs of the tick, untouched until the stores at the end) is requested BEFORE the tick barrier: the loads
   // complete while the wavefront waits there instead of after it
+  // (4-state rollout workgroups, WBC_RO_MERGE: the state lives in the workgroup's LDS image -- device_types.hpp, SIMG_* -- and the new one goes to both)
+  constexpr bool SIMG = PHASE == 2 && SPW == 4 && WBC_RO_MERGE != 0;
+  T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
+#define STS(comp, val) do { if constexpr (SIMG) si_[(comp) * 16] = (val); } while (0)
+  const bool to_mem = !(SIMG && a.skip_state != 0);   // (wavefront-uniform: a kernel argument) the state in memory is read by nobody before the launch ends
   T ql[3], vl[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { ql[k] = LDV(a.q, 7 + jx[k]); vl[k] = LDV(a.v, 6 + jx[k]); }
+  for (int k = 0; k < 3; ++k) { ql[k] = SIMG ? si_[(7 + jx[k]) * 16] : LDV(a.q, 7 + jx[k]); vl[k] = SIMG ? si_[(SIMG_V + 6 + jx[k]) * 16] : LDV(a.v, 6 + jx[k]); }
   T vb0[6], qb[7];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) vb0[c] = LDU(a.v, c);
+  for (int c = 0; c < 6; ++c) vb0[c] = SIMG ? si_[(SIMG_V + c) * 16] : LDU(a.v, c);
 #pragma unroll
-  for (int c = 0; c < 7; ++c) qb[c] = LDU(a.q, c);
+  for (int c = 0; c < 7; ++c) qb[c] = SIMG ? si_[c * 16] : LDU(a.q, c);
 
   // (so is the unit quaternion of the state: a square root and a division of ~0.2 us for a lone wavefront, which used to sit behind the barrier)
   // Three shortenings of phase 2 (round 5), each 1 = fp32 only (default), 2 = both scalar types, 0 = off.  Measured at 1 024 rollouts
@@ -238,7 +248,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   }
   ISTAMP(5);   // barrier passed
   // (the image is indexed by the slot of the state a lane COMPUTES: a lane beyond the workgroup's states duplicates state s32, and with UNGUARD it stores)
-  const T* rs = res ? res + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
+  const T* rs = RESI ? res + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
   if constexpr (PHASE == 2) {   // M's blocks from the mass_jac role's image, the factors from the image phase 1 left (both complete behind the barrier)
     load_blocks();
     A[0][0] = fl_[0 * 64]; A[0][1] = A[1][0] = fl_[1 * 64]; A[0][2] = A[2][0] = fl_[2 * 64]; A[1][1] = fl_[3 * 64]; A[1][2] = A[2][1] = fl_[4 * 64]; A[2][2] = fl_[5 * 64];
@@ -249,17 +259,17 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   }
   // the external torques: rows RES_WORDS .. RES_WORDS + 17 of the image hold them for the whole launch (parked once by the rollout kernel: fetched per
   // tick in front of the barrier they cost 18 registers across it -- and scratch), or the caller's buffer
-  auto text = [&](int comp) __attribute__((always_inline)) -> T { return rs ? rs[(42 + comp) * 16] : (a.tau_ext ? LDV(a.tau_ext, comp) : (T)0); };
+  auto text = [&](int comp) __attribute__((always_inline)) -> T { if constexpr (RESI) return rs[(42 + comp) * 16]; else return a.tau_ext ? LDV(a.tau_ext, comp) : (T)0; };
 
   // ================================================================== phase 2: tau, f, h, q, v
   // ---- my leg: rhs_l = tau_l + JcL^T f_l + tau_ext_l - h_l
-  const V3<T> fl = rs ? mk<T>(rs[(12 + 3 * leg + 0) * 16], rs[(12 + 3 * leg + 1) * 16], rs[(12 + 3 * leg + 2) * 16])
+  const V3<T> fl = RESI ? mk<T>(rs[(12 + 3 * leg + 0) * 16], rs[(12 + 3 * leg + 1) * 16], rs[(12 + 3 * leg + 2) * 16])
                       : mk<T>(LDL(a.f, 0, 3), LDL(a.f, 1, 3), LDL(a.f, 2, 3));
   T rl[3], taul[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    taul[k] = rs ? rs[jx[k] * 16] : LDV(a.tau, jx[k]);
-    const T hl_k = rs ? rs[(24 + 6 + jx[k]) * 16] : LDV(a.h, 6 + jx[k]);
+    taul[k] = RESI ? rs[jx[k] * 16] : LDV(a.tau, jx[k]);
+    const T hl_k = RESI ? rs[(24 + 6 + jx[k]) * 16] : LDV(a.h, 6 + jx[k]);
     rl[k] = taul[k] + jcl[0][k] * fl.x + jcl[1][k] * fl.y + jcl[2][k] * fl.z - hl_k + text(6 + jx[k]);
   }
   ISTAMP(6);   // tau, f, h arrived: leg right-hand side
@@ -281,7 +291,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
         for (int k = 0; k < 3; ++k) Wr[k] = Mb[r][0] * A[0][k] + Mb[r][1] * A[1][k] + Mb[r][2] * A[2][k];
         part = own[r] - (Wr[0] * rl[0] + Wr[1] * rl[1] + Wr[2] * rl[2]);
       }
-      rb[r] = xrow_sum(part) - (rs ? rs[(24 + r) * 16] : LDU(a.h, r)) + text(r);
+      rb[r] = xrow_sum(part) - (RESI ? rs[(24 + r) * 16] : LDU(a.h, r)) + text(r);
     }
   }
   ISTAMP(7);   // base right-hand side summed
@@ -332,8 +342,13 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const T vn = vl[k] + dt * vdl[k];
-    STV(a.v, 6 + jx[k], vn);
-    STV(a.q, 7 + jx[k], ql[k] + dt * vn);
+    const T qjn = ql[k] + dt * vn;
+    STS(SIMG_V + 6 + jx[k], vn);
+    STS(7 + jx[k], qjn);
+    if (to_mem) {
+      STV(a.v, 6 + jx[k], vn);
+      STV(a.q, 7 + jx[k], qjn);
+    }
     if (a.tau_traj) STV(a.tau_traj, jx[k], taul[k]);
   }
   ISTAMP(9);   // joint rows stored
@@ -380,12 +395,21 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   // the 13 base words are replicated over the four leg rows: every row stores its share.  All rows have read
   // q/v base rows above (their values feed these stores), so no lane can store before every lane has loaded.
   ISTAMP(10);   // quaternion advanced
-  STV(a.v, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, vbn[0], vbn[1], vbn[2], vbn[3]));
-  if (leg < 2) STV(a.v, 4 + leg, leg == 0 ? vbn[4] : vbn[5]);
-  STV(a.q, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, qn[0], qn[1], qn[2], qn[3]));
-  if (leg < 3) STV(a.q, 4 + leg, sel4<T>(leg, qn[4], qn[5], qn[6], qn[6]));
+  if constexpr (SIMG) {   // (every row holds all 13 base words: row `leg` writes its share, as to memory)
+    STS(SIMG_V + sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, vbn[0], vbn[1], vbn[2], vbn[3]));
+    if (leg < 2) STS(SIMG_V + 4 + leg, leg == 0 ? vbn[4] : vbn[5]);
+    STS(sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, qn[0], qn[1], qn[2], qn[3]));
+    if (leg < 3) STS(4 + leg, sel4<T>(leg, qn[4], qn[5], qn[6], qn[6]));
+  }
+  if (to_mem) {
+    STV(a.v, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, vbn[0], vbn[1], vbn[2], vbn[3]));
+    if (leg < 2) STV(a.v, 4 + leg, leg == 0 ? vbn[4] : vbn[5]);
+    STV(a.q, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, qn[0], qn[1], qn[2], qn[3]));
+    if (leg < 3) STV(a.q, 4 + leg, sel4<T>(leg, qn[4], qn[5], qn[6], qn[6]));
+  }
   ISTAMP(11);   // base rows stored
 #undef ISTAMP
+#undef STS
 #undef STV
 #undef LDLX
 #undef LDL

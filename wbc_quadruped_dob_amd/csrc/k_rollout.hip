@@ -14,9 +14,11 @@ namespace wbc {
 hipError_t rollout_plain(WBC_ROLLOUT_ARGS);
 hipError_t rollout_track(WBC_ROLLOUT_ARGS);
 
+// (4-state workgroups are four wavefronts since round 5: WBC_RO_MERGE, fused_tick.hip.hpp)
+#define WBC_ROLLOUT_THREADS(OB_, SPW_) rollout_threads(OB_, SPW_)
 #define WBC_ROLLOUT(OB_, SPW_) \
-  do { if (warm) WBC_KLAUNCH(L, (rollout_kernel<T, OB_, (WBC_ROLLOUT_TRACK != 0), SPW_, true>), grid, dim3(OB_ ? 512 : 448), model, prm, a, qa, jmap, ia, horizon, G, ra); \
-       else WBC_KLAUNCH(L, (rollout_kernel<T, OB_, (WBC_ROLLOUT_TRACK != 0), SPW_, false>), grid, dim3(OB_ ? 512 : 448), model, prm, a, qa, jmap, ia, horizon, G, ra); } while (0)
+  do { if (warm) WBC_KLAUNCH(L, (rollout_kernel<T, OB_, (WBC_ROLLOUT_TRACK != 0), SPW_, true>), grid, dim3(WBC_ROLLOUT_THREADS(OB_, SPW_)), model, prm, a, qa, jmap, ia, horizon, G, ra); \
+       else WBC_KLAUNCH(L, (rollout_kernel<T, OB_, (WBC_ROLLOUT_TRACK != 0), SPW_, false>), grid, dim3(WBC_ROLLOUT_THREADS(OB_, SPW_)), model, prm, a, qa, jmap, ia, horizon, G, ra); } while (0)
 
 #if WBC_ROLLOUT_TRACK
 hipError_t rollout_track(WBC_ROLLOUT_ARGS) {

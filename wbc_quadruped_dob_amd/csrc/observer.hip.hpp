@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
+#include <type_traits>
 #include "dyn_sweep.hip.hpp"
 
 namespace wbc {
@@ -30,13 +31,19 @@ namespace wbc {
 // and 2 side by side share the sweeps' arithmetic but each drops the other's projections and update.
 // `before_store()` (roles) runs right before the base rows of {integ, r} are stored: the fused kernels wait there until the QP wavefronts
 // have read r_prev (QpSync::rp_ack) -- normally long past by then.
-struct ObsNoWait { WBC_DEV void operator()() const {} };
-template <class T, int BLOCK, int EXT, int PART = 0, int SPW = 16, class BeforeStore = ObsNoWait>
+// `after_base(stage)` (PART 0 as the ONE observer wavefront of a 4-state rollout workgroup, round 5): called with 0 as soon as rhat_base is in the LDS image
+// -- the QP waits for nothing else of this role until its torque map and starts ~1.2 us earlier than behind the whole body -- and with 1 when rhat_joint is;
+// the new observer state goes to memory behind both.  With the hook the observer state {f_prev, r, integ, tau_prev} is requested at the head of the body, with q and v (24
+// values more in flight across the sweeps: the four-wavefront rollout kernel has the registers), instead of where the update needs it.
+struct ObsNoWait { WBC_DEV void operator()() const {} WBC_DEV void operator()(int) const {} };
+template <class T, int BLOCK, int EXT, int PART = 0, int SPW = 16, class BeforeStore = ObsNoWait, class AfterBase = ObsNoWait>
 WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext, T* wsl,
-                           BeforeStore before_store = BeforeStore()) {
+                           BeforeStore before_store = BeforeStore(), AfterBase after_base = AfterBase()) {
   static_assert(EXT == 0 || BLOCK == 64, "one wavefront");
   static_assert(PART == 0 || EXT != 0, "split parts exist only as roles");
   constexpr bool BASE = PART != 2, JOINTS = PART != 1;
+  constexpr bool EARLY_BASE = !std::is_same<AfterBase, ObsNoWait>::value;
+  static_assert(!EARLY_BASE || (PART == 0 && EXT != 0), "the early hand-over of rhat_base: whole update, as a role");
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
   const T* cst = EXT ? cst_ext : cst_own;
   unsigned tx = threadIdx.x;
@@ -55,12 +62,14 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 #define OST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) OSTV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<T>(leg, v0_, v1_, v2_, v3_))
   // rhat: HBM workspace (stand-alone kernel) or the workgroup's LDS image (role)
 #define ORHAT(comp, val) do { if constexpr (EXT != 0) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else OSTV(a.ws, comp, val); } while (0)
-  // state loads first, table staging while they are in flight
+  // state loads first, table staging while they are in flight (4-state rollout workgroups: the state is in LDS, see WBC_STATE_MACROS in dyn_split.hip.hpp)
+  constexpr bool SIMG = EXT != 0 && SPW == 4 && WBC_RO_MERGE != 0;
+  const T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
   T qq[4], vb[6];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) qq[c] = OLDU(a.q, 3 + c);
+  for (int c = 0; c < 4; ++c) qq[c] = SIMG ? si_[(3 + c) * 16] : OLDU(a.q, 3 + c);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) vb[c] = OLDU(a.v, c);
+  for (int c = 0; c < 6; ++c) vb[c] = SIMG ? si_[(SIMG_V + c) * 16] : OLDU(a.v, c);
   int jx[3];
   // (the role keeps the table load: its joint-state loads are not on the tick's critical path -- the QP starts on r_prev -- and with the indices in
   // hand two cycles after entry the fp64 observer-on fused tick, which sits at 255 registers, spills a value)
@@ -69,8 +78,26 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   T ql[3], vl[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    ql[k] = OLDV(a.q, 7 + jx[k]);
-    vl[k] = OLDV(a.v, 6 + jx[k]);
+    ql[k] = SIMG ? si_[(7 + jx[k]) * 16] : OLDV(a.q, 7 + jx[k]);
+    vl[k] = SIMG ? si_[(SIMG_V + 6 + jx[k]) * 16] : OLDV(a.v, 6 + jx[k]);
+  }
+  T pre_k1[3] = {0, 0, 0}, pre_k2[3] = {0, 0, 0};
+  T pre_fp[3] = {0, 0, 0}, pre_rb[6] = {0, 0, 0, 0, 0, 0}, pre_igb[6] = {0, 0, 0, 0, 0, 0}, pre_rj[3] = {0, 0, 0}, pre_igj[3] = {0, 0, 0}, pre_tp[3] = {0, 0, 0};
+  if constexpr (EARLY_BASE) {
+    if (prm.observer_order > 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pre_fp[c] = OLDV(a.f_prev, 3 * leg + c);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { pre_rb[c] = OLDU(a.obs_r, c); pre_igb[c] = OLDU(a.obs_integ, c); }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { pre_rj[k] = OLDV(a.obs_r, 6 + jx[k]); pre_igj[k] = OLDV(a.obs_integ, 6 + jx[k]); pre_tp[k] = OLDV(a.tau_prev, jx[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // gains of my joint rows by a select (no run-time index into the kernel arguments), while those loads are in flight
+      pre_k1[k] = prm.K1[6]; pre_k2[k] = prm.K2[6];
+#pragma unroll
+      for (int j = 1; j < 12; ++j) { pre_k1[k] = (jx[k] == j) ? prm.K1[6 + j] : pre_k1[k]; pre_k2[k] = (jx[k] == j) ? prm.K2[6 + j] : pre_k2[k]; }
+    }
   }
   if constexpr (EXT == 0) {
     // branch-free (clamped index, the tail lanes rewrite the last word): with a divergent staging loop here hipcc 7.2 put
@@ -175,6 +202,54 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   }
   // ---- observer update (order 1 or 2) and rhat for the QP kernel
   T rb[6] = {0, 0, 0, 0, 0, 0}, rl[3] = {0, 0, 0};
+  if constexpr (EARLY_BASE) {
+    // the one-wavefront form: everything the QP waits for goes to the LDS image first -- rhat_base, hook(0), rhat_joint, hook(1) -- and only then the new
+    // observer state to memory (14 store instructions of a lone wavefront, ~0.1 us each with their guards)
+    T igj[3] = {0, 0, 0};
+    if (prm.observer_order > 0) {
+      const V3<T> fp = mk<T>(pre_fp[0], pre_fp[1], pre_fp[2]);
+      const T dt = prm.dt;
+      const bool o1 = prm.observer_order == 1;
+      const V3<T> dxf = cross(dw, fp);
+      T ub[6] = {fp.x, fp.y, fp.z, dxf.x, dxf.y, dxf.z};
+      xrow_sum_k<T, 6>(ub);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const T r0 = pre_rb[c];
+        const T ig = pre_igb[c] + dt * (ub[c] + beta_b[c] + r0);
+        const T e = p_b[c] - ig;
+        rb[c] = o1 ? prm.K1[c] * e : r0 + dt * prm.K2[c] * (prm.K1[c] * e - r0);
+        p_b[c] = ig;
+      }
+      ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<T>(leg, rb[0], rb[1], rb[2], rb[3]));
+      if (leg < 2) ORHAT(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
+      after_base(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const T r0 = pre_rj[k];
+        const T u = pre_tp[k] + dot(jw[k], fp);
+        igj[k] = pre_igj[k] + dt * (u + beta_l[k] + r0);
+        const T e = p_leg[k] - igj[k];
+        rl[k] = o1 ? pre_k1[k] * e : r0 + dt * pre_k2[k] * (pre_k1[k] * e - r0);
+        ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
+      }
+      after_base(1);
+      before_store();
+      OST4(a.obs_integ, 0, p_b[0], 1, p_b[1], 2, p_b[2], 3, p_b[3]);
+      if (leg < 2) OSTV(a.obs_integ, 4 + leg, leg == 0 ? p_b[4] : p_b[5]);
+      OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
+      if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { OSTV(a.obs_integ, 6 + jx[k], igj[k]); OSTV(a.obs_r, 6 + jx[k], rl[k]); }
+    } else {   // (observer off in an observer kernel: not launched that way, but the QP must not wait for ever)
+      ORHAT(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), (T)0);
+      if (leg < 2) ORHAT(WS_RHAT + 4 + leg, (T)0);
+      after_base(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, (T)0);
+      after_base(1);
+    }
+  } else {
   if (prm.observer_order > 0) {
     const V3<T> fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
     const T dt = prm.dt;
@@ -221,6 +296,7 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   if constexpr (JOINTS) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) ORHAT(WS_RHAT + 6 + 3 * leg + k, rl[k]);
+  }
   }
 #undef ORHAT
 #undef OST4
