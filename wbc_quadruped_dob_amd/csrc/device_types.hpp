@@ -82,11 +82,16 @@ template <class T> struct SweepArgs {
                               // SGPRs instead of loading DevModel::jidx -- a per-lane global load in FRONT of the joint-state loads, i.e. one
                               // more dependent trip through L2 at the head of every role of every tick (round 5)
   const T* simg;              // (set by the persistent rollout kernel, never by the host) the workgroup's state image in LDS: see WBC_RO_MERGE
+  const T* resimg;            // (likewise) the result image: the observer role of a 4-state workgroup takes tau_prev, f_prev from the rows the QP of the
+                              // previous tick wrote there, instead of from memory
 };
 // The state image of a 4-state rollout workgroup (WBC_RO_MERGE, fused_tick.hip.hpp): q (rows 0 .. 18) and v (19 .. 36) of the workgroup's states,
 // [row][16 slots], in LDS for the whole launch.  The integrator writes the new state there (and to memory); the roles of the next tick read it from
 // there instead of waiting for those stores and a trip through L2 at the head of the tick.
 constexpr int SIMG_V = 19, SIMG_WORDS = 37;
+// The result image of a rollout workgroup (QpSync::res, qp_group16.hip.hpp): this tick's tau (rows 0 .. 11, caller's joint order), f (12 .. 23), h (24 .. 41),
+// [row][16 slots]; rows 42 .. 59 hold the external torques of the workgroup's states for the whole launch.
+constexpr int RES_TAU = 0, RES_F = 12, RES_H = 24, RES_WORDS = 42;
 #ifndef WBC_RO_MERGE
 #define WBC_RO_MERGE 1
 #endif

@@ -307,6 +307,14 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
       st = st < a.N ? st : a.N - 1;
       res_sh[(RES_WORDS + comp) * 16 + slot] = ia.tau_ext ? ia.tau_ext[(size_t)comp * a.N + st] : (T)0;
     }
+    if constexpr (MERGE && OBSERVER) {   // tau_prev, f_prev of the first tick: the caller's; of every later tick: what the QP left in these rows
+      for (int i = threadIdx.x; i < 24 * 16; i += blockDim.x) {
+        const int comp = i >> 4, slot = i & 15;
+        size_t st = (size_t)blockIdx.x * SPW + (slot < SPW ? slot : 0);
+        st = st < a.N ? st : a.N - 1;
+        res_sh[i] = comp < 12 ? (a.tau_prev ? a.tau_prev[(size_t)comp * a.N + st] : (T)0) : (a.f_prev ? a.f_prev[(size_t)(comp - 12) * a.N + st] : (T)0);
+      }
+    }
     __syncthreads();
   }
   auto barrier_A = [] __device__() {
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
     QpArgs<T> qat = qa;
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
-    at.simg = st_sh; iat.simg = st_sh;
+    at.simg = st_sh; iat.simg = st_sh; at.resimg = res_sh;
 #ifndef WBC_RO_SKIP_STATE
 #define WBC_RO_SKIP_STATE 1   // 0: every tick stores its q, v (A/B)
 #endif
@@ -490,6 +498,10 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #endif
       if constexpr (SPEC_ORDER) { if (qa.rprev) sy.rp_ack = &rpack; }
       sy.res = res_img;
+#ifndef WBC_RO_SKIP_OUT
+#define WBC_RO_SKIP_OUT 1   // 0: every tick stores its tau, f, status, iters (A/B)
+#endif
+      sy.skip_out = MERGE && WBC_RO_SKIP_OUT && t < horizon - 1;   // (the LAST tick's are what the caller finds, as with per-tick launches)
       if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, 1, SPW>(model, prm, at, cst, wsl, NoWait(), NoWait(), res_img ? res_img + RES_H * 16 : nullptr); }   // bias forces h
       if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }
       if constexpr (JOINT_WAVE >= 0) { if (wave == JOINT_WAVE) joint_rows_role(); }

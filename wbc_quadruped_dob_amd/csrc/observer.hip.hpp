@@ -86,11 +86,11 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   if constexpr (EARLY_BASE) {
     if (prm.observer_order > 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pre_fp[c] = OLDV(a.f_prev, 3 * leg + c);
+      for (int c = 0; c < 3; ++c) pre_fp[c] = SIMG ? a.resimg[(RES_F + 3 * leg + c) * 16 + (si_ - a.simg)] : OLDV(a.f_prev, 3 * leg + c);
 #pragma unroll
       for (int c = 0; c < 6; ++c) { pre_rb[c] = OLDU(a.obs_r, c); pre_igb[c] = OLDU(a.obs_integ, c); }
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { pre_rj[k] = OLDV(a.obs_r, 6 + jx[k]); pre_igj[k] = OLDV(a.obs_integ, 6 + jx[k]); pre_tp[k] = OLDV(a.tau_prev, jx[k]); }
+      for (int k = 0; k < 3; ++k) { pre_rj[k] = OLDV(a.obs_r, 6 + jx[k]); pre_igj[k] = OLDV(a.obs_integ, 6 + jx[k]); pre_tp[k] = SIMG ? a.resimg[(RES_TAU + jx[k]) * 16 + (si_ - a.simg)] : OLDV(a.tau_prev, jx[k]); }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {   // gains of my joint rows by a select (no run-time index into the kernel arguments), while those loads are in flight

@@ -168,8 +168,10 @@ struct QpSync {
   // order), f (12 .. 23), and -- from the rnea role -- h (24 .. 41).  The integrator takes them from there behind an LDS-only barrier, instead of waiting
   // for the global stores to be acknowledged and reading them back through L2
   void* res = nullptr;
+  // (round 5, persistent rollout with the image) true: tau, f, status, iters of THIS tick go to the image only -- nobody reads them from memory before the
+  // launch's last tick (the next tick's observer takes tau_prev, f_prev from the image, the integrator tau and f)
+  bool skip_out = false;
 };
-constexpr int RES_TAU = 0, RES_F = 12, RES_H = 24, RES_WORDS = 42;
 #ifdef WBC_FUSED_STAMP
 // (one column per workgroup: column = first state of the workgroup, i.e. blockIdx.x * states-per-workgroup)
 #define WBC_FSTAMP_S(ptr, N_, slot, spw) do { if ((threadIdx.x & 63) == 0) (ptr)[(size_t)(slot) * (N_) + (size_t)blockIdx.x * (spw)] = (double)wall_clock64(); } while (0)
@@ -682,6 +684,8 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   WBC_QSTAMP3(10);
   if constexpr (WSLDS) { if (sync) qp_wait(sync->fin, sync->need_fin); }
   WBC_QSTAMP(6);
+  bool to_mem = true;   // (QpSync::skip_out: wavefront-uniform)
+  if constexpr (WSLDS) { if (sync) to_mem = !sync->skip_out; }
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     int jm = 0;   // caller's index of my joint (leg f, joint c3)
@@ -700,9 +704,11 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     }
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     if (isvar) {
-      GST(a.f, v, on ? x_me : (T)0);
       const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
-      GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+      if (to_mem) {
+        GST(a.f, v, on ? x_me : (T)0);
+        GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+      }
       if constexpr (WSLDS) {
         if (sync && sync->res) {
           T* rs = (T*)sync->res + (int)(tx >> 4);
@@ -711,7 +717,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
         }
       }
     }
-    if (l16 == 0) {
+    if (l16 == 0 && to_mem) {
       a.status[s32] = status;
 #ifdef WBC_QP_STAMP  // diagnostic build only: per-wave cycle stamps (two 16-bit fields of cycles/16 per group) instead of iteration counts
       {

@@ -749,6 +749,8 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     if constexpr (WARM == 2) { if (l16 == 0) *carry = aset_fin; }   // (LDS: read back by this row in the next tick -- program order of one wavefront)
     if (a.aset_out && live && l16 == 0) a.aset_out[s32] = aset_fin;
   }
+  bool to_mem = true;   // (QpSync::skip_out: wavefront-uniform)
+  if constexpr (WSLDS) { if (sync) to_mem = !sync->skip_out; }
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;
     int jm = 0;
@@ -767,9 +769,11 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     }
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     if (isvar) {
-      GST(a.f, v, on ? x_me : (T)0);
       const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
-      GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+      if (to_mem) {
+        GST(a.f, v, on ? x_me : (T)0);
+        GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+      }
       if constexpr (WSLDS) {
         if (sync && sync->res) {   // (persistent rollout: the integrator reads this tick's tau, f from LDS -- QpSync::res)
           TS* rs = (TS*)sync->res + (int)(tx >> 4);
@@ -778,7 +782,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
         }
       }
     }
-    if (l16 == 0) {
+    if (l16 == 0 && to_mem) {
       a.status[s32] = status;
 #ifdef WBC_QP_STAMP
       {
