@@ -530,6 +530,9 @@ def _gpu_rollout(torch, solver, P, H, B, tau_ext, integ, r, want_traj=True, dtyp
                    None if tau_ext is None else dv(tau_ext), traj)
     torch.cuda.synchronize()
     res = dict(q=to_host(q), v=to_host(v), status=out["status"].cpu().numpy())
+    # what the caller finds in its output buffers: the LAST tick's (the 4-state rollout workgroups store nothing else since round 5)
+    res.update(out_tau=to_host(out["tau"]), out_f=to_host(out["f"]), out_M=to_host(out["M"]), out_h=to_host(out["h"]), out_Jc=to_host(out["Jc"]),
+               out_pf=to_host(out["pf"]))
     if traj is not None:
         res["tau_traj"] = traj.cpu().numpy().transpose(2, 0, 1).copy()  # [n, H, 12]
     if ig is not None:
@@ -563,7 +566,7 @@ def test_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H):
     assert np.allclose(np.linalg.norm(got["q"][:, 3:7], axis=1), 1.0, atol=1e-13)
 
 
-@pytest.mark.parametrize("cfg,obs,n,H", [(3, 1, 1000, 20), (2, 0, 129, 7)])
+@pytest.mark.parametrize("cfg,obs,n,H", [(3, 1, 1000, 20), (2, 0, 129, 7), (4, 2, 1, 1), (3, 1, 5, 1), (2, 0, 3, 2), (4, 1, 6, 3)])
 def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, oracle, cfg, obs, n, H):
     """wbc_rollout_batch of small batches is ONE launch for the whole horizon (rollout_kernel); WBC_ROLLOUT_PERSISTENT=0
     forces {fused tick, integrate} launches per tick.  Same device functions -> equal to rounding."""
@@ -579,8 +582,9 @@ def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, orac
                                 np.zeros((n, 18)) if obs else None)
     a, b = res["persistent"], res["per_tick"]
     assert np.array_equal(a["status"], b["status"])
-    for k in ("q", "v", "tau_traj") + (("integ", "r") if obs else ()):
+    for k in ("q", "v", "tau_traj", "out_tau", "out_f", "out_M", "out_h", "out_Jc", "out_pf") + (("integ", "r") if obs else ()):
         assert relerr(a[k], b[k]) < 1e-10, k
+    assert relerr(a["out_tau"], a["tau_traj"][:, H - 1]) == 0.0   # the output buffer holds the last tick's torques
 
 
 @pytest.mark.parametrize("obs,n", [(1, 777), (0, 130), (2, 1500)])
