@@ -520,8 +520,19 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
           iat.istamp = rstamp; iat.istampN = rstampN;
           RSTAMP(7);   // phase 2 starts (the factors are there)
 #endif
-          integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true>(model, iat, IntegrateNoWait(), mj_hand, res_img, fact_sh);
-          RSTAMP(8);
+#ifndef WBC_RO_EARLY_BARRIER
+#define WBC_RO_EARLY_BARRIER 0   // 1: the tick's barrier in FRONT of this wavefront's stores (integrate.hip.hpp, after_state: measured, not kept)
+#endif
+          if constexpr (WBC_RO_EARLY_BARRIER != 0) {
+            auto state_out = [] __device__() { __syncthreads(); };   // <- the tick's barrier, for this wavefront
+            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true, decltype(state_out)>(model, iat, IntegrateNoWait(), mj_hand, res_img,
+                                                                                                                  fact_sh, state_out);
+            RSTAMP(8);
+            continue;
+          } else {
+            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true>(model, iat, IntegrateNoWait(), mj_hand, res_img, fact_sh);
+            RSTAMP(8);
+          }
         }
       }
     }

@@ -10,6 +10,7 @@
 // columns of Jc, own-leg Jacobian blocks = its joint columns).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_types.hpp"
 #include "dyn_sweep.hip.hpp"
 
@@ -41,9 +42,14 @@ constexpr int INT_FACT_WORDS = 27;
 #endif                 // fp32 rollout tests ask for (NaN on stiff states): not kept
 // HAND / RESI: `hand` / `res` are given (template parameters, not null tests: a pointer that may be an LDS image or null turns every load behind it into a
 // flat_load -- 39 of them in the round-4 rollout kernels, 30 in phase 2 -- where the image wants a ds_read).
-template <class T, int SPW = 16, class Between = IntegrateNoWait, int PHASE = 0, bool UNGUARD = false, bool HAND = false, bool RESI = false>
+// `after_state()` (4-state rollout workgroups): called when the new state is complete in the LDS image and before anything goes to memory -- the kernel
+// can put the tick's barrier there, so that the next tick's roles start while this wavefront (the next tick's QP, idle until the lever arms are out)
+// still issues its stores.  Measured (profiles/r05q_ab_rollout_early_barrier.log): 9.39-9.47 -> 9.48-9.52 us per tick at 1 024 robots, cold 15.71 -> 15.97:
+// not kept (-DWBC_RO_EARLY_BARRIER=1).
+template <class T, int SPW = 16, class Between = IntegrateNoWait, int PHASE = 0, bool UNGUARD = false, bool HAND = false, bool RESI = false,
+          class AfterState = IntegrateNoWait>
 WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between(), const T* hand_ = nullptr,
-                            const T* res_ = nullptr, T* fact = nullptr) {
+                            const T* res_ = nullptr, T* fact = nullptr, AfterState after_state = AfterState()) {
   static_assert(PHASE == 0 || PHASE == 1 || PHASE == 2, "phase");
   static_assert(PHASE == 0 || HAND, "the split phases hand M's blocks over in LDS");
   const T* const hand = HAND ? hand_ : nullptr;
@@ -208,6 +214,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   constexpr bool SIMG = PHASE == 2 && SPW == 4 && WBC_RO_MERGE != 0;
   T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
 #define STS(comp, val) do { if constexpr (SIMG) si_[(comp) * 16] = (val); } while (0)
+  constexpr bool DEFER = SIMG && !std::is_same<AfterState, IntegrateNoWait>::value;   // (see after_state)
   const bool to_mem = !(SIMG && a.skip_state != 0);   // (wavefront-uniform: a kernel argument) the state in memory is read by nobody before the launch ends
   T ql[3], vl[3];
 #pragma unroll
@@ -339,17 +346,20 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
 
   // ---- semi-implicit Euler
   const T dt = a.dt;
+  T vjn[3], qjn[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const T vn = vl[k] + dt * vdl[k];
-    const T qjn = ql[k] + dt * vn;
-    STS(SIMG_V + 6 + jx[k], vn);
-    STS(7 + jx[k], qjn);
-    if (to_mem) {
-      STV(a.v, 6 + jx[k], vn);
-      STV(a.q, 7 + jx[k], qjn);
+    vjn[k] = vl[k] + dt * vdl[k];
+    qjn[k] = ql[k] + dt * vjn[k];
+    STS(SIMG_V + 6 + jx[k], vjn[k]);
+    STS(7 + jx[k], qjn[k]);
+    if constexpr (!DEFER) {
+      if (to_mem) {
+        STV(a.v, 6 + jx[k], vjn[k]);
+        STV(a.q, 7 + jx[k], qjn[k]);
+      }
+      if (a.tau_traj) STV(a.tau_traj, jx[k], taul[k]);
     }
-    if (a.tau_traj) STV(a.tau_traj, jx[k], taul[k]);
   }
   ISTAMP(9);   // joint rows stored
   T vbn[6];
@@ -400,6 +410,17 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     if (leg < 2) STS(SIMG_V + 4 + leg, leg == 0 ? vbn[4] : vbn[5]);
     STS(sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, qn[0], qn[1], qn[2], qn[3]));
     if (leg < 3) STS(4 + leg, sel4<T>(leg, qn[4], qn[5], qn[6], qn[6]));
+  }
+  if constexpr (DEFER) {
+    after_state();   // the image is complete: memory comes behind
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (to_mem) {
+        STV(a.v, 6 + jx[k], vjn[k]);
+        STV(a.q, 7 + jx[k], qjn[k]);
+      }
+      if (a.tau_traj) STV(a.tau_traj, jx[k], taul[k]);
+    }
   }
   if (to_mem) {
     STV(a.v, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, vbn[0], vbn[1], vbn[2], vbn[3]));
