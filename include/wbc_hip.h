@@ -260,7 +260,10 @@ int wbc_integrate_batch(wbc_solver* s, size_t N, void* q, void* v, const void* M
 /* `horizon` dependent ticks of {wbc_step_batch, wbc_integrate_batch} with constant references (BASELINE.json
  * configs[4]: MPC-style WBC-in-the-loop rollouts).  in->q / in->v are ADVANCED IN PLACE (const is cast away);
  * out->tau / out->f must hold the previous tick's outputs (or zeros) on entry and serve as tau_prev / f_prev;
- * out->M, out->h, out->Jc are required.  tau_traj (optional) receives tau of every tick: [horizon][nj][N]. */
+ * out->M, out->h, out->Jc are required.  tau_traj (optional) receives tau of every tick: [horizon][nj][N].
+ * On return the out-> buffers (tau, f, status, iters, M, h, Jc, pf), the observer state and (tracking) w_des / vdot_des hold the LAST
+ * tick's values, as after per-tick calls; while the call runs their contents are unspecified (rollouts of up to 1024 states are one launch that
+ * keeps state, torques and observer inputs on chip from tick to tick and writes them out once). */
 int wbc_rollout_batch(wbc_solver* s, size_t N, int horizon, const wbc_batch_in* in, const wbc_batch_out* out,
                       const wbc_observer_state* obs, const void* tau_ext, void* tau_traj, void* stream);
 

@@ -47,7 +47,7 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
 #pragma unroll
   for (int c = 0; c < 6; ++c) vb[c] = SIMG ? si_[(SIMG_V + c) * 16] : RLDU(a.v, c);
 #pragma unroll
-  for (int c = 0; c < PLAN_WORDS; ++c) pl[c] = RLDU(a.plan, c);
+  for (int c = 0; c < PLAN_WORDS; ++c) pl[c] = SIMG ? a.planimg[c * 16 + (si_ - a.simg)] : RLDU(a.plan, c);
   int jx[3];
   jidx_of_leg(model, a.jpack, leg, jx);
   T ql[3], vl[3];
@@ -154,12 +154,28 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
   const V3<T> Mo = cross(crel, F) + mul(R, mk<T>(G->inertia_nom[0] * lb.x, G->inertia_nom[1] * lb.y, G->inertia_nom[2] * lb.z));
 
   // outputs: the base-replicated words are dealt over the four leg rows (no redundant store), joints by their owner
-  RSTV(a.w_des, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, F.x, F.y, F.z, Mo.x));
-  if (leg < 2) RSTV(a.w_des, 4 + leg, leg == 0 ? Mo.y : Mo.z);
-  RSTV(a.vdot_des, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, acmd[0], acmd[1], acmd[2], alcmd[0]));
-  if (leg >= 2) RSTV(a.vdot_des, 2 + leg, leg == 2 ? alcmd[1] : alcmd[2]);
+  T adj[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) RSTV(a.vdot_des, 6 + jx[k], G->kp_joint * (G->q_nom[jx[k]] - ql[k]) - G->kd_joint * vl[k]);
+  for (int k = 0; k < 3; ++k) adj[k] = G->kp_joint * (G->q_nom[jx[k]] - ql[k]) - G->kd_joint * vl[k];
+  bool to_mem = true;
+  if constexpr (SIMG) {   // the rnea role of the same workgroup reads the references in LDS (its caller raises a flag behind an LDS-only fence)
+    T* const ri = a.refimg + (si_ - a.simg);
+    ri[sel4<int>(leg, 0, 1, 2, 3) * 16] = sel4<T>(leg, F.x, F.y, F.z, Mo.x);
+    if (leg < 2) ri[(4 + leg) * 16] = leg == 0 ? Mo.y : Mo.z;
+    ri[(6 + sel4<int>(leg, 0, 1, 2, 3)) * 16] = sel4<T>(leg, acmd[0], acmd[1], acmd[2], alcmd[0]);
+    if (leg >= 2) ri[(6 + 2 + leg) * 16] = leg == 2 ? alcmd[1] : alcmd[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ri[(6 + 6 + jx[k]) * 16] = adj[k];
+    to_mem = a.skip_out == 0;
+  }
+  if (to_mem) {
+    RSTV(a.w_des, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, F.x, F.y, F.z, Mo.x));
+    if (leg < 2) RSTV(a.w_des, 4 + leg, leg == 0 ? Mo.y : Mo.z);
+    RSTV(a.vdot_des, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, acmd[0], acmd[1], acmd[2], alcmd[0]));
+    if (leg >= 2) RSTV(a.vdot_des, 2 + leg, leg == 2 ? alcmd[1] : alcmd[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) RSTV(a.vdot_des, 6 + jx[k], adj[k]);
+  }
   if (a.com) {
     RSTV(a.com, sel4<int>(leg, 0, 1, 2, 3), sel4<T>(leg, c.x, c.y, c.z, cd.x));
     if (leg < 2) RSTV(a.com, 4 + leg, leg == 0 ? cd.y : cd.z);

@@ -82,6 +82,7 @@ template <class T> struct SweepArgs {
                               // SGPRs instead of loading DevModel::jidx -- a per-lane global load in FRONT of the joint-state loads, i.e. one
                               // more dependent trip through L2 at the head of every role of every tick (round 5)
   const T* simg;              // (set by the persistent rollout kernel, never by the host) the workgroup's state image in LDS: see WBC_RO_MERGE
+  const T* refimg;            // (likewise, planner in the loop) this tick's references [24][16]: w_des (rows 0 .. 5), vdot_des (6 .. 23), written by the planner role
   const T* resimg;            // (likewise) the result image: the observer role of a 4-state workgroup takes tau_prev, f_prev from the rows the QP of the
                               // previous tick wrote there, instead of from memory
 };
@@ -149,6 +150,9 @@ template <class T> struct RefArgs {
   T* com;   // [6][N] or null
   unsigned long long jpack;   // see SweepArgs::jpack
   const T* simg;              // see SweepArgs::simg
+  T* refimg;                  // see SweepArgs::refimg: where the planner role of a 4-state rollout workgroup leaves the references (and in memory in the last tick)
+  const T* planimg;           // (likewise) the plans of the workgroup's states [PLAN_WORDS][16], parked in LDS for the whole launch
+  int skip_out;               // (likewise) 1: w_des, vdot_des go to the LDS image only -- every tick of a launch but the last
 };
 
 // MODE bits of dyn_sweep_kernel (dyn_sweep.hip.hpp)
@@ -164,6 +168,10 @@ constexpr int RS_PF = 8;    // write pf (when mass_jac does not run)
 constexpr int RS_OBSW = 16; // observer ROLE of the fused tick (with RS_OBS, without RS_STEP / RS_H): no force recursion, the
                             // momentum observer is updated and rhat (18 words) goes to the LDS image at WS_RHAT
 constexpr int RS_NOB = 32;  // (stand-alone kernel, observer off) w_des is not forwarded to the workspace: see SW_NOB
+constexpr int RS_REFIMG = 256; // (role with RS_STEP, four-wavefront rollout workgroups with the planner in the loop) w_des, vdot_des come from the planner role's LDS
+                               // image (SweepArgs::refimg), not from memory
+constexpr int RS_NOJC = 128; // (role with RS_STEP, four-wavefront rollout workgroups) the own-leg Jacobian blocks are NOT propagated up the return sweep and not written
+                             // to WS_JCL: the QP's torque map takes them from the mass_jac role's LDS image, which is complete ~2 us before this role ends
 constexpr int RS_LANE2 = 64; // (roles with 4 states per workgroup, RS_STEP | RS_H) the two force recursions SIDE BY SIDE in the lanes instead of one after the
                              // other: slots 0 .. 3 of every leg row run RNEA(q, v, 0) (the bias forces h), slots 4 .. 7 RNEA(q, 0, vdot_des) without gravity
                              // (M vdot_des) of the same states, as ONE instruction stream; tau_partial = their sum, across lanes (round 5)

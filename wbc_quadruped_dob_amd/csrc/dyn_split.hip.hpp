@@ -407,7 +407,9 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0, FWD_B = (MODE & RS_NOB) == 0;
   constexpr bool OBSW = (MODE & RS_OBSW) != 0;
   static_assert(!OBSW || (EXT != 0 && OBS && !STEP && !WH), "the observer role exists only inside the fused tick");
-  constexpr bool GEOM = STEP || OBS || WPF;     // foot position / own-leg Jacobian needed
+  constexpr bool NOJC = (MODE & RS_NOJC) != 0;
+  static_assert(!NOJC || (EXT != 0 && STEP && !OBS && !WPF), "RS_NOJC: a step role next to a mass_jac role");
+  constexpr bool GEOM = (STEP && !NOJC) || OBS || WPF;     // foot position / own-leg Jacobian needed (the lever arms of a role go out EARLY, from their own chain)
   constexpr bool LANE2 = (MODE & RS_LANE2) != 0;   // the two chains side by side in the lanes (device_types.hpp)
   static_assert(!LANE2 || (EXT != 0 && SPW == 4 && STEP && WH && !OBS), "RS_LANE2: a role of 4-state workgroups that wants h and tau_partial");
   constexpr bool TWO = STEP && WH && !LANE2;    // h and tau_partial both wanted: two force chains in every lane; else one (merged, or one per lane group)
@@ -452,17 +454,20 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   // the planner role of the tracking rollout), in which case the lever arms, which need q only, go out before that wait.
   constexpr bool LATE_REFS = EARLY && !std::is_same<BeforeRefs, NoWait>::value;
   T bw[6] = {0, 0, 0, 0, 0, 0};
+  constexpr bool RIMG = (MODE & RS_REFIMG) != 0;   // (planner in the loop, 4-state rollout workgroups) the references are in the planner role's LDS image
+  static_assert(!RIMG || (SIMG && STEP), "RS_REFIMG: a step role of a 4-state rollout workgroup");
   auto load_refs = [&]() __attribute__((always_inline)) {
     before_refs();
+    const T* const ri = RIMG ? a.refimg + (si_ - a.simg) : nullptr;
     if (STEP) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) al[k] = LDX(a.vdot_des, 6, jxN[k]);
+      for (int k = 0; k < 3; ++k) al[k] = RIMG ? ri[(6 + 6 + jx[k]) * 16] : LDX(a.vdot_des, 6, jxN[k]);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) ad[c] = LDU(a.vdot_des, c);
+      for (int c = 0; c < 6; ++c) ad[c] = RIMG ? ri[(6 + c) * 16] : LDU(a.vdot_des, c);
     }
     if (STEP && !OBS && FWD_B) {  // observer off: the QP target wrench is just w_des (RS_NOB: the QP kernel reads it itself)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) bw[c] = LDU(a.w_des, c);
+      for (int c = 0; c < 6; ++c) bw[c] = RIMG ? ri[c * 16] : LDU(a.w_des, c);
     }
   };
   if constexpr (!LATE_REFS) load_refs();
@@ -716,11 +721,13 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
       WSTL(WS_D + 1, 3, dw.y);
       WSTL(WS_D + 2, 3, dw.z);
     }
+    if constexpr (GEOM) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      WSTL(WS_JCL + 0 + k, 9, jw[k].x);
-      WSTL(WS_JCL + 3 + k, 9, jw[k].y);
-      WSTL(WS_JCL + 6 + k, 9, jw[k].z);
+      for (int k = 0; k < 3; ++k) {
+        WSTL(WS_JCL + 0 + k, 9, jw[k].x);
+        WSTL(WS_JCL + 3 + k, 9, jw[k].y);
+        WSTL(WS_JCL + 6 + k, 9, jw[k].z);
+      }
     }
   }
   if (WH) {

@@ -222,6 +222,11 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   // 11.1 us per tick for the eight-wavefront layout; profiles/r05o_ab_rollout_merge.log)
   constexpr bool OBS_ONE = MERGE && WBC_RO_MERGE_OBS == 1;
   constexpr bool OBS_FIFTH = MERGE && OBSERVER && FUSED_OBS_WAVES == 2 && WBC_RO_MERGE_OBS == 3;
+#ifndef WBC_RO_NOJC
+#define WBC_RO_NOJC 1   // (four-wavefront layout) 1: the fp64 rnea role does not propagate the own-leg Jacobian blocks -- the torque map takes them from the mass_jac
+#endif                  // role's image (RS_NOJC): 9.33 -> 9.23 us per tick at 1 024 robots, 128 robots 9.13 -> 9.01; fp32 7.57 -> 7.62 and cold 15.75 -> 15.86, hence
+                        // fp64 only (profiles/r05s_ab_rollout_nojc_refimg.log); 2: both scalar types; 0: never
+  constexpr bool NOJC = MERGE && (WBC_RO_NOJC == 2 || (WBC_RO_NOJC == 1 && sizeof(T) == 8));
   constexpr bool SPEC_ORDER = OBSERVER && !WARM && WBC_QP_SPEC != 0 && WBC_SPEC_ORDER != 0;
   constexpr int QP_WAVES = SPW / 4;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
@@ -289,12 +294,22 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   constexpr bool SPLIT_INT = MERGE || WBC_RO_SPLIT_INT != 0;
   __shared__ T fact_sh[SPLIT_INT ? INT_FACT_WORDS * 64 : 1];   // the integrator's phase 1 -> phase 2 hand-over (integrate.hip.hpp, PHASE)
   __shared__ T st_sh[MERGE ? SIMG_WORDS * 16 : 1];             // (MERGE) the workgroup's states
+  __shared__ T ref_sh[(MERGE && TRACK) ? 24 * 16 : 1];         // (MERGE, planner in the loop) this tick's references: planner role -> rnea role
+  __shared__ T plan_sh[(MERGE && TRACK) ? PLAN_WORDS * 16 : 1];   // ... and the plans of the workgroup's states
   if constexpr (MERGE) {
     for (int i = threadIdx.x; i < SIMG_WORDS * 16; i += blockDim.x) {
       const int comp = i >> 4, slot = i & 15;
       size_t st = (size_t)blockIdx.x * SPW + (slot < SPW ? slot : 0);
       st = st < a.N ? st : a.N - 1;
       st_sh[i] = comp < SIMG_V ? a.q[(size_t)comp * a.N + st] : a.v[(size_t)(comp - SIMG_V) * a.N + st];
+    }
+    if constexpr (TRACK) {
+      for (int i = threadIdx.x; i < PLAN_WORDS * 16; i += blockDim.x) {
+        const int comp = i >> 4, slot = i & 15;
+        size_t st = (size_t)blockIdx.x * SPW + (slot < SPW ? slot : 0);
+        st = st < a.N ? st : a.N - 1;
+        plan_sh[i] = ra.plan[(size_t)comp * a.N + st];
+      }
     }
     if constexpr (!RES_LDS) __syncthreads();
   }
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
     QpArgs<T> qat = qa;
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
-    at.simg = st_sh; iat.simg = st_sh; at.resimg = res_sh;
+    at.simg = st_sh; iat.simg = st_sh; at.resimg = res_sh; at.refimg = ref_sh;
 #ifndef WBC_RO_SKIP_STATE
 #define WBC_RO_SKIP_STATE 1   // 0: every tick stores its q, v (A/B)
 #endif
@@ -365,11 +380,13 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
       if constexpr (TRACK) {
         RefArgs<T> rt = ra;
         rt.N = (size_t)n_tick;
-        rt.simg = st_sh;
+        rt.simg = st_sh; rt.refimg = ref_sh; rt.planimg = plan_sh;
+        rt.skip_out = (MERGE && t < horizon - 1) ? 1 : 0;   // (the caller finds the LAST tick's references in its w_des / vdot_des buffers)
         rt.t = (T)t * prm.dt + ra.t;
         rt.com = com0 ? com0 + (size_t)t * 6 * (size_t)n_tick : nullptr;
         com_reference_body<T, true, SPW>(model, G, rt, cst);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
+        if constexpr (MERGE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // w_des, vdot_des are in the LDS image ...
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
       }
     };
@@ -426,7 +443,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #ifndef WBC_RO_LANE2
 #define WBC_RO_LANE2 1
 #endif
-      constexpr int RNEA_MODE = H_WAVE >= 0 ? RS_STEP : ((SPW == 4 && WBC_RO_LANE2) ? (RS_STEP | RS_H | RS_LANE2) : (RS_STEP | RS_H));
+      constexpr int RNEA_MODE = (H_WAVE >= 0 ? RS_STEP : ((SPW == 4 && WBC_RO_LANE2) ? (RS_STEP | RS_H | RS_LANE2) : (RS_STEP | RS_H))) | (NOJC ? RS_NOJC : 0) | ((MERGE && TRACK) ? RS_REFIMG : 0);
       rnea_step_body<T, RNEA_MODE, 64, 1, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
@@ -501,6 +518,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #ifndef WBC_RO_SKIP_OUT
 #define WBC_RO_SKIP_OUT 1   // 0: every tick stores its tau, f, status, iters (A/B)
 #endif
+      if constexpr (NOJC) { sy.hand = mj_hand; sy.hand_flag = &mready; sy.need_hand = t + 1; }
       sy.skip_out = MERGE && WBC_RO_SKIP_OUT && t < horizon - 1;   // (the LAST tick's are what the caller finds, as with per-tick launches)
       if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, 1, SPW>(model, prm, at, cst, wsl, NoWait(), NoWait(), res_img ? res_img + RES_H * 16 : nullptr); }   // bias forces h
       if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }

@@ -171,6 +171,10 @@ struct QpSync {
   // (round 5, persistent rollout with the image) true: tau, f, status, iters of THIS tick go to the image only -- nobody reads them from memory before the
   // launch's last tick (the next tick's observer takes tau_prev, f_prev from the image, the integrator tau and f)
   bool skip_out = false;
+  // (four-wavefront rollout workgroups) the mass_jac role's LDS image [46][64] (dyn_split.hip.hpp, MJ_HAND_WORDS): the torque map takes the own-leg Jacobian
+  // blocks from its words 24 .. 32 (row m of foot f, joint k at (24 + 3 m + k) * 64 + 16 f + slot) once `hand_flag` has reached `need_hand`, and the rnea
+  // role does not compute them (RS_NOJC)
+  const void* hand = nullptr; int* hand_flag = nullptr; int need_hand = 0;
 };
 #ifdef WBC_FUSED_STAMP
 // (one column per workgroup: column = first state of the workgroup, i.e. blockIdx.x * states-per-workgroup)
@@ -685,7 +689,14 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   if constexpr (WSLDS) { if (sync) qp_wait(sync->fin, sync->need_fin); }
   WBC_QSTAMP(6);
   bool to_mem = true;   // (QpSync::skip_out: wavefront-uniform)
-  if constexpr (WSLDS) { if (sync) to_mem = !sync->skip_out; }
+  bool from_hand = false;   // (QpSync::hand)
+  const T* hand_img = nullptr;
+  if constexpr (WSLDS) {
+    if (sync) {
+      to_mem = !sync->skip_out;
+      if (sync->hand) { qp_wait(sync->hand_flag, sync->need_hand); from_hand = true; hand_img = (const T*)sync->hand; }
+    }
+  }
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     int jm = 0;   // caller's index of my joint (leg f, joint c3)
@@ -696,7 +707,10 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
 #endif
     if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
-      if (geom_jc) {
+      if (from_hand) {
+        const int hslot = 16 * f + (int)((tx >> 4) & 3);
+        jl0 = (T)hand_img[(24 + c3) * 64 + hslot]; jl1 = (T)hand_img[(27 + c3) * 64 + hslot]; jl2 = (T)hand_img[(30 + c3) * 64 + hslot];
+      } else if (geom_jc) {
         jl0 = GLD(a.Jc, (3 * f + 0) * 18 + 6 + jm); jl1 = GLD(a.Jc, (3 * f + 1) * 18 + 6 + jm); jl2 = GLD(a.Jc, (3 * f + 2) * 18 + 6 + jm);
       } else {
         jl0 = WSLD(WS_JCL + 9 * f + 0 + c3); jl1 = WSLD(WS_JCL + 9 * f + 3 + c3); jl2 = WSLD(WS_JCL + 9 * f + 6 + c3);

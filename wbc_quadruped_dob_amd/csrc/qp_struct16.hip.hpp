@@ -750,7 +750,14 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     if (a.aset_out && live && l16 == 0) a.aset_out[s32] = aset_fin;
   }
   bool to_mem = true;   // (QpSync::skip_out: wavefront-uniform)
-  if constexpr (WSLDS) { if (sync) to_mem = !sync->skip_out; }
+  bool from_hand = false;   // (QpSync::hand)
+  const TS* hand_img = nullptr;
+  if constexpr (WSLDS) {
+    if (sync) {
+      to_mem = !sync->skip_out;
+      if (sync->hand) { qp_wait(sync->hand_flag, sync->need_hand); from_hand = true; hand_img = (const TS*)sync->hand; }
+    }
+  }
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;
     int jm = 0;
@@ -761,7 +768,10 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #endif
     if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
-      if (geom_jc) {
+      if (from_hand) {
+        const int hslot = 16 * f + (int)((tx >> 4) & 3);
+        jl0 = (T)hand_img[(24 + c3) * 64 + hslot]; jl1 = (T)hand_img[(27 + c3) * 64 + hslot]; jl2 = (T)hand_img[(30 + c3) * 64 + hslot];
+      } else if (geom_jc) {
         jl0 = GLD(a.Jc, (3 * f + 0) * 18 + 6 + jm); jl1 = GLD(a.Jc, (3 * f + 1) * 18 + 6 + jm); jl2 = GLD(a.Jc, (3 * f + 2) * 18 + 6 + jm);
       } else {
         jl0 = WSLD(WS_JCL + 9 * f + 0 + c3); jl1 = WSLD(WS_JCL + 9 * f + 3 + c3); jl2 = WSLD(WS_JCL + 9 * f + 6 + c3);
