@@ -582,8 +582,10 @@ def test_persistent_rollout_equals_per_tick_launches(torch_cuda, gpu_model, orac
                                 np.zeros((n, 18)) if obs else None)
     a, b = res["persistent"], res["per_tick"]
     assert np.array_equal(a["status"], b["status"])
+    # (the 4-state rollout workgroups normalise quaternions and pivots with rsqrt_fast -- hardware estimate + two Newton steps, 1-2 ulp -- the per-tick
+    #  kernels with 1 / sqrt: two implementations of the same maths, compounding over the horizon)
     for k in ("q", "v", "tau_traj", "out_tau", "out_f", "out_M", "out_h", "out_Jc", "out_pf") + (("integ", "r") if obs else ()):
-        assert relerr(a[k], b[k]) < 1e-10, k
+        assert relerr(a[k], b[k]) < TIGHT64, k
     assert relerr(a["out_tau"], a["tau_traj"][:, H - 1]) == 0.0   # the output buffer holds the last tick's torques
 
 
@@ -592,7 +594,8 @@ def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, orac
     """The persistent rollout kernel gives a workgroup 4 states (up to 1024 rollouts) or 16 (wbc_solver_options.rollout_spw): another
     distribution of the same per-state arithmetic over the device.  Since round 5 the 4-state workgroups run the two force recursions of the
     rnea role side by side in the lanes (RS_LANE2) and add their torques across lanes, where the 16-state ones add them inside one fused
-    multiply-add chain: the last bit of ~3 % of the torques differs per tick (tools/spw_diff.py), the active sets do not."""
+    multiply-add chain, and normalise quaternions / Cholesky pivots with rsqrt_fast (1-2 ulp) where the 16-state ones divide by a square root: the
+    last bits of the torques differ per tick (tools/spw_diff.py) and compound over the 9 ticks to ~1e-11, the active sets do not differ."""
     torch = torch_cuda
     B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=67)
     tau_ext = np.zeros((n, 18))
@@ -607,7 +610,7 @@ def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, orac
         if res["4"][k].dtype.kind in "iu":
             assert np.array_equal(res["4"][k], res["16"][k]), k
         else:
-            assert relerr(res["4"][k], res["16"][k]) < 1e-11, k
+            assert relerr(res["4"][k], res["16"][k]) < 1e-10, k
 
 
 def test_rollout_vs_golden(torch_cuda, gpu_model):

@@ -58,7 +58,7 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
   }
   T qx, qy, qz, qw;
   {
-    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    const T n = rsqrt_sel<SIMG>(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
     qx = qb[3] * n; qy = qb[4] * n; qz = qb[5] * n; qw = qb[6] * n;
   }
   M3<T> R;
@@ -137,7 +137,7 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
     }
   }
   {
-    const T dn = rsqrt_t(pl[8] * pl[8] + pl[9] * pl[9] + pl[10] * pl[10] + pl[11] * pl[11]);
+    const T dn = rsqrt_sel<SIMG>(pl[8] * pl[8] + pl[9] * pl[9] + pl[10] * pl[10] + pl[11] * pl[11]);
     const T dx = pl[8] * dn, dy = pl[9] * dn, dz = pl[10] * dn, dw = pl[11] * dn;
     const T x = -qx, y = -qy, z = -qz, w = qw;
     T ex = dw * x + dx * w + dy * z - dz * y;

@@ -213,7 +213,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   }
   T qx, qy, qz, qw;
   {
-    const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    const T n = rsqrt_sel<SIMG>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
   // joint transforms: E of joints 0 and 1 wait in LDS ([word][lane]) until the return sweep reaches them
@@ -489,7 +489,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   }
   T qx, qy, qz, qw;
   {
-    const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    const T n = rsqrt_sel<SIMG>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
   T sn3[3] = {0, 0, 0}, cs3[3] = {0, 0, 0};

@@ -190,6 +190,23 @@ WBC_DEV void sincos_t(double x, double* sp, double* cp) {
 WBC_DEV void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
 WBC_DEV double rsqrt_t(double x) { return 1.0 / sqrt(x); }
 WBC_DEV float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
+// 1 / sqrt(x) from the hardware estimate (v_rsq_f64: ~2^-23 relative) and two Newton steps -- 9 dependent operations (~0.05 us for a lone wavefront) where
+// `1.0 / sqrt(x)` compiles to a refined square root followed by a full IEEE division (~45, ~0.25 us).  Within 1-2 ulp of the correctly rounded value.  Used by
+// the roles of the 4-state rollout workgroups, where the quaternion normalisation at the head of the rnea role is on the tick's critical chain: 9.21 -> 9.05 us
+// per tick.  NOT used elsewhere: the one-launch tick at 4 096 states measured 13.3 -> 13.5 us with it, the large sweeps are HBM-bound
+// (profiles/r05t_ab_rsqrt.log).
+WBC_DEV double rsqrt_fast(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = __builtin_fma(-x * y, y, 1.0); y = __builtin_fma(0.5 * y, e, y);
+  e = __builtin_fma(-x * y, y, 1.0); y = __builtin_fma(0.5 * y, e, y);
+  return y;
+}
+WBC_DEV float rsqrt_fast(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  const float e = __builtin_fmaf(-x * y, y, 1.0f);
+  return __builtin_fmaf(0.5f * y, e, y);
+}
+template <bool FAST, class X> WBC_DEV X rsqrt_sel(X x) { if constexpr (FAST) return rsqrt_fast(x); else return rsqrt_t(x); }
 
 __host__ __device__ constexpr int midx18(int i, int j) { return i * 18 - i * (i - 1) / 2 + (j - i); }
 

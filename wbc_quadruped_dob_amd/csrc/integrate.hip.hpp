@@ -52,6 +52,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
                             const T* res_ = nullptr, T* fact = nullptr, AfterState after_state = AfterState()) {
   static_assert(PHASE == 0 || PHASE == 1 || PHASE == 2, "phase");
   static_assert(PHASE == 0 || HAND, "the split phases hand M's blocks over in LDS");
+  constexpr bool FASTR = PHASE != 0 && SPW == 4 && WBC_RO_MERGE != 0;   // (4-state rollout workgroups) rsqrt_fast, see dyn_sweep.hip.hpp
   const T* const hand = HAND ? hand_ : nullptr;
   const T* const res = RESI ? res_ : nullptr;
   const size_t N = a.N;
@@ -162,7 +163,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     T d = S[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-    const T inv = rsqrt_t(d);
+    const T inv = rsqrt_sel<FASTR>(d);
     L[j][j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
@@ -244,13 +245,13 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   constexpr bool QNORM_EARLY = WBC_INT_QNORM_EARLY == 2 || (WBC_INT_QNORM_EARLY == 1 && sizeof(T) == 4);
   T ux, uy, uz, uw;
   if constexpr (QNORM_EARLY) {
-    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    const T n = rsqrt_sel<FASTR>(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
     ux = qb[3] * n; uy = qb[4] * n; uz = qb[5] * n; uw = qb[6] * n;
   }
 
   between();
   if constexpr (!QNORM_EARLY) {
-    const T n = rsqrt_t(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
+    const T n = rsqrt_sel<FASTR>(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
     ux = qb[3] * n; uy = qb[4] * n; uz = qb[5] * n; uw = qb[6] * n;
   }
   ISTAMP(5);   // barrier passed
@@ -386,7 +387,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     sc = sc * (T)0.5;
     const bool big = QUAT_SERIES ? !(u <= (T)0.0625) : true;
     if (!QUAT_SERIES || __ballot(big) != 0) {   // the closed form (with its own two-term series next to th = 0, as in rounds 1-4)
-      const T th = th2 > (T)0 ? th2 * rsqrt_t(th2) : (T)0;
+      const T th = th2 > (T)0 ? th2 * rsqrt_sel<FASTR>(th2) : (T)0;
       T sn, cs;
       sincos_t(th * (T)0.5, &sn, &cs);
       const bool small = th <= (T)1e-8;

@@ -114,7 +114,7 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 
   T qx, qy, qz, qw;
   {
-    const T n = rsqrt_t(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    const T n = rsqrt_sel<SIMG>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
   M3<T> R;
