@@ -635,6 +635,9 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
 
   // ------------------------------------------------------------------ return sweep
   T p_leg[3], ct_leg[3], g_leg[3], taup[3] = {0, 0, 0};
+  // (persistent rollout: h goes to the integrator through the LDS image `hres`; the caller's buffer gets the LAST tick's -- SweepArgs::skip_mats -- and the three
+  //  guarded stores inside the return sweep were ~0.15 us of the rnea role, the tick's critical chain)
+  const bool h_mem = !(hres != nullptr && a.skip_mats != 0);
   V3<T> dft = mk<T>(CS(129), CS(130), CS(131));
   V3<T> jc[3];
   SF<T> facc, aacc, macc, gacc;
@@ -677,10 +680,10 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
         asm volatile("" : "+s"(jp));
         const unsigned jx_k = ((unsigned)(jp >> (12 * leg)) >> (4 * k)) & 15u;
         const unsigned jxN_k = jx_k * N32;
-        STLX(a.h, 6, 0, jxN_k, hk);
+        if (h_mem) STLX(a.h, 6, 0, jxN_k, hk);
         if (hres) hres[(6 + (int)jx_k) * 16 + (int)(tx & 15)] = hk;
 #else
-        STLX(a.h, 6, 0, jxN[k], hk);
+        if (h_mem) STLX(a.h, 6, 0, jxN[k], hk);
         if (hres) hres[(6 + jx[k]) * 16 + (int)(tx & 15)] = hk;
 #endif
       }
@@ -735,8 +738,10 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     const V3<T> bfn = xrow_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);
     const V3<T> bff = xrow_sum(facc.f) + mk<T>(pb[BLOCK * 3], pb[BLOCK * 4], pb[BLOCK * 5]);
     const V3<T> hb_f = mul(R, bff), hb_n = mul(R, bfn);
-    ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
-    if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
+    if (h_mem) {
+      ST4(a.h, 0, hb_f.x, 1, hb_f.y, 2, hb_f.z, 3, hb_n.x);
+      if (leg < 2) STV(a.h, 4 + leg, leg == 0 ? hb_n.y : hb_n.z);
+    }
     if (hres) {
       hres[sel4<int>(leg, 0, 1, 2, 3) * 16 + (int)(tx & 15)] = sel4<T>(leg, hb_f.x, hb_f.y, hb_f.z, hb_n.x);
       if (leg < 2) hres[(4 + leg) * 16 + (int)(tx & 15)] = leg == 0 ? hb_n.y : hb_n.z;
