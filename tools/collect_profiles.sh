@@ -13,7 +13,7 @@ done
 for f in bench_driver_flags_steps20 bench_cfg2_n262144_keep_structural bench_cfg2_n4096_keep_structural bench_scale_legs_1rank bench_under_rocprof_cfg4_n262144; do
   [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
 done
-for f in bench_scale_legs_1rank_graph bench_cfg5_h20_n1024_cold bench_cfg5_tracking_h20_n1024_cold bench_cfg5_h20_n4096 bench_cfg5_f32_h20_n1024 qp_general; do
+for f in bench_scale_legs_1rank_graph bench_cfg5_h20_n1024_cold bench_cfg5_tracking_h20_n1024_cold bench_cfg5_h20_n2048 bench_cfg5_f32_h20_n1024 qp_general; do
   [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"
 done
 for f in "$O"/bench_cfg?_n262144_nomats.json; do [ -s "$f" ] && cp "$f" "$P/${T}_$(basename "$f")"; done

@@ -39,7 +39,7 @@ python bench.py --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --
 for c in 2 3 4; do python bench.py --config $c --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 --no-mats > "$O/bench_cfg${c}_n262144_nomats.json" 2>> "$O/bench.err"; done
 python bench.py --config 5 --steps 100 --warmup 10 > "$O/bench_cfg5_h20_n1024.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 100 --warmup 10 --batch 128 > "$O/bench_cfg5_h20_n128.json" 2>> "$O/bench.err"
-python bench.py --config 5 --steps 50 --warmup 5 --batch 4096 --no-cpu > "$O/bench_cfg5_h20_n4096.json" 2>> "$O/bench.err"   # 16 states per workgroup (eight-wavefront layout)
+python bench.py --config 5 --steps 50 --warmup 5 --batch 2048 --no-cpu > "$O/bench_cfg5_h20_n2048.json" 2>> "$O/bench.err"   # 16 states per workgroup (eight-wavefront layout)
 python bench.py --config 5 --dtype f32 --steps 100 --warmup 10 --no-cpu > "$O/bench_cfg5_f32_h20_n1024.json" 2>> "$O/bench.err"
 python bench.py --config 5 --tracking --steps 100 --warmup 10 > "$O/bench_cfg5_tracking_h20_n1024.json" 2>> "$O/bench.err"
 python bench.py --config 5 --steps 20 --warmup 3 --batch 32768 > "$O/bench_cfg5_h20_n32768.json" 2>> "$O/bench.err"
