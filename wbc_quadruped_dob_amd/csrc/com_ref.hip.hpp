@@ -17,7 +17,7 @@
 namespace wbc {
 
 // EXT (persistent rollout kernel, fused_tick.hip.hpp): one wavefront of a larger workgroup, tables already in LDS.
-template <class T, bool EXT, int SPW = 16>
+template <class T, bool EXT, int SPW = 16, bool SIMG = false>   // SIMG: role of a rollout workgroup that keeps states / plans / references in LDS
 WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const DevRefParams<T>* __restrict__ G, const RefArgs<T>& a,
                                 const T* cst_ext) {
   __shared__ T cst_own[EXT ? 1 : CST_WORDS];
@@ -39,7 +39,7 @@ WBC_DEV void com_reference_body(const DevModel<T>* __restrict__ model, const Dev
 #define RLDU(ptr, comp) (*(const T*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define RLDV(ptr, comp) (*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
 #define RSTV(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
-  constexpr bool SIMG = EXT && SPW == 4 && WBC_RO_MERGE != 0;   // the state from the workgroup's LDS image (WBC_STATE_MACROS, dyn_split.hip.hpp)
+  static_assert(!SIMG || EXT, "the LDS images belong to the rollout kernel's roles");   // (the state from the workgroup's LDS image: WBC_STATE_MACROS, dyn_split.hip.hpp)
   const T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
   T qb[7], vb[6], pl[PLAN_WORDS];
 #pragma unroll

@@ -45,10 +45,10 @@ namespace wbc {
   const bool live = slot_ok && s_raw < N;                                                                                  \
   unsigned s32 = (unsigned)(live ? s_raw : (slot_ok ? N - 1 : (size_t)blockIdx.x * SPW));                                  \
   const unsigned legN = (unsigned)leg * N32;
-// the state (q, v): from memory, or -- roles of 4-state rollout workgroups, WBC_RO_MERGE -- from the workgroup's LDS image (device_types.hpp, SIMG_*),
+// the state (q, v): from memory, or -- roles of the rollout workgroups that keep their states on chip, EXT = 3 -- from the workgroup's LDS image (device_types.hpp, SIMG_*),
 // indexed by the slot of the state the lane COMPUTES (dead lanes duplicate a state of their own workgroup).  Needs jx / jxN in scope for the joint rows.
 #define WBC_STATE_MACROS                                                                                                                          \
-  constexpr bool SIMG = EXT != 0 && SPW == 4 && WBC_RO_MERGE != 0;                                                                                \
+  constexpr bool SIMG = EXT == 3;   /* role of a rollout workgroup that keeps its states in LDS (EXT = 3: like 1, plus the image) */                  \
   const T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;                                               \
   auto ldq = [&](int comp) __attribute__((always_inline)) -> T { if constexpr (SIMG) return si_[comp * 16]; else return LDU(a.q, comp); };         \
   auto ldv = [&](int comp) __attribute__((always_inline)) -> T { if constexpr (SIMG) return si_[(SIMG_V + comp) * 16]; else return LDU(a.v, comp); }; \

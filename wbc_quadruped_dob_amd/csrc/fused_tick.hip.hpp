@@ -199,8 +199,16 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
 #ifndef WBC_RO_MERGE_OBS
 #define WBC_RO_MERGE_OBS 1
 #endif
+// WBC_RO_MERGE16: the same re-ordering for the 16-state workgroups (1 025 ... 11 264 rollouts) as far as it carries over -- the integrator's phase 2 on QP
+// wavefront 0 behind all four QPs, phase 1 on the mass_jac wavefront, one barrier per tick, states / torques / references in LDS, outputs in the last tick
+// only.  Eight (observer off: six) wavefronts remain, i.e. two per SIMD and 256 registers; the recursions stay one after the other (all 16 slots are states).
+#ifndef WBC_RO_MERGE16
+#define WBC_RO_MERGE16 1
+#endif
 __host__ __device__ constexpr int rollout_threads(bool observer, int spw) {
-  return (spw == 4 && WBC_RO_MERGE != 0) ? ((observer && WBC_RO_MERGE_OBS == 3) ? 320 : 256) : (observer ? 512 : 448);
+  return (spw == 4 && WBC_RO_MERGE != 0) ? ((observer && WBC_RO_MERGE_OBS == 3) ? 320 : 256)
+       : (spw == 16 && WBC_RO_MERGE16 != 0) ? (observer ? 512 : 384)   // QP x 4, rnea, mass_jac [, observer base rows, joint rows]: no integrator wavefront
+       : (observer ? 512 : 448);
 }
 template <class T, bool OBSERVER, bool TRACK, int SPW = 16, bool WARM = false>
 __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm,
@@ -209,19 +217,21 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready, gready, oready, mready, rready, fready;
+  __shared__ int ready, gready, oready, mready, rready, fready, qdone;   // (qdone, MERGE: QP wavefronts whose tau, f of this tick are in the result image)
   __shared__ int rpack;   // (QpSync::rp_ack: QP wavefronts that have read r_prev in this tick, counted over the ticks)
   // MERGE (round 5, 4-state workgroups): FOUR wavefronts instead of eight -- one per SIMD, so each may use the SIMD's whole register file (512 with the
   // accumulation registers: the 8-wavefront kernel sat at 256 and spilled into the tick's critical phases) -- and the tick's critical chain on ONE of them:
   //   wavefront 0  [planner,] QP, then the integrator's phase 2 right behind the torque map: no barrier and no trip through memory between them
   //   wavefront 1  rnea role        wavefront 2  mass_jac role, then the integrator's phase 1 on its own image        wavefront 3  observer: base rows, then joint rows
   // One barrier per tick (the state of the next one) instead of two; q and v stay in an LDS image (device_types.hpp, SIMG_*) from tick to tick.
-  constexpr bool MERGE = SPW == 4 && WBC_RO_MERGE != 0;
+  constexpr bool MERGE = (SPW == 4 && WBC_RO_MERGE != 0) || (SPW == 16 && WBC_RO_MERGE16 != 0);
+  constexpr int REXT = MERGE ? 3 : 1;   // the roles' EXT: 3 = states from the LDS image (dyn_split.hip.hpp, WBC_STATE_MACROS)
   // (MERGE) the observer wavefront runs the WHOLE update in one pass (PART 0: both sets of rows share the sweeps) instead of the base rows and then the joint
   // rows as two passes (-DWBC_RO_MERGE_OBS=2: measured, the joint rows then arrive behind the rnea role and the fp64 tick waits for them -- 11.8 against
   // 11.1 us per tick for the eight-wavefront layout; profiles/r05o_ab_rollout_merge.log)
-  constexpr bool OBS_ONE = MERGE && WBC_RO_MERGE_OBS == 1;
-  constexpr bool OBS_FIFTH = MERGE && OBSERVER && FUSED_OBS_WAVES == 2 && WBC_RO_MERGE_OBS == 3;
+  constexpr bool OBS_ONE = MERGE && SPW == 4 && WBC_RO_MERGE_OBS == 1;
+  constexpr bool OBS_FIFTH = MERGE && OBSERVER && FUSED_OBS_WAVES == 2 && (SPW == 16 || WBC_RO_MERGE_OBS == 3);   // joint rows on their own wavefront
+  constexpr int W_JOINT = SPW == 16 ? 7 : 4;
 #ifndef WBC_RO_NOJC
 #define WBC_RO_NOJC 1   // (four-wavefront layout) 1: the fp64 rnea role does not propagate the own-leg Jacobian blocks -- the torque map takes them from the mass_jac
 #endif                  // role's image (RS_NOJC): 9.33 -> 9.23 us per tick at 1 024 robots, 128 robots 9.13 -> 9.01; fp32 7.57 -> 7.62 and cold 15.75 -> 15.86, hence
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   constexpr int QP_WAVES = SPW / 4;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; fready = 0; rpack = 0; }
+  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; fready = 0; qdone = 0; rpack = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   // -DWBC_RO_PRIO=1: the rnea role -- the chain a rollout tick waits for (tools/ro_knock.sh) -- at a higher issue priority than QP wavefront 0, its SIMD-mate
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #endif
   if constexpr (WBC_RO_PRIO != 0) { if (wave == 4) __builtin_amdgcn_s_setprio(3); }
   constexpr int WINT = MERGE ? -1 : (OBSERVER ? 7 : 6);   // the integrator wavefront (MERGE: none -- phase 1 on the mass_jac wavefront, phase 2 on the QP's)
-  constexpr int W_RNEA = MERGE ? 1 : 4, W_MJ = MERGE ? 2 : 5, W_OBS = MERGE ? 3 : 6;
+  constexpr int W_RNEA = (MERGE && SPW == 4) ? 1 : 4, W_MJ = (MERGE && SPW == 4) ? 2 : 5, W_OBS = (MERGE && SPW == 4) ? 3 : 6;
   // Workgroups of 4 states (SPW = 4) use QP wavefront 0 only; wavefronts 1..3 idle through the kernel and can take the two roles the
   // integrator wavefront runs in front of its factorisation: the observer's joint rows (WBC_RO_JOINT_WAVE) and the planner (WBC_RO_PLAN_WAVE).
   // -1 = the integrator wavefront keeps the role (always so with 16 states per workgroup).  Measured placements: docs/DESIGN_R04.md 8.0a; round 5: DESIGN.md 4.7.
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   constexpr int H_WAVE = (SPW == 4 && !MERGE) ? WBC_RO_H_WAVE : -1;
   constexpr int INT_WAVE = (SPW == 4 && !MERGE) ? WBC_RO_INT_WAVE : -1;   // the integrator itself on an idle QP wavefront (the aux wavefront keeps the roles not moved)
   constexpr int JOINT_WAVE = (OBSERVER && FUSED_OBS_WAVES == 2 && SPW == 4 && !MERGE) ? WBC_RO_JOINT_WAVE : -1;
-  constexpr int PLAN_WAVE = (TRACK && SPW == 4) ? (MERGE ? 0 : WBC_RO_PLAN_WAVE) : -1;   // (MERGE: in front of the QP, whose first input -- the lever arms -- the rnea role
+  constexpr int PLAN_WAVE = (TRACK && MERGE) ? 0 : ((TRACK && SPW == 4) ? WBC_RO_PLAN_WAVE : -1);   // (MERGE: in front of the QP, whose first input -- the lever arms -- the rnea role
                                                                                          // publishes only after it has waited for these references)
   T* const traj0 = ia.tau_traj;
   T* const com0 = ra.com;
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         rt.skip_out = (MERGE && t < horizon - 1) ? 1 : 0;   // (the caller finds the LAST tick's references in its w_des / vdot_des buffers)
         rt.t = (T)t * prm.dt + ra.t;
         rt.com = com0 ? com0 + (size_t)t * 6 * (size_t)n_tick : nullptr;
-        com_reference_body<T, true, SPW>(model, G, rt, cst);
+        com_reference_body<T, true, SPW, MERGE>(model, G, rt, cst);
         if constexpr (MERGE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // w_des, vdot_des are in the LDS image ...
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
       if constexpr (OBSERVER && FUSED_OBS_WAVES == 2) {
         // the JOINT rows of the observer update (rhat_joint, which the QP needs only in its torque map); wave 6 is left with the base rows,
         // whose rhat_base the QP's b waits for
-        observer_body<T, 64, 1, 2, SPW>(model, prm, at, cst, wsl);
+        observer_body<T, 64, REXT, 2, SPW>(model, prm, at, cst, wsl);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #define WBC_RO_LANE2 1
 #endif
       constexpr int RNEA_MODE = (H_WAVE >= 0 ? RS_STEP : ((SPW == 4 && WBC_RO_LANE2) ? (RS_STEP | RS_H | RS_LANE2) : (RS_STEP | RS_H))) | (NOJC ? RS_NOJC : 0) | ((MERGE && TRACK) ? RS_REFIMG : 0);
-      rnea_step_body<T, RNEA_MODE, 64, 1, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
+      rnea_step_body<T, RNEA_MODE, 64, REXT, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         RSTAMP(1);   // (WBC_RO_STAMP_ALT) mass_jac: image published
         // phase 1 of the integrator, on my own image (my own LDS words: program order of one lane); the factors are complete when this wavefront
         // reaches the tick barrier, behind which the integrator wavefront reads them
-        if constexpr (SPLIT_INT) integrate_body<T, SPW, IntegrateNoWait, 1, (WBC_RO_INT_UNGUARD != 0), true, false>(model, ia1, IntegrateNoWait(), handp, nullptr, factp);
+        if constexpr (SPLIT_INT) integrate_body<T, SPW, IntegrateNoWait, 1, (WBC_RO_INT_UNGUARD != 0), true, false, IntegrateNoWait, MERGE>(model, ia1, IntegrateNoWait(), handp, nullptr, factp);
         if constexpr (MERGE) {   // the factors are in LDS: wavefront 0 may start phase 2
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
           if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(fflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
       };
       // (the M / Jc / pf stores to HBM come BEHIND the flag, from the image, and only in the launch's last tick: nothing in this kernel reads them)
       if constexpr ((WBC_RO_KNOCK & 4) != 0) publish();
-      else mass_jac_body<T, 64, 1, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
+      else mass_jac_body<T, 64, REXT, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
     } else if (OBSERVER && wave == W_OBS) {
       if constexpr (OBSERVER) {
         int* const ack = &rpack;
@@ -492,19 +502,19 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(stage == 0 ? oflag : jflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           };
-          observer_body<T, 64, 1, 0, SPW, decltype(wait_ack), decltype(rows_out)>(model, prm, at, cst, wsl, wait_ack, rows_out);
+          observer_body<T, 64, REXT, 0, SPW, decltype(wait_ack), decltype(rows_out)>(model, prm, at, cst, wsl, wait_ack, rows_out);
           RSTAMP(10);
         } else {
         if constexpr ((WBC_RO_KNOCK & 8) != 0) {}
-        else if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 1, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
-        else observer_body<T, 64, 1, 0, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);
+        else if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, REXT, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
+        else observer_body<T, 64, REXT, 0, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         RSTAMP(10);
         }
         if constexpr (MERGE && FUSED_OBS_WAVES == 2 && !OBS_ONE && !OBS_FIFTH) joint_rows_role();   // (-DWBC_RO_MERGE_OBS=2) ... then the joint rows, which the torque map needs ~3 us later
       }
-    } else if (OBS_FIFTH && wave == 4) {
+    } else if (OBS_FIFTH && wave == W_JOINT) {
       joint_rows_role();
     } else {
       constexpr int NFIN = (OBSERVER && (FUSED_OBS_WAVES == 2 || OBS_ONE)) ? 2 : 1;   // rnea role (+ the observer's joint rows, run by the integrator wavefront)
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #endif
       if constexpr (NOJC) { sy.hand = mj_hand; sy.hand_flag = &mready; sy.need_hand = t + 1; }
       sy.skip_out = MERGE && WBC_RO_SKIP_OUT && t < horizon - 1;   // (the LAST tick's are what the caller finds, as with per-tick launches)
-      if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, 1, SPW>(model, prm, at, cst, wsl, NoWait(), NoWait(), res_img ? res_img + RES_H * 16 : nullptr); }   // bias forces h
+      if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, REXT, SPW>(model, prm, at, cst, wsl, NoWait(), NoWait(), res_img ? res_img + RES_H * 16 : nullptr); }   // bias forces h
       if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }
       if constexpr (JOINT_WAVE >= 0) { if (wave == JOINT_WAVE) joint_rows_role(); }
       if constexpr (INT_WAVE >= 0) { if (wave == INT_WAVE) { integrator_role(); continue; } }
@@ -529,8 +539,15 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_sh[(threadIdx.x & 255) >> 4]);
       } else
       if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
+      if constexpr (MERGE && QP_WAVES > 1) {   // (16 states: four QP wavefronts fill the result image; phase 2 runs behind all of them)
+        if (wave * 4 < SPW) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&qdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
       if constexpr (MERGE) {
         if (wave == 0) {   // phase 2 of the integrator, on the wavefront that has just written tau and f to the LDS image (its own LDS traffic: program order)
+          if constexpr (QP_WAVES > 1) { while (__hip_atomic_load(&qdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < QP_WAVES * (t + 1)) __builtin_amdgcn_s_sleep(1); }
           while (__hip_atomic_load(&fready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);   // M's blocks and the factors
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
           iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
@@ -543,12 +560,12 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #endif
           if constexpr (WBC_RO_EARLY_BARRIER != 0) {
             auto state_out = [] __device__() { __syncthreads(); };   // <- the tick's barrier, for this wavefront
-            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true, decltype(state_out)>(model, iat, IntegrateNoWait(), mj_hand, res_img,
+            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true, decltype(state_out), true>(model, iat, IntegrateNoWait(), mj_hand, res_img,
                                                                                                                   fact_sh, state_out);
             RSTAMP(8);
             continue;
           } else {
-            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true>(model, iat, IntegrateNoWait(), mj_hand, res_img, fact_sh);
+            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true, IntegrateNoWait, true>(model, iat, IntegrateNoWait(), mj_hand, res_img, fact_sh);
             RSTAMP(8);
           }
         }

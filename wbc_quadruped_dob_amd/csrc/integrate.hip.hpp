@@ -47,12 +47,12 @@ constexpr int INT_FACT_WORDS = 27;
 // still issues its stores.  Measured (profiles/r05q_ab_rollout_early_barrier.log): 9.39-9.47 -> 9.48-9.52 us per tick at 1 024 robots, cold 15.71 -> 15.97:
 // not kept (-DWBC_RO_EARLY_BARRIER=1).
 template <class T, int SPW = 16, class Between = IntegrateNoWait, int PHASE = 0, bool UNGUARD = false, bool HAND = false, bool RESI = false,
-          class AfterState = IntegrateNoWait>
+          class AfterState = IntegrateNoWait, bool SIMG_ = false>
 WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const IntegrateArgs<T>& a, Between between = Between(), const T* hand_ = nullptr,
                             const T* res_ = nullptr, T* fact = nullptr, AfterState after_state = AfterState()) {
   static_assert(PHASE == 0 || PHASE == 1 || PHASE == 2, "phase");
   static_assert(PHASE == 0 || HAND, "the split phases hand M's blocks over in LDS");
-  constexpr bool FASTR = PHASE != 0 && SPW == 4 && WBC_RO_MERGE != 0;   // (4-state rollout workgroups) rsqrt_fast, see dyn_sweep.hip.hpp
+  constexpr bool FASTR = PHASE != 0 && SIMG_;   // (rollout workgroups with the state image) rsqrt_fast, see dyn_sweep.hip.hpp
   const T* const hand = HAND ? hand_ : nullptr;
   const T* const res = RESI ? res_ : nullptr;
   const size_t N = a.N;
@@ -212,7 +212,7 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   // the state of this tick (q, v: inputs of the tick, untouched until the stores at the end) is requested BEFORE the tick barrier: the loads
   // complete while the wavefront waits there instead of after it
   // (4-state rollout workgroups, WBC_RO_MERGE: the state lives in the workgroup's LDS image -- device_types.hpp, SIMG_* -- and the new one goes to both)
-  constexpr bool SIMG = PHASE == 2 && SPW == 4 && WBC_RO_MERGE != 0;
+  constexpr bool SIMG = PHASE == 2 && SIMG_;
   T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
 #define STS(comp, val) do { if constexpr (SIMG) si_[(comp) * 16] = (val); } while (0)
   constexpr bool DEFER = SIMG && !std::is_same<AfterState, IntegrateNoWait>::value;   // (see after_state)

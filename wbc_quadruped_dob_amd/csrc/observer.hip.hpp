@@ -63,7 +63,7 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
   // rhat: HBM workspace (stand-alone kernel) or the workgroup's LDS image (role)
 #define ORHAT(comp, val) do { if constexpr (EXT != 0) wsl[(comp) * 16 + (int)(tx & 15)] = (val); else OSTV(a.ws, comp, val); } while (0)
   // state loads first, table staging while they are in flight (4-state rollout workgroups: the state is in LDS, see WBC_STATE_MACROS in dyn_split.hip.hpp)
-  constexpr bool SIMG = EXT != 0 && SPW == 4 && WBC_RO_MERGE != 0;
+  constexpr bool SIMG = EXT == 3;
   const T* const si_ = SIMG ? a.simg + (int)(s32 - (unsigned)((size_t)blockIdx.x * SPW)) : nullptr;
   T qq[4], vb[6];
 #pragma unroll
@@ -251,7 +251,10 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
     }
   } else {
   if (prm.observer_order > 0) {
-    const V3<T> fp = mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
+    // (SIMG: tau_prev, f_prev are the rows the previous tick's QP left in the workgroup's result image -- nothing of them is in memory before the last tick)
+    const T* const rimg = SIMG ? a.resimg + (si_ - a.simg) : nullptr;
+    const V3<T> fp = SIMG ? mk<T>(rimg[(RES_F + 3 * leg + 0) * 16], rimg[(RES_F + 3 * leg + 1) * 16], rimg[(RES_F + 3 * leg + 2) * 16])
+                          : mk<T>(OLDV(a.f_prev, 3 * leg + 0), OLDV(a.f_prev, 3 * leg + 1), OLDV(a.f_prev, 3 * leg + 2));
     const T dt = prm.dt;
     const bool o1 = prm.observer_order == 1;
     if constexpr (BASE) {
@@ -278,7 +281,7 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
     for (int k = 0; k < (JOINTS ? 3 : 0); ++k) {
       const int c = 6 + jx[k];
       const T r0 = OLDV(a.obs_r, c);
-      const T u = OLDV(a.tau_prev, jx[k]) + dot(jw[k], fp);
+      const T u = (SIMG ? rimg[(RES_TAU + jx[k]) * 16] : OLDV(a.tau_prev, jx[k])) + dot(jw[k], fp);
       const T ig = OLDV(a.obs_integ, c) + dt * (u + beta_l[k] + r0);
       const T e = p_leg[k] - ig;
       T k1 = prm.K1[6], k2 = prm.K2[6];   // gains of joint row c by a select (no run-time index into the kernel arguments)

@@ -708,7 +708,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
       if (from_hand) {
-        const int hslot = 16 * f + (int)((tx >> 4) & 3);
+        const int hslot = 16 * f + (int)((tx >> 4) & 15);   // (my state's slot in the workgroup)
         jl0 = (T)hand_img[(24 + c3) * 64 + hslot]; jl1 = (T)hand_img[(27 + c3) * 64 + hslot]; jl2 = (T)hand_img[(30 + c3) * 64 + hslot];
       } else if (geom_jc) {
         jl0 = GLD(a.Jc, (3 * f + 0) * 18 + 6 + jm); jl1 = GLD(a.Jc, (3 * f + 1) * 18 + 6 + jm); jl2 = GLD(a.Jc, (3 * f + 2) * 18 + 6 + jm);
