@@ -77,6 +77,9 @@ namespace wbc {
     R_.a[3] = 2 * (x * y + z * w);     R_.a[4] = 1 - 2 * (x * x + z * z); R_.a[5] = 2 * (y * z - x * w); \
     R_.a[6] = 2 * (x * z - y * w);     R_.a[7] = 2 * (y * z + x * w);     R_.a[8] = 1 - 2 * (x * x + y * y); } while (0)
 
+#ifndef WBC_FUSED_RNEA_FASTR
+#define WBC_FUSED_RNEA_FASTR 0   // (A/B) 1: the one-launch tick's rnea role normalises the quaternion with rsqrt_fast: lever arms ~0.2 us earlier
+#endif
 #ifndef WBC_MJ_WAVES
 #define WBC_MJ_WAVES 2
 #endif
@@ -489,7 +492,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   }
   T qx, qy, qz, qw;
   {
-    const T n = rsqrt_sel<SIMG>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    const T n = rsqrt_sel<(SIMG || (WBC_FUSED_RNEA_FASTR && EXT == 2))>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
   T sn3[3] = {0, 0, 0}, cs3[3] = {0, 0, 0};

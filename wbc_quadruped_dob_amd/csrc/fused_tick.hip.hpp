@@ -100,6 +100,8 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
 #endif
   if constexpr (WBC_FUSED_PRIO == 1) { if (wave < 4) __builtin_amdgcn_s_setprio(3); }
   if constexpr (WBC_FUSED_PRIO == 2) { if (wave == 4) __builtin_amdgcn_s_setprio(3); }
+  if constexpr (WBC_FUSED_PRIO == 3) { if (wave != 5) __builtin_amdgcn_s_setprio(2); }   // 3: everybody above the mass_jac role, whose output nobody in the kernel waits for
+  if constexpr (WBC_FUSED_PRIO == 4) { if (wave < 4) __builtin_amdgcn_s_setprio(3); else if (wave == 4) __builtin_amdgcn_s_setprio(2); }   // 4: QP > rnea > mass_jac
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the pf output carries the role timestamps (slot, workgroup) instead of foot positions
   double* const stamp = (double*)a.pf;
   const unsigned stampN = (unsigned)a.N;
