@@ -157,6 +157,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #define GLD(ptr, comp) ((T)(*(const TS*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS)))))
 #define WSLD(comp) (WSLDS ? (T)wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
 #define BLD(c) (WSLDS ? (T)wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
+#ifndef WBC_QP_CONS_EARLY
+#define WBC_QP_CONS_EARLY 1
+#endif
 #define GST(ptr, comp, val) (*(TS*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS))) = (TS)(val))
 
 #ifdef WBC_QP_STAMP
@@ -175,6 +178,32 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   if constexpr (WARM == 2) aset = *carry;
   WBC_QSTAMP(1);
   idle();
+  // ------------------------------------------------------------------ my constraints (friction pyramid, force box): as in qp_group16_body.
+  // They need the normals and mu only: the kernels that wait for the lever arms (WSLDS: one-launch tick, rollouts) form them in front of that wait
+  // (13.3 -> 13.2 us at 4 096 states; -DWBC_QP_CONS_EARLY=0: behind the factor, as the stand-alone kernels keep it -- there the early form costs 0.8 %)
+  constexpr bool CONS_EARLY = WBC_QP_CONS_EARLY != 0 && WSLDS && WARM == 0;   // (the warm observer-on tick sits at 255 registers: the rows held across the wait spill there)
+  T cAx, cAy, cAz, rA, cBx = 0, cBy = 0, cBz = 0;
+  const bool hasB = c3 < 2;
+#define WBC_QP_FORM_ROWS do { \
+    T nx = dppx<0x00>(n_ld), ny = dppx<0x55>(n_ld), nz = dppx<0xAA>(n_ld); \
+    const T iln = rsqrt_nr(nx * nx + ny * ny + nz * nz); \
+    nx *= iln; ny *= iln; nz *= iln; \
+    const bool usex = fabs_t(nx) < (T)0.9; \
+    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1; \
+    const T rd = rx * nx + ry * ny; \
+    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd; \
+    const T it = rsqrt_nr(t1x * t1x + t1y * t1y + t1z * t1z); \
+    t1x *= it; t1y *= it; t1z *= it; \
+    const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x; \
+    const T mt = mu_f * prm.mu_scale; \
+    const T ttx = (c3 == 0) ? t1x : t2x, tty = (c3 == 0) ? t1y : t2y, ttz = (c3 == 0) ? t1z : t2z; \
+    if (hasB) { \
+      cAx = mt * nx - ttx; cAy = mt * ny - tty; cAz = mt * nz - ttz; rA = 0; \
+      cBx = mt * nx + ttx; cBy = mt * ny + tty; cBz = mt * nz + ttz; \
+    } else if (c3 == 2) { cAx = nx; cAy = ny; cAz = nz; rA = prm.fn_min; } \
+    else { cAx = -nx; cAy = -ny; cAz = -nz; rA = -prm.fn_max; } \
+  } while (0)
+  if constexpr (CONS_EARLY) WBC_QP_FORM_ROWS;
   if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
   WBC_QSTAMP(2);
   T d_me = 0;
@@ -215,28 +244,8 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     w2 = onf * (s2 * y[2]) + (m0 * dqy - m1 * dqx);
   };
 
-  // ------------------------------------------------------------------ my constraints (friction pyramid, force box): as in qp_group16_body
-  T cAx, cAy, cAz, rA, cBx = 0, cBy = 0, cBz = 0;
-  const bool hasB = c3 < 2;
-  {
-    T nx = dppx<0x00>(n_ld), ny = dppx<0x55>(n_ld), nz = dppx<0xAA>(n_ld);
-    const T iln = rsqrt_nr(nx * nx + ny * ny + nz * nz);
-    nx *= iln; ny *= iln; nz *= iln;
-    const bool usex = fabs_t(nx) < (T)0.9;
-    const T rx = usex ? (T)1 : (T)0, ry = usex ? (T)0 : (T)1;
-    const T rd = rx * nx + ry * ny;
-    T t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
-    const T it = rsqrt_nr(t1x * t1x + t1y * t1y + t1z * t1z);
-    t1x *= it; t1y *= it; t1z *= it;
-    const T t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
-    const T mt = mu_f * prm.mu_scale;
-    const T ttx = (c3 == 0) ? t1x : t2x, tty = (c3 == 0) ? t1y : t2y, ttz = (c3 == 0) ? t1z : t2z;
-    if (hasB) {
-      cAx = mt * nx - ttx; cAy = mt * ny - tty; cAz = mt * nz - ttz; rA = 0;
-      cBx = mt * nx + ttx; cBy = mt * ny + tty; cBz = mt * nz + ttz;
-    } else if (c3 == 2) { cAx = nx; cAy = ny; cAz = nz; rA = prm.fn_min; }
-    else { cAx = -nx; cAy = -ny; cAz = -nz; rA = -prm.fn_max; }
-  }
+  if constexpr (!CONS_EARLY) WBC_QP_FORM_ROWS;
+#undef WBC_QP_FORM_ROWS
   // per-lane state of the active set: row c3 of P_k, slot c3 of foot k (N^+ row, multiplier, constraint id), |active set of foot k|
   T Pr0 = c3 == 0 ? (T)1 : (T)0, Pr1 = c3 == 1 ? (T)1 : (T)0, Pr2 = c3 == 2 ? (T)1 : (T)0;
   T Np0 = 0, Np1 = 0, Np2 = 0, u_s = 0;
