@@ -97,10 +97,11 @@ def _gpu_tracking(torch, solver, H, B, plan, tau_ext, integ, r, want_com=True):
     return res
 
 
-@pytest.mark.parametrize("cfg,obs,n,H", [(3, 1, 1000, 20), (4, 2, 257, 9), (2, 0, 64, 20)])
-def test_tracking_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H):
+@pytest.mark.parametrize("cfg,obs,n,H,spw", [(3, 1, 1000, 20, 0), (4, 2, 257, 9, 0), (2, 0, 64, 20, 0), (3, 1, 301, 7, 16), (2, 0, 1100, 5, 0), (4, 2, 37, 3, 16)])
+def test_tracking_rollout_vs_oracle(torch_cuda, gpu_model, oracle, cfg, obs, n, H, spw):
+    """(spw = 16, or more than 1 024 rollouts: the 16-state workgroups of the persistent kernel -- planner on QP wavefront 0, references through LDS)"""
     torch = torch_cuda
-    solver, P, G = _solver(gpu_model, obs=obs, max_batch=n)
+    solver, P, G = _solver(gpu_model, obs=obs, max_batch=n, options={"rollout_spw": spw} if spw else None)
     B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=43)
     plan = synth.make_plan(B, rank=43)
     tau_ext = np.zeros((n, 18)); tau_ext[:, 0:3] = B["push"]
