@@ -165,7 +165,7 @@ WBC_DEV void structural_consts_quarter(const DevModel<T>* __restrict__ model, co
 // store instruction costs ~90 cycles to issue whatever its width (tools/issue_probe.hip): they were ~2 us of the mass_jac -> factorisation chain.
 constexpr int MJ_HAND_WORDS = 46;
 struct MjNoHook { WBC_DEV void operator()() const {} };
-template <class T, int BLOCK, int EXT, int SPW = 16, bool ZEROS = true, class AfterHand = MjNoHook>
+template <class T, int BLOCK, int EXT, int SPW = 16, int ZEROS = 1, class AfterHand = MjNoHook>   // ZEROS: 0 = other wavefronts write the structural constants, 1 = first, 2 = LAST (behind the data: fused_tick.hip.hpp)
 WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext, T* hand = nullptr,
                            AfterHand after_hand = AfterHand()) {
   static_assert(!EXT || BLOCK == 64, "one wavefront");
@@ -197,8 +197,8 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   for (int k = 0; k < 3; ++k) ql[k] = LDQJ(k);
   if constexpr (EXT == 2) __syncthreads();   // tables staged by the other wavefronts while my loads are in flight
 
-  // structural zeros / ones first: they drain while the sweeps compute (ZEROS = false: other wavefronts write them)
-  if (ZEROS && !a.skip_consts) {
+  // structural zeros / ones first: they drain while the sweeps compute (ZEROS = 0: other wavefronts write them; 2: last, see the end of the body)
+  auto write_consts = [&]() __attribute__((always_inline)) {
     const T Z = (T)0;
     for (int e = leg; e < 64; e += 4) {
       const int zi = zidx_s[e];
@@ -213,7 +213,8 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
       for (int c = 0; c < 12; ++c)
         if (c != jx[0] && c != jx[1] && c != jx[2]) STL(a.Jc, 18 * mrow + 6 + c, 54, Z);   // own-leg columns get data below
     }
-  }
+  };
+  if constexpr (ZEROS == 1) { if (!a.skip_consts) write_consts(); }
   T qx, qy, qz, qw;
   {
     const T n = rsqrt_sel<SIMG>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
@@ -383,6 +384,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
       if (leg < 3) STV(M, sel4<int>(leg, midx18(4, 4), midx18(4, 5), midx18(5, 5), 0), sel4<T>(leg, hl[43 * 64], hl[44 * 64], hl[45 * 64], hl[45 * 64]));
     }
   }
+  if constexpr (ZEROS == 2) { if (!a.skip_consts) write_consts(); }   // (own-leg columns were written above: the constants never overlap them)
 }
 
 template <class T, int BLOCK>

@@ -124,7 +124,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
   } else if (wave == 5) {
-    if constexpr (MATS) mass_jac_body<T, 64, 2, 16, !WBC_FUSED_ZEROS_BY_QP>(model, a, cst, zidx_s);
+    if constexpr (MATS) mass_jac_body<T, 64, 2, 16, (WBC_FUSED_ZEROS_BY_QP == 1 ? 0 : (WBC_FUSED_ZEROS_BY_QP == 2 ? 2 : 1))>(model, a, cst, zidx_s);   // (2: the role writes them LAST)
     else __syncthreads();
     FSTAMP(9);
   } else if (fused_split_h<T, OBSERVER, MATS, WARM>() && wave == 6) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
     QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN};   // the QP waits for each piece where it first needs it
 #endif
     if constexpr (SPEC_ORDER) sy.rp_ack = &rpack;
-#if WBC_FUSED_ZEROS_BY_QP
+#if WBC_FUSED_ZEROS_BY_QP == 1
     if constexpr (MATS) {
       const int* const zs = zidx_s;
       const unsigned tq = threadIdx.x;
