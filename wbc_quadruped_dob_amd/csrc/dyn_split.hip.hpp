@@ -498,6 +498,13 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
   T sn3[3] = {0, 0, 0}, cs3[3] = {0, 0, 0};
+  // (four-wavefront rollout workgroups: the role has its SIMD's whole register file, so the three joint rotations of the early lever-arm chain are KEPT
+  //  for the forward sweep instead of being rebuilt there from the same sin / cos -- 81 multiply-adds off the tick's critical chain; -DWBC_RNEA_KEEP_E=0: rebuilt)
+#ifndef WBC_RNEA_KEEP_E
+#define WBC_RNEA_KEEP_E 1
+#endif
+  constexpr bool KEEP_E = WBC_RNEA_KEEP_E != 0 && EARLY && SIMG && SPW == 4;
+  M3<T> Ekeep[KEEP_E ? 3 : 1];
   if constexpr (EARLY) {
     // The QP waves can assemble and factor H from the four lever arms alone, so those go out ahead of the force
     // recursions: d = r_0 + E_0 (r_1 + E_1 (r_2 + E_2 d_foot)), the same expression the return sweep evaluates (which
@@ -510,10 +517,11 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     for (int k = 2; k >= 0; --k) {
       const int o = JOINT_WORDS * k;
       T s_ = sn3[k], c_ = cs3[k];
-      asm volatile("" : "+v"(s_), "+v"(c_));
+      if constexpr (!KEEP_E) asm volatile("" : "+v"(s_), "+v"(c_));
       M3<T> E;
 #pragma unroll
       for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + c_ * CS(o + 9 + e) + s_ * CS(o + 18 + e);
+      if constexpr (KEEP_E) Ekeep[k] = E;
       d = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29)) + mul(E, d);
     }
     M3<T> R0;
@@ -581,8 +589,11 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     if constexpr (EARLY) { sn = sn3[k]; cs = cs3[k]; }
     else sincos_t(ql[k], &sn, &cs);
     M3<T> E;
+    if constexpr (KEEP_E) E = Ekeep[k];
+    else {
 #pragma unroll
-    for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+      for (int e = 0; e < 9; ++e) E.a[e] = CS(o + e) + cs * CS(o + 9 + e) + sn * CS(o + 18 + e);
+    }
     const V3<T> r = mk<T>(CS(o + 27), CS(o + 28), CS(o + 29));
     const V3<T> ax = mk<T>(CS(o + 30), CS(o + 31), CS(o + 32));
     const T m = CS(o + 33);
