@@ -172,11 +172,16 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
 }
 
 // Persistent rollout (BASELINE.json configs[4]): `horizon` dependent ticks of {tick roles as above, forward
-// dynamics + integrator} in ONE launch.  A workgroup owns its 16 states for the whole horizon, so no tick boundary ever
-// leaves the CU: per tick two workgroup barriers (tau, f, h visible to the integrator wave; q, v visible to the next
-// tick's producers), no launch, no HBM round trip of the workspace.  The integrator is its own wavefront: it factors the
-// arrow matrix beside the QP (that needs only M, Jc, published by the mass_jac role through a flag) and finishes the
-// right-hand sides, solves and state update between the two barriers.
+// dynamics + integrator} in ONE launch.  A workgroup owns its 4 or 16 states for the whole horizon, so no tick boundary ever
+// leaves the CU: no launch, no HBM round trip of the workspace.
+// LAYOUT SINCE ROUND 5 (MERGE below): the integrator's factorisation (phase 1) runs on the mass_jac wavefront behind its LDS
+// image, its right-hand sides / solves / state update (phase 2) on QP wavefront 0 right behind the torque map; ONE barrier per tick; the
+// states, this tick's tau / f / h, the planner's references and plans live in LDS images from tick to tick, and the caller's buffers are
+// written in the launch's last tick only.  4-state workgroups are four wavefronts (one per SIMD: the whole register file each).
+// The text below describes the layout of rounds 1-4 (-DWBC_RO_MERGE=0 -DWBC_RO_MERGE16=0): two workgroup barriers per tick (tau, f, h visible
+// to the integrator wave; q, v visible to the next tick's producers); the integrator is its own wavefront: it factors the arrow matrix
+// beside the QP (that needs only M, Jc, published by the mass_jac role through a flag) and finishes the right-hand sides, solves and
+// state update between the two barriers.
 // tau_prev / f_prev of the observer are the tau / f buffers themselves: the observer role reads them before it raises
 // its flag, the QP waves overwrite them only after both flags.
 // Measured (MI355X, observer on, horizon 20): 33.7 us per tick against 37.2 us for {fused tick + integrate} launches at
