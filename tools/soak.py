@@ -188,7 +188,27 @@ for c in range(cases):
         H = int(rng.integers(2, 12))
         tau_ext = np.zeros((n, 18)); tau_ext[:, 0:3] = B["push"] if cfg > 2 else 5.0
         res = {}
-        for tag, env in (("persistent", {}), ("per_tick", {"rollout_persistent": 0}), ("cold", {"rollout_warm": 0})):   # (the first two start every tick after the first from the previous tick's active set)
+        spw = int(rng.choice([0, 0, 4, 16]))   # (round 5: the persistent kernel's 4- and 16-state workgroups, whatever the batch size)
+        if c % 4 == 1:   # ---- the planner in the loop: persistent against per-tick launches
+            from tests import test_gpu_reference as tr
+            plan = synth.make_plan(B, rank=1000 + c)
+            rt = {}
+            for tag, env in (("persistent", {"rollout_spw": spw} if spw else {}), ("per_tick", {"rollout_persistent": 0})):
+                s, P, G = tr._solver(gm, obs=obs, max_batch=n, options=env)
+                rt[tag] = tr._gpu_tracking(torch, s, H, B, plan, tau_ext, None if integ0 is None else integ0.copy(), np.zeros((n, 18)) if obs else None)
+            a, b = rt["persistent"], rt["per_tick"]
+            ok = (a["status"] == 0) & (b["status"] == 0)   # (far-from-plan random states may saturate a force box: such rows amplify rounding)
+            if not np.array_equal(a["status"], b["status"]):
+                bad.append((c, "tracking status", n, obs, cfg, spw))
+            for k in a:
+                if k == "status" or not ok.any():
+                    continue
+                e = relerr(a[k][ok], b[k][ok])
+                worst = max(worst, e)
+                if not e < 1e-8:
+                    bad.append((c, "tracking " + k, n, obs, cfg, H, spw, e))
+            continue
+        for tag, env in (("persistent", {"rollout_spw": spw} if spw else {}), ("per_tick", {"rollout_persistent": 0}), ("cold", {"rollout_warm": 0})):   # (the first two start every tick after the first from the previous tick's active set)
             s, P = solver_with(env, obs=obs, max_batch=n)
             res[tag] = _gpu_rollout(torch, s, P, H, B, tau_ext, None if integ0 is None else integ0.copy(), np.zeros((n, 18)) if obs else None)
         a, b = res["persistent"], res["cold"]
@@ -209,7 +229,8 @@ for c in range(cases):
                 continue
             e = relerr(a[k], b[k])
             worst = max(worst, e)
-            if not e < 1e-9:
+            if not e < 1e-8:   # (the persistent kernel's roles normalise with rsqrt_fast, the per-tick kernels with 1 / sqrt: 1-2 ulp per tick, compounding through
+                               #  the dynamics over up to 11 ticks -- up to 1e-9 seen; the warm-against-cold comparison above runs the same kernels: 1e-9)
                 bad.append((c, "rollout " + k, n, obs, cfg, H, e))
 print("soak: %d cases (%s), seed %d, %.0f s, worst relative difference between dispatch variants %.2e (tiled vs one-wave QP kernel: %.2e), status flips %d, mismatches: %d %s"
       % (cases, DT, seed, time.time() - t0, worst, worst_big, flips, len(bad), bad[:10]))
