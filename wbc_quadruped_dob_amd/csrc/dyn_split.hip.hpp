@@ -403,9 +403,12 @@ __global__ __launch_bounds__(BLOCK, WBC_MJ_WAVES) void mass_jac_kernel(const Dev
 // in the LDS image -- all the QP needs to assemble and factor H -- and again when the target wrench WS_B (w_des) is; the
 // role counts both on its first flag.
 struct NoWait { WBC_DEV void operator()() const {} };
-template <class T, int MODE, int BLOCK, int EXT, int SPW = 16, class BeforeRefs = NoWait, class AfterGeom = NoWait>
+// `after_taup()` (a real hook only in the four-wavefront rollout workgroups): tau_partial goes to the LDS image -- and the hook raises the QP's flag -- BEFORE the base
+// rows of h are summed over the legs, rotated and written; only the integrator's phase 2, which starts behind the torque map, needs those (the caller raises a second
+// flag behind the body).
+template <class T, int MODE, int BLOCK, int EXT, int SPW = 16, class BeforeRefs = NoWait, class AfterGeom = NoWait, class AfterTaup = NoWait>
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
-                            T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom(), T* hres = nullptr) {
+                            T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom(), T* hres = nullptr, AfterTaup after_taup = AfterTaup()) {
   // hres (persistent rollout): LDS image [..][16] whose rows 0 .. 17 ALSO receive h (the integrator reads it behind an LDS-only barrier)
   static_assert(!EXT || BLOCK == 64, "one wavefront");
   WBC_LAUNDERED_TID(tx);
@@ -749,6 +752,16 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
       }
     }
   }
+  constexpr bool TAUP_FIRST = STEP && !OBS && !OBSW && WH && !std::is_same<AfterTaup, NoWait>::value;
+  if constexpr (TAUP_FIRST) {
+    if constexpr (LANE2) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) taup[k] += dpp_mov<0x12C>(taup[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) WSTL(WS_TAUP + k, 3, taup[k]);
+    after_taup();
+  }
   if (WH) {
     const T* pb = &park[2 * PW][ln];
     const V3<T> bfn = xrow_sum(facc.n) + mk<T>(pb[0], pb[BLOCK], pb[BLOCK * 2]);
@@ -843,12 +856,14 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
         WST4(WS_B + 0, b[0], WS_B + 1, b[1], WS_B + 2, b[2], WS_B + 3, b[3]);
         if (leg < 2) WSTV(WS_B + 4 + leg, leg == 0 ? b[4] : b[5]);
       }
+      if constexpr (!TAUP_FIRST) {
       if constexpr (LANE2) {   // tau_partial = h (my chain, slot s) + M vdot_des (slot s + 4): row_ror:12 hands lane i the value of lane (i + 4) mod 16
 #pragma unroll
         for (int k = 0; k < 3; ++k) taup[k] += dpp_mov<0x12C>(taup[k]);
       }
 #pragma unroll
       for (int k = 0; k < 3; ++k) WSTL(WS_TAUP + k, 3, taup[k] - rl[k]);
+      }
     }
   }
 #undef WSTL

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready, gready, oready, mready, rready, fready, qdone;   // (qdone, MERGE: QP wavefronts whose tau, f of this tick are in the result image)
+  __shared__ int ready, gready, oready, mready, rready, fready, qdone, hready;   // (hready, TAUP_FIRST: the rnea role's h is complete in the result image)   // (qdone, MERGE: QP wavefronts whose tau, f of this tick are in the result image)
   __shared__ int rpack;   // (QpSync::rp_ack: QP wavefronts that have read r_prev in this tick, counted over the ticks)
   // MERGE (round 5, 4-state workgroups): FOUR wavefronts instead of eight -- one per SIMD, so each may use the SIMD's whole register file (512 with the
   // accumulation registers: the 8-wavefront kernel sat at 256 and spilled into the tick's critical phases) -- and the tick's critical chain on ONE of them:
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   constexpr int QP_WAVES = SPW / 4;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
-  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; fready = 0; qdone = 0; rpack = 0; }
+  if (threadIdx.x == 0) { ready = 0; gready = 0; oready = 0; mready = 0; rready = 0; fready = 0; qdone = 0; hready = 0; rpack = 0; }
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   // -DWBC_RO_PRIO=1: the rnea role -- the chain a rollout tick waits for (tools/ro_knock.sh) -- at a higher issue priority than QP wavefront 0, its SIMD-mate
@@ -461,17 +461,38 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #define WBC_RO_LANE2 1
 #endif
       constexpr int RNEA_MODE = (H_WAVE >= 0 ? RS_STEP : ((SPW == 4 && WBC_RO_LANE2) ? (RS_STEP | RS_H | RS_LANE2) : (RS_STEP | RS_H))) | (NOJC ? RS_NOJC : 0) | ((MERGE && TRACK) ? RS_REFIMG : 0);
-      rnea_step_body<T, RNEA_MODE, 64, REXT, SPW>(model, prm, at, cst, wsl, [rflag, rneed] __device__() {
+      auto wait_refs = [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-      }, [gflag] __device__() {
+      };
+      auto geom_out = [gflag] __device__() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }, res_img ? res_img + RES_H * 16 : nullptr);
+      };
+      // (MERGE, 16-state workgroups) tau_partial is handed to the QP BEFORE the base rows of h are summed, rotated and written: only phase 2 of the integrator,
+      // behind the torque map, needs those -- it waits for `hready`.  Measured (profiles/r05zz_ab_rollout_taup_first.log): 2 048 rollouts 12.33 -> 12.11 us
+      // per tick; the 4-state workgroups LOSE with it (8.84 -> 8.96, planner in the loop 11.39 -> 11.51) and keep the one flag behind the whole body
+      // (-DWBC_RO_TAUP_FIRST=2: both; 0: neither)
+#ifndef WBC_RO_TAUP_FIRST
+#define WBC_RO_TAUP_FIRST 1
+#endif
+      constexpr bool TAUP_FIRST = MERGE && (WBC_RO_TAUP_FIRST == 2 || (WBC_RO_TAUP_FIRST == 1 && SPW == 16));
+      if constexpr (TAUP_FIRST) {
+        int* const finflag = &ready;
+        auto taup_out = [finflag] __device__() {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+          if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(finflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        rnea_step_body<T, RNEA_MODE, 64, REXT, SPW>(model, prm, at, cst, wsl, wait_refs, geom_out, res_img ? res_img + RES_H * 16 : nullptr, taup_out);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&hready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+      rnea_step_body<T, RNEA_MODE, 64, REXT, SPW>(model, prm, at, cst, wsl, wait_refs, geom_out, res_img ? res_img + RES_H * 16 : nullptr);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       RSTAMP(3);   // (WBC_RO_STAMP_ALT) rnea: done
     } else if (wave == W_MJ) {
       int* const mflag = &mready;
@@ -556,6 +577,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         if (wave == 0) {   // phase 2 of the integrator, on the wavefront that has just written tau and f to the LDS image (its own LDS traffic: program order)
           if constexpr (QP_WAVES > 1) { while (__hip_atomic_load(&qdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < QP_WAVES * (t + 1)) __builtin_amdgcn_s_sleep(1); }
           while (__hip_atomic_load(&fready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);   // M's blocks and the factors
+          if constexpr (MERGE && (WBC_RO_TAUP_FIRST == 2 || (WBC_RO_TAUP_FIRST == 1 && SPW == 16))) { while (__hip_atomic_load(&hready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1); }   // h
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
           iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
 #ifdef WBC_FUSED_STAMP
