@@ -115,14 +115,29 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   // barrier from inside their bodies (EXT = 2), so table staging and state loads share a memory round trip.
   if (wave == 4) {
     int* const gflag = &gready;
-    rnea_step_body<T, ((MATS && !fused_split_h<T, OBSERVER, MATS, WARM>()) ? (RS_STEP | RS_H) : RS_STEP), 64, 2>(model, prm, a, cst, wsl, NoWait(), [=] __device__() {
+    constexpr int RMODE = (MATS && !fused_split_h<T, OBSERVER, MATS, WARM>()) ? (RS_STEP | RS_H) : RS_STEP;
+    auto geom_out = [=] __device__() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       FSTAMP(7);
-    });
+    };
+    // -DWBC_FUSED_TAUP_FIRST=1 (A/B): with h wanted from this role, tau_partial is handed to the QP wavefronts before the base rows of h are summed, rotated and stored
+#ifndef WBC_FUSED_TAUP_FIRST
+#define WBC_FUSED_TAUP_FIRST 0
+#endif
+    if constexpr (WBC_FUSED_TAUP_FIRST != 0 && (RMODE & RS_H) != 0) {
+      int* const finflag = &ready;
+      rnea_step_body<T, RMODE, 64, 2>(model, prm, a, cst, wsl, NoWait(), geom_out, nullptr, [=] __device__() {
+        FSTAMP(8);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(finflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      });
+    } else {
+    rnea_step_body<T, RMODE, 64, 2>(model, prm, a, cst, wsl, NoWait(), geom_out);
     FSTAMP(8);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
+    }
   } else if (wave == 5) {
     if constexpr (MATS) mass_jac_body<T, 64, 2, 16, (WBC_FUSED_ZEROS_BY_QP == 1 ? 0 : (WBC_FUSED_ZEROS_BY_QP == 2 ? 2 : 1))>(model, a, cst, zidx_s);   // (2: the role writes them LAST)
     else __syncthreads();
