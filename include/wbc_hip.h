@@ -116,9 +116,10 @@ typedef struct wbc_solver_options {
   int timing_mode;        /* enum wbc_timing_mode, used by wbc_solver_enable_timing */
   int qp_tile;            /* GRF-QP kernel of the two-kernel tick: 0 = auto (tiles of states dealt to the wavefronts by predicted work,
                              sized so that the launch is ONE round of resident workgroups: fp64 from 14336 states on, 32 ... 64 states
-                             per tile; fp32 from 30720, 64 ... 128; one-wavefront workgroups below), -1 = never tiles, otherwise always
-                             tiles of that many states: 32 | 64 | 128 | 256 | 512, fp64 also 36 ... 60 in steps of 4, fp32 also
-                             72 ... 120 in steps of 8 */
+                             per tile; fp32 from 16384 to 49152 states STAGED tiles -- one workgroup per CU holds ceil(N / 256) states
+                             and their inputs in LDS -- then 72 ... 128 states per tile; one-wavefront workgroups below), -1 = never
+                             tiles, otherwise always tiles of that many states: 32 | 64 | 128 | 256 | 512, fp64 also 36 ... 60 in
+                             steps of 4, fp32 also every multiple of 4 up to 192 (staged) */
   int obs_split_serial;   /* that observer kernel runs 1 (default) = on the caller's stream before the sweep, 0 = beside it on a
                              second stream (measured slower: the two compete for the same SIMDs) */
   int qp_lane;            /* two-kernel ticks solve the QPs one state per LANE first (semismooth Newton on the residual wrench)
@@ -168,7 +169,8 @@ typedef struct wbc_tick_plan {
                          4 = observer update and observer-free dyn_sweep as the two roles of ONE launch (sweep_obs_kernel) */
   int qp;             /* 0 = qp_group16 (one-wavefront workgroups), 1 = qp_tile (tiles dealt by predicted work), 2 = qp_lane + qp_list */
   int qp_tile;        /* states per tile when qp == 1 */
-  int qp_body;        /* 0 = wrench-space dual active set in fp64 arithmetic, 1 = 12 x 12 orthogonal-factor body in fp32 (fp32 tiles beyond 65 536 states) */
+  int qp_body;        /* 0 = wrench-space dual active set in fp64 arithmetic, 1 = 12 x 12 orthogonal-factor body in fp32 (fp32 tiles beyond 65 536 states),
+                         2 = as 0 on STAGED tiles: the tile's inputs go through LDS, results are stored row by row (fp32 solvers, tiles <= 192) */
   int sweep_pack2;    /* fp32 dyn_sweep with two states per lane */
   int sweep_block;    /* threads per workgroup of the dyn_sweep launch (64 / 256); 0 when no dyn_sweep runs */
   int qp_warm;        /* wbc_step_batch_warm: 1 = the QP kernels START from the carried active sets, 0 = they only report them (the sizes at which

@@ -1,0 +1,95 @@
+"""GPU: what round 6 added.
+
+* Staged QP tiles (qp_stile_kernel, fp32 solvers): the tile's inputs go through an LDS image, the predictor runs one foot per thread, the
+  row-form body works out of LDS and the workgroup stores the results row by row.  Per state it is the arithmetic of the one-wavefront
+  kernel (states the predictor finishes: f = x0 in fp32 arithmetic), so: status equal, tau / f against the one-wavefront kernel and against
+  the fp32 oracle at the fp32 gates, for every chunk count (tiles of 4 ... 192 states), ragged batches, batches smaller than a tile,
+  geometry from Jc and from the workspace (ticks without M, h, Jc), rhat folded in from the workspace (observer kernel in front), and the
+  active sets reported for warm callers.
+"""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import _np_dtype, _run_step, _solver
+from tests.util import relerr, to_dev, to_host
+from wbc_quadruped_dob_amd import synth
+
+pytestmark = pytest.mark.gpu
+F32_TOL = 5e-4        # fp32 solver against the fp32 oracle, relative to the largest entry
+F32_FLIPS = 1e-3      # share of states whose status may differ (a decision at the fp32 rounding level)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+@pytest.mark.parametrize("obs,n,tile,split,mats", [
+    (0, 5000, 128, -2, True), (1, 9000, 96, -2, True), (1, 20000, 0, -2, True), (1, 40001, 0, -2, True), (2, 33001, 0, 1, True),
+    (0, 3, 64, -2, True), (1, 100, 192, -2, True), (1, 777, 4, -2, True), (0, 1999, 52, -2, False), (1, 4099, 68, 1, False),
+    (1, 6001, 132, 1, True), (0, 49152, 0, -2, True), (1, 16384, 0, -2, False), (1, 12345, 188, -2, True)])
+def test_staged_tiles_equal_one_wave_kernel_and_oracle(torch_cuda, gpu_model, oracle, obs, n, tile, split, mats):
+    torch = torch_cuda
+    dtype = "f32"
+    nd = _np_dtype(dtype)
+    B = synth.make_batch(4 if obs else 3, n, gpu_model.total_mass, rank=61)
+    c = lambda a: np.ascontiguousarray(a, nd)
+    res = {}
+    for tag, qt in (("staged", tile), ("plain", -1)):
+        solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n, options={"fused_max": 0, "qp_tile": qt, "obs_split_min": split})
+        if tag == "staged":
+            pl = solver.plan_tick(n, want_mats=mats)
+            assert pl["qp"] == 1 and pl["qp_body"] == 2 and pl["qp_tile"] % 4 == 0 and 0 < pl["qp_tile"] <= 192, pl
+            if tile == 0:
+                assert (n + pl["qp_tile"] - 1) // pl["qp_tile"] <= 256, pl      # one workgroup per CU
+        integ = r = None
+        if obs:
+            integ = to_host(solver.dynamics(to_dev(B["q"], torch, torch.float32), to_dev(B["v"], torch, torch.float32), want=("p",))["p"]).astype(nd)
+            r = (0.05 * np.cos(np.arange(n * 18).reshape(n, 18))).astype(nd)
+        res[tag] = _run_step(torch, solver, B, dtype, integ, None if r is None else r.copy(), want_mats=mats)
+        if tag == "staged":
+            integ_in, r_in = integ, r
+    a, b = res["staged"], res["plain"]
+    assert np.array_equal(a["status"], b["status"])
+    assert np.mean(a["iters"] != b["iters"]) < 1e-2
+    assert relerr(a["tau"], b["tau"]) < 1e-4 and relerr(a["f"], b["f"]) < 1e-4      # (fp32 rounding of x0 for the states the predictor finishes)
+    if "active" in a and "active" in b:
+        same = a["iters"] == b["iters"]
+        assert np.array_equal(a["active"][same], b["active"][same])
+    assert a["iters"].max() >= (2 if n > 100 else 0)
+    P0 = synth.default_params(observer_order=obs, dtype=dtype)
+    ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], c(B["tau_prev"]), c(B["f_prev"]),
+                      None if integ_in is None else integ_in.copy(), None if r_in is None else r_in.copy(), nthreads=8)
+    flips = a["status"] != ref["status"]
+    assert flips.mean() <= F32_FLIPS
+    ok = ~flips & (ref["status"] == 0)
+    assert relerr(a["tau"][ok], ref["tau"][ok]) < F32_TOL and relerr(a["f"][ok], ref["f"][ok]) < F32_TOL
+
+
+def test_staged_tiles_report_the_active_sets_a_warm_tick_starts_from(torch_cuda, gpu_model):
+    """Between the warm one-wavefront kernel's range and the warm per-lane pair's, wbc_step_batch_warm runs the COLD staged tiles, which only report
+    the sets: a second warm tick from those sets gives the cold tick's answer."""
+    torch = torch_cuda
+    n, dtype = 32768, "f32"
+    solver, P = _solver(gpu_model, dtype=dtype, obs=1, max_batch=n)
+    pl = solver.plan_tick(n, warm=True)
+    assert pl["qp"] == 1 and pl["qp_body"] == 2 and pl["qp_warm"] == 0, pl
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=3)
+    td = torch.float32
+    dv = lambda k: to_dev(B[k], torch, td)
+    mask = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
+    ig = solver.dynamics(dv("q"), dv("v"), want=("p",))["p"]
+    rr = torch.zeros_like(ig)
+    args = (dv("q"), dv("v"), dv("w_des"), dv("vdot_des"), dv("normals"), dv("mu"), mask)
+    o1 = solver.step(*args, warm=True, tau_prev=dv("tau_prev"), f_prev=dv("f_prev"), obs_integ=ig.clone(), obs_r=rr.clone())
+    torch.cuda.synchronize()
+    sets = o1["active"].clone()
+    st1 = o1["status"].clone(); tau1 = o1["tau"].clone()
+    assert int((sets != 0).sum()) > n // 10          # the batch does have active constraints
+    o2 = solver.step(*args, active_in=sets, tau_prev=dv("tau_prev"), f_prev=dv("f_prev"), obs_integ=ig.clone(), obs_r=rr.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(o2["status"], st1)
+    assert relerr(to_host(o2["tau"]), to_host(tau1)) < 1e-5
+    assert torch.equal(o2["active"], sets)

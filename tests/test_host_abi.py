@@ -250,7 +250,8 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     import wbc_quadruped_dob_amd as W
     assert W.dispatch_thresholds("f64", 0) == [11265, 14336, 65536, 106496]
     assert W.dispatch_thresholds("f64", 1) == [12289, 14336, 14337, 20480, 65536, 106496]
-    assert W.dispatch_thresholds("f32", 1) == [12289, 30720, 32769, 33792, 65537, 131072, 212992]
+    assert W.dispatch_thresholds("f32", 1) == [12289, 16384, 32769, 33792, 49153, 65537, 131072, 212992]      # (round 6: staged QP tiles 16 384 .. 49 152)
+    assert [(W.plan_tick(n, "f32", 1)["qp_body"], W.plan_tick(n, "f32", 1)["qp_tile"]) for n in (16382, 16384, 32768, 49152, 49154)] == [(0, 0), (2, 64), (2, 128), (2, 192), (0, 72)]
     assert [W.plan_tick(n, "f64", 1)["front"] for n in (12288, 12289, 14336, 14337, 20480)] == [0, 4, 4, 0, 2]
     assert [W.plan_tick(n, "f32", 1)["front"] for n in (12290, 12291, 32768, 32770, 33792)] == [4, 0, 4, 0, 2]
     assert W.plan_tick(20000, "f32", 1)["sweep_pack2"] == 1 and W.plan_tick(20000, "f32", 1, options={"obs_colaunch": -1})["sweep_pack2"] == 0
@@ -260,7 +261,7 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.dispatch_thresholds("f64", 0, options={"qp_lane": -1, "qp_tile": -1, "fused_max": 0}) == [65536]
     # ticks whose caller passes no M / h / Jc buffers: rnea_step front half; observer kernel + observer-free rnea_step from 16 384 fp64 / 32 768 fp32 states
     assert W.dispatch_thresholds("f64", 1, want_mats=False) == [14336, 16384, 106496]
-    assert W.dispatch_thresholds("f32", 1, want_mats=False) == [30720, 32768, 65537, 212992]
+    assert W.dispatch_thresholds("f32", 1, want_mats=False) == [16384, 32768, 49153, 65537, 212992]
     assert [W.plan_tick(n, "f64", 1, want_mats=False)["front"] for n in (9000, 16383, 16384, 262144)] == [1, 1, 3, 3]
     assert W.plan_tick(262144, "f64", 0, want_mats=False)["front"] == 1
     # warm-started ticks (wbc_step_batch_warm): fused, warm one-wavefront kernel, cold tiles that only report the sets, warm per-lane pair

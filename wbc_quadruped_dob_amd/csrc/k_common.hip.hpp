@@ -16,6 +16,12 @@
     else hipLaunchKernelGGL(kern, grid, block, 0, (L).st, __VA_ARGS__);                                         \
   } while (0)
 
+#define WBC_KLAUNCH_SMEM(L, kern, grid, block, smem, ...)                                                       \
+  do {                                                                                                          \
+    if ((L).ev_start) hipExtLaunchKernelGGL(kern, grid, block, smem, (L).st, (L).ev_start, (L).ev_stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, smem, (L).st, __VA_ARGS__);                                      \
+  } while (0)
+
 namespace wbc {
 using Scalar = WBC_SCALAR;
 }  // namespace wbc

@@ -3,8 +3,27 @@
 #include "qp_kernels.hip.hpp"
 #include "qp_lane.hip.hpp"
 #include <type_traits>
+#include <cstdlib>
 
 namespace wbc {
+
+// staged tiles: NW wavefronts per workgroup, tiles of up to 64 CH states
+template <int NW, int CH>
+static hipError_t qp_staged(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
+  using T = Scalar;
+  const size_t smem = stile_lds_bytes(tile, sizeof(T));
+  static bool raised[2] = {false, false};   // (more than 64 kB of dynamic LDS needs the attribute once per kernel)
+  if (!raised[rhat ? 1 : 0]) {
+    const hipError_t e = rhat ? hipFuncSetAttribute((const void*)qp_stile_kernel<T, true, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024 - (int)(NW * sizeof(S16Lds<double>)))
+                              : hipFuncSetAttribute((const void*)qp_stile_kernel<T, false, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024 - (int)(NW * sizeof(S16Lds<double>)));
+    if (e != hipSuccess) return e;
+    raised[rhat ? 1 : 0] = true;
+  }
+  const dim3 grid((unsigned)((a.N + tile - 1) / tile));
+  if (rhat) WBC_KLAUNCH_SMEM(L, (qp_stile_kernel<T, true, NW, CH>), grid, dim3(64 * NW), smem, prm, a, jmap, tile);
+  else WBC_KLAUNCH_SMEM(L, (qp_stile_kernel<T, false, NW, CH>), grid, dim3(64 * NW), smem, prm, a, jmap, tile);
+  return hipGetLastError();
+}
 
 template <int TILE>
 static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
@@ -23,7 +42,7 @@ static hipError_t qp_tiled(const LaunchCtx& L, bool rhat, const DevParams<Scalar
 }
 
 template <>
-hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* list, bool warm) {
+hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* list, bool warm, int body) {
   using T = Scalar;
   if (warm && !list) {   // dependent ticks: every state starts from its previous active set, so the rows of a wavefront do about equal work -- no dealing by predicted work
     if (tile > 0) return hipErrorInvalidValue;
@@ -47,6 +66,24 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
   }
   // tile sizes in small steps so that the host can launch ONE round of resident workgroups (wbc_api.cpp): fp64 tiles keep three workgroups on a
   // CU (768 at once) up to 64 states per tile, fp32 tiles two (512) -- hence steps of 4 from 32 to 64 for fp64, of 8 from 64 to 128 for fp32
+#ifdef WBC_STILE_ENV   // experiment builds only: staged tiles of this size / with this many wavefronts per workgroup, whatever the plan says
+  int nw_env = 0;
+  if (const char* e = getenv("WBC_STILE_TILE")) { tile = atoi(e); body = 2; }
+  if (const char* e = getenv("WBC_STILE_NW")) nw_env = atoi(e);
+#endif
+  if (body == 2) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (tile <= 0 || tile > STILE_MAX_TILE || tile % 4 != 0) return hipErrorInvalidValue;
+      const int ch = (tile + 63) / 64;
+#ifdef WBC_STILE_ENV
+      if (nw_env == 4 && ch == 1) return qp_staged<4, 1>(L, rhat, tile, prm, a, jmap);
+      if (nw_env == 8 && ch <= 2) return qp_staged<8, 2>(L, rhat, tile, prm, a, jmap);
+#endif
+      if (ch == 1) return qp_staged<12, 1>(L, rhat, tile, prm, a, jmap);
+      if (ch == 2) return qp_staged<12, 2>(L, rhat, tile, prm, a, jmap);
+      return qp_staged<12, 3>(L, rhat, tile, prm, a, jmap);
+    } else return hipErrorInvalidValue;   // (fp64 solvers: the image of a CU's states does not fit beside the solver tables)
+  }
 #define WBC_TILE_CASE(n) case n: return qp_tiled<n>(L, rhat, prm, a, jmap);
   if constexpr (std::is_same<T, double>::value) {
     switch (tile) {

@@ -23,6 +23,14 @@ constexpr size_t BIG_GRID_THREADS = (size_t)256 * 8 * 64 * 2;
 #define WBC_F32_DENSE_TILE_MIN 65537
 #endif
 
+// staged tiles (qp_stile_kernel, fp32 solvers): one workgroup of twelve wavefronts per CU holds ceil(N / 256) states, up to 192 (three 64-column chunks:
+// image 80 kB + twelve wavefronts' solver tables 70 kB of the CU's 160 kB of LDS) -- i.e. one round of workgroups up to 49 152 states
+constexpr int STILE_MAX_TILE = 192;
+constexpr size_t STILE_MAX_STATES = (size_t)STILE_MAX_TILE * 256;
+#ifndef WBC_STILE_MIN_F32
+#define WBC_STILE_MIN_F32 16384
+#endif
+
 // stream of the launch + (optionally) the events that receive the dispatch's own start / stop timestamps
 struct LaunchCtx {
   hipStream_t st = nullptr;
@@ -44,8 +52,10 @@ template <class T> hipError_t k_sweep_obs(const LaunchCtx& L, const DevModel<T>*
 // list (optional): solve the states list[4 .. 4 + list[0]) instead of the whole batch (qp_list_kernel; the count is reset by the
 // NEXT tick's front-half kernel, SweepArgs::qp_todo -- not here)
 // warm (tile = 0, no list): qp_group16_kernel<.., WARM>, every state starts from its active set in a.aset_in
+// body (tiles): 0 structured body on gathered inputs (qp_tile_kernel), 1 its lean fp32 form (from WBC_F32_DENSE_TILE_MIN states), 2 STAGED tiles --
+// qp_stile_kernel, the tile's inputs through LDS, twelve wavefronts per workgroup, tile <= STILE_MAX_TILE (a multiple of 4)
 template <class T> hipError_t k_qp(const LaunchCtx& L, bool rhat, int tile, const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap,
-                                  int* list = nullptr, bool warm = false);
+                                  int* list = nullptr, bool warm = false, int body = 0);
 // qp_lane_kernel<T, RHAT>: the GRF QP one state per LANE (semismooth Newton on the 6-dimensional residual wrench); states it
 // does not finish are appended to todo (todo[0] = count, todo[4 ...] = indices) for k_qp(..., list = todo); the count must be
 // zero when this kernel starts: the front-half kernel of the tick empties it (SweepArgs::qp_todo)

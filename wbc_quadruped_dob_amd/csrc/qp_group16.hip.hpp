@@ -199,7 +199,16 @@ WBC_DEV void qp_wait(int* flag, int need) {
 
 // TILED (qp_tile_kernel below): the four rows of the wavefront solve the states `who` names (dealt by predicted work)
 // instead of four consecutive ones; the workgroup is four such wavefronts.
-struct QpWho { size_t state; bool live; const double* pre = nullptr; };   // pre: the tile predictor's record of this state (qp_kernels.hip.hpp), LDS
+struct QpWho {
+  size_t state; bool live;
+  const double* pre = nullptr;   // the tile predictor's record of this state (qp_kernels.hip.hpp), LDS
+  // STG (staged tiles, qp_kernels.hip.hpp): the tile's inputs wait in an LDS image [ST_WORDS][stride] of the solver's scalar type, the state is column
+  // `slot`; f, tau go back into the image and status / iters / active set into iimg ([4][tile]: mask, status, iters, set) -- the body touches no memory
+  void* img = nullptr; int* iimg = nullptr; int slot = 0, stride = 0, tile = 0;
+};
+// rows of the staged image: normals 12, mu 4, lever arms 12, b = w_des - rhat_base 6, tau_partial - rhat_joint 12 (leg-major), own-leg Jacobian blocks 36
+// (9 f + 3 m + k), then the results f 12, tau 12 (caller's joint order)
+constexpr int ST_N = 0, ST_MU = 12, ST_D = 16, ST_B = 28, ST_TAUP = 34, ST_JCL = 46, ST_F = 82, ST_TAU = 94, ST_WORDS = 106;
 struct QpNoIdle { WBC_DEV void operator()() const {} };
 // `idle()` (fused tick) runs after this wavefront has requested its own inputs and before it first waits for the producer roles:
 // work that would otherwise sit on a producer's critical path (the structural constants of M and Jc, dyn_split.hip.hpp).

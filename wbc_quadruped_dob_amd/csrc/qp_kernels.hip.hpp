@@ -229,10 +229,13 @@ WBC_DEV int qp_predict_keyval(int cnt_all, float mag) {
 
 // the whole predictor by one lane (tiles of more than 64 states): key 0 ... 61, or -1 = finished here
 template <class T, bool RHAT, bool PRE = false>
-WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32, double* pre = nullptr) {
+WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32, double* pre = nullptr, long long* st_part = nullptr) {
   constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
   PredPart<typename PredA<T, PRE>::type> pp;
   qp_predict_part<T, RHAT, PRE>(prm, a, s32, N32, pre, 0xF, 0x3F, pp);
+#ifdef WBC_TILE_STAMP
+  if (st_part) { asm volatile("" :: "v"(pp.cnt), "v"(pp.mag)); *st_part = __builtin_readcyclecounter(); }
+#endif
   if (FIN && pp.fin_ok) { qp_predict_finish<T, RHAT, PRE>(prm, a, jmap, s32, N32, pp); return -1; }
   return qp_predict_keyval(pp.cnt, (float)pp.mag);
 }
@@ -258,6 +261,15 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
   const size_t base = (size_t)blockIdx.x * TILE;
   if (tid < 64) hist[tid] = 0;
   if (tid == 0) next_grp = 0;
+#ifdef WBC_TILE_STAMP   // diagnostic build (tools/tile_stamp.py): per-wavefront cycle stamps of a tile go out in place of its iteration counts
+  const long long ts_c0 = __builtin_readcyclecounter();
+  const long long ts_w0 = wall_clock64();
+  long long ts_b1 = 0, ts_b3 = 0, ts_g1 = 0, ts_end = 0, ts_pp = 0;
+  int ts_ng = 0;
+#define TSTAMP(x) x = __builtin_readcyclecounter()
+#else
+#define TSTAMP(x) do {} while (0)
+#endif
   __syncthreads();
   // 1. keys: bucket 0 = most predicted work ... 61 = none; 62 = finished by the predictor, or beyond the end (not dealt)
   int bucket[(TILE + 255) / 256], rank[(TILE + 255) / 256];
@@ -271,12 +283,17 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
     if (i < TILE) {
       const size_t s = base + i;
       if (s < N) {
+#ifdef WBC_TILE_STAMP
+        const int key = qp_predict_key<T, RHAT, PRE>(prm, a, jmap, (unsigned)s, N32, pre + (PRE ? i * QP_PRE_WORDS : 0), &ts_pp);
+#else
         const int key = qp_predict_key<T, RHAT, PRE>(prm, a, jmap, (unsigned)s, N32, pre + (PRE ? i * QP_PRE_WORDS : 0));
+#endif
         bucket[r] = key < 0 ? 62 : 61 - key;
       }
       rank[r] = __hip_atomic_fetch_add(&hist[bucket[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
+  TSTAMP(ts_b1);
   __syncthreads();
   // 2. counting sort: position = states in harder buckets + my arrival rank in mine
 #pragma unroll
@@ -289,6 +306,7 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
     }
   }
   __syncthreads();
+  TSTAMP(ts_b3);
   // 3. the four wavefronts pull groups of four states, hardest first
   const int row = (int)((tid & 63) >> 4);
   const int nsolve = TILE - hist[62];
@@ -302,7 +320,313 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
     const size_t s = base + oi;
     if constexpr (DENSE) qp_group16_body<T, false, RHAT, 16, true>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live});
     else qp_body<T, false, RHAT, 16, true, 4, QpNoIdle, PRE>(prm, a, jmap, nullptr, nullptr, QpWho{live ? s : (size_t)0, live, pre + (PRE ? oi * QP_PRE_WORDS : 0)});
+#ifdef WBC_TILE_STAMP
+    if (ts_ng == 0) TSTAMP(ts_g1);
+    ++ts_ng;
+#endif
   }
+#ifdef WBC_TILE_STAMP
+  TSTAMP(ts_end);
+  const long long ts_w1 = wall_clock64();
+  __syncthreads();
+  if (a.iters && TILE >= 64 && (tid & 63) == 0 && base + TILE <= N) {
+    int* o = a.iters + base + 8 * (tid >> 6);
+    o[0] = (int)(ts_b1 - ts_c0); o[1] = (int)(ts_b3 - ts_c0); o[2] = ts_ng ? (int)(ts_g1 - ts_c0) : 0; o[3] = (int)(ts_end - ts_c0);
+    o[4] = ts_ng | ((int)((ts_pp ? ts_pp - ts_c0 : 0) >> 4) << 8); o[5] = (int)(ts_w0 & 0x7FFFFFFF); o[6] = (int)(ts_w1 & 0x7FFFFFFF); o[7] = nsolve;
+  }
+#endif
+#undef TSTAMP
+}
+
+// ======================================================================================================================
+// qp_stile_kernel (round 6): the tile kernel with the tile's inputs STAGED THROUGH LDS.
+// What the timeline of qp_tile_kernel showed at configs[3]'s shard (32 768 fp32 states, observer on; tools/tile_stamp.py,
+// profiles/r06a_tile_timeline.txt): the predictor's decision is there at +2.6 us, but the states it finishes keep its ONE wavefront busy
+// until +8.4 us (per-lane loads of the Jacobian blocks, two feet per round) while three wavefronts wait at the barrier; every group of
+// four states then pays two dependent rounds of global loads (inputs in front of the set-up, the torque map's Jacobian blocks behind the
+// iteration), each a GATHER: the sixteen lanes of a row read sixteen different component rows of one state, a whole 64-byte sector per
+// 4-byte word (19 MB fetched from Jc per launch).
+// Here the workgroup first copies everything its states need -- normals, mu, lever arms, b = w_des - rhat_base, tau_partial - rhat_joint,
+// the own-leg Jacobian blocks: 82 words per state -- from HBM into an LDS image, row by row, a 256-byte line per load instruction, all
+// loads of a wavefront in flight together: ONE memory latency per tile and every byte fetched once.  Predictor, finisher and the
+// row-form body then work out of LDS (qp_struct16_body<..., STG>), results go back into the image, and the workgroup stores f, tau, status,
+// iters and the active sets row by row at the end.  The predictor runs one FOOT per thread (thread = foot x state): the 6 x 6 factor is
+// computed redundantly, the foot's minimiser and slacks once; a thread finishes its own foot of a state whose four verdicts say "x0
+// violates nothing" from the values it still holds.
+// NW wavefronts per workgroup, tiles of up to 64 CH states (`tile`, a multiple of 4, run-time): the host sizes the tile so that the launch
+// is ONE round of resident workgroups -- at 32 768 states one workgroup of 128 states per CU, whose NW wavefronts all pull groups from
+// the one queue (two 64-state tiles per CU level only within each tile: the slower tile of a CU set the pace).
+// Same keys, same order of the groups within a tile, same arithmetic per state as qp_tile_kernel.
+constexpr int STILE_IN_ROWS = 82;   // staged input rows per state (ST_F: the results follow)
+constexpr size_t stile_lds_bytes(int tile, size_t scalar) {
+  return (size_t)ST_WORDS * (size_t)(tile | 1) * scalar + (size_t)tile * (4 * 4 + 4 * 4 + 4 * scalar + 2) + 64 * 4 * 2 + 16;
+}
+template <class T, bool RHAT, int NW, int CH>
+__global__ __launch_bounds__(64 * NW, (NW > 8 ? 3 : 2)) void qp_stile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int tile) {
+  constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
+  static_assert(NW >= 4 * CH, "the predictor needs one thread per foot and state");
+  using A = T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char stile_dyn[];
+  const int ST = tile | 1;   // row stride of the image: the sixteen lanes of a row read sixteen ROWS of one column -- an odd stride spreads them over the banks
+  T* const img = (T*)stile_dyn;
+  A* const pmag = (A*)(img + ST_WORDS * ST);            // [4][tile] per foot: summed violation at x0
+  int* const iimg = (int*)(pmag + 4 * tile);            // [4][tile] mask | status | iters | active set
+  int* const pcnt = iimg + 4 * tile;                    // [4][tile] per foot: violated rows at x0 (bit 8: some slack of the foot is below the finishing threshold)
+  int* const hist = pcnt + 4 * tile;                    // [64]
+  int* const hbase = hist + 64;                         // [64] exclusive prefix of hist
+  int* const next_grp = hbase + 64;
+  unsigned short* const order = (unsigned short*)(next_grp + 4);
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const size_t N = a.N;
+  const unsigned N32 = (unsigned)a.N;
+  const size_t base = (size_t)blockIdx.x * (size_t)tile;
+  if (tid < 64) hist[tid] = 0;
+  if (tid == 0) *next_grp = 0;
+#ifdef WBC_TILE_STAMP
+  const long long ts_c0 = __builtin_readcyclecounter();
+  const long long ts_w0 = wall_clock64();
+  long long ts_b1 = 0, ts_b3 = 0, ts_g1 = 0, ts_end = 0, ts_pp = 0;
+  int ts_ng = 0;
+#define TSTAMP(x) x = __builtin_readcyclecounter()
+#else
+#define TSTAMP(x) do {} while (0)
+#endif
+  // ---- 0. stage in.  Unit u = (staging row su, chunk ch of 64 columns); wavefront W takes the units u = j NW + W: every wavefront requests all its units,
+  // then parks them.  One straight-line copy of the code per wavefront (rows, and so the source arrays and components, are compile-time there).
+  // Staging order: b (6 rows) and tau_partial (12) first -- the rows the observer estimate is subtracted from -- then normals, mu, lever arms, Jacobian blocks.
+  {
+    const bool jc = a.Jc != nullptr;
+    const T* gsrc = jc ? a.Jc : a.ws;   // geometry: from the Jacobian the sweep wrote, or from the workspace (ticks without M, h, Jc)
+    const T* bsrc = a.wdes ? a.wdes : a.ws;
+    const unsigned boff = a.wdes ? 0u : (unsigned)WS_B;
+    sfor<0, NW>([&](auto w_) __attribute__((always_inline)) {
+      constexpr int W = decltype(w_)::value;
+      if (wave != (unsigned)W) return;
+      constexpr int UNITS = STILE_IN_ROWS * CH, UPW = (UNITS - W + NW - 1) / NW;
+      T val[UPW], sub[UPW];
+      int mk[CH];
+      sfor<0, UPW>([&](auto j_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        constexpr unsigned u = (unsigned)j * NW + W, su = u / CH, ch = u % CH;
+        const unsigned col = ch * 64 + lane;
+        const unsigned sidx = (unsigned)(base + col < N ? base + col : N - 1);
+        const T* ptr; unsigned comp;
+        if constexpr (su < 6) { ptr = bsrc; comp = boff + su; }
+        else if constexpr (su < 18) { ptr = a.ws; comp = (unsigned)WS_TAUP + (su - 6); }
+        else if constexpr (su < 30) { ptr = a.normals; comp = su - 18; }
+        else if constexpr (su < 34) { ptr = a.mu; comp = su - 30; }
+        else if constexpr (su < 46) {
+          constexpr unsigned v = su - 34, f = v / 3, c = v - 3 * f;
+          ptr = gsrc;
+          comp = jc ? (c == 0 ? (3 * f + 1) * 18 + 5 : (c == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4)) : (unsigned)WS_D + v;
+        } else {
+          constexpr unsigned r = su - 46, f = r / 9, mm = (r - 9 * f) / 3, k = r - 9 * f - 3 * mm;
+          const unsigned jm = (unsigned)((a.jpack >> (4 * (3 * f + k))) & 15u);
+          ptr = gsrc;
+          comp = jc ? (3 * f + mm) * 18 + 6 + jm : (unsigned)WS_JCL + r;
+        }
+        val[j] = *(const T*)((const char*)ptr + (size_t)((comp * N32 + sidx) * (unsigned)sizeof(T)));
+        if constexpr (RHAT && su < 18) sub[j] = *(const T*)((const char*)a.ws + (size_t)((((unsigned)WS_RHAT + su) * N32 + sidx) * (unsigned)sizeof(T)));
+        else sub[j] = 0;
+      });
+      if constexpr (W == NW - 1) sfor<0, CH>([&](auto c_) __attribute__((always_inline)) {
+        constexpr int ch = decltype(c_)::value;
+        const unsigned col = ch * 64 + lane;
+        mk[ch] = a.mask[base + col < N ? base + col : N - 1];
+      });
+      sfor<0, UPW>([&](auto j_) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        constexpr unsigned u = (unsigned)j * NW + W, su = u / CH, ch = u % CH;
+        constexpr unsigned row = su < 18 ? (unsigned)ST_B + su : (su < 46 ? su - 18 : su);
+        const unsigned col = ch * 64 + lane;
+        if (col < (unsigned)tile) img[row * ST + col] = val[j] - sub[j];
+      });
+      if constexpr (W == NW - 1) sfor<0, CH>([&](auto c_) __attribute__((always_inline)) {
+        constexpr int ch = decltype(c_)::value;
+        const unsigned col = ch * 64 + lane;
+        if (col < (unsigned)tile) iimg[col] = base + col < N ? mk[ch] : 0;
+      });
+    });
+  }
+  __syncthreads();
+  // ---- 1. predictor: thread = (foot, column); the arithmetic of qp_predict_part out of the image
+  const unsigned pfoot = wave / CH, pcol = (wave % CH) * 64 + lane;
+  const bool pred = pfoot < 4;                        // (wavefronts beyond 4 CH only solve)
+  const bool incol = pred && pcol < (unsigned)tile;
+  const bool valid = incol && base + pcol < N;
+  const unsigned colr = incol ? pcol : 0u;
+  const int fo = (int)(pred ? pfoot : 0u);
+#define IMGR(row) ((A)img[(row) * ST + colr])
+#define IMGW(row) img[(row) * ST + pcol]
+  A x0 = 0, x1 = 0, x2 = 0;       // my foot's part of the unconstrained minimum
+  if (pred) {
+    const int mask = iimg[colr] & 0xF;
+    const A s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
+    A nc = 0, sx = 0, sy = 0, sz = 0, Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const bool on = (mask >> f) & 1;
+      A dx = IMGR(ST_D + 3 * f), dy = IMGR(ST_D + 3 * f + 1), dz = IMGR(ST_D + 3 * f + 2);
+      dx = on ? dx : (A)0; dy = on ? dy : (A)0; dz = on ? dz : (A)0;
+      nc += on ? (A)1 : (A)0; sx += dx; sy += dy; sz += dz;
+      Pxx += dx * dx; Pxy += dx * dy; Pxz += dx * dz; Pyy += dy * dy; Pyz += dy * dz; Pzz += dz * dz;
+    }
+    A bt[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bt[k] = IMGR(ST_B + k);
+    const A g00 = prm.alpha + s0 * s0 * nc, g11 = prm.alpha + s1 * s1 * nc, g22 = prm.alpha + s2 * s2 * nc;
+    const A gm01 = -(s3 * s1) * sz, gm02 = (s3 * s2) * sy, gm10 = (s4 * s0) * sz, gm12 = -(s4 * s2) * sx, gm20 = -(s5 * s0) * sy, gm21 = (s5 * s1) * sx;
+    const A m00 = prm.alpha + (s3 * s3) * (Pyy + Pzz), m11 = prm.alpha + (s4 * s4) * (Pxx + Pzz), m22 = prm.alpha + (s5 * s5) * (Pxx + Pyy);
+    const A m10 = -(s4 * s3) * Pxy, m20 = -(s5 * s3) * Pxz, m21 = -(s5 * s4) * Pyz;
+    auto rs = [](A x) __attribute__((always_inline)) -> A {
+      if constexpr (FIN) return rsqrt_nr(x);
+      else if constexpr (std::is_same<A, double>::value) return __builtin_amdgcn_rsq(x); else return __builtin_amdgcn_rsqf(x);
+    };
+    A il[6];
+    il[0] = rs(g00); il[1] = rs(g11); il[2] = rs(g22);
+    const A a01 = gm01 * il[1], a02 = gm02 * il[2], a10 = gm10 * il[0], a12 = gm12 * il[2], a20 = gm20 * il[0], a21 = gm21 * il[1];
+    const A c00 = m00 - a01 * a01 - a02 * a02, c11 = m11 - a10 * a10 - a12 * a12, c22 = m22 - a20 * a20 - a21 * a21;
+    const A c10 = m10 - a12 * a02, c20 = m20 - a21 * a01, c21 = m21 - a20 * a10;
+    il[3] = rs(c00);
+    const A b10 = c10 * il[3], b20 = c20 * il[3];
+    il[4] = rs(c11 - b10 * b10);
+    const A b21 = (c21 - b20 * b10) * il[4];
+    il[5] = rs(c22 - b20 * b20 - b21 * b21);
+    A w[6], z[6];   // z = G^-1 S^(1/2) b
+    w[0] = s0 * bt[0] * il[0]; w[1] = s1 * bt[1] * il[1]; w[2] = s2 * bt[2] * il[2];
+    w[3] = (s3 * bt[3] - a01 * w[1] - a02 * w[2]) * il[3];
+    w[4] = (s4 * bt[4] - a10 * w[0] - a12 * w[2] - b10 * w[3]) * il[4];
+    w[5] = (s5 * bt[5] - a20 * w[0] - a21 * w[1] - b20 * w[3] - b21 * w[4]) * il[5];
+    z[5] = w[5] * il[5];
+    z[4] = (w[4] - b21 * z[5]) * il[4];
+    z[3] = (w[3] - b10 * z[4] - b20 * z[5]) * il[3];
+    z[2] = (w[2] - a02 * z[3] - a12 * z[4]) * il[2];
+    z[1] = (w[1] - a01 * z[3] - a21 * z[5]) * il[1];
+    z[0] = (w[0] - a10 * z[4] - a20 * z[5]) * il[0];
+    const A zf0 = s0 * z[0], zf1 = s1 * z[1], zf2 = s2 * z[2], zm0 = s3 * z[3], zm1 = s4 * z[4], zm2 = s5 * z[5];
+    // my foot: x0 = on (s_f z_f + (s_m z_m) x d), its six slacks
+    const bool on = (mask >> fo) & 1;
+    const A dx = IMGR(ST_D + 3 * fo), dy = IMGR(ST_D + 3 * fo + 1), dz = IMGR(ST_D + 3 * fo + 2);
+    x0 = on ? zf0 + (zm1 * dz - zm2 * dy) : (A)0;
+    x1 = on ? zf1 + (zm2 * dx - zm0 * dz) : (A)0;
+    x2 = on ? zf2 + (zm0 * dy - zm1 * dx) : (A)0;
+    A nx = IMGR(ST_N + 3 * fo), ny = IMGR(ST_N + 3 * fo + 1), nz = IMGR(ST_N + 3 * fo + 2);
+    const A iln = rs(nx * nx + ny * ny + nz * nz);
+    nx *= iln; ny *= iln; nz *= iln;
+    const bool usex = fabs_t(nx) < (A)0.9;
+    const A rx = usex ? (A)1 : (A)0, ry = usex ? (A)0 : (A)1;
+    const A rd = rx * nx + ry * ny;
+    A t1x = rx - nx * rd, t1y = ry - ny * rd, t1z = -nz * rd;
+    const A it = rs(t1x * t1x + t1y * t1y + t1z * t1z);
+    t1x *= it; t1y *= it; t1z *= it;
+    const A t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    const A fn = nx * x0 + ny * x1 + nz * x2, f1 = t1x * x0 + t1y * x1 + t1z * x2, f2 = t2x * x0 + t2y * x1 + t2z * x2;
+    const A mf = IMGR(ST_MU + fo) * prm.mu_scale * fn, tol = -prm.qp_tol;
+    const A sl[6] = {mf - f1, mf + f1, mf - f2, mf + f2, fn - prm.fn_min, prm.fn_max - fn};
+    const A fin_thr = std::is_same<T, double>::value ? (A)-prm.qp_tol : (A)1e-3;
+    int cnt = 0;
+    A mg = 0;
+    bool okf = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { cnt += (sl[c] < tol) ? 1 : 0; mg += (sl[c] < tol) ? -sl[c] : (A)0; okf = okf && (sl[c] >= fin_thr); }
+    if (incol) {
+      pcnt[fo * tile + pcol] = on ? (okf ? cnt : (cnt | 0x100)) : 0;    // (a NaN state fails every comparison: never finished here)
+      pmag[fo * tile + pcol] = on ? mg : (A)0;
+    }
+  }
+  TSTAMP(ts_pp);
+  __syncthreads();
+  // ---- 2. the state's verdict (every thread of the column); a thread finishes its foot, the threads of foot 0 file the key
+  int bucket = 62, rank = 0;
+  if (pred) {
+    const int c0 = pcnt[colr], c1 = pcnt[tile + colr], c2 = pcnt[2 * tile + colr], c3 = pcnt[3 * tile + colr];
+    const bool fin = FIN && valid && ((c0 | c1 | c2 | c3) & 0x100) == 0;
+    if (fin) {   // f = x0, tau = tau_partial - Jc_leg^T f of my foot's leg; status 0, no iterations, the empty set
+      IMGW(ST_F + 3 * fo) = (T)x0; IMGW(ST_F + 3 * fo + 1) = (T)x1; IMGW(ST_F + 3 * fo + 2) = (T)x2;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int jm = (int)((a.jpack >> (4 * (3 * fo + k))) & 15u);
+        const A j0 = IMGR(ST_JCL + 9 * fo + k), j1 = IMGR(ST_JCL + 9 * fo + 3 + k), j2 = IMGR(ST_JCL + 9 * fo + 6 + k);
+        IMGW(ST_TAU + jm) = (T)(IMGR(ST_TAUP + 3 * fo + k) - (j0 * x0 + j1 * x1 + j2 * x2));
+      }
+      if (fo == 0) { iimg[tile + pcol] = 0; iimg[2 * tile + pcol] = 0; iimg[3 * tile + pcol] = 0; }
+    }
+    if (fo == 0 && incol) {
+      if (valid && !fin) {
+        const A mag = ((pmag[colr] + pmag[tile + colr]) + pmag[2 * tile + colr]) + pmag[3 * tile + colr];
+        bucket = 61 - qp_predict_keyval((c0 & 0xFF) + (c1 & 0xFF) + (c2 & 0xFF) + (c3 & 0xFF), (float)mag);
+      }
+      rank = __hip_atomic_fetch_add(&hist[bucket], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  TSTAMP(ts_b1);
+  __syncthreads();
+  // ---- 3. counting sort: position = states in harder buckets (exclusive prefix over the histogram, one wavefront) + my arrival rank in mine
+  if (wave == 0) {
+    const int h = hist[lane];
+    int incl = h;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); incl += (int)lane >= d ? t : 0; }
+    hbase[lane] = incl - h;
+  }
+  __syncthreads();
+  if (pred && fo == 0 && incol) order[hbase[bucket] + rank] = (unsigned short)pcol;
+  __syncthreads();
+  TSTAMP(ts_b3);
+  // ---- 4. the wavefronts pull groups of four states, hardest first
+  const int row = (int)(lane >> 4);
+  const int nsolve = tile - hist[62];
+  for (;;) {
+    int g = 0;
+    if (lane == 0) g = __hip_atomic_fetch_add(next_grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (4 * g >= nsolve) break;
+    const bool live = 4 * g + row < nsolve;
+    const unsigned oi = order[live ? 4 * g + row : 0];
+    qp_body<T, false, false, 16, true, NW, QpNoIdle, false, 0, 1>(prm, a, jmap, nullptr, nullptr, QpWho{0, live, nullptr, (void*)img, iimg, (int)oi, ST, tile});
+#ifdef WBC_TILE_STAMP
+    if (ts_ng == 0) TSTAMP(ts_g1);
+    ++ts_ng;
+#endif
+  }
+  TSTAMP(ts_end);
+  __syncthreads();
+  // ---- 5. stage out: f, tau row by row (unit = (row, chunk), u = j NW + wave); status, iters, active sets
+  {
+    constexpr int OUNITS = 27 * CH, OPW = (OUNITS + NW - 1) / NW;
+    sfor<0, OPW>([&](auto j_) __attribute__((always_inline)) {
+      constexpr int j = decltype(j_)::value;
+      const unsigned u = (unsigned)j * NW + wave;
+      const unsigned r = u / CH, ch = u % CH;
+      const unsigned col = ch * 64 + lane;
+      if (r < 27u && col < (unsigned)tile && base + col < N) {
+        const unsigned sidx = (unsigned)(base + col);
+        if (r < 12) *(T*)((char*)a.f + (size_t)((r * N32 + sidx) * (unsigned)sizeof(T))) = img[(ST_F + r) * ST + col];
+        else if (r < 24) *(T*)((char*)a.tau + (size_t)(((r - 12) * N32 + sidx) * (unsigned)sizeof(T))) = img[(ST_TAU + r - 12) * ST + col];
+        else if (r == 24) a.status[sidx] = iimg[tile + col];
+#ifndef WBC_TILE_STAMP
+        else if (r == 25) { if (a.iters) a.iters[sidx] = iimg[2 * tile + col]; }
+#endif
+        else if (r == 26) { if (a.aset_out) a.aset_out[sidx] = iimg[3 * tile + col]; }
+      }
+    });
+  }
+#ifdef WBC_TILE_STAMP
+  {
+    const long long ts_w1 = wall_clock64();
+    __syncthreads();
+    if (a.iters && tile >= 8 * NW && lane == 0 && base + tile <= N) {
+      int* o = a.iters + base + 8 * wave;
+      o[0] = (int)(ts_b1 - ts_c0); o[1] = (int)(ts_b3 - ts_c0); o[2] = ts_ng ? (int)(ts_g1 - ts_c0) : 0; o[3] = (int)(ts_end - ts_c0);
+      o[4] = ts_ng | ((int)((ts_pp - ts_c0) >> 4) << 8); o[5] = (int)(ts_w0 & 0x7FFFFFFF); o[6] = (int)(ts_w1 & 0x7FFFFFFF); o[7] = nsolve;
+    }
+  }
+#endif
+#undef TSTAMP
+#undef IMGR
+#undef IMGW
 }
 
 // qp_list_kernel: the dense active-set solver over a LIST of states (list[0] = how many, list[4 ...] = their indices): the

@@ -112,11 +112,12 @@ WBC_DEV void s16_cold_inverse_row(int mask, T d_me, T alpha_l, T s0, T s1, T s2,
 // A set with more than three rows on a foot, dependent rows or a negative multiplier is no S-pair of the dual method: that row of the
 // wavefront repeats the set-up with the empty set (= the cold start; the loop below runs at most twice).  The QP is strictly convex, so
 // the start changes the iteration count, never the solution.
-template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0>
+template <class TS, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0, int STG = 0>
 WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, const QpJidx& jmap, const TS* wsl, const QpSync* sync = nullptr,
                               const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
   using T = double;
   static_assert(!(WSLDS && TILED), "tiles are dealt by the stand-alone kernel only");
+  static_assert(STG == 0 || (TILED && WARM == 0 && !RHAT), "staged tiles: cold, rhat folded into the image");
   // SPEC (fused / rollout kernels with the observer on, cold start): the target wrench b = w_des - rhat_base is the last input to arrive -- the observer
   // role's base rows end at about +6.2 us, the QP's factor is done at +3.6.  The iteration therefore STARTS on b~ = w_des - r_prev (the observer state as
   // the tick finds it: an input, one filter step away from rhat; QpArgs::rprev, null = opt out) and, when rhat is there, moves the solution to b on the
@@ -161,16 +162,19 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #define WBC_QP_CONS_EARLY 1
 #endif
 #define GST(ptr, comp, val) (*(TS*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS))) = (TS)(val))
+  const int stg_slot = (STG != 0 && live) ? who.slot : 0;
+#define IMG(comp) (((TS*)who.img)[(comp) * who.stride + stg_slot])
 
 #ifdef WBC_QP_STAMP
   const long long st_t0 = __builtin_readcyclecounter();
 #endif
   // ------------------------------------------------------------------ inputs
-  int mask = a.mask[s32] & 0xF;
+  int mask;
+  T n_ld, mu_f;
+  if constexpr (STG != 0) { mask = who.iimg[stg_slot] & 0xF; n_ld = isvar ? (T)IMG(ST_N + v) : (T)0; mu_f = (T)IMG(ST_MU + f); }
+  else { mask = a.mask[s32] & 0xF; n_ld = isvar ? GLD(a.normals, v) : (T)0; mu_f = GLD(a.mu, f); }
   bool on = (mask >> f) & 1;
-  const bool geom_jc = !WSLDS && a.Jc != nullptr;
-  const T n_ld = isvar ? GLD(a.normals, v) : (T)0;
-  const T mu_f = GLD(a.mu, f);
+  const bool geom_jc = STG == 0 && !WSLDS && a.Jc != nullptr;
   T rprev_in = 0;
   if constexpr (SPEC) { if (a.rprev && l16 < 6) rprev_in = GLD(a.rprev, l16); }   // (parked in LDS once b~ is formed: read back behind the iteration)
   int aset = 0;
@@ -207,7 +211,8 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   if constexpr (WSLDS) { if (sync) qp_wait(sync->geom, sync->need_geom); }
   WBC_QSTAMP(2);
   T d_me = 0;
-  if (geom_jc) {
+  if constexpr (STG != 0) { if (isvar) d_me = (T)IMG(ST_D + v); }
+  else if (geom_jc) {
     const int comp = c3 == 0 ? (3 * f + 1) * 18 + 5 : (c3 == 1 ? (3 * f + 2) * 18 + 3 : (3 * f) * 18 + 4);
     if (isvar) d_me = GLD(a.Jc, comp);
   } else if (isvar) d_me = WSLD(WS_D + v);
@@ -442,7 +447,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     if constexpr (PRE) {
       x_me = isvar ? who.pre[36 + v] : (T)0;
     } else {
-    const T b_ld = (l16 < 6) ? BLD(l16) - (SPEC ? rprev_in : (RHAT ? WSLD(WS_RHAT + l16) : (T)0)) : (T)0;   // (SPEC: b~, see the top)
+    T b_ld;
+    if constexpr (STG != 0) b_ld = (l16 < 6) ? (T)IMG(ST_B + l16) : (T)0;
+    else b_ld = (l16 < 6) ? BLD(l16) - (SPEC ? rprev_in : (RHAT ? WSLD(WS_RHAT + l16) : (T)0)) : (T)0;   // (SPEC: b~, see the top)
     if constexpr (SPEC) {
       if (l16 < 6) L.R[grp][l16] = rprev_in;
       if (sync && sync->rp_ack) {   // r_prev is in my registers: the observer role may overwrite it now (QpSync::rp_ack)
@@ -756,7 +763,8 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     const unsigned long long ba = __ballot(actA), bbm = __ballot(actB);
     const int aset_fin = (int)(((unsigned)(ba >> rowbase) & 0xFFFFu) | (((unsigned)(bbm >> rowbase) & 0xFFFFu) << 16));
     if constexpr (WARM == 2) { if (l16 == 0) *carry = aset_fin; }   // (LDS: read back by this row in the next tick -- program order of one wavefront)
-    if (a.aset_out && live && l16 == 0) a.aset_out[s32] = aset_fin;
+    if constexpr (STG != 0) { if (live && l16 == 0) who.iimg[3 * who.tile + stg_slot] = aset_fin; }
+    else if (a.aset_out && live && l16 == 0) a.aset_out[s32] = aset_fin;
   }
   bool to_mem = true;   // (QpSync::skip_out: wavefront-uniform)
   bool from_hand = false;   // (QpSync::hand)
@@ -775,7 +783,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #else
     sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
 #endif
-    if (isvar) {
+    if constexpr (STG != 0) {
+      if (isvar) { taup = (T)IMG(ST_TAUP + v); jl0 = (T)IMG(ST_JCL + 9 * f + 0 + c3); jl1 = (T)IMG(ST_JCL + 9 * f + 3 + c3); jl2 = (T)IMG(ST_JCL + 9 * f + 6 + c3); }
+    } else if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
       if (from_hand) {
         const int hslot = 16 * f + (int)((tx >> 4) & 15);   // (my state's slot in the workgroup)
@@ -789,7 +799,10 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
     const T xq0 = dppx<0x00>(x_me), xq1 = dppx<0x55>(x_me), xq2 = dppx<0xAA>(x_me);
     if (isvar) {
       const T fx = on ? xq0 : (T)0, fy = on ? xq1 : (T)0, fz = on ? xq2 : (T)0;
-      if (to_mem) {
+      if constexpr (STG != 0) {
+        IMG(ST_F + v) = (TS)(on ? x_me : (T)0);
+        IMG(ST_TAU + jm) = (TS)(taup - (jl0 * fx + jl1 * fy + jl2 * fz));
+      } else if (to_mem) {
         GST(a.f, v, on ? x_me : (T)0);
         GST(a.tau, jm, taup - (jl0 * fx + jl1 * fy + jl2 * fz));
       }
@@ -801,7 +814,9 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
         }
       }
     }
-    if (l16 == 0 && to_mem) {
+    if constexpr (STG != 0) {
+      if (l16 == 0) { who.iimg[who.tile + stg_slot] = status; who.iimg[2 * who.tile + stg_slot] = iter; }
+    } else if (l16 == 0 && to_mem) {
       a.status[s32] = status;
 #ifdef WBC_QP_STAMP
       {
@@ -820,6 +835,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   }
   WBC_QSTAMP(11);
 #undef SEG
+#undef IMG
 #undef GST
 #undef WSLD
 #undef BLD
@@ -831,11 +847,12 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #ifndef WBC_QP_STRUCT
 #define WBC_QP_STRUCT 2
 #endif
-template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0>
+template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0, int STG = 0>
 WBC_DEV void qp_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
                      const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
+  static_assert(STG == 0 || WBC_QP_STRUCT > 1, "staged tiles run the structured body");
   if constexpr (WARM != 0 || (WBC_QP_STRUCT != 0 && (WBC_QP_STRUCT > 1 || std::is_same<T, double>::value)))
-    qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle, PRE, WARM>(prm, a, jmap, wsl, sync, who, idle, carry);
+    qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle, PRE, WARM, STG>(prm, a, jmap, wsl, sync, who, idle, carry);
   else qp_group16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
 }
 

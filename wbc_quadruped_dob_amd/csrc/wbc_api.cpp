@@ -84,7 +84,7 @@ constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints 
 #ifndef WBC_COLAUNCH_MAX_F64
 #define WBC_COLAUNCH_MAX_F64 14336
 #endif
-struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max; };
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -362,6 +362,11 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // tiles dealt by predicted work (auto): fp64 from 14 336 states, fp32 from 30 720; per-lane QP pair (auto): fp64 from 106 496, fp32 from 212 992
   r.tile_min = dtype == WBC_F32 ? 30720 : 14336;
   r.lane_min = dtype == WBC_F32 ? 212992 : 106496;
+  // staged tiles (round 6, fp32 solvers; qp_stile_kernel): ONE workgroup of twelve wavefronts per CU holds the CU's share of the batch and its inputs in LDS.
+  // Measured on MI355X (profiles/r06b_ab_staged_tiles.log; QP stage in us, one-wavefront workgroups or gathered tiles -> staged): fp32 trot batch 16 384: 17.5 -> 16.2,
+  // 20 480: 19.9 -> 17.8, 24 576: 20.1 -> 15.6, 28 672: 22.5 -> 17.1, 32 768 (configs[3]'s shard): 22.6 -> 17.2, 40 960: 26.5 -> 20.8, 49 152: 26.9 -> 21.6
+  r.stile_min = dtype == WBC_F32 ? (size_t)WBC_STILE_MIN_F32 : (size_t)-1;
+  r.stile_max = dtype == WBC_F32 ? wbc::STILE_MAX_STATES : 0;
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
@@ -436,9 +441,11 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // 64 (576 workgroups, 2.25 per CU) 37.8 us, of 48 (768) 30.8 us; fp32 at 40 960: 64 -> 36.7, 80 (512 workgroups) -> 27.2.  So the tile is the
   // smallest size (steps of 4 / 8: k_qp.hip) that fits the batch into one round.
   int tile = warm ? (o.qp_tile == 0 && N >= r.warm_tile_min && !(f32 && N > 65536) ? 0 : -1) : o.qp_tile;   // (warm: the auto tiles only, and never the fp32 12 x 12 body, which reports no set)
+  bool staged = false;
   if (tile == 0) {
     if (f32) {
-      if (N >= r.tile_min && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
+      if (N >= (warm ? r.warm_tile_min : r.stile_min) && N <= r.stile_max) { tile = (int)(((N + 255) / 256 + 3) / 4 * 4); staged = true; }   // one workgroup per CU
+      else if (N >= r.tile_min && N <= 65536) { tile = (int)(((N + 767) / 768 + 7) / 8 * 8); tile = tile < 64 ? 64 : tile; }   // (159 registers since the QP weights stay scalar: three workgroups per CU, but 64-state tiles at two per CU beat 44-state ones at three: 22.2 vs 24.1 us at 32 768)
       else if (N > 65536) {                    // (beyond: the leaner fp32 body, FOUR workgroups per CU -- k_qp.hip: one round is 1 024 tiles)
         tile = (int)(((N + 1023) / 1024 + 7) / 8 * 8);
         tile = tile > 128 ? 64 : tile;         // (more than one round of 128-state tiles: many rounds of 64-state ones)
@@ -452,7 +459,8 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   if (p.lane) { p.qp = 2; p.tile = 0; }
   else { p.qp = tile > 0 ? 1 : 0; p.tile = tile; }
   p.qp_warm = warm && p.qp != 1;
-  p.qp_body = (p.qp == 1 && f32 && tile >= 64 && tile <= 128 && N >= (size_t)WBC_F32_DENSE_TILE_MIN) ? 1 : 0;
+  if (!warm && o.qp_tile > 0 && f32 && tile <= wbc::STILE_MAX_TILE && tile % 4 == 0 && N < (size_t)WBC_F32_DENSE_TILE_MIN) staged = true;   // (an explicit qp_tile: staged where the kernel exists)
+  p.qp_body = (p.qp == 1 && staged) ? 2 : ((p.qp == 1 && f32 && tile >= 64 && tile <= 128 && N >= (size_t)WBC_F32_DENSE_TILE_MIN) ? 1 : 0);
   return p;
 }
 
@@ -498,9 +506,9 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
-  size_t keep[16]; int k = 0;
+  size_t keep[20]; int k = 0;
   for (size_t c : cand) {
     if (c < 2 || c == (size_t)-1 || c > ((size_t)1 << 21)) continue;
     // an odd N never packs: compare like with like (both even) for the fp32 sweep, plain neighbours otherwise
@@ -512,7 +520,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
     if (!changes) continue;
     bool dup = false;
     for (int i = 0; i < k; ++i) dup = dup || keep[i] == c;
-    if (!dup && k < 16) keep[k++] = c;
+    if (!dup && k < 20) keep[k++] = c;
   }
   for (int i = 0; i < k; ++i) for (int j = i + 1; j < k; ++j) if (keep[j] < keep[i]) { const size_t t = keep[i]; keep[i] = keep[j]; keep[j] = t; }
   *n = k;
@@ -537,8 +545,8 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
     const int ok32[] = {0, -1, 32, 36, 40, 44, 48, 52, 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 256, 512};
     bool found = false;
     if (dtype == WBC_F64) { for (int v : ok64) found = found || o.qp_tile == v; }
-    else { for (int v : ok32) found = found || o.qp_tile == v; }
-    if (!found) return fail(WBC_E_INVALID, "qp_tile: 0 (auto), -1 (off), 32, 64, 128, 256, 512; fp64 also 36 ... 60 in steps of 4, fp32 also 72 ... 120 in steps of 8");
+    else { for (int v : ok32) found = found || o.qp_tile == v; found = found || (o.qp_tile > 0 && o.qp_tile <= wbc::STILE_MAX_TILE && o.qp_tile % 4 == 0); }
+    if (!found) return fail(WBC_E_INVALID, "qp_tile: 0 (auto), -1 (off), 32, 64, 128, 256, 512; fp64 also 36 ... 60 in steps of 4, fp32 also every multiple of 4 up to 192");
   }
   if (o.timing_mode != WBC_TIMING_DISPATCH && o.timing_mode != WBC_TIMING_EVENT_PAIR) return fail(WBC_E_INVALID, "bad timing_mode");
   if (o.f32_pack2 < -1 || o.f32_pack2 > 1) return fail(WBC_E_INVALID, "f32_pack2 must be -1, 0 or 1");
@@ -881,7 +889,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, 0, dp, qa, s->jmap, s->d_todo, warm));
     return WBC_OK;
   }
-  TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, pl.tile, dp, qa, s->jmap, nullptr, warm));
+  TIMED_LAUNCH(1, st, "qp", k_qp<T>(L, pl.obs_split, pl.tile, dp, qa, s->jmap, nullptr, warm, pl.qp_body));
   return WBC_OK;
 }
 
