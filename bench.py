@@ -288,7 +288,8 @@ def main():
 
     if rank == 0:
         ts = 8 if dtype == "f64" else 4
-        fused = tm.get("fused_launches", 0) > 0   # small batches: sweep + QP run as ONE kernel (fused_tick_kernel)
+        fused = tm.get("fused_launches", 0) > 0   # the whole tick as ONE kernel: fused_tick_kernel (small batches) or tile_tick_kernel (wbc_tick_plan.fused = 2)
+        tile_tick = fused and solver.plan_tick(n, want_mats=want_mats)["fused"] == 2
         dyn_s = (tm["fused_ms"] * 1e-3 / tm["fused_launches"]) if fused else tm["dyn_ms"] * 1e-3 / max(1, tm["dyn_launches"])
         qp_s = tm["qp_ms"] * 1e-3 / max(1, tm["qp_launches"])
         qpl_s = tm.get("qp_lane_ms", 0.0) * 1e-3 / max(1, tm.get("qp_lane_launches", 0))
@@ -332,10 +333,11 @@ def main():
                                                              "on" if obs else "off", dtype),
                        "batch_per_gpu": n, "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "writes_M_h_Jc": want_mats},
-            "roofline": {"kernel": ("fused_tick_kernel" if fused else tick_sweep_name(dtype, obs, n, split)),
+            "roofline": {"kernel": (("tile_tick_kernel (sweep + observer roles of a 64 / 96 / 128-state workgroup, then the staged QP tile of the same states: one launch)" if tile_tick
+                                     else "fused_tick_kernel") if fused else tick_sweep_name(dtype, obs, n, split)),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": pmc_traffic(("fused_tick" if fused else tick_sweep_symbol(dtype, obs, n)), n, dtype),
+                         "traffic": pmc_traffic((("tile_tick" if tile_tick else "fused_tick") if fused else tick_sweep_symbol(dtype, obs, n)), n, dtype),
                          "traffic_source": PMC_SOURCE,
                          "algorithmic_words_per_state": words,
                          "algorithmic_bytes_per_launch": dyn_bytes, "avg_launch_us": dyn_s * 1e6,
@@ -348,10 +350,12 @@ def main():
                          "event_pair_overhead_us": ev_overhead_us,
                          "note": ("HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on the launch stream, every "
                                   "%d-th tick of the timed region" % sample) +
+                                 ("; the whole tick is ONE launch (a workgroup per CU runs the dynamics roles, then the staged QP tile of its own states), so `achieved` = the "
+                                  "algorithmic bytes of the whole tick (inputs incl. observer state + tau, f + M, h, Jc + new observer state) over that launch" if tile_tick else "") +
                                  ("; at this batch the whole tick is ONE launch (dynamics + GRF QP as wavefront roles of a "
                                   "workgroup, latency-bound: one workgroup per CU), so `achieved` = the algorithmic bytes of the whole tick "
                                   "(inputs + tau, f + M, h, Jc) over that launch -- see roofline_dyn_sweep_alone for the 443-word "
-                                  "sweep kernel by itself at this batch and roofline_large_batch for the HBM-bound regime" if fused else "")},
+                                  "sweep kernel by itself at this batch and roofline_large_batch for the HBM-bound regime" if (fused and not tile_tick) else "")},
             "kernels": {"dyn_sweep_us": None if fused else dyn_s * 1e6, "fused_tick_us": dyn_s * 1e6 if fused else None,
                         "rnea_step_us": rnea_s * 1e6 if tm["rnea_launches"] else None,
                         "qp_us": None if fused else qp_s * 1e6,

@@ -151,6 +151,10 @@ typedef struct wbc_solver_options {
                              ONE LAUNCH (wbc_tick_plan.front = 4) while both roles' wavefronts are resident together -- fp32 batches of 12290 ... 32768
                              states (even; both roles with two states per lane), BASELINE's configs[3] shard; fp64 batches of 12289 ... 14336.
                              0 = auto, 1 = whenever the tick is a two-kernel tick with the observer on, -1 = never */
+  int tile_tick;          /* (ABI 8) fp32 observer-on ticks with M/h/Jc outputs of an even batch: ONE launch of 128-state workgroups, one per CU -- the sweep and
+                             observer roles of obs_colaunch side by side in a workgroup, then the staged QP tile of the same states behind one barrier
+                             (wbc_tick_plan.fused = 2).  0 = auto (from 12290 states on; 64 / 96 / 128 states per workgroup: one round of workgroups up to 32768 states,
+                             BASELINE's configs[3] shard), 1 = every such tick beyond the fused_tick size, -1 = never */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -163,7 +167,8 @@ int wbc_solver_invalidate_structural(wbc_solver* s);
  * that a caller -- and the parity tests, which straddle every switch -- never restate them.  All fields are informational. */
 typedef struct wbc_tick_plan {
   size_t struct_size; /* in: sizeof of the caller's build (0 = this build's); out: bytes written */
-  int fused;          /* 1: the whole tick is ONE fused_tick launch (wavefront roles); everything below is 0 then */
+  int fused;          /* 1: the whole tick is ONE fused_tick launch (wavefront roles); everything below is 0 then.  2: ONE tile_tick launch (sweep | observer roles,
+                         then the staged QP tile of the same states: front = 4, qp = 1, qp_body = 2, qp_tile = states per workgroup say what runs inside it) */
   int front;          /* two-kernel ticks, front half: 0 = dyn_sweep (observer inside when on), 1 = rnea_step (caller passes no M/h/Jc),
                          2 = observer kernel + observer-free dyn_sweep, 3 = observer kernel + observer-free rnea_step (no M/h/Jc),
                          4 = observer update and observer-free dyn_sweep as the two roles of ONE launch (sweep_obs_kernel) */
@@ -432,7 +437,7 @@ int wbc_qp_dense_batch(int dtype, size_t N, int n, int m, int meq, const void* H
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void); /* 7 */
+int wbc_abi_version(void); /* 8 */
 
 #ifdef __cplusplus
 }

@@ -118,18 +118,22 @@ def _dispatch_cases(want_mats=True):
     if not os.path.exists(W.LIB_PATH):
         W.build_library()
     cases = []
-    for dtype, obs, cfg in (("f64", 0, 2), ("f64", 1, 3), ("f32", 1, 4), ("f32", 0, 2)):
-        for t in W.dispatch_thresholds(dtype, obs, want_mats=want_mats):
+    # (round 6: even fp32 observer-on batches beyond the fused size all run the tile tick; the two-launch plans underneath -- what odd batches and
+    #  tile_tick = -1 callers get -- keep their own straddling cases)
+    for dtype, obs, cfg, opt in (("f64", 0, 2, None), ("f64", 1, 3, None), ("f32", 1, 4, None), ("f32", 0, 2, None), ("f32", 1, 4, {"tile_tick": -1})):
+        if opt and not want_mats:
+            continue
+        for t in W.dispatch_thresholds(dtype, obs, want_mats=want_mats, options=opt):
             # fp32: the packed sweep needs an even batch, so both sides are even (like with like)
             lo, hi = (t - 1, t) if dtype == "f64" else ((t - 2, t) if t % 2 == 0 else (t - 1, t + 1))
-            cases.append(pytest.param(dtype, obs, cfg, lo, hi, id="%s-obs%d-%d|%d" % (dtype, obs, lo, hi)))
+            cases.append(pytest.param(dtype, obs, cfg, lo, hi, opt, id="%s-obs%d-%d|%d%s" % (dtype, obs, lo, hi, "-two-launch" if opt else "")))
     return cases
 
 
-def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_rank=17, want_mats=True):
+def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_rank=17, want_mats=True, options=None):
     nd = _np_dtype(dtype)
     c = lambda a: np.ascontiguousarray(a, nd)
-    solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n)
+    solver, P = _solver(gpu_model, dtype=dtype, obs=obs, max_batch=n, options=options)
     B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=seed_rank)
     integ = r = None
     if obs:
@@ -169,20 +173,20 @@ def _step_default_vs_oracle(torch, gpu_model, oracle, dtype, obs, cfg, n, seed_r
     return solver
 
 
-@pytest.mark.parametrize("dtype,obs,cfg,lo,hi", _dispatch_cases())
-def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, lo, hi):
+@pytest.mark.parametrize("dtype,obs,cfg,lo,hi,opt", _dispatch_cases())
+def test_default_dispatch_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, lo, hi, opt):
     import wbc_quadruped_dob_amd as W
-    p_lo, p_hi = W.plan_tick(lo, dtype, obs), W.plan_tick(hi, dtype, obs)
+    p_lo, p_hi = W.plan_tick(lo, dtype, obs, options=opt), W.plan_tick(hi, dtype, obs, options=opt)
     assert p_lo != p_hi, "no switch between %d and %d: %r" % (lo, hi, p_lo)       # the planner really changes kernels here
     for n, plan in ((lo, p_lo), (hi, p_hi)):
-        solver = _step_default_vs_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n)
+        solver = _step_default_vs_oracle(torch_cuda, gpu_model, oracle, dtype, obs, cfg, n, options=opt)
         assert solver.plan_tick(n) == plan                                           # ... and the solver launches what the planner says
         del solver
         torch_cuda.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("dtype,obs,cfg,lo,hi", _dispatch_cases(want_mats=False))
-def test_default_dispatch_without_matrix_outputs_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, lo, hi):
+@pytest.mark.parametrize("dtype,obs,cfg,lo,hi,opt", _dispatch_cases(want_mats=False))
+def test_default_dispatch_without_matrix_outputs_either_side_of_every_switch(torch_cuda, gpu_model, oracle, dtype, obs, cfg, lo, hi, opt):
     """The same for ticks whose caller passes no M / h / Jc buffers (tau, f only: what a controller needs): rnea_step front half, from
     16 384 fp64 / 32 768 fp32 observer-on states the observer kernel + the observer-free rnea_step."""
     import wbc_quadruped_dob_amd as W

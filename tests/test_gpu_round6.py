@@ -93,3 +93,89 @@ def test_staged_tiles_report_the_active_sets_a_warm_tick_starts_from(torch_cuda,
     assert torch.equal(o2["status"], st1)
     assert relerr(to_host(o2["tau"]), to_host(tau1)) < 1e-5
     assert torch.equal(o2["active"], sets)
+
+
+def _tick_inputs(torch, gpu_model, solver, n, rank):
+    B = synth.make_batch(4, n, gpu_model.total_mass, rank=rank)
+    td = torch.float32
+    dv = lambda k: to_dev(B[k], torch, td)
+    mask = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
+    ig = solver.dynamics(dv("q"), dv("v"), want=("p",))["p"]
+    r = to_dev(0.05 * np.cos(np.arange(n * 18).reshape(n, 18)), torch, td)
+    return B, [dv(k) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")] + [mask, dv("tau_prev"), dv("f_prev")], ig, r
+
+
+@pytest.mark.parametrize("n,obs,force", [(32768, 1, 0), (12290, 1, 0), (20002, 2, 0), (24576, 1, 0), (40000, 1, 1), (130, 1, 1), (65536, 2, 1), (16384, 1, 0), (8200, 1, 1)])
+def test_tile_tick_equals_the_two_launch_tick_bit_for_bit_and_the_oracle(torch_cuda, gpu_model, oracle, n, obs, force):
+    """tile_tick_kernel (wbc_tick_plan.fused = 2): the sweep and observer roles of sweep_obs_kernel side by side in a 64 / 96 / 128-state workgroup, then the
+    staged QP tile of the same states behind one barrier.  Role bodies and QP stage are those of the two launches and no state's arithmetic depends on which
+    states share its wavefront or tile, so every output -- M, h, Jc, pf, tau, f, status, iters, the new observer state -- is BIT-IDENTICAL to
+    sweep_obs -> staged tiles; and within the fp32 gates of the fp32 oracle.  Ragged ends, every workgroup size, more than one round of workgroups."""
+    torch = torch_cuda
+    outs = {}
+    for tag, tt in (("tile", 1 if force else 0), ("two", -1)):
+        opt = {"tile_tick": tt, "fused_max": 0} if (force or tt < 0) else {}
+        if tt < 0:
+            opt.update({"obs_colaunch": 1, "qp_tile": 64})
+        solver, P = _solver(gpu_model, dtype="f32", obs=obs, max_batch=n, options=opt)
+        pl = solver.plan_tick(n)
+        assert pl["fused"] == (2 if tag == "tile" else 0), (tag, pl)
+        if tag == "tile":
+            assert pl["qp_tile"] in (64, 96, 128) and (force or (n + pl["qp_tile"] - 1) // pl["qp_tile"] <= 256)
+        else:
+            assert pl["front"] == 4 and pl["qp_body"] == 2
+        B, args, ig, r = _tick_inputs(torch, gpu_model, solver, n, rank=17)
+        if tag == "tile":
+            ig0, r0 = to_host(ig).copy(), to_host(r).copy()
+        out = solver.step(*args, ig, r, want_mats=True)
+        torch.cuda.synchronize()
+        outs[tag] = {k: v.clone() for k, v in out.items()}
+        outs[tag]["integ"], outs[tag]["r"] = ig.clone(), r.clone()
+    for k, v in outs["tile"].items():
+        assert torch.equal(v, outs["two"][k]), k
+    c = lambda a: np.ascontiguousarray(a, np.float32)
+    P0 = synth.default_params(observer_order=obs, dtype="f32")
+    ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], c(B["tau_prev"]), c(B["f_prev"]), ig0, r0, nthreads=8)
+    st = outs["tile"]["status"].cpu().numpy()
+    flips = st != ref["status"]
+    assert flips.mean() <= F32_FLIPS
+    ok = ~flips & (ref["status"] == 0)
+    assert relerr(to_host(outs["tile"]["tau"])[ok], ref["tau"][ok]) < F32_TOL and relerr(to_host(outs["tile"]["f"])[ok], ref["f"][ok]) < F32_TOL
+    assert relerr(to_host(outs["tile"]["r"]), r0) < 1e-4 and relerr(to_host(outs["tile"]["h"]), oracle.dynamics(B["q"], B["v"], nthreads=8)["h"]) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["tile_tick", "staged"])
+def test_round6_ticks_are_graph_capturable(torch_cuda, gpu_model, mode):
+    """The tile tick and the staged QP tiles (kernels with > 64 kB of dynamic LDS: the limit is raised at solver creation) captured into a hipGraph
+    replay bit for bit -- also when the FIRST launch of the process's kernel happens under capture (no eager warm-up of this solver's kernel variant)."""
+    torch = torch_cuda
+    n = 1000
+    opt = {"fused_max": 0, "tile_tick": 1} if mode == "tile_tick" else {"fused_max": 0, "tile_tick": -1, "qp_tile": 52}
+    solver, P = _solver(gpu_model, dtype="f32", obs=1, max_batch=n, options=opt)
+    pl = solver.plan_tick(n)
+    assert (pl["fused"] == 2) if mode == "tile_tick" else (pl["fused"] == 0 and pl["qp_body"] == 2), pl
+    B, args, ig, r = _tick_inputs(torch, gpu_model, solver, n, rank=23)
+    ig0, r0 = ig.clone(), r.clone()
+    run, out = solver.prepare_step(*args, ig, r, want_mats=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        run()
+    ig.copy_(ig0); r.copy_(r0)
+    for t in out.values():
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    got = {k: t.clone() for k, t in out.items()}
+    got["ig"], got["r"] = ig.clone(), r.clone()
+    ig.copy_(ig0); r.copy_(r0)
+    for t in out.values():
+        t.zero_()
+    run()
+    torch.cuda.synchronize()
+    want = dict(out, ig=ig, r=r)
+    for k in got:
+        assert torch.equal(got[k], want[k]), (mode, k)
+    assert int(got["iters"].max()) > 0

@@ -250,12 +250,18 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     import wbc_quadruped_dob_amd as W
     assert W.dispatch_thresholds("f64", 0) == [11265, 14336, 65536, 106496]
     assert W.dispatch_thresholds("f64", 1) == [12289, 14336, 14337, 20480, 65536, 106496]
-    assert W.dispatch_thresholds("f32", 1) == [12289, 16384, 32769, 33792, 49153, 65537, 131072, 212992]      # (round 6: staged QP tiles 16 384 .. 49 152)
-    assert [(W.plan_tick(n, "f32", 1)["qp_body"], W.plan_tick(n, "f32", 1)["qp_tile"]) for n in (16382, 16384, 32768, 49152, 49154)] == [(0, 0), (2, 64), (2, 128), (2, 192), (0, 72)]
+    # round 6: even fp32 observer-on batches of 12 290 .. 32 768 states run the tile tick (one launch of 64 / 96 / 128-state workgroups); staged QP tiles up to 49 152
+    assert W.dispatch_thresholds("f32", 1) == [12289]
+    assert W.dispatch_thresholds("f32", 1, options={"tile_tick": -1}) == [12289, 16384, 32769, 33792, 49153, 65537, 131072, 212992]
+    assert [(W.plan_tick(n, "f32", 1)["fused"], W.plan_tick(n, "f32", 1)["qp_tile"]) for n in (12288, 12290, 16384, 16386, 24576, 24578, 32768, 32770, 32771, 262144)] == [
+        (1, 0), (2, 64), (2, 64), (2, 96), (2, 96), (2, 128), (2, 128), (2, 128), (0, 132), (2, 128)]
+    assert W.dispatch_thresholds("f32", 0) == [11265, 16384, 32768, 49153, 65537, 131072, 212992]
+    assert [(W.plan_tick(n, "f32", 0)["qp_body"], W.plan_tick(n, "f32", 0)["qp_tile"]) for n in (16382, 16384, 32768, 49152, 49154)] == [(0, 0), (2, 64), (2, 128), (2, 192), (0, 72)]
+    assert W.plan_tick(32768, "f32", 1, options={"tile_tick": -1}) == dict(fused=0, front=4, qp=1, qp_tile=128, qp_body=2, sweep_pack2=1, sweep_block=64, qp_warm=0)
     assert [W.plan_tick(n, "f64", 1)["front"] for n in (12288, 12289, 14336, 14337, 20480)] == [0, 4, 4, 0, 2]
-    assert [W.plan_tick(n, "f32", 1)["front"] for n in (12290, 12291, 32768, 32770, 33792)] == [4, 0, 4, 0, 2]
-    assert W.plan_tick(20000, "f32", 1)["sweep_pack2"] == 1 and W.plan_tick(20000, "f32", 1, options={"obs_colaunch": -1})["sweep_pack2"] == 0
-    assert W.plan_tick(262144, "f64", 0)["qp"] == 2 and W.plan_tick(262144, "f32", 1) == dict(
+    assert [W.plan_tick(n, "f32", 1, options={"tile_tick": -1})["front"] for n in (12290, 12291, 32768, 32770, 33792)] == [4, 0, 4, 0, 2]
+    assert W.plan_tick(20000, "f32", 1)["sweep_pack2"] == 1 and W.plan_tick(20000, "f32", 1, options={"obs_colaunch": -1, "tile_tick": -1})["sweep_pack2"] == 0
+    assert W.plan_tick(262144, "f64", 0)["qp"] == 2 and W.plan_tick(262144, "f32", 1, options={"tile_tick": -1}) == dict(
         fused=0, front=2, qp=2, qp_tile=0, qp_body=0, sweep_pack2=1, sweep_block=256, qp_warm=0)
     # options move the switches, and the list follows
     assert W.dispatch_thresholds("f64", 0, options={"qp_lane": -1, "qp_tile": -1, "fused_max": 0}) == [65536]
@@ -266,7 +272,7 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.plan_tick(262144, "f64", 0, want_mats=False)["front"] == 1
     # warm-started ticks (wbc_step_batch_warm): fused, warm one-wavefront kernel, cold tiles that only report the sets, warm per-lane pair
     assert W.dispatch_thresholds("f64", 1, warm=True) == [12289, 14337, 20480, 24576, 53248, 65536]
-    assert W.dispatch_thresholds("f32", 1, warm=True) == [12289, 30720, 32769, 33792, 36864, 131072]
+    assert W.dispatch_thresholds("f32", 1, warm=True) == [12289, 30720, 36864, 131072]
     assert [W.plan_tick(n, "f64", 1, warm=True)["qp_warm"] for n in (4096, 13000, 20000, 30000, 60000)] == [1, 1, 1, 0, 1]
     assert [W.plan_tick(n, "f64", 1, warm=True)["qp"] for n in (13000, 20000, 30000, 60000)] == [0, 0, 1, 2]
     assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((11264, 0), (11265, 0), (12288, 1), (12289, 1))] == [1, 0, 1, 0]

@@ -2,12 +2,13 @@
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 L=gpurun_out/r06_run.log; : > $L
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 >> $L
-echo "=== staged tiles, first ticks" >> $L
-WBC_LIB=$PWD/wbc_quadruped_dob_amd/lib_tstamp/libwbc_hip.so timeout 300 python tools/tile_stamp.py 32768 f32 4 128 12 5 >> $L 2>&1
-echo "=== staged tiles, bench steady state" >> $L
-WBC_LIB=$PWD/wbc_quadruped_dob_amd/lib_tstamp/libwbc_hip.so timeout 300 python tools/tile_stamp.py 32768 f32 4 128 12 2000 >> $L 2>&1
-tools/ab_r06.sh "--steps 100 --warmup 10 --batch 32768 --config 4" lib_base lib >> $L 2>&1
-tools/ab_r06.sh "--steps 100 --warmup 10 --batch 16384 --config 4" lib_base lib >> $L 2>&1
-tools/ab_r06.sh "--steps 100 --warmup 10 --batch 49152 --config 4" lib_base lib >> $L 2>&1
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 >> $L
+B="python bench.py --no-cpu --no-latency --large-batch 0 --no-closed-loop"
+pick='import sys,json; d=json.loads(sys.stdin.read()); k=d.get("kernels") or {}; f=lambda x: "-" if x is None else "%.2f" % x; print("%-12s %-44s %9.1f M steps/s  %8.4f ms/step  fused %s sweep %s  qp %s lane %s" % (sys.argv[1], sys.argv[2], d["value"]/1e6, d["ms_per_step"], f(k.get("fused_tick_us")), f(k.get("dyn_sweep_us")), f(k.get("qp_us")), f(k.get("qp_lane_us"))))'
+for n in 36864 40960 45056 49152 57344 65536 73728 81920 90112 98304 114688 131072 163840 196608 229376 262144; do
+  st=$(( 3000000 / n + 10 ))
+  A="--steps $st --warmup 5 --batch $n --config 4"
+  WBC_TILE_TICK=-1 $B $A 2>/dev/null | python -c "$pick" "two-launch" "$A" >> $L
+  WBC_TILE_TICK=1 $B $A 2>/dev/null | python -c "$pick" "tile_tick" "$A" >> $L
+done
 cat $L

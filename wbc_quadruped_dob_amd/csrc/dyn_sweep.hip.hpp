@@ -329,8 +329,9 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
   // lane = 16*leg + (state within the wave): each 16-lane row owns one leg of 16 consecutive states
-  const int leg = (int)((threadIdx.x & 63) >> 4);
-  const size_t s_raw = (((size_t)blk * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 15)) * W;   // first state of this lane
+  const unsigned tix = threadIdx.x & (unsigned)(BLOCK - 1);   // thread within the BLOCK threads that run this body (a kernel may run several bodies side by side: tile_tick.hip.hpp)
+  const int leg = (int)((tix & 63) >> 4);
+  const size_t s_raw = (((size_t)blk * (BLOCK / 64) + (tix >> 6)) * 16 + (tix & 15)) * W;   // first state of this lane
   const bool live = s_raw < N;                            // (W = 2: N is even, so both states of a lane are in range together)
   // Dead lanes (beyond the batch) recompute the last state(s) and STORE what they computed: bit-identical duplicates of the live
   // lane's values at the same addresses.  Guarding every store with `if (live)` made each of the ~100 stores its own exec region
@@ -406,11 +407,11 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 
   SSTAMP();  // 1: state loads issued
   // the per-leg constant table is staged AFTER the state loads have been issued: one memory round trip, not two
-  for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
-  if (MATS && threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
+  for (int i = tix; i < CST_WORDS; i += BLOCK) cst[i] = model->cst[i];
+  if (MATS && tix < 64) zidx_s[tix] = model->zidx[tix];
   // observer gains of the joint rows are indexed by a run-time joint number: from LDS (a dynamic index into the
   // kernel-argument struct can end up as a private copy of the whole struct)
-  if (OBS && threadIdx.x == 0) {
+  if (OBS && tix == 0) {
 #pragma unroll
     for (int i = 0; i < 18; ++i) { kgain[i] = prm.K1[i]; kgain[18 + i] = prm.K2[i]; }  // static indices only
   }
@@ -494,7 +495,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   bI.xx = model->base_Io[0]; bI.xy = model->base_Io[1]; bI.xz = model->base_Io[2];
   bI.yy = model->base_Io[3]; bI.yz = model->base_Io[4]; bI.zz = model->base_Io[5];
   // the base body's own wrench / momentum / weight are formed now, so that om0, v0, aL0 die after joint 0
-  const int ln = threadIdx.x;
+  const int ln = (int)tix;
   V* const px = &park[2 * PW + PB + PE2][ln];
   {
 #pragma unroll

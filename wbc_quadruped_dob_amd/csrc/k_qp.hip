@@ -11,11 +11,11 @@ namespace wbc {
 template <int NW, int CH>
 static hipError_t qp_staged(const LaunchCtx& L, bool rhat, int tile, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap) {
   using T = Scalar;
-  const size_t smem = stile_lds_bytes(tile, sizeof(T));
+  const size_t smem = stile_lds_bytes(tile, sizeof(T), NW);
   static bool raised[2] = {false, false};   // (more than 64 kB of dynamic LDS needs the attribute once per kernel)
   if (!raised[rhat ? 1 : 0]) {
-    const hipError_t e = rhat ? hipFuncSetAttribute((const void*)qp_stile_kernel<T, true, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024 - (int)(NW * sizeof(S16Lds<double>)))
-                              : hipFuncSetAttribute((const void*)qp_stile_kernel<T, false, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024 - (int)(NW * sizeof(S16Lds<double>)));
+    const hipError_t e = rhat ? hipFuncSetAttribute((const void*)qp_stile_kernel<T, true, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                              : hipFuncSetAttribute((const void*)qp_stile_kernel<T, false, NW, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     raised[rhat ? 1 : 0] = true;
   }
@@ -106,6 +106,19 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
   else WBC_KLAUNCH(L, (qp_group16_kernel<T, false>), grid, dim3(64), prm, a, jmap);
   return hipGetLastError();
 }
+
+template <class T>
+static hipError_t qp_prepare_t() {
+  if constexpr (std::is_same<T, float>::value) {
+    hipError_t e = hipSuccess;
+    auto up = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    up((const void*)qp_stile_kernel<T, true, 12, 1>); up((const void*)qp_stile_kernel<T, false, 12, 1>);
+    up((const void*)qp_stile_kernel<T, true, 12, 2>); up((const void*)qp_stile_kernel<T, false, 12, 2>);
+    up((const void*)qp_stile_kernel<T, true, 12, 3>); up((const void*)qp_stile_kernel<T, false, 12, 3>);
+    return e;
+  } else return hipSuccess;
+}
+template <> hipError_t k_qp_prepare<Scalar>() { return qp_prepare_t<Scalar>(); }
 
 template <>
 hipError_t k_qp_lane<Scalar>(const LaunchCtx& L, bool rhat, const DevParams<Scalar>& prm, const QpArgs<Scalar>& a, const QpJidx& jmap, int* todo, bool warm) {

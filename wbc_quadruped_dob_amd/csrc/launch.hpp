@@ -46,6 +46,17 @@ template <class T> hipError_t k_rnea_step(const LaunchCtx& L, int mode, const De
 template <class T> hipError_t k_observer(const LaunchCtx& L, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
 // sweep_obs_kernel<T, W>: k_observer and the observer-free k_dyn_sweep(SW_MATS | SW_STEP | SW_NOB) as the two roles of ONE launch (mid-size observer-on batches)
 template <class T> hipError_t k_sweep_obs(const LaunchCtx& L, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a);
+// tile_tick_kernel<T, W, NS>: the whole tick of a mid-size observer-on fp32 batch (even N, M / h / Jc outputs) as one launch of `states`-state workgroups
+// (64 | 96 | 128: NS = 2 | 3 | 4 packed sweep wavefronts + as many observer wavefronts): sweep | observer roles, then the staged QP tile of the same
+// states (tile_tick.hip.hpp).  The host picks the smallest size that makes ONE round of workgroups on the 256 CUs.
+constexpr int TILE_TICK_STATES = 128;
+inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : 128); }
+#ifndef WBC_TILE_TICK_MIN
+#define WBC_TILE_TICK_MIN 12290
+#endif
+template <class T> hipError_t k_tile_prepare();   // raises the dynamic-LDS limit of the tile_tick kernels (once per process and device)
+template <class T> hipError_t k_qp_prepare();     // ... of the staged QP tile kernels
+template <class T> hipError_t k_tile_tick(const LaunchCtx& L, int states, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);
 // GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran).
 // tile = 0: qp_group16_kernel, one wavefront per workgroup, four consecutive states per wavefront;
 // tile = 64 | 128 | 256 | 512: qp_tile_kernel, workgroups of four wavefronts deal a tile of that many states by predicted work

@@ -327,7 +327,7 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   T (&cst)[CST_WORDS] = lds.cst;
   T (&kgain)[36] = lds.kgain;
   V (&park)[3 * PKW][BLOCK] = lds.park;
-  unsigned tx = threadIdx.x;
+  unsigned tx = threadIdx.x & (unsigned)(BLOCK - 1);   // (thread within the BLOCK threads that run this body)
   asm volatile("" : "+v"(tx));   // see WBC_LAUNDERED_TID (dyn_split.hip.hpp)
   const size_t N = a.N;
   const unsigned N32 = (unsigned)N;
@@ -599,6 +599,11 @@ __global__ __launch_bounds__(64, 2) void sweep_obs_kernel(const DevModel<T>* __r
   };
   __shared__ Lds lds;
   if (a.qp_todo && blockIdx.x == 0 && threadIdx.x == 0) a.qp_todo[0] = 0;
+#ifdef WBC_SO_STAMP   // diagnostic build (tools/so_stamp.py): role, 100 MHz wall clock at entry / exit and the hardware slot of every workgroup, in place of pf
+  unsigned* const so_stamp = (unsigned*)a.pf;
+  a.pf = nullptr;
+  const long long so_t0 = wall_clock64();
+#endif
   // -DWBC_SWEEP_OBS_PRIO=1: the sweep role (the longer chain: ~16 us alone against ~12) at a higher issue priority than the observer role it shares SIMDs with
 #ifndef WBC_SWEEP_OBS_PRIO
 #define WBC_SWEEP_OBS_PRIO 0
@@ -607,6 +612,15 @@ __global__ __launch_bounds__(64, 2) void sweep_obs_kernel(const DevModel<T>* __r
     if constexpr (WBC_SWEEP_OBS_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     dyn_sweep_body<T, MODE, 64, W>(model, prm, a, lds.sw, blockIdx.x);
   } else observer_park_body<T, 64, W>(model, prm, a, lds.ob, blockIdx.x - nsweep);
+#ifdef WBC_SO_STAMP
+  if (so_stamp && threadIdx.x == 0) {
+    const long long so_t1 = wall_clock64();
+    unsigned* o = so_stamp + (size_t)blockIdx.x * 8;
+    o[0] = blockIdx.x < nsweep ? 0u : 1u; o[1] = (unsigned)so_t0; o[2] = (unsigned)so_t1;
+    o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+    o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+  }
+#endif
 }
 
 }  // namespace wbc

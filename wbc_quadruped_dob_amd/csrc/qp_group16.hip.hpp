@@ -205,6 +205,7 @@ struct QpWho {
   // STG (staged tiles, qp_kernels.hip.hpp): the tile's inputs wait in an LDS image [ST_WORDS][stride] of the solver's scalar type, the state is column
   // `slot`; f, tau go back into the image and status / iters / active set into iimg ([4][tile]: mask, status, iters, set) -- the body touches no memory
   void* img = nullptr; int* iimg = nullptr; int slot = 0, stride = 0, tile = 0;
+  void* tab = nullptr;   // this wavefront's solver tables (S16Lds<double>)
 };
 // rows of the staged image: normals 12, mu 4, lever arms 12, b = w_des - rhat_base 6, tau_partial - rhat_joint 12 (leg-major), own-leg Jacobian blocks 36
 // (9 f + 3 m + k), then the results f 12, tau 12 (caller's joint order)

@@ -358,17 +358,18 @@ __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_
 // the one queue (two 64-state tiles per CU level only within each tile: the slower tile of a CU set the pace).
 // Same keys, same order of the groups within a tile, same arithmetic per state as qp_tile_kernel.
 constexpr int STILE_IN_ROWS = 82;   // staged input rows per state (ST_F: the results follow)
-constexpr size_t stile_lds_bytes(int tile, size_t scalar) {
-  return (size_t)ST_WORDS * (size_t)(tile | 1) * scalar + (size_t)tile * (4 * 4 + 4 * 4 + 4 * scalar + 2) + 64 * 4 * 2 + 16;
+constexpr size_t stile_lds_bytes(int tile, size_t scalar, int nw) {
+  return (size_t)nw * sizeof(S16Lds<double>) + (size_t)ST_WORDS * (size_t)(tile | 1) * scalar + (size_t)tile * (4 * 4 + 4 * 4 + 4 * scalar + 2) + 64 * 4 * 2 + 16;
 }
+// the stage as a function of the workgroup's dynamic LDS (`smem`, stile_lds_bytes bytes, 16-byte aligned) and of this wavefront's index among the NW that
+// run it: the stand-alone kernel below, and the second half of tile_tick_kernel (tile_tick.hip.hpp).  blk = the tile's index.
 template <class T, bool RHAT, int NW, int CH>
-__global__ __launch_bounds__(64 * NW, (NW > 8 ? 3 : 2)) void qp_stile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int tile) {
+WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int tile, unsigned blk, unsigned char* smem, unsigned wave_in) {
   constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
-  static_assert(NW >= 4 * CH, "the predictor needs one thread per foot and state");
-  using A = T;
-  extern __shared__ __attribute__((aligned(16))) unsigned char stile_dyn[];
+  using A = T;   // (the caller sizes the tile: 4 tile <= 64 NW, one predictor thread per foot and state)
   const int ST = tile | 1;   // row stride of the image: the sixteen lanes of a row read sixteen ROWS of one column -- an odd stride spreads them over the banks
-  T* const img = (T*)stile_dyn;
+  S16Lds<double>* const tabs = (S16Lds<double>*)smem;   // [NW] solver tables, one per wavefront
+  T* const img = (T*)(tabs + NW);
   A* const pmag = (A*)(img + ST_WORDS * ST);            // [4][tile] per foot: summed violation at x0
   int* const iimg = (int*)(pmag + 4 * tile);            // [4][tile] mask | status | iters | active set
   int* const pcnt = iimg + 4 * tile;                    // [4][tile] per foot: violated rows at x0 (bit 8: some slack of the foot is below the finishing threshold)
@@ -376,12 +377,12 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 3 : 2)) void qp_stile_kernel(Dev
   int* const hbase = hist + 64;                         // [64] exclusive prefix of hist
   int* const next_grp = hbase + 64;
   unsigned short* const order = (unsigned short*)(next_grp + 4);
-  const unsigned tid = threadIdx.x;
-  const unsigned lane = tid & 63;
-  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_in);
+  const unsigned tid = wave * 64 + lane;
   const size_t N = a.N;
   const unsigned N32 = (unsigned)a.N;
-  const size_t base = (size_t)blockIdx.x * (size_t)tile;
+  const size_t base = (size_t)blk * (size_t)tile;
   if (tid < 64) hist[tid] = 0;
   if (tid == 0) *next_grp = 0;
 #ifdef WBC_TILE_STAMP
@@ -451,13 +452,13 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 3 : 2)) void qp_stile_kernel(Dev
     });
   }
   __syncthreads();
-  // ---- 1. predictor: thread = (foot, column); the arithmetic of qp_predict_part out of the image
-  const unsigned pfoot = wave / CH, pcol = (wave % CH) * 64 + lane;
-  const bool pred = pfoot < 4;                        // (wavefronts beyond 4 CH only solve)
-  const bool incol = pred && pcol < (unsigned)tile;
+  // ---- 1. predictor: thread t = (foot t / tile, column t mod tile) for t < 4 tile; the arithmetic of qp_predict_part out of the image
+  const unsigned pfoot = tid / (unsigned)tile, pcol = tid - pfoot * (unsigned)tile;
+  const bool incol = pfoot < 4u;
+  const bool pred = __ballot(incol) != 0ull;          // (wavefronts beyond the 4 tile tasks only solve)
   const bool valid = incol && base + pcol < N;
   const unsigned colr = incol ? pcol : 0u;
-  const int fo = (int)(pred ? pfoot : 0u);
+  const int fo = (int)(incol ? pfoot : 0u);
 #define IMGR(row) ((A)img[(row) * ST + colr])
 #define IMGW(row) img[(row) * ST + pcol]
   A x0 = 0, x1 = 0, x2 = 0;       // my foot's part of the unconstrained minimum
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 3 : 2)) void qp_stile_kernel(Dev
     if (4 * g >= nsolve) break;
     const bool live = 4 * g + row < nsolve;
     const unsigned oi = order[live ? 4 * g + row : 0];
-    qp_body<T, false, false, 16, true, NW, QpNoIdle, false, 0, 1>(prm, a, jmap, nullptr, nullptr, QpWho{0, live, nullptr, (void*)img, iimg, (int)oi, ST, tile});
+    qp_body<T, false, false, 16, true, NW, QpNoIdle, false, 0, 1>(prm, a, jmap, nullptr, nullptr, QpWho{0, live, nullptr, (void*)img, iimg, (int)oi, ST, tile, (void*)(tabs + wave)});
 #ifdef WBC_TILE_STAMP
     if (ts_ng == 0) TSTAMP(ts_g1);
     ++ts_ng;
@@ -627,6 +628,11 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 3 : 2)) void qp_stile_kernel(Dev
 #undef TSTAMP
 #undef IMGR
 #undef IMGW
+}
+template <class T, bool RHAT, int NW, int CH>
+__global__ __launch_bounds__(64 * NW, (NW > 8 ? 3 : 2)) void qp_stile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap, int tile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char stile_dyn[];
+  qp_stile_body<T, RHAT, NW, CH>(prm, a, jmap, tile, blockIdx.x, stile_dyn, threadIdx.x >> 6);
 }
 
 // qp_list_kernel: the dense active-set solver over a LIST of states (list[0] = how many, list[4 ...] = their indices): the

@@ -131,7 +131,6 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #endif
   constexpr bool SPEC = WBC_QP_SPEC != 0 && WSLDS && RHAT && WARM == 0 && !PRE && !TILED;
   static_assert(!(WARM != 0 && PRE), "warm starts set their blocks up themselves");
-  __shared__ S16Lds<T> lds_all[WPB];
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
   const int lane = tx & 63;
@@ -141,7 +140,10 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   const int f = l16 >> 2, c3 = l16 & 3;
   const bool isvar = c3 < 3;
   const int v = 3 * f + (isvar ? c3 : 0);
-  S16Lds<T>& L = lds_all[tx >> 6];
+  S16Lds<T>* Lp;
+  if constexpr (STG != 0) Lp = (S16Lds<T>*)who.tab;     // (staged tiles: this wavefront's tables live in the kernel's dynamic LDS, beside the image)
+  else { __shared__ S16Lds<T> lds_all[WPB]; Lp = &lds_all[tx >> 6]; }
+  S16Lds<T>& L = *Lp;
   T* Cl = L.C[grp];
   T* Pl = L.P[grp];
   T* Dl = L.D[grp];

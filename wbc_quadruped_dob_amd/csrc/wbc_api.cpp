@@ -84,7 +84,7 @@ constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints 
 #ifndef WBC_COLAUNCH_MAX_F64
 #define WBC_COLAUNCH_MAX_F64 14336
 #endif
-struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max; };
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -324,6 +324,7 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->multi_threads = 0;
   o->multi_spin_us = 200;
   o->obs_colaunch = 0;
+  o->tile_tick = 0;
 }
 
 // ------------------------------------------------------------------------------------------ which kernels run a tick
@@ -367,6 +368,12 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // 20 480: 19.9 -> 17.8, 24 576: 20.1 -> 15.6, 28 672: 22.5 -> 17.1, 32 768 (configs[3]'s shard): 22.6 -> 17.2, 40 960: 26.5 -> 20.8, 49 152: 26.9 -> 21.6
   r.stile_min = dtype == WBC_F32 ? (size_t)WBC_STILE_MIN_F32 : (size_t)-1;
   r.stile_max = dtype == WBC_F32 ? wbc::STILE_MAX_STATES : 0;
+  // the whole tick as one launch of 64 / 96 / 128-state workgroups (round 6; tile_tick_kernel): fp32, observer on, M / h / Jc outputs, even N.  Measured on MI355X
+  // (profiles/r06c_ab_tile_tick.log; M steps/s, sweep_obs / observer + sweep -> staged or gathered tiles / per-lane pair against the tile tick): 12 800: 445 -> 492,
+  // 16 384: 521 -> 613, 24 576: 750 -> 843, 32 768 (configs[3]'s shard): 913 -> 1 059, 36 864 (a second, nearly empty round of workgroups): 694 -> 719, 49 152: 851 -> 892,
+  // 65 536: 910 -> 1 123, 98 304: 1 045 -> 1 132, 131 072: 1 002 -> 1 038, 196 608: 927 -> 1 078, 262 144: 993 -> 1 049 -- every size measured, so: no upper limit
+  r.tt_min = (size_t)-1; r.tt_max = 0;
+  if (dtype == WBC_F32 && o.tile_tick >= 0) { r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN; r.tt_max = (size_t)-1; }
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
@@ -390,6 +397,13 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
     // workspace through LDS (fused_tick.hip.hpp)
     p.fused = 1;
     p.qp_warm = warm;
+    return p;
+  }
+  if (mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && (!warm || (N >= r.warm_tile_min && N < r.warm_lane_min && o.qp_lane <= 0))) {
+    // mid-size fp32 observer-on batch: sweep | observer roles and the staged QP tile of the same 128 states per workgroup, one launch (tile_tick.hip.hpp).
+    // (warm ticks: only where the cold tiles are the plan anyway -- the kernel reports the sets; from warm_lane_min on the warm per-lane pair stays faster:
+    //  230 against 250 us at 262 144 states)
+    p.fused = 2; p.front = 4; p.obs_split = true; p.pack2 = 1; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states(N); p.qp_body = 2;
     return p;
   }
   // Large batches solve the QPs ONE STATE PER LANE first (qp_lane_kernel: semismooth Newton on the residual wrench, 64 QPs
@@ -506,7 +520,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.tt_min, r.tt_max + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
   size_t keep[20]; int k = 0;
   for (size_t c : cand) {
@@ -523,6 +537,8 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
     if (!dup && k < 20) keep[k++] = c;
   }
   for (int i = 0; i < k; ++i) for (int j = i + 1; j < k; ++j) if (keep[j] < keep[i]) { const size_t t = keep[i]; keep[i] = keep[j]; keep[j] = t; }
+  // (an even candidate right behind a kept odd one is the same switch seen from the even side -- the plans of fp32 batches are compared even with even)
+  for (int i = 1; i < k; ++i) if (keep[i] % 2 == 0 && keep[i - 1] + 1 == keep[i]) { for (int j = i; j + 1 < k; ++j) keep[j] = keep[j + 1]; --k; --i; }
   *n = k;
   for (int i = 0; i < k && i < cap; ++i) out[i] = keep[i];
   return WBC_OK;
@@ -554,6 +570,7 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (o.one_zerocopy < 0 || o.one_zerocopy > 3) return fail(WBC_E_INVALID, "one_zerocopy must be 0 ... 3");
   if (o.rollout_warm != 0 && o.rollout_warm != 1) return fail(WBC_E_INVALID, "rollout_warm must be 0 or 1");
   if (o.obs_colaunch < -1 || o.obs_colaunch > 1) return fail(WBC_E_INVALID, "obs_colaunch must be -1, 0 or 1");
+  if (o.tile_tick < -1 || o.tile_tick > 1) return fail(WBC_E_INVALID, "tile_tick must be -1, 0 or 1");
   int leg_body[4][3];
   std::string err;
   rc = quadruped_topology(m->fm, leg_body, err);
@@ -604,6 +621,9 @@ extern "C" int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
+  // kernels with more than 64 kB of dynamic LDS (staged QP tiles, tile tick): the limit is raised here, not inside a tick (which may be under stream capture)
+  if (e == hipSuccess) e = dtype == WBC_F64 ? k_qp_prepare<double>() : k_qp_prepare<float>();
+  if (e == hipSuccess) e = dtype == WBC_F64 ? k_tile_prepare<double>() : k_tile_prepare<float>();
   if (e != hipSuccess) {
     std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
     wbc_solver_destroy(s);
@@ -838,8 +858,14 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
     if (pc.qp_body == 0) pl = pc;
   }
   const bool warm = warm_api && aset_in != nullptr && pl.qp_warm;
-  if (pl.fused) {
+  if (pl.fused == 1) {
     TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap, warm));
+    keep.written();
+    return WBC_OK;
+  }
+  if (pl.fused == 2) {   // (the roles leave w_des to the QP stage: SW_NOB)
+    qa.wdes = (const T*)in->w_des;
+    TIMED_LAUNCH(3, st, "tile tick", k_tile_tick<T>(L, pl.tile, dev_model<T>(s), dp, a, qa, s->jmap));
     keep.written();
     return WBC_OK;
   }
@@ -1370,4 +1396,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 7; }  // 7: wbc_solver_collect_timing_n (the unsized call writes 5 entries again), wbc_solver_options.multi_threads / multi_spin_us, wbc_multi_tick_gather / wbc_multi_issue_threads / wbc_multi_host_stats; 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_multi_step_batch_warm, wbc_solver_options.rollout_warm, wbc_tick_plan.qp_warm, WBC_PLAN_* flags), wbc_multi_allgather_tau_async / wbc_multi_gather_wait; 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
+extern "C" int wbc_abi_version(void) { return 8; }  // 8: wbc_solver_options.tile_tick, wbc_tick_plan.fused = 2 / qp_body = 2 (staged QP tiles); 7: wbc_solver_collect_timing_n (the unsized call writes 5 entries again), wbc_solver_options.multi_threads / multi_spin_us, wbc_multi_tick_gather / wbc_multi_issue_threads / wbc_multi_host_stats; 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_multi_step_batch_warm, wbc_solver_options.rollout_warm, wbc_tick_plan.qp_warm, WBC_PLAN_* flags), wbc_multi_allgather_tau_async / wbc_multi_gather_wait; 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
