@@ -154,7 +154,8 @@ typedef struct wbc_solver_options {
   int tile_tick;          /* (ABI 8) fp32 observer-on ticks with M/h/Jc outputs of an even batch: ONE launch of 128-state workgroups, one per CU -- the sweep and
                              observer roles of obs_colaunch side by side in a workgroup, then the staged QP tile of the same states behind one barrier
                              (wbc_tick_plan.fused = 2).  0 = auto (from 12290 states on; 64 / 96 / 128 states per workgroup: one round of workgroups up to 32768 states,
-                             BASELINE's configs[3] shard), 1 = every such tick beyond the fused_tick size, -1 = never */
+                             BASELINE's configs[3] shard), 1 = every such tick beyond the fused_tick size, -1 = never.  Also fp64 observer-off ticks of 11265 ... 28672 states (32 ... 112-state workgroups;
+                             1: every size).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,

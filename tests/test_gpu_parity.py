@@ -120,7 +120,7 @@ def _dispatch_cases(want_mats=True):
     cases = []
     # (round 6: even fp32 observer-on batches beyond the fused size all run the tile tick; the two-launch plans underneath -- what odd batches and
     #  tile_tick = -1 callers get -- keep their own straddling cases)
-    for dtype, obs, cfg, opt in (("f64", 0, 2, None), ("f64", 1, 3, None), ("f32", 1, 4, None), ("f32", 0, 2, None), ("f32", 1, 4, {"tile_tick": -1})):
+    for dtype, obs, cfg, opt in (("f64", 0, 2, None), ("f64", 1, 3, None), ("f32", 1, 4, None), ("f32", 0, 2, None), ("f32", 1, 4, {"tile_tick": -1}), ("f64", 0, 2, {"tile_tick": -1})):
         if opt and not want_mats:
             continue
         for t in W.dispatch_thresholds(dtype, obs, want_mats=want_mats, options=opt):

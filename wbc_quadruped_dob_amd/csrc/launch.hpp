@@ -51,12 +51,17 @@ template <class T> hipError_t k_sweep_obs(const LaunchCtx& L, const DevModel<T>*
 // states (tile_tick.hip.hpp).  The host picks the smallest size that makes ONE round of workgroups on the 256 CUs.
 constexpr int TILE_TICK_STATES = 128;
 inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : 128); }
+// fp64, observer off: NS = 2 ... 7 sweep wavefronts of 16 states (a CU's LDS holds seven wavefronts' parking lots), again the smallest one-round size
+inline int tile_tick_states_f64(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 7 ? 7 : ns)); }
+#ifndef WBC_TILE_TICK_MIN_F64
+#define WBC_TILE_TICK_MIN_F64 11265
+#endif
 #ifndef WBC_TILE_TICK_MIN
 #define WBC_TILE_TICK_MIN 12290
 #endif
 template <class T> hipError_t k_tile_prepare();   // raises the dynamic-LDS limit of the tile_tick kernels (once per process and device)
 template <class T> hipError_t k_qp_prepare();     // ... of the staged QP tile kernels
-template <class T> hipError_t k_tile_tick(const LaunchCtx& L, int states, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);
+template <class T> hipError_t k_tile_tick(const LaunchCtx& L, bool observer, int states, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);
 // GRF QP + torque map; rhat = the observer estimate arrives through the workspace (k_observer ran).
 // tile = 0: qp_group16_kernel, one wavefront per workgroup, four consecutive states per wavefront;
 // tile = 64 | 128 | 256 | 512: qp_tile_kernel, workgroups of four wavefronts deal a tile of that many states by predicted work

@@ -363,9 +363,11 @@ constexpr size_t stile_lds_bytes(int tile, size_t scalar, int nw) {
 }
 // the stage as a function of the workgroup's dynamic LDS (`smem`, stile_lds_bytes bytes, 16-byte aligned) and of this wavefront's index among the NW that
 // run it: the stand-alone kernel below, and the second half of tile_tick_kernel (tile_tick.hip.hpp).  blk = the tile's index.
-template <class T, bool RHAT, int NW, int CH>
+// FIN: the predictor finishes the states whose unconstrained minimum violates nothing (default: WBC_QP_PRED_FINISH's rule -- fp32 solvers; the fp64 tile tick
+// turns it on too: here the predictor is spread over all wavefronts and one foot per thread, not the serial stretch of one wavefront it was in qp_tile_kernel)
+constexpr bool stile_fin_default(bool is_float) { return WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && is_float); }
+template <class T, bool RHAT, int NW, int CH, bool FIN = stile_fin_default(std::is_same<T, float>::value)>
 WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int tile, unsigned blk, unsigned char* smem, unsigned wave_in) {
-  constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
   using A = T;   // (the caller sizes the tile: 4 tile <= 64 NW, one predictor thread per foot and state)
   const int ST = tile | 1;   // row stride of the image: the sixteen lanes of a row read sixteen ROWS of one column -- an odd stride spreads them over the banks
   S16Lds<double>* const tabs = (S16Lds<double>*)smem;   // [NW] solver tables, one per wavefront

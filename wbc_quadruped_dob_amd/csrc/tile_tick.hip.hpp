@@ -1,9 +1,9 @@
-// tile_tick_kernel (round 6): the WHOLE tick of a mid-size observer-on batch as ONE launch of big workgroups -- one per CU.
+// tile_tick_kernel (round 6): the WHOLE tick of a batch beyond the fused size as ONE launch of big workgroups -- one per CU in a round.
 // A workgroup owns `tile` = 16 W NS consecutive states.  Its first NS wavefronts run the observer-free dynamics sweep (dyn_sweep_body: M, h, Jc, the
-// step workspace), the other NS the momentum-observer update (observer_park_body: the new observer state, rhat -> workspace) -- the two roles of
-// sweep_obs_kernel (observer.hip.hpp), here side by side in one workgroup, two wavefronts per SIMD as there.  Behind ONE barrier the same 2 NS
-// wavefronts are the staged QP tile of exactly those states (qp_stile_body, qp_kernels.hip.hpp): the image is read back from memory this CU has just
-// written (L2), predictor, finisher, groups, results row by row.
+// step workspace); with the observer on the next NS run the momentum-observer update (observer_park_body: the new observer state, rhat -> workspace)
+// -- the two roles of sweep_obs_kernel (observer.hip.hpp), here side by side in one workgroup.  Behind ONE barrier the workgroup's NWQ wavefronts (the role
+// wavefronts plus, for small tiles, helpers that idle through the roles) are the staged QP tile of exactly those states (qp_stile_body,
+// qp_kernels.hip.hpp): the image is read back from memory this CU has just written (L2), predictor, finisher, groups, results row by row.
 // Why (configs[3]'s shard, 32 768 fp32 states, observer on): as two launches the tick is sweep_obs 19.4 us + staged tiles 17.3 us by the dispatch events,
 // of which 16.5 and 15.2 us lie between the first workgroup's entry and the last one's exit (tools/so_stamp.py, tools/tile_stamp.py) -- every launch
 // pays its ramp and the drain of its slowest workgroup with the rest of the device idle, and the second one a cold read of what the first wrote.
@@ -16,30 +16,32 @@
 
 namespace wbc {
 
-template <class T, int W, int NS>
+template <class T, int W, int NS, int NWQ, bool OBS>
 constexpr size_t tile_tick_lds_bytes() {
   constexpr int MODE = SW_MATS | SW_STEP | SW_NOB;
-  constexpr size_t roles = (size_t)NS * (sizeof(SweepLds<T, MODE, 64, W>) + sizeof(ObsLds<T, 64, W>));
-  constexpr size_t qp = stile_lds_bytes(16 * W * NS, sizeof(T), 2 * NS);
+  constexpr size_t roles = (size_t)NS * (sizeof(SweepLds<T, MODE, 64, W>) + (OBS ? sizeof(ObsLds<T, 64, W>) : 0));
+  constexpr size_t qp = stile_lds_bytes(16 * W * NS, sizeof(T), NWQ);
   return (roles > qp ? roles : qp) + 16;
 }
 
-template <class T, int W, int NS>
-__global__ __launch_bounds__(128 * NS, 2) void tile_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
+template <class T, int W, int NS, int NWQ, bool OBS>
+__global__ __launch_bounds__(64 * NWQ, 2) void tile_tick_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
   constexpr int MODE = SW_MATS | SW_STEP | SW_NOB;
-  constexpr int TILE = 16 * W * NS, CH = (TILE + 63) / 64, NW = 2 * NS;
-  static_assert(64 * NW >= 4 * TILE, "the predictor needs one thread per foot and state");
+  constexpr int TILE = 16 * W * NS, CH = (TILE + 63) / 64, NR = OBS ? 2 * NS : NS;
+  static_assert(NWQ >= NR && 64 * NWQ >= 4 * TILE, "every role wavefront joins the QP stage; the predictor needs one thread per foot and state");
   using SwL = SweepLds<T, MODE, 64, W>;
   using ObL = ObsLds<T, 64, W>;
   extern __shared__ __attribute__((aligned(16))) unsigned char tt_dyn[];
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave < (unsigned)NS) dyn_sweep_body<T, MODE, 64, W>(model, prm, a, *(SwL*)(tt_dyn + (size_t)wave * sizeof(SwL)), blockIdx.x * NS + wave);
-  else observer_park_body<T, 64, W>(model, prm, a, *(ObL*)(tt_dyn + (size_t)NS * sizeof(SwL) + (size_t)(wave - NS) * sizeof(ObL)), blockIdx.x * NS + (wave - NS));
+  else if (OBS && wave < (unsigned)NR)
+    observer_park_body<T, 64, W>(model, prm, a, *(ObL*)(tt_dyn + (size_t)NS * sizeof(SwL) + (size_t)(wave - NS) * sizeof(ObL)), blockIdx.x * NS + (wave - NS));
+  else __syncthreads();   // (helper wavefronts: the one barrier every role body has behind its table staging)
   // What the roles stored (workspace, Jc) is read by OTHER wavefronts of this workgroup below.  __syncthreads() is a workgroup-scope release / acquire: the
   // stores have left the wavefronts, and the wavefronts of a workgroup share their CU's vector L1 (write-through), so they see them.  (An AGENT-scope
   // release here writes back the XCD's whole L2 -- 256 times per launch: the tick took 79 us instead of 37.)
   __syncthreads();
-  qp_stile_body<T, true, NW, CH>(prm, qa, jmap, TILE, blockIdx.x, tt_dyn, wave);
+  qp_stile_body<T, OBS, NWQ, CH, true>(prm, qa, jmap, TILE, blockIdx.x, tt_dyn, wave);
 }
 
 }  // namespace wbc

@@ -372,8 +372,15 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // (profiles/r06c_ab_tile_tick.log; M steps/s, sweep_obs / observer + sweep -> staged or gathered tiles / per-lane pair against the tile tick): 12 800: 445 -> 492,
   // 16 384: 521 -> 613, 24 576: 750 -> 843, 32 768 (configs[3]'s shard): 913 -> 1 059, 36 864 (a second, nearly empty round of workgroups): 694 -> 719, 49 152: 851 -> 892,
   // 65 536: 910 -> 1 123, 98 304: 1 045 -> 1 132, 131 072: 1 002 -> 1 038, 196 608: 927 -> 1 078, 262 144: 993 -> 1 049 -- every size measured, so: no upper limit
+  // (auto only while the kernel-selection options of the two-launch tick are at auto themselves: a caller who names a QP kernel or a front half gets it)
+  const bool tt_auto_ok = o.qp_tile == 0 && o.qp_lane == 0 && o.obs_colaunch == 0 && o.obs_split_min == -1;
   r.tt_min = (size_t)-1; r.tt_max = 0;
-  if (dtype == WBC_F32 && o.tile_tick >= 0) { r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN; r.tt_max = (size_t)-1; }
+  if (dtype == WBC_F32 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) { r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN; r.tt_max = (size_t)-1; }
+  // ... and of fp64 observer-off batches (32 ... 112-state workgroups: NS = 2 ... 7 sweep wavefronts; small tiles get helper wavefronts for the QP stage).  fp64 QPs of
+  // the standing batch iterate 2.5 times per state against the trot batches' 0.5, so the QP stage weighs more and the gain is small, and only while the batch is ONE
+  // round of workgroups (profiles/r06d_ab_tile_tick_f64.log; M steps/s, default -> tile tick): 11 264: 333 -> 355, 12 288: 347 -> 379, 16 384: 425 -> 475, 24 576: 531 -> 550,
+  // 28 672: 541 -> 568; but 8 192: 343 -> 287 (the fused tick's role split overlaps QP and dynamics), 32 768: 602 -> 376 (a second round), 262 144: 790 -> 550
+  if (dtype == WBC_F64 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) { r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN_F64; r.tt_max = o.tile_tick > 0 ? (size_t)-1 : (size_t)7 * 16 * 256; }
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
@@ -397,6 +404,10 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
     // workspace through LDS (fused_tick.hip.hpp)
     p.fused = 1;
     p.qp_warm = warm;
+    return p;
+  }
+  if (mats && !ob && !f32 && !warm && N >= r.tt_min && N <= r.tt_max) {   // fp64, observer off (configs[1]'s shape): sweep wavefronts, then the staged QP tile of their states
+    p.fused = 2; p.front = 0; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64(N); p.qp_body = 2;
     return p;
   }
   if (mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && (!warm || (N >= r.warm_tile_min && N < r.warm_lane_min && o.qp_lane <= 0))) {
@@ -865,7 +876,7 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   }
   if (pl.fused == 2) {   // (the roles leave w_des to the QP stage: SW_NOB)
     qa.wdes = (const T*)in->w_des;
-    TIMED_LAUNCH(3, st, "tile tick", k_tile_tick<T>(L, pl.tile, dev_model<T>(s), dp, a, qa, s->jmap));
+    TIMED_LAUNCH(3, st, "tile tick", k_tile_tick<T>(L, ob, pl.tile, dev_model<T>(s), dp, a, qa, s->jmap));
     keep.written();
     return WBC_OK;
   }
