@@ -143,8 +143,8 @@ typedef struct wbc_solver_options {
                              depend on it -- the time per tick does.  0: every tick solves from the unconstrained minimum */
   int multi_threads;      /* (ABI 7; read by wbc_multi_create only) one persistent ISSUE THREAD per shard, bound to the shard's device: an entry point
                              validates every shard on the caller's thread, posts one ticket, the threads enqueue their shards in parallel and the call
-                             returns when all have -- eight devices are no longer fed one launch after the other from one thread.  0 = auto (threads when
-                             the shards sit on more than one device), 1 = always, -1 = never (the serial issue of ABI <= 6) */
+                             returns when all have -- eight devices are no longer fed one launch after the other from one thread.  1 = on, -1 = never (the
+                             serial issue of ABI <= 6), 0 = auto = serial (ABI 8: the threads are opt-in until they have been run on more than one device) */
   int multi_spin_us;      /* (default 200) an idle issue thread polls for its next ticket this long before it parks on a condition variable: a tick loop
                              never pays a wake-up, a 1 kHz control loop does not burn a core per shard */
   int obs_colaunch;       /* (ABI 7) observer-on two-kernel ticks with M/h/Jc outputs: the observer update and the observer-free sweep as the TWO ROLES OF
@@ -398,6 +398,13 @@ int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* ta
  *     wbc_multi_gather_wait(mm, b);  wbc_multi_step_batch(... out[b] ...);  wbc_multi_allgather_tau_async(mm, n, tau_b, tau_all_b, b);  */
 int wbc_multi_allgather_tau_async(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all, int slot);
 int wbc_multi_gather_wait(wbc_multi* mm, int slot);
+/* WBC_GATHER_PEER_COPY: where every device can map every other's memory, shard j's block reaches all devices through ONE kernel that stores into the
+ * tau_all buffers directly (peer mappings).  That needs every tau_all[k] to be plain hipMalloc memory of devices[k]: the library checks each new set of
+ * buffers once (hipPointerGetAttributes: device memory of the right device) and falls back to hipMemcpyPeerAsync per block otherwise -- but memory from a
+ * virtual-memory pool (PyTorch expandable segments, hipMallocAsync) can pass that check without being mapped on the peers.  Callers with such buffers
+ * switch the push kernel off: on = 1 -> always copies, 0 (default) -> push where allowed.  wbc_multi_gather_pushes: 1 when the next peer gather would push. */
+int wbc_multi_set_peer_copies(wbc_multi* mm, int on);
+int wbc_multi_gather_pushes(const wbc_multi* mm);
 /* One call per tick of that double-buffered loop: wbc_multi_gather_wait(slot), the tick (wbc_multi_step_batch, or _warm when active is given)
  * writing out[k].tau -- the slot's buffer -- and wbc_multi_allgather_tau_async of out[k].tau into tau_all[k]: two tickets to the issue threads. */
 int wbc_multi_tick_gather(wbc_multi* mm, size_t n_total, const wbc_batch_in* in, const wbc_batch_out* out, const wbc_observer_state* obs,

@@ -533,7 +533,7 @@ def _gpu_rollout(torch, solver, P, H, B, tau_ext, integ, r, want_traj=True, dtyp
     solver.rollout(H, q, v, dv(B["w_des"]), dv(B["vdot_des"]), dv(B["normals"]), dv(B["mu"]), mask, out, ig, rr,
                    None if tau_ext is None else dv(tau_ext), traj)
     torch.cuda.synchronize()
-    res = dict(q=to_host(q), v=to_host(v), status=out["status"].cpu().numpy())
+    res = dict(q=to_host(q), v=to_host(v), status=out["status"].cpu().numpy(), iters=out["iters"].cpu().numpy())   # (iters: the last tick's)
     # what the caller finds in its output buffers: the LAST tick's (the 4-state rollout workgroups store nothing else since round 5)
     res.update(out_tau=to_host(out["tau"]), out_f=to_host(out["f"]), out_M=to_host(out["M"]), out_h=to_host(out["h"]), out_Jc=to_host(out["Jc"]),
                out_pf=to_host(out["pf"]))
@@ -612,9 +612,13 @@ def test_rollout_states_per_workgroup_variants_agree(torch_cuda, gpu_model, orac
                                 np.zeros((n, 18)) if obs else None)
     for k in res["4"]:
         if res["4"][k].dtype.kind in "iu":
-            assert np.array_equal(res["4"][k], res["16"][k]), k
+            assert np.array_equal(res["4"][k], res["16"][k]), k      # status AND the last tick's iteration counts: the pivot sequences agree
         else:
             assert relerr(res["4"][k], res["16"][k]) < 1e-10, k
+    # ... and tick by tick: a divergence in one tick would show as a torque difference of that tick, not only in the compounded end state
+    ta, tb = res["4"]["tau_traj"], res["16"]["tau_traj"]
+    for t in range(ta.shape[1]):
+        assert relerr(ta[:, t], tb[:, t]) < 1e-10, t
 
 
 def test_rollout_vs_golden(torch_cuda, gpu_model):

@@ -208,3 +208,74 @@ def test_fp64_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, ora
     assert relerr(a["tau"][ok], ref["tau"][ok]) < 1e-9 and relerr(a["f"][ok], ref["f"][ok]) < 1e-9
     assert elementwise_excess(a["tau"][ok], ref["tau"][ok]) <= 1.0 and elementwise_excess(a["f"][ok], ref["f"][ok]) <= 1.0
     assert np.sum(a["iters"] != ref["iters"]) <= max(2, 0.02 * n) and a["iters"].max() >= 3      # (a near-tie between two violated rows may be taken in the other order)
+
+
+ROWS = dict(q=19, v=18, w_des=6, vdot_des=18, normals=12, mu=4, tau_prev=12, f_prev=12)
+
+
+def _multi_gather(torch, gpu_model, devices, n, gather, options, copies=None, host_dst=False):
+    import wbc_quadruped_dob_amd as W
+    td = torch.float64
+    prm = W.Params.from_dict(synth.default_params(observer_order=0))
+    B = synth.make_batch(2, n, gpu_model.total_mass, rank=41)
+    full = {k: to_dev(B[k], torch, td) for k in ROWS}
+    mask = torch.from_numpy(B["mask"]).cuda()
+    ms = W.MultiSolver(gpu_model, prm, devices=devices, max_batch_total=n, gather=gather, options=options)
+    if copies is not None:
+        ms.set_peer_copies(copies)
+    ins = {k: ms.scatter(full[k], ROWS[k], n) for k in ROWS}
+    ins["mask"] = ms.scatter(mask, 1, n)
+    tick, outs = ms.prepare_step(n, ins, None)
+    tick()
+    tau_all = None
+    if host_dst:   # destination 1 is pinned HOST memory: not what the push kernel may write through a peer mapping
+        _, c0 = W.shard_range(n, ms.n, 0)
+        tau_all = [torch.zeros((ms.n, 12 * c0), dtype=td, device=torch.device("cuda", d)) for d in devices]
+        tau_all[1] = torch.zeros((ms.n, 12 * c0), dtype=td).pin_memory()
+        ms.sync_torch_streams()
+    alls = ms.allgather_tau(n, outs, tau_all)
+    ms.synchronize()
+    torch.cuda.synchronize()
+    return ms, outs, alls
+
+
+def test_multi_defaults_to_serial_issue_and_the_peer_gather_checks_its_destinations(torch_cuda, gpu_model):
+    """ADVICE r5.  (1) multi_threads = 0 (auto) starts no issue threads -- they are opt-in until a run on several devices exists.  (2) The peer gather's push
+    kernel stores through peer mappings: wbc_multi_set_peer_copies(1) takes the copy path instead, with the same bits; a destination that is not device
+    memory of its shard's device (here: pinned host memory) is detected per buffer set and takes the copy path by itself."""
+    import wbc_quadruped_dob_amd as W
+    torch = torch_cuda
+    n, devices = 4099, [0, 0, 0, 0]
+    ms_a, outs_a, alls_a = _multi_gather(torch, gpu_model, devices, n, "peer", {})
+    assert ms_a.issue_threads == 0 and ms_a.gather_pushes == 1
+    ms_b, outs_b, alls_b = _multi_gather(torch, gpu_model, devices, n, "peer", {}, copies=1)
+    assert ms_b.gather_pushes == 0
+    for d in range(len(devices)):
+        assert torch.equal(alls_a[d], alls_b[d])
+        for j in range(len(devices)):
+            st, cnt = W.shard_range(n, len(devices), j)
+            assert torch.equal(alls_a[d][j, :12 * cnt].reshape(12, cnt), outs_a[j]["tau"])
+    ms_c, outs_c, alls_c = _multi_gather(torch, gpu_model, devices, n, "peer", {}, host_dst=True)
+    assert ms_c.gather_pushes == 0                              # the buffer set was refused: copies
+    for d in range(len(devices)):
+        assert torch.equal(alls_c[d].cuda() if d == 1 else alls_c[d], alls_a[d])
+    ms_c.set_peer_copies(0)
+    alls_d = ms_c.allgather_tau(n, outs_c)                      # fresh device buffers: cleared for the push kernel again
+    ms_c.synchronize()
+    assert ms_c.gather_pushes == 1 and all(torch.equal(alls_d[d], alls_a[d]) for d in range(len(devices)))
+
+
+def test_issue_threads_on_distinct_devices_equal_serial_issue(torch_cuda, gpu_model):
+    """The case the issue threads exist for: shards on DIFFERENT devices, RCCL and peer gathers.  Needs more than one GPU."""
+    torch = torch_cuda
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: wbc_multi issue threads / RCCL gather across devices have never run on this pool's one-GPU boxes (ADVICE r5); "
+                    "auto therefore keeps the serial issue")
+    nd = min(torch.cuda.device_count(), 8)
+    n, devices = 4099, list(range(nd))
+    for gather in ("rccl", "peer"):
+        ms_s, outs_s, alls_s = _multi_gather(torch, gpu_model, devices, n, gather, {"multi_threads": -1})
+        ms_t, outs_t, alls_t = _multi_gather(torch, gpu_model, devices, n, gather, {"multi_threads": 1})
+        assert ms_s.issue_threads == 0 and ms_t.issue_threads == nd
+        for d in range(nd):
+            assert torch.equal(alls_s[d].cpu(), alls_t[d].cpu()), (gather, d)

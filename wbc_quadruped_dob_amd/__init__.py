@@ -242,6 +242,8 @@ def lib():
         L.wbc_solver_collect_timing_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.wbc_multi_tick_gather.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.wbc_multi_issue_threads.argtypes = [C.c_void_p]
+        L.wbc_multi_set_peer_copies.argtypes = [C.c_void_p, C.c_int]
+        L.wbc_multi_gather_pushes.argtypes = [C.c_void_p]
         L.wbc_multi_host_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.wbc_multi_probe_issue.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
@@ -776,6 +778,15 @@ class MultiSolver:
     @property
     def issue_threads(self):
         return lib().wbc_multi_issue_threads(self._h)
+
+    def set_peer_copies(self, on):
+        """wbc_multi_set_peer_copies: 1 = the peer gather never stores through peer mappings (for gather buffers from virtual-memory pools)"""
+        _check(lib().wbc_multi_set_peer_copies(self._h, 1 if on else 0), "wbc_multi_set_peer_copies")
+
+    @property
+    def gather_pushes(self):
+        """1 when the next peer gather would use the push kernel"""
+        return lib().wbc_multi_gather_pushes(self._h)
 
     def host_stats(self, reset=True):
         """(calls, seconds) the caller has spent inside the tick / rollout / gather entry points since the last reset"""

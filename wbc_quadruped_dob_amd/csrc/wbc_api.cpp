@@ -1122,6 +1122,7 @@ template <class T>
 static int reference_impl(wbc_solver* s, size_t N, const void* q, const void* v, const void* plan, double t, void* w_des,
                           void* vdot_des, void* com, hipStream_t st) {
   RefArgs<T> a;
+  std::memset(&a, 0, sizeof(a));   // (simg, refimg, planimg, skip_out: set by the rollout kernel only -- ADVICE r5)
   a.N = N; a.q = (const T*)q; a.v = (const T*)v; a.plan = (const T*)plan; a.t = (T)t;
   a.w_des = (T*)w_des; a.vdot_des = (T*)vdot_des; a.com = (T*)com;
   a.jpack = s->jpack;

@@ -117,14 +117,21 @@ class IssuePool {
     int rc = 0;
     std::string err;
   };
-  IssuePool(const std::vector<int>& devices, int spin_us) : spin_ns_((long long)spin_us * 1000), w_(devices.size()) {
-    for (size_t k = 0; k < devices.size(); ++k) w_[k].reset(new Worker);
-    for (size_t k = 0; k < devices.size(); ++k) w_[k]->th = std::thread([this, k, dev = devices[k]] { loop((int)k, dev); });
+  // never throws (it is built under an extern "C" entry point): ok() says whether every worker exists and every thread started; the destructor joins
+  // whatever did start (`new Worker` / std::thread construction used to be able to throw through wbc_multi_create, with joinable threads alive)
+  IssuePool(const std::vector<int>& devices, int spin_us) noexcept : spin_ns_((long long)spin_us * 1000) {
+    try {
+      w_.resize(devices.size());
+      for (size_t k = 0; k < devices.size(); ++k) w_[k].reset(new Worker);
+      for (size_t k = 0; k < devices.size(); ++k) w_[k]->th = std::thread([this, k, dev = devices[k]] { loop((int)k, dev); });
+      ok_ = true;
+    } catch (...) { ok_ = false; }
   }
+  bool ok() const { return ok_; }
   ~IssuePool() {
     quit_.store(true, std::memory_order_seq_cst);
-    for (auto& w : w_) { post_one(*w); }
-    for (auto& w : w_) if (w->th.joinable()) w->th.join();
+    for (auto& w : w_) if (w && w->th.joinable()) post_one(*w);
+    for (auto& w : w_) if (w && w->th.joinable()) w->th.join();
   }
   // runs job(k) on the thread of every shard k and returns the first non-zero status (its message becomes wbc_last_error())
   int run(const JobRef& j) {
@@ -149,7 +156,7 @@ class IssuePool {
     }
   }
   void loop(int k, int dev) {
-    (void)hipSetDevice(dev);   // every call this thread makes runs on the shard's device: no device switch per tick
+    const hipError_t bind = dev < 0 ? hipSuccess : hipSetDevice(dev);   // every call this thread makes runs on the shard's device: no device switch per tick (dev < 0: the device-free self-test)
     Worker& w = *w_[(size_t)k];
     unsigned last = 0;
     for (;;) {
@@ -172,13 +179,16 @@ class IssuePool {
       }
       ++last;
       if (quit_.load(std::memory_order_seq_cst)) { w.done.store(last, std::memory_order_release); return; }
-      const int rc = job_.call(job_.ctx, k);
+      int rc;
+      if (bind != hipSuccess) rc = fail(WBC_E_HIP, std::string("issue thread could not bind to its device: ") + hipGetErrorString(bind));   // (never launch on the wrong device)
+      else rc = job_.call(job_.ctx, k);
       w.rc = rc;
       if (rc) w.err = wbc_last_error();
       w.done.store(last, std::memory_order_release);
     }
   }
   JobRef job_;
+  bool ok_ = false;
   std::atomic<bool> quit_{false};
   long long spin_ns_;
   std::vector<std::unique_ptr<Worker>> w_;
@@ -194,6 +204,12 @@ struct wbc_multi {
   int rccl_ranks = 0;
   int observer_order = 0;
   bool push_ok = false;           // peer backend: every device can write every other device's memory (the push kernel); else peer copies
+  bool force_copies = false;      // wbc_multi_set_peer_copies: never the push kernel
+  // the destination set the push kernel was last cleared for (hipPointerGetAttributes on every tau_all[d]: device memory of devices[d]): checked once per
+  // buffer set, not per tick (a buffer that is not plain peer-mapped device memory must take the copy path, not a GPU page fault)
+  const void* push_seen[64] = {};
+  int push_seen_n = 0;
+  bool push_seen_ok = false;
   Rccl rccl;
   std::vector<Shard> sh;
   std::unique_ptr<IssuePool> pool;   // null: the shards are issued one after the other on the caller's thread
@@ -336,13 +352,15 @@ extern "C" int wbc_multi_create(const wbc_model* m, const wbc_params* p, int dty
   }
   int distinct = 0;
   for (int i = 0; i < n_devices; ++i) { bool seen = false; for (int j = 0; j < i; ++j) seen = seen || devices[j] == devices[i]; distinct += seen ? 0 : 1; }
-  // auto: threads when the shards sit on more than one DEVICE.  Shards that share a device share its queue lock in the runtime: measured on one MI355X
-  // (bench.py --single-process, profiles/r05a_*), 8 shards 30 -> 17 us per tick call, but 2 shards 7.2 -> 10.6 us -- the ticket round trip costs more than
-  // two launches that the runtime serialises anyway
-  if (multi_threads == 1 || (multi_threads == 0 && distinct > 1)) {
+  // Issue threads are OPT-IN (multi_threads = 1).  Round 5 switched them on by itself once the shards sat on more than one device -- the case they are for,
+  // and the one case this build has never been able to run: every measurement is from ONE device, where the shards share the runtime's queue lock
+  // (bench.py --single-process, profiles/r05a_*: 8 shards 30 -> 17 us per tick call, 2 shards 7.2 -> 10.6 us).  Until a run on several devices exists, auto
+  // (0) keeps the serial issue of ABI <= 6; `distinct` is kept for the day the default can move.
+  (void)distinct;
+  if (multi_threads == 1) {
     std::vector<int> devs(devices, devices + n_devices);
     mm->pool.reset(new (std::nothrow) IssuePool(devs, multi_spin_us));
-    if (!mm->pool) { wbc_multi_destroy(mm); return fail(WBC_E_INVALID, "out of memory"); }
+    if (!mm->pool || !mm->pool->ok()) { mm->pool.reset(); wbc_multi_destroy(mm); return fail(WBC_E_HIP, "could not start the issue threads"); }
   }
   *out = mm;
   return WBC_OK;
@@ -377,8 +395,9 @@ extern "C" int wbc_multi_host_stats(wbc_multi* mm, unsigned long long* calls, do
 // pause_us > 0 lets the threads park between tickets.  Returns WBC_OK, or WBC_E_INVALID with the first discrepancy in wbc_last_error().
 extern "C" int wbc_multi_selftest_issue(int threads, int tickets, int spin_us, int pause_us) {
   if (threads < 1 || threads > 64 || tickets < 1 || spin_us < 0 || pause_us < 0) return fail(WBC_E_INVALID, "bad argument");
-  std::vector<int> devs((size_t)threads, 0);
+  std::vector<int> devs((size_t)threads, -1);   // (no device: the threads bind to none)
   IssuePool pool(devs, spin_us);
+  if (!pool.ok()) return fail(WBC_E_HIP, "could not start the issue threads");
   std::vector<long long> seen((size_t)threads, -1), bad((size_t)threads, 0);
   for (int t = 0; t < tickets; ++t) {
     auto job = [&](int k) -> int {
@@ -505,8 +524,42 @@ static int gather_geom(wbc_multi* mm, size_t n_total, const void* const* tau_loc
 // shard j's part of a gather on stream `gs` (its shard stream, or its gather stream): RCCL = its rank's ncclAllGather; peer = push my block
 // into every device's buffer.  `grouped`: the caller brackets all shards' calls with ncclGroupStart / End (serial issue); the issue threads
 // call their rank's collective concurrently instead, the one-thread-per-device form of the library.
-static int gather_shard(wbc_multi* mm, int j, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all,
-                        hipStream_t gs, void* staging) {
+// may the push kernel write these destinations?  Every tau_all[d] must be plain device memory of devices[d] (the peer mappings of wbc_multi_create cover
+// hipMalloc allocations); anything else -- another device's memory, host memory, a pointer the runtime does not know -- takes the copy path.  Cached per
+// buffer set.  (Memory from a virtual-memory pool -- PyTorch expandable segments, hipMallocAsync -- can look like device memory here without being mapped on
+// the peers: callers with such buffers switch the push kernel off, wbc_multi_set_peer_copies.)
+static bool push_allowed(wbc_multi* mm, void* const* tau_all) {
+  if (!mm->push_ok || mm->force_copies) return false;
+  const int n = (int)mm->sh.size();
+  bool same = mm->push_seen_n == n;
+  for (int d = 0; d < n && same; ++d) same = mm->push_seen[d] == tau_all[d];
+  if (same) return mm->push_seen_ok;
+  bool ok = true;
+  for (int d = 0; d < n && ok; ++d) {
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof(at));
+    const hipError_t e = hipPointerGetAttributes(&at, tau_all[d]);
+    if (e != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+    ok = at.type == hipMemoryTypeDevice && at.device == mm->sh[(size_t)d].device;
+  }
+  for (int d = 0; d < n; ++d) mm->push_seen[d] = tau_all[d];
+  mm->push_seen_n = n;
+  mm->push_seen_ok = ok;
+  return ok;
+}
+
+// RCCL, ragged shards: the collective needs equal counts, so a short shard sends from a padded staging copy.  The fallible step IN FRONT of the collective,
+// kept apart from it: a rank that fails here must fail before ANY rank has enqueued its ncclAllGather, or the others' streams wait for it for ever
+static int gather_pre(wbc_multi* mm, int j, size_t n_total, const GatherGeom& g, const void* const* tau_local, hipStream_t gs, void* staging) {
+  if (mm->backend != WBC_GATHER_RCCL) return WBC_OK;
+  size_t st, cnt;
+  (void)wbc_shard_range(n_total, (int)mm->sh.size(), j, &st, &cnt);
+  if (cnt != g.cmax && cnt) HIP_TRY(hipMemcpyAsync(staging, tau_local[j], (size_t)mm->nj * cnt * mm->ts(), hipMemcpyDeviceToDevice, gs));
+  return WBC_OK;
+}
+// ... and the collective (RCCL; gather_pre has run on every shard) or the peer push / copies of shard j
+static int gather_post(wbc_multi* mm, int j, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all,
+                       hipStream_t gs, void* staging, bool push) {
   const int n = (int)mm->sh.size();
   const size_t ts = mm->ts();
   Shard& src = mm->sh[(size_t)j];
@@ -514,17 +567,13 @@ static int gather_shard(wbc_multi* mm, int j, size_t n_total, const GatherGeom& 
   (void)wbc_shard_range(n_total, n, j, &st, &cnt);
   const size_t bytes = (size_t)mm->nj * cnt * ts;
   if (mm->backend == WBC_GATHER_RCCL) {
-    const void* send = tau_local[j];
-    if (cnt != g.cmax) {   // ragged: the collective needs equal counts, so the short shards send from a padded staging copy
-      if (cnt) HIP_TRY(hipMemcpyAsync(staging, tau_local[j], bytes, hipMemcpyDeviceToDevice, gs));
-      send = staging;
-    }
+    const void* send = cnt != g.cmax ? staging : tau_local[j];
     const ncclResult_t r = mm->rccl.AllGather(send, tau_all[j], g.blk, mm->dtype == WBC_F64 ? ncclFloat64 : ncclFloat32, src.comm, gs);
     if (r != ncclSuccess) return fail(WBC_E_HIP, std::string("ncclAllGather: ") + mm->rccl.GetErrorString(r));
     return WBC_OK;
   }
   if (!bytes) return WBC_OK;
-  if (mm->push_ok) {   // ONE launch writes my block to all n destinations (peer mappings over xGMI; 2 n^2 -> n runtime calls per gather against the copies)
+  if (push) {   // ONE launch writes my block to all n destinations (peer mappings over xGMI; 2 n^2 -> n runtime calls per gather against the copies)
     void* dst[64];
     int nd = 0;
     for (int d = 0; d < n; ++d) {
@@ -540,7 +589,7 @@ static int gather_shard(wbc_multi* mm, int j, size_t n_total, const GatherGeom& 
   for (int d = 0; d < n; ++d) {
     char* dst = (char*)tau_all[d] + (size_t)j * g.blk * ts;
     if ((const void*)dst == tau_local[j]) continue;
-    if (mm->sh[(size_t)d].device == src.device) HIP_TRY(hipMemcpyAsync(dst, tau_local[j], bytes, hipMemcpyDeviceToDevice, gs));
+    if (mm->sh[(size_t)d].device == src.device) HIP_TRY(hipMemcpyAsync(dst, tau_local[j], bytes, hipMemcpyDefault, gs));   // (default kind: a destination the push check refused may be host memory)
     else HIP_TRY(hipMemcpyPeerAsync(dst, mm->sh[(size_t)d].device, tau_local[j], src.device, bytes, gs));
   }
   return WBC_OK;
@@ -551,6 +600,30 @@ static int record_ticks(wbc_multi* mm) {
   return for_shards(mm, [&](int k) -> int { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipEventRecord(s.ev_tick, s.stream)); return WBC_OK; });
 }
 
+// the serial RCCL form of a gather over `streams[k]`: the fallible steps of every rank first, then ONE group call that is ALWAYS closed (an early
+// return between ncclGroupStart and ncclGroupEnd used to leave the group open)
+template <class StreamOf, class StagingOf>
+static int rccl_gather_serial(wbc_multi* mm, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all, StreamOf stream_of, StagingOf staging_of) {
+  DeviceScope keep;
+  const int n = (int)mm->sh.size();
+  for (int k = 0; k < n; ++k) {
+    HIP_TRY(hipSetDevice(mm->sh[(size_t)k].device));
+    const int rc = gather_pre(mm, k, n_total, g, tau_local, stream_of(k), staging_of(k));
+    if (rc) return rc;
+  }
+  ncclResult_t r = mm->rccl.GroupStart();
+  if (r != ncclSuccess) return fail(WBC_E_HIP, std::string("ncclGroupStart: ") + mm->rccl.GetErrorString(r));
+  int rc = WBC_OK;
+  for (int k = 0; k < n && !rc; ++k) {
+    const hipError_t e = hipSetDevice(mm->sh[(size_t)k].device);
+    if (e != hipSuccess) { rc = fail(WBC_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); break; }
+    rc = gather_post(mm, k, n_total, g, tau_local, tau_all, stream_of(k), staging_of(k), false);
+  }
+  r = mm->rccl.GroupEnd();
+  if (!rc && r != ncclSuccess) rc = fail(WBC_E_HIP, std::string("ncclGroupEnd: ") + mm->rccl.GetErrorString(r));
+  return rc;
+}
+
 // behind the tick, on the shard streams; on return every shard stream is ordered behind ALL blocks of its tau_all
 extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void* const* tau_local, void* const* tau_all) {
   GatherGeom g;
@@ -559,28 +632,23 @@ extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void
   HostTimer ht(mm);
   const int n = (int)mm->sh.size();
   if (mm->backend == WBC_GATHER_RCCL) {
-    if (mm->pool) return for_shards(mm, [&](int k) { Shard& s = mm->sh[(size_t)k]; return gather_shard(mm, k, n_total, g, tau_local, tau_all, s.stream, s.d_send); });
-    DeviceScope keep;
-    ncclResult_t r = mm->rccl.GroupStart();
-    if (r != ncclSuccess) return fail(WBC_E_HIP, std::string("ncclGroupStart: ") + mm->rccl.GetErrorString(r));
-    for (int k = 0; k < n && !rc; ++k) {
-      Shard& s = mm->sh[(size_t)k];
-      HIP_TRY(hipSetDevice(s.device));
-      rc = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.stream, s.d_send);
+    if (mm->pool) {   // issue threads: one ticket for the fallible steps, a second one for the collectives only when every rank got through the first
+      rc = for_shards(mm, [&](int k) { Shard& s = mm->sh[(size_t)k]; return gather_pre(mm, k, n_total, g, tau_local, s.stream, s.d_send); });
+      if (rc) return rc;
+      return for_shards(mm, [&](int k) { Shard& s = mm->sh[(size_t)k]; return gather_post(mm, k, n_total, g, tau_local, tau_all, s.stream, s.d_send, false); });
     }
-    r = mm->rccl.GroupEnd();
-    if (!rc && r != ncclSuccess) rc = fail(WBC_E_HIP, std::string("ncclGroupEnd: ") + mm->rccl.GetErrorString(r));
-    return rc;
+    return rccl_gather_serial(mm, n_total, g, tau_local, tau_all, [&](int k) { return mm->sh[(size_t)k].stream; }, [&](int k) { return mm->sh[(size_t)k].d_send; });
   }
   rc = record_ticks(mm);
   if (rc) return rc;
+  const bool push = push_allowed(mm, tau_all);
   // peer: (1) every shard stream waits for every OTHER shard's tick -- a push lands in buffers that the destination's own tick, or a consumer
   // enqueued behind it, may still be reading -- then pushes its block and records; (2) every shard stream waits for all pushes
   rc = for_shards(mm, [&](int k) -> int {
     Shard& s = mm->sh[(size_t)k];
     for (int d = 0; d < n; ++d)
       if (d != k && mm->sh[(size_t)d].ev_tick) HIP_TRY(hipStreamWaitEvent(s.stream, mm->sh[(size_t)d].ev_tick, 0));
-    const int r = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.stream, nullptr);
+    const int r = gather_post(mm, k, n_total, g, tau_local, tau_all, s.stream, nullptr, push);
     if (r) return r;
     HIP_TRY(hipEventRecord(s.ev, s.stream));
     return WBC_OK;
@@ -593,19 +661,6 @@ extern "C" int wbc_multi_allgather_tau(wbc_multi* mm, size_t n_total, const void
   });
 }
 
-// shard k's part of the overlapped gather of `slot`: on its GATHER stream, behind the ticks that are enqueued now, beside the next tick
-static int gather_async_shard(wbc_multi* mm, int k, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all, int slot) {
-  const int n = (int)mm->sh.size();
-  Shard& s = mm->sh[(size_t)k];
-  if (mm->backend == WBC_GATHER_RCCL) HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0));   // (the collective itself meets the other ranks)
-  else   // peer pushes write OTHER devices' buffers: behind every shard's tick and whatever read those buffers before it
-    for (int d = 0; d < n; ++d) HIP_TRY(hipStreamWaitEvent(s.gstream, mm->sh[(size_t)d].ev_tick, 0));
-  const int rc = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.gstream, s.d_send_slot[slot]);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream));
-  return WBC_OK;
-}
-
 // every shard stream waits (on the device, not on the host) for the last gather of `slot`
 static int gather_wait_shard(wbc_multi* mm, int k, int slot) {
   Shard& s = mm->sh[(size_t)k];
@@ -615,28 +670,57 @@ static int gather_wait_shard(wbc_multi* mm, int k, int slot) {
   return WBC_OK;
 }
 
-// all shards' parts of the overlapped gather of `slot` (see wbc_multi_allgather_tau_async); the ev_tick events have been recorded
+// all shards' parts of the overlapped gather of `slot` (see wbc_multi_allgather_tau_async), each on its GATHER stream, behind the ticks that are enqueued now
+// (the ev_tick events have been recorded), beside the next tick
 static int gather_async_all(wbc_multi* mm, size_t n_total, const GatherGeom& g, const void* const* tau_local, void* const* tau_all, int slot) {
-  if (mm->backend == WBC_GATHER_RCCL && !mm->pool) {   // serial issue: one group call over all ranks
-    DeviceScope keep;
-    const int n = (int)mm->sh.size();
-    int rc = WBC_OK;
-    for (int k = 0; k < n; ++k) { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0)); }
-    ncclResult_t r = mm->rccl.GroupStart();
-    if (r != ncclSuccess) return fail(WBC_E_HIP, std::string("ncclGroupStart: ") + mm->rccl.GetErrorString(r));
-    for (int k = 0; k < n && !rc; ++k) {
-      Shard& s = mm->sh[(size_t)k];
-      HIP_TRY(hipSetDevice(s.device));
-      rc = gather_shard(mm, k, n_total, g, tau_local, tau_all, s.gstream, s.d_send_slot[slot]);
+  const int n = (int)mm->sh.size();
+  if (mm->backend == WBC_GATHER_RCCL) {
+    // (the collective itself meets the other ranks: a rank's gather stream waits for its own tick only)
+    if (!mm->pool) {   // serial issue: one group call over all ranks
+      {
+        DeviceScope keep;
+        for (int k = 0; k < n; ++k) { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0)); }
+      }
+      const int rc = rccl_gather_serial(mm, n_total, g, tau_local, tau_all, [&](int k) { return mm->sh[(size_t)k].gstream; }, [&](int k) { return mm->sh[(size_t)k].d_send_slot[slot]; });
+      if (rc) return rc;
+      DeviceScope keep;
+      for (int k = 0; k < n; ++k) { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream)); }
+      return WBC_OK;
     }
-    r = mm->rccl.GroupEnd();
-    if (!rc && r != ncclSuccess) rc = fail(WBC_E_HIP, std::string("ncclGroupEnd: ") + mm->rccl.GetErrorString(r));
+    int rc = for_shards(mm, [&](int k) -> int {
+      Shard& s = mm->sh[(size_t)k];
+      HIP_TRY(hipStreamWaitEvent(s.gstream, s.ev_tick, 0));
+      return gather_pre(mm, k, n_total, g, tau_local, s.gstream, s.d_send_slot[slot]);
+    });
     if (rc) return rc;
-    for (int k = 0; k < n; ++k) { Shard& s = mm->sh[(size_t)k]; HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream)); }
-    return WBC_OK;
+    return for_shards(mm, [&](int k) -> int {
+      Shard& s = mm->sh[(size_t)k];
+      const int r = gather_post(mm, k, n_total, g, tau_local, tau_all, s.gstream, s.d_send_slot[slot], false);
+      if (r) return r;
+      HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream));
+      return WBC_OK;
+    });
   }
-  return for_shards(mm, [&](int k) { return gather_async_shard(mm, k, n_total, g, tau_local, tau_all, slot); });
+  const bool push = push_allowed(mm, tau_all);
+  return for_shards(mm, [&](int k) -> int {
+    Shard& s = mm->sh[(size_t)k];
+    // peer pushes write OTHER devices' buffers: behind every shard's tick and whatever read those buffers before it
+    for (int d = 0; d < n; ++d) HIP_TRY(hipStreamWaitEvent(s.gstream, mm->sh[(size_t)d].ev_tick, 0));
+    const int r = gather_post(mm, k, n_total, g, tau_local, tau_all, s.gstream, s.d_send_slot[slot], push);
+    if (r) return r;
+    HIP_TRY(hipEventRecord(s.ev_slot[slot], s.gstream));
+    return WBC_OK;
+  });
 }
+
+// 1: the peer gather never uses the push kernel (hipMemcpyPeerAsync / hipMemcpyAsync per block instead) -- for tau_all buffers that are not plain hipMalloc
+// memory of their device (virtual-memory pools: PyTorch expandable segments, hipMallocAsync); 0 (default): the push kernel where every destination is
+extern "C" int wbc_multi_set_peer_copies(wbc_multi* mm, int on) {
+  if (!mm) return fail(WBC_E_INVALID, "null argument");
+  mm->force_copies = on != 0;
+  return WBC_OK;
+}
+extern "C" int wbc_multi_gather_pushes(const wbc_multi* mm) { return (mm && mm->backend == WBC_GATHER_PEER_COPY && mm->push_ok && !mm->force_copies && (mm->push_seen_n == 0 || mm->push_seen_ok)) ? 1 : 0; }
 
 // The gather OFF the tick's path: enqueued on the shards' gather streams behind the tick that is on the shard streams now, so that it
 // runs beside the NEXT tick.  The caller double-buffers tau (two wbc_batch_out.tau per shard, alternating) and names the buffer's
