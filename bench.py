@@ -83,7 +83,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min_blocks=7):
+def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min_blocks=7, device="cuda", sync=None):
     """Times blocks of EXACTLY `steps` ticks, each bracketed by barrier + synchronize on both sides, until at least
     `min_total_s` has been measured AND at least `min_blocks` blocks exist; returns the per-block seconds (max over ranks).
     The ranks leave the opening barrier together and do not talk to each other inside a block (no data-path collective), so
@@ -92,22 +92,25 @@ def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min
     wait, tens of microseconds) is not part of the K ticks and would be 10 % of a 20-tick block.
     A 20-tick block at the bench default lasts 0.5 ms -- one scheduler hiccup moves a single sample by > 5 %, the median of
     ~100 blocks does not.  (min_blocks: a one-off stall of ~70 ms was seen in about one in twelve fp32 runs, always in the first
-    or second block; with one or two blocks it WAS the median.)"""
+    or second block; with one or two blocks it WAS the median.)
+    device / sync: where the agreement tensors live and how a rank waits for its device ("cuda" / torch.cuda.synchronize; the gloo rehearsal of the N > 1
+    path, tests/test_sharding_gloo.py, passes "cpu" and a no-op -- the SAME function times its stand-in ticks)."""
+    sync = sync or torch.cuda.synchronize
     times = []
     total = 0.0
     while len(times) < max_blocks and (total < min_total_s or len(times) < min_blocks):
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0     # this rank's K ticks, finished on its device
         if dist is not None:
             dist.barrier()
         if dist is not None:   # every rank takes the same decision: the slowest rank's clock
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         times.append(dt)
@@ -117,20 +120,78 @@ def timed_blocks(step, steps, dist, torch, min_total_s=0.05, max_blocks=400, min
     return times
 
 
-def long_blocks_of(step, k0, dist, torch, np, min_block_s=5e-3):
+def long_blocks_of(step, k0, dist, torch, np, min_block_s=5e-3, device="cuda", sync=None):
     """timed_blocks with a block length that is raised until the median block lasts at least min_block_s (a first estimate of the
     step time taken right after set-up can be off by an order of magnitude: module load, clocks)"""
     k = max(1, int(k0))
     if dist is not None:   # k0 comes from each rank's own clock: every rank must run the SAME number of steps (callers follow the blocks
         from wbc_quadruped_dob_amd.sharding import agree_on_steps   # with per-step collectives; a different count per rank would hang them)
-        k = agree_on_steps(k, dist, "cuda")
+        k = agree_on_steps(k, dist, device)
     for _ in range(4):
-        bl = timed_blocks(step, k, dist, torch)
+        bl = timed_blocks(step, k, dist, torch, device=device, sync=sync)
         el = float(np.median(bl))
         if el >= min_block_s:
             break
         k = int(np.ceil(k * min_block_s / max(el, 1e-7) * 1.15))
     return k, bl, el
+
+
+def measure_job(step, steps, n, world, dist, torch, np, device="cuda", sync=None, after_blocks=None):
+    """The timed region of the contract and its N > 1 companion: blocks of EXACTLY `steps` ticks (median block = `elapsed`), and -- with a process group --
+    the same ticks again in blocks of >= 5 ms (rank skew at the barriers < 1 % of a block), reported beside `value`.  after_blocks(): called between the two
+    (main() closes its sampled-timing window there).  Returns (blocks, elapsed, long_blocks)."""
+    blocks = timed_blocks(step, steps, dist, torch, device=device, sync=sync)
+    if after_blocks is not None:
+        after_blocks()
+    elapsed = float(np.median(blocks))   # seconds per block of exactly `steps` ticks
+    long_blocks = None
+    if dist is not None:
+        # N > 1: the driver's K may be 20 ticks = 0.4 ms per block, where one late rank moves the maximum by several per cent.
+        k_long, lb, el_long = long_blocks_of(step, max(steps, int(np.ceil(5e-3 / max(elapsed / steps, 1e-7)))), dist, torch, np, device=device, sync=sync)
+        long_blocks = {"value": k_long * n * world / el_long, "ms_per_step": el_long / k_long * 1e3, "steps_per_block": k_long,
+                       "blocks": len(lb), "block_ms_median": el_long * 1e3,
+                       "note": "blocks of >= 5 ms so that rank skew at the barriers is < 1 % of a block; `value` keeps the contract's K"}
+    return blocks, elapsed, long_blocks
+
+
+def contract_fields(steps, warmup, n, world, elapsed, dtype, workload, want_mats):
+    """The driver's contract: `value` = units all ranks processed / the slowest rank's time for exactly `steps` ticks (median block)."""
+    return {
+        "metric": "WBC control-steps/sec (batched DogBot)",
+        "value": steps * n * world / elapsed,
+        "unit": "control-steps/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic",
+        "config": {"workload": workload, "batch_per_gpu": n, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                   "writes_M_h_Jc": want_mats},
+    }
+
+
+def job_fields(blocks, steps, elapsed, long_blocks, gather_res, world, dist):
+    """what the line says about the timing itself and the N > 1 extras"""
+    res = {"timing": {"blocks": len(blocks), "steps_per_block": steps, "block_ms_min": min(blocks) * 1e3,
+                      "block_ms_median": elapsed * 1e3, "block_ms_max": max(blocks) * 1e3,
+                      "note": "value and ms_per_step are the MEDIAN block of exactly `steps` ticks (barrier + synchronize on both "
+                              "sides of every block, max over ranks); blocks repeat until >= 50 ms are measured"},
+           "with_tau_allgather": gather_res,
+           "rccl_ranks": world if dist is not None else None}
+    if long_blocks is not None:
+        res["value_long_blocks"] = long_blocks
+    return res
+
+
+def leg_fields(workload, k, units_per_step, world, el, bl, gather, dtype, unit_ms_key="ms_per_step"):
+    """one extra leg of an N > 1 line (scale_legs): k steps per block, each step `units_per_step` control-steps on every one of `world` ranks, median block `el` s"""
+    return {"workload": workload, "value": k * units_per_step * world / el, "unit": "control-steps/s", unit_ms_key: el / k * 1e3,
+            ("steps_per_block" if unit_ms_key == "ms_per_step" else "rollouts_per_block"): k, "blocks": len(bl), "with_tau_allgather": gather,
+            "rccl_ranks": world, "dtype": dtype}
 
 
 def main():
@@ -242,18 +303,14 @@ def main():
     # events around every launch costs ~15 us per tick at this batch size, which would be a quarter of the step.
     sample = max(1, args.sample_every)
     solver.enable_timing(sample)
-    blocks = timed_blocks(step, args.steps, dist, torch)
-    tm = solver.collect_timing()
-    solver.enable_timing(0)
-    elapsed = float(np.median(blocks))   # seconds per block of exactly args.steps ticks
-    long_blocks = None
-    if dist is not None:
-        # N > 1: the driver's K may be 20 ticks = 0.4 ms per block, where one late rank moves the maximum by several per cent.
-        # The same ticks again in blocks of >= 5 ms (same bracketing, same max over ranks), reported BESIDE `value`.
-        k_long, lb, el_long = long_blocks_of(step, max(args.steps, int(np.ceil(5e-3 / max(elapsed / args.steps, 1e-7)))), dist, torch, np)
-        long_blocks = {"value": k_long * n * world / el_long, "ms_per_step": el_long / k_long * 1e3, "steps_per_block": k_long,
-                       "blocks": len(lb), "block_ms_median": el_long * 1e3,
-                       "note": "blocks of >= 5 ms so that rank skew at the barriers is < 1 % of a block; `value` keeps the contract's K"}
+    tmbox = {}
+
+    def close_sampling():
+        tmbox["tm"] = solver.collect_timing()
+        solver.enable_timing(0)
+    # (tests/test_sharding_gloo.py drives measure_job / gather_leg / contract_fields / job_fields with eight gloo ranks and stand-in ticks)
+    blocks, elapsed, long_blocks = measure_job(step, args.steps, n, world, dist, torch, np, after_blocks=close_sampling)
+    tm = tmbox["tm"]
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
     # the optional consumer-side collective (every rank receives all torques), reported BESIDE `value`
@@ -314,25 +371,10 @@ def main():
         path_words = 102 + (96 if obs else 0)
         path_gbs = path_words * ts * (args.steps * n / elapsed) / 1e9
         devinfo = device_probe(torch) if world == 1 else None
-        res = {
-            "metric": "WBC control-steps/sec (batched DogBot)",
-            "value": args.steps * n * world / elapsed,
-            "unit": "control-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": dtype,
-            "data": "synthetic",
-            "config": {"workload": "configs[%d]: batch=%d states/GPU, %s, observer %s, %s; synthetic quadruped URDF "
-                                   "(DogBot URDF absent)" % (args.config - 1, n,
-                                                             "4-contact stance" if args.config == 2 else "mixed 2/3/4-foot trot masks",
-                                                             "on" if obs else "off", dtype),
-                       "batch_per_gpu": n, "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "writes_M_h_Jc": want_mats},
+        res = contract_fields(args.steps, args.warmup, n, world, elapsed, dtype,
+                              "configs[%d]: batch=%d states/GPU, %s, observer %s, %s; synthetic quadruped URDF (DogBot URDF absent)"
+                              % (args.config - 1, n, "4-contact stance" if args.config == 2 else "mixed 2/3/4-foot trot masks", "on" if obs else "off", dtype), want_mats)
+        res.update({
             "roofline": {"kernel": (("tile_tick_kernel (sweep + observer roles of a 64 / 96 / 128-state workgroup, then the staged QP tile of the same states: one launch)" if tile_tick
                                      else "fused_tick_kernel") if fused else tick_sweep_name(dtype, obs, n, split)),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -367,21 +409,14 @@ def main():
                                   else "rnea_step (no CRBA, no M/h/Jc) -> qp")},
             "qp": {"status_ok_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                    "iters_max": int(iters.max())},
-            "timing": {"blocks": len(blocks), "steps_per_block": args.steps, "block_ms_min": min(blocks) * 1e3,
-                       "block_ms_median": elapsed * 1e3, "block_ms_max": max(blocks) * 1e3,
-                       "note": "value and ms_per_step are the MEDIAN block of exactly `steps` ticks (barrier + synchronize on both "
-                               "sides of every block, max over ranks); blocks repeat until >= 50 ms are measured"},
-            "with_tau_allgather": gather_res,
-            "rccl_ranks": world if dist is not None else None,
             "roofline_whole_path_bytes": {"bound": "hbm", "achieved": path_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": path_gbs / HBM_PEAK_GBS / world, "bytes_per_step": path_words * ts,
                                           "note": "SURVEY.md 8(d) whole-path algorithmic bytes per control step (inputs + tau, f%s) x "
                                                   "control-steps/s, per GPU against 8 TB/s: the path is latency / issue-bound long before "
                                                   "it is bound by these bytes" % (" + observer state" if obs else "")},
             "device": devinfo,
-        }
-        if long_blocks is not None:
-            res["value_long_blocks"] = long_blocks
+        })
+        res.update(job_fields(blocks, args.steps, elapsed, long_blocks, gather_res, world, dist))
         if not args.no_latency and world == 1:
             res["qp_latency"] = qp_latency(W, synth, torch, np, model, B, P, dtype, td, obs)
         if not args.no_latency and world == 1:
@@ -541,7 +576,7 @@ def closed_loop_leg(W, torch, np, model, P, B, dtype, td, obs, n, device, want_m
     return res
 
 
-def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch):
+def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch, device="cuda", sync=None):
     """SURVEY.md 8e "steps/s with and without the all-gather": the consumer-side collective of every tick.  The ticks write their
     torques straight into this rank's block of the gather buffer (in-place all-gather: no second copy of the local block), two
     buffers alternate.  `value` = K ticks + K gathers captured ONCE as a hipGraph and replayed (what the device needs; a tick of
@@ -551,15 +586,16 @@ def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch):
     from wbc_quadruped_dob_amd.sharding import (agree_on_steps, gather_buffers, graph_steps_with_gather, timed_steps_with_gather,
                                                 timed_steps_with_overlapped_gather)
     get = lambda o: o["tau"]
-    flats, views = gather_buffers(world, rank, 12, n, td, "cuda")
+    sync = sync or torch.cuda.synchronize
+    flats, views = gather_buffers(world, rank, 12, n, td, device)
     step_fns = tuple(make_tick(v) for v in views)
-    el_serial, _ = timed_steps_with_gather(step_fns[0], get, dist, steps, torch.cuda.synchronize, flat=flats[0])
+    el_serial, _ = timed_steps_with_gather(step_fns[0], get, dist, steps, sync, flat=flats[0])
     res = {"collective": "all_gather_into_tensor(tau) of every step, RCCL, %d B per rank per step, in place (the tick writes tau into its block of "
                          "the gather buffer); two buffers alternate" % nbytes,
            "eager_serial": {"value": steps * n * world / el_serial, "ms_per_step": el_serial / steps * 1e3,
                             "note": "host-issued, the gather on the tick's stream behind every tick"}}
     try:
-        el_o, _ = timed_steps_with_overlapped_gather(step_fns, get, dist, steps, torch.cuda.synchronize, flats=flats)
+        el_o, _ = timed_steps_with_overlapped_gather(step_fns, get, dist, steps, sync, flats=flats)
         res["eager_overlapped"] = {"value": steps * n * world / el_o, "ms_per_step": el_o / steps * 1e3,
                                    "note": "host-issued, side stream beside the next tick: bound by the Python cost of the collective calls"}
     except Exception as e:
@@ -571,7 +607,7 @@ def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch):
         if os.environ.get("WBC_BENCH_GRAPH_GATHER") == "1" else ()
     # graphs long enough (>= 5 ms) that the replay's own launch cost is < 1 % of what it times
     kg = max(steps, int(5e-3 / max(el_serial / steps, 1e-6)) + 1)
-    kg = agree_on_steps(kg, dist, "cuda") if graph_forms else kg
+    kg = agree_on_steps(kg, dist, device) if graph_forms else kg
     for key, ov, ga in graph_forms:
         try:
             el, _ = graph_steps_with_gather(step_fns, get, dist, kg, replays=5, overlapped=ov, gather=ga, flats=flats)
@@ -661,12 +697,9 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
             return st
         g3 = gather_leg(make_tick, dist, k3, n3, world, rank, 12 * n3 * 4, td, torch)
         ok = float((out["status"] == 0).double().mean().item())
-        res["scale_config3"] = {
-            "workload": "configs[3]: batch=%d fp32 = %d states per GPU x %d, tilted terrain normals + disturbances, observer on, M/h/Jc written"
-                        % (n3 * world, n3, world),
-            "value": k3 * n3 * world / el, "unit": "control-steps/s", "ms_per_step": el / k3 * 1e3, "steps_per_block": k3, "blocks": len(bl),
-            "with_tau_allgather": g3,
-            "rccl_ranks": world, "dtype": "f32", "status_ok_frac_rank0": ok}
+        res["scale_config3"] = leg_fields("configs[3]: batch=%d fp32 = %d states per GPU x %d, tilted terrain normals + disturbances, observer on, M/h/Jc written"
+                                          % (n3 * world, n3, world), k3, n3, world, el, bl, g3, "f32")
+        res["scale_config3"]["status_ok_frac_rank0"] = ok
         del solver, tick, out, inp, integ, rr, make_tick
         torch.cuda.empty_cache()
     except Exception as e:   # never lose the headline to an extra leg
@@ -690,15 +723,13 @@ def scale_legs(args, W, synth, torch, np, dist, world, rank, local_rank, model):
                             else {"flops_per_tick": rollout_flops_only(r5, args.horizon)})
                 except Exception as e:
                     cpu5 = None
-            res.setdefault("scale_config5", {})[name] = {
-                "roofline": rollout_measurement_objects(rf5, cpu5, None, n5, args.horizon, "f64", world) if cpu5 else None,
-                "cpu_baseline": cpu5 if (cpu5 and "value" in cpu5) else None,
-                "workload": "configs[4]: horizon=%d x %d rollouts per GPU x %d GPUs, trot masks, observer on, pushes, fp64, rank-local for all ticks"
-                            % (args.horizon, n5, world),
-                "value": k5 * args.horizon * n5 * world / el, "unit": "control-steps/s", "ms_per_rollout": el / k5 * 1e3,
-                "us_per_tick": el / k5 / args.horizon * 1e6, "rollouts_per_block": k5, "blocks": len(bl), "rccl_ranks": world,
-                "with_tau_allgather": None, "dtype": "f64",
-                "note": "no gather leg: a rollout keeps tau of 20 ticks on its rank; the consumer-side collective is configs[3]'s"}
+            leg = leg_fields("configs[4]: horizon=%d x %d rollouts per GPU x %d GPUs, trot masks, observer on, pushes, fp64, rank-local for all ticks"
+                             % (args.horizon, n5, world), k5, args.horizon * n5, world, el, bl, None, "f64", unit_ms_key="ms_per_rollout")
+            leg.update({"roofline": rollout_measurement_objects(rf5, cpu5, None, n5, args.horizon, "f64", world) if cpu5 else None,
+                        "cpu_baseline": cpu5 if (cpu5 and "value" in cpu5) else None,
+                        "us_per_tick": el / k5 / args.horizon * 1e6,
+                        "note": "no gather leg: a rollout keeps tau of 20 ticks on its rank; the consumer-side collective is configs[3]'s"})
+            res.setdefault("scale_config5", {})[name] = leg
             del r5
             torch.cuda.empty_cache()
         except Exception as e:

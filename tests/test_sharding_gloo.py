@@ -3,6 +3,7 @@ The per-rank compute is the CPU oracle injected as a stand-in (allowed in tests/
 the same ShardedBatch wraps Solver.step over RCCL."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,8 @@ import torch.multiprocessing as mp
 
 from wbc_quadruped_dob_amd import synth
 from wbc_quadruped_dob_amd.sharding import ShardedBatch, shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_range_partitions_exactly():
@@ -174,3 +177,84 @@ def test_model_constants_are_broadcast_once():
         p.join(60)
         assert p.exitcode == 0
     assert same == 1 and dims == (13, 19, 18, 12, 4) and dm < 1e-12
+
+
+def _bench_line_worker(rank, world, port, q):
+    """One rank of the rehearsal: bench.py's OWN N > 1 functions (measure_job -> timed_blocks / long_blocks_of, gather_leg, contract_fields, job_fields,
+    leg_fields) over gloo, with a stand-in tick that sleeps a rank-dependent time and writes a recognisable tau."""
+    import json
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        import bench
+        n, steps, warmup = 96, 4, 2
+        tick_s = 0.8e-3 * (1.0 + 0.25 * rank)            # the slowest rank (world - 1) sets the job's time
+        tau = torch.zeros((12, n), dtype=torch.float64)
+        calls = [0]
+
+        def step():
+            calls[0] += 1
+            time.sleep(tick_s)
+            tau.fill_(float(rank + 1))
+            return {"tau": tau}
+        nosync = lambda: None
+        blocks, elapsed, long_blocks = bench.measure_job(step, steps, n, world, dist, torch, np, device="cpu", sync=nosync)
+
+        def make_tick(view):
+            def st():
+                time.sleep(tick_s)
+                view.fill_(float(rank + 1))
+                return {"tau": view}
+            return st
+        gather = bench.gather_leg(make_tick, dist, steps, n, world, rank, 12 * n * 8, torch.float64, torch, device="cpu", sync=nosync)
+        line = bench.contract_fields(steps, warmup, n, world, elapsed, "f64", "rehearsal: stand-in ticks", True)
+        line.update(bench.job_fields(blocks, steps, elapsed, long_blocks, gather, world, dist))
+        k_leg, bl_leg, el_leg = bench.long_blocks_of(step, 3, dist, torch, np, device="cpu", sync=nosync)
+        line["scale_config3"] = bench.leg_fields("rehearsal leg", k_leg, n, world, el_leg, bl_leg, gather, "f32")
+        q.put((rank, json.dumps(line), blocks, elapsed, tick_s, calls[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_bench_line_rehearsal():
+    """bench.py's N > 1 aggregation had only ever executed with world = 1.  Eight gloo ranks drive the very functions the driver's
+    `--gpus 8` run goes through: every rank arrives at the SAME blocks (max over ranks), `value` = steps x n x 8 / the slowest rank's block, the long
+    blocks and the gather leg agree with it, and rank 0's line is valid JSON of the contract's shape."""
+    import json
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_line_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    lines = [json.loads(g[1]) for g in got]
+    blocks0, elapsed0 = got[0][2], got[0][3]
+    slowest = max(g[4] for g in got)
+    n, steps = 96, 4
+    for (rank, _, blocks, elapsed, tick_s, ncalls), line in zip(got, lines):
+        assert blocks == blocks0 and elapsed == elapsed0                        # every rank took the slowest rank's clock: same decisions everywhere
+        assert ncalls == got[0][5]                                              # ... and ran the same number of ticks (agree_on_steps)
+        assert line["n_gpus"] == world and line["rccl_ranks"] == world and line["steps"] == steps and line["scaling"] == "weak" and line["higher_is_better"] is True
+        assert abs(line["value"] - steps * n * world / elapsed0) < 1e-6 * line["value"]
+        assert abs(line["ms_per_step"] - elapsed0 / steps * 1e3) < 1e-9
+        assert line["timing"]["blocks"] == len(blocks0) >= 7 and abs(line["timing"]["block_ms_median"] - elapsed0 * 1e3) < 1e-9
+    line = lines[0]
+    # the job's time is the SLOWEST rank's: a block of 4 ticks lasts at least 4 x its sleep, and not much more than that
+    assert steps * slowest <= elapsed0 < steps * slowest * 1.6 + 2e-3
+    lb = line["value_long_blocks"]
+    assert lb["steps_per_block"] >= steps and lb["block_ms_median"] >= 5.0 * 0.9 and 0.6 < lb["value"] / line["value"] < 1.6
+    g = line["with_tau_allgather"]
+    assert g["value_is"] in ("eager_serial", "eager_overlapped") and 0.3 < g["value"] / line["value"] < 1.3 and "value" in g["eager_serial"]
+    leg = line["scale_config3"]
+    assert leg["rccl_ranks"] == world and abs(leg["value"] - leg["steps_per_block"] * n * world / (leg["ms_per_step"] * 1e-3 * leg["steps_per_block"])) < 1e-6 * leg["value"]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["config"]["batch_per_gpu"] == n and "x8" in line["config"]["parallelism"]
