@@ -371,6 +371,10 @@ def main():
         path_words = 102 + (96 if obs else 0)
         path_gbs = path_words * ts * (args.steps * n / elapsed) / 1e9
         devinfo = device_probe(torch) if world == 1 else None
+        # rows of the priced launch: whole tick = in 78 (+ 60 with the observer) / out 24 + 405 (+ 36); the dynamics stage alone = in 38, out 405
+        rows_in = (78 + (60 if obs else 0)) if fused else 38
+        rows_out = words - rows_in
+        pattern = pattern_ceiling(ts, rows_in, rows_out, n) if world == 1 else None
         res = contract_fields(args.steps, args.warmup, n, world, elapsed, dtype,
                               "configs[%d]: batch=%d states/GPU, %s, observer %s, %s; synthetic quadruped URDF (DogBot URDF absent)"
                               % (args.config - 1, n, "4-contact stance" if args.config == 2 else "mixed 2/3/4-foot trot masks", "on" if obs else "off", dtype), want_mats)
@@ -387,7 +391,9 @@ def main():
                          "avg_launch_source": ("sampled dispatch spans (start/stop events of the dispatch) scaled by %.3f so that the "
                                                "tick's kernels fit inside the measured step period: a sampled launch is slower than "
                                                "the un-sampled ones `value` is made of" % span_scale),
-                         "frac_of_measured_copy_bw": (achieved / devinfo["hbm_copy_gbs"]) if (achieved and devinfo) else None,
+                         # the yardstick: tools/bw_probe.bin moving EXACTLY this launch's rows (reads and writes, leg-major lanes, no arithmetic) on this device, now
+                         "pattern_ceiling": pattern,
+                         "frac_of_pattern_ceiling": (achieved / pattern["gbs"]) if (achieved and pattern and pattern.get("gbs")) else None,
                          "launches_timed": tm["fused_launches"] if fused else tm["dyn_launches"],
                          "event_pair_overhead_us": ev_overhead_us,
                          "note": ("HIP start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on the launch stream, every "
@@ -627,6 +633,23 @@ def gather_leg(make_tick, dist, steps, n, world, rank, nbytes, td, torch, device
         res["note"] = ("host-issued ticks and collectives: at this tick length the Python call of a collective costs more than the tick; the device-side "
                        "cost (the same sequence captured as a hipGraph) is measured with WBC_BENCH_GRAPH_GATHER=1")
     return res
+
+
+def pattern_ceiling(scalar_bytes, rows_in, rows_out, n):
+    """What this device's memory system delivers on the launch's own footprint: tools/bw_probe.bin (built by __graft_entry__.build()) run as a CHILD process --
+    `rows_in` rows read and `rows_out` rows written per state, component-major, leg-major lanes, 8 bytes per lane and row, no arithmetic.  None when the probe
+    is not built.  (the yardstick used to be torch's 1 GiB copy, 4.5 TB/s -- below what the sweep's own pattern reaches.)"""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "bw_probe.bin")
+    if not os.path.exists(exe):
+        return None
+    try:
+        run = subprocess.run([exe, "rw", str(scalar_bytes), str(rows_in), str(rows_out), str(n)], capture_output=True, text=True, timeout=120)
+        gbs, us = run.stdout.split()[:2]
+        return {"gbs": float(gbs), "us": float(us), "rows_in": rows_in, "rows_out": rows_out, "states": n,
+                "source": "tools/bw_probe.bin rw %d %d %d %d (child process, after the timed region)" % (scalar_bytes, rows_in, rows_out, n)}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
 
 
 def device_probe(torch):

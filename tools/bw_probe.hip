@@ -3,6 +3,8 @@
 // "443 rows x 128-byte segments per wave" store pattern of the dynamics sweep with no arithmetic at all.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 __global__ void k_copy8(const double* __restrict__ in, double* __restrict__ out, size_t n) {
@@ -109,6 +111,20 @@ __global__ __launch_bounds__(64) void k_soa_write_x4(double* __restrict__ out, u
     *(double2*)((char*)out + (size_t)((comp * N + s) * 8u)) = make_double2(v + r, v - r);
   }
 }
+// The footprint of a whole kernel of this build, reads AND writes, nothing else: leg-major lanes (lane = 16 leg + j, as every dynamics body), 8 bytes per lane
+// and row (an fp64 state, or an fp32 PAIR of states: the packed lane type), a lane reads the rows r = leg (mod 4) of `rin` input rows, then writes its share of
+// `rout` output rows; what it read is folded into what it writes.  Rows are E elements apart (E = states, or pairs of fp32 states).  One-wavefront workgroups.
+__global__ __launch_bounds__(64) void k_soa_rw(const double* __restrict__ in, double* __restrict__ out, unsigned E, int rin, int rout) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned leg = lane >> 4;
+  const unsigned s = blockIdx.x * 16 + (lane & 15);
+  if (s >= E) return;
+  double acc = 0;
+#pragma unroll 8
+  for (int r = (int)leg; r < rin; r += 4) acc += *(const double*)((const char*)in + (size_t)(((unsigned)r * E + s) * 8u));
+#pragma unroll 8
+  for (int r = (int)leg; r < rout; r += 4) *(double*)((char*)out + (size_t)(((unsigned)r * E + s) * 8u)) = acc + r;
+}
 template <class F> float timeit(F f, int reps) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -118,7 +134,30 @@ template <class F> float timeit(F f, int reps) {
   float ms; hipEventElapsedTime(&ms, a, b);
   return ms / reps;
 }
-int main() {
+// `bw_probe.bin rw <bytes per scalar: 4 | 8> <input rows> <output rows> <states>`: one line "<GB/s> <us>" for that footprint (bench.py: roofline.frac_of_pattern_ceiling)
+static int probe_rw(int scalar, int rin, int rout, unsigned N, bool quiet) {
+  const unsigned E = scalar == 4 ? (N + 1) / 2 : N;   // fp32: a lane holds a pair of states
+  double *a = nullptr, *b = nullptr;
+  if (hipMalloc(&a, (size_t)(rin > 0 ? rin : 1) * E * 8) != hipSuccess || hipMalloc(&b, (size_t)(rout > 0 ? rout : 1) * E * 8) != hipSuccess) return 1;
+  hipMemset(a, 0, (size_t)(rin > 0 ? rin : 1) * E * 8);
+  const float t = timeit([&] { hipLaunchKernelGGL(k_soa_rw, dim3((E + 15) / 16), dim3(64), 0, 0, a, b, E, rin, rout); }, 50);
+  const double bytes = (double)(rin + rout) * N * scalar;
+  if (quiet) printf("%.1f %.3f\n", bytes / t / 1e6, t * 1e3);
+  else printf("rw pattern %3d in + %3d out rows x %6u %s states : %.1f us  %.0f GB/s\n", rin, rout, N, scalar == 4 ? "fp32" : "fp64", t * 1e3, bytes / t / 1e6);
+  hipFree(a); hipFree(b);
+  return 0;
+}
+int main(int argc, char** argv) {
+  if (argc == 6 && std::string(argv[1]) == "rw") return probe_rw(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), (unsigned)atol(argv[5]), true);
+  // the footprints this build's rooflines are argued on (DESIGN.md sections 4, 7, 9): reads + writes of the whole kernel
+  probe_rw(4, 138, 465, 32768, false);    // tile tick, fp32, observer on: in 78 + 60, out M, h, Jc 405 + tau, f 24 + observer state 36 = 603 words
+  probe_rw(4, 138, 465, 262144, false);
+  probe_rw(4, 37, 406, 32768, false);     // the dynamics stage alone: 443 words
+  probe_rw(4, 97, 511, 32768, false);     // sweep_obs as launched (PMC: 608 words incl. the step workspace)
+  probe_rw(8, 78, 429, 4096, false);      // one-launch tick, fp64, observer off: 507 words
+  probe_rw(8, 138, 465, 4096, false);     // ... observer on: 603
+  probe_rw(8, 37, 406, 262144, false);    // dyn_sweep, fp64, 262 144 states: 443
+  probe_rw(8, 78, 429, 28672, false);     // tile tick, fp64, observer off, one round of workgroups
   const size_t bytes = (size_t)1 << 30;
   double *a, *b;
   hipMalloc(&a, bytes); hipMalloc(&b, bytes);
