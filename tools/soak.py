@@ -215,7 +215,7 @@ for c in range(cases):
         if not np.array_equal(a["status"], b["status"]):
             bad.append((c, "warm rollout status", n, obs, cfg))
         for k in a:
-            if k == "status":
+            if k in ("status", "iters"):   # (iters: a warm-started tick and a cold one reach the same solution in different numbers of iterations)
                 continue
             e = relerr(a[k], b[k])
             worst = max(worst, e)
@@ -226,6 +226,10 @@ for c in range(cases):
             bad.append((c, "rollout status", n, obs, cfg))
         for k in a:
             if k == "status":
+                continue
+            if k == "iters":   # (the last tick's: last-bit differences of the state flip a near-tie between two violated rows now and then -- a share of the states, not a bound)
+                if np.mean(a[k] != b[k]) > 1e-2:
+                    bad.append((c, "rollout iters differ in %.3f of the states" % np.mean(a[k] != b[k]), n, obs, cfg, H))
                 continue
             e = relerr(a[k], b[k])
             worst = max(worst, e)

@@ -15,9 +15,8 @@
 
 // 1 (round 5): joint indices come from the packed kernel argument jpack, 0: from DevModel::jidx loads / the QpJidx select chain (rounds 1-4);
 // see jidx_of_leg (dyn_sweep.hip.hpp)
-#ifndef WBC_JIDX_ARGS
-#define WBC_JIDX_ARGS 1
-#endif
+
+#define WBC_DEV __device__ __forceinline__
 
 namespace wbc {
 
@@ -93,9 +92,6 @@ constexpr int SIMG_V = 19, SIMG_WORDS = 37;
 // The result image of a rollout workgroup (QpSync::res, qp_group16.hip.hpp): this tick's tau (rows 0 .. 11, caller's joint order), f (12 .. 23), h (24 .. 41),
 // [row][16 slots]; rows 42 .. 59 hold the external torques of the workgroup's states for the whole launch.
 constexpr int RES_TAU = 0, RES_F = 12, RES_H = 24, RES_WORDS = 42;
-#ifndef WBC_RO_MERGE
-#define WBC_RO_MERGE 1
-#endif
 
 template <class T> struct QpArgs {
   size_t N;

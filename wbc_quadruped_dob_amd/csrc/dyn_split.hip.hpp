@@ -62,10 +62,7 @@ namespace wbc {
 // (pure-output stores keep their `if (live)` guard here: without it the roles save ~1 % in the fused tick but the persistent rollout
 // kernel, which sits at 256 registers, spills -- 19.5 -> 24.0 us per tick, measured)
 // -DWBC_ROLE_UNGUARD=1 (A/B): pure-output stores of the ROLES (EXT != 0) without their guard -- a dead lane of a role duplicates a state of its own wavefront
-#ifndef WBC_ROLE_UNGUARD
-#define WBC_ROLE_UNGUARD 0
-#endif
-#define WBC_ROLE_LIVE ((WBC_ROLE_UNGUARD && EXT != 0) || live)
+#define WBC_ROLE_LIVE ((0 && EXT != 0) || live)
 #define STV(ptr, comp, val) do { if (WBC_ROLE_LIVE) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define STVG(ptr, comp, val) do { if (live) *(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)   /* in/out state (observer): dead lanes of OTHER wavefronts would race with the live one */
 #define STL(ptr, c0, stride, val) do { if (WBC_ROLE_LIVE) *(T*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
@@ -77,15 +74,9 @@ namespace wbc {
     R_.a[3] = 2 * (x * y + z * w);     R_.a[4] = 1 - 2 * (x * x + z * z); R_.a[5] = 2 * (y * z - x * w); \
     R_.a[6] = 2 * (x * z - y * w);     R_.a[7] = 2 * (y * z + x * w);     R_.a[8] = 1 - 2 * (x * x + y * y); } while (0)
 
-#ifndef WBC_FUSED_RNEA_FASTR
-#define WBC_FUSED_RNEA_FASTR 0   // (A/B) 1: the one-launch tick's rnea role normalises the quaternion with rsqrt_fast: lever arms ~0.2 us earlier
-#endif
-#ifndef WBC_MJ_WAVES
-#define WBC_MJ_WAVES 2
-#endif
-#ifndef WBC_RS_WAVES
-#define WBC_RS_WAVES 2
-#endif
+// (A/B) 1: the one-launch tick's rnea role normalises the quaternion with rsqrt_fast: lever arms ~0.2 us earlier
+constexpr int WBC_MJ_WAVES = 2;
+constexpr int WBC_RS_WAVES = 2;
 
 // ======================================================================================================================
 // mass_jac_kernel: M(q) by CRBA, Jc(q), pf(q).  No velocities anywhere.
@@ -497,16 +488,13 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   }
   T qx, qy, qz, qw;
   {
-    const T n = rsqrt_sel<(SIMG || (WBC_FUSED_RNEA_FASTR && EXT == 2))>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    const T n = rsqrt_sel<(SIMG || (0 && EXT == 2))>(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
     qx = qq[0] * n; qy = qq[1] * n; qz = qq[2] * n; qw = qq[3] * n;
   }
   T sn3[3] = {0, 0, 0}, cs3[3] = {0, 0, 0};
   // (four-wavefront rollout workgroups: the role has its SIMD's whole register file, so the three joint rotations of the early lever-arm chain are KEPT
   //  for the forward sweep instead of being rebuilt there from the same sin / cos -- 81 multiply-adds off the tick's critical chain; -DWBC_RNEA_KEEP_E=0: rebuilt)
-#ifndef WBC_RNEA_KEEP_E
-#define WBC_RNEA_KEEP_E 1
-#endif
-  constexpr bool KEEP_E = WBC_RNEA_KEEP_E != 0 && EARLY && SIMG && SPW == 4;
+  constexpr bool KEEP_E = EARLY && SIMG && SPW == 4;
   M3<T> Ekeep[KEEP_E ? 3 : 1];
   if constexpr (EARLY) {
     // The QP waves can assemble and factor H from the four lever arms alone, so those go out ahead of the force
@@ -694,17 +682,12 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
     {
       const T hk = dot(ax, fk.n);  // bias torque (TWO) or merged M vdot_des + h (one chain)
       if (WH) {
-#if WBC_JIDX_ARGS   // the column offset again, from a laundered copy of the packed map: three VGPRs less across both sweeps than keeping jxN alive
         unsigned long long jp = a.jpack;
         asm volatile("" : "+s"(jp));
         const unsigned jx_k = ((unsigned)(jp >> (12 * leg)) >> (4 * k)) & 15u;
         const unsigned jxN_k = jx_k * N32;
         if (h_mem) STLX(a.h, 6, 0, jxN_k, hk);
         if (hres) hres[(6 + (int)jx_k) * 16 + (int)(tx & 15)] = hk;
-#else
-        if (h_mem) STLX(a.h, 6, 0, jxN[k], hk);
-        if (hres) hres[(6 + jx[k]) * 16 + (int)(tx & 15)] = hk;
-#endif
       }
       if (STEP) taup[k] = hk + (TWO ? dot(ax, fak.n) : (T)0);
     }

@@ -20,7 +20,6 @@
 
 namespace wbc {
 
-#define WBC_DEV __device__ __forceinline__
 
 template <class T> struct V3 { T x, y, z; };
 template <class T> WBC_DEV V3<T> mk(T x, T y, T z) { V3<T> r; r.x = x; r.y = y; r.z = z; return r; }
@@ -150,13 +149,8 @@ template <class T> WBC_DEV T sel4(int leg, T a, T b, T c, T d) { return leg == 0
 // joint-state loads of every body: two dependent trips through L2 at the head of every role of the fused tick and of every tick of a rollout.
 // (the macro lives in device_types.hpp: the QP bodies use it too)
 template <class Model> WBC_DEV void jidx_of_leg(const Model* __restrict__ model, unsigned long long jpack, int leg, int (&jx)[3]) {
-#if WBC_JIDX_ARGS
   const unsigned t = (unsigned)(jpack >> (12 * leg));
   jx[0] = (int)(t & 15u); jx[1] = (int)((t >> 4) & 15u); jx[2] = (int)((t >> 8) & 15u);
-#else
-#pragma unroll
-  for (int k = 0; k < 3; ++k) jx[k] = model->jidx[leg][k];
-#endif
 }
 
 // fp64 sin/cos, straight-line (no branches, so the three joints of a leg interleave in the pipeline): two-term
@@ -272,9 +266,7 @@ template <class X> WBC_DEV void pin(V3<X>& v) { pin(v.x); pin(v.y); pin(v.z); }
 
 // MODE bits
 
-#ifndef WBC_SWEEP_WAVES
-#define WBC_SWEEP_WAVES 2
-#endif
+constexpr int WBC_SWEEP_WAVES = 2;
 // BLOCK = 64 for small batches (N/16 workgroups: one per CU at N = 4096) or 256 for large ones (four waves
 // share one constant table, which lets two workgroups = 8 waves fit the CU's 160 KB of LDS).
 // The observer variants may use more than 256 VGPRs (their occupancy is LDS-bound anyway); forcing two waves per

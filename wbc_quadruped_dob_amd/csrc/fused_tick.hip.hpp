@@ -29,9 +29,6 @@ namespace wbc {
 #endif
 // 1 (default): the structural zeros / ones of M and Jc are written by the four QP wavefronts while they wait for the lever arms,
 // not by the mass_jac role (~55 store instructions = ~4 us of store issue off that role's path); 0: by the mass_jac role
-#ifndef WBC_FUSED_ZEROS_BY_QP
-#define WBC_FUSED_ZEROS_BY_QP 1
-#endif
 // fused tick, observer on: the observer role is TWO wavefronts (base rows -> rhat_base, which the QP's b waits for; joint
 // rows -> rhat_joint, needed only in the torque map); -DWBC_OBS_ONE_WAVE: one wavefront does both
 #ifdef WBC_OBS_ONE_WAVE
@@ -60,26 +57,15 @@ constexpr int FUSED_OBS_WAVES = 2;
 // are taken).  Wave 4 runs the ONE merged force recursion RNEA(q, v, vdot_des) -- tau_partial, all the QP's torque map waits
 // for -- and wave 6 the bias-force recursion whose only consumer is the caller's h buffer.  One wavefront doing both chains
 // (round 2) kept the QP wavefronts waiting for tau_partial until +9.1 us.
-#ifndef WBC_FUSED_SPLIT_H
-#define WBC_FUSED_SPLIT_H 0
-#endif
 // 1 (default, round 5): the observer role stores r only after the QP wavefronts have read r_prev (QpSync::rp_ack); 0: the unordered read of round 4 (A/B)
-#ifndef WBC_SPEC_ORDER
-#define WBC_SPEC_ORDER 1
-#endif
 // (fp64 only: the fp32 tick fits two six-wavefront workgroups on a CU -- 147 VGPRs, 49 kB LDS -- and a seventh wavefront would end that)
 // WARM ticks are another matter: the block set-up ends the QP at about +5.5 us, so the tick ends with the rnea role and its torque map, and taking
 // the bias-force chain off that role shows: tick kernel 12.0 -> 11.0 us at 1 024 states, 13.2 -> 12.6 at 4 096, 22.2 -> 21.3 at 8 192 in a closed
 // loop of drifting states (13.5 -> 13.2 on the bench's own batch; tools/ab_libs.sh with --closed-loop).  On by default for the warm instantiation.
-#ifndef WBC_FUSED_SPLIT_H_WARM
-#define WBC_FUSED_SPLIT_H_WARM 1
-#endif
-#ifndef WBC_FUSED_SPLIT_H_WARM_F32   // (the fp32 WARM instantiation holds 254 registers: one workgroup per CU whatever the wavefront count -- measured: tick
-                                     //  kernel 12.4 -> 12.1 us at 4 096 drifting states, 21.3 -> 20.4 at 8 192: too little to carry another instantiation)
-#define WBC_FUSED_SPLIT_H_WARM_F32 0
-#endif
+// (the fp32 WARM instantiation holds 254 registers -- one workgroup per CU whatever the wavefront count; with the split 12.4 -> 12.1 us at 4 096 drifting states: too little
+//  to carry another instantiation, so fp64 only)
 template <class T, bool OBSERVER, bool MATS, bool WARM = false> constexpr bool fused_split_h() {
-  return !OBSERVER && MATS && ((WBC_FUSED_SPLIT_H && sizeof(T) == 8) || (WBC_FUSED_SPLIT_H_WARM && WARM && (sizeof(T) == 8 || WBC_FUSED_SPLIT_H_WARM_F32)));
+  return !OBSERVER && MATS && WARM && sizeof(T) == 8;
 }
 template <class T, bool OBSERVER, bool MATS, bool WARM = false> constexpr int fused_threads() { return OBSERVER ? 384 + 64 * FUSED_OBS_WAVES : (fused_split_h<T, OBSERVER, MATS, WARM>() ? 448 : 384); }
 // WARM: the QP of every state starts from the active set in qa.aset_in (wbc_step_batch_warm: dependent ticks of a closed loop)
@@ -91,17 +77,10 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   __shared__ T wsl[WS_LDS_WORDS * 16];
   __shared__ int ready, gready, oready;   // rnea role done / its lever arms are out / observer role done
   __shared__ int rpack;                   // QP wavefronts that have read r_prev (speculative start): the observer role stores r behind all four
-  constexpr bool SPEC_ORDER = OBSERVER && !WARM && WBC_QP_SPEC != 0 && WBC_SPEC_ORDER != 0;
+  constexpr bool SPEC_ORDER = OBSERVER && !WARM;
   const int wave = (int)(threadIdx.x >> 6);
   // -DWBC_FUSED_PRIO=1: QP wavefronts at a higher issue priority than the producers they share a SIMD with (the kernel lasts as long as its slowest QP);
   // 2: the rnea role (whose lever arms and tau_partial the QPs wait for) high instead
-#ifndef WBC_FUSED_PRIO
-#define WBC_FUSED_PRIO 0
-#endif
-  if constexpr (WBC_FUSED_PRIO == 1) { if (wave < 4) __builtin_amdgcn_s_setprio(3); }
-  if constexpr (WBC_FUSED_PRIO == 2) { if (wave == 4) __builtin_amdgcn_s_setprio(3); }
-  if constexpr (WBC_FUSED_PRIO == 3) { if (wave != 5) __builtin_amdgcn_s_setprio(2); }   // 3: everybody above the mass_jac role, whose output nobody in the kernel waits for
-  if constexpr (WBC_FUSED_PRIO == 4) { if (wave < 4) __builtin_amdgcn_s_setprio(3); else if (wave == 4) __builtin_amdgcn_s_setprio(2); }   // 4: QP > rnea > mass_jac
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the pf output carries the role timestamps (slot, workgroup) instead of foot positions
   double* const stamp = (double*)a.pf;
   const unsigned stampN = (unsigned)a.N;
@@ -122,10 +101,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
       FSTAMP(7);
     };
     // -DWBC_FUSED_TAUP_FIRST=1 (A/B): with h wanted from this role, tau_partial is handed to the QP wavefronts before the base rows of h are summed, rotated and stored
-#ifndef WBC_FUSED_TAUP_FIRST
-#define WBC_FUSED_TAUP_FIRST 0
-#endif
-    if constexpr (WBC_FUSED_TAUP_FIRST != 0 && (RMODE & RS_H) != 0) {
+    if constexpr (false && (RMODE & RS_H) != 0) {
       int* const finflag = &ready;
       rnea_step_body<T, RMODE, 64, 2>(model, prm, a, cst, wsl, NoWait(), geom_out, nullptr, [=] __device__() {
         FSTAMP(8);
@@ -139,7 +115,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
     }
   } else if (wave == 5) {
-    if constexpr (MATS) mass_jac_body<T, 64, 2, 16, (WBC_FUSED_ZEROS_BY_QP == 1 ? 0 : (WBC_FUSED_ZEROS_BY_QP == 2 ? 2 : 1))>(model, a, cst, zidx_s);   // (2: the role writes them LAST)
+    if constexpr (MATS) mass_jac_body<T, 64, 2, 16, (0)>(model, a, cst, zidx_s);   // (2: the role writes them LAST)
     else __syncthreads();
     FSTAMP(9);
   } else if (fused_split_h<T, OBSERVER, MATS, WARM>() && wave == 6) {
@@ -174,14 +150,12 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
     QpSync sy{&gready, &oready, &ready, 1, 2, 1, NFIN};   // the QP waits for each piece where it first needs it
 #endif
     if constexpr (SPEC_ORDER) sy.rp_ack = &rpack;
-#if WBC_FUSED_ZEROS_BY_QP == 1
     if constexpr (MATS) {
       const int* const zs = zidx_s;
       const unsigned tq = threadIdx.x;
       auto idle = [=] __device__() { if (!a.skip_consts) structural_consts_quarter<T>(model, a, zs, tq); };
       qp_body<T, true, OBSERVER, 16, false, 4, decltype(idle), false, WARM ? 1 : 0>(prm, qa, jmap, wsl, &sy, QpWho{0, false}, idle);
     } else
-#endif
     qp_body<T, true, OBSERVER, 16, false, 4, QpNoIdle, false, WARM ? 1 : 0>(prm, qa, jmap, wsl, &sy);
   }
 }
@@ -189,47 +163,25 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
 // Persistent rollout (BASELINE.json configs[4]): `horizon` dependent ticks of {tick roles as above, forward
 // dynamics + integrator} in ONE launch.  A workgroup owns its 4 or 16 states for the whole horizon, so no tick boundary ever
 // leaves the CU: no launch, no HBM round trip of the workspace.
-// LAYOUT SINCE ROUND 5 (MERGE below): the integrator's factorisation (phase 1) runs on the mass_jac wavefront behind its LDS
-// image, its right-hand sides / solves / state update (phase 2) on QP wavefront 0 right behind the torque map; ONE barrier per tick; the
-// states, this tick's tau / f / h, the planner's references and plans live in LDS images from tick to tick, and the caller's buffers are
-// written in the launch's last tick only.  4-state workgroups are four wavefronts (one per SIMD: the whole register file each).
-// The text below describes the layout of rounds 1-4 (-DWBC_RO_MERGE=0 -DWBC_RO_MERGE16=0): two workgroup barriers per tick (tau, f, h visible
-// to the integrator wave; q, v visible to the next tick's producers); the integrator is its own wavefront: it factors the arrow matrix
-// beside the QP (that needs only M, Jc, published by the mass_jac role through a flag) and finishes the right-hand sides, solves and
-// state update between the two barriers.
-// tau_prev / f_prev of the observer are the tau / f buffers themselves: the observer role reads them before it raises
-// its flag, the QP waves overwrite them only after both flags.
-// Measured (MI355X, observer on, horizon 20): 33.7 us per tick against 37.2 us for {fused tick + integrate} launches at
-// 1 024 rollouts, 28.6 against 32.8 at 128.  History: with the integrator as "wave 0 after its QP" the tick cost 37.1 us
-// -- with the QP, the integrator or both compiled out 17.4 / 28.4 us, i.e. front ~8.7, QP ~19.7, integrator + barrier
-// ~8.7 us, about what the stand-alone kernels take; moving the factorisation beside the QP removed ~3.5 us of that.
-// Back-to-back launches on one stream cost far less than their nominal 2-3 us each, so removing them buys little; what a
-// tick is made of is ~6 dependent trips through L2 (state loads, table-indexed joint loads, store acks at the two
-// barriers) around the arithmetic.  PMC (tools/icache_profile.sh): instruction-cache hit rate 99.7 %, same misses per
-// tick as the per-tick launches -- code size (72 kB) is not the limiter.
-// TRACK: the CoM planner in the loop (wbc_rollout_tracking_batch).  The integrator wavefront, idle at the head of a tick,
-// first runs the reference generator (com_reference_body: w_des, vdot_des of this tick -> HBM, optional CoM record) and
-// raises a third flag; the rnea role issues its state loads, then waits for that flag before it reads the references.
-// SPW: states per workgroup (16, or 4 for rollouts of at most 1 024 states: every CU gets a workgroup and a tick waits for
-// the slowest of 4 QPs instead of 16 -- only QP wavefront 0 works then, the producer lanes of the other slots idle along).
-// WARM: every tick after the first starts its QPs from the previous tick's active set, carried in a register of the QP wavefronts
-// (wbc_solver_options.rollout_warm; the QP body of these instantiations is the block set-up of qp_struct16.hip.hpp for EVERY tick --
-// tick 0 from the empty set, or from qa.aset_in when the caller continues an earlier rollout).
-// WBC_RO_MERGE_OBS (four-wavefront layout of the 4-state workgroups, see MERGE below): where the observer's rows run -- 1: one pass over both sets of rows on
-// wavefront 3; 2: base rows, then joint rows, on wavefront 3; 3: base rows on wavefront 3, joint rows on a FIFTH wavefront (which shares SIMD 0 with the QP's,
-// and takes the kernel back to 256 registers per wavefront)
-#ifndef WBC_RO_MERGE_OBS
-#define WBC_RO_MERGE_OBS 1
-#endif
-// WBC_RO_MERGE16: the same re-ordering for the 16-state workgroups (1 025 ... 11 264 rollouts) as far as it carries over -- the integrator's phase 2 on QP
-// wavefront 0 behind all four QPs, phase 1 on the mass_jac wavefront, one barrier per tick, states / torques / references in LDS, outputs in the last tick
-// only.  Eight (observer off: six) wavefronts remain, i.e. two per SIMD and 256 registers; the recursions stay one after the other (all 16 slots are states).
-#ifndef WBC_RO_MERGE16
-#define WBC_RO_MERGE16 1
-#endif
+// Layout (round 5; DESIGN.md 4.7 -- the layouts of rounds 1-4, with an integrator wavefront of its own and two barriers per tick, and every placement
+// tried on the way are in docs/DESIGN_R04.md 8.0a and profiles/r05*_ab_rollout_*.log; their code went in round 6): the integrator's factorisation
+// (phase 1) runs on the mass_jac wavefront behind its LDS image, its right-hand sides / solves / state update (phase 2) on QP wavefront 0 right behind
+// the torque map; ONE barrier per tick; the states, this tick's tau / f / h, the planner's references and plans live in LDS images from tick to tick,
+// and the caller's buffers are written in the launch's last tick only.
+//   SPW = 4 (up to 1 024 rollouts: every CU gets a workgroup and a tick waits for the slowest of 4 QPs): FOUR wavefronts, one per SIMD --
+//     wavefront 0  [planner,] QP of the 4 states, then phase 2        wavefront 1  rnea role, its two force recursions side by side in the lanes (RS_LANE2)
+//     wavefront 2  mass_jac role, then phase 1 on its own image       wavefront 3  observer, ONE pass over both sets of rows (rhat_base handed to the QP first)
+//   SPW = 16: QP x 4 (phase 2 on wavefront 0 behind all four), rnea (tau_partial handed to the QPs before the base rows of h), mass_jac + phase 1,
+//     observer base rows and, on a wavefront of their own, joint rows: six / eight wavefronts, two per SIMD.
+// tau_prev / f_prev of the observer are the result image's rows of the previous tick (first tick: the caller's buffers).
+// TRACK: the CoM planner in the loop (wbc_rollout_tracking_batch): QP wavefront 0 first runs the reference generator (com_reference_body: w_des, vdot_des
+// of this tick -> LDS image, optional CoM record) and raises a flag; the rnea role issues its state loads, then waits for that flag.
+// WARM: every tick after the first starts its QPs from the previous tick's active set, carried in an LDS word per state (wbc_solver_options.rollout_warm;
+// the QP body of these instantiations is the block set-up of qp_struct16.hip.hpp for EVERY tick -- tick 0 from the empty set, or from qa.aset_in when
+// the caller continues an earlier rollout).
 __host__ __device__ constexpr int rollout_threads(bool observer, int spw) {
-  return (spw == 4 && WBC_RO_MERGE != 0) ? ((observer && WBC_RO_MERGE_OBS == 3) ? 320 : 256)
-       : (spw == 16 && WBC_RO_MERGE16 != 0) ? (observer ? 512 : 384)   // QP x 4, rnea, mass_jac [, observer base rows, joint rows]: no integrator wavefront
+  return (spw == 4) ? (256)
+       : (spw == 16) ? (observer ? 512 : 384)   // QP x 4, rnea, mass_jac [, observer base rows, joint rows]: no integrator wavefront
        : (observer ? 512 : 448);
 }
 template <class T, bool OBSERVER, bool TRACK, int SPW = 16, bool WARM = false>
@@ -239,27 +191,20 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // (the alignment puts the table FIRST in the workgroup's LDS: within reach of the 16-bit ds_read offset, see dyn_sweep.hip.hpp)
   __shared__ int zidx_s[64];
   __shared__ T wsl[WS_LDS_WORDS * 16];
-  __shared__ int ready, gready, oready, mready, rready, fready, qdone, hready;   // (hready, TAUP_FIRST: the rnea role's h is complete in the result image)   // (qdone, MERGE: QP wavefronts whose tau, f of this tick are in the result image)
+  __shared__ int ready, gready, oready, mready, rready, fready, qdone, hready;   // (hready, TAUP_FIRST: the rnea role's h is complete in the result image)   // (qdone: QP wavefronts whose tau, f of this tick are in the result image)
   __shared__ int rpack;   // (QpSync::rp_ack: QP wavefronts that have read r_prev in this tick, counted over the ticks)
-  // MERGE (round 5, 4-state workgroups): FOUR wavefronts instead of eight -- one per SIMD, so each may use the SIMD's whole register file (512 with the
-  // accumulation registers: the 8-wavefront kernel sat at 256 and spilled into the tick's critical phases) -- and the tick's critical chain on ONE of them:
-  //   wavefront 0  [planner,] QP, then the integrator's phase 2 right behind the torque map: no barrier and no trip through memory between them
-  //   wavefront 1  rnea role        wavefront 2  mass_jac role, then the integrator's phase 1 on its own image        wavefront 3  observer: base rows, then joint rows
-  // One barrier per tick (the state of the next one) instead of two; q and v stay in an LDS image (device_types.hpp, SIMG_*) from tick to tick.
-  constexpr bool MERGE = (SPW == 4 && WBC_RO_MERGE != 0) || (SPW == 16 && WBC_RO_MERGE16 != 0);
-  constexpr int REXT = MERGE ? 3 : 1;   // the roles' EXT: 3 = states from the LDS image (dyn_split.hip.hpp, WBC_STATE_MACROS)
-  // (MERGE) the observer wavefront runs the WHOLE update in one pass (PART 0: both sets of rows share the sweeps) instead of the base rows and then the joint
-  // rows as two passes (-DWBC_RO_MERGE_OBS=2: measured, the joint rows then arrive behind the rnea role and the fp64 tick waits for them -- 11.8 against
-  // 11.1 us per tick for the eight-wavefront layout; profiles/r05o_ab_rollout_merge.log)
-  constexpr bool OBS_ONE = MERGE && SPW == 4 && WBC_RO_MERGE_OBS == 1;
-  constexpr bool OBS_FIFTH = MERGE && OBSERVER && FUSED_OBS_WAVES == 2 && (SPW == 16 || WBC_RO_MERGE_OBS == 3);   // joint rows on their own wavefront
+  // (four wavefronts, one per SIMD: each may use the SIMD's whole register file -- 512 with the accumulation registers; an eight-wavefront form sat at 256 and spilled)
+  static_assert(SPW == 4 || SPW == 16, "4 or 16 states per workgroup");
+  constexpr int REXT = 3;   // the roles' EXT: 3 = states from the LDS image (dyn_split.hip.hpp, WBC_STATE_MACROS)
+  // 4 states: the observer wavefront runs the WHOLE update in one pass (PART 0: both sets of rows share the sweeps; as two passes the joint rows arrived behind
+  // the rnea role: 11.8 against 11.1 us per tick, profiles/r05o_ab_rollout_merge.log)
+  constexpr bool OBS_ONE = SPW == 4;
+  constexpr bool OBS_FIFTH = OBSERVER && FUSED_OBS_WAVES == 2 && (SPW == 16);   // joint rows on their own wavefront
   constexpr int W_JOINT = SPW == 16 ? 7 : 4;
-#ifndef WBC_RO_NOJC
-#define WBC_RO_NOJC 1   // (four-wavefront layout) 1: the fp64 rnea role does not propagate the own-leg Jacobian blocks -- the torque map takes them from the mass_jac
-#endif                  // role's image (RS_NOJC): 9.33 -> 9.23 us per tick at 1 024 robots, 128 robots 9.13 -> 9.01; fp32 7.57 -> 7.62 and cold 15.75 -> 15.86, hence
-                        // fp64 only (profiles/r05s_ab_rollout_nojc_refimg.log); 2: both scalar types; 0: never
-  constexpr bool NOJC = MERGE && (WBC_RO_NOJC == 2 || (WBC_RO_NOJC == 1 && sizeof(T) == 8));
-  constexpr bool SPEC_ORDER = OBSERVER && !WARM && WBC_QP_SPEC != 0 && WBC_SPEC_ORDER != 0;
+  // the fp64 rnea role does not propagate the own-leg Jacobian blocks -- the torque map takes them from the mass_jac role's image (RS_NOJC): 9.33 -> 9.23 us per
+  // tick at 1 024 robots; fp32 7.57 -> 7.62 and cold 15.75 -> 15.86, hence fp64 only (profiles/r05s_ab_rollout_nojc_refimg.log)
+  constexpr bool NOJC = sizeof(T) == 8;
+  constexpr bool SPEC_ORDER = OBSERVER && !WARM;
   constexpr int QP_WAVES = SPW / 4;
   for (int i = threadIdx.x; i < CST_WORDS; i += blockDim.x) cst[i] = model->cst[i];
   if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
@@ -267,34 +212,10 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   __syncthreads();
   const int wave = (int)(threadIdx.x >> 6);
   // -DWBC_RO_PRIO=1: the rnea role -- the chain a rollout tick waits for (tools/ro_knock.sh) -- at a higher issue priority than QP wavefront 0, its SIMD-mate
-#ifndef WBC_RO_PRIO
-#define WBC_RO_PRIO 0
-#endif
-  if constexpr (WBC_RO_PRIO != 0) { if (wave == 4) __builtin_amdgcn_s_setprio(3); }
-  constexpr int WINT = MERGE ? -1 : (OBSERVER ? 7 : 6);   // the integrator wavefront (MERGE: none -- phase 1 on the mass_jac wavefront, phase 2 on the QP's)
-  constexpr int W_RNEA = (MERGE && SPW == 4) ? 1 : 4, W_MJ = (MERGE && SPW == 4) ? 2 : 5, W_OBS = (MERGE && SPW == 4) ? 3 : 6;
-  // Workgroups of 4 states (SPW = 4) use QP wavefront 0 only; wavefronts 1..3 idle through the kernel and can take the two roles the
-  // integrator wavefront runs in front of its factorisation: the observer's joint rows (WBC_RO_JOINT_WAVE) and the planner (WBC_RO_PLAN_WAVE).
-  // -1 = the integrator wavefront keeps the role (always so with 16 states per workgroup).  Measured placements: docs/DESIGN_R04.md 8.0a; round 5: DESIGN.md 4.7.
-#ifndef WBC_RO_JOINT_WAVE
-#define WBC_RO_JOINT_WAVE -1
-#endif
-#ifndef WBC_RO_PLAN_WAVE
-#define WBC_RO_PLAN_WAVE 3    // planner on QP wavefront 3: 17.7 -> 16.4 us per tick at 1 024 tracked rollouts (wavefront 1: 16.65); the joint rows anywhere else
-#endif                        // than on the integrator wavefront LOSE (wavefront 1: 15.1, 2: 13.9, 3: 13.55 against 13.3 us per tick)
-#ifndef WBC_RO_INT_WAVE
-#define WBC_RO_INT_WAVE -1
-#endif
-  // (round 5) 4-state workgroups: the bias-force recursion -- whose only consumers are the caller's h buffer and the integrator behind the tick's barrier --
-  // leaves the rnea role for idle QP wavefront WBC_RO_H_WAVE; the rnea role is left with the ONE merged recursion RNEA(q, v, vdot_des) that the torque map
-  // waits for (the tick's second chain once the mass_jac role publishes early).  -1: one wavefront runs both recursions (rounds 1-4)
-#ifndef WBC_RO_H_WAVE
-#define WBC_RO_H_WAVE -1   // measured (profiles/r05b_ab_rollout_*.log): wavefront 2: 12.26 -> 12.67 us per tick at 1 024 robots, wavefront 1: 12.83 -- not kept
-#endif
-  constexpr int H_WAVE = (SPW == 4 && !MERGE) ? WBC_RO_H_WAVE : -1;
-  constexpr int INT_WAVE = (SPW == 4 && !MERGE) ? WBC_RO_INT_WAVE : -1;   // the integrator itself on an idle QP wavefront (the aux wavefront keeps the roles not moved)
-  constexpr int JOINT_WAVE = (OBSERVER && FUSED_OBS_WAVES == 2 && SPW == 4 && !MERGE) ? WBC_RO_JOINT_WAVE : -1;
-  constexpr int PLAN_WAVE = (TRACK && MERGE) ? 0 : ((TRACK && SPW == 4) ? WBC_RO_PLAN_WAVE : -1);   // (MERGE: in front of the QP, whose first input -- the lever arms -- the rnea role
+  constexpr int W_RNEA = (SPW == 4) ? 1 : 4, W_MJ = (SPW == 4) ? 2 : 5, W_OBS = (SPW == 4) ? 3 : 6;
+  // (where the idle QP wavefronts of a 4-state workgroup were tried as hosts of the observer's joint rows, the bias-force recursion and the integrator: docs/DESIGN_R04.md 8.0a,
+  //  DESIGN.md 4.7 -- all measured slower than the four-wavefront layout below and removed in round 6; the A/B logs are profiles/r05b_ab_rollout_*.log)
+  constexpr int PLAN_WAVE = (TRACK) ? 0 : ((TRACK && SPW == 4) ? 3 : -1);   // (in front of the QP, whose first input -- the lever arms -- the rnea role
                                                                                          // publishes only after it has waited for these references)
   T* const traj0 = ia.tau_traj;
   T* const com0 = ra.com;
@@ -309,26 +230,17 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
   // joint rows, waits at the tick barrier and does phase 2 with the factors from an LDS image.  In the stamp build the tick's barrier moves from +10.3 to
   // +9.2 us (profiles/r05g_rollout_timeline_spw4.txt); WITHOUT stamps the tick gets slower -- 12.5 -> 13.1 us at 1 024 robots, fp32 10.6 -> 11.2
   // (profiles/r05g_ab_rollout_*.log): measured, not kept.  0 (default): phase 1 on the integrator wavefront behind the joint rows
-#ifndef WBC_RO_SPLIT_INT
-#define WBC_RO_SPLIT_INT 0
-#endif
-#ifndef WBC_RO_INT_UNGUARD   // the integrator's state stores without their `if (live)` (integrate.hip.hpp, UNGUARD)
-#define WBC_RO_INT_UNGUARD 1
-#endif
+// the integrator's state stores without their `if (live)` (integrate.hip.hpp, UNGUARD)
   // (round 5) this tick's tau, f (QP wavefronts) and h (rnea role) for the integrator ALSO in LDS, the tick's first barrier ordering LDS only (the global
   // stores drain until barrier B) and phase 2 reading them there instead of through L2.  Measured (profiles/r05f_ab_rollout_reslds_*.log, us per tick at
   // 1 024 robots, off -> on): fp32 10.57 -> 10.01, fp64 12.51 -> 12.80 (128 robots 12.30 -> 12.67, planner in the loop 15.15 -> 15.6) -- round 4 had seen the
   // same sign for fp64.  1 (default): fp32 kernels only; 0: never; 2: both scalar types (A/B)
-#ifndef WBC_RO_RES_LDS
-#define WBC_RO_RES_LDS 1
-#endif
-  constexpr bool RES_LDS = MERGE || WBC_RO_RES_LDS == 2 || (WBC_RO_RES_LDS == 1 && sizeof(T) == 4);
-  constexpr bool SPLIT_INT = MERGE || WBC_RO_SPLIT_INT != 0;
-  __shared__ T fact_sh[SPLIT_INT ? INT_FACT_WORDS * 64 : 1];   // the integrator's phase 1 -> phase 2 hand-over (integrate.hip.hpp, PHASE)
-  __shared__ T st_sh[MERGE ? SIMG_WORDS * 16 : 1];             // (MERGE) the workgroup's states
-  __shared__ T ref_sh[(MERGE && TRACK) ? 24 * 16 : 1];         // (MERGE, planner in the loop) this tick's references: planner role -> rnea role
-  __shared__ T plan_sh[(MERGE && TRACK) ? PLAN_WORDS * 16 : 1];   // ... and the plans of the workgroup's states
-  if constexpr (MERGE) {
+  constexpr bool RES_LDS = true || (sizeof(T) == 4);
+  __shared__ T fact_sh[true ? INT_FACT_WORDS * 64 : 1];   // the integrator's phase 1 -> phase 2 hand-over (integrate.hip.hpp, PHASE)
+  __shared__ T st_sh[SIMG_WORDS * 16];             // the workgroup's states
+  __shared__ T ref_sh[(TRACK) ? 24 * 16 : 1];         // (planner in the loop) this tick's references: planner role -> rnea role
+  __shared__ T plan_sh[(TRACK) ? PLAN_WORDS * 16 : 1];   // ... and the plans of the workgroup's states
+  {
     for (int i = threadIdx.x; i < SIMG_WORDS * 16; i += blockDim.x) {
       const int comp = i >> 4, slot = i & 15;
       size_t st = (size_t)blockIdx.x * SPW + (slot < SPW ? slot : 0);
@@ -354,7 +266,7 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
       st = st < a.N ? st : a.N - 1;
       res_sh[(RES_WORDS + comp) * 16 + slot] = ia.tau_ext ? ia.tau_ext[(size_t)comp * a.N + st] : (T)0;
     }
-    if constexpr (MERGE && OBSERVER) {   // tau_prev, f_prev of the first tick: the caller's; of every later tick: what the QP left in these rows
+    if constexpr (OBSERVER) {   // tau_prev, f_prev of the first tick: the caller's; of every later tick: what the QP left in these rows
       for (int i = threadIdx.x; i < 24 * 16; i += blockDim.x) {
         const int comp = i >> 4, slot = i & 15;
         size_t st = (size_t)blockIdx.x * SPW + (slot < SPW ? slot : 0);
@@ -389,14 +301,10 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
     IntegrateArgs<T> iat = ia;
     at.N = qat.N = iat.N = (size_t)n_tick;
     at.simg = st_sh; iat.simg = st_sh; at.resimg = res_sh; at.refimg = ref_sh;
-#ifndef WBC_RO_SKIP_STATE
-#define WBC_RO_SKIP_STATE 1   // 0: every tick stores its q, v (A/B)
-#endif
-    iat.skip_state = (MERGE && WBC_RO_SKIP_STATE && t < horizon - 1) ? 1 : 0;   // q, v of the LAST tick are what the caller finds (the roles read the LDS image)
-#ifndef WBC_RO_SKIP_MATS
-#define WBC_RO_SKIP_MATS 1   // 0: every tick stores its M / Jc / pf (A/B)
-#endif
-    at.skip_mats = (WBC_RO_SKIP_MATS && t < horizon - 1) ? 1 : 0;   // M, Jc, pf of the LAST tick are what the caller finds in its buffers (as with per-tick launches)
+// 0: every tick stores its q, v (A/B)
+    iat.skip_state = (1 && t < horizon - 1) ? 1 : 0;   // q, v of the LAST tick are what the caller finds (the roles read the LDS image)
+// 0: every tick stores its M / Jc / pf (A/B)
+    at.skip_mats = (1 && t < horizon - 1) ? 1 : 0;   // M, Jc, pf of the LAST tick are what the caller finds in its buffers (as with per-tick launches)
     if (t > 0) at.skip_consts = 1;   // the structural zeros / ones of M, Jc were written by tick 0 of THIS launch into the same buffers (the mass_jac role's
                                      // ~55 store instructions per tick sit in front of the integrator's factorisation: wbc_api.cpp, rollout_persistent)
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the last tick's role timestamps go out through the pf output
@@ -413,12 +321,11 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         RefArgs<T> rt = ra;
         rt.N = (size_t)n_tick;
         rt.simg = st_sh; rt.refimg = ref_sh; rt.planimg = plan_sh;
-        rt.skip_out = (MERGE && t < horizon - 1) ? 1 : 0;   // (the caller finds the LAST tick's references in its w_des / vdot_des buffers)
+        rt.skip_out = (t < horizon - 1) ? 1 : 0;   // (the caller finds the LAST tick's references in its w_des / vdot_des buffers)
         rt.t = (T)t * prm.dt + ra.t;
         rt.com = com0 ? com0 + (size_t)t * 6 * (size_t)n_tick : nullptr;
-        com_reference_body<T, true, SPW, MERGE>(model, G, rt, cst);
-        if constexpr (MERGE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // w_des, vdot_des are in the LDS image ...
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // w_des, vdot_des are in L2 ...
+        com_reference_body<T, true, SPW, true>(model, G, rt, cst);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // w_des, vdot_des are in L2 ...
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&rready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
       }
     };
@@ -431,51 +338,12 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     };
-    auto integrator_role = [&]() __attribute__((always_inline)) {
-      // Integrator: its factorisation needs only M and Jc, so it starts as soon as the mass_jac role has handed them over
-      // and runs beside the QP; the tick barrier sits between the factorisation and the right-hand sides.
-      if constexpr (!SPLIT_INT) {
-        while (__hip_atomic_load(&mready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-      }
-      iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
-      constexpr int PH = SPLIT_INT ? 2 : 0;
-#ifdef WBC_FUSED_STAMP
-      iat.istamp = rstamp; iat.istampN = rstampN;
-      RSTAMP(9);   // factorisation can start (M, Jc handed over; the roles in front of it on this wavefront are done)
-      auto betw = [=] __device__() { RSTAMP(2); barrier_A(); RSTAMP(7); };   // (2, WBC_RO_STAMP_ALT: this wavefront is at the tick barrier)
-      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0), true, RES_LDS>(model, iat, betw, mj_hand, res_img, fact_sh);
-      RSTAMP(8);
-#else
-      auto betw = [=] __device__() { barrier_A(); };
-      integrate_body<T, SPW, decltype(betw), PH, (WBC_RO_INT_UNGUARD != 0), true, RES_LDS>(model, iat, betw, mj_hand, res_img, fact_sh);   // <- barrier A inside
-#endif
-      __syncthreads();                                                       // barrier B: q, v of the next tick
-    };
-    // -DWBC_RO_KNOCK=<bits> (diagnostic, results are garbage): roles reduced to their flags / barriers, to read the tick's critical path off the time that is
-    // left -- 1: integrator, 2: observer joint rows, 4: mass_jac, 8: observer base rows (tools/ro_knock.sh)
-#ifndef WBC_RO_KNOCK
-#define WBC_RO_KNOCK 0
-#endif
-    if (wave == WINT) {
-      if constexpr (PLAN_WAVE < 0) planner_role();       // planner role first
-      if constexpr (JOINT_WAVE < 0) {
-        if constexpr ((WBC_RO_KNOCK & 2) != 0) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        else joint_rows_role();   // idle until M, Jc exist: this wavefront takes the joint rows
-      }
-      if constexpr ((WBC_RO_KNOCK & 1) != 0) { barrier_A(); __syncthreads(); continue; }
-      if constexpr (INT_WAVE < 0) { integrator_role(); continue; }
-      else { barrier_A(); __syncthreads(); continue; }
-    }
     if (wave == W_RNEA) {
       int* const rflag = &rready;
       const int rneed = t + 1;
       int* const gflag = &gready;
       // (4-state workgroups: the bias and the acceleration recursion side by side in the lanes -- RS_LANE2, device_types.hpp; -DWBC_RO_LANE2=0: one after the other)
-#ifndef WBC_RO_LANE2
-#define WBC_RO_LANE2 1
-#endif
-      constexpr int RNEA_MODE = (H_WAVE >= 0 ? RS_STEP : ((SPW == 4 && WBC_RO_LANE2) ? (RS_STEP | RS_H | RS_LANE2) : (RS_STEP | RS_H))) | (NOJC ? RS_NOJC : 0) | ((MERGE && TRACK) ? RS_REFIMG : 0);
+      constexpr int RNEA_MODE = (SPW == 4 ? (RS_STEP | RS_H | RS_LANE2) : (RS_STEP | RS_H)) | (NOJC ? RS_NOJC : 0) | ((TRACK) ? RS_REFIMG : 0);
       auto wait_refs = [rflag, rneed] __device__() {
         if constexpr (TRACK) {
           while (__hip_atomic_load(rflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rneed) __builtin_amdgcn_s_sleep(1);
@@ -486,14 +354,11 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
-      // (MERGE, 16-state workgroups) tau_partial is handed to the QP BEFORE the base rows of h are summed, rotated and written: only phase 2 of the integrator,
+      // (16-state workgroups) tau_partial is handed to the QP BEFORE the base rows of h are summed, rotated and written: only phase 2 of the integrator,
       // behind the torque map, needs those -- it waits for `hready`.  Measured (profiles/r05zz_ab_rollout_taup_first.log): 2 048 rollouts 12.33 -> 12.11 us
       // per tick; the 4-state workgroups LOSE with it (8.84 -> 8.96, planner in the loop 11.39 -> 11.51) and keep the one flag behind the whole body
       // (-DWBC_RO_TAUP_FIRST=2: both; 0: neither)
-#ifndef WBC_RO_TAUP_FIRST
-#define WBC_RO_TAUP_FIRST 1
-#endif
-      constexpr bool TAUP_FIRST = MERGE && (WBC_RO_TAUP_FIRST == 2 || (WBC_RO_TAUP_FIRST == 1 && SPW == 16));
+      constexpr bool TAUP_FIRST = ((SPW == 16));
       if constexpr (TAUP_FIRST) {
         int* const finflag = &ready;
         auto taup_out = [finflag] __device__() {
@@ -521,15 +386,14 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
         RSTAMP(1);   // (WBC_RO_STAMP_ALT) mass_jac: image published
         // phase 1 of the integrator, on my own image (my own LDS words: program order of one lane); the factors are complete when this wavefront
         // reaches the tick barrier, behind which the integrator wavefront reads them
-        if constexpr (SPLIT_INT) integrate_body<T, SPW, IntegrateNoWait, 1, (WBC_RO_INT_UNGUARD != 0), true, false, IntegrateNoWait, MERGE>(model, ia1, IntegrateNoWait(), handp, nullptr, factp);
-        if constexpr (MERGE) {   // the factors are in LDS: wavefront 0 may start phase 2
+        integrate_body<T, SPW, IntegrateNoWait, 1, true, true, false, IntegrateNoWait, true>(model, ia1, IntegrateNoWait(), handp, nullptr, factp);
+           // the factors are in LDS: wavefront 0 may start phase 2
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
           if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(fflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        
       };
       // (the M / Jc / pf stores to HBM come BEHIND the flag, from the image, and only in the launch's last tick: nothing in this kernel reads them)
-      if constexpr ((WBC_RO_KNOCK & 4) != 0) publish();
-      else mass_jac_body<T, 64, REXT, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
+      mass_jac_body<T, 64, REXT, SPW, true, decltype(publish)>(model, at, cst, zidx_s, mj_hand, publish);
     } else if (OBSERVER && wave == W_OBS) {
       if constexpr (OBSERVER) {
         int* const ack = &rpack;
@@ -548,14 +412,13 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
           observer_body<T, 64, REXT, 0, SPW, decltype(wait_ack), decltype(rows_out)>(model, prm, at, cst, wsl, wait_ack, rows_out);
           RSTAMP(10);
         } else {
-        if constexpr ((WBC_RO_KNOCK & 8) != 0) {}
-        else if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, REXT, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
+        if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, REXT, 1, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);   // base rows
         else observer_body<T, 64, REXT, 0, SPW, decltype(wait_ack)>(model, prm, at, cst, wsl, wait_ack);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         RSTAMP(10);
         }
-        if constexpr (MERGE && FUSED_OBS_WAVES == 2 && !OBS_ONE && !OBS_FIFTH) joint_rows_role();   // (-DWBC_RO_MERGE_OBS=2) ... then the joint rows, which the torque map needs ~3 us later
+        if constexpr (FUSED_OBS_WAVES == 2 && !OBS_ONE && !OBS_FIFTH) joint_rows_role();   // (-DWBC_RO_MERGE_OBS=2) ... then the joint rows, which the torque map needs ~3 us later
       }
     } else if (OBS_FIFTH && wave == W_JOINT) {
       joint_rows_role();
@@ -568,54 +431,39 @@ __global__ __launch_bounds__(rollout_threads(OBSERVER, SPW), 1) void rollout_ker
 #endif
       if constexpr (SPEC_ORDER) { if (qa.rprev) sy.rp_ack = &rpack; }
       sy.res = res_img;
-#ifndef WBC_RO_SKIP_OUT
-#define WBC_RO_SKIP_OUT 1   // 0: every tick stores its tau, f, status, iters (A/B)
-#endif
+// 0: every tick stores its tau, f, status, iters (A/B)
       if constexpr (NOJC) { sy.hand = mj_hand; sy.hand_flag = &mready; sy.need_hand = t + 1; }
-      sy.skip_out = MERGE && WBC_RO_SKIP_OUT && t < horizon - 1;   // (the LAST tick's are what the caller finds, as with per-tick launches)
-      if constexpr (H_WAVE >= 0) { if (wave == H_WAVE) rnea_step_body<T, RS_H, 64, REXT, SPW>(model, prm, at, cst, wsl, NoWait(), NoWait(), res_img ? res_img + RES_H * 16 : nullptr); }   // bias forces h
+      sy.skip_out = 1 && t < horizon - 1;   // (the LAST tick's are what the caller finds, as with per-tick launches)
       if constexpr (PLAN_WAVE >= 0) { if (wave == PLAN_WAVE) planner_role(); }
-      if constexpr (JOINT_WAVE >= 0) { if (wave == JOINT_WAVE) joint_rows_role(); }
-      if constexpr (INT_WAVE >= 0) { if (wave == INT_WAVE) { integrator_role(); continue; } }
       if constexpr (WARM) {
         qat.aset_out = (t == horizon - 1) ? qa.aset_out : nullptr;   // the set goes out once, behind the last tick
         if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW, false, 4, QpNoIdle, false, 2>(prm, qat, jmap, wsl, &sy, QpWho{0, false}, QpNoIdle(), &aset_sh[(threadIdx.x & 255) >> 4]);
       } else
       if (wave * 4 < SPW) qp_body<T, true, OBSERVER, SPW>(prm, qat, jmap, wsl, &sy);   // (SPW = 4: QP wavefront 0 only)
-      if constexpr (MERGE && QP_WAVES > 1) {   // (16 states: four QP wavefronts fill the result image; phase 2 runs behind all of them)
+      if constexpr (QP_WAVES > 1) {   // (16 states: four QP wavefronts fill the result image; phase 2 runs behind all of them)
         if (wave * 4 < SPW) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
           if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&qdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      if constexpr (MERGE) {
-        if (wave == 0) {   // phase 2 of the integrator, on the wavefront that has just written tau and f to the LDS image (its own LDS traffic: program order)
+              if (wave == 0) {   // phase 2 of the integrator, on the wavefront that has just written tau and f to the LDS image (its own LDS traffic: program order)
           if constexpr (QP_WAVES > 1) { while (__hip_atomic_load(&qdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < QP_WAVES * (t + 1)) __builtin_amdgcn_s_sleep(1); }
           while (__hip_atomic_load(&fready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);   // M's blocks and the factors
-          if constexpr (MERGE && (WBC_RO_TAUP_FIRST == 2 || (WBC_RO_TAUP_FIRST == 1 && SPW == 16))) { while (__hip_atomic_load(&hready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1); }   // h
+          if constexpr (((SPW == 16))) { while (__hip_atomic_load(&hready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1); }   // h
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
           iat.tau_traj = traj0 ? traj0 + (size_t)t * 12 * (size_t)n_tick : nullptr;
 #ifdef WBC_FUSED_STAMP
           iat.istamp = rstamp; iat.istampN = rstampN;
           RSTAMP(7);   // phase 2 starts (the factors are there)
 #endif
-#ifndef WBC_RO_EARLY_BARRIER
-#define WBC_RO_EARLY_BARRIER 0   // 1: the tick's barrier in FRONT of this wavefront's stores (integrate.hip.hpp, after_state: measured, not kept)
-#endif
-          if constexpr (WBC_RO_EARLY_BARRIER != 0) {
-            auto state_out = [] __device__() { __syncthreads(); };   // <- the tick's barrier, for this wavefront
-            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true, decltype(state_out), true>(model, iat, IntegrateNoWait(), mj_hand, res_img,
-                                                                                                                  fact_sh, state_out);
+// 1: the tick's barrier in FRONT of this wavefront's stores (integrate.hip.hpp, after_state: measured, not kept)
+                      integrate_body<T, SPW, IntegrateNoWait, 2, true, true, true, IntegrateNoWait, true>(model, iat, IntegrateNoWait(), mj_hand, res_img, fact_sh);
             RSTAMP(8);
-            continue;
-          } else {
-            integrate_body<T, SPW, IntegrateNoWait, 2, (WBC_RO_INT_UNGUARD != 0), true, true, IntegrateNoWait, true>(model, iat, IntegrateNoWait(), mj_hand, res_img, fact_sh);
-            RSTAMP(8);
-          }
+          
         }
-      }
+      
     }
-    if constexpr (MERGE) { __syncthreads(); continue; }   // the tick's only barrier: the new state (LDS image), tau, f (memory: the next tick's observer reads them)
+    __syncthreads(); continue;   // the tick's only barrier: the new state (LDS image), tau, f (memory: the next tick's observer reads them)
     barrier_A();       // barrier A: tau, f (waves 0..3), h (wave 4) are visible to the integrator (round 5: in LDS)
     __syncthreads();   // barrier B: q, v of the next tick -- and this tick's tau, f, h in memory (the next tick's observer role reads tau, f as tau_prev, f_prev)
   }

@@ -37,9 +37,8 @@ constexpr int INT_FACT_WORDS = 27;
 // which nothing else runs (knock-out analysis: profiles/r05h_ro_knock.log).  Not for the stand-alone kernel: there a dead lane may sit in another wavefront.
 // WBC_INT_SINV: 1 = phase 1 (which runs beside the QP: hidden) ends with the explicit inverse of the base Schur complement, and phase 2 multiplies by it --
 // 36 independent multiply-adds instead of two triangular solves of 54 dependent operations at 13 cycles each for a lone wavefront; 0 (default) = the solves.
-#ifndef WBC_INT_SINV
-#define WBC_INT_SINV 0   // measured (profiles/r05i_ab_rollout_phase2_*.log): 12.05 -> 12.22 us per tick in fp64, and the fp32 inverse loses the accuracy the
-#endif                 // fp32 rollout tests ask for (NaN on stiff states): not kept
+// measured (profiles/r05i_ab_rollout_phase2_*.log): 12.05 -> 12.22 us per tick in fp64, and the fp32 inverse loses the accuracy the
+// fp32 rollout tests ask for (NaN on stiff states): not kept
 // HAND / RESI: `hand` / `res` are given (template parameters, not null tests: a pointer that may be an LDS image or null turns every load behind it into a
 // flat_load -- 39 of them in the round-4 rollout kernels, 30 in phase 2 -- where the image wants a ds_read).
 // `after_state()` (4-state rollout workgroups): called when the new state is complete in the LDS image and before anything goes to memory -- the kernel
@@ -174,31 +173,6 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
     }
   }
 
-#if WBC_INT_SINV
-  {   // S^-1 = L^-T L^-1 into the lower triangle of L (L[i][i] holds 1 / L_ii on entry): first Li = L^-1 (lower), then the products
-    T Li[6][6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      Li[j][j] = L[j][j];
-#pragma unroll
-      for (int i = j + 1; i < 6; ++i) {
-        T acc = (T)0;
-#pragma unroll
-        for (int k = j; k < i; ++k) acc -= L[i][k] * Li[k][j];
-        Li[i][j] = acc * L[i][i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j <= i; ++j) {
-        T acc = (T)0;
-#pragma unroll
-        for (int k = i; k < 6; ++k) acc += Li[k][i] * Li[k][j];
-        L[i][j] = acc;   // (S^-1)_ij, i >= j
-      }
-  }
-#endif
   if constexpr (PHASE == 1) {   // hand the factors to the integrator wavefront (which reads them behind the tick barrier) and return
     fl_[0 * 64] = A[0][0]; fl_[1 * 64] = A[0][1]; fl_[2 * 64] = A[0][2]; fl_[3 * 64] = A[1][1]; fl_[4 * 64] = A[1][2]; fl_[5 * 64] = A[2][2];
 #pragma unroll
@@ -231,18 +205,12 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   // (profiles/r05n_ab_rollout_phase2.log): fp32 10.08 -> 9.82 us per tick with all three; fp64 11.57 -> 11.75 / 11.68 / 11.88 as they are added -- the fp64
   // rollout kernel sits at its 256 registers and each of them moves spill code INTO this phase (ISA: 11 scratch loads behind the barrier), so fp64 keeps
   // the forms of rounds 1-4.
-#ifndef WBC_INT_ARL           // W rl = Mb (A rl) instead of forming W = Mb A again behind the barrier
-#define WBC_INT_ARL 1
-#endif
-#ifndef WBC_INT_QUAT_SERIES   // the quaternion increment from its power series (below)
-#define WBC_INT_QUAT_SERIES 1
-#endif
-#ifndef WBC_INT_QNORM_EARLY   // the state's unit quaternion (a square root and a division) in front of the barrier
-#define WBC_INT_QNORM_EARLY 1
-#endif
-  constexpr bool ARL = WBC_INT_ARL == 2 || (WBC_INT_ARL == 1 && sizeof(T) == 4);
-  constexpr bool QUAT_SERIES = WBC_INT_QUAT_SERIES == 2 || (WBC_INT_QUAT_SERIES == 1 && sizeof(T) == 4);
-  constexpr bool QNORM_EARLY = WBC_INT_QNORM_EARLY == 2 || (WBC_INT_QNORM_EARLY == 1 && sizeof(T) == 4);
+// W rl = Mb (A rl) instead of forming W = Mb A again behind the barrier
+// the quaternion increment from its power series (below)
+// the state's unit quaternion (a square root and a division) in front of the barrier
+  constexpr bool ARL = (sizeof(T) == 4);
+  constexpr bool QUAT_SERIES = (sizeof(T) == 4);
+  constexpr bool QNORM_EARLY = (sizeof(T) == 4);
   T ux, uy, uz, uw;
   if constexpr (QNORM_EARLY) {
     const T n = rsqrt_sel<FASTR>(qb[3] * qb[3] + qb[4] * qb[4] + qb[5] * qb[5] + qb[6] * qb[6]);
@@ -305,15 +273,6 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
   ISTAMP(7);   // base right-hand side summed
   // ---- base accelerations: S vb = rb
   T vb[6];
-#if WBC_INT_SINV
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    T acc = (T)0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc += (k <= i ? L[i][k] : L[k][i]) * rb[k];
-    vb[i] = acc;
-  }
-#else
   {
     T y[6];
 #pragma unroll
@@ -331,7 +290,6 @@ WBC_DEV void integrate_body(const DevModel<T>* __restrict__ model, const Integra
       vb[i] = sx * L[i][i];
     }
   }
-#endif
   ISTAMP(8);   // solves done
   // ---- leg accelerations: vdl = A (rl - Mb^T vb)
   T tl[3], vdl[3];

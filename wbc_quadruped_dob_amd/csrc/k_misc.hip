@@ -5,25 +5,12 @@
 #include "integrate.hip.hpp"
 #include "com_ref.hip.hpp"
 
-#ifndef WBC_OBS_PACK2
-#define WBC_OBS_PACK2 0
-#endif
 
 namespace wbc {
 
 template <>
 hipError_t k_observer<Scalar>(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a) {
   using T = Scalar;
-#if WBC_OBS_PACK2   // (fp32, even N from WBC_PACK2_MIN_STATES on: two states per lane, as the sweep -- measured before it is made the default)
-  if constexpr (std::is_same<Scalar, float>::value) {
-    if ((a.N & 1) == 0 && L.f32_pack2 >= 0 && (L.f32_pack2 > 0 || a.N >= (size_t)WBC_PACK2_MIN_STATES)) {
-      const size_t threads = (a.N / 2) * 4;
-      if (threads >= BIG_GRID_THREADS) WBC_KLAUNCH(L, (observer_kernel<T, 256, 2>), dim3((unsigned)((threads + 255) / 256)), dim3(256), model, prm, a);
-      else WBC_KLAUNCH(L, (observer_kernel<T, 64, 2>), dim3((unsigned)((threads + 63) / 64)), dim3(64), model, prm, a);
-      return hipGetLastError();
-    }
-  }
-#endif
   if (a.N * 4 >= BIG_GRID_THREADS)
     WBC_KLAUNCH(L, (observer_kernel<T, 256>), dim3((unsigned)((a.N * 4 + 255) / 256)), dim3(256), model, prm, a);
   else

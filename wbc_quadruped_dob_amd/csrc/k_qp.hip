@@ -53,13 +53,11 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
   }
   if (list) {   // the hand-over list of the per-lane kernel: one wavefront per four listed states, grid-stride
     const dim3 grid((unsigned)((a.N + 31) / 32));
-#ifndef WBC_LIST_COLD
     if (warm) {
       if (rhat) WBC_KLAUNCH(L, (qp_list_kernel<T, true, true>), grid, dim3(64), prm, a, jmap, list);
       else WBC_KLAUNCH(L, (qp_list_kernel<T, false, true>), grid, dim3(64), prm, a, jmap, list);
       return hipGetLastError();
     }
-#endif
     if (rhat) WBC_KLAUNCH(L, (qp_list_kernel<T, true>), grid, dim3(64), prm, a, jmap, list);
     else WBC_KLAUNCH(L, (qp_list_kernel<T, false>), grid, dim3(64), prm, a, jmap, list);
     return hipGetLastError();

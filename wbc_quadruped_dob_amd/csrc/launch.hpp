@@ -15,21 +15,15 @@ namespace wbc {
 constexpr size_t BIG_GRID_THREADS = (size_t)256 * 8 * 64 * 2;
 // fp32 sweep, even N: two states per lane as packed pairs.  Below this the batch does not fill the SIMDs with one state per lane
 // either, and the shorter dependent chain per state of the unpacked form wins
-#ifndef WBC_PACK2_MIN_STATES
-#define WBC_PACK2_MIN_STATES 32768
-#endif
+constexpr long long WBC_PACK2_MIN_STATES = 32768;
 // fp32 tiles of 64 ... 128 states from this batch size on run the leaner dense fp32 body (four workgroups per CU)
-#ifndef WBC_F32_DENSE_TILE_MIN
-#define WBC_F32_DENSE_TILE_MIN 65537
-#endif
+constexpr long long WBC_F32_DENSE_TILE_MIN = 65537;
 
 // staged tiles (qp_stile_kernel, fp32 solvers): one workgroup of twelve wavefronts per CU holds ceil(N / 256) states, up to 192 (three 64-column chunks:
 // image 80 kB + twelve wavefronts' solver tables 70 kB of the CU's 160 kB of LDS) -- i.e. one round of workgroups up to 49 152 states
 constexpr int STILE_MAX_TILE = 192;
 constexpr size_t STILE_MAX_STATES = (size_t)STILE_MAX_TILE * 256;
-#ifndef WBC_STILE_MIN_F32
-#define WBC_STILE_MIN_F32 16384
-#endif
+constexpr long long WBC_STILE_MIN_F32 = 16384;
 
 // stream of the launch + (optionally) the events that receive the dispatch's own start / stop timestamps
 struct LaunchCtx {
@@ -53,12 +47,8 @@ constexpr int TILE_TICK_STATES = 128;
 inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : 128); }
 // fp64, observer off: NS = 2 ... 7 sweep wavefronts of 16 states (a CU's LDS holds seven wavefronts' parking lots), again the smallest one-round size
 inline int tile_tick_states_f64(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 7 ? 7 : ns)); }
-#ifndef WBC_TILE_TICK_MIN_F64
-#define WBC_TILE_TICK_MIN_F64 11265
-#endif
-#ifndef WBC_TILE_TICK_MIN
-#define WBC_TILE_TICK_MIN 12290
-#endif
+constexpr long long WBC_TILE_TICK_MIN_F64 = 11265;
+constexpr long long WBC_TILE_TICK_MIN = 12290;
 template <class T> hipError_t k_tile_prepare();   // raises the dynamic-LDS limit of the tile_tick kernels (once per process and device)
 template <class T> hipError_t k_qp_prepare();     // ... of the staged QP tile kernels
 template <class T> hipError_t k_tile_tick(const LaunchCtx& L, bool observer, int states, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);

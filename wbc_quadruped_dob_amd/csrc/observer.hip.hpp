@@ -570,9 +570,7 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
 #undef OCS
 }
 
-#ifndef WBC_OBS_WAVES
-#define WBC_OBS_WAVES 2
-#endif
+constexpr int WBC_OBS_WAVES = 2;
 template <class T, int BLOCK, int W = 1>
 __global__ __launch_bounds__(BLOCK, WBC_OBS_WAVES) void observer_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a) {
   __shared__ ObsLds<T, BLOCK, W> lds;
@@ -605,11 +603,7 @@ __global__ __launch_bounds__(64, 2) void sweep_obs_kernel(const DevModel<T>* __r
   const long long so_t0 = wall_clock64();
 #endif
   // -DWBC_SWEEP_OBS_PRIO=1: the sweep role (the longer chain: ~16 us alone against ~12) at a higher issue priority than the observer role it shares SIMDs with
-#ifndef WBC_SWEEP_OBS_PRIO
-#define WBC_SWEEP_OBS_PRIO 0
-#endif
   if (blockIdx.x < nsweep) {
-    if constexpr (WBC_SWEEP_OBS_PRIO != 0) __builtin_amdgcn_s_setprio(3);
     dyn_sweep_body<T, MODE, 64, W>(model, prm, a, lds.sw, blockIdx.x);
   } else observer_park_body<T, 64, W>(model, prm, a, lds.ob, blockIdx.x - nsweep);
 #ifdef WBC_SO_STAMP

@@ -22,9 +22,6 @@
 
 namespace wbc {
 
-#ifndef WBC_DEV
-#define WBC_DEV __device__ __forceinline__
-#endif
 template <class T> struct Lim;
 template <> struct Lim<double> { static constexpr double eps = 2.220446049250313e-16; static constexpr double inf = __builtin_huge_val(); };
 template <> struct Lim<float> { static constexpr float eps = 1.1920929e-07f; static constexpr float inf = __builtin_huge_valf(); };
@@ -91,15 +88,11 @@ template <class T> WBC_DEV bool gargmin(T& v, int& id) {
 // read from a run-time lane of my own row
 template <class T> WBC_DEV T gread(T x, int lane16, int rowbase) { return __shfl(x, rowbase | lane16); }
 
-#ifndef WBC_NR_STEPS
-#define WBC_NR_STEPS 2   // Newton steps after v_rsq_f64 / v_rcp_f64 (2^-23 relative): 2 -> full double
-#endif
+// Newton steps after v_rsq_f64 / v_rcp_f64 (2^-23 relative): 2 -> full double
 WBC_DEV double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
   double e = fma(-x * y, y, 1.0); y = fma(0.5 * y, e, y);
-#if WBC_NR_STEPS > 1
   e = fma(-x * y, y, 1.0); y = fma(0.5 * y, e, y);
-#endif
   return y;
 }
 WBC_DEV float rsqrt_nr(float x) {
@@ -110,9 +103,7 @@ WBC_DEV float rsqrt_nr(float x) {
 WBC_DEV double rcp_nr(double x) {
   double y = __builtin_amdgcn_rcp(x);
   double e = fma(-x, y, 1.0); y = fma(y, e, y);
-#if WBC_NR_STEPS > 1
   e = fma(-x, y, 1.0); y = fma(y, e, y);
-#endif
   return y;
 }
 // one Newton step: 2^-46 relative (where the result only scales a step or a projector row)
@@ -132,17 +123,12 @@ WBC_DEV float rcp_nr(float x) {
 // ... and the 32 constraint rows (3 coefficients each) so that a candidate's normal is three broadcast reads
 template <class T> struct G16Lds { T J0[4][144]; T R[4][12 * 12]; T C[4][32 * 3]; };
 
-#ifndef WBC_QP_WAVES
-#define WBC_QP_WAVES 2
-#endif
+constexpr int WBC_QP_WAVES = 2;
 // WBC_QP_RINV = 1: the active-set factor is kept as U = R^-1 (row `me` of U per variable lane, in the LDS image that held R).
 // The dual step r = R^-1 d1 is then a matrix-vector product -- twelve broadcasts and FMAs in three independent chains --
 // instead of a back-substitution whose iq steps each wait for the one before (round 2 stamps: 610 of the ~3 200 cycles of an
 // iteration).  Appending a constraint needs nothing new: with r = R^-1 d1 at hand the new column of U is
 // [-r / delta ; 1 / delta], delta = the new diagonal entry of R.
-#ifndef WBC_QP_RINV
-#define WBC_QP_RINV 1
-#endif
 // One-wave workgroups (stand-alone kernel): every wavefront is its own workgroup, so its LDS and wave slot are released the
 // moment ITS four QPs are done and the CU backfills.  Workgroups that share a 128-byte line of the inputs are mapped to the
 // same XCD (L2).
@@ -434,11 +420,9 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   {
     T* c = Cl + 3 * (2 * l16);
     c[0] = cAx; c[1] = cAy; c[2] = cAz; c[3] = cBx; c[4] = cBy; c[5] = cBz;
-#if WBC_QP_RINV
     // the image of U starts at zero for EVERY QP: columns beyond the active set enter the dual step multiplied by a masked
     // zero, so whatever they hold must be finite -- a NaN left by an earlier state of this row slot (tiles, rollouts) must not leak
     if (isvar) sfor<0, 12>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rl[12 * k] = (T)0; });
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // (LDS hand-over inside the wavefront: no global traffic to wait for)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -450,9 +434,6 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   bool done = !live;
   bool actA = false, actB = false;
   T sip = 0, Rnorm = 1, u_me = 0;
-#if !WBC_QP_RINV
-  T rdinv = 0;
-#endif
   T u_c = 0;  // multiplier of the candidate constraint (row-uniform; it has no position until it is added)
   int Aid = -1;
 
@@ -495,14 +476,8 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     y_me = doit ? y_me * beta : (T)0;
     sfor<0, 12>([&](auto jc) __attribute__((always_inline)) { constexpr int j = decltype(jc)::value; Jr[j] -= y_me * gbc<j>(w_me); });
     sfor<0, 12>([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; Jc[i] -= gbc<i>(y_me) * w_me; });
-#if WBC_QP_RINV
     const T rdn = -sg * inr;   // 1 / (new diagonal entry of R)
     if (doit && isvar) Rl[12 * pos] = (v < pos) ? -r_in * rdn : (v == pos ? rdn : (T)0);   // column `pos` of U = R^-1, every row
-#else
-    const T newr = (v < pos) ? dd : -sg * nr;
-    if (doit && isvar && v <= pos) Rl[12 * pos] = newr;
-    if (doit && isvar && v == pos) rdinv = -sg * inr;
-#endif
     nr_out = nr;
   };
   // d = J^T np for my column, np = (n0,n1,n2) on the variables of foot fp
@@ -515,7 +490,6 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     const T j2 = m0 * Jc[2] + m1 * Jc[5] + m2 * Jc[8] + m3 * Jc[11];
     return isvar ? j0 * n0 + j1 * n1 + j2 * n2 : (T)0;
   };
-#if WBC_QP_RINV
   // r = U d1 (U = R^-1 by rows, d1 = d[0 .. q)); kmax = wave-uniform bound on q
   auto dual_step = [&](T dd, int q, int kmax) __attribute__((always_inline)) -> T {
     T Urow[12];
@@ -528,7 +502,6 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     });
     return (isvar && v < q) ? (ra[0] + ra[1]) + ra[2] : (T)0;
   };
-#endif
   // normal of constraint id: its three coefficients live in lane (id >> 1)
   auto normal_of = [&](int id, T& n0, T& n1, T& n2) __attribute__((always_inline)) {
     const T* c = Cl + 3 * (id & 31);
@@ -573,7 +546,6 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
     SEG(1);
     // r = R^-1 d1 : column-oriented back-substitution, row k of R lives in variable lane k
     T r_me = 0;
-#if WBC_QP_RINV
     {
       const int iqg = go ? iq : 0;
       int iqmax = __builtin_amdgcn_readlane(iqg, 0);
@@ -581,27 +553,6 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
         iqmax = iqmax > b1 ? iqmax : b1; iqmax = iqmax > b2 ? iqmax : b2; iqmax = iqmax > b3 ? iqmax : b3; }
       r_me = dual_step(dd, iq, iqmax);
     }
-#else
-    {
-      T acc = (isvar && v < iq) ? dd : (T)0;
-      T Rrow[12];  // my row of R, fetched up front so that no LDS latency sits inside the dependent chain
-      sfor<0, 12>([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rrow[k] = Rl[12 * k]; });
-      // wave-uniform bound: the largest active-set size among the four rows (one readlane per row, scalar max)
-      const int iqg = go ? iq : 0;
-      int iqmax = __builtin_amdgcn_readlane(iqg, 0);
-      { const int b1 = __builtin_amdgcn_readlane(iqg, 16), b2 = __builtin_amdgcn_readlane(iqg, 32), b3 = __builtin_amdgcn_readlane(iqg, 48);
-        iqmax = iqmax > b1 ? iqmax : b1; iqmax = iqmax > b2 ? iqmax : b2; iqmax = iqmax > b3 ? iqmax : b3; }
-      sfor_down<0, 12>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        if (k < iqmax) {
-          const T rk = gbc<k>(acc * rdinv);
-          const bool use = k < iq;
-          acc = (use && isvar && v < k) ? acc - Rrow[k] * rk : acc;
-          r_me = (use && isvar && v == k) ? rk : r_me;
-        }
-      });
-    }
-#endif
     SEG(2);
     // step lengths
     T t1 = INF;
@@ -675,11 +626,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
         const T dp = jt_np(((idc >> 1) & 15) >> 2, m0, m1, m2);
         const T dp2 = gsum((isvar && v >= p) ? dp * dp : (T)0);
         T nr;
-#if WBC_QP_RINV
         const T rp = dual_step(dp, rg ? p : 0, p);
-#else
-        const T rp = 0;
-#endif
         add_column(rg, p, dp, dp2, nr, rp);
         if (rg) Rnorm = (nr > Rnorm) ? nr : Rnorm;
       }
@@ -710,11 +657,7 @@ WBC_DEV void qp_group16_body(const DevParams<T>& prm, const QpArgs<T>& a, const 
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;  // own-leg Jacobian entries d pf_m / d q_(f,c3)
     int jm = 0;   // caller's index of my joint (leg f, joint c3)
-#if WBC_JIDX_ARGS   // (nibble v of the packed joint map, a kernel argument in two SGPRs: the select chain over jmap held twelve)
     jm = (int)((unsigned)(a.jpack >> (4 * (v & 15))) & 15u);
-#else
-    sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
-#endif
     if (isvar) {
       taup = WSLD(WS_TAUP + v) - (RHAT ? WSLD(WS_RHAT + 6 + v) : (T)0);
       if (from_hand) {

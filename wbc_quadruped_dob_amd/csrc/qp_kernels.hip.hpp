@@ -37,20 +37,9 @@ __global__ __launch_bounds__(64, WBC_QP_WAVES) void qp_group16_kernel(DevParams<
 // plus the finishing loads lengthen exactly that serial stretch by more than the skipped groups (set-up only, no trips) give back.
 // fp32 solvers, whose row form works in fp64, finish a state here only when every slack clears a 1e-3 N margin, so a decision fp32
 // rounding could flip is always left to the solver; the factor then uses Newton-refined reciprocal square roots.
-#ifndef WBC_PRED_UNROLL_C
-#define WBC_PRED_UNROLL_C 4
-#endif
-#ifndef WBC_PRED_UNROLL_F
-#define WBC_PRED_UNROLL_F 2   // feet per round of finishing loads (4: +38 VGPRs in fp64 -> two instead of three tiles per CU)
-#endif
-#ifndef WBC_QP_PRED_FINISH
-#define WBC_QP_PRED_FINISH 1
-#endif
+// feet per round of finishing loads (4: +38 VGPRs in fp64 -> two instead of three tiles per CU)
 // WBC_QP_TILE_PRE (default 1; fp64 tiles of <= 64 states): the predictor also leaves G^-1 (36 values) and x0 (12) of its state in LDS, and
 // the row-form body starts from them (qp_struct16_body<..., PRE>) instead of factorising G again in all 16 lanes of the state's row.
-#ifndef WBC_QP_TILE_PRE
-#define WBC_QP_TILE_PRE 1
-#endif
 constexpr int QP_PRE_WORDS = 48;
 // The predictor's arithmetic: the 6x6 factor and z = G^-1 S^(1/2) b, then the feet of `fmask` (x0 of the foot, its six slacks: count, summed
 // violation, "every slack clears the finishing threshold") and the columns of G^-1 in `cmask` (PRE only).  (The masks exist because sharing
@@ -63,7 +52,7 @@ WBC_DEV void qp_predict_part(const DevParams<T>& prm, const QpArgs<T>& a, unsign
                              PredPart<typename PredA<T, PRE>::type>& out) {
   using A = typename PredA<T, PRE>::type;
 #define PLD(ptr, comp) ((A)(*(const T*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T)))))
-  constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
+  constexpr bool FIN = (std::is_same<T, float>::value);
   const int mask = a.mask[s32] & 0xF;
   const A s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
   // (loops over the feet are NOT unrolled where they carry per-foot data: with Dx..Dz[4] and the four feet's normals in flight the
@@ -140,7 +129,7 @@ WBC_DEV void qp_predict_part(const DevParams<T>& prm, const QpArgs<T>& a, unsign
   bool fin_ok = true;   // every slack of every stance foot at or above the finishing threshold (false for a NaN state: the solver reports those)
   const A fin_thr = std::is_same<T, double>::value ? (A)-prm.qp_tol : (A)1e-3;
   A mag = 0;   // summed violation of the violated constraints
-#pragma unroll WBC_PRED_UNROLL_C
+#pragma unroll 4
   for (int f = 0; f < 4; ++f) {
     // x0 of foot f = on (s_f z_f + (s_m z_m) x d_f)
     if (!((fmask >> f) & 1)) continue;      // (wavefront-uniform)
@@ -194,7 +183,7 @@ WBC_DEV void qp_predict_finish(const DevParams<T>& prm, const QpArgs<T>& a, cons
   const A zf0 = pp.zf0, zf1 = pp.zf1, zf2 = pp.zf2, zm0 = pp.zm0, zm1 = pp.zm1, zm2 = pp.zm2;
   {
 #define PST(ptr, comp, val) (*(T*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (T)(val))
-#pragma unroll WBC_PRED_UNROLL_F
+#pragma unroll 2
     for (int f = 0; f < 4; ++f) {
       const bool on = (mask >> f) & 1;
       A dx, dy, dz;
@@ -230,7 +219,7 @@ WBC_DEV int qp_predict_keyval(int cnt_all, float mag) {
 // the whole predictor by one lane (tiles of more than 64 states): key 0 ... 61, or -1 = finished here
 template <class T, bool RHAT, bool PRE = false>
 WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, unsigned s32, unsigned N32, double* pre = nullptr, long long* st_part = nullptr) {
-  constexpr bool FIN = WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && std::is_same<T, float>::value);
+  constexpr bool FIN = (std::is_same<T, float>::value);
   PredPart<typename PredA<T, PRE>::type> pp;
   qp_predict_part<T, RHAT, PRE>(prm, a, s32, N32, pre, 0xF, 0x3F, pp);
 #ifdef WBC_TILE_STAMP
@@ -240,9 +229,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   return qp_predict_keyval(pp.cnt, (float)pp.mag);
 }
 
-#ifndef WBC_QP_TILE_WAVES
-#define WBC_QP_TILE_WAVES 2
-#endif
+constexpr int WBC_QP_TILE_WAVES = 2;
 
 // DENSE (fp32 only): the orthogonal-factor body in fp32 arithmetic instead of the structured body in fp64 arithmetic.  At 117 VGPRs
 // four workgroups share a CU where the structured body's 183 allow two: from ~49 152 fp32 states on (more than two tiles of 64 per
@@ -250,7 +237,7 @@ WBC_DEV int qp_predict_key(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
 template <class T, bool RHAT, int TILE, bool DENSE = false>
 __global__ __launch_bounds__(256, (DENSE ? 4 : WBC_QP_TILE_WAVES)) void qp_tile_kernel(DevParams<T> prm, QpArgs<T> a, QpJidx jmap) {
   static_assert(TILE % 4 == 0 && TILE <= 1024, "tile of whole four-state groups");
-  constexpr bool PRE = WBC_QP_TILE_PRE != 0 && (WBC_QP_TILE_PRE > 1 || std::is_same<T, double>::value) && !DENSE && TILE <= 64 && (WBC_QP_STRUCT > 1 || (WBC_QP_STRUCT == 1 && std::is_same<T, double>::value));
+  constexpr bool PRE = (std::is_same<T, double>::value) && !DENSE && TILE <= 64 && (true || (false && std::is_same<T, double>::value));
   __shared__ double pre[PRE ? TILE * QP_PRE_WORDS : 1];
   __shared__ unsigned short order[TILE];
   __shared__ int hist[64];
@@ -365,7 +352,7 @@ constexpr size_t stile_lds_bytes(int tile, size_t scalar, int nw) {
 // run it: the stand-alone kernel below, and the second half of tile_tick_kernel (tile_tick.hip.hpp).  blk = the tile's index.
 // FIN: the predictor finishes the states whose unconstrained minimum violates nothing (default: WBC_QP_PRED_FINISH's rule -- fp32 solvers; the fp64 tile tick
 // turns it on too: here the predictor is spread over all wavefronts and one foot per thread, not the serial stretch of one wavefront it was in qp_tile_kernel)
-constexpr bool stile_fin_default(bool is_float) { return WBC_QP_PRED_FINISH > 1 || (WBC_QP_PRED_FINISH == 1 && is_float); }
+constexpr bool stile_fin_default(bool is_float) { return (is_float); }
 template <class T, bool RHAT, int NW, int CH, bool FIN = stile_fin_default(std::is_same<T, float>::value)>
 WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int tile, unsigned blk, unsigned char* smem, unsigned wave_in) {
   using A = T;   // (the caller sizes the tile: 4 tile <= 64 NW, one predictor thread per foot and state)
@@ -609,7 +596,9 @@ WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
         if (r < 12) *(T*)((char*)a.f + (size_t)((r * N32 + sidx) * (unsigned)sizeof(T))) = img[(ST_F + r) * ST + col];
         else if (r < 24) *(T*)((char*)a.tau + (size_t)(((r - 12) * N32 + sidx) * (unsigned)sizeof(T))) = img[(ST_TAU + r - 12) * ST + col];
         else if (r == 24) a.status[sidx] = iimg[tile + col];
-#ifndef WBC_TILE_STAMP
+#ifdef WBC_TILE_STAMP   // (the stamp build returns its stamps through `iters`)
+        else if (r == 25) {}
+#else
         else if (r == 25) { if (a.iters) a.iters[sidx] = iimg[2 * tile + col]; }
 #endif
         else if (r == 26) { if (a.aset_out) a.aset_out[sidx] = iimg[3 * tile + col]; }

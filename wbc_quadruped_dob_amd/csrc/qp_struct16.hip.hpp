@@ -126,10 +126,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   // the inverse the loop maintains.  Multipliers still >= 0: an S-pair for b, the loop goes on from it (usually it has nothing left to do).  A negative
   // multiplier (a row that the last filter step releases): that row of the wavefront starts over from the empty set with b itself.  The QP is
   // strictly convex, so f, tau, status do not depend on b~ at all -- a torn or already updated read of r_prev only makes the guess better or worse.
-#ifndef WBC_QP_SPEC
-#define WBC_QP_SPEC 1
-#endif
-  constexpr bool SPEC = WBC_QP_SPEC != 0 && WSLDS && RHAT && WARM == 0 && !PRE && !TILED;
+  constexpr bool SPEC = WSLDS && RHAT && WARM == 0 && !PRE && !TILED;
   static_assert(!(WARM != 0 && PRE), "warm starts set their blocks up themselves");
   unsigned tx = threadIdx.x;
   asm volatile("" : "+v"(tx));   // lane-derived predicates stay inside this call (see WBC_LAUNDERED_TID, dyn_split.hip.hpp)
@@ -160,9 +157,6 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 #define GLD(ptr, comp) ((T)(*(const TS*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS)))))
 #define WSLD(comp) (WSLDS ? (T)wsl[(comp) * 16 + (int)(tx >> 4)] : GLD(a.ws, comp))
 #define BLD(c) (WSLDS ? (T)wsl[(WS_B + (c)) * 16 + (int)(tx >> 4)] : (a.wdes ? GLD(a.wdes, c) : GLD(a.ws, WS_B + (c))))
-#ifndef WBC_QP_CONS_EARLY
-#define WBC_QP_CONS_EARLY 1
-#endif
 #define GST(ptr, comp, val) (*(TS*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(TS))) = (TS)(val))
   const int stg_slot = (STG != 0 && live) ? who.slot : 0;
 #define IMG(comp) (((TS*)who.img)[(comp) * who.stride + stg_slot])
@@ -187,7 +181,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   // ------------------------------------------------------------------ my constraints (friction pyramid, force box): as in qp_group16_body.
   // They need the normals and mu only: the kernels that wait for the lever arms (WSLDS: one-launch tick, rollouts) form them in front of that wait
   // (13.3 -> 13.2 us at 4 096 states; -DWBC_QP_CONS_EARLY=0: behind the factor, as the stand-alone kernels keep it -- there the early form costs 0.8 %)
-  constexpr bool CONS_EARLY = WBC_QP_CONS_EARLY != 0 && WSLDS && WARM == 0;   // (the warm observer-on tick sits at 255 registers: the rows held across the wait spill there)
+  constexpr bool CONS_EARLY = WSLDS && WARM == 0;   // (the warm observer-on tick sits at 255 registers: the rows held across the wait spill there)
   T cAx, cAy, cAz, rA, cBx = 0, cBy = 0, cBz = 0;
   const bool hasB = c3 < 2;
 #define WBC_QP_FORM_ROWS do { \
@@ -780,11 +774,7 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
   if (live) {
     T taup = 0, jl0 = 0, jl1 = 0, jl2 = 0;
     int jm = 0;
-#if WBC_JIDX_ARGS   // (nibble v of the packed joint map, a kernel argument in two SGPRs: the select chain over jmap held twelve)
     jm = (int)((unsigned)(a.jpack >> (4 * (v & 15))) & 15u);
-#else
-    sfor<0, 12>([&](auto cc) __attribute__((always_inline)) { constexpr int c = decltype(cc)::value; jm = (v == c) ? jmap.j[c] : jm; });
-#endif
     if constexpr (STG != 0) {
       if (isvar) { taup = (T)IMG(ST_TAUP + v); jl0 = (T)IMG(ST_JCL + 9 * f + 0 + c3); jl1 = (T)IMG(ST_JCL + 9 * f + 3 + c3); jl2 = (T)IMG(ST_JCL + 9 * f + 6 + c3); }
     } else if (isvar) {
@@ -846,14 +836,11 @@ WBC_DEV void qp_struct16_body(const DevParams<TS>& prm, const QpArgs<TS>& a, con
 
 // the QP body of a scalar type.  WBC_QP_STRUCT = 2 (default): the structured form for both scalar types (fp32 solvers: fp32 arrays,
 // fp64 arithmetic); 1: structured for fp64, the orthogonal-factor form (qp_group16.hip.hpp) for fp32; 0: always the latter
-#ifndef WBC_QP_STRUCT
-#define WBC_QP_STRUCT 2
-#endif
 template <class T, bool WSLDS, bool RHAT = false, int SPW = 16, bool TILED = false, int WPB = (WSLDS || TILED) ? 4 : 1, class Idle = QpNoIdle, bool PRE = false, int WARM = 0, int STG = 0>
 WBC_DEV void qp_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, const T* wsl, const QpSync* sync = nullptr,
                      const QpWho who = QpWho{0, false}, Idle idle = Idle(), int* carry = nullptr) {
-  static_assert(STG == 0 || WBC_QP_STRUCT > 1, "staged tiles run the structured body");
-  if constexpr (WARM != 0 || (WBC_QP_STRUCT != 0 && (WBC_QP_STRUCT > 1 || std::is_same<T, double>::value)))
+  static_assert(STG == 0 || true, "staged tiles run the structured body");
+  if constexpr (WARM != 0 || ((true || std::is_same<T, double>::value)))
     qp_struct16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle, PRE, WARM, STG>(prm, a, jmap, wsl, sync, who, idle, carry);
   else qp_group16_body<T, WSLDS, RHAT, SPW, TILED, WPB, Idle>(prm, a, jmap, wsl, sync, who, idle);
 }

@@ -60,30 +60,14 @@ constexpr int ONE_SCRATCH = 200;        // first scalar of the helpers' scratch 
 constexpr int ONE_SCALARS = 288;        // scalars in front of the image's ints (the tick uses the first 161)
 
 // thresholds between kernel variants after the options are applied (resolve_options)
-#ifndef WBC_OBS_SPLIT_MIN_NOMATS_F64
-#define WBC_OBS_SPLIT_MIN_NOMATS_F64 16384
-#endif
-#ifndef WBC_OBS_SPLIT_MIN_NOMATS_F32
-#define WBC_OBS_SPLIT_MIN_NOMATS_F32 32768
-#endif
-#ifndef WBC_WARM_LANE_MIN_F64
-#define WBC_WARM_LANE_MIN_F64 53248
-#endif
-#ifndef WBC_WARM_LANE_MIN_F32
-#define WBC_WARM_LANE_MIN_F32 36864
-#endif
-#ifndef WBC_COLAUNCH_MIN_F32
-#define WBC_COLAUNCH_MIN_F32 12289
-#endif
-#ifndef WBC_COLAUNCH_MAX_F32
-#define WBC_COLAUNCH_MAX_F32 32768
-#endif
-#ifndef WBC_COLAUNCH_MIN_F64
-#define WBC_COLAUNCH_MIN_F64 12289
-#endif
-#ifndef WBC_COLAUNCH_MAX_F64
-#define WBC_COLAUNCH_MAX_F64 14336
-#endif
+constexpr long long WBC_OBS_SPLIT_MIN_NOMATS_F64 = 16384;
+constexpr long long WBC_OBS_SPLIT_MIN_NOMATS_F32 = 32768;
+constexpr long long WBC_WARM_LANE_MIN_F64 = 53248;
+constexpr long long WBC_WARM_LANE_MIN_F32 = 36864;
+constexpr long long WBC_COLAUNCH_MIN_F32 = 12289;
+constexpr long long WBC_COLAUNCH_MAX_F32 = 32768;
+constexpr long long WBC_COLAUNCH_MIN_F64 = 12289;
+constexpr long long WBC_COLAUNCH_MAX_F64 = 14336;
 struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max; };
 
 struct wbc_solver {
