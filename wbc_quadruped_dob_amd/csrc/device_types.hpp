@@ -2,19 +2,8 @@
 #pragma once
 #include <cstddef>
 
-// Stores of pure outputs by lanes beyond the batch: those lanes recompute the last state, so what they would store is a
-// bit-identical duplicate at the same address -- no guard, and so no exec region per store (-DWBC_GUARD_STORES=1: the round-2 form).
-#ifndef WBC_GUARD_STORES
-#define WBC_GUARD_STORES 0
-#endif
-#if WBC_GUARD_STORES
-#define WBC_OUT_GUARD if (live)
-#else
-#define WBC_OUT_GUARD
-#endif
-
-// 1 (round 5): joint indices come from the packed kernel argument jpack, 0: from DevModel::jidx loads / the QpJidx select chain (rounds 1-4);
-// see jidx_of_leg (dyn_sweep.hip.hpp)
+// (Stores of pure outputs by lanes beyond the batch carry no guard: those lanes recompute the last state, so what they store is a bit-identical duplicate at
+//  the same address -- no exec region per store.  Joint indices come from the packed kernel argument jpack: jidx_of_leg, dyn_sweep.hip.hpp.)
 
 #define WBC_DEV __device__ __forceinline__
 

@@ -339,12 +339,12 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   //   LDU/STU: component index is wave-uniform;  LDV/STV: component index differs per lane.
 #define LDU(ptr, comp) (*(const V*)((const char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))))
 #define LDV(ptr, comp) (*(const V*)((const char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))))
-#define STU(ptr, comp, val) do { WBC_OUT_GUARD *(V*)((char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))) = (val); } while (0)
-#define STV(ptr, comp, val) do { WBC_OUT_GUARD *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STU(ptr, comp, val) do { *(V*)((char*)((ptr) + (size_t)(comp) * N) + (size_t)(s32 * (unsigned)sizeof(T))) = (val); } while (0)
+#define STV(ptr, comp, val) do { *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)
 #define STVG(ptr, comp, val) do { if (live) *(V*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s32) * (unsigned)sizeof(T))) = (val); } while (0)   /* in/out state (observer): dead lanes of OTHER wavefronts would race with the live one */
   // leg-strided component: comp = c0 + stride*leg (+ per-lane extra element offset xN = x*N)
-#define STL(ptr, c0, stride, val) do { WBC_OUT_GUARD *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
-#define STLX(ptr, c0, stride, xN, val) do { WBC_OUT_GUARD *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STL(ptr, c0, stride, val) do { *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + s32) * (unsigned)sizeof(T))) = (val); } while (0)
+#define STLX(ptr, c0, stride, xN, val) do { *(V*)((char*)((ptr) + (size_t)(c0) * N) + (size_t)(((unsigned)(stride) * legN + (xN) + s32) * (unsigned)sizeof(T))) = (val); } while (0)
   // four base-replicated values, one per lane of the quad
 #define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
 #define ST4G(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STVG(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
@@ -433,7 +433,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
       struct alignas(2 * sizeof(V)) T2 { V a, b; };
       const unsigned odd = (s32 / W) & 1u, s2 = s32 & ~(unsigned)(2 * W - 1);
       // (N is a multiple of 2 W here: the states of a lane pair are in range together, so the pair store needs no guard of its own)
-#define ST2C(ptr, comp, val) do { WBC_OUT_GUARD *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
+#define ST2C(ptr, comp, val) do { *(T2*)((char*)(ptr) + (size_t)(((unsigned)(comp) * N32 + s2) * (unsigned)sizeof(T))) = T2{(val), (val)}; } while (0)
       for (int e = 2 * leg + (int)odd; e < 64; e += 8) {
         const int zi = zidx_s[e];
         if (zi >= 0) ST2C(a.M, zi, Z);
