@@ -29,6 +29,8 @@ for f in issue_probe tile_sweep midrange midrange_f64 midrange_f32 warm_loop war
 [ -f "$O/stats_n32768_kernel_stats.csv" ] && cp "$O/stats_n32768_kernel_stats.csv" "$P/${T}_kernel_stats_cfg2_n32768.csv"
 [ -f "$O/stats_cfg4_n32768_kernel_stats.csv" ] && cp "$O/stats_cfg4_n32768_kernel_stats.csv" "$P/${T}_kernel_stats_cfg4_f32_n32768.csv"
 [ -f "$O/fused_timeline.txt" ] && cp "$O/fused_timeline.txt" "$P/${T}_fused_timeline.txt"
+[ -f "$O/tile_timeline.txt" ] && cp "$O/tile_timeline.txt" "$P/${T}_tile_timeline.txt"
+[ -f "$O/stats_cfg4_n32768_two_launch_kernel_stats.csv" ] && cp "$O/stats_cfg4_n32768_two_launch_kernel_stats.csv" "$P/${T}_kernel_stats_cfg4_f32_n32768_two_launch.csv"
 [ -f "$O/rollout_timeline.txt" ] && cp "$O/rollout_timeline.txt" "$P/${T}_rollout_timeline.txt"
 for f in bench_single_process_8shards_b4096 bench_single_process_8shards_b512; do [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"; done
 for f in ab_colaunch_f32 ab_colaunch_f64; do [ -f "$O/$f.log" ] && cp "$O/$f.log" "$P/${T}_$f.log"; done

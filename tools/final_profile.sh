@@ -65,6 +65,11 @@ bash tools/n_sweep.sh 2>/dev/null > "$O/n_sweep.csv"
 if [ -f wbc_quadruped_dob_amd/lib_fstamp/libwbc_hip.so ]; then
   WBC_LIB=$R/wbc_quadruped_dob_amd/lib_fstamp/libwbc_hip.so python tools/fused_stamp.py > "$O/fused_timeline.txt" 2>> "$O/bench.err"
 fi
+# timeline of the staged QP tiles as their own launch (WBC_TILE_TICK=-1; make ... LIBDIR=../lib_tstamp EXTRA=-DWBC_TILE_STAMP): first ticks and the bench's steady state
+if [ -f wbc_quadruped_dob_amd/lib_tstamp/libwbc_hip.so ]; then
+  WBC_TILE_TICK=-1 WBC_LIB=$R/wbc_quadruped_dob_amd/lib_tstamp/libwbc_hip.so python tools/tile_stamp.py 32768 f32 4 128 12 5 > "$O/tile_timeline.txt" 2>> "$O/bench.err"
+  WBC_TILE_TICK=-1 WBC_LIB=$R/wbc_quadruped_dob_amd/lib_tstamp/libwbc_hip.so python tools/tile_stamp.py 32768 f32 4 128 12 2000 >> "$O/tile_timeline.txt" 2>> "$O/bench.err"
+fi
 if [ -f wbc_quadruped_dob_amd/lib_qstamp/libwbc_hip.so ]; then
   WBC_LIB=$R/wbc_quadruped_dob_amd/lib_qstamp/libwbc_hip.so python tools/qp_stamp.py > "$O/qp_segments.txt" 2>> "$O/bench.err"
 fi
@@ -79,6 +84,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg4_n2621
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_dyn_f32 -- python3 "$R/tools/dyn_only.py" 262144 f32 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_dyn_f32_n32768 -- python3 "$R/tools/dyn_only.py" 32768 f32 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg4_n32768 -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch 32768 --config 4 > "$O/bench_under_rocprof_cfg4_n32768.json" 2>> "$O/rocprof.err"
+WBC_TILE_TICK=-1 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg4_n32768_two_launch -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch 32768 --config 4 > "$O/bench_under_rocprof_cfg4_n32768_two_launch.json" 2>> "$O/rocprof.err"
 # the default bench command itself (incl. its N = 262 144 characterisation legs: tick sweep and the dynamics stage alone)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_default -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency > "$O/bench_under_rocprof_default.json" 2>> "$O/rocprof.err"
 find "$O" -name "*kernel_trace.csv" -delete
