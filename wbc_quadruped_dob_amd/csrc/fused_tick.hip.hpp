@@ -79,8 +79,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   __shared__ int rpack;                   // QP wavefronts that have read r_prev (speculative start): the observer role stores r behind all four
   constexpr bool SPEC_ORDER = OBSERVER && !WARM;
   const int wave = (int)(threadIdx.x >> 6);
-  // -DWBC_FUSED_PRIO=1: QP wavefronts at a higher issue priority than the producers they share a SIMD with (the kernel lasts as long as its slowest QP);
-  // 2: the rnea role (whose lever arms and tau_partial the QPs wait for) high instead
+  // (issue priorities for the QP wavefronts / the rnea role / everybody above the mass_jac role: 13.2 -> 13.4 ... 13.5 us, DESIGN_R05.md section 9)
 #ifdef WBC_FUSED_STAMP   // diagnostic build: the pf output carries the role timestamps (slot, workgroup) instead of foot positions
   double* const stamp = (double*)a.pf;
   const unsigned stampN = (unsigned)a.N;
@@ -100,20 +99,11 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       FSTAMP(7);
     };
-    // -DWBC_FUSED_TAUP_FIRST=1 (A/B): with h wanted from this role, tau_partial is handed to the QP wavefronts before the base rows of h are summed, rotated and stored
-    if constexpr (false && (RMODE & RS_H) != 0) {
-      int* const finflag = &ready;
-      rnea_step_body<T, RMODE, 64, 2>(model, prm, a, cst, wsl, NoWait(), geom_out, nullptr, [=] __device__() {
-        FSTAMP(8);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(finflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      });
-    } else {
+    // (tau_partial handed to the QP wavefronts before the base rows of h are summed, rotated and stored: measured neutral here, profiles/r05*_ab_*taup_first*.log)
     rnea_step_body<T, RMODE, 64, 2>(model, prm, a, cst, wsl, NoWait(), geom_out);
     FSTAMP(8);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // my LDS writes first (lgkmcnt only) ...
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ... then the flag
-    }
   } else if (wave == 5) {
     if constexpr (MATS) mass_jac_body<T, 64, 2, 16, (0)>(model, a, cst, zidx_s);   // (2: the role writes them LAST)
     else __syncthreads();
