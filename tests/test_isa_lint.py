@@ -34,6 +34,8 @@ BUDGET = [
     (r"qp_tile_kernelIfLb[01]ELi(32|36|40|44|48|52|56|60|64|72|80|88|96|104|112|120|128)ELb0E", 168), (r"qp_list_kernelI[df]Lb[01]ELb0E", 168),
     # staged tiles run twelve wavefronts per workgroup, one workgroup per CU: three wavefronts per SIMD
     (r"qp_stile_kernelIfLb[01]ELi12ELi[123]E", 168),
+    # the tile tick: sweep | observer roles and the QP stage in one workgroup, two wavefronts per SIMD
+    (r"tile_tick_kernelIfLi2ELi[234]E", 256), (r"tile_tick_kernelIdLi1ELi[2-7]E", 256),
     # (the WARM list kernel -- a few per cent of a warm-started batch at most -- carries the block set-up: two wavefronts per SIMD)
     (r"qp_general_kernelI[df]", 128),
     (r"rnea_step_kernelIdLi(2|10|34|42)ELi256", 256),

@@ -22,7 +22,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 KUNITS = [("k_sweep", ()), ("k_rnea", ()), ("k_qp", ()), ("k_qp_general", ()), ("k_misc", ()), ("k_fused", ()), ("k_rollout", ()),
-          ("k_rollout", ("-DWBC_ROLLOUT_TRACK=1",))]
+          ("k_rollout", ("-DWBC_ROLLOUT_TRACK=1",)), ("k_tile", ())]
 
 
 def compile_asm(out="/tmp/asm/wbc_lint.s", extra=()):
