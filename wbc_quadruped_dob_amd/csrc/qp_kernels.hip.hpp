@@ -363,8 +363,7 @@ WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   int* const iimg = (int*)(pmag + 4 * tile);            // [4][tile] mask | status | iters | active set
   int* const pcnt = iimg + 4 * tile;                    // [4][tile] per foot: violated rows at x0 (bit 8: some slack of the foot is below the finishing threshold)
   int* const hist = pcnt + 4 * tile;                    // [64]
-  int* const hbase = hist + 64;                         // [64] exclusive prefix of hist
-  int* const next_grp = hbase + 64;
+  int* const next_grp = hist + 64 + 64;                 // (64 spare words: stile_lds_bytes)
   unsigned short* const order = (unsigned short*)(next_grp + 4);
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_in);
@@ -451,7 +450,14 @@ WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
 #define IMGR(row) ((A)img[(row) * ST + colr])
 #define IMGW(row) img[(row) * ST + pcol]
   A x0 = 0, x1 = 0, x2 = 0;       // my foot's part of the unconstrained minimum
+  A fjl[9], ftp[3];               // my foot's Jacobian block and tau_partial rows: read in front of the verdict barrier, used behind it by the threads that finish their foot
   if (pred) {
+    if constexpr (FIN) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) fjl[k] = IMGR(ST_JCL + 9 * fo + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ftp[k] = IMGR(ST_TAUP + 3 * fo + k);
+    }
     const int mask = iimg[colr] & 0xF;
     const A s0 = prm.sS[0], s1 = prm.sS[1], s2 = prm.sS[2], s3 = prm.sS[3], s4 = prm.sS[4], s5 = prm.sS[5];
     A nc = 0, sx = 0, sy = 0, sz = 0, Pxx = 0, Pxy = 0, Pxz = 0, Pyy = 0, Pyz = 0, Pzz = 0;
@@ -538,8 +544,7 @@ WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int jm = (int)((a.jpack >> (4 * (3 * fo + k))) & 15u);
-        const A j0 = IMGR(ST_JCL + 9 * fo + k), j1 = IMGR(ST_JCL + 9 * fo + 3 + k), j2 = IMGR(ST_JCL + 9 * fo + 6 + k);
-        IMGW(ST_TAU + jm) = (T)(IMGR(ST_TAUP + 3 * fo + k) - (j0 * x0 + j1 * x1 + j2 * x2));
+        IMGW(ST_TAU + jm) = (T)(ftp[k] - (fjl[k] * x0 + fjl[3 + k] * x1 + fjl[6 + k] * x2));
       }
       if (fo == 0) { iimg[tile + pcol] = 0; iimg[2 * tile + pcol] = 0; iimg[3 * tile + pcol] = 0; }
     }
@@ -553,16 +558,16 @@ WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
   }
   TSTAMP(ts_b1);
   __syncthreads();
-  // ---- 3. counting sort: position = states in harder buckets (exclusive prefix over the histogram, one wavefront) + my arrival rank in mine
-  if (wave == 0) {
+  // ---- 3. counting sort: position = states in harder buckets + my arrival rank in mine.  Every wavefront that holds threads of foot 0 scans the 64-bin histogram
+  // itself (lane j = bin j, shuffles) and each thread fetches its bucket's exclusive prefix from the lane of that bin: no table, no barrier in between
+  if (__ballot(incol && fo == 0) != 0ull) {
     const int h = hist[lane];
     int incl = h;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); incl += (int)lane >= d ? t : 0; }
-    hbase[lane] = incl - h;
+    const int base_of_mine = __shfl(incl - h, bucket);
+    if (incol && fo == 0) order[base_of_mine + rank] = (unsigned short)pcol;
   }
-  __syncthreads();
-  if (pred && fo == 0 && incol) order[hbase[bucket] + rank] = (unsigned short)pcol;
   __syncthreads();
   TSTAMP(ts_b3);
   // ---- 4. the wavefronts pull groups of four states, hardest first
