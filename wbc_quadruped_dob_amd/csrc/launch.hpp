@@ -44,7 +44,9 @@ template <class T> hipError_t k_sweep_obs(const LaunchCtx& L, const DevModel<T>*
 // (64 | 96 | 128: NS = 2 | 3 | 4 packed sweep wavefronts + as many observer wavefronts): sweep | observer roles, then the staged QP tile of the same
 // states (tile_tick.hip.hpp).  The host picks the smallest size that makes ONE round of workgroups on the 256 CUs.
 constexpr int TILE_TICK_STATES = 128;
-inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : 128); }
+// Beyond one round (N > 32 768) 64-state workgroups again, two resident per CU: they drift apart over the rounds, so that one's QP stage (latency-bound) shares the SIMDs with
+// the other's roles (issue-bound) -- 49 152 states: 895 -> 960 M steps/s, 262 144: 1 051 -> 1 088; a tie at 65 536 (profiles/r06h_ab_tile_tick_states.log)
+inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : (N <= 128 * 256 ? 128 : 64)); }
 // fp64, observer off: NS = 2 ... 7 sweep wavefronts of 16 states (a CU's LDS holds seven wavefronts' parking lots), again the smallest one-round size
 inline int tile_tick_states_f64(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 7 ? 7 : ns)); }
 constexpr long long WBC_TILE_TICK_MIN_F64 = 11265;
