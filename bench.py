@@ -647,7 +647,8 @@ def pattern_ceiling(scalar_bytes, rows_in, rows_out, n):
         run = subprocess.run([exe, "rw", str(scalar_bytes), str(rows_in), str(rows_out), str(n)], capture_output=True, text=True, timeout=120)
         gbs, us = run.stdout.split()[:2]
         return {"gbs": float(gbs), "us": float(us), "rows_in": rows_in, "rows_out": rows_out, "states": n,
-                "source": "tools/bw_probe.bin rw %d %d %d %d (child process, after the timed region)" % (scalar_bytes, rows_in, rows_out, n)}
+                "source": "tools/bw_probe.bin rw %d %d %d %d (child process, after the timed region): the better of 64- and 256-thread workgroups moving these rows 8 bytes per lane; a "
+                          "kernel whose own store order does better than the probe's (the sweep writes its 162 structural words as 16-byte stores) can exceed it" % (scalar_bytes, rows_in, rows_out, n)}
     except Exception as e:
         return {"error": repr(e)[:200]}
 

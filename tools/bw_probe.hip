@@ -114,10 +114,11 @@ __global__ __launch_bounds__(64) void k_soa_write_x4(double* __restrict__ out, u
 // The footprint of a whole kernel of this build, reads AND writes, nothing else: leg-major lanes (lane = 16 leg + j, as every dynamics body), 8 bytes per lane
 // and row (an fp64 state, or an fp32 PAIR of states: the packed lane type), a lane reads the rows r = leg (mod 4) of `rin` input rows, then writes its share of
 // `rout` output rows; what it read is folded into what it writes.  Rows are E elements apart (E = states, or pairs of fp32 states).  One-wavefront workgroups.
-__global__ __launch_bounds__(64) void k_soa_rw(const double* __restrict__ in, double* __restrict__ out, unsigned E, int rin, int rout) {
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_soa_rw(const double* __restrict__ in, double* __restrict__ out, unsigned E, int rin, int rout) {
   const unsigned lane = threadIdx.x & 63;
   const unsigned leg = lane >> 4;
-  const unsigned s = blockIdx.x * 16 + (lane & 15);
+  const unsigned s = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 16 + (lane & 15);
   if (s >= E) return;
   double acc = 0;
 #pragma unroll 8
@@ -140,7 +141,10 @@ static int probe_rw(int scalar, int rin, int rout, unsigned N, bool quiet) {
   double *a = nullptr, *b = nullptr;
   if (hipMalloc(&a, (size_t)(rin > 0 ? rin : 1) * E * 8) != hipSuccess || hipMalloc(&b, (size_t)(rout > 0 ? rout : 1) * E * 8) != hipSuccess) return 1;
   hipMemset(a, 0, (size_t)(rin > 0 ? rin : 1) * E * 8);
-  const float t = timeit([&] { hipLaunchKernelGGL(k_soa_rw, dim3((E + 15) / 16), dim3(64), 0, 0, a, b, E, rin, rout); }, 50);
+  // the better of one-wavefront workgroups (small batches: one per CU and more) and 256-thread workgroups (large batches: what the sweep launches there)
+  const float t64 = timeit([&] { hipLaunchKernelGGL(k_soa_rw<64>, dim3((E + 15) / 16), dim3(64), 0, 0, a, b, E, rin, rout); }, 50);
+  const float t256 = timeit([&] { hipLaunchKernelGGL(k_soa_rw<256>, dim3((E + 63) / 64), dim3(256), 0, 0, a, b, E, rin, rout); }, 50);
+  const float t = t64 < t256 ? t64 : t256;
   const double bytes = (double)(rin + rout) * N * scalar;
   if (quiet) printf("%.1f %.3f\n", bytes / t / 1e6, t * 1e3);
   else printf("rw pattern %3d in + %3d out rows x %6u %s states : %.1f us  %.0f GB/s\n", rin, rout, N, scalar == 4 ? "fp32" : "fp64", t * 1e3, bytes / t / 1e6);
