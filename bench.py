@@ -431,6 +431,8 @@ def main():
             res["roofline_dyn_sweep_alone"] = sweep_alone_roofline(solver, torch, inp, n, dtype, ts)
         if args.large_batch and world == 1:
             res["roofline_large_batch"] = large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split)
+        if args.large_batch and world == 1 and not args.no_latency and args.config == 2:   # (the full default line only)
+            res["baseline_configs"] = baseline_configs_leg(W, synth, torch, np, model, args)
         lb_ = res.get("roofline_large_batch")
         if lb_ and isinstance(res.get("device"), dict) and dtype == "f64" and not obs and args.large_batch == 262144:
             # the pool's devices fall into two classes on the HBM-bound tick at identical clocks (docs/DESIGN_R04.md 6.0: sweep 182-187 us on
@@ -1248,6 +1250,51 @@ def pmc_traffic(kernel, n, dtype):
     except Exception:
         pass
     return None
+
+
+def baseline_configs_leg(W, synth, torch, np, model, args):
+    """BASELINE.json's other configs beside `value` (N = 1, full line only; `value` stays configs[1]): configs[2] (4 096 states, trot masks, observer on, fp64), the per-GPU
+    shard of configs[3] (32 768 fp32 states, tilted normals, observer on) and configs[4] (horizon-20 rollouts of 1 024 robots) -- each a short timed run of the same
+    bracketing (timed_blocks: blocks of K ticks, barrier-free at N = 1, synchronize on both sides, median block), so that the driver's one command records them too."""
+    res = {}
+    for key, cfg, n, dtype, K in (("configs[2]_n4096_f64_observer_on", 3, 4096, "f64", 100), ("configs[3]_shard_n32768_f32_observer_on", 4, 32768, "f32", 50)):
+        try:
+            td = torch.float64 if dtype == "f64" else torch.float32
+            P = synth.default_params(observer_order=1, dtype=dtype)
+            solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=torch.cuda.current_device(), max_batch=n)
+            B = synth.make_batch(cfg, n, model.total_mass, rank=0)
+            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(td).cuda()
+            inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
+            mask = torch.from_numpy(B["mask"]).cuda()
+            integ = solver.dynamics(inp["q"], inp["v"], want=("p",))["p"].clone()
+            rr = torch.zeros_like(integ)
+            tick, out = solver.prepare_step(inp["q"], inp["v"], inp["w_des"], inp["vdot_des"], inp["normals"], inp["mu"], mask, inp["tau_prev"], inp["f_prev"], integ, rr, want_mats=True)
+            for _ in range(30):
+                tick()
+            bl = timed_blocks(tick, K, None, torch, min_total_s=0.03)
+            el = float(np.median(bl))
+            pl = solver.plan_tick(n)
+            res[key] = {"value": K * n / el, "unit": "control-steps/s", "ms_per_step": el / K * 1e3, "steps_per_block": K, "blocks": len(bl), "dtype": dtype,
+                        "status_ok_frac": float((out["status"] == 0).double().mean().item()),
+                        "kernels": ("one launch: tile_tick_kernel" if pl["fused"] == 2 else "one launch: fused_tick_kernel" if pl["fused"] == 1 else "front %d -> qp %d" % (pl["front"], pl["qp"])),
+                        "plan": pl}
+            del solver, tick, out, inp, integ, rr
+            torch.cuda.empty_cache()
+        except Exception as e:   # never lose the headline to an extra leg
+            res[key] = {"error": repr(e)[:200]}
+    try:
+        r5 = rollout_setup(args, W, synth, torch, np, model, "f64", 1024, args.horizon, 0, torch.cuda.current_device(), False)
+        for _ in range(3):
+            r5["one_rollout"]()
+        bl = timed_blocks(r5["one_rollout"], 10, None, torch, min_total_s=0.03)
+        el = float(np.median(bl))
+        res["configs[4]_h%d_n1024_f64" % args.horizon] = {"value": 10 * args.horizon * 1024 / el, "unit": "control-steps/s", "ms_per_rollout": el / 10 * 1e3,
+                                                        "us_per_tick": el / 10 / args.horizon * 1e6, "rollouts_per_block": 10, "blocks": len(bl), "dtype": "f64"}
+        del r5
+        torch.cuda.empty_cache()
+    except Exception as e:
+        res["configs[4]"] = {"error": repr(e)[:200]}
+    return res
 
 
 def large_batch_roofline(W, synth, torch, np, model, args, dtype, td, obs, split):
