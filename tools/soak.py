@@ -51,23 +51,30 @@ for c in range(cases):
             B = synth.make_batch(cfg, n, gm.total_mass, rank=1000 + c)
             integ0 = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
         zz = lambda: tuple(None if t is None else t.astype(np.float32 if DT == "f32" else np.float64) for t in z())
-        for tag, opt in (("tiled", {"qp_tile": int(rng.choice(tiles)), "qp_lane": -1}), ("plain", {"qp_tile": -1, "qp_lane": -1}), ("lane", {"qp_lane": 1})):
+        variants = [("tiled", {"qp_tile": int(rng.choice(tiles)), "qp_lane": -1}), ("plain", {"qp_tile": -1, "qp_lane": -1}), ("lane", {"qp_lane": 1})]
+        # round 6: the tile tick (one launch: roles + staged QP tile per workgroup) where it exists -- fp32 with the observer on (even batches), fp64 with it off; matrix outputs
+        ttick = bool(c % 2) and ((DT == "f32" and obs > 0 and n % 2 == 0) or (DT == "f64" and obs == 0))
+        if ttick:
+            variants.append(("ttick", {"tile_tick": 1, "fused_max": 0}))
+        for tag, opt in variants:
             s, P = solver_with(opt, obs=obs, max_batch=n, dtype=DT)
+            if tag == "ttick" and s.plan_tick(n, want_mats=True)["fused"] != 2:
+                bad.append((c, "tile tick not planned", n, obs, cfg))
             a1 = _run_step(torch, s, B, DT, *zz(), want_mats=bool(c % 2))
             a2 = _run_step(torch, s, B, DT, a1.get("integ"), a1.get("r"), want_mats=bool(c % 2))
             res[tag] = (a1, a2)
-        for i in (0, 1):     # same solver body, started from the predictor's numbers: status equal, iteration counts equal up to near-ties, values to rounding
-            a, b = res["tiled"][i], res["plain"][i]
+        for vtag, i in [(t_, i_) for t_ in (("tiled", "ttick") if ttick else ("tiled",)) for i_ in (0, 1)]:     # same solver body, started from the predictor's numbers: status equal, iteration counts equal up to near-ties, values to rounding
+            a, b = res[vtag][i], res["plain"][i]
             same = a["status"] == b["status"]
             if not same.all():
                 if DT == "f64" or same.mean() < 0.995:
-                    bad.append((c, "tiled status", n, obs, cfg))
+                    bad.append((c, vtag + " status", n, obs, cfg))
                 flips += int((~same).sum())
             # (the standing batch is symmetric: equally violated rows on different feet are exact ties in one kernel and rounding-level
             #  near-ties in the other -- 0.1-0.15 % of its states take another, equally valid pivot sequence to the same solution; fp32 batches
             #  past 65 536 states run the tiles on the fp32-arithmetic body: 2-3 %)
             if np.mean(a["iters"] != b["iters"]) > (5e-3 if DT == "f64" else 5e-2):
-                bad.append((c, "tiled iters", n, obs, cfg, float(np.mean(a["iters"] != b["iters"]))))
+                bad.append((c, vtag + " iters", n, obs, cfg, float(np.mean(a["iters"] != b["iters"]))))
             for k in b:
                 if k in ("status", "iters"):
                     continue
@@ -75,7 +82,7 @@ for c in range(cases):
                 e = relerr(x, y)
                 worst_big = max(worst_big, e)
                 if not e < (1e-10 if DT == "f64" else TOL):
-                    bad.append((c, "tiled " + k, n, obs, cfg, e))
+                    bad.append((c, vtag + " " + k, n, obs, cfg, e))
         if DT == "f32":
             continue
         for i in (0, 1):   # per-lane semismooth Newton + hand-over list: another algorithm, same unique solution
