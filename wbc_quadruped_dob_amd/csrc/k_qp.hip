@@ -3,7 +3,6 @@
 #include "qp_kernels.hip.hpp"
 #include "qp_lane.hip.hpp"
 #include <type_traits>
-#include <cstdlib>
 
 namespace wbc {
 
@@ -64,19 +63,10 @@ hipError_t k_qp<Scalar>(const LaunchCtx& L, bool rhat, int tile, const DevParams
   }
   // tile sizes in small steps so that the host can launch ONE round of resident workgroups (wbc_api.cpp): fp64 tiles keep three workgroups on a
   // CU (768 at once) up to 64 states per tile, fp32 tiles two (512) -- hence steps of 4 from 32 to 64 for fp64, of 8 from 64 to 128 for fp32
-#ifdef WBC_STILE_ENV   // experiment builds only: staged tiles of this size / with this many wavefronts per workgroup, whatever the plan says
-  int nw_env = 0;
-  if (const char* e = getenv("WBC_STILE_TILE")) { tile = atoi(e); body = 2; }
-  if (const char* e = getenv("WBC_STILE_NW")) nw_env = atoi(e);
-#endif
   if (body == 2) {
     if constexpr (std::is_same<T, float>::value) {
       if (tile <= 0 || tile > STILE_MAX_TILE || tile % 4 != 0) return hipErrorInvalidValue;
       const int ch = (tile + 63) / 64;
-#ifdef WBC_STILE_ENV
-      if (nw_env == 4 && ch == 1) return qp_staged<4, 1>(L, rhat, tile, prm, a, jmap);
-      if (nw_env == 8 && ch <= 2) return qp_staged<8, 2>(L, rhat, tile, prm, a, jmap);
-#endif
       if (ch == 1) return qp_staged<12, 1>(L, rhat, tile, prm, a, jmap);
       if (ch == 2) return qp_staged<12, 2>(L, rhat, tile, prm, a, jmap);
       return qp_staged<12, 3>(L, rhat, tile, prm, a, jmap);

@@ -1,5 +1,5 @@
-// The stand-alone GRF-QP kernels: one-wavefront workgroups (qp_group16_kernel), tiles dealt by predicted work (qp_tile_kernel),
-// the dense solver over a device-side list (qp_list_kernel).  The per-QP body is qp_body (qp_struct16.hip.hpp): the structured
+// The stand-alone GRF-QP kernels: one-wavefront workgroups (qp_group16_kernel), tiles dealt by predicted work -- inputs gathered per state (qp_tile_kernel) or
+// staged through LDS (qp_stile_kernel / qp_stile_body, round 6: also the second half of tile_tick_kernel) --, the dense solver over a device-side list (qp_list_kernel).  The per-QP body is qp_body (qp_struct16.hip.hpp): the structured
 // wrench-space form in fp64, the orthogonal-factor form (qp_group16.hip.hpp) in fp32.
 #pragma once
 #include "qp_struct16.hip.hpp"
