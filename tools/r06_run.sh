@@ -1,9 +1,10 @@
-#!/bin/bash
 set -u
-mkdir -p gpurun_out; export TMPDIR=/tmp
-L=gpurun_out/r06_run.log; : > $L
-timeout 900 python -m pytest tests/test_gpu_round6.py -x -q -m gpu -k "two_pass" 2>&1 | grep -E "passed|failed|Error" >> $L
-for n in 4608 5120 6144 7168 8192; do tools/ab_r06.sh "--steps 300 --warmup 30 --batch $n" lib_prev lib 2>&1 | head -4 >> $L; done
-tools/ab_r06.sh "--steps 300 --warmup 30 --batch 8192 --no-mats" lib_prev lib 2>&1 | head -4 >> $L
-tools/ab_r06.sh "--steps 300 --warmup 30 --batch 6144 --dtype f32" lib_prev lib 2>&1 | head -4 >> $L
-cat $L
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r06_pytest_gpu.log 2>&1; tail -3 gpurun_out/r06_pytest_gpu.log
+{
+echo "# output rows (M, h, Jc, pf) of the sweep body stored non-temporally (lib_nt, -DWBC_NT_STORES=1) against plain stores (lib); alternating, one MI355X"
+for a in "--steps 200 --warmup 20 --batch 32768 --config 4" "--steps 40 --warmup 5 --batch 262144 --config 4" "--steps 40 --warmup 5 --batch 262144" "--steps 100 --warmup 10 --batch 32768" "--steps 100 --warmup 10 --batch 65536" "--steps 200 --warmup 20 --batch 16384"; do
+  bash tools/ab_r06.sh "$a" lib lib_nt 2>&1
+done
+} > gpurun_out/r06l_ab_nt_stores.log
+cat gpurun_out/r06l_ab_nt_stores.log | cut -c1-175

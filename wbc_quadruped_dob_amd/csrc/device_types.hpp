@@ -51,6 +51,12 @@ template <class T> struct DevParams {
 constexpr int WS_D = 0, WS_B = 12, WS_TAUP = 18, WS_JCL = 30, WS_WORDS = 66;
 // LDS image of the fused tick only: 66..83 rhat (observer estimate: base rows 6, joint rows leg-major 12)
 constexpr int WS_RHAT = 66, WS_LDS_WORDS = 84;
+// Roles of a tile tick (tile_tick.hip.hpp) share their workgroup's constant table and hand their step-workspace words to the QP stage in LDS instead of through memory.
+// cst: the workgroup's table (CST_WORDS), staged by `stage_threads` role threads (threadIdx.x below that) in front of the roles' common barrier;
+// hand: [HAND_ROWS][hs] words, row r of the tile's state c at hand[r * hs + c] (tau_partial from the sweep role, rhat from the observer role);
+// col0: the tile column of this wavefront's first state
+constexpr int HAND_TAUP = 0, HAND_RHAT = 12, HAND_ROWS = 30;
+template <class T> struct RoleShare { T* cst; T* hand; int hs; int stage_threads; int col0; };
 
 template <class T> struct SweepArgs {
   size_t N;

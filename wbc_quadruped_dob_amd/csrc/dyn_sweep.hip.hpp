@@ -282,14 +282,18 @@ constexpr int WBC_SWEEP_WAVES = 2;
 // row moved half a line per instruction and the kernel took as long as the fp64 one (round 2: 24.1 vs 24.7 us at 32 768 states).
 // The workgroup's LDS (declared by the KERNEL and handed to the body, so that a kernel that runs this body as one of two roles can overlay
 // it with the other role's: sweep_obs_kernel below).  Layout: see the comment in dyn_sweep_body.
-template <class T, int MODE, int BLOCK, int W> struct SweepLds {
+// XR (tile_tick.hip.hpp): the body is one role wavefront of a big workgroup that SHARES one constant table among its roles and takes the roles' step-workspace
+// words (tau_partial from the sweep, rhat from the observer) in LDS instead of through memory: RoleShare below; the object then holds no table of its own.
+template <class T, int MODE, int BLOCK, int W, bool XR = false> struct SweepLds {
   using V = typename LaneT<T, W>::type;
   static constexpr bool OBS = (MODE & SW_OBS) != 0;
-  T cst[CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; V park[2 * 8 + 6 + (OBS ? 2 : 0) + 9][BLOCK];
+  T cst[XR ? 4 : CST_WORDS]; T kgain[OBS ? 36 : 2]; int zidx_s[64]; V park[2 * 8 + 6 + (OBS ? 2 : 0) + 9][BLOCK];
 };
+template <bool XR, class L, class T> WBC_DEV decltype(auto) role_cst(L& lds, T* shared) { if constexpr (XR) return shared; else return (lds.cst); }
 // blk: the index of this workgroup among the workgroups that run this body (blockIdx.x in the stand-alone kernel)
-template <class T, int MODE, int BLOCK, int W = 1>
-WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, SweepLds<T, MODE, BLOCK, W>& lds, const unsigned blk) {
+template <class T, int MODE, int BLOCK, int W = 1, bool XR = false>
+WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, SweepLds<T, MODE, BLOCK, W, XR>& lds, const unsigned blk,
+                            const RoleShare<T> xr = RoleShare<T>()) {
   using V = typename LaneT<T, W>::type;   // what a lane computes with: T, or a packed pair of T
   constexpr bool MATS = (MODE & SW_MATS) != 0, STEP = (MODE & SW_STEP) != 0, OBS = (MODE & SW_OBS) != 0, FWD_B = (MODE & SW_NOB) == 0;
   // ONE LDS object with the constant table first: ds_read / ds_write reach base + 16-bit offset, and the compiler places
@@ -305,7 +309,8 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr int PE2 = OBS ? 2 : 0;         // observer: sin, cos of joint 2 too (the momentum pass walks the leg again)
   constexpr int PX = 9;                    // vdot_des base rows 6, base position 3
   static_assert(sizeof(lds.park) == sizeof(V) * (2 * PW + PB + PE2 + PX) * BLOCK, "SweepLds::park is sized for this layout");
-  T (&cst)[CST_WORDS] = lds.cst;
+  static_assert(!XR || (BLOCK == 64 && MATS && STEP && !OBS && !FWD_B), "a shared role is one observer-free sweep wavefront of a tile tick");
+  decltype(auto) cst = role_cst<XR>(lds, xr.cst);
   int (&zidx_s)[64] = lds.zidx_s;
   T (&kgain)[OBS ? 36 : 2] = lds.kgain;
   V (&park)[2 * PW + PB + PE2 + PX][BLOCK] = lds.park;
@@ -348,7 +353,9 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   // four base-replicated values, one per lane of the quad
 #define ST4(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STV(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
 #define ST4G(ptr, c0, v0_, c1, v1_, c2, v2_, c3, v3_) STVG(ptr, sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
-#define WSTV(comp, val) STV(a.ws, comp, val)   /* step workspace */
+  const int hcol = xr.col0 + (int)(tix & 15) * W;   // (XR) my first state's column of the tile
+  (void)hcol;
+#define WSTV(comp, val) do { if constexpr (XR) *(V*)(xr.hand + ((comp) - WS_TAUP + HAND_TAUP) * xr.hs + hcol) = (val); else STV(a.ws, comp, val); } while (0)   /* step workspace */
 #define WST4(c0, v0_, c1, v1_, c2, v2_, c3, v3_) WSTV(sel4<int>(leg, c0, c1, c2, c3), sel4<V>(leg, v0_, v1_, v2_, v3_))
 #define WSTL(c0, stride, val) WSTV((c0) + (stride) * leg, val)
 
@@ -399,7 +406,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
 
   SSTAMP();  // 1: state loads issued
   // the per-leg constant table is staged AFTER the state loads have been issued: one memory round trip, not two
-  for (int i = tix; i < CST_WORDS; i += BLOCK) cst[i] = model->cst[i];
+  for (int i = XR ? (int)threadIdx.x : (int)tix; i < CST_WORDS; i += XR ? xr.stage_threads : BLOCK) cst[i] = model->cst[i];
   if (MATS && tix < 64) zidx_s[tix] = model->zidx[tix];
   // observer gains of the joint rows are indexed by a run-time joint number: from LDS (a dynamic index into the
   // kernel-argument struct can end up as a private copy of the whole struct)
@@ -686,7 +693,7 @@ WBC_DEV void dyn_sweep_body(const DevModel<T>* __restrict__ model, const DevPara
   }
   // the QP's geometry (foot lever arms, own-leg Jacobian blocks: 48 of the 66 workspace words) is a subset of Jc; when
   // Jc is being written anyway the QP kernel reads it from there and these stores are skipped (-9 % store bytes)
-  if (STEP && (!MATS || a.ws_geom)) {
+  if (!XR && STEP && (!MATS || a.ws_geom)) {
     WSTL(WS_D + 0, 3, dw.x);
     WSTL(WS_D + 1, 3, dw.y);
     WSTL(WS_D + 2, 3, dw.z);

@@ -316,15 +316,17 @@ WBC_DEV void observer_body(const DevModel<T>* __restrict__ model, const DevParam
 // as one of the two roles of sweep_obs_kernel (below).
 // ======================================================================================================================
 constexpr int OBS_PKW = 11;   // parked words per joint: sin, cos, body angular / linear velocity, gravity direction
-template <class T, int BLOCK, int W> struct ObsLds {   // one LDS object, constant table first (see dyn_sweep.hip.hpp)
+template <class T, int BLOCK, int W, bool XR = false> struct ObsLds {   // one LDS object, constant table first (see dyn_sweep.hip.hpp; XR: the table is the workgroup's, SweepLds)
   using V = typename LaneT<T, W>::type;
-  T cst[CST_WORDS]; T kgain[36]; V park[3 * OBS_PKW][BLOCK];
+  T cst[XR ? 4 : CST_WORDS]; T kgain[36]; V park[3 * OBS_PKW][BLOCK];
 };
-template <class T, int BLOCK, int W = 1>
-WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, ObsLds<T, BLOCK, W>& lds, const unsigned blk) {
+template <class T, int BLOCK, int W = 1, bool XR = false>
+WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, ObsLds<T, BLOCK, W, XR>& lds, const unsigned blk,
+                                const RoleShare<T> xr = RoleShare<T>()) {
   using V = typename LaneT<T, W>::type;
   constexpr int PKW = OBS_PKW;
-  T (&cst)[CST_WORDS] = lds.cst;
+  static_assert(!XR || BLOCK == 64, "a shared role is one wavefront");
+  decltype(auto) cst = role_cst<XR>(lds, xr.cst);
   T (&kgain)[36] = lds.kgain;
   V (&park)[3 * PKW][BLOCK] = lds.park;
   unsigned tx = threadIdx.x & (unsigned)(BLOCK - 1);   // (thread within the BLOCK threads that run this body)
@@ -357,10 +359,17 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
   // branch-free staging (clamped index, the tail lanes rewrite the last word): with a divergent staging loop here hipcc 7.2 put
   // VGPR spill stores of the fp64 build into the loop's exit block BEFORE exec is restored, i.e. with no lane enabled
   // (found by parity: rhat garbage in every state; tools/spill_lint.py scans the ISA for that pattern)
+  if constexpr (XR) {
+    for (int i0 = 0; i0 < CST_WORDS; i0 += xr.stage_threads) {
+      const int i = min(i0 + (int)threadIdx.x, CST_WORDS - 1);
+      cst[i] = model->cst[i];
+    }
+  } else {
 #pragma unroll
-  for (int i0 = 0; i0 < CST_WORDS; i0 += BLOCK) {
-    const int i = min(i0 + (int)tx, CST_WORDS - 1);
-    cst[i] = model->cst[i];
+    for (int i0 = 0; i0 < CST_WORDS; i0 += BLOCK) {
+      const int i = min(i0 + (int)tx, CST_WORDS - 1);
+      cst[i] = model->cst[i];
+    }
   }
   // the gains are read from LDS: those of the joint rows are indexed by a run-time joint number, and 72 SGPRs of gains held to
   // the end of a kernel are SGPR spills
@@ -369,6 +378,9 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
     for (int i = 0; i < 18; ++i) { kgain[i] = prm.K1[i]; kgain[18 + i] = prm.K2[i]; }  // static indices only
   }
   __syncthreads();
+  const int hcol = xr.col0 + (int)(tx & 15) * W;   // (XR) my first state's column of the tile
+  (void)hcol;
+#define ORH(comp, val) do { if constexpr (XR) *(V*)(xr.hand + ((comp) - WS_RHAT + HAND_RHAT) * xr.hs + hcol) = (val); else OSTV(a.ws, comp, val); } while (0)   /* rhat for the QP stage */
 
   V qx, qy, qz, qw;
   {
@@ -521,7 +533,7 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
       }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) OSTV(a.ws, WS_RHAT + 6 + 3 * leg + k, rl[k]);
+    for (int k = 0; k < 3; ++k) ORH(WS_RHAT + 6 + 3 * leg + k, rl[k]);
   }
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -560,9 +572,10 @@ WBC_DEV void observer_park_body(const DevModel<T>* __restrict__ model, const Dev
       OST4(a.obs_r, 0, rb[0], 1, rb[1], 2, rb[2], 3, rb[3]);
       if (leg < 2) OSTV(a.obs_r, 4 + leg, leg == 0 ? rb[4] : rb[5]);
     }
-    OSTV(a.ws, sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<V>(leg, rb[0], rb[1], rb[2], rb[3]));
-    if (leg < 2) OSTV(a.ws, WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
+    ORH(sel4<int>(leg, WS_RHAT + 0, WS_RHAT + 1, WS_RHAT + 2, WS_RHAT + 3), sel4<V>(leg, rb[0], rb[1], rb[2], rb[3]));
+    if (leg < 2) ORH(WS_RHAT + 4 + leg, leg == 0 ? rb[4] : rb[5]);
   }
+#undef ORH
 #undef OST4
 #undef OSTV
 #undef OLDV

@@ -353,8 +353,10 @@ constexpr size_t stile_lds_bytes(int tile, size_t scalar, int nw) {
 // FIN: the predictor finishes the states whose unconstrained minimum violates nothing (default: WBC_QP_PRED_FINISH's rule -- fp32 solvers; the fp64 tile tick
 // turns it on too: here the predictor is spread over all wavefronts and one foot per thread, not the serial stretch of one wavefront it was in qp_tile_kernel)
 constexpr bool stile_fin_default(bool is_float) { return (is_float); }
-template <class T, bool RHAT, int NW, int CH, bool FIN = stile_fin_default(std::is_same<T, float>::value)>
-WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int tile, unsigned blk, unsigned char* smem, unsigned wave_in) {
+// HAND (tile tick): tau_partial and, with RHAT, the observer's estimate are NOT in the memory workspace: the role wavefronts of this workgroup left them in LDS
+// (`hand`: [HAND_ROWS][tile] words outside this stage's `smem`, dyn_sweep.hip.hpp)
+template <class T, bool RHAT, int NW, int CH, bool FIN = stile_fin_default(std::is_same<T, float>::value), bool HAND = false>
+WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const QpJidx& jmap, int tile, unsigned blk, unsigned char* smem, unsigned wave_in, const T* hand = nullptr) {
   using A = T;   // (the caller sizes the tile: 4 tile <= 64 NW, one predictor thread per foot and state)
   const int ST = tile | 1;   // row stride of the image: the sixteen lanes of a row read sixteen ROWS of one column -- an odd stride spreads them over the banks
   S16Lds<double>* const tabs = (S16Lds<double>*)smem;   // [NW] solver tables, one per wavefront
@@ -416,9 +418,13 @@ WBC_DEV void qp_stile_body(const DevParams<T>& prm, const QpArgs<T>& a, const Qp
           ptr = gsrc;
           comp = jc ? (3 * f + mm) * 18 + 6 + jm : (unsigned)WS_JCL + r;
         }
-        val[j] = *(const T*)((const char*)ptr + (size_t)((comp * N32 + sidx) * (unsigned)sizeof(T)));
-        if constexpr (RHAT && su < 18) sub[j] = *(const T*)((const char*)a.ws + (size_t)((((unsigned)WS_RHAT + su) * N32 + sidx) * (unsigned)sizeof(T)));
-        else sub[j] = 0;
+        const unsigned hcol = col < (unsigned)tile ? col : (unsigned)tile - 1u;
+        if constexpr (HAND && su >= 6 && su < 18) val[j] = hand[((unsigned)HAND_TAUP + su - 6) * (unsigned)tile + hcol];
+        else val[j] = *(const T*)((const char*)ptr + (size_t)((comp * N32 + sidx) * (unsigned)sizeof(T)));
+        if constexpr (RHAT && su < 18) {
+          if constexpr (HAND) sub[j] = hand[((unsigned)HAND_RHAT + su) * (unsigned)tile + hcol];
+          else sub[j] = *(const T*)((const char*)a.ws + (size_t)((((unsigned)WS_RHAT + su) * N32 + sidx) * (unsigned)sizeof(T)));
+        } else sub[j] = 0;
       });
       if constexpr (W == NW - 1) sfor<0, CH>([&](auto c_) __attribute__((always_inline)) {
         constexpr int ch = decltype(c_)::value;
