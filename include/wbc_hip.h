@@ -103,7 +103,8 @@ enum wbc_timing_mode { WBC_TIMING_DISPATCH = 0, /* the dispatch's own start/stop
 typedef struct wbc_solver_options {
   size_t struct_size;     /* sizeof(wbc_solver_options) of the caller's build (set by wbc_solver_options_default) */
   long long fused_max;    /* ticks of at most this many states run as ONE launch of wavefront roles; -1 = auto
-                             (11264, observer on 12288; rollouts: 4096 -- wbc_plan_tick / wbc_dispatch_thresholds report it), 0 = always the two-kernel tick */
+                             (11264, observer on 12288; rollouts: 4096 -- wbc_plan_tick / wbc_dispatch_thresholds report it; at auto, fp64 observer-off ticks with matrix outputs
+                             leave the one-launch tick at 8192 states already: tile_tick below), 0 = always the two-kernel tick */
   int rollout_persistent; /* 1 (default): rollouts of at most fused_max (auto: 4096) states = one launch per rollout; 0: per-tick launches */
   int rollout_spw;        /* states per workgroup of the rollout kernel: 0 = auto (4 up to 1024 states, else 16), 4, 16 */
   long long obs_split_min;/* observer-on two-kernel ticks of at least this many states run the observer update as its own
@@ -154,8 +155,8 @@ typedef struct wbc_solver_options {
   int tile_tick;          /* (ABI 8) fp32 observer-on ticks with M/h/Jc outputs of an even batch: ONE launch of 128-state workgroups, one per CU -- the sweep and
                              observer roles of obs_colaunch side by side in a workgroup, then the staged QP tile of the same states behind one barrier
                              (wbc_tick_plan.fused = 2).  0 = auto (from 12290 states on; 64 / 96 / 128 states per workgroup: one round of workgroups up to 32768 states,
-                             BASELINE's configs[3] shard), 1 = every such tick beyond the fused_tick size, -1 = never.  Also fp64 observer-off ticks of 11265 ... 28672 states (32 ... 112-state workgroups;
-                             1: every size).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */
+                             BASELINE's configs[3] shard), 1 = every such tick beyond the fused_tick size, -1 = never.  Also fp64 observer-off ticks of 8193 ... 28672 states (48 ... 112-state workgroups, ahead of the one-launch tick while
+                             fused_max is at auto; 1: every size beyond the fused_tick size).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,

@@ -181,7 +181,7 @@ def test_round6_ticks_are_graph_capturable(torch_cuda, gpu_model, mode):
     assert int(got["iters"].max()) > 0
 
 
-@pytest.mark.parametrize("n,force", [(12288, 0), (28672, 0), (11265, 0), (37, 1), (4099, 1), (30001, 1), (20000, 0)])
+@pytest.mark.parametrize("n,force", [(12288, 0), (28672, 0), (11265, 0), (8193, 0), (9216, 0), (37, 1), (4099, 1), (30001, 1), (20000, 0)])
 def test_fp64_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, oracle, n, force):
     """fp64, observer off (configs[1]'s shape): NS sweep wavefronts of 16 states, then the staged QP tile of those states with the predictor finishing
     the states whose unconstrained minimum violates nothing.  Against the oracle at the fp64 gates (status equal, 1e-9 of the largest entry, the

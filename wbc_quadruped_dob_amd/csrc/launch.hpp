@@ -49,7 +49,7 @@ constexpr int TILE_TICK_STATES = 128;
 inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : (N <= 128 * 256 ? 128 : 64)); }
 // fp64, observer off: NS = 2 ... 7 sweep wavefronts of 16 states (a CU's LDS holds seven wavefronts' parking lots), again the smallest one-round size
 inline int tile_tick_states_f64(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 7 ? 7 : ns)); }
-constexpr long long WBC_TILE_TICK_MIN_F64 = 11265;
+constexpr long long WBC_TILE_TICK_MIN_F64 = 8193;
 constexpr long long WBC_TILE_TICK_MIN = 12290;
 template <class T> hipError_t k_tile_prepare();   // raises the dynamic-LDS limit of the tile_tick kernels (once per process and device)
 template <class T> hipError_t k_qp_prepare();     // ... of the staged QP tile kernels

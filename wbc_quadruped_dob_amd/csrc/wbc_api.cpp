@@ -68,7 +68,7 @@ constexpr long long WBC_COLAUNCH_MIN_F32 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F32 = 32768;
 constexpr long long WBC_COLAUNCH_MIN_F64 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F64 = 14336;
-struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max; };
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max, tt_first_min; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -364,7 +364,14 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // the standing batch iterate 2.5 times per state against the trot batches' 0.5, so the QP stage weighs more and the gain is small, and only while the batch is ONE
   // round of workgroups (profiles/r06d_ab_tile_tick_f64.log; M steps/s, default -> tile tick): 11 264: 333 -> 355, 12 288: 347 -> 379, 16 384: 425 -> 475, 24 576: 531 -> 550,
   // 28 672: 541 -> 568; but 8 192: 343 -> 287 (the fused tick's role split overlaps QP and dynamics), 32 768: 602 -> 376 (a second round), 262 144: 790 -> 550
-  if (dtype == WBC_F64 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) { r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN_F64; r.tt_max = o.tile_tick > 0 ? (size_t)-1 : (size_t)7 * 16 * 256; }
+  // With tau_partial handed over in LDS (profiles/r06j_ab_tile_tick_lds_handover.log, r06k_tile_tick_f64_range.log, r06m_tile_tick_f64_small.log; default -> tile tick): 9 216: 303 -> 324,
+  // 10 240: 319 -> 350, 11 264: 333 -> 378, 12 288: 348 -> 404, 16 384: 427 -> 501, 24 576: 532 -> 575, 28 672: 546 -> 596; 8 192 (two full rounds of the one-launch tick): 342 -> 305.
+  // So from 8 193 states on the tile tick also goes IN FRONT of the one-launch tick (tt_first_min) -- while the caller leaves fused_max at auto.
+  r.tt_first_min = (size_t)-1;
+  if (dtype == WBC_F64 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) {
+    r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN_F64; r.tt_max = o.tile_tick > 0 ? (size_t)-1 : (size_t)7 * 16 * 256;
+    if (o.tile_tick == 0 && o.fused_max < 0) r.tt_first_min = r.tt_min;
+  }
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
@@ -383,6 +390,11 @@ struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block, qp_wa
 static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf, bool warm = false) {
   TickPlan p{};
   const bool ob = observer_order > 0, f32 = dtype == WBC_F32;
+  const bool tt64 = mats && !ob && !f32 && !warm && N >= r.tt_min && N <= r.tt_max;   // fp64, observer off (configs[1]'s shape): sweep wavefronts, then the staged QP tile of their states
+  if (tt64 && N >= r.tt_first_min) {
+    p.fused = 2; p.front = 0; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64(N); p.qp_body = 2;
+    return p;
+  }
   if ((mats || !pf) && N <= (ob ? r.fused_max_obs : r.fused_max_noobs)) {
     // small batch: one launch, 16 states per workgroup, rnea_step | mass_jac | [observer] | QP as wavefront roles and the
     // workspace through LDS (fused_tick.hip.hpp)
@@ -390,7 +402,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
     p.qp_warm = warm;
     return p;
   }
-  if (mats && !ob && !f32 && !warm && N >= r.tt_min && N <= r.tt_max) {   // fp64, observer off (configs[1]'s shape): sweep wavefronts, then the staged QP tile of their states
+  if (tt64) {
     p.fused = 2; p.front = 0; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64(N); p.qp_body = 2;
     return p;
   }
