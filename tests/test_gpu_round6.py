@@ -95,9 +95,9 @@ def test_staged_tiles_report_the_active_sets_a_warm_tick_starts_from(torch_cuda,
     assert torch.equal(o2["active"], sets)
 
 
-def _tick_inputs(torch, gpu_model, solver, n, rank):
+def _tick_inputs(torch, gpu_model, solver, n, rank, dtype="f32"):
     B = synth.make_batch(4, n, gpu_model.total_mass, rank=rank)
-    td = torch.float32
+    td = torch.float32 if dtype == "f32" else torch.float64
     dv = lambda k: to_dev(B[k], torch, td)
     mask = torch.from_numpy(np.ascontiguousarray(B["mask"])).to(torch.int32).cuda()
     ig = solver.dynamics(dv("q"), dv("v"), want=("p",))["p"]
@@ -208,6 +208,39 @@ def test_fp64_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, ora
     assert relerr(a["tau"][ok], ref["tau"][ok]) < 1e-9 and relerr(a["f"][ok], ref["f"][ok]) < 1e-9
     assert elementwise_excess(a["tau"][ok], ref["tau"][ok]) <= 1.0 and elementwise_excess(a["f"][ok], ref["f"][ok]) <= 1.0
     assert np.sum(a["iters"] != ref["iters"]) <= max(2, 0.02 * n) and a["iters"].max() >= 3      # (a near-tie between two violated rows may be taken in the other order)
+
+
+@pytest.mark.parametrize("n,obs,force", [(12289, 1, 0), (16384, 1, 0), (14000, 2, 0), (16385, 1, 1), (41, 1, 1), (20000, 2, 1)])
+def test_fp64_observer_on_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, oracle, n, obs, force):
+    """fp64, observer on (configs[2]'s shape) behind the one-launch tick: NS sweep + NS observer wavefronts of 16 states, then the staged QP tile of those states.
+    The dynamics outputs and the new observer state are BIT-IDENTICAL to the two-launch tick's (same role bodies); tau, f, status against the oracle at the fp64 gates."""
+    from tests.util import elementwise_excess
+    torch = torch_cuda
+    res = {}
+    for tag, opt in (("tile", {"tile_tick": 1, "fused_max": 0} if force else {}), ("two", {"tile_tick": -1, "fused_max": 0, "obs_colaunch": 1})):
+        solver, P = _solver(gpu_model, dtype="f64", obs=obs, max_batch=n, options=opt)
+        pl = solver.plan_tick(n)
+        assert pl["fused"] == (2 if tag == "tile" else 0), (tag, pl)
+        if tag == "tile":
+            assert pl["qp_tile"] in (32, 48, 64) and pl["front"] == 4
+        B, args, ig, r = _tick_inputs(torch, gpu_model, solver, n, rank=31, dtype="f64")
+        if tag == "tile":
+            ig0, r0 = to_host(ig).copy(), to_host(r).copy()
+        out = solver.step(*args, ig, r, want_mats=True)
+        torch.cuda.synchronize()
+        res[tag] = {k: to_host(v) if v.dtype.is_floating_point else v.cpu().numpy() for k, v in out.items()}
+        res[tag]["integ"], res[tag]["r"] = to_host(ig), to_host(r)
+    a, b = res["tile"], res["two"]
+    for k in ("M", "h", "Jc", "pf", "integ", "r"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["status"], b["status"]) and relerr(a["tau"], b["tau"]) < 1e-10 and relerr(a["f"], b["f"]) < 1e-10
+    P0 = synth.default_params(observer_order=obs)
+    ref = oracle.step(P0, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"], ig0, r0, nthreads=8)
+    assert np.array_equal(a["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert relerr(a["tau"][ok], ref["tau"][ok]) < 1e-9 and relerr(a["f"][ok], ref["f"][ok]) < 1e-9
+    assert elementwise_excess(a["tau"][ok], ref["tau"][ok]) <= 1.0 and elementwise_excess(a["f"][ok], ref["f"][ok]) <= 1.0
+    assert relerr(a["r"], r0) < 1e-9 and relerr(a["integ"], ig0) < 1e-9      # (the oracle updates the observer state it is given in place)
 
 
 ROWS = dict(q=19, v=18, w_des=6, vdot_des=18, normals=12, mu=4, tau_prev=12, f_prev=12)

@@ -251,7 +251,11 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.dispatch_thresholds("f64", 0) == [8193, 28673, 65536, 106496]      # (round 6: 8 193 .. 28 672 states as one round of tile-tick workgroups, in front of the one-launch tick)
     assert W.dispatch_thresholds("f64", 0, options={"tile_tick": -1}) == [11265, 14336, 65536, 106496]
     assert [(W.plan_tick(n, "f64", 0)["fused"], W.plan_tick(n, "f64", 0)["qp_tile"]) for n in (8192, 8193, 12288, 12289, 28672, 28673)] == [(1, 0), (2, 48), (2, 48), (2, 64), (2, 112), (0, 40)]
-    assert W.dispatch_thresholds("f64", 1) == [12289, 14336, 14337, 20480, 65536, 106496]
+    # round 6: fp64 observer-on batches of 8 193 .. 196 608 states run the tile tick too (32 / 48 / 64-state workgroups; 64-state ones in rounds beyond 16 384 states)
+    assert W.dispatch_thresholds("f64", 1) == [8193, 196609]
+    assert W.dispatch_thresholds("f64", 1, options={"tile_tick": -1}) == [12289, 14336, 14337, 20480, 65536, 106496]
+    assert [(W.plan_tick(n, "f64", 1)["fused"], W.plan_tick(n, "f64", 1)["qp_tile"]) for n in (8192, 8193, 12288, 12289, 16384, 65536, 196608, 196609)] == [
+        (1, 0), (2, 48), (2, 48), (2, 64), (2, 64), (2, 64), (2, 64), (0, 0)]
     # round 6: even fp32 observer-on batches of 12 290 .. 32 768 states run the tile tick (one launch of 64 / 96 / 128-state workgroups); staged QP tiles up to 49 152
     assert W.dispatch_thresholds("f32", 1) == [12289]
     assert W.dispatch_thresholds("f32", 1, options={"tile_tick": -1}) == [12289, 16384, 32769, 33792, 49153, 65537, 131072, 212992]
@@ -260,7 +264,7 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.dispatch_thresholds("f32", 0) == [11265, 16384, 32768, 49153, 65537, 131072, 212992]
     assert [(W.plan_tick(n, "f32", 0)["qp_body"], W.plan_tick(n, "f32", 0)["qp_tile"]) for n in (16382, 16384, 32768, 49152, 49154)] == [(0, 0), (2, 64), (2, 128), (2, 192), (0, 72)]
     assert W.plan_tick(32768, "f32", 1, options={"tile_tick": -1}) == dict(fused=0, front=4, qp=1, qp_tile=128, qp_body=2, sweep_pack2=1, sweep_block=64, qp_warm=0)
-    assert [W.plan_tick(n, "f64", 1)["front"] for n in (12288, 12289, 14336, 14337, 20480)] == [0, 4, 4, 0, 2]
+    assert [W.plan_tick(n, "f64", 1, options={"tile_tick": -1})["front"] for n in (12288, 12289, 14336, 14337, 20480)] == [0, 4, 4, 0, 2]
     assert [W.plan_tick(n, "f32", 1, options={"tile_tick": -1})["front"] for n in (12290, 12291, 32768, 32770, 33792)] == [4, 0, 4, 0, 2]
     assert W.plan_tick(20000, "f32", 1)["sweep_pack2"] == 1 and W.plan_tick(20000, "f32", 1, options={"obs_colaunch": -1, "tile_tick": -1})["sweep_pack2"] == 0
     assert W.plan_tick(262144, "f64", 0)["qp"] == 2 and W.plan_tick(262144, "f32", 1, options={"tile_tick": -1}) == dict(
@@ -277,7 +281,7 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.dispatch_thresholds("f32", 1, warm=True) == [12289, 30720, 36864, 131072]
     assert [W.plan_tick(n, "f64", 1, warm=True)["qp_warm"] for n in (4096, 13000, 20000, 30000, 60000)] == [1, 1, 1, 0, 1]
     assert [W.plan_tick(n, "f64", 1, warm=True)["qp"] for n in (13000, 20000, 30000, 60000)] == [0, 0, 1, 2]
-    assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((8192, 0), (8193, 0), (11264, 0), (12288, 1), (12289, 1))] == [1, 2, 2, 1, 0]
+    assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((8192, 0), (8193, 0), (11264, 0), (8192, 1), (12288, 1), (12289, 1))] == [1, 2, 2, 1, 2, 2]
     assert [W.plan_tick(n, "f64", 0, options={"fused_max": 11264})["fused"] for n in (8193, 11264, 11265)] == [1, 1, 2]   # (a caller who names the one-launch tick's limit keeps it)
 
 

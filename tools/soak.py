@@ -52,8 +52,8 @@ for c in range(cases):
             integ0 = orc.dynamics(B["q"], B["v"], nthreads=8)["p"] if obs else None
         zz = lambda: tuple(None if t is None else t.astype(np.float32 if DT == "f32" else np.float64) for t in z())
         variants = [("tiled", {"qp_tile": int(rng.choice(tiles)), "qp_lane": -1}), ("plain", {"qp_tile": -1, "qp_lane": -1}), ("lane", {"qp_lane": 1})]
-        # round 6: the tile tick (one launch: roles + staged QP tile per workgroup) where it exists -- fp32 with the observer on (even batches), fp64 with it off; matrix outputs
-        ttick = bool(c % 2) and ((DT == "f32" and obs > 0 and n % 2 == 0) or (DT == "f64" and obs == 0))
+        # round 6: the tile tick (one launch: roles + staged QP tile per workgroup) where it exists -- fp32 with the observer on (even batches), fp64 with it on or off; matrix outputs
+        ttick = bool(c % 2) and ((DT == "f32" and obs > 0 and n % 2 == 0) or DT == "f64")
         if ttick:
             variants.append(("ttick", {"tile_tick": 1, "fused_max": 0}))
         for tag, opt in variants:

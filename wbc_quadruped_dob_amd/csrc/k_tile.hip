@@ -28,6 +28,8 @@ static hipError_t tile_tick_any(const LaunchCtx* L, bool observer, int states, c
   } else {
     // fp64, observer off: NS sweep wavefronts of 16 states; small tiles get helper wavefronts for the QP stage
     TT_CASE(1, 2, 8, false) TT_CASE(1, 3, 8, false) TT_CASE(1, 4, 8, false) TT_CASE(1, 5, 8, false) TT_CASE(1, 6, 8, false) TT_CASE(1, 7, 7, false)
+    // fp64, observer on: NS sweep + NS observer wavefronts of 16 states (64 states: the CU's eight wavefronts)
+    TT_CASE(1, 2, 8, true) TT_CASE(1, 3, 8, true) TT_CASE(1, 4, 8, true)
   }
 #undef TT_CASE
   return hit ? e : hipErrorInvalidValue;

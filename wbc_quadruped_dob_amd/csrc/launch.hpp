@@ -50,6 +50,9 @@ inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 2
 // fp64, observer off: NS = 2 ... 7 sweep wavefronts of 16 states (a CU's LDS holds seven wavefronts' parking lots), again the smallest one-round size
 inline int tile_tick_states_f64(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 7 ? 7 : ns)); }
 constexpr long long WBC_TILE_TICK_MIN_F64 = 8193;
+// fp64, observer on: NS = 2 ... 4 sweep + as many observer wavefronts of 16 states -- one round of workgroups holds 64 x 256 states, larger batches take several
+inline int tile_tick_states_f64_obs(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 4 ? 4 : ns)); }
+constexpr long long WBC_TILE_TICK_MAX_F64_OBS = 196608;
 constexpr long long WBC_TILE_TICK_MIN = 12290;
 template <class T> hipError_t k_tile_prepare();   // raises the dynamic-LDS limit of the tile_tick kernels (once per process and device)
 template <class T> hipError_t k_qp_prepare();     // ... of the staged QP tile kernels

@@ -68,7 +68,7 @@ constexpr long long WBC_COLAUNCH_MIN_F32 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F32 = 32768;
 constexpr long long WBC_COLAUNCH_MIN_F64 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F64 = 14336;
-struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max, tt_first_min; };
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max, tt_first_min, tt_max_obs; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -367,10 +367,15 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // With tau_partial handed over in LDS (profiles/r06j_ab_tile_tick_lds_handover.log, r06k_tile_tick_f64_range.log, r06m_tile_tick_f64_small.log; default -> tile tick): 9 216: 303 -> 324,
   // 10 240: 319 -> 350, 11 264: 333 -> 378, 12 288: 348 -> 404, 16 384: 427 -> 501, 24 576: 532 -> 575, 28 672: 546 -> 596; 8 192 (two full rounds of the one-launch tick): 342 -> 305.
   // So from 8 193 states on the tile tick also goes IN FRONT of the one-launch tick (tt_first_min) -- while the caller leaves fused_max at auto.
-  r.tt_first_min = (size_t)-1;
+  r.tt_first_min = (size_t)-1; r.tt_max_obs = 0;
   if (dtype == WBC_F64 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) {
     r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN_F64; r.tt_max = o.tile_tick > 0 ? (size_t)-1 : (size_t)7 * 16 * 256;
     if (o.tile_tick == 0 && o.fused_max < 0) r.tt_first_min = r.tt_min;
+    // observer on (NS sweep + NS observer wavefronts of 16 states: 32 / 48 / 64-state workgroups, 64 in rounds beyond 16 384 states), profiles/r06n_tile_tick_f64_obs.log,
+    // M steps/s default -> tile tick: 8 192: 358 -> 326 (one-launch tick, two full rounds) but 8 704: 311 -> 350, 10 240: 358 -> 398, 12 288: 388 -> 461; against the
+    // two-launch ticks 12 800: 355 -> 399, 16 384: 416 -> 567, 24 576: 499 -> 525, 32 768: 532 -> 639, 49 152: 614 -> 656, 65 536: 553 -> 578, 98 304: 557 -> 597,
+    // 131 072: 580 -> 586, 196 608: 571 -> 598, but 262 144: 611 -> 574
+    r.tt_max_obs = o.tile_tick > 0 ? (size_t)-1 : (size_t)WBC_TILE_TICK_MAX_F64_OBS;
   }
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
@@ -390,9 +395,17 @@ struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block, qp_wa
 static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf, bool warm = false) {
   TickPlan p{};
   const bool ob = observer_order > 0, f32 = dtype == WBC_F32;
-  const bool tt64 = mats && !ob && !f32 && !warm && N >= r.tt_min && N <= r.tt_max;   // fp64, observer off (configs[1]'s shape): sweep wavefronts, then the staged QP tile of their states
+  // (warm ticks: only where the cold tiles are the plan anyway -- the staged tiles report the sets)
+  const bool tt_warm_ok = !warm || (N >= r.warm_tile_min && N < r.warm_lane_min && o.qp_lane <= 0);
+  const bool tt64 = mats && !ob && !f32 && tt_warm_ok && N >= r.tt_min && N <= r.tt_max;   // fp64, observer off (configs[1]'s shape): sweep wavefronts, then the staged QP tile of their states
+  // fp64, observer on (configs[2]'s shape): NS sweep + NS observer wavefronts, then the staged QP tile; 64-state workgroups in rounds beyond 16 384 states
+  const bool tt64o = mats && ob && !f32 && tt_warm_ok && N >= r.tt_min && N <= r.tt_max_obs;
   if (tt64 && N >= r.tt_first_min) {
     p.fused = 2; p.front = 0; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64(N); p.qp_body = 2;
+    return p;
+  }
+  if (tt64o && N >= r.tt_first_min) {
+    p.fused = 2; p.front = 4; p.obs_split = true; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64_obs(N); p.qp_body = 2;
     return p;
   }
   if ((mats || !pf) && N <= (ob ? r.fused_max_obs : r.fused_max_noobs)) {
@@ -404,6 +417,10 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   }
   if (tt64) {
     p.fused = 2; p.front = 0; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64(N); p.qp_body = 2;
+    return p;
+  }
+  if (tt64o) {
+    p.fused = 2; p.front = 4; p.obs_split = true; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64_obs(N); p.qp_body = 2;
     return p;
   }
   if (mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && (!warm || (N >= r.warm_tile_min && N < r.warm_lane_min && o.qp_lane <= 0))) {
@@ -527,7 +544,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.tt_min, r.tt_max + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
   size_t keep[20]; int k = 0;
   for (size_t c : cand) {
