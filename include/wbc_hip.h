@@ -154,7 +154,7 @@ typedef struct wbc_solver_options {
                              0 = auto, 1 = whenever the tick is a two-kernel tick with the observer on, -1 = never */
   int tile_tick;          /* (ABI 8) fp32 observer-on ticks with M/h/Jc outputs of an even batch: ONE launch of 128-state workgroups, one per CU -- the sweep and
                              observer roles of obs_colaunch side by side in a workgroup, then the staged QP tile of the same states behind one barrier
-                             (wbc_tick_plan.fused = 2).  0 = auto (from 12290 states on; 64 / 96 / 128 states per workgroup: one round of workgroups up to 32768 states,
+                             (wbc_tick_plan.fused = 2).  0 = auto (from 8194 states on -- up to 12288 in front of the one-launch tick while fused_max is at auto; 64 / 96 / 128 states per workgroup: one round of workgroups up to 32768 states,
                              BASELINE's configs[3] shard), 1 = every such tick beyond the fused_tick size, -1 = never.  Also fp64 observer-off ticks of 8193 ... 28672 states (48 ... 112-state workgroups, ahead of the one-launch tick while
                              fused_max is at auto; 1: every size beyond the fused_tick size) and fp64 observer-on ticks of 8193 ... 196608 states (32 / 48 / 64-state
                              workgroups of sweep + observer wavefronts, 64-state ones in rounds beyond 16384 states).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */

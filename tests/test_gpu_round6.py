@@ -105,7 +105,7 @@ def _tick_inputs(torch, gpu_model, solver, n, rank, dtype="f32"):
     return B, [dv(k) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu")] + [mask, dv("tau_prev"), dv("f_prev")], ig, r
 
 
-@pytest.mark.parametrize("n,obs,force", [(32768, 1, 0), (12290, 1, 0), (20002, 2, 0), (24576, 1, 0), (40000, 1, 1), (130, 1, 1), (65536, 2, 1), (16384, 1, 0), (8200, 1, 1)])
+@pytest.mark.parametrize("n,obs,force", [(32768, 1, 0), (12290, 1, 0), (20002, 2, 0), (24576, 1, 0), (40000, 1, 1), (130, 1, 1), (65536, 2, 1), (16384, 1, 0), (8200, 1, 0), (10240, 2, 0)])
 def test_tile_tick_equals_the_two_launch_tick_bit_for_bit_and_the_oracle(torch_cuda, gpu_model, oracle, n, obs, force):
     """tile_tick_kernel (wbc_tick_plan.fused = 2): the sweep and observer roles of sweep_obs_kernel side by side in a 64 / 96 / 128-state workgroup, then the
     staged QP tile of the same states behind one barrier.  Role bodies and QP stage are those of the two launches and no state's arithmetic depends on which

@@ -256,11 +256,11 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.dispatch_thresholds("f64", 1, options={"tile_tick": -1}) == [12289, 14336, 14337, 20480, 65536, 106496]
     assert [(W.plan_tick(n, "f64", 1)["fused"], W.plan_tick(n, "f64", 1)["qp_tile"]) for n in (8192, 8193, 12288, 12289, 16384, 65536, 196608, 196609)] == [
         (1, 0), (2, 48), (2, 48), (2, 64), (2, 64), (2, 64), (2, 64), (0, 0)]
-    # round 6: even fp32 observer-on batches of 12 290 .. 32 768 states run the tile tick (one launch of 64 / 96 / 128-state workgroups); staged QP tiles up to 49 152
-    assert W.dispatch_thresholds("f32", 1) == [12289]
+    # round 6: even fp32 observer-on batches from 8 194 states on run the tile tick (one launch of 64 / 96 / 128-state workgroups; up to 12 288 states in front of the one-launch tick); staged QP tiles up to 49 152
+    assert W.dispatch_thresholds("f32", 1) == [8194]
     assert W.dispatch_thresholds("f32", 1, options={"tile_tick": -1}) == [12289, 16384, 32769, 33792, 49153, 65537, 131072, 212992]
-    assert [(W.plan_tick(n, "f32", 1)["fused"], W.plan_tick(n, "f32", 1)["qp_tile"]) for n in (12288, 12290, 16384, 16386, 24576, 24578, 32768, 32770, 32771, 262144)] == [
-        (1, 0), (2, 64), (2, 64), (2, 96), (2, 96), (2, 128), (2, 128), (2, 64), (0, 132), (2, 64)]      # (beyond one round of workgroups: 64-state ones, two per CU)
+    assert [(W.plan_tick(n, "f32", 1)["fused"], W.plan_tick(n, "f32", 1)["qp_tile"]) for n in (8192, 8194, 12288, 12290, 16384, 16386, 24576, 24578, 32768, 32770, 32771, 262144)] == [
+        (1, 0), (2, 64), (2, 64), (2, 64), (2, 64), (2, 96), (2, 96), (2, 128), (2, 128), (2, 64), (0, 132), (2, 64)]      # (beyond one round of workgroups: 64-state ones, two per CU)
     assert W.dispatch_thresholds("f32", 0) == [11265, 16384, 32768, 49153, 65537, 131072, 212992]
     assert [(W.plan_tick(n, "f32", 0)["qp_body"], W.plan_tick(n, "f32", 0)["qp_tile"]) for n in (16382, 16384, 32768, 49152, 49154)] == [(0, 0), (2, 64), (2, 128), (2, 192), (0, 72)]
     assert W.plan_tick(32768, "f32", 1, options={"tile_tick": -1}) == dict(fused=0, front=4, qp=1, qp_tile=128, qp_body=2, sweep_pack2=1, sweep_block=64, qp_warm=0)

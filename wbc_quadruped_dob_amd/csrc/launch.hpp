@@ -46,14 +46,14 @@ template <class T> hipError_t k_sweep_obs(const LaunchCtx& L, const DevModel<T>*
 constexpr int TILE_TICK_STATES = 128;
 // Beyond one round (N > 32 768) 64-state workgroups again, two resident per CU: they drift apart over the rounds, so that one's QP stage (latency-bound) shares the SIMDs with
 // the other's roles (issue-bound) -- 49 152 states: 895 -> 960 M steps/s, 262 144: 1 051 -> 1 088; a tie at 65 536 (profiles/r06h_ab_tile_tick_states.log)
-inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : (N <= 128 * 256 ? 128 : 64)); }
+inline int tile_tick_states(size_t N) { return N <= 64 * 256 ? 64 : (N <= 96 * 256 ? 96 : (N <= 128 * 256 ? 128 : 64)); }   // (32-state workgroups for <= 8 192 states: measured, no faster -- the tick's floor is ~22 us; r06o)
 // fp64, observer off: NS = 2 ... 7 sweep wavefronts of 16 states (a CU's LDS holds seven wavefronts' parking lots), again the smallest one-round size
 inline int tile_tick_states_f64(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 7 ? 7 : ns)); }
 constexpr long long WBC_TILE_TICK_MIN_F64 = 8193;
 // fp64, observer on: NS = 2 ... 4 sweep + as many observer wavefronts of 16 states -- one round of workgroups holds 64 x 256 states, larger batches take several
 inline int tile_tick_states_f64_obs(size_t N) { const size_t ns = (N + 4095) / 4096; return 16 * (int)(ns < 2 ? 2 : (ns > 4 ? 4 : ns)); }
 constexpr long long WBC_TILE_TICK_MAX_F64_OBS = 196608;
-constexpr long long WBC_TILE_TICK_MIN = 12290;
+constexpr long long WBC_TILE_TICK_MIN = 8194;
 template <class T> hipError_t k_tile_prepare();   // raises the dynamic-LDS limit of the tile_tick kernels (once per process and device)
 template <class T> hipError_t k_qp_prepare();     // ... of the staged QP tile kernels
 template <class T> hipError_t k_tile_tick(const LaunchCtx& L, bool observer, int states, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);

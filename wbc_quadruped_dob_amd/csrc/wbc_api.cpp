@@ -358,8 +358,13 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // 65 536: 910 -> 1 123, 98 304: 1 045 -> 1 132, 131 072: 1 002 -> 1 038, 196 608: 927 -> 1 078, 262 144: 993 -> 1 049 -- every size measured, so: no upper limit
   // (auto only while the kernel-selection options of the two-launch tick are at auto themselves: a caller who names a QP kernel or a front half gets it)
   const bool tt_auto_ok = o.qp_tile == 0 && o.qp_lane == 0 && o.obs_colaunch == 0 && o.obs_split_min == -1;
-  r.tt_min = (size_t)-1; r.tt_max = 0;
-  if (dtype == WBC_F32 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) { r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN; r.tt_max = (size_t)-1; }
+  r.tt_min = (size_t)-1; r.tt_max = 0; r.tt_first_min = (size_t)-1;
+  // (fp32 below the one-launch tick's limit, profiles/r06o_tile_tick_f32_small.log, one-launch -> tile tick: 8 192: 347 -> 335 but 8 704: 337 -> 353, 10 240: 357 -> 434, 12 288: 413 -> 490:
+  //  from 8 194 states the tile tick goes in front of the one-launch tick while fused_max is at auto -- tt_first_min, as for fp64 below)
+  if (dtype == WBC_F32 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) {
+    r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN; r.tt_max = (size_t)-1;
+    if (o.tile_tick == 0 && o.fused_max < 0) r.tt_first_min = r.tt_min;
+  }
   // ... and of fp64 observer-off batches (32 ... 112-state workgroups: NS = 2 ... 7 sweep wavefronts; small tiles get helper wavefronts for the QP stage).  fp64 QPs of
   // the standing batch iterate 2.5 times per state against the trot batches' 0.5, so the QP stage weighs more and the gain is small, and only while the batch is ONE
   // round of workgroups (profiles/r06d_ab_tile_tick_f64.log; M steps/s, default -> tile tick): 11 264: 333 -> 355, 12 288: 347 -> 379, 16 384: 425 -> 475, 24 576: 531 -> 550,
@@ -367,7 +372,7 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // With tau_partial handed over in LDS (profiles/r06j_ab_tile_tick_lds_handover.log, r06k_tile_tick_f64_range.log, r06m_tile_tick_f64_small.log; default -> tile tick): 9 216: 303 -> 324,
   // 10 240: 319 -> 350, 11 264: 333 -> 378, 12 288: 348 -> 404, 16 384: 427 -> 501, 24 576: 532 -> 575, 28 672: 546 -> 596; 8 192 (two full rounds of the one-launch tick): 342 -> 305.
   // So from 8 193 states on the tile tick also goes IN FRONT of the one-launch tick (tt_first_min) -- while the caller leaves fused_max at auto.
-  r.tt_first_min = (size_t)-1; r.tt_max_obs = 0;
+  r.tt_max_obs = 0;
   if (dtype == WBC_F64 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) {
     r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN_F64; r.tt_max = o.tile_tick > 0 ? (size_t)-1 : (size_t)7 * 16 * 256;
     if (o.tile_tick == 0 && o.fused_max < 0) r.tt_first_min = r.tt_min;
@@ -400,6 +405,12 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   const bool tt64 = mats && !ob && !f32 && tt_warm_ok && N >= r.tt_min && N <= r.tt_max;   // fp64, observer off (configs[1]'s shape): sweep wavefronts, then the staged QP tile of their states
   // fp64, observer on (configs[2]'s shape): NS sweep + NS observer wavefronts, then the staged QP tile; 64-state workgroups in rounds beyond 16 384 states
   const bool tt64o = mats && ob && !f32 && tt_warm_ok && N >= r.tt_min && N <= r.tt_max_obs;
+  // fp32, observer on (configs[3]'s shape), even batches: packed sweep + observer wavefronts, staged QP tile
+  const bool tt32 = mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && tt_warm_ok;
+  if (tt32 && !warm && N >= r.tt_first_min) {
+    p.fused = 2; p.front = 4; p.obs_split = true; p.pack2 = 1; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states(N); p.qp_body = 2;
+    return p;
+  }
   if (tt64 && N >= r.tt_first_min) {
     p.fused = 2; p.front = 0; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64(N); p.qp_body = 2;
     return p;
@@ -423,7 +434,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
     p.fused = 2; p.front = 4; p.obs_split = true; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64_obs(N); p.qp_body = 2;
     return p;
   }
-  if (mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && (!warm || (N >= r.warm_tile_min && N < r.warm_lane_min && o.qp_lane <= 0))) {
+  if (tt32) {
     // mid-size fp32 observer-on batch: sweep | observer roles and the staged QP tile of the same 128 states per workgroup, one launch (tile_tick.hip.hpp).
     // (warm ticks: only where the cold tiles are the plan anyway -- the kernel reports the sets; from warm_lane_min on the warm per-lane pair stays faster:
     //  230 against 250 us at 262 144 states)
