@@ -157,7 +157,8 @@ typedef struct wbc_solver_options {
                              (wbc_tick_plan.fused = 2).  0 = auto (from 8194 states on -- up to 12288 in front of the one-launch tick while fused_max is at auto; 64 / 96 / 128 states per workgroup: one round of workgroups up to 32768 states,
                              BASELINE's configs[3] shard), 1 = every such tick beyond the fused_tick size, -1 = never.  Also fp64 observer-off ticks of 8193 ... 28672 states (48 ... 112-state workgroups, ahead of the one-launch tick while
                              fused_max is at auto; 1: every size beyond the fused_tick size) and fp64 observer-on ticks of 8193 ... 196608 states (32 / 48 / 64-state
-                             workgroups of sweep + observer wavefronts, 64-state ones in rounds beyond 16384 states).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */
+                             workgroups of sweep + observer wavefronts, 64-state ones in rounds beyond 16384 states).  fp32 observer-off ticks: only with tile_tick = 1
+                             (measured: +16 % at 32768 states, a loss at 49152 and below 16384 -- profiles/r06q_tile_tick_f32_noobs.log).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,

@@ -243,6 +243,33 @@ def test_fp64_observer_on_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gp
     assert relerr(a["r"], r0) < 1e-9 and relerr(a["integ"], ig0) < 1e-9      # (the oracle updates the observer state it is given in place)
 
 
+@pytest.mark.parametrize("n,cfg", [(16384, 2), (20000, 3), (32768, 2), (40000, 2), (130, 2), (9000, 3)])
+def test_fp32_observer_off_tile_tick_vs_two_launch_tick_and_oracle(torch_cuda, gpu_model, oracle, n, cfg):
+    """fp32, observer off: NS packed sweep wavefronts (32 states each) plus helpers, then the staged QP tile of the same states.  Against the two-launch tick
+    (sweep, then staged or gathered tiles) to rounding, and within the fp32 gates of the fp32 oracle."""
+    torch = torch_cuda
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=37)
+    B["w_des"][: n // 2, 0:2] += np.random.default_rng(11).uniform(-60, 60, (n // 2, 2))
+    res = {}
+    for tag, opt in (("tile", {"tile_tick": 1, "fused_max": 0}), ("two", {"tile_tick": -1, "fused_max": 0})):
+        solver, P = _solver(gpu_model, dtype="f32", obs=0, max_batch=n, options=opt)
+        pl = solver.plan_tick(n)
+        assert pl["fused"] == (2 if tag == "tile" else 0), (tag, pl)
+        res[tag] = _run_step(torch, solver, B, "f32", want_mats=True)
+    a, b = res["tile"], res["two"]
+    for k in ("M", "h", "Jc", "pf"):
+        assert relerr(a[k], b[k]) < 1e-6, k
+    same = a["status"] == b["status"]
+    assert (~same).mean() <= F32_FLIPS and relerr(a["tau"][same], b["tau"][same]) < F32_TOL and relerr(a["f"][same], b["f"][same]) < F32_TOL
+    c = lambda x: np.ascontiguousarray(x, np.float32)
+    P0 = synth.default_params(dtype="f32")
+    ref = oracle.step(P0, c(B["q"]), c(B["v"]), c(B["w_des"]), c(B["vdot_des"]), c(B["normals"]), c(B["mu"]), B["mask"], c(B["tau_prev"]), c(B["f_prev"]), None, None, nthreads=8)
+    flips = a["status"] != ref["status"]
+    assert flips.mean() <= F32_FLIPS
+    ok = ~flips & (ref["status"] == 0)
+    assert relerr(a["tau"][ok], ref["tau"][ok]) < F32_TOL and relerr(a["f"][ok], ref["f"][ok]) < F32_TOL and a["iters"].max() >= 2
+
+
 ROWS = dict(q=19, v=18, w_des=6, vdot_des=18, normals=12, mu=4, tau_prev=12, f_prev=12)
 
 

@@ -25,6 +25,8 @@ static hipError_t tile_tick_any(const LaunchCtx* L, bool observer, int states, c
   if constexpr (std::is_same<T, float>::value) {
     // fp32: packed roles (32 states per wavefront), observer on: NS sweep + NS observer wavefronts
     TT_CASE(2, 2, 4, true) TT_CASE(2, 3, 6, true) TT_CASE(2, 4, 8, true)
+    // fp32, observer off: NS packed sweep wavefronts, helpers for the QP stage
+    TT_CASE(2, 2, 4, false) TT_CASE(2, 3, 6, false) TT_CASE(2, 4, 8, false)
   } else {
     // fp64, observer off: NS sweep wavefronts of 16 states; small tiles get helper wavefronts for the QP stage
     TT_CASE(1, 2, 8, false) TT_CASE(1, 3, 8, false) TT_CASE(1, 4, 8, false) TT_CASE(1, 5, 8, false) TT_CASE(1, 6, 8, false) TT_CASE(1, 7, 7, false)

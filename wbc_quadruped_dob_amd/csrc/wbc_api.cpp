@@ -68,7 +68,7 @@ constexpr long long WBC_COLAUNCH_MIN_F32 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F32 = 32768;
 constexpr long long WBC_COLAUNCH_MIN_F64 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F64 = 14336;
-struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max, tt_first_min, tt_max_obs; };
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max, tt_first_min, tt_max_obs, tt_max_noobs32; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -358,12 +358,15 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
   // 65 536: 910 -> 1 123, 98 304: 1 045 -> 1 132, 131 072: 1 002 -> 1 038, 196 608: 927 -> 1 078, 262 144: 993 -> 1 049 -- every size measured, so: no upper limit
   // (auto only while the kernel-selection options of the two-launch tick are at auto themselves: a caller who names a QP kernel or a front half gets it)
   const bool tt_auto_ok = o.qp_tile == 0 && o.qp_lane == 0 && o.obs_colaunch == 0 && o.obs_split_min == -1;
-  r.tt_min = (size_t)-1; r.tt_max = 0; r.tt_first_min = (size_t)-1;
+  r.tt_min = (size_t)-1; r.tt_max = 0; r.tt_first_min = (size_t)-1; r.tt_max_noobs32 = 0;
   // (fp32 below the one-launch tick's limit, profiles/r06o_tile_tick_f32_small.log, one-launch -> tile tick: 8 192: 347 -> 335 but 8 704: 337 -> 353, 10 240: 357 -> 434, 12 288: 413 -> 490:
   //  from 8 194 states the tile tick goes in front of the one-launch tick while fused_max is at auto -- tt_first_min, as for fp64 below)
   if (dtype == WBC_F32 && (o.tile_tick > 0 || (o.tile_tick == 0 && tt_auto_ok))) {
     r.tt_min = o.tile_tick > 0 ? 2 : (size_t)WBC_TILE_TICK_MIN; r.tt_max = (size_t)-1;
     if (o.tile_tick == 0 && o.fused_max < 0) r.tt_first_min = r.tt_min;
+    // observer off (fp32): forced only.  Measured on the standing batch (profiles/r06q_tile_tick_f32_noobs.log; M steps/s, default -> tile tick): 16 384: 490 -> 484,
+    // 24 576: 610 -> 633, 32 768: 688 -> 800, but 49 152: 807 -> 738, 10 240: 343 -> 307, 262 144: 1 254 -> 850 -- no range worth a default
+    r.tt_max_noobs32 = o.tile_tick > 0 ? (size_t)-1 : 0;
   }
   // ... and of fp64 observer-off batches (32 ... 112-state workgroups: NS = 2 ... 7 sweep wavefronts; small tiles get helper wavefronts for the QP stage).  fp64 QPs of
   // the standing batch iterate 2.5 times per state against the trot batches' 0.5, so the QP stage weighs more and the gain is small, and only while the batch is ONE
@@ -407,6 +410,11 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   const bool tt64o = mats && ob && !f32 && tt_warm_ok && N >= r.tt_min && N <= r.tt_max_obs;
   // fp32, observer on (configs[3]'s shape), even batches: packed sweep + observer wavefronts, staged QP tile
   const bool tt32 = mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && tt_warm_ok;
+  const bool tt32n = mats && !ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max_noobs32 && tt_warm_ok;   // ... observer off
+  if (tt32n && !warm && N >= r.tt_first_min) {
+    p.fused = 2; p.front = 0; p.pack2 = 1; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states(N); p.qp_body = 2;
+    return p;
+  }
   if (tt32 && !warm && N >= r.tt_first_min) {
     p.fused = 2; p.front = 4; p.obs_split = true; p.pack2 = 1; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states(N); p.qp_body = 2;
     return p;
@@ -432,6 +440,10 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   }
   if (tt64o) {
     p.fused = 2; p.front = 4; p.obs_split = true; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64_obs(N); p.qp_body = 2;
+    return p;
+  }
+  if (tt32n) {
+    p.fused = 2; p.front = 0; p.pack2 = 1; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states(N); p.qp_body = 2;
     return p;
   }
   if (tt32) {
@@ -555,7 +567,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.tt_max_noobs32 + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
   size_t keep[20]; int k = 0;
   for (size_t c : cand) {
