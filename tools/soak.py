@@ -235,7 +235,7 @@ for c in range(cases):
             if k == "status":
                 continue
             if k == "iters":   # (the last tick's: last-bit differences of the state flip a near-tie between two violated rows now and then -- a share of the states, not a bound)
-                if np.mean(a[k] != b[k]) > 1e-2:
+                if np.sum(a[k] != b[k]) > max(1, 1e-2 * a[k].size):   # (one state of a small batch is not a share)
                     bad.append((c, "rollout iters differ in %.3f of the states" % np.mean(a[k] != b[k]), n, obs, cfg, H))
                 continue
             e = relerr(a[k], b[k])
