@@ -1,14 +1,10 @@
 set -u
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_round6.py -x -q -m gpu -k "fp32_observer_off" 2>&1 | tail -12
-B="python bench.py --no-cpu --no-latency --large-batch 0 --no-closed-loop --dtype f32"
-pick='import sys,json; d=json.loads(sys.stdin.read()); k=d.get("kernels") or {}; f=lambda x: "-" if x is None else "%.2f" % x; print("%-8s %-10s %9.1f M steps/s  %8.4f ms/step  fused %s  sweep %s  qp %s  lane %s" % (sys.argv[1], sys.argv[2], d["value"]/1e6, d["ms_per_step"], f(k.get("fused_tick_us")), f(k.get("dyn_sweep_us")), f(k.get("qp_us")), f(k.get("qp_lane_us"))))'
+export WBC_TILE_TICK=1 WBC_FUSED_MAX=0
 {
-echo "# fp32 observer OFF (configs[1] inputs in fp32): tile tick forced (WBC_TILE_TICK=1 WBC_FUSED_MAX=0) against the default plans"
-for n in 8192 9216 10240 12288 16384 24576 32768 49152 65536 98304 131072 262144; do
-  st=200; [ $n -gt 40000 ] && st=60; [ $n -gt 140000 ] && st=30
-  $B --steps $st --warmup 10 --batch $n 2>/dev/null | python -c "$pick" $n default
-  WBC_TILE_TICK=1 WBC_FUSED_MAX=0 $B --steps $st --warmup 10 --batch $n 2>/dev/null | python -c "$pick" $n forced
+echo "# fp64 observer on, tile tick beyond one round: 32-state workgroups of four wavefronts, two per CU (lib_x) against 64-state workgroups of eight, one per CU (lib); tile tick forced"
+for a in "--steps 100 --warmup 10 --batch 32768 --config 3" "--steps 60 --warmup 10 --batch 65536 --config 3" "--steps 40 --warmup 5 --batch 131072 --config 3" "--steps 30 --warmup 5 --batch 262144 --config 3" "--steps 100 --warmup 10 --batch 24576 --config 3"; do
+  bash tools/ab_r06.sh "$a" lib lib_x 2>&1
 done
-} > gpurun_out/r06q_tile_tick_f32_noobs.log
-cat gpurun_out/r06q_tile_tick_f32_noobs.log
+} > gpurun_out/r06s_ab_tile_tick_f64_obs_two_per_cu.log
+cat gpurun_out/r06s_ab_tile_tick_f64_obs_two_per_cu.log
