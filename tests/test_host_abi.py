@@ -277,10 +277,14 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert [W.plan_tick(n, "f64", 1, want_mats=False)["front"] for n in (9000, 16383, 16384, 262144)] == [1, 1, 3, 3]
     assert W.plan_tick(262144, "f64", 0, want_mats=False)["front"] == 1
     # warm-started ticks (wbc_step_batch_warm): fused, warm one-wavefront kernel, cold tiles that only report the sets, warm per-lane pair
-    assert W.dispatch_thresholds("f64", 1, warm=True) == [12289, 14337, 20480, 24576, 53248, 65536]
-    assert W.dispatch_thresholds("f32", 1, warm=True) == [12289, 30720, 36864, 131072]
-    assert [W.plan_tick(n, "f64", 1, warm=True)["qp_warm"] for n in (4096, 13000, 20000, 30000, 60000)] == [1, 1, 1, 0, 1]
-    assert [W.plan_tick(n, "f64", 1, warm=True)["qp"] for n in (13000, 20000, 30000, 60000)] == [0, 0, 1, 2]
+    # (round 6: behind the one-launch warm tick and below the warm per-lane pair the warm call runs the cold, set-reporting tile tick)
+    assert W.dispatch_thresholds("f64", 1, warm=True) == [12289, 53248, 65536]
+    assert W.dispatch_thresholds("f64", 1, warm=True, options={"tile_tick": -1}) == [12289, 14337, 20480, 24576, 53248, 65536]
+    assert W.dispatch_thresholds("f32", 1, warm=True) == [12289, 81920, 131072]
+    assert W.dispatch_thresholds("f32", 1, warm=True, options={"tile_tick": -1}) == [12289, 30720, 32769, 33792, 36864, 131072]
+    assert [(W.plan_tick(n, "f64", 1, warm=True)["fused"], W.plan_tick(n, "f64", 1, warm=True)["qp_warm"]) for n in (4096, 12288, 13000, 30000, 53247, 60000)] == [(1, 1), (1, 1), (2, 0), (2, 0), (2, 0), (0, 1)]
+    assert [W.plan_tick(n, "f64", 1, warm=True, options={"tile_tick": -1})["qp_warm"] for n in (4096, 13000, 20000, 30000, 60000)] == [1, 1, 1, 0, 1]
+    assert [W.plan_tick(n, "f64", 1, warm=True, options={"tile_tick": -1})["qp"] for n in (13000, 20000, 30000, 60000)] == [0, 0, 1, 2]
     assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((8192, 0), (8193, 0), (11264, 0), (8192, 1), (12288, 1), (12289, 1))] == [1, 2, 2, 1, 2, 2]
     assert [W.plan_tick(n, "f64", 0, options={"fused_max": 11264})["fused"] for n in (8193, 11264, 11265)] == [1, 1, 2]   # (a caller who names the one-launch tick's limit keeps it)
 

@@ -1,10 +1,5 @@
 set -u
 export TMPDIR=/tmp
-export WBC_TILE_TICK=1 WBC_FUSED_MAX=0
-{
-echo "# fp64 observer on, tile tick beyond one round: 32-state workgroups of four wavefronts, two per CU (lib_x) against 64-state workgroups of eight, one per CU (lib); tile tick forced"
-for a in "--steps 100 --warmup 10 --batch 32768 --config 3" "--steps 60 --warmup 10 --batch 65536 --config 3" "--steps 40 --warmup 5 --batch 131072 --config 3" "--steps 30 --warmup 5 --batch 262144 --config 3" "--steps 100 --warmup 10 --batch 24576 --config 3"; do
-  bash tools/ab_r06.sh "$a" lib lib_x 2>&1
-done
-} > gpurun_out/r06s_ab_tile_tick_f64_obs_two_per_cu.log
-cat gpurun_out/r06s_ab_tile_tick_f64_obs_two_per_cu.log
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r06_pytest_gpu.log 2>&1; grep -n "passed\|failed" gpurun_out/r06_pytest_gpu.log | tail -3
+timeout 600 python tools/soak.py 400 91 f64 2>&1 | tail -1
+timeout 600 python tools/soak.py 200 92 f32 2>&1 | tail -1

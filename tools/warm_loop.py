@@ -30,6 +30,8 @@ def main():
             if os.environ.get("WARM_LOOP_LANE") == "1":
                 variants = [(False, False, {}), ("warm16", True, {"qp_lane": -1}), ("warmlane", True, {"qp_lane": 1}),
                             ("warm16f", True, {"qp_lane": -1, "qp_tile": -1})]     # (the last: the warm one-wavefront kernel at every size)
+            if os.environ.get("WARM_LOOP_LANE") == "2":   # the planner's warm tick against the two-launch warm plans (tile_tick = -1) and the forced per-lane pair
+                variants = [(False, False, {}), ("warm", True, {}), ("warm2l", True, {"tile_tick": -1}), ("warmlane", True, {"qp_lane": 1})]
             for tag, warm, opts in variants:
                 solver = W.Solver(model, W.Params.from_dict(P, dtype), dtype=dtype, device=0, max_batch=n, options=opts)
                 inp = {k: dev(B[k]) for k in ("q", "v", "w_des", "vdot_des", "normals", "mu", "tau_prev", "f_prev")}
@@ -77,6 +79,11 @@ def main():
                 if solver.plan_tick(n, warm=warm)["qp"] == 2:
                     kern["handed_over"] = solver.qp_handover()
                 res[tag] = (el / K * 1e6, el0 / K * 1e6, float(out["iters"].double().mean()), float((out["status"] == 0).double().mean()), kern)
+            if os.environ.get("WARM_LOOP_LANE") == "2":
+                pw = solver_plan = W.plan_tick(n, dtype, obs, warm=True)
+                print("cfg%d %s obs%d n=%6d wall us/tick: cold %6.2f  warm (planner: fused=%d qp=%d qp_warm=%d) %6.2f  warm, tile_tick = -1 %6.2f  warm per-lane pair forced %6.2f | iters %.2f / %.2f / %.2f / %.2f" % (
+                    cfg, dtype, obs, n, res[False][0], pw["fused"], pw["qp"], pw["qp_warm"], res["warm"][0], res["warm2l"][0], res["warmlane"][0], res[False][2], res["warm"][2], res["warm2l"][2], res["warmlane"][2]), flush=True)
+                continue
             if len(variants) == 4:
                 print("cfg%d %s obs%d n=%6d wall us/tick: cold %6.2f  warm, per-lane pair off %6.2f  warm per-lane %6.2f  warm one-wavefront kernel forced %6.2f | iters %.2f / %.2f / %.2f / %.2f | kernels cold %s  warm16 %s  warmlane %s  warm16f %s" % (
                     cfg, dtype, obs, n, res[False][0], res["warm16"][0], res["warmlane"][0], res["warm16f"][0], res[False][2], res["warm16"][2], res["warmlane"][2], res["warm16f"][2],

@@ -64,6 +64,7 @@ constexpr long long WBC_OBS_SPLIT_MIN_NOMATS_F64 = 16384;
 constexpr long long WBC_OBS_SPLIT_MIN_NOMATS_F32 = 32768;
 constexpr long long WBC_WARM_LANE_MIN_F64 = 53248;
 constexpr long long WBC_WARM_LANE_MIN_F32 = 36864;
+constexpr long long WBC_TT_WARM_MAX_F32 = 81920;   // warm fp32 observer-on ticks below this run the (cold, set-reporting) tile tick: plan_tick
 constexpr long long WBC_COLAUNCH_MIN_F32 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F32 = 32768;
 constexpr long long WBC_COLAUNCH_MIN_F64 = 12289;
@@ -403,8 +404,11 @@ struct TickPlan { int fused, front, qp, tile, qp_body, pack2, sweep_block, qp_wa
 static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_options& o, const Resolved& r, size_t N, bool mats, bool pf, bool warm = false) {
   TickPlan p{};
   const bool ob = observer_order > 0, f32 = dtype == WBC_F32;
-  // (warm ticks: only where the cold tiles are the plan anyway -- the staged tiles report the sets)
-  const bool tt_warm_ok = !warm || (N >= r.warm_tile_min && N < r.warm_lane_min && o.qp_lane <= 0);
+  // (warm ticks: behind the one-launch warm tick and below the warm per-lane pair the COLD tile tick -- its staged tiles report the sets -- beats the two-launch warm plans:
+  //  closed loops of 16 384 drifting states, wall us per tick, warm one-wavefront kernels -> tile tick: fp64 observer off 41.8 -> 38.8, on 44.8 -> 37.1, fp32 37.8 -> 34.4;
+  //  profiles/r06zz_warm_loop_large.log, r06t_warm_loop_tile_tick.log)
+  //  fp32 against the warm per-lane pair: 49 152: 75.6 -> 66.5, 65 536: 80.8 -> 76.6, 81 920: 94.0 / 95.4, 98 304: 101 / 108 -- so up to 81 920 states; fp64: up to warm_lane_min)
+  const bool tt_warm_ok = !warm || (N < (f32 ? (size_t)WBC_TT_WARM_MAX_F32 : r.warm_lane_min) && o.qp_lane <= 0);
   const bool tt64 = mats && !ob && !f32 && tt_warm_ok && N >= r.tt_min && N <= r.tt_max;   // fp64, observer off (configs[1]'s shape): sweep wavefronts, then the staged QP tile of their states
   // fp64, observer on (configs[2]'s shape): NS sweep + NS observer wavefronts, then the staged QP tile; 64-state workgroups in rounds beyond 16 384 states
   const bool tt64o = mats && ob && !f32 && tt_warm_ok && N >= r.tt_min && N <= r.tt_max_obs;
@@ -419,11 +423,11 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
     p.fused = 2; p.front = 4; p.obs_split = true; p.pack2 = 1; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states(N); p.qp_body = 2;
     return p;
   }
-  if (tt64 && N >= r.tt_first_min) {
+  if (tt64 && !warm && N >= r.tt_first_min) {
     p.fused = 2; p.front = 0; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64(N); p.qp_body = 2;
     return p;
   }
-  if (tt64o && N >= r.tt_first_min) {
+  if (tt64o && !warm && N >= r.tt_first_min) {
     p.fused = 2; p.front = 4; p.obs_split = true; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states_f64_obs(N); p.qp_body = 2;
     return p;
   }
@@ -567,7 +571,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.tt_max_noobs32 + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {(size_t)WBC_TT_WARM_MAX_F32, r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.tt_max_noobs32 + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
   size_t keep[20]; int k = 0;
   for (size_t c : cand) {
