@@ -21,21 +21,11 @@
 
 namespace wbc {
 
-// the observer role: the register-only body of observer.hip.hpp (no LDS parking), or -DWBC_OBS_ROLE_RNEA: rnea_step_body
-#ifdef WBC_OBS_ROLE_RNEA
-#define WBC_OBS_ROLE(EXT_, ARGS_) rnea_step_body<T, RS_OBS | RS_OBSW, 64, EXT_>(model, prm, ARGS_, cst, wsl)
-#else
-#define WBC_OBS_ROLE(EXT_, ARGS_) observer_body<T, 64, EXT_>(model, prm, ARGS_, cst, wsl)
-#endif
-// 1 (default): the structural zeros / ones of M and Jc are written by the four QP wavefronts while they wait for the lever arms,
-// not by the mass_jac role (~55 store instructions = ~4 us of store issue off that role's path); 0: by the mass_jac role
-// fused tick, observer on: the observer role is TWO wavefronts (base rows -> rhat_base, which the QP's b waits for; joint
-// rows -> rhat_joint, needed only in the torque map); -DWBC_OBS_ONE_WAVE: one wavefront does both
-#ifdef WBC_OBS_ONE_WAVE
-constexpr int FUSED_OBS_WAVES = 1;
-#else
+// fused tick, observer on: the observer role (observer_body: the register-only body of observer.hip.hpp, no LDS parking) is TWO wavefronts -- base rows -> rhat_base,
+// which the QP's b waits for; joint rows -> rhat_joint, needed only in the torque map.  (One wavefront doing both, and rnea_step_body as the observer role, were the
+// forms of rounds 2-3: docs/DESIGN_R04.md.)  The structural zeros / ones of M and Jc are written by the four QP wavefronts while they wait for the lever arms, not by
+// the mass_jac role (~55 store instructions = ~4 us of store issue off that role's path).
 constexpr int FUSED_OBS_WAVES = 2;
-#endif
 
 // The front half is SPLIT by consumer.  Six wavefronts per workgroup of
 // 16 states: wave 4 runs rnea_step_body (bias forces h, and the 66-word step workspace -- all the QP needs -- into LDS),
@@ -116,8 +106,7 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
       auto wait_ack = [ack] __device__() {   // (see QpSync::rp_ack; the QP wavefronts count at about +2.6 us, this role gets here at about +6)
         if constexpr (SPEC_ORDER) { while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1); }
       };
-      if constexpr (FUSED_OBS_WAVES == 2) observer_body<T, 64, 2, 1, 16, decltype(wait_ack)>(model, prm, a, cst, wsl, wait_ack);   // base rows
-      else WBC_OBS_ROLE(2, a);
+      observer_body<T, 64, 2, 1, 16, decltype(wait_ack)>(model, prm, a, cst, wsl, wait_ack);   // base rows
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&oready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       FSTAMP(10);      // (observer builds: slot 10 is the observer role's end, otherwise QP wave 3's)

@@ -45,32 +45,17 @@ namespace wbc {
 // A bracketing line search on phi'(t) = F(e + t dir) . dir rescues a few per cent of the stragglers and costs every wavefront
 // an evaluation per step: it does not pay.  (An undamped semismooth Newton iteration can cycle on under-determined stances;
 // such a lane simply ends up in the hand-over list.)
-#ifndef QPL_MAX_NEWTON
-#define QPL_MAX_NEWTON 5
-#endif
-#ifndef QPL_MIN_NEWTON
-#define QPL_MIN_NEWTON 3
-#endif
-#ifndef QPL_MORE_LANES
-#define QPL_MORE_LANES 5
-#endif
+constexpr int QPL_MAX_NEWTON = 5;
+constexpr int QPL_MIN_NEWTON = 3;
+constexpr int QPL_MORE_LANES = 5;
 
-#ifndef QPL_F64_WAVES
-#define QPL_F64_WAVES 2
-#endif
-#ifndef QPL_F32_WAVES
-#define QPL_F32_WAVES 2
-#endif
-#ifndef QPL_UNROLL_EVAL
-#define QPL_UNROLL_EVAL 1
-#endif
-#ifndef QPL_UNROLL_NEWTON
-#define QPL_UNROLL_NEWTON 1
-#endif
-#ifndef QPL_WG_THREADS
-#define QPL_WG_THREADS 256   // measured 64 / 128 / 256: equal at 262 144 states (100-105 us); at 65 536 the 256-thread workgroups land one
-#endif                       // wavefront on every SIMD (36 us), the smaller ones double up on some CUs and leave others idle (44-45 us)
-constexpr int QPL_WG = QPL_WG_THREADS;   // threads per workgroup (LDS below: 72 kB fp64, 40 kB fp32)
+constexpr int QPL_F64_WAVES = 2;
+constexpr int QPL_F32_WAVES = 2;
+constexpr int QPL_UNROLL_EVAL = 1;
+constexpr int QPL_UNROLL_NEWTON = 1;
+// threads per workgroup: measured 64 / 128 / 256 -- equal at 262 144 states (100-105 us); at 65 536 the 256-thread workgroups land one
+// wavefront on every SIMD (36 us), the smaller ones double up on some CUs and leave others idle (44-45 us)
+constexpr int QPL_WG = 256;   // threads per workgroup (LDS below: 72 kB fp64, 40 kB fp32)
 constexpr int QPL_FREE = 1 | (1 << 2) | (1 << 4);   // no face active
 
 // The contact frames live in LDS, one slot per lane ([component][foot][lane]: conflict-free), and the loops over the feet are
@@ -310,9 +295,7 @@ WBC_DEV int qpl_aset_from_codes(int codes, int mask) {
 
 // todo[0] = number of states handed to the dense kernel (zeroed by the front-half kernel of the same tick: SweepArgs::qp_todo),
 // todo[2] = that number of the last tick (diagnostics), todo[4 ...] = their indices
-#ifndef QPL_WARM_MIN_NEWTON
-#define QPL_WARM_MIN_NEWTON 1
-#endif
+constexpr int QPL_WARM_MIN_NEWTON = 1;
 // WARM (wbc_step_batch_warm at large batches: dependent ticks): the Newton iteration starts from the faces of a.aset_in instead of from "all free".
 // Any face set is a valid starting iterate of the semismooth Newton method -- a wrong or stale guess costs iterations (or sends the state to the
 // hand-over list), never the solution -- and the right one is confirmed by ONE Newton step that leaves the faces unchanged; a wavefront then
