@@ -159,6 +159,10 @@ typedef struct wbc_solver_options {
                              fused_max is at auto; 1: every size beyond the fused_tick size) and fp64 observer-on ticks of 8193 ... 196608 states (32 / 48 / 64-state
                              workgroups of sweep + observer wavefronts, 64-state ones in rounds beyond 16384 states).  fp32 observer-off ticks: only with tile_tick = 1
                              (measured: +16 % at 32768 states, a loss at 49152 and below 16384 -- profiles/r06q_tile_tick_f32_noobs.log).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */
+  int fused_pair;         /* (ABI 9) fp64 observer-off cold ticks with M/h/Jc outputs of N = a multiple of 32 states: the one-launch tick as twelve-wavefront workgroups of 32 states
+                             (wbc_tick_plan.fused = 3: two of the 16-state workgroups in one, at 168 registers, so that BOTH halves are resident on a CU together -- 8192 states are
+                             one round of workgroups instead of two).  0 = auto (WBC_FUSED_PAIR_MIN ... WBC_FUSED_PAIR_MAX states, wbc_dispatch_thresholds reports them; only while
+                             fused_max, tile_tick and the kernel selectors above are at auto), 1 = every such tick up to 65536 states, -1 = never */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);
 int wbc_solver_create_ex(const wbc_model* m, const wbc_params* p, int dtype, int device, size_t max_batch,
@@ -171,7 +175,8 @@ int wbc_solver_invalidate_structural(wbc_solver* s);
  * that a caller -- and the parity tests, which straddle every switch -- never restate them.  All fields are informational. */
 typedef struct wbc_tick_plan {
   size_t struct_size; /* in: sizeof of the caller's build (0 = this build's); out: bytes written */
-  int fused;          /* 1: the whole tick is ONE fused_tick launch (wavefront roles); everything below is 0 then.  2: ONE tile_tick launch (sweep | observer roles,
+  int fused;          /* 1: the whole tick is ONE fused_tick launch (wavefront roles); everything below is 0 then.  3 (ABI 9): the same as 32-state workgroups
+                         (fused_pair_kernel, wbc_solver_options.fused_pair).  2: ONE tile_tick launch (sweep | observer roles,
                          then the staged QP tile of the same states: front = 4, qp = 1, qp_body = 2, qp_tile = states per workgroup say what runs inside it) */
   int front;          /* two-kernel ticks, front half: 0 = dyn_sweep (observer inside when on), 1 = rnea_step (caller passes no M/h/Jc),
                          2 = observer kernel + observer-free dyn_sweep, 3 = observer kernel + observer-free rnea_step (no M/h/Jc),
@@ -448,7 +453,7 @@ int wbc_qp_dense_batch(int dtype, size_t N, int n, int m, int meq, const void* H
 
 const char* wbc_strerror(int status);
 const char* wbc_last_error(void); /* thread-local detail string of the last failure */
-int wbc_abi_version(void); /* 8 */
+int wbc_abi_version(void); /* 9 */
 
 #ifdef __cplusplus
 }

@@ -210,6 +210,47 @@ def test_fp64_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, ora
     assert np.sum(a["iters"] != ref["iters"]) <= max(2, 0.02 * n) and a["iters"].max() >= 3      # (a near-tie between two violated rows may be taken in the other order)
 
 
+@pytest.mark.parametrize("n,force,cfg", [(6144, 0, 2), (8192, 0, 2), (4128, 0, 2), (32, 1, 2), (4096, 1, 2), (16384, 1, 2), (5120, 0, 3), (7200, 0, 2)])
+def test_fused_pair_tick_equals_the_one_launch_tick_bit_for_bit_and_the_oracle(torch_cuda, gpu_model, oracle, n, force, cfg):
+    """fused_pair_kernel (wbc_tick_plan.fused = 3): two of the one-launch tick's 16-state workgroups as ONE twelve-wavefront workgroup of 32 states at 168 registers, the
+    second half on the batch's upper half through shifted argument pointers.  Same role and QP bodies, so EVERY output is bit-identical to fused_tick_kernel's
+    (wbc_solver_options.fused_pair = -1), and the tick passes the fp64 gates against the oracle (trot masks too: cfg 3's batch on an observer-free solver)."""
+    from tests.util import elementwise_excess
+    torch = torch_cuda
+    B = synth.make_batch(cfg, n, gpu_model.total_mass, rank=31)
+    B["w_des"][: n // 2, 0:2] += np.random.default_rng(11).uniform(-60, 60, (n // 2, 2))
+    res = {}
+    for tag, opt in (("pair", {"fused_pair": 1} if force else {}), ("one", {"fused_pair": -1, "fused_max": 65536})):
+        solver, P = _solver(gpu_model, dtype="f64", obs=0, max_batch=n, options=opt)
+        pl = solver.plan_tick(n)
+        assert pl["fused"] == (3 if tag == "pair" else 1), (tag, pl)
+        res[tag] = _run_step(torch, solver, B, "f64", want_mats=True)
+    a, b = res["pair"], res["one"]
+    for k in ("M", "h", "Jc", "pf", "tau", "f"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
+    P0 = synth.default_params()
+    ref = oracle.step(P0, B["q"], B["v"], B["w_des"], B["vdot_des"], B["normals"], B["mu"], B["mask"], B["tau_prev"], B["f_prev"], None, None, nthreads=8)
+    assert np.array_equal(a["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert relerr(a["tau"][ok], ref["tau"][ok]) < 1e-9 and relerr(a["f"][ok], ref["f"][ok]) < 1e-9
+    assert elementwise_excess(a["tau"][ok], ref["tau"][ok]) <= 1.0 and elementwise_excess(a["f"][ok], ref["f"][ok]) <= 1.0
+    dyn = oracle.dynamics(B["q"], B["v"], nthreads=8)
+    for k in ("M", "h", "Jc"):
+        if k in dyn:
+            assert relerr(a[k], dyn[k]) < 1e-9, k
+
+
+def test_fused_pair_plan_only_where_it_applies(gpu_model):
+    """N not a multiple of 32, the observer, fp32, warm ticks and ticks without M / h / Jc keep their plans; a caller who sets fused_max or tile_tick keeps the plan that names."""
+    import wbc_quadruped_dob_amd as W
+    assert [W.plan_tick(n, "f64", 0)["fused"] for n in (4096, 4127, 4128, 6144, 6145, 8192, 8224)] == [1, 1, 3, 3, 1, 3, 2]
+    assert W.plan_tick(6144, "f64", 1)["fused"] == 1 and W.plan_tick(6144, "f32", 0)["fused"] == 1 and W.plan_tick(6144, "f64", 0, warm=True)["fused"] == 1
+    assert W.plan_tick(6144, "f64", 0, want_mats=False)["fused"] != 3
+    assert W.plan_tick(6144, "f64", 0, options={"fused_max": 11264})["fused"] == 1 and W.plan_tick(6144, "f64", 0, options={"tile_tick": -1})["fused"] == 1
+    assert W.plan_tick(6144, "f64", 0, options={"fused_pair": -1})["fused"] == 1 and W.plan_tick(16384, "f64", 0, options={"fused_pair": 1})["fused"] == 3
+
+
 @pytest.mark.parametrize("n,obs,force", [(12289, 1, 0), (16384, 1, 0), (14000, 2, 0), (16385, 1, 1), (41, 1, 1), (20000, 2, 1)])
 def test_fp64_observer_on_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, oracle, n, obs, force):
     """fp64, observer on (configs[2]'s shape) behind the one-launch tick: NS sweep + NS observer wavefronts of 16 states, then the staged QP tile of those states.

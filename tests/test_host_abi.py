@@ -248,9 +248,9 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     """The defaults as the planner reports them; a deliberate change of a default changes this list.  Round 5: mid-size observer-on
     ticks with matrix outputs run the observer update and the sweep as the two roles of one launch (front = 4): fp64 12 289 .. 14 336, fp32 .. 32 768."""
     import wbc_quadruped_dob_amd as W
-    assert W.dispatch_thresholds("f64", 0) == [8193, 28673, 65536, 106496]      # (round 6: 8 193 .. 28 672 states as one round of tile-tick workgroups, in front of the one-launch tick)
+    assert W.dispatch_thresholds("f64", 0) == [4128, 8193, 28673, 65536, 106496]      # (round 6: 8 193 .. 28 672 states as one round of tile-tick workgroups, in front of the one-launch tick; 4 128 .. 8 192, multiples of 32: the one-launch tick as 32-state workgroups)
     assert W.dispatch_thresholds("f64", 0, options={"tile_tick": -1}) == [11265, 14336, 65536, 106496]
-    assert [(W.plan_tick(n, "f64", 0)["fused"], W.plan_tick(n, "f64", 0)["qp_tile"]) for n in (8192, 8193, 12288, 12289, 28672, 28673)] == [(1, 0), (2, 48), (2, 48), (2, 64), (2, 112), (0, 40)]
+    assert [(W.plan_tick(n, "f64", 0)["fused"], W.plan_tick(n, "f64", 0)["qp_tile"]) for n in (8191, 8192, 8193, 12288, 12289, 28672, 28673)] == [(1, 0), (3, 0), (2, 48), (2, 48), (2, 64), (2, 112), (0, 40)]
     # round 6: fp64 observer-on batches of 8 193 .. 196 608 states run the tile tick too (32 / 48 / 64-state workgroups; 64-state ones in rounds beyond 16 384 states)
     assert W.dispatch_thresholds("f64", 1) == [8193, 196609]
     assert W.dispatch_thresholds("f64", 1, options={"tile_tick": -1}) == [12289, 14336, 14337, 20480, 65536, 106496]
@@ -285,7 +285,7 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert [(W.plan_tick(n, "f64", 1, warm=True)["fused"], W.plan_tick(n, "f64", 1, warm=True)["qp_warm"]) for n in (4096, 12288, 13000, 30000, 53247, 60000)] == [(1, 1), (1, 1), (2, 0), (2, 0), (2, 0), (0, 1)]
     assert [W.plan_tick(n, "f64", 1, warm=True, options={"tile_tick": -1})["qp_warm"] for n in (4096, 13000, 20000, 30000, 60000)] == [1, 1, 1, 0, 1]
     assert [W.plan_tick(n, "f64", 1, warm=True, options={"tile_tick": -1})["qp"] for n in (13000, 20000, 30000, 60000)] == [0, 0, 1, 2]
-    assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((8192, 0), (8193, 0), (11264, 0), (8192, 1), (12288, 1), (12289, 1))] == [1, 2, 2, 1, 2, 2]
+    assert [W.plan_tick(n, "f64", ob)["fused"] for n, ob in ((8192, 0), (8193, 0), (11264, 0), (8192, 1), (12288, 1), (12289, 1))] == [3, 2, 2, 1, 2, 2]
     assert [W.plan_tick(n, "f64", 0, options={"fused_max": 11264})["fused"] for n in (8193, 11264, 11265)] == [1, 1, 2]   # (a caller who names the one-launch tick's limit keeps it)
 
 

@@ -7,7 +7,8 @@
 extern __shared__ char dyn_lds[];
 template <int REGS>
 __global__ __launch_bounds__(384) void spin(unsigned ticks, int* sink, int stagger) {
-  if (REGS > 128) asm volatile("v_mov_b32 v231, 0" ::: "v231");
+  if (REGS > 200) asm volatile("v_mov_b32 v231, 0" ::: "v231");
+  else if (REGS > 128) asm volatile("v_mov_b32 v163, 0" ::: "v163");   // 164 -> 168 registers: three wavefronts per SIMD
   else asm volatile("v_mov_b32 v120, 0" ::: "v120");
   const unsigned w = threadIdx.x >> 6;
   dyn_lds[threadIdx.x] = (char)w;
@@ -38,5 +39,8 @@ int main() {
   for (unsigned lds : {16384u, 80272u, 98192u})
     printf("staggered, LDS %6u B: 232 VGPRs: 256 wg %.1f us, 512 wg %.1f us | 120 VGPRs: 256 wg %.1f us, 512 wg %.1f us\n", lds,
            run<232>(256, lds, ticks, 1), run<232>(512, lds, ticks, 1), run<120>(256, lds, ticks, 1), run<120>(512, lds, ticks, 1));
+  // round 6: six-wavefront workgroups at 168 registers (three wavefronts per SIMD): do TWO of them share a CU (12 wavefronts = 3 + 3 + 3 + 3)?
+  for (unsigned lds : {16384u, 49152u, 73728u})
+    printf("LDS %6u B: 168 VGPRs: 256 wg %.1f us, 512 wg %.1f us\n", lds, run<168>(256, lds, ticks), run<168>(512, lds, ticks));
   return 0;
 }

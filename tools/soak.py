@@ -159,6 +159,14 @@ for c in range(cases):
                     worst = max(worst, e)
                     if not e < (1e-9 if DT == "f64" else TOL):
                         bad.append((c, "warm tick " + k_ + wtag, n, obs, cfg, e))
+        if DT == "f64" and obs == 0 and c % 2 and n % 32 == 0:   # round 6: the one-launch tick as 32-state workgroups (fused_pair_kernel) -- same bodies: bit for bit
+            pr = {}
+            for ptag, popt in (("pair", {"fused_pair": 1}), ("one", {"fused_pair": -1, "fused_max": 65536})):
+                s, P = solver_with(popt, obs=0, max_batch=n)
+                pr[ptag] = _run_step(torch, s, B, "f64", want_mats=True)
+            for k in pr["pair"]:
+                if not np.array_equal(pr["pair"][k], pr["one"][k], equal_nan=True):
+                    bad.append((c, "fused pair " + k, n, obs, cfg))
         if c % 5 == 0 and DT == "f64":   # the same launch again, several times: results must be bit-identical run to run
             s, P = solver_with({}, obs=obs, max_batch=n)
             first = _run_step(torch, s, B, "f64", *z(), want_mats=True)

@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("WBC_LIB") or os.path.join(_HERE, "lib", "libwbc_hip.s
 SYNTHETIC_URDF = os.path.join(_HERE, "assets", "synthetic_quadruped.urdf")
 WBC_MAXV = 32
 F64, F32 = 0, 1
-ABI_VERSION = 8   # include/wbc_hip.h: wbc_abi_version()
+ABI_VERSION = 9   # include/wbc_hip.h: wbc_abi_version()
 
 _lib = None
 
@@ -99,11 +99,11 @@ class SolverOptions(C.Structure):
     convenience of THIS binding for the A/B scripts under tools/ and bench.py."""
     _fields_ = [("struct_size", C.c_size_t), ("fused_max", C.c_longlong), ("rollout_persistent", C.c_int),
                 ("rollout_spw", C.c_int), ("obs_split_min", C.c_longlong), ("one_zerocopy", C.c_int), ("timing_mode", C.c_int), ("qp_tile", C.c_int), ("obs_split_serial", C.c_int), ("qp_lane", C.c_int), ("f32_pack2", C.c_int), ("keep_structural", C.c_int), ("rollout_warm", C.c_int),
-                ("multi_threads", C.c_int), ("multi_spin_us", C.c_int), ("obs_colaunch", C.c_int), ("tile_tick", C.c_int)]
+                ("multi_threads", C.c_int), ("multi_spin_us", C.c_int), ("obs_colaunch", C.c_int), ("tile_tick", C.c_int), ("fused_pair", C.c_int)]
     ENV = {"WBC_FUSED_MAX": ("fused_max", int), "WBC_ROLLOUT_PERSISTENT": ("rollout_persistent", int),
            "WBC_ROLLOUT_SPW": ("rollout_spw", int), "WBC_OBS_SPLIT_MIN": ("obs_split_min", int),
            "WBC_ONE_ZEROCOPY": ("one_zerocopy", int), "WBC_QP_TILE": ("qp_tile", int), "WBC_OBS_SPLIT_SERIAL": ("obs_split_serial", int), "WBC_QP_LANE": ("qp_lane", int), "WBC_F32_PACK2": ("f32_pack2", int), "WBC_KEEP_STRUCTURAL": ("keep_structural", int), "WBC_ROLLOUT_WARM": ("rollout_warm", int),
-           "WBC_MULTI_THREADS": ("multi_threads", int), "WBC_MULTI_SPIN_US": ("multi_spin_us", int), "WBC_OBS_COLAUNCH": ("obs_colaunch", int), "WBC_TILE_TICK": ("tile_tick", int),
+           "WBC_MULTI_THREADS": ("multi_threads", int), "WBC_MULTI_SPIN_US": ("multi_spin_us", int), "WBC_OBS_COLAUNCH": ("obs_colaunch", int), "WBC_TILE_TICK": ("tile_tick", int), "WBC_FUSED_PAIR": ("fused_pair", int),
            "WBC_TIMING": ("timing_mode", lambda v: 1 if v == "pair" else 0)}
 
     @staticmethod

@@ -159,7 +159,7 @@ struct MjNoHook { WBC_DEV void operator()() const {} };
 template <class T, int BLOCK, int EXT, int SPW = 16, int ZEROS = 1, class AfterHand = MjNoHook>   // ZEROS: 0 = other wavefronts write the structural constants, 1 = first, 2 = LAST (behind the data: fused_tick.hip.hpp)
 WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArgs<T>& a, const T* cst_ext, const int* zidx_ext, T* hand = nullptr,
                            AfterHand after_hand = AfterHand()) {
-  static_assert(!EXT || BLOCK == 64, "one wavefront");
+  static_assert(!EXT || BLOCK == 64 || BLOCK == 128, "one wavefront (128: one of the two role wavefronts of a fused_pair_kernel workgroup, each with its own half of the parking lot)");
   static_assert(SPW == 16 || EXT != 0, "fewer states per workgroup only for roles");
   WBC_LAUNDERED_TID(tx);
   __shared__ __attribute__((aligned(512))) T cst_own[EXT ? 1 : CST_WORDS];   // (aligned: first in LDS, see section 4.9 of docs/DESIGN_R04.md)
@@ -213,7 +213,7 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
   }
   // joint transforms: E of joints 0 and 1 wait in LDS ([word][lane]) until the return sweep reaches them
   __shared__ T park[18][BLOCK];
-  const int ln = EXT ? (int)(tx & 63) : (int)tx;
+  const int ln = EXT ? (int)(tx & (unsigned)(BLOCK - 1)) : (int)tx;
   T* const hl = hand ? hand + (int)(tx & 63) : nullptr;
   M3<T> E2;
 #pragma unroll
@@ -401,7 +401,7 @@ template <class T, int MODE, int BLOCK, int EXT, int SPW = 16, class BeforeRefs 
 WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevParams<T> prm, const SweepArgs<T>& a, const T* cst_ext,
                             T* wsl, BeforeRefs before_refs = BeforeRefs(), AfterGeom after_geom = AfterGeom(), T* hres = nullptr, AfterTaup after_taup = AfterTaup()) {
   // hres (persistent rollout): LDS image [..][16] whose rows 0 .. 17 ALSO receive h (the integrator reads it behind an LDS-only barrier)
-  static_assert(!EXT || BLOCK == 64, "one wavefront");
+  static_assert(!EXT || BLOCK == 64 || BLOCK == 128, "one wavefront (128: one of the two role wavefronts of a fused_pair_kernel workgroup, each with its own half of the parking lot)");
   WBC_LAUNDERED_TID(tx);
   constexpr bool WH = (MODE & RS_H) != 0, STEP = (MODE & RS_STEP) != 0, OBS = (MODE & RS_OBS) != 0, WPF = (MODE & RS_PF) != 0, FWD_B = (MODE & RS_NOB) == 0;
   constexpr bool OBSW = (MODE & RS_OBSW) != 0;
@@ -539,7 +539,7 @@ WBC_DEV void rnea_step_body(const DevModel<T>* __restrict__ model, const DevPara
   constexpr int PW = 15 + (TWO ? 6 : 0) + (OBS ? 18 : 0);
   constexpr int PB = BASEROWS ? (OBS ? 18 : 6) : 1;
   __shared__ T park[2 * PW + PB][BLOCK];
-  const int ln = EXT ? (int)(tx & 63) : (int)tx;
+  const int ln = EXT ? (int)(tx & (unsigned)(BLOCK - 1)) : (int)tx;
   constexpr int OFF_A = 15, OFF_O = 15 + (TWO ? 6 : 0);
 
   V3<T> omp, vp, aAp, aLp, gLp, a2Ap, a2Lp;

@@ -139,6 +139,76 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   }
 }
 
+// fused_pair_kernel (round 6): TWO of the observer-off, cold, M/h/Jc-writing tick workgroups above as ONE workgroup of twelve wavefronts and 32 states, for fp64 batches
+// between one and about three rounds of the 16-state workgroups (4 097 ... states).  Why a pair and not launch bounds: the six-wavefront workgroup holds 214 registers, so
+// a CU takes one of them and 6 144 states cost two full rounds (23.6 us against 13.2 for 4 096).  Compiled to 168 registers (three wavefronts per SIMD) two of them still do
+// NOT share a CU: the dispatcher deals a workgroup's wavefronts to the SIMDs round robin from SIMD 0 -- 2 + 2 + 1 + 1, twice = 4 on SIMD 0 (tools/cores_probe.hip: 512
+// six-wavefront workgroups of 168 registers take 1.5 T, not T; profiles/r06u_cores_probe_168.log; the tick itself: profiles/r06u_ab_occ2.log, 8 192 states 23.9 -> 26.2 us).
+// Twelve wavefronts of ONE workgroup land 3 + 3 + 3 + 3: wavefronts 0 .. 3 / 4 .. 7 the QPs of the first / second 16 states, 8 / 9 their rnea roles, 10 / 11 their mass_jac
+// roles -- every SIMD holds two QP wavefronts and one role.  The bodies are those of fused_tick_kernel, untouched: they address state blockIdx.x * 16 + slot, so the second
+// half works on the batch's upper half -- states gridDim.x * 16 + blockIdx.x * 16 + slot -- through argument pointers advanced by that many states (scalar registers: `half` is
+// wave-uniform); its QP wavefronts are threads 256 .. 511, whose slots 16 .. 31 are folded into the same shift (and into the workspace pointer).  N must be a multiple of 32
+// (the host falls back to fused_tick_kernel otherwise): every lane is live and the component stride N is the same for both halves.
+// The price: the rnea role's spill (55 dwords per lane at 168 registers: + 1.1 us when the halves do not share a CU) and the halves' shared issue slots -- a pair lasts
+// 18.3 us where a lone 16-state workgroup lasts 13.3 -- so the host runs this form only where it saves a round: 4 128 ... 8 192 states (6 144: 23.9 -> 20.0 us, 257 -> 307 M
+// steps/s; 8 192: 24.0 -> 20.4 us, 342 -> 402 M; profiles/r06v_ab_fused_pair.log).  Measured on top and not kept (profiles/r06v_pair_variants.log): issue priorities (rnea role
+// above the QPs: 6 144 states 306 -> 284 M; QPs above: no change), the bias-force recursion moved behind the mass_jac role (h off the rnea role's chain: 306 -> 295 M).
+// The role bodies park joint transforms and forces in static LDS arrays [word][BLOCK] indexed by the thread within BLOCK: the pair instantiates them with BLOCK = 128, so
+// that the role wavefronts of the two halves (threads 512 .. 639 and 640 .. 767: 0 .. 63 and 64 .. 127 within 128) own disjoint columns.
+template <class P> WBC_DEV void shift_ptr(P*& p, unsigned off) { if (p) p += off; }
+template <class T> WBC_DEV void shift_states(SweepArgs<T>& a, unsigned off) {
+  shift_ptr(a.q, off); shift_ptr(a.v, off); shift_ptr(a.M, off); shift_ptr(a.h, off); shift_ptr(a.Jc, off); shift_ptr(a.pf, off); shift_ptr(a.p, off); shift_ptr(a.beta, off);
+  shift_ptr(a.w_des, off); shift_ptr(a.vdot_des, off); shift_ptr(a.tau_prev, off); shift_ptr(a.f_prev, off); shift_ptr(a.obs_integ, off); shift_ptr(a.obs_r, off); shift_ptr(a.ws, off);
+}
+template <class T> WBC_DEV void shift_states(QpArgs<T>& a, unsigned off) {
+  shift_ptr(a.ws, off); shift_ptr(a.normals, off); shift_ptr(a.mu, off); shift_ptr(a.mask, off); shift_ptr(a.Jc, off); shift_ptr(a.wdes, off);
+  shift_ptr(a.tau, off); shift_ptr(a.f, off); shift_ptr(a.status, off); shift_ptr(a.iters, off); shift_ptr(a.aset_in, off); shift_ptr(a.aset_out, off); shift_ptr(a.rprev, off);
+}
+constexpr int FUSED_PAIR_THREADS = 768;
+template <class T>
+__global__ __launch_bounds__(FUSED_PAIR_THREADS) void fused_pair_kernel(const DevModel<T>* __restrict__ model, DevParams<T> prm, SweepArgs<T> a, QpArgs<T> qa, QpJidx jmap) {
+  __shared__ __attribute__((aligned(512))) T cst[CST_WORDS];   // one constant table for both halves (first in LDS: see fused_tick_kernel)
+  __shared__ int zidx_s[64];
+  __shared__ T wsl2[2 * WS_LDS_WORDS * 16];
+  __shared__ int flags[2][4];   // per half: rnea role done / its lever arms, w_des are out / (observer: unused)
+  const int wave = (int)(threadIdx.x >> 6);
+  const int half = __builtin_amdgcn_readfirstlane(wave < 8 ? (wave >> 2) : (wave & 1));
+  const unsigned off = gridDim.x * 16u;   // first state of the upper half
+  T* const wsl = wsl2 + half * (WS_LDS_WORDS * 16);
+  int* const ready = &flags[half][0];
+  int* const gready = &flags[half][1];
+  int* const oready = &flags[half][2];
+  if (wave >= 8) {
+    if (half) shift_states(a, off);
+    if (wave < 10) {
+      auto geom_out = [=] __device__() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(gready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      rnea_step_body<T, RS_STEP | RS_H, 128, 2>(model, prm, a, cst, wsl, NoWait(), geom_out);   // (128: the role's parking lot has a half per role wavefront -- threads 512 .. 639, 640 .. 767)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      mass_jac_body<T, 128, 2, 16, (0)>(model, a, cst, zidx_s);
+    }
+  } else {
+    for (int i = threadIdx.x; i < CST_WORDS; i += 512) cst[i] = model->cst[i];
+    if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
+    if (threadIdx.x < 8) (&flags[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+    if (half) { shift_states(a, off); shift_states(qa, off - 16u); }   // (QP slots 16 .. 31 of threads 256 .. 511: see above)
+#ifdef WBC_FUSED_STAMP
+    QpSync sy{gready, oready, ready, 1, 2, 1, 1, nullptr, 0};
+#else
+    QpSync sy{gready, oready, ready, 1, 2, 1, 1};
+#endif
+    const int* const zs = zidx_s;
+    const unsigned tq = threadIdx.x & 255u;
+    auto idle = [=] __device__() { if (!a.skip_consts) structural_consts_quarter<T>(model, a, zs, tq); };
+    qp_body<T, true, false, 16, false, 8, decltype(idle), false, 0>(prm, qa, jmap, wsl - (half ? 16 : 0), &sy, QpWho{0, false}, idle);
+  }
+}
+
 // Persistent rollout (BASELINE.json configs[4]): `horizon` dependent ticks of {tick roles as above, forward
 // dynamics + integrator} in ONE launch.  A workgroup owns its 4 or 16 states for the whole horizon, so no tick boundary ever
 // leaves the CU: no launch, no HBM round trip of the workspace.

@@ -69,7 +69,7 @@ constexpr long long WBC_COLAUNCH_MIN_F32 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F32 = 32768;
 constexpr long long WBC_COLAUNCH_MIN_F64 = 12289;
 constexpr long long WBC_COLAUNCH_MAX_F64 = 14336;
-struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max, tt_first_min, tt_max_obs, tt_max_noobs32; };
+struct Resolved { size_t fused_max, fused_max_noobs, fused_max_obs, obs_split_min, obs_split_min_nomats, tile_min, lane_min, warm_tile_min, warm_lane_min, colaunch_min, colaunch_max, stile_min, stile_max, tt_min, tt_max, tt_first_min, tt_max_obs, tt_max_noobs32, pair_min, pair_max; };
 
 struct wbc_solver {
   int dtype = WBC_F64;
@@ -310,6 +310,7 @@ extern "C" void wbc_solver_options_default(wbc_solver_options* o) {
   o->multi_spin_us = 200;
   o->obs_colaunch = 0;
   o->tile_tick = 0;
+  o->fused_pair = 0;
 }
 
 // ------------------------------------------------------------------------------------------ which kernels run a tick
@@ -386,6 +387,13 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
     // 131 072: 580 -> 586, 196 608: 571 -> 598, but 262 144: 611 -> 574
     r.tt_max_obs = o.tile_tick > 0 ? (size_t)-1 : (size_t)WBC_TILE_TICK_MAX_F64_OBS;
   }
+  // the one-launch tick as 32-state, twelve-wavefront workgroups (fused_pair_kernel, fused_tick.hip.hpp): fp64, observer off, cold, M / h / Jc outputs, N a multiple of 32.
+  // Both halves of a pair are resident together, so a round of workgroups is 8 192 states instead of 4 096 -- at the price of the rnea role's spill (168 registers).
+  r.pair_min = (size_t)-1; r.pair_max = 0;
+  if (dtype == WBC_F64) {
+    if (o.fused_pair > 0) { r.pair_min = 32; r.pair_max = 65536; }
+    else if (o.fused_pair == 0 && o.fused_max < 0 && o.tile_tick == 0 && tt_auto_ok) { r.pair_min = (size_t)WBC_FUSED_PAIR_MIN; r.pair_max = (size_t)WBC_FUSED_PAIR_MAX; }
+  }
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
@@ -415,6 +423,10 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // fp32, observer on (configs[3]'s shape), even batches: packed sweep + observer wavefronts, staged QP tile
   const bool tt32 = mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && tt_warm_ok;
   const bool tt32n = mats && !ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max_noobs32 && tt_warm_ok;   // ... observer off
+  if (mats && !ob && !f32 && !warm && (N & 31) == 0 && N >= r.pair_min && N <= r.pair_max) {   // fp64, observer off, cold: 32-state workgroups of the one-launch tick
+    p.fused = 3;
+    return p;
+  }
   if (tt32n && !warm && N >= r.tt_first_min) {
     p.fused = 2; p.front = 0; p.pack2 = 1; p.sweep_block = 64; p.qp = 1; p.tile = wbc::tile_tick_states(N); p.qp_body = 2;
     return p;
@@ -571,9 +583,9 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {(size_t)WBC_TT_WARM_MAX_F32, r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.tt_max_noobs32 + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.pair_min, r.pair_max ? r.pair_max + 2 : (size_t)-1, (size_t)WBC_TT_WARM_MAX_F32, r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.tt_max_noobs32 + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
-  size_t keep[20]; int k = 0;
+  size_t keep[24]; int k = 0;
   for (size_t c : cand) {
     if (c < 2 || c == (size_t)-1 || c > ((size_t)1 << 21)) continue;
     // an odd N never packs: compare like with like (both even) for the fp32 sweep, plain neighbours otherwise
@@ -585,7 +597,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
     if (!changes) continue;
     bool dup = false;
     for (int i = 0; i < k; ++i) dup = dup || keep[i] == c;
-    if (!dup && k < 20) keep[k++] = c;
+    if (!dup && k < 24) keep[k++] = c;
   }
   for (int i = 0; i < k; ++i) for (int j = i + 1; j < k; ++j) if (keep[j] < keep[i]) { const size_t t = keep[i]; keep[i] = keep[j]; keep[j] = t; }
   // (an even candidate right behind a kept odd one is the same switch seen from the even side -- the plans of fp32 batches are compared even with even)
@@ -911,6 +923,11 @@ static int step_impl(wbc_solver* s, size_t N, const wbc_batch_in* in, const wbc_
   const bool warm = warm_api && aset_in != nullptr && pl.qp_warm;
   if (pl.fused == 1) {
     TIMED_LAUNCH(3, st, "fused tick", k_fused_tick<T>(L, ob, mats, dev_model<T>(s), dp, a, qa, s->jmap, warm));
+    keep.written();
+    return WBC_OK;
+  }
+  if (pl.fused == 3) {
+    TIMED_LAUNCH(3, st, "fused pair tick", k_fused_pair<T>(L, dev_model<T>(s), dp, a, qa, s->jmap));
     keep.written();
     return WBC_OK;
   }
@@ -1448,4 +1465,4 @@ extern "C" const char* wbc_strerror(int st) {
   }
 }
 extern "C" const char* wbc_last_error(void) { return g_err.c_str(); }
-extern "C" int wbc_abi_version(void) { return 8; }  // 8: wbc_solver_options.tile_tick, wbc_tick_plan.fused = 2 / qp_body = 2 (staged QP tiles); 7: wbc_solver_collect_timing_n (the unsized call writes 5 entries again), wbc_solver_options.multi_threads / multi_spin_us, wbc_multi_tick_gather / wbc_multi_issue_threads / wbc_multi_host_stats; 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_multi_step_batch_warm, wbc_solver_options.rollout_warm, wbc_tick_plan.qp_warm, WBC_PLAN_* flags), wbc_multi_allgather_tau_async / wbc_multi_gather_wait; 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
+extern "C" int wbc_abi_version(void) { return 9; }  // 9: wbc_solver_options.fused_pair, wbc_tick_plan.fused = 3 (fused_pair_kernel); 8: wbc_solver_options.tile_tick, wbc_tick_plan.fused = 2 / qp_body = 2 (staged QP tiles); 7: wbc_solver_collect_timing_n (the unsized call writes 5 entries again), wbc_solver_options.multi_threads / multi_spin_us, wbc_multi_tick_gather / wbc_multi_issue_threads / wbc_multi_host_stats; 6: wbc_plan_tick / wbc_solver_plan_tick / wbc_dispatch_thresholds, wbc_solver_invalidate_structural, warm start (wbc_step_batch_warm, wbc_multi_step_batch_warm, wbc_solver_options.rollout_warm, wbc_tick_plan.qp_warm, WBC_PLAN_* flags), wbc_multi_allgather_tau_async / wbc_multi_gather_wait; 5: wbc_qp_dense_batch; 4: wbc_one_map / wbc_one_tick, wbc_solver_options.f32_pack2 and one_zerocopy 2 / 3 (options struct grows at its end: struct_size keeps version-3 callers valid); 3: wbc_solver_options / wbc_solver_create_ex, wbc_observer_init, wbc_multi_* (2: integrate takes Jc, timing arrays have 4 entries, reference / tracking entry points)
