@@ -347,6 +347,7 @@ def main():
         ts = 8 if dtype == "f64" else 4
         fused = tm.get("fused_launches", 0) > 0   # the whole tick as ONE kernel: fused_tick_kernel (small batches) or tile_tick_kernel (wbc_tick_plan.fused = 2)
         tile_tick = fused and solver.plan_tick(n, want_mats=want_mats)["fused"] == 2
+        pair_tick = fused and solver.plan_tick(n, want_mats=want_mats)["fused"] == 3   # fused_pair_kernel: the one-launch tick as 32-state workgroups (ABI 9)
         dyn_s = (tm["fused_ms"] * 1e-3 / tm["fused_launches"]) if fused else tm["dyn_ms"] * 1e-3 / max(1, tm["dyn_launches"])
         qp_s = tm["qp_ms"] * 1e-3 / max(1, tm["qp_launches"])
         qpl_s = tm.get("qp_lane_ms", 0.0) * 1e-3 / max(1, tm.get("qp_lane_launches", 0))
@@ -380,7 +381,7 @@ def main():
                               % (args.config - 1, n, "4-contact stance" if args.config == 2 else "mixed 2/3/4-foot trot masks", "on" if obs else "off", dtype), want_mats)
         res.update({
             "roofline": {"kernel": (("tile_tick_kernel (sweep + observer roles of a 64 / 96 / 128-state workgroup, then the staged QP tile of the same states: one launch)" if tile_tick
-                                     else "fused_tick_kernel") if fused else tick_sweep_name(dtype, obs, n, split)),
+                                     else ("fused_pair_kernel (two 16-state tick workgroups as one twelve-wavefront workgroup of 32 states)" if pair_tick else "fused_tick_kernel")) if fused else tick_sweep_name(dtype, obs, n, split)),
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": pmc_traffic((("tile_tick" if tile_tick else "fused_tick") if fused else tick_sweep_symbol(dtype, obs, n)), n, dtype),
@@ -1276,7 +1277,7 @@ def baseline_configs_leg(W, synth, torch, np, model, args):
             pl = solver.plan_tick(n)
             res[key] = {"value": K * n / el, "unit": "control-steps/s", "ms_per_step": el / K * 1e3, "steps_per_block": K, "blocks": len(bl), "dtype": dtype,
                         "status_ok_frac": float((out["status"] == 0).double().mean().item()),
-                        "kernels": ("one launch: tile_tick_kernel" if pl["fused"] == 2 else "one launch: fused_tick_kernel" if pl["fused"] == 1 else "front %d -> qp %d" % (pl["front"], pl["qp"])),
+                        "kernels": ("one launch: tile_tick_kernel" if pl["fused"] == 2 else "one launch: fused_tick_kernel" if pl["fused"] == 1 else "one launch: fused_pair_kernel" if pl["fused"] == 3 else "front %d -> qp %d" % (pl["front"], pl["qp"])),
                         "plan": pl}
             del solver, tick, out, inp, integ, rr
             torch.cuda.empty_cache()
