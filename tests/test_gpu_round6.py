@@ -210,10 +210,12 @@ def test_fp64_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, ora
     assert np.sum(a["iters"] != ref["iters"]) <= max(2, 0.02 * n) and a["iters"].max() >= 3      # (a near-tie between two violated rows may be taken in the other order)
 
 
-@pytest.mark.parametrize("n,force,cfg", [(6144, 0, 2), (8192, 0, 2), (4128, 0, 2), (32, 1, 2), (4096, 1, 2), (16384, 1, 2), (5120, 0, 3), (7200, 0, 2)])
+@pytest.mark.parametrize("n,force,cfg", [(6144, 0, 2), (8192, 0, 2), (4097, 1, 2), (64, 1, 2), (4096, 1, 2), (16384, 1, 2), (5120, 0, 3), (7200, 0, 2),
+                                         (5000, 0, 2), (6001, 0, 3), (8191, 0, 2), (65, 1, 2), (79, 1, 3), (95, 1, 2), (4111, 1, 2), (4225, 0, 2), (10007, 1, 2), (127, 1, 2), (98, 1, 3)])
 def test_fused_pair_tick_equals_the_one_launch_tick_bit_for_bit_and_the_oracle(torch_cuda, gpu_model, oracle, n, force, cfg):
     """fused_pair_kernel (wbc_tick_plan.fused = 3): two of the one-launch tick's 16-state workgroups as ONE twelve-wavefront workgroup of 32 states at 168 registers, the
-    second half on the batch's upper half through shifted argument pointers.  Same role and QP bodies, so EVERY output is bit-identical to fused_tick_kernel's
+    second half on the batch's upper half through shifted argument pointers; a batch that is not a multiple of 32 gets one more workgroup anchored at its END (it recomputes
+    up to 31 states and stores the same bits): odd and even ragged sizes down to 65 states.  Same role and QP bodies, so EVERY output is bit-identical to fused_tick_kernel's
     (wbc_solver_options.fused_pair = -1), and the tick passes the fp64 gates against the oracle (trot masks too: cfg 3's batch on an observer-free solver)."""
     from tests.util import elementwise_excess
     torch = torch_cuda
@@ -242,9 +244,10 @@ def test_fused_pair_tick_equals_the_one_launch_tick_bit_for_bit_and_the_oracle(t
 
 
 def test_fused_pair_plan_only_where_it_applies(gpu_model):
-    """N not a multiple of 32, the observer, fp32, warm ticks and ticks without M / h / Jc keep their plans; a caller who sets fused_max or tile_tick keeps the plan that names."""
+    """The observer, fp32, warm ticks, ticks without M / h / Jc and batches below 64 states keep their plans; a caller who sets fused_max or tile_tick keeps the plan that names."""
     import wbc_quadruped_dob_amd as W
-    assert [W.plan_tick(n, "f64", 0)["fused"] for n in (4096, 4127, 4128, 6144, 6145, 8192, 8224)] == [1, 1, 3, 3, 1, 3, 2]
+    assert [W.plan_tick(n, "f64", 0)["fused"] for n in (4096, 4224, 4225, 6144, 6145, 8192, 8193)] == [1, 1, 3, 3, 3, 3, 2]
+    assert W.plan_tick(63, "f64", 0, options={"fused_pair": 1})["fused"] == 1 and W.plan_tick(64, "f64", 0, options={"fused_pair": 1})["fused"] == 3
     assert W.plan_tick(6144, "f64", 1)["fused"] == 1 and W.plan_tick(6144, "f32", 0)["fused"] == 1 and W.plan_tick(6144, "f64", 0, warm=True)["fused"] == 1
     assert W.plan_tick(6144, "f64", 0, want_mats=False)["fused"] != 3
     assert W.plan_tick(6144, "f64", 0, options={"fused_max": 11264})["fused"] == 1 and W.plan_tick(6144, "f64", 0, options={"tile_tick": -1})["fused"] == 1

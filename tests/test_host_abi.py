@@ -248,9 +248,9 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     """The defaults as the planner reports them; a deliberate change of a default changes this list.  Round 5: mid-size observer-on
     ticks with matrix outputs run the observer update and the sweep as the two roles of one launch (front = 4): fp64 12 289 .. 14 336, fp32 .. 32 768."""
     import wbc_quadruped_dob_amd as W
-    assert W.dispatch_thresholds("f64", 0) == [4128, 8193, 28673, 65536, 106496]      # (round 6: 8 193 .. 28 672 states as one round of tile-tick workgroups, in front of the one-launch tick; 4 128 .. 8 192, multiples of 32: the one-launch tick as 32-state workgroups)
+    assert W.dispatch_thresholds("f64", 0) == [4225, 8193, 28673, 65536, 106496]      # (round 6: 8 193 .. 28 672 states as one round of tile-tick workgroups, in front of the one-launch tick; 4 225 .. 8 192: the one-launch tick as 32-state workgroups)
     assert W.dispatch_thresholds("f64", 0, options={"tile_tick": -1}) == [11265, 14336, 65536, 106496]
-    assert [(W.plan_tick(n, "f64", 0)["fused"], W.plan_tick(n, "f64", 0)["qp_tile"]) for n in (8191, 8192, 8193, 12288, 12289, 28672, 28673)] == [(1, 0), (3, 0), (2, 48), (2, 48), (2, 64), (2, 112), (0, 40)]
+    assert [(W.plan_tick(n, "f64", 0)["fused"], W.plan_tick(n, "f64", 0)["qp_tile"]) for n in (4096, 8191, 8192, 8193, 12288, 12289, 28672, 28673)] == [(1, 0), (3, 0), (3, 0), (2, 48), (2, 48), (2, 64), (2, 112), (0, 40)]
     # round 6: fp64 observer-on batches of 8 193 .. 196 608 states run the tile tick too (32 / 48 / 64-state workgroups; 64-state ones in rounds beyond 16 384 states)
     assert W.dispatch_thresholds("f64", 1) == [8193, 196609]
     assert W.dispatch_thresholds("f64", 1, options={"tile_tick": -1}) == [12289, 14336, 14337, 20480, 65536, 106496]

@@ -147,20 +147,20 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
 // Twelve wavefronts of ONE workgroup land 3 + 3 + 3 + 3: wavefronts 0 .. 3 / 4 .. 7 the QPs of the first / second 16 states, 8 / 9 their rnea roles, 10 / 11 their mass_jac
 // roles -- every SIMD holds two QP wavefronts and one role.  The bodies are those of fused_tick_kernel, untouched: they address state blockIdx.x * 16 + slot, so the second
 // half works on the batch's upper half -- states gridDim.x * 16 + blockIdx.x * 16 + slot -- through argument pointers advanced by that many states (scalar registers: `half` is
-// wave-uniform); its QP wavefronts are threads 256 .. 511, whose slots 16 .. 31 are folded into the same shift (and into the workspace pointer).  N must be a multiple of 32
-// (the host falls back to fused_tick_kernel otherwise): every lane is live and the component stride N is the same for both halves.
+// wave-uniform); its QP wavefronts are threads 256 .. 511, whose slots 16 .. 31 are folded into the same shift (and into the workspace pointer).  Every lane is live and the component stride N
+// is the same for both halves; a batch that is not a multiple of 32 gets one more workgroup anchored at its end (below).
 // The price: the rnea role's spill (55 dwords per lane at 168 registers: + 1.1 us when the halves do not share a CU) and the halves' shared issue slots -- a pair lasts
 // 18.3 us where a lone 16-state workgroup lasts 13.3 -- so the host runs this form only where it saves a round: 4 128 ... 8 192 states (6 144: 23.9 -> 20.0 us, 257 -> 307 M
 // steps/s; 8 192: 24.0 -> 20.4 us, 342 -> 402 M; profiles/r06v_ab_fused_pair.log).  Measured on top and not kept (profiles/r06v_pair_variants.log): issue priorities (rnea role
 // above the QPs: 6 144 states 306 -> 284 M; QPs above: no change), the bias-force recursion moved behind the mass_jac role (h off the rnea role's chain: 306 -> 295 M).
 // The role bodies park joint transforms and forces in static LDS arrays [word][BLOCK] indexed by the thread within BLOCK: the pair instantiates them with BLOCK = 128, so
 // that the role wavefronts of the two halves (threads 512 .. 639 and 640 .. 767: 0 .. 63 and 64 .. 127 within 128) own disjoint columns.
-template <class P> WBC_DEV void shift_ptr(P*& p, unsigned off) { if (p) p += off; }
-template <class T> WBC_DEV void shift_states(SweepArgs<T>& a, unsigned off) {
+template <class P> WBC_DEV void shift_ptr(P*& p, int off) { if (p) p += off; }
+template <class T> WBC_DEV void shift_states(SweepArgs<T>& a, int off) {
   shift_ptr(a.q, off); shift_ptr(a.v, off); shift_ptr(a.M, off); shift_ptr(a.h, off); shift_ptr(a.Jc, off); shift_ptr(a.pf, off); shift_ptr(a.p, off); shift_ptr(a.beta, off);
   shift_ptr(a.w_des, off); shift_ptr(a.vdot_des, off); shift_ptr(a.tau_prev, off); shift_ptr(a.f_prev, off); shift_ptr(a.obs_integ, off); shift_ptr(a.obs_r, off); shift_ptr(a.ws, off);
 }
-template <class T> WBC_DEV void shift_states(QpArgs<T>& a, unsigned off) {
+template <class T> WBC_DEV void shift_states(QpArgs<T>& a, int off) {
   shift_ptr(a.ws, off); shift_ptr(a.normals, off); shift_ptr(a.mu, off); shift_ptr(a.mask, off); shift_ptr(a.Jc, off); shift_ptr(a.wdes, off);
   shift_ptr(a.tau, off); shift_ptr(a.f, off); shift_ptr(a.status, off); shift_ptr(a.iters, off); shift_ptr(a.aset_in, off); shift_ptr(a.aset_out, off); shift_ptr(a.rprev, off);
 }
@@ -173,13 +173,19 @@ __global__ __launch_bounds__(FUSED_PAIR_THREADS) void fused_pair_kernel(const De
   __shared__ int flags[2][4];   // per half: rnea role done / its lever arms, w_des are out / (observer: unused)
   const int wave = (int)(threadIdx.x >> 6);
   const int half = __builtin_amdgcn_readfirstlane(wave < 8 ? (wave >> 2) : (wave & 1));
-  const unsigned off = gridDim.x * 16u;   // first state of the upper half
+  // Workgroups 0 .. N / 32 - 1: the lower half of the first 32 (N / 32) states on the first half's wavefronts, the upper half on the second's.  N not a multiple of 32: one
+  // more workgroup, anchored at the END of the batch -- states N - 32 .. N - 17 and N - 16 .. N - 1.  It recomputes up to 31 states a regular workgroup also owns and stores
+  // the same bits (same bodies, same inputs, no observer state to advance): every lane of every workgroup is live.  N >= 64: the bodies test their UNSHIFTED state index
+  // against N -- the role wavefronts blockIdx.x * 16 + slot <= 16 pairs + 15, the QP wavefronts of a second half 16 pairs + 31 at most, both < N from two pairs on.
+  const int pairs = (int)(a.N >> 5);
+  const bool tail = (int)blockIdx.x == pairs;
+  const int off = tail ? (int)a.N - 32 + 16 * half - 16 * pairs : (half ? 16 * pairs : 0);   // what the bodies' blockIdx.x * 16 + slot lacks
   T* const wsl = wsl2 + half * (WS_LDS_WORDS * 16);
   int* const ready = &flags[half][0];
   int* const gready = &flags[half][1];
   int* const oready = &flags[half][2];
   if (wave >= 8) {
-    if (half) shift_states(a, off);
+    shift_states(a, off);
     if (wave < 10) {
       auto geom_out = [=] __device__() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(FUSED_PAIR_THREADS) void fused_pair_kernel(const De
     if (threadIdx.x < 64) zidx_s[threadIdx.x] = model->zidx[threadIdx.x];
     if (threadIdx.x < 8) (&flags[0][0])[threadIdx.x] = 0;
     __syncthreads();
-    if (half) { shift_states(a, off); shift_states(qa, off - 16u); }   // (QP slots 16 .. 31 of threads 256 .. 511: see above)
+    shift_states(a, off);
+    shift_states(qa, half ? off - 16 : off);   // (QP slots 16 .. 31 of threads 256 .. 511: see above; `off` >= 16 for every second half)
 #ifdef WBC_FUSED_STAMP
     QpSync sy{gready, oready, ready, 1, 2, 1, 1, nullptr, 0};
 #else

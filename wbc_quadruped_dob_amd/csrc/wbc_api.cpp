@@ -387,11 +387,11 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
     // 131 072: 580 -> 586, 196 608: 571 -> 598, but 262 144: 611 -> 574
     r.tt_max_obs = o.tile_tick > 0 ? (size_t)-1 : (size_t)WBC_TILE_TICK_MAX_F64_OBS;
   }
-  // the one-launch tick as 32-state, twelve-wavefront workgroups (fused_pair_kernel, fused_tick.hip.hpp): fp64, observer off, cold, M / h / Jc outputs, N a multiple of 32.
+  // the one-launch tick as 32-state, twelve-wavefront workgroups (fused_pair_kernel, fused_tick.hip.hpp): fp64, observer off, cold, M / h / Jc outputs, N >= 64.
   // Both halves of a pair are resident together, so a round of workgroups is 8 192 states instead of 4 096 -- at the price of the rnea role's spill (168 registers).
   r.pair_min = (size_t)-1; r.pair_max = 0;
   if (dtype == WBC_F64) {
-    if (o.fused_pair > 0) { r.pair_min = 32; r.pair_max = 65536; }
+    if (o.fused_pair > 0) { r.pair_min = 64; r.pair_max = 65536; }   // (from 64 states: the QP wavefronts of a tail workgroup test their unshifted slots 16 p + 16 .. 31 against N, fused_tick.hip.hpp)
     else if (o.fused_pair == 0 && o.fused_max < 0 && o.tile_tick == 0 && tt_auto_ok) { r.pair_min = (size_t)WBC_FUSED_PAIR_MIN; r.pair_max = (size_t)WBC_FUSED_PAIR_MAX; }
   }
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
@@ -423,7 +423,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // fp32, observer on (configs[3]'s shape), even batches: packed sweep + observer wavefronts, staged QP tile
   const bool tt32 = mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && tt_warm_ok;
   const bool tt32n = mats && !ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max_noobs32 && tt_warm_ok;   // ... observer off
-  if (mats && !ob && !f32 && !warm && (N & 31) == 0 && N >= r.pair_min && N <= r.pair_max) {   // fp64, observer off, cold: 32-state workgroups of the one-launch tick
+  if (mats && !ob && !f32 && !warm && N >= r.pair_min && N <= r.pair_max) {   // fp64, observer off, cold: 32-state workgroups of the one-launch tick
     p.fused = 3;
     return p;
   }
@@ -583,7 +583,7 @@ extern "C" int wbc_dispatch_thresholds(int dtype, int observer_order, const wbc_
   if (rc) return rc;
   const Resolved r = resolve_options(dtype, o);
   // candidates: every constant the planner compares N with (+ 1 where the comparison is <=); kept when the plan really changes there
-  const size_t cand[] = {r.pair_min, r.pair_max ? r.pair_max + 2 : (size_t)-1, (size_t)WBC_TT_WARM_MAX_F32, r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.tt_max_noobs32 + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
+  const size_t cand[] = {r.pair_min, r.pair_max ? r.pair_max + 1 : (size_t)-1, (size_t)WBC_TT_WARM_MAX_F32, r.tt_min, r.tt_max + 1, r.tt_max_obs + 1, r.tt_max_noobs32 + 1, r.stile_min, r.stile_max + 1, r.fused_max_noobs + 1, r.fused_max_obs + 1, r.tile_min, r.obs_split_min, r.lane_min, r.warm_tile_min, r.warm_lane_min, r.obs_split_min_nomats, (size_t)WBC_PACK2_MIN_STATES, (size_t)WBC_F32_DENSE_TILE_MIN,
                          wbc::BIG_GRID_THREADS / 4, wbc::BIG_GRID_THREADS / 2, (size_t)65537, r.colaunch_min, r.colaunch_max + 1};
   size_t keep[24]; int k = 0;
   for (size_t c : cand) {
