@@ -43,3 +43,7 @@ cp "$O/stats_cfg5trk_kernel_stats.csv" "$P/${T}_kernel_stats_cfg5_tracking_h20_n
 for f in "$O"/bench_*.json; do [ -s "$f" ] && python3 -c "
 import json,sys; r=json.load(open('$f')); print('%-46s ms/step %.5f  value %.4e' % ('$(basename $f)', r['ms_per_step'], r['value']))"; done
 grep -h "wbc::" "$P/${T}_kernel_stats_default_bench.csv" "$P/${T}_kernel_stats_cfg2_n4096.csv" "$P/${T}_kernel_stats_cfg2_n262144.csv" "$P/${T}_kernel_stats_cfg5_h20_n1024.csv" | awk -F'",' '{split($1,a,"("); print a[1], $2}' | cut -c1-140
+for f in bench_cfg2_n6144 bench_cfg2_n8192 bench_under_rocprof_n8192; do [ -s "$O/$f.json" ] && cp "$O/$f.json" "$P/${T}_$f.json"; done
+[ -f "$O/stats_n8192_kernel_stats.csv" ] && cp "$O/stats_n8192_kernel_stats.csv" "$P/${T}_kernel_stats_cfg2_n8192.csv"
+[ -f "$O/smoke.log" ] && cp "$O/smoke.log" "$P/${T}_smoke.log"
+true

@@ -34,6 +34,7 @@ python bench.py --steps 300 --warmup 30 > "$O/bench_cfg2_n4096.json" 2> "$O/benc
 python bench.py --steps 300 --warmup 30 --config 3 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg3_n4096.json" 2>> "$O/bench.err"
 python bench.py --steps 100 --warmup 10 --config 4 --batch 32768 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg4_f32_n32768.json" 2>> "$O/bench.err"
 python bench.py --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 > "$O/bench_cfg2_n262144.json" 2>> "$O/bench.err"
+for n in 6144 8192; do python bench.py --steps 200 --warmup 20 --batch $n --no-cpu --no-latency --large-batch 0 --no-closed-loop > "$O/bench_cfg2_n$n.json" 2>> "$O/bench.err"; done   # the pair tick (fused_pair_kernel)
 python bench.py --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --no-mats > "$O/bench_cfg2_n4096_nomats.json" 2>> "$O/bench.err"
 # tau, f only (no M / h / Jc buffers) at the large batch: what a controller that needs only the torques gets
 for c in 2 3 4; do python bench.py --config $c --steps 50 --warmup 5 --batch 262144 --no-cpu --no-latency --large-batch 0 --no-mats > "$O/bench_cfg${c}_n262144_nomats.json" 2>> "$O/bench.err"; done
@@ -78,6 +79,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5 -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_qp_general -- python3 "$R/tools/qp_general_profile.py" > "$O/qp_general.json" 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg5trk -- python3 "$R/bench.py" --config 5 --tracking --steps 50 --warmup 5 > /dev/null 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n4096 -- python3 "$R/bench.py" --steps 300 --warmup 30 --no-cpu --no-latency --large-batch 0 > "$O/bench_under_rocprof_n4096.json" 2> "$O/rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n8192 -- python3 "$R/bench.py" --steps 200 --warmup 20 --no-cpu --no-latency --large-batch 0 --no-closed-loop --batch 8192 > "$O/bench_under_rocprof_n8192.json" 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 > "$O/bench_under_rocprof_n262144.json" 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_n32768 -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu --no-latency --large-batch 0 --batch 32768 > "$O/bench_under_rocprof_n32768.json" 2>> "$O/rocprof.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats_cfg4_n262144 -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu --no-latency --large-batch 0 --batch 262144 --config 4 > "$O/bench_under_rocprof_cfg4_n262144.json" 2>> "$O/rocprof.err"

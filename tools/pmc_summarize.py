@@ -35,7 +35,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if ("copy<float>" in k and c == "FETCH_SIZE") or ("write<float>" in k and c == "WRITE_SIZE"):
             scale[c + "_f32"] = GIB / (v * 1024.0) if v else None
 res["scale"] = scale
-for prefix, key, sfx in (("n4096", "n4096", "_f64"), ("n262144", "n262144", "_f64"), ("n262144dyn", "n262144", "_f64"),
+for prefix, key, sfx in (("n4096", "n4096", "_f64"), ("n8192", "n8192", "_f64"), ("n262144", "n262144", "_f64"), ("n262144dyn", "n262144", "_f64"),
                          ("n32768f32", "n32768_f32", "_f32"), ("n262144f32", "n262144_f32", "_f32"), ("n262144dynf32", "n262144_f32", "_f32")):
     r = res.get(key, {})
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
