@@ -254,6 +254,29 @@ def test_fused_pair_plan_only_where_it_applies(gpu_model):
     assert W.plan_tick(6144, "f64", 0, options={"fused_pair": -1})["fused"] == 1 and W.plan_tick(16384, "f64", 0, options={"fused_pair": 1})["fused"] == 3
 
 
+@pytest.mark.parametrize("n,obs,spw", [(16, 2, 0), (16, 2, 16), (64, 1, 4)])
+def test_persistent_rollout_outputs_do_not_depend_on_timing(torch_cuda, gpu_model, oracle, n, obs, spw):
+    """Round 6 (tools/soak.py, seed 101 case 1607): the mass_jac role of a rollout workgroup stored pf -- base position + lever arm -- BEHIND its hand-over to the integrator, reading the
+    base position from the LDS state image that the integrator's phase 2 (another wavefront) overwrites with the next state: about once in a thousand rollouts phase 2 won and pf came
+    out as new base position + old lever arm (4e-4 off; q, v, M, Jc untouched).  pf now goes out in front of the hand-over.  The race cannot be forced, so: the same small warm
+    rollout 300 times -- every output of every launch equal to the first launch's bit for bit -- and pf equal to what per-tick launches leave."""
+    from tests.test_gpu_parity import _gpu_rollout
+    torch = torch_cuda
+    H = 5
+    B = synth.make_batch(2, n, gpu_model.total_mass, rank=77)
+    tau_ext = np.zeros((n, 18)); tau_ext[:, 0:3] = 5.0
+    integ0 = oracle.dynamics(B["q"], B["v"], nthreads=8)["p"]
+    solver, P = _solver(gpu_model, obs=obs, max_batch=n, options={"rollout_spw": spw} if spw else {})
+    first = _gpu_rollout(torch, solver, P, H, B, tau_ext, integ0.copy(), np.zeros((n, 18)))
+    for _ in range(300):
+        again = _gpu_rollout(torch, solver, P, H, B, tau_ext, integ0.copy(), np.zeros((n, 18)), want_traj=False)
+        for k in ("out_pf", "out_M", "out_Jc", "q", "v", "out_tau", "out_f"):
+            assert np.array_equal(first[k], again[k]), k
+    per_tick, _ = _solver(gpu_model, obs=obs, max_batch=n, options={"rollout_persistent": 0})
+    ref = _gpu_rollout(torch, per_tick, P, H, B, tau_ext, integ0.copy(), np.zeros((n, 18)), want_traj=False)
+    assert relerr(first["out_pf"], ref["out_pf"]) < 1e-9 and relerr(first["q"], ref["q"]) < 1e-9
+
+
 @pytest.mark.parametrize("n,obs,force", [(12289, 1, 0), (16384, 1, 0), (14000, 2, 0), (16385, 1, 1), (41, 1, 1), (20000, 2, 1)])
 def test_fp64_observer_on_tile_tick_vs_oracle_and_two_launch_tick(torch_cuda, gpu_model, oracle, n, obs, force):
     """fp64, observer on (configs[2]'s shape) behind the one-launch tick: NS sweep + NS observer wavefronts of 16 states, then the staged QP tile of those states.

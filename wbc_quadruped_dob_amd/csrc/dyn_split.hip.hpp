@@ -314,7 +314,17 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
       STL(a.pf, 1, 3, ldq(1) + dw.y);
       STL(a.pf, 2, 3, ldq(2) + dw.z);
     }
-  } else { hl[33 * 64] = dw.x; hl[34 * 64] = dw.y; hl[35 * 64] = dw.z; }
+  } else {
+    hl[33 * 64] = dw.x; hl[34 * 64] = dw.y; hl[35 * 64] = dw.z;
+    // pf goes out HERE, in front of the hand-over: it adds the base position, which a rollout workgroup reads from its LDS state image (SIMG) -- and behind after_hand() the
+    // integrator's phase 2 (another wavefront) overwrites that image with the NEXT state.  Stored with M and Jc behind the hand-over (rounds 5-6) a stalled store queue let
+    // phase 2 win about once in a thousand rollouts: pf = new base position + old lever arm, 4e-4 off (tools/soak.py, seed 101 case 1607; profiles/r06zzz_soak_long.log)
+    if (!a.skip_mats && a.pf) {
+      STL(a.pf, 0, 3, ldq(0) + dw.x);
+      STL(a.pf, 1, 3, ldq(1) + dw.y);
+      STL(a.pf, 2, 3, ldq(2) + dw.z);
+    }
+  }
   {
     const T bm = model->base_m;
     const V3<T> bh = mk<T>(model->base_h[0], model->base_h[1], model->base_h[2]);
@@ -362,11 +372,6 @@ WBC_DEV void mass_jac_body(const DevModel<T>* __restrict__ model, const SweepArg
       STL(a.Jc, 0 * 18 + 4, 54, dz);  STL(a.Jc, 0 * 18 + 5, 54, -dy);
       STL(a.Jc, 1 * 18 + 3, 54, -dz); STL(a.Jc, 1 * 18 + 5, 54, dx);
       STL(a.Jc, 2 * 18 + 3, 54, dy);  STL(a.Jc, 2 * 18 + 4, 54, -dx);
-      if (a.pf) {
-        STL(a.pf, 0, 3, ldq(0) + dx);
-        STL(a.pf, 1, 3, ldq(1) + dy);
-        STL(a.pf, 2, 3, ldq(2) + dz);
-      }
       const T tm = hl[36 * 64], hwx = hl[37 * 64], hwy = hl[38 * 64], hwz = hl[39 * 64];
       T* M = a.M;
       ST4(M, midx18(0, 0), tm, midx18(1, 1), tm, midx18(2, 2), tm, midx18(0, 4), hwz);
