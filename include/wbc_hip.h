@@ -159,9 +159,9 @@ typedef struct wbc_solver_options {
                              fused_max is at auto; 1: every size beyond the fused_tick size) and fp64 observer-on ticks of 8193 ... 196608 states (32 / 48 / 64-state
                              workgroups of sweep + observer wavefronts, 64-state ones in rounds beyond 16384 states).  fp32 observer-off ticks: only with tile_tick = 1
                              (measured: +16 % at 32768 states, a loss at 49152 and below 16384 -- profiles/r06q_tile_tick_f32_noobs.log).  Auto applies only while qp_tile, qp_lane, obs_colaunch and obs_split_min are at auto themselves */
-  int fused_pair;         /* (ABI 9) fp64 observer-off cold ticks with M/h/Jc outputs of N >= 64 states: the one-launch tick as twelve-wavefront workgroups of 32 states
+  int fused_pair;         /* (ABI 9) observer-off cold ticks with M/h/Jc outputs of N >= 64 states: the one-launch tick as twelve-wavefront workgroups of 32 states
                              (wbc_tick_plan.fused = 3: two of the 16-state workgroups in one, at 168 registers, so that BOTH halves are resident on a CU together -- 8192 states are
-                             one round of workgroups instead of two; a batch that is not a multiple of 32 gets one more workgroup anchored at its end).  0 = auto (4225 ... 8192 states, wbc_dispatch_thresholds reports them; only while
+                             one round of workgroups instead of two; a batch that is not a multiple of 32 gets one more workgroup anchored at its end).  0 = auto (fp64 4225 ... 8192 states, fp32 4225 ... 16384, wbc_dispatch_thresholds reports them; only while
                              fused_max, tile_tick and the kernel selectors above are at auto), 1 = every such tick up to 65536 states, -1 = never */
 } wbc_solver_options;
 void wbc_solver_options_default(wbc_solver_options* o);

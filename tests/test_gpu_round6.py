@@ -243,12 +243,32 @@ def test_fused_pair_tick_equals_the_one_launch_tick_bit_for_bit_and_the_oracle(t
             assert relerr(a[k], dyn[k]) < 1e-9, k
 
 
+@pytest.mark.parametrize("n,force", [(6144, 0), (12288, 0), (5001, 0), (16384, 0), (8190, 0), (70, 1), (20001, 1)])
+def test_fp32_fused_pair_tick_equals_the_one_launch_tick_bit_for_bit(torch_cuda, gpu_model, n, force):
+    """fp32, observer off: the pair holds its 168 registers without a spill and is the default plan for 4 225 ... 16 384 states.  Same bodies as fused_tick_kernel<float>: every output
+    bit-identical (ragged batches: the tail workgroup; more than one round of workgroups); the fp32 gates against the fp32 oracle are the generated straddling cases of
+    tests/test_gpu_parity.py (4 224 | 4 226, 16 384 | 16 386)."""
+    torch = torch_cuda
+    B = synth.make_batch(2, n, gpu_model.total_mass, rank=37)
+    B["w_des"][: n // 2, 0:2] += np.random.default_rng(13).uniform(-60, 60, (n // 2, 2))
+    res = {}
+    for tag, opt in (("pair", {"fused_pair": 1} if force else {}), ("one", {"fused_pair": -1, "fused_max": 65536})):
+        solver, P = _solver(gpu_model, dtype="f32", obs=0, max_batch=n, options=opt)
+        pl = solver.plan_tick(n)
+        assert pl["fused"] == (3 if tag == "pair" else 1), (tag, pl)
+        res[tag] = _run_step(torch, solver, B, "f32", want_mats=True)
+    a, b = res["pair"], res["one"]
+    for k in ("M", "h", "Jc", "pf", "tau", "f", "status", "iters"):
+        assert np.array_equal(a[k], b[k]), k
+    assert (a["status"] == 0).mean() > 0.99 and a["iters"].max() >= 3
+
+
 def test_fused_pair_plan_only_where_it_applies(gpu_model):
-    """The observer, fp32, warm ticks, ticks without M / h / Jc and batches below 64 states keep their plans; a caller who sets fused_max or tile_tick keeps the plan that names."""
+    """The observer, warm ticks, ticks without M / h / Jc and batches below 64 states keep their plans; a caller who sets fused_max or tile_tick keeps the plan that names."""
     import wbc_quadruped_dob_amd as W
     assert [W.plan_tick(n, "f64", 0)["fused"] for n in (4096, 4224, 4225, 6144, 6145, 8192, 8193)] == [1, 1, 3, 3, 3, 3, 2]
     assert W.plan_tick(63, "f64", 0, options={"fused_pair": 1})["fused"] == 1 and W.plan_tick(64, "f64", 0, options={"fused_pair": 1})["fused"] == 3
-    assert W.plan_tick(6144, "f64", 1)["fused"] == 1 and W.plan_tick(6144, "f32", 0)["fused"] == 1 and W.plan_tick(6144, "f64", 0, warm=True)["fused"] == 1
+    assert W.plan_tick(6144, "f64", 1)["fused"] == 1 and W.plan_tick(6144, "f32", 1)["fused"] == 1 and W.plan_tick(6144, "f32", 0)["fused"] == 3 and W.plan_tick(16386, "f32", 0)["fused"] == 0 and W.plan_tick(6144, "f64", 0, warm=True)["fused"] == 1
     assert W.plan_tick(6144, "f64", 0, want_mats=False)["fused"] != 3
     assert W.plan_tick(6144, "f64", 0, options={"fused_max": 11264})["fused"] == 1 and W.plan_tick(6144, "f64", 0, options={"tile_tick": -1})["fused"] == 1
     assert W.plan_tick(6144, "f64", 0, options={"fused_pair": -1})["fused"] == 1 and W.plan_tick(16384, "f64", 0, options={"fused_pair": 1})["fused"] == 3

@@ -261,8 +261,9 @@ def test_dispatch_thresholds_cover_the_documented_switches(hip_lib):
     assert W.dispatch_thresholds("f32", 1, options={"tile_tick": -1}) == [12289, 16384, 32769, 33792, 49153, 65537, 131072, 212992]
     assert [(W.plan_tick(n, "f32", 1)["fused"], W.plan_tick(n, "f32", 1)["qp_tile"]) for n in (8192, 8194, 12288, 12290, 16384, 16386, 24576, 24578, 32768, 32770, 32771, 262144)] == [
         (1, 0), (2, 64), (2, 64), (2, 64), (2, 64), (2, 96), (2, 96), (2, 128), (2, 128), (2, 64), (0, 132), (2, 64)]      # (beyond one round of workgroups: 64-state ones, two per CU)
-    assert W.dispatch_thresholds("f32", 0) == [11265, 16384, 32768, 49153, 65537, 131072, 212992]
-    assert [(W.plan_tick(n, "f32", 0)["qp_body"], W.plan_tick(n, "f32", 0)["qp_tile"]) for n in (16382, 16384, 32768, 49152, 49154)] == [(0, 0), (2, 64), (2, 128), (2, 192), (0, 72)]
+    assert W.dispatch_thresholds("f32", 0) == [4225, 16385, 32768, 49153, 65537, 131072, 212992]      # (round 6: 4 225 .. 16 384 states as 32-state workgroups of the one-launch tick)
+    assert W.dispatch_thresholds("f32", 0, options={"fused_pair": -1}) == [11265, 16384, 32768, 49153, 65537, 131072, 212992]
+    assert [(W.plan_tick(n, "f32", 0)["qp_body"], W.plan_tick(n, "f32", 0)["qp_tile"]) for n in (16382, 16386, 32768, 49152, 49154)] == [(0, 0), (2, 68), (2, 128), (2, 192), (0, 72)]
     assert W.plan_tick(32768, "f32", 1, options={"tile_tick": -1}) == dict(fused=0, front=4, qp=1, qp_tile=128, qp_body=2, sweep_pack2=1, sweep_block=64, qp_warm=0)
     assert [W.plan_tick(n, "f64", 1, options={"tile_tick": -1})["front"] for n in (12288, 12289, 14336, 14337, 20480)] == [0, 4, 4, 0, 2]
     assert [W.plan_tick(n, "f32", 1, options={"tile_tick": -1})["front"] for n in (12290, 12291, 32768, 32770, 33792)] == [4, 0, 4, 0, 2]

@@ -19,7 +19,7 @@ bad = []
 ticks = [("f64", 0, 2, 4096, {}, "one-launch tick"), ("f64", 1, 3, 4096, {}, "one-launch tick, observer"), ("f64", 2, 3, 3000, {}, "one-launch tick, observer order 2"),
          ("f64", 0, 2, 6000, {}, "pair tick (ragged)"), ("f64", 0, 2, 8192, {}, "pair tick"), ("f64", 1, 3, 12000, {}, "tile tick fp64 observer"),
          ("f64", 0, 2, 20000, {}, "tile tick fp64"), ("f32", 1, 4, 12290, {}, "tile tick fp32"), ("f32", 1, 4, 40000, {"tile_tick": -1}, "two-launch fp32 (sweep_obs / staged tiles)"),
-         ("f64", 1, 3, 30000, {"tile_tick": -1}, "two-launch fp64 (observer + sweep, tiles)"), ("f64", 0, 2, 120000, {}, "per-lane pair + list"), ("f32", 0, 2, 5000, {}, "one-launch tick fp32")]
+         ("f64", 1, 3, 30000, {"tile_tick": -1}, "two-launch fp64 (observer + sweep, tiles)"), ("f64", 0, 2, 120000, {}, "per-lane pair + list"), ("f32", 0, 2, 4000, {}, "one-launch tick fp32"), ("f32", 0, 2, 9001, {}, "pair tick fp32 (ragged)")]
 for dtype, obs, cfg, n, opt, label in ticks:
     nd = np.float64 if dtype == "f64" else np.float32
     B = synth.make_batch(cfg, n, gm.total_mass, rank=5)

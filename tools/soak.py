@@ -169,11 +169,11 @@ for c in range(cases):
                     worst = max(worst, e)
                     if not e < (1e-9 if DT == "f64" else TOL):
                         bad.append((c, "warm tick " + k_ + wtag, n, obs, cfg, e))
-        if DT == "f64" and obs == 0 and c % 2 and n >= 64:   # round 6: the one-launch tick as 32-state workgroups (fused_pair_kernel; ragged batches: a tail workgroup) -- same bodies: bit for bit
+        if obs == 0 and c % 2 and n >= 64:   # round 6: the one-launch tick as 32-state workgroups (fused_pair_kernel; ragged batches: a tail workgroup) -- same bodies: bit for bit
             pr = {}
             for ptag, popt in (("pair", {"fused_pair": 1}), ("one", {"fused_pair": -1, "fused_max": 65536})):
-                s, P = solver_with(popt, obs=0, max_batch=n)
-                pr[ptag] = _run_step(torch, s, B, "f64", want_mats=True)
+                s, P = solver_with(popt, obs=0, max_batch=n, dtype=DT)
+                pr[ptag] = _run_step(torch, s, B, DT, want_mats=True)
             for k in pr["pair"]:
                 if not np.array_equal(pr["pair"][k], pr["one"][k], equal_nan=True):
                     bad.append((c, "fused pair " + k, n, obs, cfg))

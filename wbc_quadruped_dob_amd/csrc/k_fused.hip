@@ -24,19 +24,14 @@ hipError_t k_fused_tick<Scalar>(const LaunchCtx& L, bool observer, bool mats, co
   return hipGetLastError();
 }
 
-// fused_pair_kernel (fp64 only): N >= 64, observer off, M / h / Jc wanted, cold
+// fused_pair_kernel: N >= 64, observer off, M / h / Jc wanted, cold
 template <>
 hipError_t k_fused_pair<Scalar>(const LaunchCtx& L, const DevModel<Scalar>* model, const DevParams<Scalar>& prm, const SweepArgs<Scalar>& a, const QpArgs<Scalar>& qa,
                                 const QpJidx& jmap) {
-#ifdef WBC_SCALAR_IS_DOUBLE
   using T = Scalar;
   if (a.N < 64) return hipErrorInvalidValue;
   WBC_KLAUNCH(L, (fused_pair_kernel<T>), dim3((unsigned)((a.N + 31) / 32)), dim3((unsigned)FUSED_PAIR_THREADS), model, prm, a, qa, jmap);
   return hipGetLastError();
-#else
-  (void)L; (void)model; (void)prm; (void)a; (void)qa; (void)jmap;
-  return hipErrorInvalidValue;
-#endif
 }
 
 }  // namespace wbc

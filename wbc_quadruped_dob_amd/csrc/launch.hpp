@@ -74,12 +74,12 @@ template <class T> hipError_t k_qp_lane(const LaunchCtx& L, bool rhat, const Dev
 // fused_tick_kernel<T, OBSERVER, MATS>: the whole tick of a small batch as one launch
 template <class T> hipError_t k_fused_tick(const LaunchCtx& L, bool observer, bool mats, const DevModel<T>* model, const DevParams<T>& prm,
                                           const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap, bool warm = false);
-// fused_pair_kernel<T> (fp64 only; fp32: hipErrorInvalidValue): two 16-state tick workgroups as ONE twelve-wavefront workgroup of 32 states at 168 registers -- both halves
+// fused_pair_kernel<T>: two 16-state tick workgroups as ONE twelve-wavefront workgroup of 32 states at 168 registers (fp64: the rnea / mass_jac roles spill; fp32: no spill) -- both halves
 // resident on a CU together -- for observer-off, cold, M/h/Jc-writing ticks of N >= 64 states
 // auto range (wbc_solver_options.fused_pair = 0), measured on MI355X: profiles/r06v_ab_fused_pair.log
 // (just above 4 096 states the 16-state workgroups' second round is a handful of workgroups and the pair's tail workgroup costs ~0.9 us: 4 097: 18.7 against 19.7 us, 4 128: 19.0 / 18.8,
 //  4 352: 20.0 / 18.5, 5 000: 21.3 / 19.6, 6 000: 24.4 / 20.5, 7 500: 24.4 / 20.3, 8 191: 27.4 / 21.1 -- profiles/r06y3_ab_fused_pair_ragged.log)
-constexpr long long WBC_FUSED_PAIR_MIN = 4225, WBC_FUSED_PAIR_MAX = 8192;
+constexpr long long WBC_FUSED_PAIR_MIN = 4225, WBC_FUSED_PAIR_MAX = 8192, WBC_FUSED_PAIR_MAX_F32 = 16384;
 template <class T> hipError_t k_fused_pair(const LaunchCtx& L, const DevModel<T>* model, const DevParams<T>& prm, const SweepArgs<T>& a, const QpArgs<T>& qa, const QpJidx& jmap);
 // rollout_kernel<T, OBSERVER, TRACK, SPW>: `horizon` dependent ticks incl. forward dynamics (and the planner) as one launch
 template <class T> hipError_t k_rollout(const LaunchCtx& L, bool observer, bool track, int spw, const DevModel<T>* model, const DevParams<T>& prm,

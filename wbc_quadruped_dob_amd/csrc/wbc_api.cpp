@@ -387,13 +387,14 @@ static Resolved resolve_options(int dtype, const wbc_solver_options& o) {
     // 131 072: 580 -> 586, 196 608: 571 -> 598, but 262 144: 611 -> 574
     r.tt_max_obs = o.tile_tick > 0 ? (size_t)-1 : (size_t)WBC_TILE_TICK_MAX_F64_OBS;
   }
-  // the one-launch tick as 32-state, twelve-wavefront workgroups (fused_pair_kernel, fused_tick.hip.hpp): fp64, observer off, cold, M / h / Jc outputs, N >= 64.
+  // the one-launch tick as 32-state, twelve-wavefront workgroups (fused_pair_kernel, fused_tick.hip.hpp): observer off, cold, M / h / Jc outputs, N >= 64.
   // Both halves of a pair are resident together, so a round of workgroups is 8 192 states instead of 4 096 -- at the price of the rnea role's spill (168 registers).
   r.pair_min = (size_t)-1; r.pair_max = 0;
-  if (dtype == WBC_F64) {
-    if (o.fused_pair > 0) { r.pair_min = 64; r.pair_max = 65536; }   // (from 64 states: the QP wavefronts of a tail workgroup test their unshifted slots 16 p + 16 .. 31 against N, fused_tick.hip.hpp)
-    else if (o.fused_pair == 0 && o.fused_max < 0 && o.tile_tick == 0 && tt_auto_ok) { r.pair_min = (size_t)WBC_FUSED_PAIR_MIN; r.pair_max = (size_t)WBC_FUSED_PAIR_MAX; }
-  }
+  // fp32 (observer off): the pair holds 168 registers WITHOUT a spill (the six-wavefront workgroup 152), a pair lasts 15.3 us against 12.4 -- ahead of every other plan from one round of
+  // 16-state workgroups up to two rounds of pairs (profiles/r06zzz_ab_pair_f32.log, M steps/s default -> pair: 5 000: 245 -> 283, 6 144: 285 -> 352, 8 192: 364 -> 457, 10 240: 341 -> 364,
+  // 12 288: 369 -> 432, 16 384: 485 -> 527; 24 576: 608 -> 507-549)
+  if (o.fused_pair > 0) { r.pair_min = 64; r.pair_max = 65536; }   // (from 64 states: the QP wavefronts of a tail workgroup test their unshifted slots 16 p + 16 .. 31 against N, fused_tick.hip.hpp)
+  else if (o.fused_pair == 0 && o.fused_max < 0 && o.tile_tick == 0 && tt_auto_ok) { r.pair_min = (size_t)WBC_FUSED_PAIR_MIN; r.pair_max = (size_t)(dtype == WBC_F32 ? WBC_FUSED_PAIR_MAX_F32 : WBC_FUSED_PAIR_MAX); }
   r.warm_tile_min = dtype == WBC_F32 ? r.tile_min : 24576;   // (warm ticks: the one-wavefront kernel with the block set-up up to here; plan_tick)
   r.warm_lane_min = dtype == WBC_F32 ? WBC_WARM_LANE_MIN_F32 : WBC_WARM_LANE_MIN_F64;   // (measured: tools/warm_loop.py with WARM_LOOP_LANE=1; plan_tick)
   // observer update + observer-free sweep as the two roles of ONE launch (sweep_obs_kernel, observer.hip.hpp): while both roles' wavefronts are resident
@@ -423,7 +424,7 @@ static TickPlan plan_tick(int dtype, int observer_order, const wbc_solver_option
   // fp32, observer on (configs[3]'s shape), even batches: packed sweep + observer wavefronts, staged QP tile
   const bool tt32 = mats && ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max && tt_warm_ok;
   const bool tt32n = mats && !ob && f32 && (N & 1) == 0 && o.f32_pack2 >= 0 && N >= r.tt_min && N <= r.tt_max_noobs32 && tt_warm_ok;   // ... observer off
-  if (mats && !ob && !f32 && !warm && N >= r.pair_min && N <= r.pair_max) {   // fp64, observer off, cold: 32-state workgroups of the one-launch tick
+  if (mats && !ob && !warm && N >= r.pair_min && N <= r.pair_max) {   // observer off, cold: 32-state workgroups of the one-launch tick
     p.fused = 3;
     return p;
   }
