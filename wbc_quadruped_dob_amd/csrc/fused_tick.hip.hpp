@@ -139,20 +139,22 @@ __global__ __launch_bounds__((fused_threads<T, OBSERVER, MATS, WARM>()), 1) void
   }
 }
 
-// fused_pair_kernel (round 6): TWO of the observer-off, cold, M/h/Jc-writing tick workgroups above as ONE workgroup of twelve wavefronts and 32 states, for fp64 batches
-// between one and about three rounds of the 16-state workgroups (4 097 ... states).  Why a pair and not launch bounds: the six-wavefront workgroup holds 214 registers, so
-// a CU takes one of them and 6 144 states cost two full rounds (23.6 us against 13.2 for 4 096).  Compiled to 168 registers (three wavefronts per SIMD) two of them still do
-// NOT share a CU: the dispatcher deals a workgroup's wavefronts to the SIMDs round robin from SIMD 0 -- 2 + 2 + 1 + 1, twice = 4 on SIMD 0 (tools/cores_probe.hip: 512
-// six-wavefront workgroups of 168 registers take 1.5 T, not T; profiles/r06u_cores_probe_168.log; the tick itself: profiles/r06u_ab_occ2.log, 8 192 states 23.9 -> 26.2 us).
+// fused_pair_kernel (round 6): TWO of the observer-off, cold, M/h/Jc-writing tick workgroups above as ONE workgroup of twelve wavefronts and 32 states, for batches
+// between one round of the 16-state workgroups and one (fp64) or two (fp32) rounds of pairs.  Why a pair and not launch bounds: the fp64 six-wavefront workgroup holds 214
+// registers, so a CU takes one of them and 6 144 states cost two full rounds (23.9 us against 13.3 for 4 096).  Compiled to 168 registers (three wavefronts per SIMD) two of
+// them still do NOT share a CU: the dispatcher deals a workgroup's wavefronts to the SIMDs round robin from SIMD 0 -- 2 + 2 + 1 + 1, twice = 4 on SIMD 0 (tools/cores_probe.hip:
+// 512 six-wavefront workgroups of 168 registers take 1.5 T, not T; profiles/r06u_cores_probe_168.log; the tick itself, 8 192 states 23.9 -> 26.2 us:
+// profiles/r06u_ab_fused_two_per_cu_by_launch_bounds_not_kept.log).
 // Twelve wavefronts of ONE workgroup land 3 + 3 + 3 + 3: wavefronts 0 .. 3 / 4 .. 7 the QPs of the first / second 16 states, 8 / 9 their rnea roles, 10 / 11 their mass_jac
 // roles -- every SIMD holds two QP wavefronts and one role.  The bodies are those of fused_tick_kernel, untouched: they address state blockIdx.x * 16 + slot, so the second
-// half works on the batch's upper half -- states gridDim.x * 16 + blockIdx.x * 16 + slot -- through argument pointers advanced by that many states (scalar registers: `half` is
-// wave-uniform); its QP wavefronts are threads 256 .. 511, whose slots 16 .. 31 are folded into the same shift (and into the workspace pointer).  Every lane is live and the component stride N
-// is the same for both halves; a batch that is not a multiple of 32 gets one more workgroup anchored at its end (below).
-// The price: the rnea role's spill (55 dwords per lane at 168 registers: + 1.1 us when the halves do not share a CU) and the halves' shared issue slots -- a pair lasts
-// 18.3 us where a lone 16-state workgroup lasts 13.3 -- so the host runs this form only where it saves a round: 4 128 ... 8 192 states (6 144: 23.9 -> 20.0 us, 257 -> 307 M
-// steps/s; 8 192: 24.0 -> 20.4 us, 342 -> 402 M; profiles/r06v_ab_fused_pair.log).  Measured on top and not kept (profiles/r06v_pair_variants.log): issue priorities (rnea role
-// above the QPs: 6 144 states 306 -> 284 M; QPs above: no change), the bias-force recursion moved behind the mass_jac role (h off the rnea role's chain: 306 -> 295 M).
+// half works on the batch's upper half through argument pointers advanced by that many states (scalar registers: `half` is wave-uniform); its QP wavefronts are threads
+// 256 .. 511, whose slots 16 .. 31 are folded into the same shift (and into the workspace pointer).  Every lane is live and the component stride N is the same for both
+// halves; a batch that is not a multiple of 32 gets one more workgroup anchored at its end (below).
+// The price in fp64: the rnea and mass_jac roles spill (52 / 36 dwords per lane at 168 registers; 22 MB of scratch traffic per launch at 8 192 states by PMC) and the halves share
+// issue slots -- a pair lasts 18.3 us where a lone workgroup lasts 13.3 (fp32, which does not spill: 15.3 against 12.4) -- so the host runs this form only where it saves a
+// round: fp64 4 225 ... 8 192 states (6 144: 23.9 -> 20.0 us, 257 -> 307 M steps/s; 8 192: 24.0 -> 20.4 us, 342 -> 402 M), fp32 4 225 ... 16 384 (8 192: 364 -> 457 M);
+// profiles/r06v_ab_fused_pair.log, r06y3_ab_fused_pair_ragged.log, r06zzz_ab_pair_f32.log.  Measured on top and not kept (profiles/r06v_pair_variants.log,
+// r06y5_pair_knock_and_layout_not_kept.log): issue priorities, the bias-force recursion behind the mass_jac role, the roles of a half on one SIMD.
 // The role bodies park joint transforms and forces in static LDS arrays [word][BLOCK] indexed by the thread within BLOCK: the pair instantiates them with BLOCK = 128, so
 // that the role wavefronts of the two halves (threads 512 .. 639 and 640 .. 767: 0 .. 63 and 64 .. 127 within 128) own disjoint columns.
 template <class P> WBC_DEV void shift_ptr(P*& p, int off) { if (p) p += off; }
